@@ -1,0 +1,210 @@
+"""Oracle microphysics + scattering of one radial (TEST INFRASTRUCTURE ONLY).
+
+Restates cosmo_pol/scatter/doppler_scatter.py for Doppler schemes 1/2 off or
+scheme 1 (scheme 3 / Doppler spectrum is out of scope):
+  get_radar_observables   :49-489   (PSD :184-211, diameters :216-230,
+                                     LUT :236-241, rectangle-rule integral
+                                     :246-251, accumulate :259-268,
+                                     Doppler scheme 1 :276-281,313-333,418-437,
+                                     final :400-416, mask :472-477)
+  get_pol_from_sz         :491-544
+  cut_at_sensitivity      :804-862
+  nan_cumsum / nan_cumprod / aliasing : cosmo_pol/utilities/utilities.py:142-199
+Quirks reproduced: Q3 (weights not renormalised), Q4 (float32 sz_integ), Q5
+(exact zeros -> NaN), Q6 (sensitivity ranges from 0), Q7 (ZDR attenuated,
+ZH/ZV not), Q8 (elevation folded in place).
+"""
+import numpy as np
+
+from . import constants as K
+from .beam import SubBeam, nansum_pair
+from .config import hydrometeor_list
+from .psd import create_hydrometeor, vlinspace
+
+
+def nan_cumsum(x):
+    x[np.isnan(x)] = 0
+    return np.cumsum(x)
+
+
+def nan_cumprod(x):
+    x[np.isnan(x)] = 1
+    return np.cumprod(x)
+
+
+def proj_vel(U, V, W, vf, theta, phi):
+    return ((U * np.sin(phi) + V * np.cos(phi)) * np.cos(theta) + (W - vf) * np.sin(theta))
+
+
+def pol_from_sz(sz, config):
+    """(z_h, z_v, zdr, rhohv, kdp, ah, av, delta_hv) from [n,12] integrated
+    scattering entries (doppler_scatter.py:491-544)."""
+    wavelength = K.Derived(config).WAVELENGTH
+    K2 = config['radar']['K_squared']
+    with np.errstate(invalid='ignore', divide='ignore'):
+        xs_h = 2 * np.pi * (sz[:, 0] - sz[:, 1] - sz[:, 2] + sz[:, 3])
+        z_h = wavelength ** 4 / (np.pi ** 5 * K2) * xs_h
+        xs_v = 2 * np.pi * (sz[:, 0] + sz[:, 1] + sz[:, 2] + sz[:, 3])
+        z_v = wavelength ** 4 / (np.pi ** 5 * K2) * xs_v
+        zdr = xs_h / xs_v
+        kdp = 1e-3 * (180.0 / np.pi) * wavelength * (sz[:, 10] - sz[:, 8])
+        ah = 4.343e-3 * (2 * wavelength * sz[:, 11])
+        av = 4.343e-3 * (2 * wavelength * sz[:, 9])
+        a = (sz[:, 4] + sz[:, 7]) ** 2 + (sz[:, 6] - sz[:, 5]) ** 2
+        b = (sz[:, 0] - sz[:, 1] - sz[:, 2] + sz[:, 3])
+        c = (sz[:, 0] + sz[:, 1] + sz[:, 2] + sz[:, 3])
+        rhohv = np.sqrt(a / (b * c))
+        delta_hv = np.arctan2(sz[:, 5] - sz[:, 6], -sz[:, 4] - sz[:, 7])
+    return z_h, z_v, zdr, rhohv, kdp, ah, av, delta_hv
+
+
+def radar_observables(subbeams, luts, config, return_sz=False, doppler=True):
+    """One radial: list of SubBeam -> SubBeam of radar observables."""
+    mp = config['microphysics']
+    scheme = mp['scheme']
+    melting = mp['with_melting']
+    radial_res = config['radar']['radial_resolution']
+    simulate_doppler = doppler and config['radar'].get('type', 'ground') != 'GPM' \
+        and config['doppler']['scheme'] == 1
+    hydrom_types = hydrometeor_list(config)
+
+    n_sub = len(subbeams)
+    idx_0 = int(n_sub / 2)
+    n_gates = max([len(sb.dist_profile) for sb in subbeams])
+
+    hyd = {}
+    for h in hydrom_types:
+        hyd[h] = create_hydrometeor(h, scheme)
+        hyd[h].nbins_D = luts[h].value_table.shape[-2]
+        d_ax = luts[h].axes[2]
+        hyd[h].d_min = d_ax[:, 0] if h in ['mS', 'mG'] else d_ax[0]
+        hyd[h].d_max = d_ax[:, -1] if h in ['mS', 'mG'] else d_ax[-1]
+
+    sz_integ = np.zeros((n_gates, len(hydrom_types), 12), dtype='float32') + np.nan
+    rvel_avg = np.zeros(n_gates,) + np.nan
+    total_weight_rvel = np.zeros(n_gates,)
+
+    with np.errstate(invalid='ignore', divide='ignore', over='ignore'):
+        for sb in subbeams:
+            v_integ = np.zeros(n_gates,)
+            n_integ = np.zeros(n_gates,)
+            for j, h in enumerate(hydrom_types):
+                if melting and not sb.has_melting and h in ['mS', 'mG']:
+                    continue
+                elev_lut = sb.elev_profile          # in place (Q8)
+                elev_lut[elev_lut > 90] = 180 - elev_lut[elev_lut > 90]
+                elev_lut[elev_lut < 0] = - elev_lut[elev_lut < 0]
+                T = sb.values['T']
+                QM = sb.values['Q' + h + '_v']
+                valid = QM > 0
+                if not np.any(valid):
+                    continue
+                if scheme == '1mom':
+                    if h == 'mG':
+                        fwet = sb.values['fwet_' + h]
+                        hyd[h].set_psd(QM[valid], fwet[valid])
+                    elif h == 'mS':
+                        fwet = sb.values['fwet_' + h]
+                        hyd[h].set_psd(T[valid], QM[valid], fwet[valid])
+                    elif h in ['S', 'I']:
+                        hyd[h].set_psd(T[valid], QM[valid])
+                    else:
+                        hyd[h].set_psd(QM[valid])
+                else:
+                    QN = sb.values['QN' + h + '_v']
+                    hyd[h].set_psd(QN[valid], QM[valid])
+
+                if h in ['mS', 'mG']:
+                    list_D = vlinspace(hyd[h].d_min, hyd[h].d_max, hyd[h].nbins_D)
+                    dD = list_D[:, 1] - list_D[:, 0]
+                else:
+                    list_D = luts[h].axes[luts[h].axes_names['d']]
+                    dD = list_D[1] - list_D[0]
+                N = hyd[h].get_N(list_D)
+                if len(N.shape) == 1:
+                    N = np.reshape(N, [len(N), 1])
+
+                if h in ['mS', 'mG']:
+                    sz = luts[h].lookup_line(e=elev_lut[valid], wc=fwet[valid])
+                    sz_psd = np.einsum('ijk,ij->ik', sz, N) * dD[:, None]
+                else:
+                    sz = luts[h].lookup_line(e=elev_lut[valid], t=T[valid])
+                    sz_psd = np.einsum('ijk,ij->ik', sz, N) * dD
+
+                sz_integ[valid, j, :] = nansum_pair(sz_integ[valid, j, :], sz_psd * sb.quad_weight)
+
+                if simulate_doppler:
+                    vh, n = hyd[h].integrate_V()
+                    v_integ[valid] = nansum_pair(v_integ[valid], vh)
+                    n_integ[valid] = nansum_pair(n_integ[valid], n)
+
+            if simulate_doppler:
+                v_hydro = v_integ / n_integ
+                theta = np.deg2rad(sb.elev_profile)
+                phi = np.deg2rad(sb.quad_pt[0])
+                proj = proj_vel(sb.values['U'], sb.values['V'], sb.values['W'], v_hydro, theta, phi)
+                total_weight_rvel = total_weight_rvel + ~np.isnan(proj) * sb.quad_weight
+                rvel_avg = nansum_pair(rvel_avg, proj * sb.quad_weight)
+
+        sz_tot = np.nansum(sz_integ, axis=1)
+        sz_tot[sz_tot == 0] = np.nan
+        ZH, ZV, ZDR, RHOHV, KDP, AH, AV, DELTA_HV = pol_from_sz(sz_tot, config)
+        PHIDP = nan_cumsum(2 * KDP) * radial_res / 1000. + DELTA_HV
+        if mp['with_attenuation']:
+            ZV_ATT = ZV.copy()
+            ZH_ATT = ZH.copy()
+            ZV_ATT *= nan_cumprod(10 ** (-0.1 * AV * (radial_res / 1000.)))
+            ZH_ATT *= nan_cumprod(10 ** (-0.1 * AH * (radial_res / 1000.)))
+            ZDR = ZH_ATT / ZV_ATT
+        if simulate_doppler:
+            rvel_avg /= total_weight_rvel
+
+    obs = {'ZH': ZH, 'ZDR': ZDR, 'ZV': ZV, 'KDP': KDP, 'DELTA_HV': DELTA_HV, 'PHIDP': PHIDP,
+           'RHOHV': RHOHV, 'ATT_H': AH, 'ATT_V': AV}
+    if simulate_doppler:
+        obs['RVEL'] = rvel_avg
+
+    mask = np.zeros(n_gates,)
+    for sb in subbeams:
+        mask = mask + sb.mask[0:n_gates]
+    mask /= float(n_sub)
+    mask[np.logical_and(mask > -1, mask <= 0)] = 0
+
+    c = subbeams[idx_0]
+    out = SubBeam(obs, mask, c.lats_profile, c.lons_profile, c.dist_profile, c.heights_profile)
+    if return_sz:
+        out.sz_integ = sz_integ
+        out.sz_total = sz_tot
+    return out
+
+
+def sensitivity_threshold(config, n_gates):
+    """dBZ threshold per gate, ranges = res*arange(n) (Q6), or None if the
+    sensitivity spec is invalid (doppler_scatter.py:815-835)."""
+    sens = config['radar']['sensitivity']
+    if not isinstance(sens, list):
+        sens = [sens]
+    r = config['radar']['radial_resolution'] * np.arange(n_gates)
+    with np.errstate(divide='ignore'):
+        if len(sens) == 3:
+            return (sens[0] + K.Derived(config).RADAR_CONSTANT_DB + sens[2]
+                    + 20 * np.log10(r / 1000.))
+        if len(sens) == 2:
+            return (sens[0] - 20 * np.log10(sens[1] / 1000.)) + 20 * np.log10(r / 1000.)
+        if len(sens) == 1:
+            return sens[0] + 0 * r
+    return None
+
+
+def cut_at_sensitivity(radials, config):
+    """In place on a list of radials (doppler_scatter.py:804-862)."""
+    for b in radials:
+        thr = sensitivity_threshold(config, len(b.dist_profile))
+        if thr is None:
+            return radials
+        with np.errstate(invalid='ignore', divide='ignore'):
+            m = 10 * np.log10(b.values['ZH']) < thr
+        for k in b.values.keys():
+            if k in K.SIMULATED_VARIABLES:
+                b.values[k][m] = np.nan
+    return radials

@@ -1,0 +1,360 @@
+#!/usr/bin/env python
+"""oracle/gen_golden.py -- TEST INFRASTRUCTURE ONLY.
+
+Generates tests/golden/*.npz by running the REFERENCE itself (imported by path
+from /root/reference through oracle/ref_shim.py) on seeded synthetic inputs.
+Runs only in the build container (the GPU box has no /root/reference); the
+resulting fixtures are data (inputs + expected outputs) and are committed
+together with this script.
+
+Geodesy note: the reference's two third-party geodesy calls (pyproj, pycosmo)
+are bound by the shim to the oracle's own implementation, so everything
+downstream of them is pinned, the geodesy itself is not.
+
+usage: python oracle/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import ref_shim  # noqa: E402
+
+warnings.simplefilter('ignore')
+
+ORDER = ['U', 'V', 'W', 'QR_v', 'QS_v', 'QG_v', 'QI_v', 'RHO', 'T']
+ORDER_2MOM = ORDER + ['QH_v', 'QNH_v', 'QNR_v', 'QNS_v', 'QNG_v', 'QNI_v']
+
+
+def ref_luts(luts):
+    from cosmo_pol.lookup.lut import Lookup_table
+    out = {}
+    for h, s in luts.items():
+        L = Lookup_table()
+        L.axes, L.axes_names = s.axes, s.axes_names
+        L.axes_limits, L.axes_step = s.axes_limits, s.axes_step
+        L.value_table = s.value_table
+        out[h] = L
+    return out
+
+
+def gen_gate_kernel(out):
+    """get_all_radar_pts of the compiled reference C on random + adversarial
+    small cubes (bit-exact fixture)."""
+    interp = ref_shim._loaded['interp_module']
+    rng = np.random.default_rng(11)
+    nz, ny, nx = 12, 9, 10
+    topo = rng.uniform(0, 800, size=(ny, nx)).astype(np.float32)
+    eta = ((nz - np.arange(nz) - 0.5) / nz) ** 1.3
+    zl = (topo[None] + (9000 - topo)[None] * eta[:, None, None]).astype(np.float32)
+    data = rng.normal(size=(nz, ny, nx)).astype(np.float32)
+    llc = np.array([-1.0, 2.0], dtype=np.float32)        # (lon, lat)
+    res = np.array([0.02, 0.025], dtype=np.float32)
+    n = 400
+    rlat = rng.uniform(llc[1] + 0.001, llc[1] + res[1] * (ny - 1) - 0.001, n)
+    rlon = rng.uniform(llc[0] + 0.001, llc[0] + res[0] * (nx - 1) - 0.001, n)
+    h = rng.uniform(-200, 10500, n)
+    # adversarial gates: exactly on grid nodes / levels / top / lowest level
+    rlat[:8] = llc[1] + res[1] * np.arange(8)
+    rlon[:8] = llc[0] + res[0] * np.arange(8)
+    coords = np.stack([rlat, rlon], axis=1).astype(np.float32)
+    h = h.astype(np.float32)
+    for k in range(8):                                    # exactly on a level of cell (k,k)
+        h[k] = zl[k + 2, k, k]
+    h[8] = zl[0, 3, 3]
+    coords[8] = [llc[1] + res[1] * 3, llc[0] + res[0] * 3]
+    h[9] = zl[-1, 4, 4]
+    coords[9] = [llc[1] + res[1] * 4, llc[0] + res[0] * 4]
+    h[10] = np.float32(zl[-1, 5, 5] + 0.5)               # between ground level and level nz-2
+    coords[10] = [llc[1] + res[1] * 5.5, llc[0] + res[0] * 5.5]
+    vals = interp.get_all_radar_pts(n, coords, h, data, zl, llc, res)[1]
+    out['gate_kernel'] = dict(coords=coords, heights=h, data=data, zlevels=zl, llc=llc, res=res,
+                              expected=vals)
+    # binary_search known answers
+    arr = np.array([50., 40., 30., 20., 10., 5.], dtype=np.float32)
+    keys = np.array([60., 50., 45., 40., 25., 10., 7., 5., 4.], dtype=np.float32)
+    out['gate_kernel']['bs_arr'] = arr
+    out['gate_kernel']['bs_keys'] = keys
+    out['gate_kernel']['bs_expected'] = np.array([interp.binary_search(arr, k) for k in keys],
+                                                 dtype=np.int32)
+
+
+def gen_trajectory(out):
+    from cosmo_pol.interpolation.atm_refraction import _ref_4_3
+    from cosmo_pol.utilities import get_earth_radius
+    ref_shim.configure_reference({'radar': {'coords': [46.0, 7.0, 500], 'frequency': 5.6,
+                                            'range': 150000, 'radial_resolution': 300}})
+    from cosmo_pol.constants import global_constants as gc
+    rr = gc.RANGE_RADAR
+    d = dict(range_vec=rr, earth_radius_7=np.float64(get_earth_radius(7.0)),
+             wavelength=np.float64(gc.WAVELENGTH))
+    elevs = np.array([0.0, 0.5, 1.0, 3.0, 10.0, 45.0, 89.0, 95.0, -0.3])
+    d['elevations'] = elevs
+    for i, e in enumerate(elevs):
+        s, h, el = _ref_4_3(rr, e, [46.0, 7.0, 500])
+        d['s_%d' % i], d['h_%d' % i], d['e_%d' % i] = s, h, el
+    out['trajectory'] = d
+
+
+def gen_quadrature(out):
+    """Weights / kept sub-beams, recovered from get_interpolated_radial's
+    output on a trivial cube."""
+    from cosmo_pol_amd import synthetic
+    from cosmo_pol.interpolation import get_interpolated_radial
+    cube = synthetic.small_test_cube(nz=6, res=0.05, half_width_deg=0.3, seed=3)
+    d = {}
+    cases = [(1, 1, 1.0), (3, 3, 1.0), (7, 7, 1.0), (3, 9, 1.0), (3, 9, 0.999), (5, 5, 0.9)]
+    for ci, (nh, nv, thr) in enumerate(cases):
+        ref_shim.configure_reference({
+            'radar': {'coords': [46.5, 7.5, 1000], 'frequency': 5.6, 'range': 5000,
+                      'radial_resolution': 500, '3dB_beamwidth': 1.3},
+            'integration': {'nh_GH': nh, 'nv_GH': nv, 'weight_threshold': thr}})
+        dv = ref_shim.KeyListDict()
+        dv['T'] = ref_shim.ModelVar('T', cube['data']['T'], cube['zlevels'], cube['proj_info'],
+                                    cube['resolution'])
+        subs = get_interpolated_radial(dv, 10.0, 5.0, N=0)
+        d['case_%d' % ci] = np.array([nh, nv, thr])
+        d['pts_%d' % ci] = np.array([s.quad_pt for s in subs])
+        d['w_%d' % ci] = np.array([s.quad_weight for s in subs])
+    out['quadrature'] = d
+
+
+def gen_psd(out):
+    from cosmo_pol.hydrometeors import create_hydrometeor
+    rng = np.random.default_rng(5)
+    d = {}
+    n = 12
+    QM = (10 ** rng.uniform(-6, -2.5, n)).astype(np.float32)
+    T_liq = rng.uniform(265, 300, n).astype(np.float32)
+    T_sol = rng.uniform(210, 274, n).astype(np.float32)
+    fw = rng.uniform(0.01, 0.98, n)
+    d.update(QM=QM, T_liq=T_liq, T_sol=T_sol, fw=fw)
+    ksel = np.arange(0, 1024, 37)
+    d['ksel'] = ksel
+    axes = {}
+    from cosmo_pol_amd import synthetic
+    for h in ['R', 'S', 'G', 'I']:
+        axes[h] = synthetic.make_lut(h, 5.6, '1mom', n_e=2, n_t=2).axes[2]
+    for h in ['R', 'S', 'G', 'I', 'mS', 'mG']:
+        hy = create_hydrometeor(h, '1mom')
+        if h in axes:
+            hy.d_min, hy.d_max = axes[h][0], axes[h][-1]
+        if h in ('R', 'G'):
+            hy.set_psd(QM)
+        elif h in ('S', 'I'):
+            hy.set_psd(T_sol, QM)
+        elif h == 'mS':
+            hy.set_psd(T_sol + 30, QM.astype(np.float64), fw)
+        else:
+            hy.set_psd(QM.astype(np.float64), fw)
+        if h in ('mS', 'mG'):
+            from cosmo_pol.utilities import vlinspace
+            D = vlinspace(hy.d_min, hy.d_max, 1024)
+            N = hy.get_N(D)
+            d[h + '_dmin'], d[h + '_dmax'] = hy.d_min, hy.d_max
+            d[h + '_prop'] = hy.prop_factor
+            d[h + '_N'] = N[:, ksel]
+            d[h + '_Nsum'] = N.sum(axis=1)
+            v, nn = hy.integrate_V()
+            d[h + '_vint'], d[h + '_nint'] = v, nn
+        else:
+            D = axes[h]
+            N = hy.get_N(D)
+            d[h + '_lambda'] = np.asarray(hy.lambda_)
+            d[h + '_N0'] = np.asarray(hy.N0)
+            d[h + '_N'] = N[:, ksel]
+            d[h + '_Nsum'] = N.sum(axis=1)
+            d[h + '_Ndtype'] = str(N.dtype)
+            v, nn = hy.integrate_V()
+            d[h + '_vint'], d[h + '_nint'] = np.asarray(v), np.asarray(nn)
+    # 2-moment
+    QN = {}
+    for h in ['R', 'S', 'G', 'H', 'I']:
+        hy = create_hydrometeor(h, '2mom')
+        xm = np.sqrt(hy.x_min * hy.x_max)
+        qn = (QM / (xm * 10 ** rng.uniform(-1.5, 1.5, n))).astype(np.float32)
+        QN[h] = qn
+        d['2m_QN_' + h] = qn
+        ax = synthetic.make_lut(h, 13.6, '2mom', n_e=2, n_t=2).axes[2]
+        hy.d_min, hy.d_max = ax[0], ax[-1]
+        hy.set_psd(qn, QM)
+        N = hy.get_N(ax)
+        d['2m_%s_lambda' % h] = np.asarray(hy.lambda_)
+        d['2m_%s_N0' % h] = np.asarray(hy.N0)
+        d['2m_%s_N' % h] = N[:, ksel]
+        d['2m_%s_Nsum' % h] = N.sum(axis=1)
+    out['psd'] = d
+
+
+def gen_pol(out):
+    from cosmo_pol.scatter.doppler_scatter import get_pol_from_sz
+    ref_shim.configure_reference({'radar': {'coords': [46.0, 7.0, 500], 'frequency': 5.6,
+                                            'range': 150000, 'radial_resolution': 300}})
+    rng = np.random.default_rng(9)
+    base = np.array([1, -1, 1, 2, 3, -1, 1, 2, .5, .1, .7, .2])
+    sz = (base[None] * 1e-3 * (1 + 0.3 * rng.normal(size=(40, 12)))).astype(np.float32)
+    sz[5] = np.nan
+    names = ['ZH', 'ZV', 'ZDR', 'RHOHV', 'KDP', 'AH', 'AV', 'DELTA_HV']
+    res = get_pol_from_sz(sz, 0.93)
+    d = dict(sz=sz)
+    for n, r in zip(names, res):
+        d[n] = np.asarray(r)
+    out['pol'] = d
+
+
+RADIAL_CASES = {
+    # name: (config overrides, azimuth, elevation, hydrometeors kept in the cube, 2mom)
+    'c1_rain_rhi': ({'radar': {'range': 30000, 'radial_resolution': 300},
+                     'microphysics': {'with_ice_crystals': 0, 'with_melting': 0},
+                     'integration': {'nh_GH': 1, 'nv_GH': 1}}, 45.0, 3.0, ('R',), False),
+    'c2_rsg': ({'radar': {'range': 45000, 'radial_resolution': 300},
+                'microphysics': {'with_ice_crystals': 0, 'with_melting': 0},
+                'integration': {'nh_GH': 1, 'nv_GH': 1}}, 200.0, 4.0, ('R', 'S', 'G'), False),
+    'c3_melt_ice': ({'radar': {'range': 45000, 'radial_resolution': 300},
+                     'microphysics': {'with_ice_crystals': 1, 'with_melting': 1},
+                     'integration': {'nh_GH': 1, 'nv_GH': 1}}, 120.0, 5.0,
+                    ('R', 'S', 'G', 'I'), False),
+    'c4_subbeams': ({'radar': {'range': 36000, 'radial_resolution': 600},
+                     'microphysics': {'with_ice_crystals': 1, 'with_melting': 1},
+                     'integration': {'nh_GH': 3, 'nv_GH': 5, 'weight_threshold': 0.999}},
+                    300.0, 6.0, ('R', 'S', 'G', 'I'), False),
+    'c2_noatt_hi_elev': ({'radar': {'range': 20000, 'radial_resolution': 250},
+                          'microphysics': {'with_ice_crystals': 0, 'with_melting': 0,
+                                           'with_attenuation': 0},
+                          'integration': {'nh_GH': 1, 'nv_GH': 3}}, 10.0, 88.0,
+                         ('R', 'S', 'G'), False),
+    'c5_2mom': ({'radar': {'range': 30000, 'radial_resolution': 300, 'frequency': 13.6},
+                 'microphysics': {'scheme': '2mom', 'with_ice_crystals': 1, 'with_melting': 0},
+                 'integration': {'nh_GH': 1, 'nv_GH': 1}}, 75.0, 8.0, ('R', 'S', 'G', 'I'), True),
+}
+
+CUBE_KW = dict(nz=30, res=0.02, half_width_deg=0.55, seed=7)
+LUT_KW = dict(seed=20260301, n_e=8, n_t=None)
+
+
+def radial_case_inputs(name):
+    """Deterministic inputs of an end-to-end radial case (shared with
+    tests/)."""
+    from cosmo_pol_amd import synthetic
+    over, az, el, hyds, two = RADIAL_CASES[name]
+    base = {'radar': {'coords': [46.5, 7.5, 1000], 'frequency': 5.6, '3dB_beamwidth': 1.,
+                      'K_squared': 0.93, 'type': 'ground', 'sensitivity': [-5, 10000]},
+            'doppler': {'scheme': 1}}
+    for sec, dd in over.items():
+        base.setdefault(sec, {}).update(dd)
+    cube = synthetic.small_test_cube(hydrometeors=hyds, two_moment=two, **CUBE_KW)
+    return base, az, el, cube, two
+
+
+def gen_radials(out):
+    from cosmo_pol_amd import synthetic
+    from cosmo_pol.interpolation import get_interpolated_radial, integrate_radials
+    from cosmo_pol.scatter import get_radar_observables
+    from cosmo_pol_oracle.config import hydrometeor_list, make_config
+    lut_cache = {}
+    for name in RADIAL_CASES:
+        over, az, el, cube, two = radial_case_inputs(name)
+        conf = ref_shim.configure_reference(over)
+        scheme = conf['microphysics']['scheme']
+        freq = conf['radar']['frequency']
+        hl = hydrometeor_list(make_config(over))
+        key = (scheme, freq)
+        lut_cache.setdefault(key, {})
+        for h in hl:
+            if h not in lut_cache[key]:
+                lut_cache[key][h] = synthetic.make_lut(h, freq, scheme, **LUT_KW)
+        luts = ref_luts({h: lut_cache[key][h] for h in hl})
+        dv = ref_shim.KeyListDict()
+        for n in (ORDER_2MOM if two else ORDER):
+            dv[n] = ref_shim.ModelVar(n, cube['data'][n].copy(), cube['zlevels'],
+                                      cube['proj_info'], cube['resolution'])
+        subs = get_interpolated_radial(dv, az, el, N=0)
+        d = dict(azimuth=az, elevation=el, n_sub=len(subs))
+        c = subs[int(len(subs) / 2)]
+        # interpolated model variables of the central + first sub-beam
+        for tag, sb in (('c', c), ('f', subs[0])):
+            for n in sb.values:
+                d['sub%s_%s' % (tag, n)] = np.asarray(sb.values[n]).copy()
+            d['sub%s_mask' % tag] = sb.mask.copy()
+            d['sub%s_lats' % tag] = np.asarray(sb.lats_profile)
+            d['sub%s_lons' % tag] = np.asarray(sb.lons_profile)
+            d['sub%s_s' % tag] = sb.dist_profile.copy()
+            d['sub%s_h' % tag] = sb.heights_profile.copy()
+            d['sub%s_e' % tag] = sb.elev_profile.copy()
+        integ = integrate_radials(subs)
+        for n in integ.values:
+            d['model_' + n] = np.asarray(integ.values[n])
+        d['model_mask'] = integ.mask
+        n_valid = {}
+        for h in hl:
+            n_valid[h] = int(sum(np.sum(np.asarray(s.values['Q' + h + '_v']) > 0) for s in subs
+                                 if not (h in ('mS', 'mG') and not s.has_melting)))
+        obs = get_radar_observables(subs, luts)
+        for n in obs.values:
+            d['obs_' + n] = np.asarray(obs.values[n])
+        d['obs_mask'] = obs.mask
+        d['n_valid'] = np.array([n_valid[h] for h in hl])
+        print(name, 'n_sub', len(subs), 'valid items', n_valid,
+              'finite ZH', int(np.isfinite(obs.values['ZH']).sum()), '/', len(obs.values['ZH']))
+        out['radial_' + name] = d
+
+
+def gen_lut_lookup(out):
+    from cosmo_pol_amd import synthetic
+    rng = np.random.default_rng(21)
+    d = {}
+    lr = ref_luts({'R': synthetic.make_lut('R', 5.6, '1mom', n_e=5),
+                   'mS': synthetic.make_lut('mS', 5.6, '1mom', n_e=5)})
+    e = rng.uniform(-1, 12, 200).astype(np.float32)
+    e[:5] = [0, 2, 4, 1.9999999, 8]
+    t = rng.uniform(255, 320, 200).astype(np.float32)
+    t[:6] = [262, 264, 263.99997, 314, 316, 261.9]
+    wc = rng.uniform(0, 1, 200)
+    wc[:3] = [1e-3, 0.999, 0.5]
+    # recover the bins the reference uses by looking up an index-coded table
+    L = lr['R']
+    code = np.zeros(L.value_table.shape[:2] + (1, 1))
+    code[:, :, 0, 0] = np.arange(L.value_table.shape[0])[:, None] * 1000 + np.arange(L.value_table.shape[1])[None]
+    vt = L.value_table
+    L.value_table = code
+    d['R_code'] = L.lookup_line(e=e, t=t)[:, 0, 0]
+    L.value_table = vt
+    L = lr['mS']
+    code = np.zeros(L.value_table.shape[:2] + (1, 1))
+    code[:, :, 0, 0] = np.arange(L.value_table.shape[0])[:, None] * 1000 + np.arange(L.value_table.shape[1])[None]
+    vt = L.value_table
+    L.value_table = code
+    d['mS_code'] = L.lookup_line(e=e, wc=wc)[:, 0, 0]
+    L.value_table = vt
+    d.update(e=e, t=t, wc=wc)
+    out['lut_lookup'] = d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE), 'tests', 'golden'))
+    ap.add_argument('--only', default=None)
+    args = ap.parse_args()
+    ref_shim.load_reference()
+    os.makedirs(args.out, exist_ok=True)
+    out = {}
+    gens = dict(gate_kernel=gen_gate_kernel, trajectory=gen_trajectory, quadrature=gen_quadrature,
+                psd=gen_psd, pol=gen_pol, lut_lookup=gen_lut_lookup, radials=gen_radials)
+    for k, g in gens.items():
+        if args.only and k != args.only:
+            continue
+        g(out)
+    for name, d in out.items():
+        path = os.path.join(args.out, name + '.npz')
+        np.savez_compressed(path, **d)
+        print('wrote', path, os.path.getsize(path), 'bytes')
+
+
+if __name__ == '__main__':
+    main()

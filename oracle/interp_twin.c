@@ -1,0 +1,101 @@
+/* oracle/interp_twin.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Our own C restatement of the reference's native gate kernel
+ *   cosmo_pol/interpolation/interpolation_c.c:12-104  (get_all_radar_pts)
+ *   cosmo_pol/interpolation/interpolation_c.c:108-135 (binary_search)
+ *   cosmo_pol/interpolation/interpolation_c.c:138-164 (trilinear_interp)
+ * exported with the reference's exact C signature (interpolation_c.c:8) so the
+ * same ctypes binding drives either this twin or oracle/_ref/libinterp_ref.so.
+ *
+ * Written gate-by-gate: in the reference every gate ends up depending only on
+ * itself (the "fill forward" loops at :93 and :101 are overwritten by later
+ * iterations), which is what the HIP kernel exploits.  Pinned bit-for-bit
+ * against the compiled reference by tests/test_oracle_interp.py.
+ *
+ * Float semantics: x86-64 SSE float32, compiled with -ffp-contract=off.
+ * Sentinels: -9999 above the model top, NaN below topography.
+ * Deviation (only where the reference is undefined): neighbour indices are not
+ * range-checked by the reference; callers guarantee the domain check of
+ * interpolation.py:572-580, this twin additionally asserts nothing and reads
+ * exactly the same addresses.
+ */
+#include <math.h>
+
+/* largest i in [0, n-2] with col[i*stride] >= key, for a strictly descending
+ * column; -1 if key is above col[0]; -2 if key is below col[n-1].
+ * (interpolation_c.c:108-135; an exact hit returns that index, key equal to
+ * the last level returns n-2.) */
+static int level_search(const float *col, long stride, int n, float key)
+{
+    if (key > col[0]) return -1;
+    if (key < col[(long)(n - 1) * stride]) return -2;
+    int hi = 0, lo = n - 1;               /* names follow index, not height */
+    while (lo - hi > 1) {
+        int mid = (hi + lo) / 2;
+        float v = col[(long)mid * stride];
+        if (v == key) return mid;
+        if (v < key) lo = mid; else hi = mid;
+    }
+    return hi;
+}
+
+int binary_search(float *arr, int dim, float key)
+{
+    return level_search(arr, 1, dim, key);
+}
+
+static float gate_value(const float *coords2, float h,
+                        const float *data, const float *zl,
+                        int nz, int nzl, int ny, int nx,
+                        const float *llc, const float *res)
+{
+    const long plane = (long)ny * nx;
+    /* fractional grid position: row (lat) uses llc[1]/res[1], col (lon) uses
+     * llc[0]/res[0]  (interpolation_c.c:43-44) */
+    float p0 = (coords2[0] - llc[1]) / res[1];
+    float p1 = (coords2[1] - llc[0]) / res[0];
+    int i0 = (int)floor(p0);
+    int i1 = (int)floor(p1);
+    float x = (float)fmod(p0, 1.0);
+    float y = (float)fmod(p1, 1.0);
+    float dx = (float)(1.0 - x);
+    float dy = (float)(1.0 - y);
+    const int ni[4] = { i0, i0, i0 + 1, i0 + 1 };
+    const int nj[4] = { i1, i1 + 1, i1, i1 + 1 };
+
+    /* topography = bilinear blend of the LAST z-level (interpolation_c.c:58-61) */
+    float t[4];
+    for (int k = 0; k < 4; k++)
+        t[k] = zl[(long)(nzl - 1) * plane + (long)ni[k] * nx + nj[k]];
+    float topo = dx * dy * t[0] + x * t[2] * dy + dx * t[1] * y + x * y * t[3];
+    if (!(topo < h)) return (float)(0.0 / 0.0);          /* below ground */
+
+    float v[4];
+    for (int k = 0; k < 4; k++) {
+        const long cell = (long)ni[k] * nx + nj[k];
+        int idx = level_search(zl + cell, plane, nzl, h);
+        int c1;
+        if (idx == -1) return -9999.0f;                  /* above model top */
+        if (idx == -2) c1 = nzl - 3;                     /* extrapolate (:74-77) */
+        else { if (idx == nzl - 2) idx--; c1 = idx; }    /* (:79-81) */
+        int c2 = c1 + 1;
+        float z1 = zl[(long)c1 * plane + cell], z2 = zl[(long)c2 * plane + cell];
+        float v1 = data[(long)c1 * plane + cell], v2 = data[(long)c2 * plane + cell];
+        v[k] = v2 - (v2 - v1) / (z1 - z2) * (h - z2);    /* (:151) */
+    }
+    return dx * dy * v[0] + x * v[2] * dy + dx * v[1] * y + x * y * v[3];   /* (:162) */
+}
+
+float *get_all_radar_pts(float *output, int len, float *coords_rad_pts, int crp_x, int crp_y,
+                         float *radar_heights, int rh_x,
+                         float *model_data, int md_x, int md_y, int md_z,
+                         float *model_heights, int mh_x, int mh_y, int mh_z,
+                         float *llc_cosmo, int llc_cosmo_x, float *res_cosmo, int res_cosmo_x)
+{
+    (void)len; (void)rh_x; (void)llc_cosmo_x; (void)res_cosmo_x; (void)md_y; (void)md_z;
+    for (int i = 0; i < crp_x; i++)
+        output[i] = gate_value(coords_rad_pts + (long)i * crp_y, radar_heights[i],
+                               model_data, model_heights, md_x, mh_x, mh_y, mh_z,
+                               llc_cosmo, res_cosmo);
+    return output;
+}

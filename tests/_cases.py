@@ -1,0 +1,55 @@
+"""Shared deterministic inputs of the end-to-end radial cases (the same
+functions oracle/gen_golden.py used to produce tests/golden/radial_*.npz)."""
+import functools
+
+import numpy as np
+
+import gen_golden  # oracle/gen_golden.py (imports nothing of the reference at import time)
+from cosmo_pol_amd import synthetic
+from cosmo_pol_oracle import beam
+from cosmo_pol_oracle import config as ocfg
+from cosmo_pol_oracle import lut as olut
+
+RADIAL_CASES = gen_golden.RADIAL_CASES
+ORDER = gen_golden.ORDER
+ORDER_2MOM = gen_golden.ORDER_2MOM
+
+
+@functools.lru_cache(maxsize=None)
+def synthetic_lut(h, freq, scheme):
+    return synthetic.make_lut(h, freq, scheme, **gen_golden.LUT_KW)
+
+
+def as_oracle_lut(s):
+    L = olut.LookupTable()
+    L.axes, L.axes_names = s.axes, s.axes_names
+    L.axes_limits, L.axes_step = s.axes_limits, s.axes_step
+    L.value_table = s.value_table
+    return L
+
+
+def radial_case(name):
+    """-> (oracle config, azimuth, elevation, oracle ModelCube, {h: product LUT})"""
+    over, az, el, cube, two = gen_golden.radial_case_inputs(name)
+    conf = ocfg.make_config(over)
+    order = ORDER_2MOM if two else ORDER
+    oc = beam.ModelCube({n: cube['data'][n].copy() for n in order}, cube['zlevels'],
+                        cube['proj_info'], cube['resolution'], order)
+    hl = ocfg.hydrometeor_list(conf)
+    luts = {h: synthetic_lut(h, conf['radar']['frequency'], conf['microphysics']['scheme'])
+            for h in hl}
+    return conf, az, el, oc, luts, cube
+
+
+def assert_close_nan(a, b, rtol, atol=0.0, name=''):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), '%s: NaN pattern differs at %s' % (name, np.where(na != nb)[0][:10])
+    ok = ~na
+    err = np.abs(a[ok] - b[ok])
+    tol = atol + rtol * np.abs(b[ok])
+    bad = err > tol
+    assert not bad.any(), '%s: %d/%d exceed tol, worst rel %.3e' % (
+        name, bad.sum(), ok.sum(), np.max(err / np.maximum(np.abs(b[ok]), 1e-300)))
