@@ -1,0 +1,255 @@
+"""ctypes binding of libcosmo_pol_hip.so (C ABI: include/cosmo_pol_amd.h).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load the
+import raises, and every entry point raises on a non-zero status.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libcosmo_pol_hip.so')
+
+CPOL_MAX_VARS = 24
+CPOL_MAX_HYDRO = 8
+CPOL_MAX_PAR = 6
+N_SZ = 12
+
+PSD_GAMMA, PSD_ICE_FIELD, PSD_MELTING = 0, 1, 2
+(RULE_RAIN_1MOM, RULE_SNOW_1MOM, RULE_GRAUPEL_1MOM, RULE_TWO_MOMENT, RULE_ICE_1MOM,
+ RULE_MELTING_SNOW, RULE_MELTING_GRAUPEL) = range(7)
+Q_MODEL, Q_MELT_SNOW, Q_MELT_GRAUPEL = 0, 1, 2
+
+ERR_HIP, ERR_ARG, ERR_DOMAIN, ERR_NOMEM = -1, -2, -3, -4
+
+
+class HydroDesc(C.Structure):
+    _fields_ = [
+        ('psd_family', C.c_int32), ('rule', C.c_int32), ('q_source', C.c_int32),
+        ('var_q', C.c_int32), ('var_qn', C.c_int32), ('var_t', C.c_int32),
+        ('n_e', C.c_int32), ('n_t', C.c_int32), ('n_d', C.c_int32),
+        ('second_axis_f64', C.c_int32),
+        ('e_lo', C.c_float), ('e_step', C.c_float), ('t_lo', C.c_float), ('t_step', C.c_float),
+        ('dD', C.c_double),
+        ('a', C.c_double), ('b', C.c_double), ('alpha', C.c_double), ('beta', C.c_double),
+        ('mu', C.c_double), ('nu', C.c_double),
+        ('lambda_factor', C.c_double), ('ntot_factor', C.c_double), ('vel_factor', C.c_double),
+        ('n0_fixed', C.c_double), ('x_min', C.c_double), ('x_max', C.c_double),
+        ('c_n0', C.c_double), ('c_lam', C.c_double),
+        ('lam_exponent', C.c_double), ('n0_exponent', C.c_double),
+        ('r_a', C.c_double), ('r_b', C.c_double), ('r_alpha', C.c_double), ('r_beta', C.c_double),
+        ('r_n0', C.c_double), ('r_mu', C.c_double), ('r_lambda_factor', C.c_double),
+        ('r_lam_exponent', C.c_double),
+        ('r_dmin', C.c_double), ('r_dmax', C.c_double), ('s_dmin', C.c_double),
+        ('s_dmax', C.c_double),
+        ('solid_rule', C.c_int32), ('pad_', C.c_int32),
+    ]
+
+
+class SweepParams(C.Structure):
+    _fields_ = [
+        ('n_rays', C.c_int32), ('n_gates', C.c_int32), ('n_sub', C.c_int32),
+        ('n_hnodes', C.c_int32), ('n_vnodes', C.c_int32),
+        ('with_melting', C.c_int32), ('with_attenuation', C.c_int32),
+        ('integrate_model', C.c_int32), ('apply_sensitivity', C.c_int32),
+        ('outputs_on_device', C.c_int32), ('simulate_doppler', C.c_int32), ('pad_', C.c_int32),
+        ('radar_lat', C.c_double), ('radar_lon', C.c_double), ('radar_alt', C.c_double),
+        ('range0', C.c_double), ('range_step', C.c_double),
+        ('ke', C.c_double), ('re', C.c_double),
+        ('sin_u1', C.c_double), ('cos_u1', C.c_double),
+        ('wavelength', C.c_double), ('k_squared', C.c_double), ('radial_res', C.c_double),
+        ('c_zh', C.c_double),
+    ]
+
+
+class RayTables(C.Structure):
+    _fields_ = [('traj', C.c_void_p), ('geo', C.c_void_p), ('sub_h', C.c_void_p),
+                ('sub_v', C.c_void_p), ('sub_w', C.c_void_p), ('sens_thr', C.c_void_p)]
+
+
+OUTPUT_FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V',
+                 'RVEL', 'mask', 'lats', 'lons', 'dist', 'heights', 'model_vars', 'sz_total']
+
+
+class Outputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in OUTPUT_FIELDS]
+
+
+class Counters(C.Structure):
+    _fields_ = [('n_subbeam_gates', C.c_int64), ('n_valid_items', C.c_int64),
+                ('n_gates', C.c_int64), ('n_work_units', C.c_int64),
+                ('ms_traj', C.c_float), ('ms_interp', C.c_float), ('ms_classify', C.c_float),
+                ('ms_bucket', C.c_float), ('ms_psd', C.c_float), ('ms_final', C.c_float),
+                ('ms_total', C.c_float)]
+
+
+EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_set_stream',
+           'cpol_synchronize', 'cpol_stage_model', 'cpol_stage_hydro', 'cpol_set_num_hydro',
+           'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
+           'cpol_enable_timing', 'cpol_debug_read']
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Loads the HIP shared library (never falls back to anything else)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            'cosmo_pol_amd: HIP extension %s is missing. Build it with '
+            '`python -c "import __graft_entry__ as g; g.build()"` or `make -C cosmo_pol_amd/csrc`. '
+            'There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.cpol_create.restype = C.c_int
+    lib.cpol_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.cpol_destroy.restype = None
+    lib.cpol_destroy.argtypes = [vp]
+    lib.cpol_last_error.restype = C.c_char_p
+    lib.cpol_last_error.argtypes = [vp]
+    lib.cpol_set_stream.restype = C.c_int
+    lib.cpol_set_stream.argtypes = [vp, vp]
+    lib.cpol_synchronize.restype = C.c_int
+    lib.cpol_synchronize.argtypes = [vp]
+    lib.cpol_stage_model.restype = C.c_int
+    lib.cpol_stage_model.argtypes = [vp, C.c_int, C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int,
+                                     vp, vp, vp, vp]
+    lib.cpol_stage_hydro.restype = C.c_int
+    lib.cpol_stage_hydro.argtypes = [vp, C.c_int, C.POINTER(HydroDesc), vp, vp, vp, vp, C.c_int]
+    lib.cpol_set_num_hydro.restype = C.c_int
+    lib.cpol_set_num_hydro.argtypes = [vp, C.c_int]
+    lib.cpol_interp_points.restype = C.c_int
+    lib.cpol_interp_points.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.cpol_ray_tables.restype = C.c_int
+    lib.cpol_ray_tables.argtypes = [C.POINTER(SweepParams), vp, vp, vp, vp, vp, vp]
+    lib.cpol_run_sweep.restype = C.c_int
+    lib.cpol_run_sweep.argtypes = [vp, C.POINTER(SweepParams), C.POINTER(RayTables),
+                                   C.POINTER(Outputs)]
+    lib.cpol_counters.restype = C.c_int
+    lib.cpol_counters.argtypes = [vp, C.POINTER(Counters)]
+    lib.cpol_enable_timing.restype = C.c_int
+    lib.cpol_enable_timing.argtypes = [vp, C.c_int]
+    lib.cpol_debug_read.restype = C.c_int64
+    lib.cpol_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_int64]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Context(object):
+    """One device context (one per GPU per process)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.cpol_create(int(device), C.byref(h))
+        if rc != 0 or not h:
+            raise NativeError('cpol_create(device=%d) failed with status %d (no usable HIP '
+                              'device?)' % (device, rc))
+        self.h = h
+        self.device = device
+        self.n_vars = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.cpol_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc == 0:
+            return
+        msg = self.lib.cpol_last_error(self.h)
+        msg = msg.decode() if msg else ''
+        if rc == ERR_DOMAIN:
+            raise IndexError('ERROR: ' + msg + ': ABORTING')
+        if rc == ERR_ARG:
+            raise ValueError('%s: %s' % (what, msg))
+        if rc == ERR_NOMEM:
+            raise MemoryError('%s: %s' % (what, msg))
+        raise NativeError('%s failed (%d): %s' % (what, rc, msg))
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.cpol_set_stream(self.h, C.c_void_p(stream_ptr)), 'cpol_set_stream')
+
+    def synchronize(self):
+        self._check(self.lib.cpol_synchronize(self.h), 'cpol_synchronize')
+
+    def enable_timing(self, on=True):
+        self._check(self.lib.cpol_enable_timing(self.h, int(bool(on))), 'cpol_enable_timing')
+
+    def enable_debug(self, on=True):
+        self.lib.cpol_debug_read(self.h, b'enable' if on else b'disable', None, 0)
+
+    def stage_model(self, arrays, zlevels, llc, urc, res, south_pole):
+        arrays = [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]
+        zlevels = np.ascontiguousarray(zlevels, dtype=np.float32)
+        nz, ny, nx = zlevels.shape
+        for a in arrays:
+            if a.shape != (nz, ny, nx):
+                raise ValueError('model variable shape %s != z-levels shape %s'
+                                 % (a.shape, zlevels.shape))
+        ptrs = (C.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+        llc = np.ascontiguousarray(llc, dtype=np.float32)
+        urc = np.ascontiguousarray(urc, dtype=np.float32)
+        res = np.ascontiguousarray(res, dtype=np.float32)
+        sp = np.ascontiguousarray(south_pole, dtype=np.float64)
+        rc = self.lib.cpol_stage_model(self.h, len(arrays), ptrs, _ptr(zlevels), nz, ny, nx,
+                                       _ptr(llc), _ptr(urc), _ptr(res), _ptr(sp))
+        self._check(rc, 'cpol_stage_model')
+        self.n_vars = len(arrays)
+
+    def stage_hydro(self, slot, desc, table, pre=None, dnu=None, aux=None):
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        f64 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+        pre, dnu, aux = f64(pre), f64(dnu), f64(aux)
+        rc = self.lib.cpol_stage_hydro(self.h, slot, C.byref(desc), _ptr(table), _ptr(pre),
+                                       _ptr(dnu), _ptr(aux), 0 if aux is None else aux.size)
+        self._check(rc, 'cpol_stage_hydro')
+
+    def set_num_hydro(self, n):
+        self._check(self.lib.cpol_set_num_hydro(self.h, n), 'cpol_set_num_hydro')
+
+    def interp_points(self, coords, heights):
+        coords = np.ascontiguousarray(coords, dtype=np.float32)
+        heights = np.ascontiguousarray(heights, dtype=np.float32)
+        n = heights.shape[0]
+        out = np.empty((self.n_vars, n), dtype=np.float32)
+        rc = self.lib.cpol_interp_points(self.h, n, _ptr(coords), _ptr(heights), _ptr(out))
+        self._check(rc, 'cpol_interp_points')
+        return out
+
+    def run_sweep(self, params, tables, outputs):
+        rc = self.lib.cpol_run_sweep(self.h, C.byref(params), C.byref(tables), C.byref(outputs))
+        self._check(rc, 'cpol_run_sweep')
+
+    def counters(self):
+        c = Counters()
+        self._check(self.lib.cpol_counters(self.h, C.byref(c)), 'cpol_counters')
+        return c
+
+    def debug_read(self, name, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        n = self.lib.cpol_debug_read(self.h, name.encode(), _ptr(out), out.nbytes)
+        if n < 0:
+            self._check(int(n), 'cpol_debug_read(%s)' % name)
+        if n != out.nbytes:
+            raise NativeError('cpol_debug_read(%s): got %d bytes, expected %d'
+                              % (name, n, out.nbytes))
+        return out

@@ -1,0 +1,711 @@
+// cosmo_pol_hip.hip -- C ABI (include/cosmo_pol_amd.h) and launch sequence of
+// the MI355X-native cosmo_pol hot path.  gfx950 only; no CPU fallback.
+//
+// One call of cpol_run_sweep = the work of one `pool.map(worker, azimuths)`
+// of the reference (cosmo_pol/radar_operator.py:429-432) for the rays given:
+//
+//   k_trajectory      (ray, vertical node, gate)      4/3-earth ray path
+//   k_interp_sweep    (ray, sub-beam, gate)           geodesic + rotated pole +
+//                                                     trilinear gather, all vars
+//   k_classify        (sub-beam gate)                 melting, PSD parameters,
+//                                                     LUT bins, bucket histogram
+//   k_bucket_scan / k_bucket_scatter                  counting sort by LUT slice
+//   k_psd_{gamma,ice,melting}  (64 items per wave)    PSD x table integration
+//   k_final_gate      (ray, gate)                     sub-beam/hydrometeor sums,
+//                                                     polarimetric variables
+//   k_final_ray       (ray)                           range scans, sensitivity
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "cpol_device.h"
+#include "cpol_interp.inl"
+#include "cpol_psd.inl"
+#include "cpol_final.inl"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+enum { EV_T0 = 0, EV_TRAJ, EV_INTERP, EV_CLASSIFY, EV_BUCKET, EV_PSD, EV_FINAL, EV_N };
+
+}  // namespace
+
+struct cpol_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // model
+    bool model_staged = false;
+    ModelDev model{};
+    DevBuf d_H, d_V;
+    // hydrometeors
+    HydroSet hs{};
+    DevBuf d_table[CPOL_MAX_HYDRO], d_pre[CPOL_MAX_HYDRO], d_dnu[CPOL_MAX_HYDRO],
+        d_aux[CPOL_MAX_HYDRO];
+    bool hydro_staged[CPOL_MAX_HYDRO] = {};
+    // per-sweep work buffers (grow only)
+    DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj;
+    DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
+        b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err;
+    DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
+    // last sweep shapes (debug reads)
+    long last_n_sbg = 0, last_n_rg = 0;
+    int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0;
+    bool keep_debug = false;
+    // timing: one event set per sweep since cpol_enable_timing(ctx, 1); elapsed
+    // times are collected (averaged) by cpol_counters after the stream drained,
+    // so recording does not serialise the timed loop.
+    bool timing = false;
+    std::vector<hipEvent_t *> ev_sets;
+    size_t ev_used = 0;
+    hipEvent_t *ev = nullptr;          // set of the sweep being recorded
+    cpol_counters_t counters{};
+};
+
+namespace {
+
+#define HIPCHK(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            char buf_[512];                                                               \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                 \
+            ctx->err = buf_;                                                              \
+            return CPOL_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+int ensure(cpol_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return CPOL_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc failed: ") + hipGetErrorString(e);
+        return CPOL_ERR_NOMEM;
+    }
+    b.cap = want;
+    return CPOL_OK;
+}
+
+#define ENSURE(buf, bytes)                                   \
+    do {                                                     \
+        int rc_ = ensure(ctx, (buf), (size_t)(bytes));       \
+        if (rc_ != CPOL_OK) return rc_;                      \
+    } while (0)
+
+int upload(cpol_ctx *ctx, DevBuf &b, const void *src, size_t bytes)
+{
+    ENSURE(b, bytes);
+    HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return CPOL_OK;
+}
+
+void free_buf(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+extern "C" {
+
+int cpol_create(int device, cpol_ctx **out)
+{
+    if (!out) return CPOL_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return CPOL_ERR_HIP;
+    cpol_ctx *ctx = new cpol_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return CPOL_ERR_HIP;
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return CPOL_OK;
+}
+
+void cpol_destroy(cpol_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj_in, &ctx->b_geo, &ctx->b_subh, &ctx->b_subv,
+                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_vals, &ctx->b_mask,
+                     &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
+                     &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_cursor, &ctx->b_units,
+                     &ctx->b_urange, &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_err,
+                     &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model};
+    for (DevBuf *b : all) free_buf(*b);
+    for (auto &b : ctx->b_out) free_buf(b);
+    for (int j = 0; j < CPOL_MAX_HYDRO; ++j) {
+        free_buf(ctx->d_table[j]);
+        free_buf(ctx->d_pre[j]);
+        free_buf(ctx->d_dnu[j]);
+        free_buf(ctx->d_aux[j]);
+    }
+    for (hipEvent_t *set : ctx->ev_sets) {
+        for (int k = 0; k < EV_N; ++k) (void)hipEventDestroy(set[k]);
+        delete[] set;
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *cpol_last_error(cpol_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int cpol_set_stream(cpol_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    if (ctx->own_stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->own_stream = false;
+    }
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return CPOL_OK;
+}
+
+int cpol_synchronize(cpol_ctx *ctx)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CPOL_OK;
+}
+
+int cpol_enable_timing(cpol_ctx *ctx, int on)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    ctx->timing = on != 0;
+    ctx->ev_used = 0;                  // restart the averaging window
+    return CPOL_OK;
+}
+
+int cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data, const float *zlevels,
+                     int nz, int ny, int nx, const float llc[2], const float urc[2],
+                     const float res[2], const double south_pole[2])
+{
+    if (!ctx || !data || !zlevels || n_vars < 1 || n_vars > CPOL_MAX_VARS || nz < 3 || ny < 2 ||
+        nx < 2) {
+        if (ctx) ctx->err = "cpol_stage_model: bad arguments (need nz >= 3, ny, nx >= 2)";
+        return CPOL_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const long ncell = (long)ny * nx;
+    const size_t plane_bytes = (size_t)nz * ncell * sizeof(float);
+    ENSURE(ctx->d_H, plane_bytes);
+    ENSURE(ctx->d_V, plane_bytes * n_vars);
+    DevBuf tmp;
+    int rc = ensure(ctx, tmp, plane_bytes);
+    if (rc != CPOL_OK) return rc;
+    const int blk = 256, grd = cdiv(ncell, blk);
+    HIPCHK(hipMemcpyAsync(tmp.p, zlevels, plane_bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_stage_heights, dim3(grd), dim3(blk), 0, ctx->stream, (const float *)tmp.p,
+                       (float *)ctx->d_H.p, nz, ncell);
+    for (int v = 0; v < n_vars; ++v) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpyAsync(tmp.p, data[v], plane_bytes, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_stage_variable, dim3(grd), dim3(blk), 0, ctx->stream,
+                           (const float *)tmp.p, (float *)ctx->d_V.p, nz, ncell, n_vars, v);
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    free_buf(tmp);
+    ModelDev &m = ctx->model;
+    m.H = (const float *)ctx->d_H.p;
+    m.V = (const float *)ctx->d_V.p;
+    m.n_vars = n_vars; m.nz = nz; m.ny = ny; m.nx = nx;
+    m.llc0 = llc[0]; m.llc1 = llc[1];
+    m.urc0 = urc[0]; m.urc1 = urc[1];
+    m.res0 = res[0]; m.res1 = res[1];
+    // rotation constants (oracle/cosmo_pol_oracle/geodesy.py: rotation_constants)
+    const double theta = (90.0 + south_pole[0]) * CPOL_DEG, phi = south_pole[1] * CPOL_DEG;
+    const double ct = cos(theta), st = sin(theta), cp = cos(phi), sp = sin(phi);
+    m.ctcp = ct * cp; m.ctsp = ct * sp; m.st = st; m.nsp = -sp; m.cp = cp;
+    m.nstcp = -st * cp; m.stsp = st * sp; m.ct = ct;
+    ctx->model_staged = true;
+    return CPOL_OK;
+}
+
+static int n_par_of(int rule)
+{
+    switch (rule) {
+    case CPOL_RULE_ICE_1MOM: return 3;
+    case CPOL_RULE_MELTING_SNOW:
+    case CPOL_RULE_MELTING_GRAUPEL: return 3;
+    default: return 2;
+    }
+}
+
+int cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro)
+{
+    if (!ctx || n_hydro < 0 || n_hydro > CPOL_MAX_HYDRO) return CPOL_ERR_ARG;
+    ctx->hs.n_hydro = n_hydro;
+    int base = 0;
+    for (int j = 0; j < n_hydro; ++j) {
+        ctx->hs.h[j].key_base = base;
+        base += ctx->hs.h[j].d.n_e * ctx->hs.h[j].d.n_t;
+    }
+    ctx->hs.n_keys = base;
+    return CPOL_OK;
+}
+
+int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const double *table,
+                     const double *pre, const double *dnu, const double *aux, int n_aux)
+{
+    if (!ctx || !desc || !table || slot < 0 || slot >= CPOL_MAX_HYDRO || desc->n_e < 1 ||
+        desc->n_t < 1 || desc->n_d < 2) {
+        if (ctx) ctx->err = "cpol_stage_hydro: bad arguments";
+        return CPOL_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t tb = (size_t)desc->n_e * desc->n_t * desc->n_d * CPOL_N_SZ * sizeof(double);
+    const size_t db = (size_t)desc->n_d * sizeof(double);
+    int rc;
+    if ((rc = upload(ctx, ctx->d_table[slot], table, tb)) != CPOL_OK) return rc;
+    HydroDev &h = ctx->hs.h[slot];
+    h.d = *desc;
+    h.table = (const double *)ctx->d_table[slot].p;
+    h.pre = h.dnu = h.aux = nullptr;
+    if (pre) {
+        if ((rc = upload(ctx, ctx->d_pre[slot], pre, db)) != CPOL_OK) return rc;
+        h.pre = (const double *)ctx->d_pre[slot].p;
+    }
+    if (dnu) {
+        if ((rc = upload(ctx, ctx->d_dnu[slot], dnu, db)) != CPOL_OK) return rc;
+        h.dnu = (const double *)ctx->d_dnu[slot].p;
+    }
+    if (aux && n_aux > 0) {
+        if ((rc = upload(ctx, ctx->d_aux[slot], aux, (size_t)n_aux * sizeof(double))) != CPOL_OK)
+            return rc;
+        h.aux = (const double *)ctx->d_aux[slot].p;
+    }
+    if (desc->psd_family == CPOL_PSD_GAMMA && (!pre || !dnu)) {
+        ctx->err = "cpol_stage_hydro: gamma family needs pre[] and dnu[]";
+        return CPOL_ERR_ARG;
+    }
+    if (desc->psd_family == CPOL_PSD_ICE_FIELD && (!aux || n_aux < 3 * desc->n_d + 1)) {
+        ctx->err = "cpol_stage_hydro: ice family needs aux[3*n_d+1]";
+        return CPOL_ERR_ARG;
+    }
+    h.n_par = n_par_of(desc->rule);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->hydro_staged[slot] = true;
+    if (slot >= ctx->hs.n_hydro) cpol_set_num_hydro(ctx, slot + 1);
+    else cpol_set_num_hydro(ctx, ctx->hs.n_hydro);
+    return CPOL_OK;
+}
+
+int cpol_interp_points(cpol_ctx *ctx, int n, const float *coords, const float *heights, float *out)
+{
+    if (!ctx || !ctx->model_staged || n < 1 || !coords || !heights || !out) {
+        if (ctx) ctx->err = "cpol_interp_points: model not staged or bad arguments";
+        return CPOL_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf c, h, o;
+    int rc;
+    if ((rc = upload(ctx, c, coords, (size_t)n * 2 * sizeof(float))) != CPOL_OK) return rc;
+    if ((rc = upload(ctx, h, heights, (size_t)n * sizeof(float))) != CPOL_OK) return rc;
+    const size_t ob = (size_t)n * ctx->model.n_vars * sizeof(float);
+    if ((rc = ensure(ctx, o, ob)) != CPOL_OK) return rc;
+    hipLaunchKernelGGL(k_interp_points, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, ctx->model,
+                       (const float *)c.p, (const float *)h.p, (float *)o.p, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, o.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_buf(c); free_buf(h); free_buf(o);
+    return CPOL_OK;
+}
+
+int cpol_ray_tables(const cpol_sweep_params *p, const double *az_deg, const double *el_deg,
+                    const double *pts_h_deg, const double *pts_v_deg, double *traj_out,
+                    double *geo_out)
+{
+    if (!p || !az_deg || !el_deg || !pts_h_deg || !pts_v_deg || !traj_out || !geo_out)
+        return CPOL_ERR_ARG;
+    const double a = 6378137.0, f = CPOL_WGS84_F, b = (1.0 - f) * a;
+    for (int r = 0; r < p->n_rays; ++r) {
+        for (int j = 0; j < p->n_vnodes; ++j) {
+            double el = (pts_v_deg[j] + el_deg[r]) * CPOL_DEG;
+            double *o = traj_out + ((long)r * p->n_vnodes + j) * 3;
+            o[0] = el; o[1] = sin(el); o[2] = cos(el);
+        }
+        for (int i = 0; i < p->n_hnodes; ++i) {
+            double alpha1 = (pts_h_deg[i] + az_deg[r]) * CPOL_DEG;
+            double sin_a1 = sin(alpha1), cos_a1 = cos(alpha1);
+            double tan_u1 = p->sin_u1 / p->cos_u1;
+            double sigma1 = atan2(tan_u1, cos_a1);
+            double sin_alpha = p->cos_u1 * sin_a1;
+            double cos2_alpha = 1.0 - sin_alpha * sin_alpha;
+            double u2 = cos2_alpha * (a * a - b * b) / (b * b);
+            double A = 1.0 + u2 / 16384.0 * (4096.0 + u2 * (-768.0 + u2 * (320.0 - 175.0 * u2)));
+            double B = u2 / 1024.0 * (256.0 + u2 * (-128.0 + u2 * (74.0 - 47.0 * u2)));
+            double C = f / 16.0 * cos2_alpha * (4.0 + f * (4.0 - 3.0 * cos2_alpha));
+            double *o = geo_out + ((long)r * p->n_hnodes + i) * 8;
+            o[0] = sin_a1; o[1] = cos_a1; o[2] = sigma1; o[3] = sin_alpha;
+            o[4] = b * A; o[5] = B; o[6] = C; o[7] = alpha1;
+        }
+    }
+    return CPOL_OK;
+}
+
+static int copy_out(cpol_ctx *ctx, void *dst, const void *src, size_t bytes, bool dst_on_device)
+{
+    if (!dst) return CPOL_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes,
+                          dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                          ctx->stream));
+    return CPOL_OK;
+}
+
+int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tables_t *t,
+                   cpol_outputs *out)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    if (!p || !t || !out || !ctx->model_staged || ctx->hs.n_hydro < 1 || p->n_rays < 1 ||
+        p->n_gates < 1 || p->n_sub < 1 || p->n_hnodes < 1 || p->n_vnodes < 1 || !t->traj ||
+        !t->geo || !t->sub_h || !t->sub_v || !t->sub_w) {
+        ctx->err = "cpol_run_sweep: model / hydrometeors not staged or bad arguments";
+        return CPOL_ERR_ARG;
+    }
+    for (int j = 0; j < ctx->hs.n_hydro; ++j)
+        if (!ctx->hydro_staged[j]) { ctx->err = "cpol_run_sweep: hydrometeor slot not staged"; return CPOL_ERR_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int n_rays = p->n_rays, ng = p->n_gates, n_sub = p->n_sub;
+    const int n_h = p->n_hnodes, n_v = p->n_vnodes;
+    const int n_vars = ctx->model.n_vars, n_hyd = ctx->hs.n_hydro, n_keys = ctx->hs.n_keys;
+    const long n_rg = (long)n_rays * ng;
+    const long n_sbg = n_rg * n_sub;
+    if (n_sbg >= (1L << 31)) { ctx->err = "cpol_run_sweep: too many sub-beam gates in one call"; return CPOL_ERR_ARG; }
+    int rc;
+
+    // ---- per-sweep host tables -> device ----
+    if ((rc = upload(ctx, ctx->b_traj_in, t->traj, (size_t)n_rays * n_v * 3 * sizeof(double)))) return rc;
+    if ((rc = upload(ctx, ctx->b_geo, t->geo, (size_t)n_rays * n_h * 8 * sizeof(double)))) return rc;
+    if ((rc = upload(ctx, ctx->b_subh, t->sub_h, (size_t)n_sub * sizeof(int)))) return rc;
+    if ((rc = upload(ctx, ctx->b_subv, t->sub_v, (size_t)n_sub * sizeof(int)))) return rc;
+    if ((rc = upload(ctx, ctx->b_subw, t->sub_w, (size_t)n_sub * sizeof(double)))) return rc;
+    const bool cut = p->apply_sensitivity && t->sens_thr;
+    if (cut && (rc = upload(ctx, ctx->b_sens, t->sens_thr, (size_t)ng * sizeof(double)))) return rc;
+
+    // ---- work buffers ----
+    ENSURE(ctx->b_traj, (size_t)n_rays * n_v * 3 * ng * sizeof(float));
+    ENSURE(ctx->b_vals, (size_t)n_vars * n_sbg * sizeof(float));
+    ENSURE(ctx->b_mask, (size_t)n_sbg);
+    ENSURE(ctx->b_elev, (size_t)n_sbg * sizeof(float));
+    if (ctx->keep_debug) ENSURE(ctx->b_coords, (size_t)n_sbg * 2 * sizeof(float));
+    ENSURE(ctx->b_qmelt, (size_t)2 * n_sbg * sizeof(float));
+    ENSURE(ctx->b_fwmelt, (size_t)2 * n_sbg * sizeof(double));
+    ENSURE(ctx->b_key, (size_t)n_hyd * n_sbg * sizeof(int));
+    ENSURE(ctx->b_par, (size_t)n_hyd * CPOL_MAX_PAR * n_sbg * sizeof(double));
+    ENSURE(ctx->b_count, (size_t)n_keys * sizeof(int));
+    ENSURE(ctx->b_offset, (size_t)n_keys * sizeof(int));
+    ENSURE(ctx->b_cursor, (size_t)n_keys * sizeof(int));
+    const long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
+    ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
+    ENSURE(ctx->b_urange, (size_t)2 * CPOL_MAX_HYDRO * sizeof(int));
+    ENSURE(ctx->b_totals, 2 * sizeof(long long));
+    ENSURE(ctx->b_perm, (size_t)n_hyd * n_sbg * sizeof(int));
+    ENSURE(ctx->b_res, (size_t)n_hyd * n_sbg * CPOL_N_SZ * sizeof(double));
+    ENSURE(ctx->b_err, sizeof(int));
+    // output staging (device): 9 float fields + PHIDP
+    enum { O_ZH, O_ZV, O_ZDR, O_KDP, O_DHV, O_PHIDP, O_RHOHV, O_ATTH, O_ATTV, O_MASK, O_LAT, O_LON,
+           O_DIST, O_HGT };
+    for (int k = 0; k <= O_ATTV; ++k) ENSURE(ctx->b_out[k], (size_t)n_rg * sizeof(float));
+    ENSURE(ctx->b_out[O_MASK], (size_t)n_rg * sizeof(double));
+    ENSURE(ctx->b_out[O_LAT], (size_t)n_rg * sizeof(double));
+    ENSURE(ctx->b_out[O_LON], (size_t)n_rg * sizeof(double));
+    ENSURE(ctx->b_out[O_DIST], (size_t)n_rg * sizeof(float));
+    ENSURE(ctx->b_out[O_HGT], (size_t)n_rg * sizeof(float));
+    const bool want_szi = ctx->keep_debug;
+    if (want_szi) ENSURE(ctx->b_szinteg, (size_t)n_rg * n_hyd * CPOL_N_SZ * sizeof(float));
+    const bool want_szt = out->sz_total != nullptr || ctx->keep_debug;
+    if (want_szt) ENSURE(ctx->b_sztotal, (size_t)n_rg * CPOL_N_SZ * sizeof(float));
+    const bool want_model = p->integrate_model && out->model_vars;
+    if (want_model) ENSURE(ctx->b_model, (size_t)n_vars * n_rg * sizeof(double));
+
+    HIPCHK(hipMemsetAsync(ctx->b_count.p, 0, (size_t)n_keys * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(ctx->b_err.p, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(ctx->b_urange.p, 0, (size_t)2 * CPOL_MAX_HYDRO * sizeof(int), st));
+
+    const bool tm = ctx->timing;
+    if (tm) {
+        if (ctx->ev_used == ctx->ev_sets.size()) {
+            hipEvent_t *set = new hipEvent_t[EV_N];
+            for (int k = 0; k < EV_N; ++k) HIPCHK(hipEventCreate(&set[k]));
+            ctx->ev_sets.push_back(set);
+        }
+        ctx->ev = ctx->ev_sets[ctx->ev_used++];
+        HIPCHK(hipEventRecord(ctx->ev[EV_T0], st));
+    }
+
+    // ---- 1. ray paths ----
+    hipLaunchKernelGGL(k_trajectory, dim3(cdiv(ng, 256), n_rays * n_v), dim3(256), 0, st,
+                       (const double *)ctx->b_traj_in.p, (float *)ctx->b_traj.p, n_rays, n_v, ng,
+                       p->range0, p->range_step, p->ke, p->re, p->radar_alt);
+    if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_TRAJ], st));
+
+    // ---- 2. gate interpolation ----
+    InterpArgs ia{};
+    ia.traj = (const float *)ctx->b_traj.p;
+    ia.geo = (const double *)ctx->b_geo.p;
+    ia.sub_h = (const int *)ctx->b_subh.p;
+    ia.sub_v = (const int *)ctx->b_subv.p;
+    ia.vals = (float *)ctx->b_vals.p;
+    ia.mask = (signed char *)ctx->b_mask.p;
+    ia.elev = (float *)ctx->b_elev.p;
+    ia.coords = ctx->keep_debug ? (float *)ctx->b_coords.p : nullptr;
+    ia.lats = (double *)ctx->b_out[O_LAT].p;
+    ia.lons = (double *)ctx->b_out[O_LON].p;
+    ia.dist = (float *)ctx->b_out[O_DIST].p;
+    ia.heights = (float *)ctx->b_out[O_HGT].p;
+    ia.error_flag = (int *)ctx->b_err.p;
+    ia.n_rays = n_rays; ia.n_gates = ng; ia.n_sub = n_sub; ia.n_h = n_h; ia.n_v = n_v;
+    ia.central_sub = n_sub / 2;
+    ia.sin_u1 = p->sin_u1; ia.cos_u1 = p->cos_u1; ia.lon1 = p->radar_lon;
+    hipLaunchKernelGGL(k_interp_sweep, dim3(cdiv(ng, 256), n_sub, n_rays), dim3(256), 0, st,
+                       ctx->model, ia);
+    if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
+
+    // ---- 3. melting + PSD parameters + bucket histogram ----
+    ClassifyArgs ca{};
+    ca.vals = (float *)ctx->b_vals.p;
+    ca.mask = (const signed char *)ctx->b_mask.p;
+    ca.elev = (const float *)ctx->b_elev.p;
+    ca.q_melt = (float *)ctx->b_qmelt.p;
+    ca.fw_melt = (double *)ctx->b_fwmelt.p;
+    ca.key = (int *)ctx->b_key.p;
+    ca.par = (double *)ctx->b_par.p;
+    ca.count = (int *)ctx->b_count.p;
+    ca.n_sbg = n_sbg;
+    ca.with_melting = p->with_melting;
+    ca.var_qr = ca.var_qs = ca.var_qg = -1;
+    for (int j = 0; j < n_hyd; ++j) {
+        const cpol_hydro_desc &d = ctx->hs.h[j].d;
+        if (d.q_source != CPOL_Q_MODEL) continue;
+        if (d.rule == CPOL_RULE_RAIN_1MOM) ca.var_qr = d.var_q;
+        if (d.rule == CPOL_RULE_SNOW_1MOM) ca.var_qs = d.var_q;
+        if (d.rule == CPOL_RULE_GRAUPEL_1MOM) ca.var_qg = d.var_q;
+    }
+    if (p->with_melting && (ca.var_qr < 0 || ca.var_qs < 0 || ca.var_qg < 0)) {
+        ctx->err = "cpol_run_sweep: melting needs 1-moment rain, snow and graupel slots";
+        return CPOL_ERR_ARG;
+    }
+    hipLaunchKernelGGL(k_classify, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st, ctx->hs, ca);
+    if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_CLASSIFY], st));
+
+    // ---- 4. counting sort by LUT slice ----
+    ScanArgs sa{};
+    sa.count = (const int *)ctx->b_count.p;
+    sa.offset = (int *)ctx->b_offset.p;
+    sa.cursor = (int *)ctx->b_cursor.p;
+    sa.units = (WorkUnit *)ctx->b_units.p;
+    sa.unit_range = (int *)ctx->b_urange.p;
+    sa.totals = (long long *)ctx->b_totals.p;
+    sa.n_keys = n_keys;
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, ctx->hs, sa);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st,
+                       (const int *)ctx->b_key.p, (int *)ctx->b_cursor.p, (int *)ctx->b_perm.p,
+                       n_sbg, n_hyd);
+    if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st));
+
+    // ---- 5. PSD x scattering table (one launch per hydrometeor) ----
+    for (int j = 0; j < n_hyd; ++j) {
+        PsdArgs pa{};
+        pa.units = (const WorkUnit *)ctx->b_units.p;
+        pa.unit_range = (const int *)ctx->b_urange.p;
+        pa.perm = (const int *)ctx->b_perm.p;
+        pa.par = (const double *)ctx->b_par.p;
+        pa.res = (double *)ctx->b_res.p;
+        pa.n_sbg = n_sbg;
+        pa.j = j;
+        const HydroDev &h = ctx->hs.h[j];
+        const long max_units = n_sbg / 64 + (long)h.d.n_e * h.d.n_t + 1;
+        const dim3 grd(cdiv(max_units, 4)), blk(256);
+        switch (h.d.psd_family) {
+        case CPOL_PSD_GAMMA: hipLaunchKernelGGL(k_psd_gamma, grd, blk, 0, st, h, pa); break;
+        case CPOL_PSD_ICE_FIELD: hipLaunchKernelGGL(k_psd_ice, grd, blk, 0, st, h, pa); break;
+        case CPOL_PSD_MELTING: hipLaunchKernelGGL(k_psd_melting, grd, blk, 0, st, h, pa); break;
+        default: ctx->err = "unknown psd_family"; return CPOL_ERR_ARG;
+        }
+    }
+    if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
+
+    // ---- 6. accumulation + polarimetric variables + scans ----
+    FinalArgs fa{};
+    fa.res = (const double *)ctx->b_res.p;
+    fa.key = (const int *)ctx->b_key.p;
+    fa.sub_mask = (const signed char *)ctx->b_mask.p;
+    fa.vals = (const float *)ctx->b_vals.p;
+    fa.sub_w = (const double *)ctx->b_subw.p;
+    fa.sz_integ = want_szi ? (float *)ctx->b_szinteg.p : nullptr;
+    fa.sz_total = want_szt ? (float *)ctx->b_sztotal.p : nullptr;
+    fa.ZH = (float *)ctx->b_out[O_ZH].p; fa.ZV = (float *)ctx->b_out[O_ZV].p;
+    fa.ZDR = (float *)ctx->b_out[O_ZDR].p; fa.KDP = (float *)ctx->b_out[O_KDP].p;
+    fa.DELTA_HV = (float *)ctx->b_out[O_DHV].p; fa.RHOHV = (float *)ctx->b_out[O_RHOHV].p;
+    fa.ATT_H = (float *)ctx->b_out[O_ATTH].p; fa.ATT_V = (float *)ctx->b_out[O_ATTV].p;
+    fa.mask = (double *)ctx->b_out[O_MASK].p;
+    fa.model_vars = want_model ? (double *)ctx->b_model.p : nullptr;
+    fa.n_rays = n_rays; fa.n_gates = ng; fa.n_sub = n_sub; fa.n_hydro = n_hyd; fa.n_vars = n_vars;
+    fa.c_zh = (float)p->c_zh;
+    fa.c_kdp = (float)(1e-3 * (180.0 / 3.14159265358979323846) * p->wavelength);
+    fa.c_2w = (float)(2 * p->wavelength);
+    double sum_w = 0;
+    for (int s = 0; s < n_sub; ++s) sum_w += t->sub_w[s];
+    fa.sum_w = sum_w;
+    hipLaunchKernelGGL(k_final_gate, dim3(cdiv(n_rg, 256)), dim3(256), 0, st, fa);
+
+    ScanRayArgs ra{};
+    ra.ZH = fa.ZH; ra.ZV = fa.ZV; ra.ZDR = fa.ZDR; ra.KDP = fa.KDP; ra.DELTA_HV = fa.DELTA_HV;
+    ra.PHIDP = (float *)ctx->b_out[O_PHIDP].p; ra.RHOHV = fa.RHOHV; ra.ATT_H = fa.ATT_H;
+    ra.ATT_V = fa.ATT_V; ra.RVEL = nullptr;
+    ra.sens_thr = cut ? (const double *)ctx->b_sens.p : nullptr;
+    ra.n_rays = n_rays; ra.n_gates = ng; ra.with_attenuation = p->with_attenuation;
+    ra.radial_res = (float)p->radial_res;
+    ra.res_km = (float)(p->radial_res / 1000.);
+    hipLaunchKernelGGL(k_final_ray, dim3(n_rays), dim3(64), (size_t)3 * ng * sizeof(float), st, ra);
+    if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
+    HIPCHK(hipGetLastError());
+
+    // ---- outputs ----
+    const bool dev = p->outputs_on_device != 0;
+    const size_t fb = (size_t)n_rg * sizeof(float), dbb = (size_t)n_rg * sizeof(double);
+    if ((rc = copy_out(ctx, out->ZH, ctx->b_out[O_ZH].p, fb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->ZV, ctx->b_out[O_ZV].p, fb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->ZDR, ctx->b_out[O_ZDR].p, fb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->KDP, ctx->b_out[O_KDP].p, fb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->DELTA_HV, ctx->b_out[O_DHV].p, fb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->PHIDP, ctx->b_out[O_PHIDP].p, fb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->RHOHV, ctx->b_out[O_RHOHV].p, fb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->ATT_H, ctx->b_out[O_ATTH].p, fb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->ATT_V, ctx->b_out[O_ATTV].p, fb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->mask, ctx->b_out[O_MASK].p, dbb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->lats, ctx->b_out[O_LAT].p, dbb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->lons, ctx->b_out[O_LON].p, dbb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->dist, ctx->b_out[O_DIST].p, fb, dev))) return rc;
+    if ((rc = copy_out(ctx, out->heights, ctx->b_out[O_HGT].p, fb, dev))) return rc;
+    if (want_model && (rc = copy_out(ctx, out->model_vars, ctx->b_model.p, dbb * n_vars, dev))) return rc;
+    if (out->sz_total && (rc = copy_out(ctx, out->sz_total, ctx->b_sztotal.p, fb * CPOL_N_SZ, dev))) return rc;
+
+    ctx->last_n_sbg = n_sbg; ctx->last_n_rg = n_rg; ctx->last_n_rays = n_rays;
+    ctx->last_n_gates = ng; ctx->last_n_sub = n_sub; ctx->last_n_v = n_v;
+    ctx->counters.n_subbeam_gates = n_sbg;
+    ctx->counters.n_gates = n_rg;
+
+    if (!dev || ctx->keep_debug) {
+        // host-visible results requested: wait, then surface the domain error
+        HIPCHK(hipStreamSynchronize(st));
+        int flag = 0;
+        HIPCHK(hipMemcpy(&flag, ctx->b_err.p, sizeof flag, hipMemcpyDeviceToHost));
+        if (flag) {
+            ctx->err = "RADAR DOMAIN IS NOT ENTIRELY CONTAINED IN COSMO SIMULATION DOMAIN";
+            return CPOL_ERR_DOMAIN;
+        }
+    }
+    return CPOL_OK;
+}
+
+int cpol_counters(cpol_ctx *ctx, cpol_counters_t *out)
+{
+    if (!ctx || !out) return CPOL_ERR_ARG;
+    if (ctx->last_n_sbg > 0) {
+        // device-side totals of the LAST sweep (valid once the stream drained)
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        long long totals[2] = {0, 0};
+        int flag = 0;
+        HIPCHK(hipMemcpy(totals, ctx->b_totals.p, sizeof totals, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&flag, ctx->b_err.p, sizeof flag, hipMemcpyDeviceToHost));
+        ctx->counters.n_valid_items = totals[0];
+        ctx->counters.n_work_units = totals[1];
+        if (ctx->ev_used > 0) {
+            // average stage durations over the sweeps recorded since enable_timing
+            double acc[EV_N] = {}, tot = 0;
+            for (size_t i = 0; i < ctx->ev_used; ++i) {
+                hipEvent_t *e = ctx->ev_sets[i];
+                for (int k = 1; k < EV_N; ++k) {
+                    float ms = 0;
+                    HIPCHK(hipEventElapsedTime(&ms, e[k - 1], e[k]));
+                    acc[k] += ms;
+                }
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, e[EV_T0], e[EV_FINAL]));
+                tot += ms;
+            }
+            const double inv = 1.0 / (double)ctx->ev_used;
+            ctx->counters.ms_traj = (float)(acc[EV_TRAJ] * inv);
+            ctx->counters.ms_interp = (float)(acc[EV_INTERP] * inv);
+            ctx->counters.ms_classify = (float)(acc[EV_CLASSIFY] * inv);
+            ctx->counters.ms_bucket = (float)(acc[EV_BUCKET] * inv);
+            ctx->counters.ms_psd = (float)(acc[EV_PSD] * inv);
+            ctx->counters.ms_final = (float)(acc[EV_FINAL] * inv);
+            ctx->counters.ms_total = (float)(tot * inv);
+        }
+        if (flag) {
+            ctx->err = "RADAR DOMAIN IS NOT ENTIRELY CONTAINED IN COSMO SIMULATION DOMAIN";
+            *out = ctx->counters;
+            return CPOL_ERR_DOMAIN;
+        }
+    }
+    *out = ctx->counters;
+    return CPOL_OK;
+}
+
+int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_bytes)
+{
+    if (!ctx || !name) return CPOL_ERR_ARG;
+    if (!strcmp(name, "enable")) { ctx->keep_debug = true; return 0; }
+    if (!strcmp(name, "disable")) { ctx->keep_debug = false; return 0; }
+    if (!dst || ctx->last_n_sbg <= 0) return CPOL_ERR_ARG;
+    const long n_sbg = ctx->last_n_sbg, n_rg = ctx->last_n_rg;
+    const int n_hyd = ctx->hs.n_hydro, n_vars = ctx->model.n_vars;
+    const void *src = nullptr;
+    int64_t bytes = 0;
+    if (!strcmp(name, "sub_values")) { src = ctx->b_vals.p; bytes = (int64_t)n_vars * n_sbg * 4; }
+    else if (!strcmp(name, "sub_mask")) { src = ctx->b_mask.p; bytes = n_sbg; }
+    else if (!strcmp(name, "sub_elev")) { src = ctx->b_elev.p; bytes = n_sbg * 4; }
+    else if (!strcmp(name, "sub_coords")) { src = ctx->b_coords.p; bytes = n_sbg * 8; }
+    else if (!strcmp(name, "item_key")) { src = ctx->b_key.p; bytes = (int64_t)n_hyd * n_sbg * 4; }
+    else if (!strcmp(name, "item_res")) { src = ctx->b_res.p; bytes = (int64_t)n_hyd * n_sbg * CPOL_N_SZ * 8; }
+    else if (!strcmp(name, "item_par")) { src = ctx->b_par.p; bytes = (int64_t)n_hyd * CPOL_MAX_PAR * n_sbg * 8; }
+    else if (!strcmp(name, "q_melt")) { src = ctx->b_qmelt.p; bytes = 2 * n_sbg * 4; }
+    else if (!strcmp(name, "fw_melt")) { src = ctx->b_fwmelt.p; bytes = 2 * n_sbg * 8; }
+    else if (!strcmp(name, "sz_integ")) { src = ctx->b_szinteg.p; bytes = (int64_t)n_rg * n_hyd * CPOL_N_SZ * 4; }
+    else if (!strcmp(name, "sz_total")) { src = ctx->b_sztotal.p; bytes = (int64_t)n_rg * CPOL_N_SZ * 4; }
+    else if (!strcmp(name, "traj")) { src = ctx->b_traj.p; bytes = (int64_t)ctx->last_n_rays * ctx->last_n_v * 3 * ctx->last_n_gates * 4; }
+    else if (!strcmp(name, "bucket_count")) { src = ctx->b_count.p; bytes = (int64_t)ctx->hs.n_keys * 4; }
+    else { ctx->err = std::string("cpol_debug_read: unknown buffer ") + name; return CPOL_ERR_ARG; }
+    if (!src) { ctx->err = "cpol_debug_read: buffer not kept (call with name \"enable\" first)"; return CPOL_ERR_ARG; }
+    if (bytes > max_bytes) { ctx->err = "cpol_debug_read: destination too small"; return CPOL_ERR_ARG; }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        ctx->err = "cpol_debug_read: copy failed";
+        return CPOL_ERR_HIP;
+    }
+    return bytes;
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// cpol_final.inl -- sub-beam / hydrometeor accumulation, polarimetric variables,
+// range scans, radial mask, antenna-averaged model variables, sensitivity cut.
+//
+// Reference functions replaced (wolfidan/cosmo_pol):
+//   accumulation over sub-beams (float32 store, quirks Q3-Q5)
+//                                scatter/doppler_scatter.py:133-134, 259-268, 400-401
+//   get_pol_from_sz              scatter/doppler_scatter.py:491-544
+//   PHIDP / attenuated ZDR       scatter/doppler_scatter.py:406-415,
+//                                utilities/utilities.py:175-199 (nan_cumsum/-prod)
+//   radial mask                  scatter/doppler_scatter.py:472-477
+//   integrate_radials            interpolation/interpolation.py:36-89
+//   cut_at_sensitivity           scatter/doppler_scatter.py:804-862
+// float32 statements keep NumPy's operand order (python scalars are cast to
+// float32 first); libm-type float32 functions are evaluated in float64 and
+// rounded once, which reproduces a correctly rounded float32 libm.
+
+struct FinalArgs {
+    const double *res;          // [n_hydro][n_sbg][12]
+    const int *key;             // [n_hydro][n_sbg]
+    const signed char *sub_mask;
+    const float *vals;          // [n_vars][n_sbg]
+    const double *sub_w;        // [n_sub]
+    float *sz_integ;            // [n_rg][n_hydro][12] or NULL
+    float *sz_total;            // [n_rg][12] or NULL
+    float *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *RHOHV, *ATT_H, *ATT_V;   // work / outputs
+    double *mask;               // [n_rg]
+    double *model_vars;         // [n_vars][n_rg] or NULL
+    int n_rays, n_gates, n_sub, n_hydro, n_vars;
+    float c_zh, c_kdp, c_2w;    // wavelength^4/(pi^5 K^2), 1e-3*(180/pi)*wavelength, 2*wavelength
+    double sum_w;
+};
+
+__global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
+{
+    const long rg = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n_rg = (long)a.n_rays * a.n_gates;
+    if (rg >= n_rg) return;
+    const int ray = (int)(rg / a.n_gates), gate = (int)(rg % a.n_gates);
+    const long n_sbg = n_rg * a.n_sub;
+    const long sbg0 = (long)ray * a.n_sub * a.n_gates + gate;      // + sub * n_gates
+    const float qnan = __builtin_nanf("");
+
+    float tot[CPOL_N_SZ];
+    for (int j = 0; j < a.n_hydro; ++j) {
+        float acc[CPOL_N_SZ];
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = qnan;
+        for (int s = 0; s < a.n_sub; ++s) {
+            const long sbg = sbg0 + (long)s * a.n_gates;
+            if (a.key[(long)j * n_sbg + sbg] < 0) continue;
+            const double w = a.sub_w[s];
+            const double *r = a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ;
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ; ++c) {
+                // nansum([float32 acc, float64 term]) stored back as float32
+                double y = r[c] * w;
+                double x = (double)acc[c];
+                if (!(x == x)) x = 0.0;
+                if (!(y == y)) y = 0.0;
+                acc[c] = (float)(x + y);
+            }
+        }
+        if (a.sz_integ) {
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ; ++c)
+                a.sz_integ[(rg * a.n_hydro + j) * CPOL_N_SZ + c] = acc[c];
+        }
+        // np.nansum(sz_integ, axis=1): float32, hydrometeors in order
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) {
+            float v = (acc[c] == acc[c]) ? acc[c] : 0.0f;
+            tot[c] = (j == 0) ? v : tot[c] + v;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPOL_N_SZ; ++c) if (tot[c] == 0.0f) tot[c] = qnan;     // Q5
+    if (a.sz_total) {
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) a.sz_total[rg * CPOL_N_SZ + c] = tot[c];
+    }
+
+    // ---- get_pol_from_sz (float32) ----
+    const float two_pi = (float)(2 * 3.14159265358979323846);
+    const float b = tot[0] - tot[1] - tot[2] + tot[3];
+    const float cc = tot[0] + tot[1] + tot[2] + tot[3];
+    const float xs_h = two_pi * b;
+    const float xs_v = two_pi * cc;
+    a.ZH[rg] = a.c_zh * xs_h;
+    a.ZV[rg] = a.c_zh * xs_v;
+    a.ZDR[rg] = xs_h / xs_v;
+    a.KDP[rg] = a.c_kdp * (tot[10] - tot[8]);
+    a.ATT_H[rg] = 4.343e-3f * (a.c_2w * tot[11]);
+    a.ATT_V[rg] = 4.343e-3f * (a.c_2w * tot[9]);
+    const float t47 = tot[4] + tot[7], t65 = tot[6] - tot[5];
+    const float aa = t47 * t47 + t65 * t65;
+    a.RHOHV[rg] = sqrtf(aa / (b * cc));
+    a.DELTA_HV[rg] = (float)atan2((double)(tot[5] - tot[6]), (double)(-tot[4] - tot[7]));
+
+    // ---- radial mask (doppler_scatter.py:472-477) ----
+    double msum = 0.0;
+    for (int s = 0; s < a.n_sub; ++s) msum += (double)a.sub_mask[sbg0 + (long)s * a.n_gates];
+    msum /= (double)a.n_sub;
+    if (msum > -1.0 && msum <= 0.0) msum = 0.0;
+    if (a.mask) a.mask[rg] = msum;
+
+    // ---- integrate_radials: NaN-skipping weighted sum (float64) ----
+    if (a.model_vars) {
+        for (int v = 0; v < a.n_vars; ++v) {
+            double acc = 0.0;
+            for (int s = 0; s < a.n_sub; ++s) {
+                double y = (double)a.vals[(long)v * n_sbg + sbg0 + (long)s * a.n_gates]
+                           * a.sub_w[s] / a.sum_w;
+                if (y == y) acc += y;
+            }
+            a.model_vars[(long)v * n_rg + rg] = acc;
+        }
+    }
+}
+
+// One wavefront per ray: lanes stage the ray in LDS, lanes 0..2 run the three
+// strictly sequential float32 scans (np.cumsum / np.cumprod order), then all
+// lanes finish PHIDP, the attenuated ZDR and the sensitivity cut.
+struct ScanRayArgs {
+    float *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *PHIDP, *RHOHV, *ATT_H, *ATT_V;
+    double *RVEL;
+    const double *sens_thr;     // [n_gates] or NULL
+    int n_rays, n_gates, with_attenuation;
+    float radial_res;           // float32 cast of the python scalar
+    float res_km;               // (float)(radial_res / 1000.)
+};
+
+__global__ __launch_bounds__(64) void k_final_ray(ScanRayArgs a)
+{
+    extern __shared__ float lds[];          // [3][n_gates]
+    const int ray = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int ng = a.n_gates;
+    const long base = (long)ray * ng;
+    float *s_k = lds, *s_h = lds + ng, *s_v = lds + 2 * ng;
+    for (int g = lane; g < ng; g += 64) {
+        float k2 = 2.0f * a.KDP[base + g];
+        s_k[g] = (k2 == k2) ? k2 : 0.0f;                       // nan_cumsum
+        if (a.with_attenuation) {
+            // 10**(-0.1*A*(radial_res/1000.)) in float32
+            float fh = (float)pow(10.0, (double)(-0.1f * a.ATT_H[base + g] * a.res_km));
+            float fv = (float)pow(10.0, (double)(-0.1f * a.ATT_V[base + g] * a.res_km));
+            s_h[g] = (fh == fh) ? fh : 1.0f;                   // nan_cumprod
+            s_v[g] = (fv == fv) ? fv : 1.0f;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float c = 0.0f;
+        for (int g = 0; g < ng; ++g) { c = (g == 0) ? s_k[0] : c + s_k[g]; s_k[g] = c; }
+    } else if (lane == 1 && a.with_attenuation) {
+        float c = 1.0f;
+        for (int g = 0; g < ng; ++g) { c = (g == 0) ? s_h[0] : c * s_h[g]; s_h[g] = c; }
+    } else if (lane == 2 && a.with_attenuation) {
+        float c = 1.0f;
+        for (int g = 0; g < ng; ++g) { c = (g == 0) ? s_v[0] : c * s_v[g]; s_v[g] = c; }
+    }
+    __syncthreads();
+    for (int g = lane; g < ng; g += 64) {
+        const long i = base + g;
+        float zh = a.ZH[i], zv = a.ZV[i];
+        float phidp = s_k[g] * a.radial_res / 1000.0f + a.DELTA_HV[i];
+        float zdr = a.ZDR[i];
+        if (a.with_attenuation) zdr = (zh * s_h[g]) / (zv * s_v[g]);
+        bool cut = false;
+        if (a.sens_thr) {
+            // 10*np.log10(ZH) (float32) < threshold(r) (float64)
+            float dbz = 10.0f * (float)log10((double)zh);
+            cut = (double)dbz < a.sens_thr[g];
+        }
+        if (cut) {
+            const float qnan = __builtin_nanf("");
+            a.ZH[i] = qnan; a.ZV[i] = qnan; a.KDP[i] = qnan; a.RHOHV[i] = qnan;
+            zdr = qnan; phidp = qnan;
+            if (a.RVEL) a.RVEL[i] = __builtin_nan("");
+        }
+        a.PHIDP[i] = phidp;
+        a.ZDR[i] = zdr;
+    }
+}

@@ -1,0 +1,261 @@
+// cpol_interp.inl -- beam geometry + gate interpolation kernels.
+//
+// Reference functions replaced (wolfidan/cosmo_pol):
+//   _ref_4_3                 interpolation/atm_refraction.py:181-220
+//   trilin_interp_radial     interpolation/interpolation.py:498-597 (geodesic per
+//                            gate, rotated-pole transform, domain check)
+//   get_all_radar_pts        interpolation/interpolation_c.c:12-104
+//   binary_search            interpolation/interpolation_c.c:108-135
+//   trilinear_interp         interpolation/interpolation_c.c:138-164
+//   mask coding              interpolation/interpolation.py:398-411
+// All float32 arithmetic below is written in the reference's operand order and
+// the TU is compiled with -ffp-contract=off: gate values are bit-identical to
+// the x86-64 SSE build of the reference C.
+
+// ---------------------------------------------------------------- staging
+// [nz][ny][nx] -> H[cell][nz]
+__global__ void k_stage_heights(const float *__restrict__ src, float *__restrict__ dst,
+                                int nz, long ncell)
+{
+    long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= ncell) return;
+    for (int k = 0; k < nz; ++k) dst[cell * nz + k] = src[(long)k * ncell + cell];
+}
+
+// [nz][ny][nx] of variable v -> V[cell][nz][n_vars]
+__global__ void k_stage_variable(const float *__restrict__ src, float *__restrict__ dst,
+                                 int nz, long ncell, int n_vars, int v)
+{
+    long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= ncell) return;
+    for (int k = 0; k < nz; ++k)
+        dst[(cell * nz + k) * n_vars + v] = src[(long)k * ncell + cell];
+}
+
+// ---------------------------------------------------------------- trajectory
+// traj_out: float32 [n_rays][n_vnodes][3][n_gates]  (s, h, e_deg)
+__global__ void k_trajectory(const double *__restrict__ ray_traj,   // [n_rays][n_v][3]
+                             float *__restrict__ traj_out,
+                             int n_rays, int n_v, int n_gates,
+                             double range0, double range_step, double ke, double re, double alt)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    int rv = blockIdx.y;                       // ray * n_v + vnode
+    if (g >= n_gates) return;
+    const double el = ray_traj[rv * 3 + 0];
+    const double sin_el = ray_traj[rv * 3 + 1];
+    const double cos_el = ray_traj[rv * 3 + 2];
+    const double r = range0 + (double)g * range_step;
+    const double ke_re = ke * re;
+    // atm_refraction.py:206-215, same operand order
+    double temp = sqrt(r * r + ke_re * ke_re + 2.0 * r * ke * re * sin_el);
+    double h = temp - ke_re + alt;
+    double s = ke_re * asin((r * cos_el) / (ke_re + h));
+    double e = el + atan(r * cos_el / (r * sin_el + ke_re + alt));
+    float *o = traj_out + (long)rv * 3 * n_gates;
+    o[g] = (float)s;
+    o[n_gates + g] = (float)h;
+    // np.rad2deg on float32: x * (180/pi) evaluated in float32
+    o[2 * n_gates + g] = (float)e * (float)(180.0 / 3.14159265358979323846);
+}
+
+// ---------------------------------------------------------------- gate kernel
+// largest i in [0, n-2] with col[i] >= key (col strictly descending, col[0] >= key)
+__device__ __forceinline__ int level_search(const float *__restrict__ col, int n, float key)
+{
+    int step = 1;
+    while ((step << 1) <= n - 2) step <<= 1;    // wave-uniform
+    int i = 0;
+#pragma unroll 1
+    for (; step >= 1; step >>= 1) {
+        int j = i + step;
+        if (j <= n - 2 && col[j] >= key) i = j;
+    }
+    return i;
+}
+
+struct GateGeom {
+    int status;            // 0 ok, +1 above model top, -1 below topography
+    float x, y, dx, dy;    // fractional position (x along rows/lat, y along cols/lon)
+    long cell[4];          // the 4 neighbour columns (i0,i1) (i0,i1+1) (i0+1,i1) (i0+1,i1+1)
+    int c1[4];             // upper level of the bracketing pair (c2 = c1+1)
+    float z1[4], z2[4];
+};
+
+__device__ __forceinline__ void gate_geometry(const ModelDev &m, float rlat, float rlon, float h,
+                                              GateGeom &g)
+{
+    // interpolation_c.c:43-57
+    float p0 = (rlat - m.llc1) / m.res1;
+    float p1 = (rlon - m.llc0) / m.res0;
+    int i0 = (int)floor((double)p0);
+    int i1 = (int)floor((double)p1);
+    g.x = fmodf(p0, 1.0f);
+    g.y = fmodf(p1, 1.0f);
+    g.dx = 1.0f - g.x;
+    g.dy = 1.0f - g.y;
+    // the reference does not range-check; callers pass the domain check first.
+    // Clamp so that a gate exactly on the upper domain edge cannot fault.
+    int i0a = min(max(i0, 0), m.ny - 1), i0b = min(max(i0 + 1, 0), m.ny - 1);
+    int i1a = min(max(i1, 0), m.nx - 1), i1b = min(max(i1 + 1, 0), m.nx - 1);
+    g.cell[0] = (long)i0a * m.nx + i1a;
+    g.cell[1] = (long)i0a * m.nx + i1b;
+    g.cell[2] = (long)i0b * m.nx + i1a;
+    g.cell[3] = (long)i0b * m.nx + i1b;
+    const int nz = m.nz;
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = m.H[g.cell[k] * nz + (nz - 1)];
+    // interpolation_c.c:61
+    float topo = g.dx * g.dy * t[0] + g.x * t[2] * g.dy + g.dx * t[1] * g.y + g.x * g.y * t[3];
+    if (!(topo < h)) { g.status = -1; return; }
+    g.status = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float *col = m.H + g.cell[k] * nz;
+        int c1;
+        if (h > col[0]) { g.status = 1; return; }            // interpolation_c.c:70-73
+        if (h < t[k]) c1 = nz - 3;                            // :74-77 (extrapolate)
+        else c1 = min(level_search(col, nz, h), nz - 3);      // :79-81
+        g.c1[k] = c1;
+        g.z1[k] = col[c1];
+        g.z2[k] = col[c1 + 1];
+    }
+}
+
+__device__ __forceinline__ float gate_value(const ModelDev &m, const GateGeom &g, float h, int v)
+{
+    float val[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float *p = m.V + ((g.cell[k] * m.nz + g.c1[k]) * m.n_vars + v);
+        float v1 = p[0], v2 = p[m.n_vars];
+        // interpolation_c.c:151
+        val[k] = v2 - (v2 - v1) / (g.z1[k] - g.z2[k]) * (h - g.z2[k]);
+    }
+    // interpolation_c.c:162
+    return g.dx * g.dy * val[0] + g.x * val[2] * g.dy + g.dx * val[1] * g.y + g.x * g.y * val[3];
+}
+
+// explicit points -> all variables, reference sentinels (cpol_interp_points)
+__global__ void k_interp_points(ModelDev m, const float *__restrict__ coords,
+                                const float *__restrict__ heights, float *__restrict__ out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    GateGeom g;
+    float h = heights[i];
+    gate_geometry(m, coords[2 * i], coords[2 * i + 1], h, g);
+    for (int v = 0; v < m.n_vars; ++v) {
+        float r;
+        if (g.status == 1) r = -9999.0f;
+        else if (g.status == -1) r = __builtin_nanf("");
+        else r = gate_value(m, g, h, v);
+        out[(long)v * n + i] = r;
+    }
+}
+
+// ---------------------------------------------------------------- sweep kernel
+// One thread per sub-beam gate; a wave = 64 consecutive gates of ONE sub-beam
+// (gate-stride coalesced stores, neighbouring gates share grid columns).
+// grid = (ceil(n_gates/256), n_sub, n_rays)
+struct InterpArgs {
+    const float *traj;          // [n_rays][n_v][3][n_gates]
+    const double *geo;          // [n_rays][n_h][8]
+    const int *sub_h, *sub_v;
+    float *vals;                // [n_vars][n_sbg]
+    signed char *mask;          // [n_sbg]
+    float *elev;                // [n_sbg] folded elevation (doppler_scatter.py:173-176)
+    float *coords;              // [n_sbg][2] rotated (lat, lon)  (debug / parity)
+    double *lats, *lons;        // [n_rays*n_gates] central sub-beam
+    float *dist, *heights;      // [n_rays*n_gates] central sub-beam
+    int *error_flag;
+    int n_rays, n_gates, n_sub, n_h, n_v, central_sub;
+    double sin_u1, cos_u1, lon1;
+};
+
+__global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
+{
+    const int gate = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = blockIdx.y, ray = blockIdx.z;
+    if (gate >= a.n_gates) return;
+    const int ih = a.sub_h[sub], jv = a.sub_v[sub];
+    const long sbg = ((long)ray * a.n_sub + sub) * a.n_gates + gate;
+    const long n_sbg = (long)a.n_rays * a.n_sub * a.n_gates;
+
+    const float *tr = a.traj + ((long)(ray * a.n_v + jv) * 3) * a.n_gates;
+    const float s32 = tr[gate], h32 = tr[a.n_gates + gate];
+    float e32 = tr[2 * a.n_gates + gate];
+
+    // ---- WGS84 direct geodesic (Vincenty, fixed iteration count) ----
+    const double *gc = a.geo + (long)(ray * a.n_h + ih) * 8;
+    const double sin_a1 = gc[0], cos_a1 = gc[1], sigma1 = gc[2], sin_alpha = gc[3];
+    const double bA = gc[4], B = gc[5], C = gc[6];
+    const double f = CPOL_WGS84_F;
+    const double sigma0 = (double)s32 / bA;
+    double sigma = sigma0, two_sm, cos2sm, sin_s, cos_s;
+#pragma unroll 1
+    for (int it = 0; it < CPOL_VINCENTY_ITERS; ++it) {
+        two_sm = 2.0 * sigma1 + sigma;
+        cos2sm = cos(two_sm);
+        sin_s = sin(sigma);
+        cos_s = cos(sigma);
+        double dsig = B * sin_s * (cos2sm + B / 4.0 * (cos_s * (-1.0 + 2.0 * cos2sm * cos2sm)
+                      - B / 6.0 * cos2sm * (-3.0 + 4.0 * sin_s * sin_s)
+                      * (-3.0 + 4.0 * cos2sm * cos2sm)));
+        sigma = sigma0 + dsig;
+    }
+    two_sm = 2.0 * sigma1 + sigma;
+    cos2sm = cos(two_sm);
+    sin_s = sin(sigma);
+    cos_s = cos(sigma);
+    const double tmp = a.sin_u1 * sin_s - a.cos_u1 * cos_s * cos_a1;
+    const double lat2 = atan2(a.sin_u1 * cos_s + a.cos_u1 * sin_s * cos_a1,
+                              (1.0 - f) * sqrt(sin_alpha * sin_alpha + tmp * tmp));
+    const double lam = atan2(sin_s * sin_a1, a.cos_u1 * cos_s - a.sin_u1 * sin_s * cos_a1);
+    const double L = lam - (1.0 - C) * f * sin_alpha *
+        (sigma + C * sin_s * (cos2sm + C * cos_s * (-1.0 + 2.0 * cos2sm * cos2sm)));
+    const double lat_deg = lat2 / CPOL_DEG;
+    const double lon_deg = a.lon1 + L / CPOL_DEG;
+
+    // ---- rotated-pole transform (float64) -> float32 grid coordinates ----
+    const double latr = lat_deg * CPOL_DEG, lonr = lon_deg * CPOL_DEG;
+    const double cl = cos(latr);
+    const double x = cos(lonr) * cl, y = sin(lonr) * cl, z = sin(latr);
+    const double x_new = m.ctcp * x + m.ctsp * y + m.st * z;
+    const double y_new = m.nsp * x + m.cp * y;
+    const double z_new = m.nstcp * x - m.stsp * y + m.ct * z;
+    const float rlon = (float)(atan2(y_new, x_new) / CPOL_DEG);
+    const float rlat = (float)(asin(z_new) / CPOL_DEG);
+
+    // interpolation.py:572-575 (IndexError in the reference)
+    if (rlon < m.llc0 || rlat < m.llc1 || rlon > m.urc0 || rlat > m.urc1 ||
+        !(rlon == rlon) || !(rlat == rlat)) {
+        atomicOr(a.error_flag, 1);
+        a.mask[sbg] = 2;
+        for (int v = 0; v < m.n_vars; ++v) a.vals[(long)v * n_sbg + sbg] = __builtin_nanf("");
+        a.elev[sbg] = e32;
+        return;
+    }
+
+    GateGeom g;
+    gate_geometry(m, rlat, rlon, h32, g);
+    const float qnan = __builtin_nanf("");
+    for (int v = 0; v < m.n_vars; ++v)
+        a.vals[(long)v * n_sbg + sbg] = (g.status == 0) ? gate_value(m, g, h32, v) : qnan;
+    a.mask[sbg] = (signed char)g.status;
+
+    // elevation folded into [0, 90] for the LUT (doppler_scatter.py:173-176, in place)
+    if (e32 > 90.0f) e32 = 180.0f - e32;
+    if (e32 < 0.0f) e32 = -e32;
+    a.elev[sbg] = e32;
+    if (a.coords) { a.coords[2 * sbg] = rlat; a.coords[2 * sbg + 1] = rlon; }
+
+    if (sub == a.central_sub) {
+        const long rg = (long)ray * a.n_gates + gate;
+        if (a.lats) a.lats[rg] = lat_deg;
+        if (a.lons) a.lons[rg] = lon_deg;
+        if (a.dist) a.dist[rg] = s32;
+        if (a.heights) a.heights[rg] = h32;
+    }
+}

@@ -1,0 +1,479 @@
+// cpol_psd.inl -- melting diagnosis, PSD parameters, LUT-slice bucketing and the
+// PSD x scattering-table integration (the dominant kernel).
+//
+// Reference functions replaced (wolfidan/cosmo_pol):
+//   melting                         interpolation/melting.py:19-90
+//   Rain/Snow/Graupel.set_psd       hydrometeors/hydrometeors.py:747-772, 879-907, 1025-1049
+//   _Hydrometeor.set_psd (2-moment) hydrometeors/hydrometeors.py:212-256
+//   IceParticle.set_psd / get_N     hydrometeors/hydrometeors.py:1302-1373, 1231-1250
+//   Melting*.set_psd / get_N / ...  hydrometeors/hydrometeors.py:333-478, 1398-1481
+//   _Hydrometeor.get_N              hydrometeors/hydrometeors.py:128-147
+//   Lookup_table.lookup_line        lookup/lut.py:309-344  (floor-bin, no interpolation)
+//   PSD integral (rectangle rule)   scatter/doppler_scatter.py:246-251
+//
+// Design: the reference gathers one [1024 x 12] float64 LUT slice per valid
+// (gate, hydrometeor) item and contracts it with N(D).  Items with the same
+// (hydrometeor, elevation bin, temperature bin) share the slice, so items are
+// counting-sorted by slice ("bucket"); one 64-lane wavefront then integrates 64
+// items of ONE bucket with the item on the lane: the slice row, D^mu and D^nu
+// are wave-uniform and arrive through the scalar data path (s_load -> SGPR
+// operand of v_fma_f64), the 12 float64 accumulators stay in VGPRs and no
+// cross-lane reduction or LDS staging is needed.
+
+// ---------------------------------------------------------------- helpers
+__device__ __forceinline__ int clip_bin(float q, int n)
+{
+    // np.array(np.floor(x), dtype=int) then clip to [0, n-1]   (lut.py:336-341)
+    float fl = floorf(q);
+    int i;
+    if (!(fl == fl)) i = 0;                       // NaN -> INT_MIN -> clipped to 0
+    else if (fl >= 2147483648.0f) i = n - 1;
+    else if (fl <= -2147483648.0f) i = 0;
+    else i = (int)fl;
+    return min(max(i, 0), n - 1);
+}
+
+__device__ __forceinline__ int clip_bin64(double q, int n)
+{
+    double fl = floor(q);
+    int i;
+    if (!(fl == fl)) i = 0;
+    else if (fl >= 2147483648.0) i = n - 1;
+    else if (fl <= -2147483648.0) i = 0;
+    else i = (int)fl;
+    return min(max(i, 0), n - 1);
+}
+
+// wave-aggregated histogram increment: one atomic per distinct key per wave
+__device__ __forceinline__ void wave_count(int *__restrict__ count, int key, bool valid)
+{
+    unsigned long long todo = __ballot(valid);
+    const int lane = lane_id();
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        int k = __shfl(key, leader);
+        unsigned long long m = __ballot(valid && key == k);
+        if (lane == leader) atomicAdd(&count[k], __popcll(m));
+        todo &= ~m;
+    }
+}
+
+// wave-aggregated cursor claim: returns this lane's slot in its bucket
+__device__ __forceinline__ int wave_claim(int *__restrict__ cursor, int key, bool valid)
+{
+    unsigned long long todo = __ballot(valid);
+    const int lane = lane_id();
+    int slot = -1;
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        int k = __shfl(key, leader);
+        unsigned long long m = __ballot(valid && key == k);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[k], __popcll(m));
+        base = __shfl(base, leader);
+        if (valid && key == k) slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+    }
+    return slot;
+}
+
+// float32 power via float64 (rounds to the correctly rounded float32 result in
+// all but ~1e-8 of the cases; numpy's float32 power calls libm powf)
+__device__ __forceinline__ float pow10_f32(float x) { return (float)pow(10.0, (double)x); }
+__device__ __forceinline__ float exp_f32(float x) { return (float)exp((double)x); }
+
+// ---------------------------------------------------------------- classify
+struct ClassifyArgs {
+    float *vals;                 // [n_vars][n_sbg] (QR/QS/QG zeroed in place by melting)
+    const signed char *mask;
+    const float *elev;           // folded
+    float *q_melt;               // [2][n_sbg] QmS_v, QmG_v (float32 values)
+    double *fw_melt;             // [2][n_sbg] fwet_mS, fwet_mG
+    int *key;                    // [n_hydro][n_sbg]
+    double *par;                 // [n_hydro][CPOL_MAX_PAR][n_sbg]
+    int *count;                  // [n_keys]
+    long n_sbg;
+    int with_melting;
+    int var_qr, var_qs, var_qg;
+};
+
+#define CPOL_MAX_PAR 6
+
+__global__ __launch_bounds__(256) void k_classify(HydroSet hs, ClassifyArgs a)
+{
+    const long sbg = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = sbg < a.n_sbg;
+    const long n = a.n_sbg;
+    const long i = in ? sbg : 0;
+    float qms = 0.f, qmg = 0.f;
+    double fws = 0.0, fwg = 0.0;
+    if (a.with_melting && in) {
+        // melting.py:34-83, float32 arithmetic as NumPy evaluates it
+        float qr = a.vals[a.var_qr * n + i], qs = a.vals[a.var_qs * n + i],
+              qg = a.vals[a.var_qg * n + i];
+        float qsg = qs + qg;
+        if (qr > 0.f && qsg > 0.f) {
+            qms = qs + qr * (qs / qsg);
+            qmg = qg + qr * (qg / qsg);
+            if (qms > 0.f || qmg > 0.f) {
+                a.vals[a.var_qr * n + i] = 0.f;
+                a.vals[a.var_qs * n + i] = 0.f;
+                a.vals[a.var_qg * n + i] = 0.f;
+            }
+            fws = (double)(qr * qs / qsg) / (double)qms;
+            fwg = (double)(qr * qg / qsg) / (double)qmg;
+        }
+        a.q_melt[i] = qms;
+        a.q_melt[n + i] = qmg;
+        a.fw_melt[i] = fws;
+        a.fw_melt[n + i] = fwg;
+    }
+    const float e = in ? a.elev[i] : 0.f;
+    for (int j = 0; j < hs.n_hydro; ++j) {
+        const HydroDev &h = hs.h[j];
+        const cpol_hydro_desc &d = h.d;
+        float qm = 0.f;
+        double fw = 0.0;
+        if (in) {
+            if (d.q_source == CPOL_Q_MODEL) qm = a.vals[d.var_q * n + i];
+            else if (d.q_source == CPOL_Q_MELT_SNOW) { qm = qms; fw = fws; }
+            else { qm = qmg; fw = fwg; }
+        }
+        const bool valid = in && (qm > 0.f);          // NaN -> false (doppler_scatter.py:185)
+        int key = -1;
+        if (valid) {
+            const float T = a.vals[d.var_t * n + i];
+            // lut.py:336-341: float32 arithmetic for float32 queries
+            int eb = clip_bin((e - d.e_lo) / d.e_step, d.n_e);
+            int tb = d.second_axis_f64 ? clip_bin64((fw - (double)d.t_lo) / (double)d.t_step, d.n_t)
+                                       : clip_bin((T - d.t_lo) / d.t_step, d.n_t);
+            key = h.key_base + eb * d.n_t + tb;
+            double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
+            const double q = (double)qm;
+            switch (d.rule) {
+            case CPOL_RULE_RAIN_1MOM:
+            case CPOL_RULE_GRAUPEL_1MOM:
+                P[0] = pow(d.lambda_factor / q, d.lam_exponent);
+                P[n] = 1.0;                                   // N0 folded into pre[]
+                break;
+            case CPOL_RULE_SNOW_1MOM: {
+                // hydrometeors.py:896-899: float32 chain, then float64 from lambda_factor on
+                float n0 = 13.5f * (565000.0f * exp_f32(-0.107f * (T - 273.15f))) / 1000.0f;
+                float an0 = (float)d.a * n0;
+                P[0] = pow((double)an0 * d.lambda_factor / q, d.lam_exponent);
+                P[n] = (double)n0;
+                break; }
+            case CPOL_RULE_TWO_MOMENT: {
+                // hydrometeors.py:231-246
+                const double qn = (double)a.vals[d.var_qn * n + i];
+                double xm = q / (qn + 2.220446049250313e-16);
+                xm = fmin(fmax(xm, d.x_min), d.x_max);
+                double lam = pow(d.lambda_factor * xm, d.lam_exponent);
+                double n0 = (d.nu / d.ntot_factor) * qn * pow(lam, d.n0_exponent);
+                P[0] = lam * d.c_lam;
+                P[n] = n0 * d.c_n0;
+                break; }
+            case CPOL_RULE_ICE_1MOM: {
+                // hydrometeors.py:1277-1299 (float32 polynomials), :1320-1328
+                const float Tc = T - 273.15f;
+                const float n3 = 3.0f;
+                float pa = 5.065339f - 0.062659f * Tc - (float)(3.032362 * 3) + 0.029469f * Tc * n3
+                    - 0.000285f * (Tc * Tc) + (float)(0.312550 * 9) + 0.000204f * (Tc * Tc) * n3
+                    + 0.003199f * Tc * 9.0f - (float)(0.015952 * 27);
+                pa = pow10_f32(pa);
+                float pb = 0.476221f - 0.015896f * Tc + (float)(0.165977 * 3) + 0.007468f * Tc * n3
+                    - 0.000141f * (Tc * Tc) + (float)(0.060366 * 9) + 0.000079f * (Tc * Tc) * n3
+                    + 0.000594f * Tc * 9.0f - (float)(0.003577 * 27);
+                const double qb = q / 3.0;                        // QM / BM_I
+                const double Q2 = pow(qb / (double)pa, (double)(1.0f / pb));
+                double N0 = pow(Q2, 4.0) * pow(q, -3.0);
+                N0 /= 100000.0;
+                P[0] = Q2 / q;                                    // lambda (exponent 1/(b-2) = 1)
+                P[n] = N0;
+                P[2 * n] = q;
+                break; }
+            case CPOL_RULE_MELTING_SNOW:
+            case CPOL_RULE_MELTING_GRAUPEL: {
+                P[0] = q;
+                P[n] = fw;
+                P[2 * n] = pow(d.r_lambda_factor / q, d.r_lam_exponent);   // rain partner
+                // (the dry partner's PSD does not enter get_N, hydrometeors.py:372-390)
+                break; }
+            default: break;
+            }
+        }
+        if (in) a.key[(long)j * n + i] = key;
+        wave_count(a.count, key, valid);
+    }
+}
+
+// ---------------------------------------------------------------- bucket scan
+// single block: exclusive scan of the bucket counts -> offsets / cursors, and
+// the list of 64-item work units per hydrometeor.
+struct ScanArgs {
+    const int *count;
+    int *offset;                // [n_keys]
+    int *cursor;                // [n_keys]
+    WorkUnit *units;            // capacity >= n_items/64 + n_keys
+    int *unit_range;            // [n_hydro][2]
+    long long *totals;          // [0] = n_valid items, [1] = n_units
+    int n_keys;
+};
+
+__global__ __launch_bounds__(1024) void k_bucket_scan(HydroSet hs, ScanArgs a)
+{
+    __shared__ int s_items[1024];
+    __shared__ int s_units[1024];
+    const int t = threadIdx.x;
+    const int per = (a.n_keys + 1023) / 1024;
+    const int k0 = t * per, k1 = min(k0 + per, a.n_keys);
+    int items = 0, units = 0;
+    for (int k = k0; k < k1; ++k) {
+        int c = a.count[k];
+        items += c;
+        units += (c + 63) >> 6;
+    }
+    s_items[t] = items;
+    s_units[t] = units;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int off = 1; off < 1024; off <<= 1) {
+        int vi = 0, vu = 0;
+        if (t >= off) { vi = s_items[t - off]; vu = s_units[t - off]; }
+        __syncthreads();
+        s_items[t] += vi;
+        s_units[t] += vu;
+        __syncthreads();
+    }
+    int ibase = s_items[t] - items, ubase = s_units[t] - units;
+    for (int k = k0; k < k1; ++k) {
+        int c = a.count[k];
+        a.offset[k] = ibase;
+        a.cursor[k] = ibase;
+        for (int u = 0; u < ((c + 63) >> 6); ++u) {
+            WorkUnit w;
+            w.key = k;
+            w.start = ibase + u * 64;
+            w.count = min(64, c - u * 64);
+            w.pad = 0;
+            a.units[ubase + u] = w;
+        }
+        // unit ranges per hydrometeor (keys are grouped by hydrometeor)
+        for (int j = 0; j < hs.n_hydro; ++j) {
+            if (k == hs.h[j].key_base) a.unit_range[2 * j] = ubase;
+            int last = (j + 1 < hs.n_hydro ? hs.h[j + 1].key_base : hs.n_keys) - 1;
+            if (k == last) a.unit_range[2 * j + 1] = ubase + ((c + 63) >> 6);
+        }
+        ibase += c;
+        ubase += (c + 63) >> 6;
+    }
+    if (t == 1023) { a.totals[0] = s_items[1023]; a.totals[1] = s_units[1023]; }
+}
+
+// scatter item ids into bucket order: perm[slot] = sbg (per hydrometeor key space)
+__global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ key,
+                                                         int *__restrict__ cursor,
+                                                         int *__restrict__ perm,
+                                                         long n_sbg, int n_hydro)
+{
+    const long sbg = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = sbg < n_sbg;
+    for (int j = 0; j < n_hydro; ++j) {
+        int k = in ? key[(long)j * n_sbg + sbg] : -1;
+        bool valid = k >= 0;
+        int slot = wave_claim(cursor, k, valid);
+        if (valid) perm[slot] = (int)sbg;
+    }
+}
+
+// ---------------------------------------------------------------- PSD x LUT
+struct PsdArgs {
+    const WorkUnit *units;
+    const int *unit_range;      // [n_hydro][2]
+    const int *perm;
+    const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg]
+    double *res;                // [n_hydro][n_sbg][12]   sum_k sz[k][c] N[k] * dD
+    long n_sbg;
+    int j;                      // hydrometeor slot
+};
+
+// Generalised gamma family: N(D_k) = (N0 * pre[k]) * exp(-(lambda * dnu[k]))
+// (hydrometeors.py:143-147; pre/dnu hold D^mu (x N0 for fixed intercepts) and
+// D^nu exactly as NumPy evaluates them on the float32 LUT diameter axis).
+__global__ __launch_bounds__(256) void k_psd_gamma(HydroDev h, PsdArgs a)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    const int ubeg = a.unit_range[2 * a.j], uend = a.unit_range[2 * a.j + 1];
+    if (ubeg + wave >= uend) return;                       // wave-uniform
+    const WorkUnit *up = a.units + (ubeg + wave);
+    const int key = __builtin_amdgcn_readfirstlane(up->key);
+    const int start = __builtin_amdgcn_readfirstlane(up->start);
+    const int count = __builtin_amdgcn_readfirstlane(up->count);
+    const int n_d = h.d.n_d;
+    const bool active = lane < count;
+    const long n = a.n_sbg;
+    const int sbg = a.perm[start + (active ? lane : 0)];
+    const double *P = a.par + ((long)a.j * CPOL_MAX_PAR) * n + sbg;
+    const double lam = active ? P[0] : 0.0;
+    const double N0 = active ? P[n] : 0.0;
+    const double *__restrict__ slice = h.table + (long)(key - h.key_base) * n_d * CPOL_N_SZ;
+    const double *__restrict__ pre = h.pre;
+    const double *__restrict__ dnu = h.dnu;
+    double acc[CPOL_N_SZ];
+#pragma unroll
+    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = 0.0;
+#pragma unroll 2
+    for (int k = 0; k < n_d; ++k) {
+        const double nk = (N0 * pre[k]) * exp(-(lam * dnu[k]));
+        const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
+    }
+    if (active) {
+        double *o = a.res + ((long)a.j * n + sbg) * CPOL_N_SZ;
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) o[c] = acc[c] * h.d.dD;
+    }
+}
+
+// 1-moment ice crystals (Field et al. 2005 double-moment normalised PSD):
+//   aux[0..n_d)      D of the LUT axis (float64 of float32)
+//   aux[n_d..2n_d)   D of the normalisation grid  (hydrometeors.py:1331)
+//   aux[2n_d..3n_d)  a * D^b on the normalisation grid
+//   aux[3n_d]        dD of the normalisation grid
+__device__ __forceinline__ double phi23(double x)
+{
+    return 490.6 * exp(-20.78 * x) + 17.46 * pow(x, 0.6357) * exp(-3.290 * x);
+}
+
+__global__ __launch_bounds__(256) void k_psd_ice(HydroDev h, PsdArgs a)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    const int ubeg = a.unit_range[2 * a.j], uend = a.unit_range[2 * a.j + 1];
+    if (ubeg + wave >= uend) return;
+    const WorkUnit *up = a.units + (ubeg + wave);
+    const int key = __builtin_amdgcn_readfirstlane(up->key);
+    const int start = __builtin_amdgcn_readfirstlane(up->start);
+    const int count = __builtin_amdgcn_readfirstlane(up->count);
+    const int n_d = h.d.n_d;
+    const bool active = lane < count;
+    const long n = a.n_sbg;
+    const int sbg = a.perm[start + (active ? lane : 0)];
+    const double *P = a.par + ((long)a.j * CPOL_MAX_PAR) * n + sbg;
+    const double lam = active ? P[0] : 1.0;
+    const double N0 = active ? P[n] : 0.0;
+    const double QM = active ? P[2 * n] : 0.0;
+    const double *__restrict__ slice = h.table + (long)(key - h.key_base) * n_d * CPOL_N_SZ;
+    const double *__restrict__ Dl = h.aux;
+    const double *__restrict__ Dn = h.aux + n_d;
+    const double *__restrict__ aDb = h.aux + 2 * n_d;
+    const double dDn = h.aux[3 * n_d];
+    double acc[CPOL_N_SZ];
+#pragma unroll
+    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = 0.0;
+    double msum = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < n_d; ++k) {
+        const double xn = lam * Dn[k] / 1000.0;
+        msum += aDb[k] * (N0 * phi23(xn));                  // hydrometeors.py:1333-1337
+        const double xl = lam * Dl[k] / 1000.0;
+        const double ph = phi23(xl);
+        const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], ph, acc[c]);
+    }
+    if (active) {
+        const double qm_est = msum * dDn;
+        const double n0c = N0 / qm_est * QM;                // hydrometeors.py:1339
+        double *o = a.res + ((long)a.j * n + sbg) * CPOL_N_SZ;
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) o[c] = (n0c * acc[c]) * h.d.dD;
+    }
+}
+
+// Melting snow / graupel (hydrometeors.py:333-478): per-item diameter grid.
+struct MeltItem {
+    double fw, fw2, phi;        // wet fraction, fw^2, Frick et al. velocity weight
+    double lam_r;
+};
+
+__device__ __forceinline__ double powb(double x, double b)
+{
+    return (b == 2.0) ? x * x : pow(x, b);                  // NumPy: x**2 -> square
+}
+
+__device__ __forceinline__ double melt_mass(const cpol_hydro_desc &d, const MeltItem &it, double D,
+                                            double D3)
+{
+    // hydrometeors.py:404-412 ; D3 = D**3 (shared with the volume)
+    return it.fw2 * (d.r_a * D3) + (1.0 - it.fw2) * (d.a * powb(D, d.b));
+}
+
+__device__ __forceinline__ double melt_Dr(const cpol_hydro_desc &d, const MeltItem &it, double D)
+{
+    // hydrometeors.py:382-383
+    const double D3 = pow(D, 3.0);
+    const double rho = melt_mass(d, it, D, D3) / (3.14159265358979323846 / 6 * D3);
+    return pow(rho / 1.0e-6, 1.0 / 3.0) * D;               // RHO_W = 1000/1000^3 kg mm-3
+}
+
+__global__ __launch_bounds__(256) void k_psd_melting(HydroDev h, PsdArgs a)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    const int ubeg = a.unit_range[2 * a.j], uend = a.unit_range[2 * a.j + 1];
+    if (ubeg + wave >= uend) return;
+    const WorkUnit *up = a.units + (ubeg + wave);
+    const int key = __builtin_amdgcn_readfirstlane(up->key);
+    const int start = __builtin_amdgcn_readfirstlane(up->start);
+    const int count = __builtin_amdgcn_readfirstlane(up->count);
+    const cpol_hydro_desc &d = h.d;
+    const int n_d = d.n_d;
+    const bool active = lane < count;
+    const long n = a.n_sbg;
+    const int sbg = a.perm[start + (active ? lane : 0)];
+    const double *P = a.par + ((long)a.j * CPOL_MAX_PAR) * n + sbg;
+    const double q = active ? P[0] : 1.0;
+    MeltItem it;
+    it.fw = active ? P[n] : 0.5;
+    it.lam_r = active ? P[2 * n] : 1.0;
+    it.fw2 = it.fw * it.fw;
+    it.phi = 0.246 * it.fw + (1 - 0.246) * pow(it.fw, 7.0);
+    // hydrometeors.py:336-339 and utilities.py:158-173 (vlinspace)
+    const double d_max = it.fw * d.r_dmax + (1 - it.fw) * d.s_dmax;
+    const double d_min = it.fw * d.r_dmin + (1 - it.fw) * d.s_dmin;
+    const double step = (d_max - d_min) / (double)(n_d - 1);
+    const double dD = (d_min + step * 1.0) - (d_min + step * 0.0);
+    const double *__restrict__ slice = h.table + (long)(key - h.key_base) * n_d * CPOL_N_SZ;
+    double acc[CPOL_N_SZ];
+#pragma unroll
+    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = 0.0;
+    double msum = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < n_d; ++k) {
+        const double D = d_min + step * (double)k;
+        const double D3 = pow(D, 3.0);
+        const double M = melt_mass(d, it, D, D3);
+        const double rho = M / (3.14159265358979323846 / 6 * D3);
+        const double Dr = pow(rho / 1.0e-6, 1.0 / 3.0) * D;
+        const double dDr = (melt_Dr(d, it, D + 0.01) - Dr) / 0.01;          // :384
+        const double sq = sqrt(Dr);
+        const double Nr = (d.r_n0 * sq) * exp(-(it.lam_r * Dr));           // rain N(D_r)
+        const double Vr = d.r_alpha * sq;                                  // rain V(D_r)
+        const double Vd = d.alpha * pow(D, d.beta);
+        const double V = it.phi * Vr + (1 - it.phi) * Vd;                  // :431-439
+        const double Nraw = Nr * Vr / V * dDr;                             // :386-387
+        msum += Nraw * M;                                                  // :478
+        const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], Nraw, acc[c]);
+    }
+    if (active) {
+        const double prop = q / (msum * dD);                               // :1428
+        double *o = a.res + ((long)a.j * n + sbg) * CPOL_N_SZ;
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) o[c] = (prop * acc[c]) * dD;
+    }
+}

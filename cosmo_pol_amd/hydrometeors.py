@@ -1,0 +1,152 @@
+"""Host-side hydrometeor descriptions staged next to each scattering table.
+
+The per-gate microphysics (PSD parameters, N(D), the PSD integral) runs in the
+HIP kernels of csrc/cpol_psd.inl.  What is evaluated here, once per staged
+table, are the per-diameter-bin factors that do not depend on the gate, with
+the very NumPy expressions (operand kinds and order) the reference evaluates
+per call, so that dtype promotion and rounding are identical:
+
+  D**mu (x N0 for fixed intercepts), D**nu   hydrometeors/hydrometeors.py:143-147
+  ice normalisation grid, a*D**b             hydrometeors/hydrometeors.py:1331-1337
+  axes limits / steps of the table           lookup/lut.py:193-213, 336-341
+  hydrometeor list and its order             scatter/doppler_scatter.py:99-106
+  d_min / d_max taken from the table axis    scatter/doppler_scatter.py:116-122
+"""
+import numpy as np
+
+from . import _native as N
+from . import constants as K
+
+BASE_VARIABLES = ['U', 'V', 'W', 'QR_v', 'QS_v', 'QG_v', 'QI_v', 'RHO', 'T']
+BASE_VARIABLES_2MOM = ['QH_v', 'QNH_v', 'QNR_v', 'QNS_v', 'QNG_v', 'QNI_v']
+
+
+def hydrometeor_list(config):
+    """Order of doppler_scatter.py:99-106 (melting species right after R,S,G)."""
+    mp = config['microphysics']
+    h = ['R', 'S', 'G']
+    if mp['with_melting']:
+        h += ['mS', 'mG']
+    if mp['scheme'] == '2mom':
+        h += ['H']
+    if mp['with_ice_crystals']:
+        h += ['I']
+    return h
+
+
+def variable_list(config):
+    v = list(BASE_VARIABLES)
+    if config['microphysics']['scheme'] == '2mom':
+        v += BASE_VARIABLES_2MOM
+    return v
+
+
+def _consts(h, scheme):
+    c = K.C1 if (scheme == '1mom' and h != 'H') else K.C2
+    g = lambda name: getattr(c, name + '_' + h)
+    nu = g('NU') if c is K.C2 else (1.0 if h == 'R' else 1)
+    return dict(a=g('AM'), b=g('BM'), alpha=g('AV'), beta=g('BV'), mu=g('MU'), nu=nu,
+                lambda_factor=g('LAMBDA_FACTOR'), ntot_factor=g('NTOT_FACTOR'),
+                vel_factor=g('VEL_FACTOR'), d_min=g('D_MIN'), d_max=g('D_MAX'),
+                x_min=getattr(c, 'X_MIN_' + h, 0.0), x_max=getattr(c, 'X_MAX_' + h, 0.0))
+
+
+def build_hydro(h, scheme, lut, var_index):
+    """-> (HydroDesc, table float64 [n_e,n_t,n_d,12], pre, dnu, aux)"""
+    d = N.HydroDesc()
+    table = np.ascontiguousarray(lut.value_table, dtype=np.float64)
+    n_e, n_t, n_d, n_c = table.shape
+    if n_c != N.N_SZ:
+        raise ValueError('lookup table of %s has %d columns, expected 12' % (h, n_c))
+    d.n_e, d.n_t, d.n_d = n_e, n_t, n_d
+    ax_e = lut.axes_names['e']
+    second = 'wc' if h in ('mS', 'mG') else 't'
+    ax_t = lut.axes_names[second]
+    d.e_lo = np.float32(lut.axes_limits[ax_e][0])
+    d.e_step = np.float32(lut.axes_step[ax_e])
+    d.t_lo = np.float32(lut.axes_limits[ax_t][0])
+    d.t_step = np.float32(lut.axes_step[ax_t])
+    d.second_axis_f64 = 1 if h in ('mS', 'mG') else 0
+    d.var_t = var_index['T']
+    d.var_qn = -1
+    d.var_q = -1
+    pre = dnu = aux = None
+
+    if h in ('mS', 'mG'):
+        solid = 'S' if h == 'mS' else 'G'
+        if scheme != '1mom':
+            raise NotImplementedError('melting hydrometeors exist in the 1-moment scheme only')
+        cs, cr = _consts(solid, '1mom'), _consts('R', '1mom')
+        d.psd_family = N.PSD_MELTING
+        d.rule = N.RULE_MELTING_SNOW if h == 'mS' else N.RULE_MELTING_GRAUPEL
+        d.solid_rule = N.RULE_SNOW_1MOM if h == 'mS' else N.RULE_GRAUPEL_1MOM
+        d.q_source = N.Q_MELT_SNOW if h == 'mS' else N.Q_MELT_GRAUPEL
+        d.a, d.b, d.alpha, d.beta = cs['a'], cs['b'], cs['alpha'], cs['beta']
+        d.mu, d.nu = cs['mu'], float(cs['nu'])
+        d.lambda_factor = cs['lambda_factor']
+        d.lam_exponent = (1. / (cs['b'] + 1)) if solid == 'S' else (1. / (4. + cs['mu']))
+        d.n0_fixed = K.C1.N0_G if solid == 'G' else 0.0
+        d.r_a, d.r_b, d.r_alpha, d.r_beta = cr['a'], cr['b'], cr['alpha'], cr['beta']
+        d.r_n0, d.r_mu = K.C1.N0_R, cr['mu']
+        d.r_lambda_factor = cr['lambda_factor']
+        d.r_lam_exponent = 1. / (4. + cr['mu'])
+        # the melting classes own fresh Rain/Snow/Graupel partners whose d_min/d_max
+        # are the module constants, not the table axis (hydrometeors.py:325-339)
+        d.r_dmin, d.r_dmax = cr['d_min'], cr['d_max']
+        d.s_dmin, d.s_dmax = cs['d_min'], cs['d_max']
+        d.dD = 0.0
+        return d, table, None, None, None
+
+    c = _consts(h, scheme)
+    D = np.asarray(lut.axes[lut.axes_names['d']])          # float32 [n_d]
+    if D.ndim != 1 or D.shape[0] != n_d:
+        raise ValueError('diameter axis of %s has shape %s' % (h, D.shape))
+    d.dD = float(D[1] - D[0])                               # np.float32 difference
+    d.a, d.b, d.alpha, d.beta = c['a'], c['b'], c['alpha'], c['beta']
+    d.mu, d.nu = c['mu'], float(c['nu'])
+    d.lambda_factor, d.ntot_factor, d.vel_factor = (c['lambda_factor'], c['ntot_factor'],
+                                                    c['vel_factor'])
+    d.q_source = N.Q_MODEL
+    d.var_q = var_index['Q' + h + '_v']
+
+    if scheme == '1mom' and h == 'I':
+        d.psd_family = N.PSD_ICE_FIELD
+        d.rule = N.RULE_ICE_1MOM
+        # normalisation grid: np.linspace(d_min, d_max, nbins) with d_min/d_max the
+        # float32 end points of the table axis (doppler_scatter.py:117-122)
+        Dn = np.linspace(D[0], D[-1], n_d)
+        aDb = c['a'] * Dn ** c['b']
+        dDn = Dn[1] - Dn[0]
+        aux = np.concatenate([D.astype(np.float64), np.asarray(Dn, dtype=np.float64),
+                              np.asarray(aDb, dtype=np.float64), [np.float64(dDn)]])
+        return d, table, None, None, aux
+
+    d.psd_family = N.PSD_GAMMA
+    mu, nu = c['mu'], c['nu']
+    dnu = np.asarray(D ** nu, dtype=np.float64)
+    if scheme == '2mom':
+        d.rule = N.RULE_TWO_MOMENT
+        d.var_qn = var_index['QN' + h + '_v']
+        d.x_min, d.x_max = c['x_min'], c['x_max']
+        d.lam_exponent = -nu / c['b']
+        d.n0_exponent = (mu + 1) / nu
+        d.c_n0 = 1000 ** (-(1 + mu))
+        d.c_lam = 1000 ** (-nu)
+        pre = np.asarray(D ** mu, dtype=np.float64)
+    elif h == 'R':
+        d.rule = N.RULE_RAIN_1MOM
+        d.lam_exponent = 1. / (4. + mu)
+        d.n0_fixed = K.C1.N0_R
+        pre = np.asarray(K.C1.N0_R * D ** mu, dtype=np.float64)     # np.float64 * float32
+    elif h == 'G':
+        d.rule = N.RULE_GRAUPEL_1MOM
+        d.lam_exponent = 1. / (4. + mu)                               # quirk Q2
+        d.n0_fixed = K.C1.N0_G
+        pre = np.asarray(K.C1.N0_G * D ** mu, dtype=np.float64)     # python float * float32
+    elif h == 'S':
+        d.rule = N.RULE_SNOW_1MOM
+        d.lam_exponent = 1. / (c['b'] + 1)
+        pre = np.asarray(D ** mu, dtype=np.float64)
+    else:
+        raise ValueError('hydrometeor %s does not exist in the %s scheme' % (h, scheme))
+    return d, table, pre, dnu, aux

@@ -117,7 +117,7 @@ def load_lut(filename):
             name = member.name.replace('.npy', '')
             data = np.load(buf, allow_pickle=True, encoding='latin1')
             if name == 'axes_names':
-                data = data.all()
+                data = data.item()      # 0-d object array holding the dict
             setattr(lut, name, data)
     lut.axes_len = list(np.shape(lut.value_table))
     return lut

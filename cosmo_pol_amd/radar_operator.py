@@ -1,0 +1,382 @@
+"""RadarOperator: the reference's user-facing API over the HIP hot path.
+
+Same constructor, properties and scan methods as cosmo_pol/radar_operator.py:46
+(`RadarOperator(options_file, output_variables)`, `.config` getter/setter,
+`set_lut`, `load_model_file`, `get_PPI`, `get_RHI`, `get_VPROF`,
+`get_GPM_swath`, `get_pos_and_time`, `close`).  The body of the reference's scan
+loop (one `pool.map` task per radial, radar_operator.py:407-432) is replaced by
+ONE call into libcosmo_pol_hip.so per sweep; there is no CPU path.
+
+Keyword-only extras: `device`, `lut_dir`, `luts` (pre-built tables),
+`load_model_arrays(...)` (pycosmo / GRIB are not available here).
+"""
+import copy
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from . import config as cfg
+from . import constants as K
+from . import geometry as geo
+from . import hydrometeors as hyd
+from .lut import load_all_lut
+
+RADAR_FIELDS = ['ZH', 'ZDR', 'ZV', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V']
+_DB_FIELDS = ('ZDR', 'ZV', 'ZH')
+
+
+class ModelVar(object):
+    """Duck type of a pycosmo variable (what interpolation.py:547-561 reads)."""
+
+    def __init__(self, name, data, attributes):
+        self.name = name
+        self.data = data
+        self.attributes = attributes
+
+
+class RadarScan(object):
+    """Light stand-in for PyartRadop (cosmo_pol/radar/pyart_wrapper.py:186-342):
+    same field names and conventions (ZH, ZV, ZDR in dB with 0 -> NaN, masked
+    where NaN, extra 'Latitude', 'Longitude', 'rangearray' fields, one entry of
+    sweep_start/stop_ray_index per sweep)."""
+
+    def __init__(self, scan_type, elevations, azimuths, ranges, pos_time, sweeps):
+        self.scan_type = scan_type
+        self.nsweeps = len(sweeps)
+        self.range = {'data': np.asarray(ranges)}
+        self.latitude = {'data': np.array(pos_time['latitude'], dtype=float)}
+        self.longitude = {'data': np.array(pos_time['longitude'], dtype=float)}
+        self.altitude = {'data': np.array(pos_time['altitude'], dtype=float)}
+        self.time = {'data': np.zeros(len(sweeps[0]['azimuth'])),
+                     'units': 'seconds since ' + str(pos_time.get('time'))}
+        self.raw = sweeps                       # linear-unit arrays per sweep
+        az, el, start, stop = [], [], [], []
+        i0 = 0
+        for s in sweeps:
+            n = len(s['azimuth'])
+            az.extend(list(s['azimuth']))
+            el.extend(list(s['elevation']))
+            start.append(i0)
+            stop.append(i0 + n - 1)
+            i0 += n
+        self.azimuth = {'data': np.array(az, dtype=float)}
+        self.elevation = {'data': np.array(el, dtype=float)}
+        self.sweep_start_ray_index = {'data': np.array(start, dtype=float)}
+        self.sweep_stop_ray_index = {'data': np.array(stop, dtype=float)}
+        self.sweep_number = {'data': np.arange(0, self.nsweeps, dtype=float)}
+        self.sweep_mode = {'data': [scan_type] * self.nsweeps}
+        self.fixed_angle = {'data': np.array(elevations if scan_type == 'ppi' else azimuths,
+                                             dtype=float)}
+        self.fields = {}
+        names = list(sweeps[0]['fields'].keys())
+        for k in names:
+            with np.errstate(divide='ignore', invalid='ignore'):
+                stack = np.concatenate([np.array(s['fields'][k], copy=True) for s in sweeps], axis=0)
+                if k in _DB_FIELDS:
+                    stack[stack == 0] = np.nan
+                    stack = 10 * np.log10(stack)
+            self.fields[k] = {'data': np.ma.array(stack, mask=np.isnan(stack))}
+        for k, src in (('Latitude', 'lats'), ('Longitude', 'lons')):
+            stack = np.concatenate([s[src] for s in sweeps], axis=0)
+            self.fields[k] = {'data': np.ma.array(stack, mask=np.isnan(stack)),
+                              'units': ['degrees']}
+        self.fields['rangearray'] = {'data': np.tile(self.range['data'],
+                                                     (len(self.elevation['data']), 1))}
+        self.nrays = len(self.azimuth['data'])
+        self.ngates = len(self.range['data'])
+
+    def get_field(self, sweep_idx, variable):
+        i0 = int(self.sweep_start_ray_index['data'][sweep_idx])
+        i1 = int(self.sweep_stop_ray_index['data'][sweep_idx]) + 1
+        return self.fields[variable]['data'][i0:i1]
+
+
+class RadarOperator(object):
+    def __init__(self, options_file=None, output_variables='all', *, device=0, lut_dir=None,
+                 luts=None, config=None):
+        print('Reading options defined in options file')
+        self._ctx = N.Context(device)         # raises if the HIP library / GPU is missing
+        self.device = device
+        self.lut_dir = lut_dir
+        self._user_luts = luts
+        self.current_microphys_scheme = '1mom'
+        self.dic_vars = None
+        self.N = 0
+        self.lut_sz = None
+        self._model_staged = False
+        self._staged_hydro = None
+        self.constants = None
+        if output_variables in ['all', 'only_model', 'only_radar']:
+            self.output_variables = output_variables
+        else:
+            self.output_variables = 'all'
+            print("Invalid output_variables input, must be either 'all', 'only_model' or "
+                  "'only_radar'")
+        conf = config if config is not None else cfg.init(options_file)
+        self.config = conf
+
+    # ------------------------------------------------------------------ config
+    @property
+    def config(self):
+        return copy.deepcopy(self.__config)
+
+    @config.setter
+    def config(self, config_dic):
+        """Validates, derives constants and (re)loads the lookup tables when the
+        frequency or the melting switch changed (radar_operator.py:106-159)."""
+        if config_dic is None:
+            self.__config = None
+            return
+        print('Loading new configuration...')
+        checked = cfg.sanity_check(config_dic)
+        old = getattr(self, '_RadarOperator__config', None)
+        reload_lut = (old is None or not self.lut_sz
+                      or checked['radar']['frequency'] != old['radar']['frequency']
+                      or checked['microphysics']['with_melting'] != old['microphysics']['with_melting']
+                      or checked['microphysics']['with_ice_crystals'] != old['microphysics']['with_ice_crystals']
+                      or checked['microphysics']['scheme'] != old['microphysics']['scheme'])
+        self.__config = checked
+        self.constants = K.DerivedConstants(checked)
+        if reload_lut:
+            if old is not None:
+                print('Reloading lookup tables...')
+            self.set_lut()
+
+    def close(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+        self.dic_vars = None
+        self.lut_sz = None
+        self.__config = None
+
+    # ------------------------------------------------------------------ tables
+    def set_lut(self):
+        """Loads the scattering tables of the current configuration and stages
+        them (with the per-bin PSD factors) in HBM (radar_operator.py:161-182)."""
+        conf = self.__config
+        scheme = conf['microphysics']['scheme']
+        self.current_microphys_scheme = scheme
+        hl = hyd.hydrometeor_list(conf)
+        if self._user_luts is not None:
+            missing = [h for h in hl if h not in self._user_luts]
+            if missing:
+                raise IOError('no lookup table supplied for hydrometeors %s' % missing)
+            lut = {h: self._user_luts[h] for h in hl}
+        else:
+            lut = load_all_lut(scheme, hl, conf['radar']['frequency'],
+                               conf['microphysics']['scattering'], lut_dir=self.lut_dir)
+        self.lut_sz = lut
+        var_index = {v: i for i, v in enumerate(hyd.variable_list(conf))}
+        for slot, h in enumerate(hl):
+            d, table, pre, dnu, aux = hyd.build_hydro(h, scheme, lut[h], var_index)
+            self._ctx.stage_hydro(slot, d, table, pre, dnu, aux)
+        self._ctx.set_num_hydro(len(hl))
+        self._staged_hydro = hl
+        if self._model_staged and self._staged_vars != hyd.variable_list(conf):
+            self._stage_model()                 # variable set changed (1mom <-> 2mom)
+
+    # ------------------------------------------------------------------ model
+    def load_model_file(self, filename, cfilename=None):
+        """GRIB input needs pycosmo (cosmo_pol/radar_operator.py:217-309), which is
+        not installable in this environment: use load_model_arrays()."""
+        try:
+            import pycosmo  # noqa: F401
+        except ImportError:
+            raise ImportError('load_model_file needs the pycosmo package (GRIB reader); it is '
+                              'not available here. Use RadarOperator.load_model_arrays(data, '
+                              'zlevels, proj_info, resolution) with arrays [nz, ny, nx] instead.')
+        raise NotImplementedError('GRIB decoding is outside the scope of this build '
+                                  '(SURVEY.md 8(f) rank 4)')
+
+    def load_model_arrays(self, data, zlevels, proj_info, resolution, time=None):
+        """data: {name: [nz, ny, nx] float32} with the names of the reference
+        (U, V, W, QR_v, QS_v, QG_v, QI_v, RHO, T [+ QH_v, QN*_v]); zlevels
+        [nz, ny, nx] (level 0 = model top); proj_info with Lo1, La1, Lo2, La2,
+        Latitude_of_southern_pole, Longitude_of_southern_pole; resolution
+        (dlon, dlat)."""
+        two_mom = all(k in data for k in hyd.BASE_VARIABLES_2MOM)
+        missing = [k for k in hyd.BASE_VARIABLES if k not in data]
+        if missing:
+            raise ValueError('Not all necessary variables could be found: missing %s' % missing)
+        scheme = '2mom' if two_mom else '1mom'
+        attrs = {'z-levels': zlevels, 'proj_info': proj_info, 'resolution': resolution,
+                 'time': time}
+        self.dic_vars = {k: ModelVar(k, v, attrs) for k, v in data.items()}
+        self._zlevels = zlevels
+        self._proj = proj_info
+        self._res = resolution
+        if scheme != self.__config['microphysics']['scheme']:
+            print('Using %s scheme' % ('2-moment' if two_mom else '1-moment'))
+            conf = self.config
+            conf['microphysics']['scheme'] = scheme
+            self._model_staged = False
+            self.config = conf
+        self._stage_model()
+
+    def _stage_model(self):
+        conf = self.__config
+        names = hyd.variable_list(conf)
+        p = self._proj
+        llc = np.asarray((float(p['Lo1']), float(p['La1']))).astype('float32')
+        urc = np.asarray((float(p['Lo2']), float(p['La2']))).astype('float32')
+        res = np.asarray(self._res, dtype=np.float32)
+        sp = [float(p['Latitude_of_southern_pole']), float(p['Longitude_of_southern_pole'])]
+        self._ctx.stage_model([self.dic_vars[n].data for n in names], self._zlevels, llc, urc,
+                              res, sp)
+        self._staged_vars = names
+        self._model_staged = True
+
+    def get_pos_and_time(self):
+        c = self.__config['radar']['coords']
+        t = None
+        if self.dic_vars:
+            t = self.dic_vars['T'].attributes.get('time')
+        return {'latitude': c[0], 'longitude': c[1], 'altitude': c[2], 'time': t}
+
+    # ------------------------------------------------------------------ sweeps
+    def _check_ready(self):
+        if not self.dic_vars or not self._model_staged:
+            print('No model file has been loaded! Aborting...')
+            return False
+        return True
+
+    def simulate_rays(self, azimuths, elevations, on_device=False, device_outputs=None,
+                      apply_sensitivity=True):
+        """One batched launch sequence for the given rays (az[i], el[i]).
+        Returns a dict of [n_rays, n_gates] arrays (linear units, NaN = no data).
+        `device_outputs`: optional {field: device pointer} (outputs stay in HBM)."""
+        conf = self.__config
+        az = np.ascontiguousarray(np.asarray(azimuths, dtype=np.float64).reshape(-1))
+        el = np.ascontiguousarray(np.asarray(elevations, dtype=np.float64).reshape(-1))
+        if az.shape != el.shape:
+            raise ValueError('azimuths and elevations must have the same length')
+        if conf['refraction']['scheme'] != 1:
+            raise NotImplementedError('refraction scheme 2 (Zeng & Blahak ODE) is not implemented '
+                                      '(SURVEY.md 8(f) rank 3)')
+        coords = conf['radar']['coords']
+        if coords[2] > K.MAX_MODEL_HEIGHT:
+            raise NotImplementedError('spaceborne geometry: use get_GPM_swath')
+        rr = self.constants.RANGE_RADAR
+        n_rays, n_gates = len(az), len(rr)
+        sub = geo.gauss_hermite_subbeams(conf)
+        traj, geo_t = geo.ray_tables(coords, az, el, sub)
+        re, ke = geo.earth_radius_for_refraction(coords)
+        sin_u1, cos_u1, _ = geo.radar_site_constants(coords)
+
+        p = N.SweepParams()
+        p.n_rays, p.n_gates, p.n_sub = n_rays, n_gates, sub.n_sub
+        p.n_hnodes, p.n_vnodes = len(sub.pts_hor), len(sub.pts_ver)
+        p.with_melting = int(conf['microphysics']['with_melting'])
+        p.with_attenuation = int(conf['microphysics']['with_attenuation'])
+        want_model = self.output_variables in ('all', 'only_model')
+        p.integrate_model = int(want_model)
+        p.outputs_on_device = int(device_outputs is not None)
+        p.simulate_doppler = 0
+        p.radar_lat, p.radar_lon, p.radar_alt = float(coords[0]), float(coords[1]), float(coords[2])
+        p.range0 = float(rr[0])
+        p.range_step = float(conf['radar']['radial_resolution'])
+        p.ke, p.re = ke, re
+        p.sin_u1, p.cos_u1 = sin_u1, cos_u1
+        p.wavelength = float(self.constants.WAVELENGTH)
+        p.k_squared = float(conf['radar']['K_squared'])
+        p.radial_res = float(conf['radar']['radial_resolution'])
+        p.c_zh = float(self.constants.WAVELENGTH ** 4 / (np.pi ** 5 * conf['radar']['K_squared']))
+
+        thr = geo.sensitivity_threshold(conf, self.constants, n_gates) if apply_sensitivity else None
+        p.apply_sensitivity = int(thr is not None)
+        t = N.RayTables()
+        keep = [traj, geo_t, sub.sub_h, sub.sub_v, sub.sub_w, thr]
+        t.traj, t.geo = traj.ctypes.data, geo_t.ctypes.data
+        t.sub_h, t.sub_v, t.sub_w = sub.sub_h.ctypes.data, sub.sub_v.ctypes.data, sub.sub_w.ctypes.data
+        t.sens_thr = thr.ctypes.data if thr is not None else None
+
+        o = N.Outputs()
+        res = {}
+        if device_outputs is not None:
+            for k, ptr in device_outputs.items():
+                setattr(o, k, ptr)
+        else:
+            shape = (n_rays, n_gates)
+            for k in RADAR_FIELDS:
+                res[k] = np.empty(shape, dtype=np.float32)
+            res['mask'] = np.empty(shape, dtype=np.float64)
+            res['lats'] = np.empty(shape, dtype=np.float64)
+            res['lons'] = np.empty(shape, dtype=np.float64)
+            res['dist'] = np.empty(shape, dtype=np.float32)
+            res['heights'] = np.empty(shape, dtype=np.float32)
+            if want_model:
+                res['model_vars'] = np.empty((len(self._staged_vars),) + shape, dtype=np.float64)
+            for k, a in res.items():
+                setattr(o, k, a.ctypes.data)
+        self._ctx.run_sweep(p, t, o)
+        del keep
+        res['n_sub'] = sub.n_sub
+        return res
+
+    def _package(self, res, az, el):
+        fields = {}
+        if self.output_variables in ('all', 'only_radar'):
+            for k in RADAR_FIELDS:
+                fields[k] = res[k]
+        if self.output_variables in ('all', 'only_model'):
+            for i, name in enumerate(self._staged_vars):
+                fields[name] = res['model_vars'][i]
+        return {'fields': fields, 'azimuth': np.asarray(az, dtype=float),
+                'elevation': np.asarray(el, dtype=float), 'lats': res['lats'],
+                'lons': res['lons'], 'mask': res['mask'], 'dist': res['dist'],
+                'heights': res['heights']}
+
+    def get_PPI(self, elevations, azimuths=None, az_step=None, az_start=0, az_stop=359):
+        """Simulates PPI scan(s) (radar_operator.py:357-453); one sweep per
+        elevation, returned as a RadarScan."""
+        if not self._check_ready():
+            return
+        if np.isscalar(elevations):
+            elevations = [elevations]
+        if az_step is None:
+            az_step = self.__config['radar']['3dB_beamwidth']
+        if azimuths is None or np.any(np.equal(azimuths, None)):
+            if az_start > az_stop:
+                azimuths = np.hstack((np.arange(az_start, 360., az_step),
+                                      np.arange(0, az_stop + az_step, az_step)))
+            else:
+                azimuths = np.arange(az_start, az_stop + az_step, az_step)
+        azimuths = np.asarray(azimuths, dtype=float)
+        sweeps = []
+        for e in elevations:
+            el = np.full(len(azimuths), float(e))
+            sweeps.append(self._package(self.simulate_rays(azimuths, el), azimuths, el))
+        return RadarScan('ppi', list(elevations), list(azimuths), self.constants.RANGE_RADAR,
+                         self.get_pos_and_time(), sweeps)
+
+    def get_RHI(self, azimuths, elevations=None, elev_step=None, elev_start=0, elev_stop=90):
+        """Simulates RHI scan(s) (radar_operator.py:455-549); one sweep per azimuth."""
+        if not self._check_ready():
+            return
+        if np.isscalar(azimuths):
+            azimuths = [azimuths]
+        if elevations is None or np.any(np.equal(elevations, None)):
+            if elev_step is None:
+                elev_step = self.__config['radar']['3dB_beamwidth']
+            elevations = np.arange(elev_start, elev_stop + elev_step, elev_step)
+        elevations = np.asarray(elevations, dtype=float)
+        sweeps = []
+        for a in azimuths:
+            az = np.full(len(elevations), float(a))
+            sweeps.append(self._package(self.simulate_rays(az, elevations), az, elevations))
+        return RadarScan('rhi', list(elevations), list(azimuths), self.constants.RANGE_RADAR,
+                         self.get_pos_and_time(), sweeps)
+
+    def get_VPROF(self):
+        """90-degree vertical profile (the reference's version is broken as
+        shipped, radar_operator.py:311-354; implemented as a one-ray RHI)."""
+        if not self._check_ready():
+            return
+        return self.get_RHI(azimuths=[0.], elevations=[90.])
+
+    def get_GPM_swath(self, GPM_file, band='Ku'):
+        raise NotImplementedError('GPM swath geometry (SURVEY.md 3.4, config 5) is scheduled '
+                                  'for a later round; the 2-moment microphysics it needs is '
+                                  'available through get_PPI / get_RHI.')

@@ -1,0 +1,210 @@
+/* cosmo_pol_amd.h -- C ABI of the MI355X-native cosmo_pol hot path.
+ *
+ * Shared library: cosmo_pol_amd/csrc/libcosmo_pol_hip.so (hipcc, gfx950).
+ * Plain C: opaque context, raw pointers and sizes, int status codes
+ * (0 = ok, < 0 = error; text via cpol_last_error).  Never throws / aborts.
+ * The caller owns every host buffer; device copies are owned by the context.
+ * A context is NOT thread-safe: one per GPU per process (one process per GPU,
+ * sweeps sharded by rays).
+ *
+ * What each entry point replaces in the reference (wolfidan/cosmo_pol):
+ *
+ *   cpol_stage_model    pycosmo variables handed to the workers through module
+ *                       globals (radar_operator.py:199-215) and re-read for
+ *                       every radial and variable by the SWIG call
+ *                       (interpolation/interpolation.py:584-595)
+ *   cpol_stage_hydro    Lookup_table objects of load_all_lut (lookup/lut.py:
+ *                       27-76) + create_hydrometeor constants
+ *                       (hydrometeors/hydrometeors.py:39, doppler_scatter.py:
+ *                       111-122)
+ *   cpol_interp_points  the native gate kernel itself, same inputs as
+ *                       get_all_radar_pts (interpolation/interpolation_c.c:8)
+ *                       but evaluated for every staged variable in one pass
+ *   cpol_run_sweep      the body of the scan loop: for every radial
+ *                       get_interpolated_radial (interpolation/interpolation.py:
+ *                       91) -> melting (interpolation/melting.py:19) ->
+ *                       get_radar_observables (scatter/doppler_scatter.py:49)
+ *                       -> integrate_radials (interpolation.py:36), and
+ *                       cut_at_sensitivity (doppler_scatter.py:804) for the
+ *                       whole sweep: ONE call per sweep instead of one
+ *                       pool.map task per radial (radar_operator.py:429-432)
+ */
+#ifndef COSMO_POL_AMD_H
+#define COSMO_POL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cpol_ctx cpol_ctx;
+
+enum {
+    CPOL_OK = 0,
+    CPOL_ERR_HIP = -1,          /* a HIP runtime call failed            */
+    CPOL_ERR_ARG = -2,          /* invalid argument / not staged        */
+    CPOL_ERR_DOMAIN = -3,       /* a gate lies outside the model domain
+                                   (reference: IndexError,
+                                   interpolation.py:572-580)            */
+    CPOL_ERR_NOMEM = -4
+};
+
+#define CPOL_MAX_VARS   24
+#define CPOL_MAX_HYDRO  8
+#define CPOL_N_SZ       12      /* columns of a LUT row (compute_lut_sz.py:265-297) */
+
+/* PSD families (how N(D) is evaluated on the device) */
+enum {
+    CPOL_PSD_GAMMA = 0,         /* N0 D^mu exp(-lambda D^nu)   hydrometeors.py:128-147 */
+    CPOL_PSD_ICE_FIELD = 1,     /* 1-moment ice, Field (2005)  hydrometeors.py:1231-1373 */
+    CPOL_PSD_MELTING = 2        /* melting snow / graupel      hydrometeors.py:303-478  */
+};
+
+/* how (lambda, N0) follow from the model moments */
+enum {
+    CPOL_RULE_RAIN_1MOM = 0,    /* hydrometeors.py:747-772   */
+    CPOL_RULE_SNOW_1MOM = 1,    /* hydrometeors.py:879-907   */
+    CPOL_RULE_GRAUPEL_1MOM = 2, /* hydrometeors.py:1025-1049 */
+    CPOL_RULE_TWO_MOMENT = 3,   /* hydrometeors.py:212-256, 1341-1365 */
+    CPOL_RULE_ICE_1MOM = 4,     /* hydrometeors.py:1302-1339 */
+    CPOL_RULE_MELTING_SNOW = 5, /* hydrometeors.py:1398-1434 */
+    CPOL_RULE_MELTING_GRAUPEL = 6 /* hydrometeors.py:1446-1481 */
+};
+
+/* mass source of a hydrometeor slot */
+enum {
+    CPOL_Q_MODEL = 0,           /* a staged model variable (var_q)             */
+    CPOL_Q_MELT_SNOW = 1,       /* QmS_v diagnosed by the melting scheme       */
+    CPOL_Q_MELT_GRAUPEL = 2     /* QmG_v                                       */
+};
+
+typedef struct {
+    int32_t psd_family;         /* CPOL_PSD_*  */
+    int32_t rule;               /* CPOL_RULE_* */
+    int32_t q_source;           /* CPOL_Q_*    */
+    int32_t var_q;              /* staged-variable index of the mass density   */
+    int32_t var_qn;             /* ... of the number density (2-moment) or -1  */
+    int32_t var_t;              /* ... of the temperature                      */
+    int32_t n_e, n_t, n_d;      /* table shape [n_e, n_t, n_d, 12]             */
+    int32_t second_axis_f64;    /* 1: second axis queried with a float64 value
+                                   (wet fraction), 0: float32 (temperature)    */
+    float   e_lo, e_step;       /* axes_limits[0][0], axes_step[0]  (float32)  */
+    float   t_lo, t_step;       /* second axis ('t' or 'wc')        (float32)  */
+    double  dD;                 /* d axis step D[1]-D[0] (as float32 value)    */
+    /* generic power-law / PSD constants (python-float values of the reference) */
+    double  a, b, alpha, beta, mu, nu;
+    double  lambda_factor, ntot_factor, vel_factor;
+    double  n0_fixed;           /* rain / graupel 1-mom intercept (0 if per gate) */
+    double  x_min, x_max;       /* 2-moment mean-mass clip                     */
+    double  c_n0, c_lam;        /* 2-moment unit factors 1000^-(1+mu), 1000^-nu */
+    double  lam_exponent;       /* 1/(4+mu) | 1/(b+1) | -nu/b                  */
+    double  n0_exponent;        /* (mu+1)/nu (2-moment)                        */
+    /* melting species: rain and dry-solid partners                            */
+    double  r_a, r_b, r_alpha, r_beta, r_n0, r_mu, r_lambda_factor, r_lam_exponent;
+    double  r_dmin, r_dmax, s_dmin, s_dmax;
+    int32_t solid_rule;         /* CPOL_RULE_SNOW_1MOM or _GRAUPEL_1MOM        */
+    int32_t pad_;
+} cpol_hydro_desc;
+
+typedef struct {
+    int32_t n_rays, n_gates;
+    int32_t n_sub;              /* kept antenna-quadrature points per radial    */
+    int32_t n_hnodes, n_vnodes; /* distinct horizontal / vertical GH nodes      */
+    int32_t with_melting, with_attenuation;
+    int32_t integrate_model;    /* also return antenna-averaged model variables */
+    int32_t apply_sensitivity;  /* 1: censor with tables->sens_thr (cut_at_sensitivity) */
+    int32_t outputs_on_device;  /* output pointers are device pointers          */
+    int32_t simulate_doppler;   /* Doppler scheme 1 radial velocity (RVEL)      */
+    int32_t pad_;
+    double  radar_lat, radar_lon, radar_alt;
+    double  range0, range_step; /* RANGE_RADAR = range0 + k*range_step          */
+    double  ke, re;             /* 4/3 and the earth radius (host evaluates quirk Q1) */
+    double  sin_u1, cos_u1;     /* reduced latitude of the radar (Vincenty)     */
+    double  wavelength;         /* mm                                           */
+    double  k_squared;
+    double  radial_res;         /* m                                            */
+    double  c_zh;               /* wavelength^4 / (pi^5 K^2)                     */
+} cpol_sweep_params;
+
+/* per-ray host-side tables (cpol_ray_tables fills them) */
+typedef struct {
+    const double *traj;         /* [n_rays][n_vnodes][3] : el_rad, sin el, cos el */
+    const double *geo;          /* [n_rays][n_hnodes][8] : sin a1, cos a1, sigma1,
+                                   sin alpha, b*A, B, C, azimuth_rad            */
+    const int32_t *sub_h;       /* [n_sub] horizontal node of each kept sub-beam */
+    const int32_t *sub_v;       /* [n_sub] vertical node                        */
+    const double *sub_w;        /* [n_sub] quadrature weight                    */
+    const double *sens_thr;     /* [n_gates] dBZ threshold per gate or NULL      */
+} cpol_ray_tables_t;
+
+typedef struct {
+    /* all [n_rays * n_gates]; NULL = not wanted */
+    float  *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *PHIDP, *RHOHV, *ATT_H, *ATT_V;
+    double *RVEL;
+    double *mask;
+    double *lats, *lons;        /* central sub-beam                             */
+    float  *dist, *heights;
+    double *model_vars;         /* [n_vars][n_rays*n_gates] (integrate_model)   */
+    float  *sz_total;           /* [n_rays*n_gates][12]  (debug / parity)       */
+} cpol_outputs;
+
+typedef struct {
+    int64_t n_subbeam_gates;    /* N_sbg                                        */
+    int64_t n_valid_items;      /* N_valid: (sub-beam gate, hydrometeor), QM>0  */
+    int64_t n_gates;            /* output gates                                 */
+    int64_t n_work_units;       /* 64-item wave units of the PSD kernel         */
+    float   ms_traj, ms_interp, ms_classify, ms_bucket, ms_psd, ms_final, ms_total;
+} cpol_counters_t;
+
+int  cpol_create(int device, cpol_ctx **out);
+void cpol_destroy(cpol_ctx *ctx);
+const char *cpol_last_error(cpol_ctx *ctx);
+/* use an externally created hipStream_t (e.g. torch's current stream); NULL = own stream */
+int  cpol_set_stream(cpol_ctx *ctx, void *hip_stream);
+int  cpol_synchronize(cpol_ctx *ctx);
+
+/* data[v] and zlevels: [nz][ny][nx] float32, C order (x = rotated longitude
+ * fastest), level 0 = model top; llc = (Lo1, La1), urc = (Lo2, La2), res =
+ * (dlon, dlat) as float32; south_pole = (lat, lon) of the rotated south pole. */
+int  cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data,
+                      const float *zlevels, int nz, int ny, int nx,
+                      const float llc[2], const float urc[2], const float res[2],
+                      const double south_pole[2]);
+
+/* table: float64 [n_e][n_t][n_d][12]; pre: [n_d] (or NULL) host-evaluated
+ * N0*D^mu | D^mu; dnu: [n_d] D^nu; aux: family-specific per-bin tables. */
+int  cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc,
+                      const double *table, const double *pre, const double *dnu,
+                      const double *aux, int n_aux);
+int  cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro);
+
+/* gate kernel on explicit points: coords [n][2] (rotated lat, lon) float32,
+ * heights [n] float32 -> out [n_vars][n] float32 with the reference's
+ * sentinels (-9999 above the model top, NaN below topography). */
+int  cpol_interp_points(cpol_ctx *ctx, int n, const float *coords, const float *heights,
+                        float *out);
+
+/* fills per-ray tables with libm (C callers); Python callers use numpy */
+int  cpol_ray_tables(const cpol_sweep_params *p, const double *az_deg, const double *el_deg,
+                     const double *pts_h_deg, const double *pts_v_deg,
+                     double *traj_out, double *geo_out);
+
+int  cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tables_t *tables,
+                    cpol_outputs *out);
+
+int  cpol_counters(cpol_ctx *ctx, cpol_counters_t *out);
+int  cpol_enable_timing(cpol_ctx *ctx, int on);
+
+/* debug / parity access to intermediate device buffers of the last sweep:
+ * "sub_values" float32 [n_vars][n_sbg], "sub_mask" int8 [n_sbg], "sub_elev"
+ * float32 [n_sbg], "sub_coords" float32 [n_sbg][2], "item_key" int32
+ * [n_hydro][n_sbg], "sz_integ" float32 [n_rays*n_gates][n_hydro][12],
+ * "traj" float32 [n_rays][n_vnodes][3][n_gates], "item_res" float64
+ * [n_hydro][n_sbg][12].  Returns bytes copied or < 0. */
+int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -86,6 +86,6 @@ def load_lut(filename):
             name = member.name.replace('.npy', '')
             data = np.load(buf, allow_pickle=True, encoding='latin1')
             if name == 'axes_names':
-                data = data.all()
+                data = data.item()      # 0-d object array holding the dict
             setattr(lut, name, data)
     return lut

@@ -1,0 +1,182 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/cosmo_pol_amd.h declares (no compute without a GPU), the ctypes
+structures match the header, and the host-side logic of the product."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header():
+    with open(os.path.join(ROOT, 'include', 'cosmo_pol_amd.h')) as f:
+        return f.read()
+
+
+def test_library_exports_every_declared_symbol():
+    from cosmo_pol_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    declared = set(re.findall(r'\b(cpol_[a-z_]+)\s*\(', _header()))
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof of every struct as gcc sees the header == ctypes mirror."""
+    import subprocess
+    from cosmo_pol_amd import _native as N
+    pairs = [('cpol_hydro_desc', N.HydroDesc), ('cpol_sweep_params', N.SweepParams),
+             ('cpol_ray_tables_t', N.RayTables), ('cpol_outputs', N.Outputs),
+             ('cpol_counters_t', N.Counters)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cosmo_pol_amd.h"',
+             'int main(void){']
+    for cname, cls in pairs:
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines.append('return 0;}')
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = str(tmp_path / 'layout')
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), '-o', exe, str(src)])
+    got = dict(l.split() for l in subprocess.check_output([exe]).decode().splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got['%s.%s' % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a HIP device the product must raise, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    from cosmo_pol_amd import RadarOperator, _native
+    with pytest.raises(_native.NativeError):
+        RadarOperator(config={'radar': {'coords': [46.5, 7.5, 1000.], 'frequency': 5.6}}, luts={})
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'cosmo_pol_amd')
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.inl', '.h')):
+                src = open(os.path.join(dp, fn)).read()
+                assert not re.search(r'^\s*(from|import)\s+(oracle|cosmo_pol_oracle|ref_shim)', src, re.M), fn
+                assert 'interp_twin' not in src and '_ref/' not in src, fn
+
+
+def test_config_defaults_and_validation(capsys):
+    from cosmo_pol_amd import config as cfg
+    c = cfg.sanity_check({'radar': {'coords': [46.0, 7.0, 500], 'frequency': 5.6,
+                                    'radial_resolution': 7}})        # invalid -> default
+    assert c['radar']['radial_resolution'] == 500
+    assert 'Invalid value entered for key: radar/radial_resolution' in capsys.readouterr().out
+    assert c['integration']['nh_GH'] == 3 and c['integration']['nv_GH'] == 9
+    assert c['microphysics']['with_ice_crystals'] == 1 and c['radar']['K_squared'] == 0.93
+    with pytest.raises(ValueError):
+        cfg.sanity_check({'radar': {'frequency': 5.6}})
+    with pytest.raises(ValueError):
+        cfg.sanity_check({'radar': {'coords': [1, 2], 'frequency': 5.6}})
+    c = cfg.sanity_check({'radar': {'coords': [46.0, 7.0, 500], 'frequency': 5.6, 'K_squared': None},
+                          'attenuation': {'correction': 1}})          # unknown section kept
+    assert abs(c['radar']['K_squared'] - 0.9304396232221553) < 1e-15
+    assert c['attenuation'] == {'correction': 1}
+    assert 2.3 in cfg.Range(1.2, 5.3) and 1.9 not in cfg.Range(2.0, 10.0) and 3 not in cfg.Range(1.2, 5.3)
+
+
+def test_reference_option_file_parses():
+    from cosmo_pol_amd import config as cfg
+    yml = os.path.join(ROOT, 'tests', 'golden', 'CH_PPI_like.yml')
+    c = cfg.sanity_check(cfg.init(yml))
+    assert c['radar']['frequency'] == 5.6 and c['radar']['radial_resolution'] == 150
+    assert c['integration']['weight_threshold'] == 0.999 and c['doppler']['scheme'] == 2
+
+
+def test_host_geometry_matches_oracle(golden):
+    """Sub-beam weights / order and per-ray constants of the product's host side
+    against the oracle (which is pinned to the reference's golden vectors)."""
+    from cosmo_pol_amd import config as cfg
+    from cosmo_pol_amd import geometry as geo
+    from cosmo_pol_oracle import beam, geodesy
+    from cosmo_pol_oracle import config as ocfg
+    g = golden('quadrature')
+    for ci in range(6):
+        nh, nv, thr = g['case_%d' % ci]
+        over = {'radar': {'coords': [46.5, 7.5, 1000], 'frequency': 5.6, '3dB_beamwidth': 1.3},
+                'integration': {'nh_GH': int(nh), 'nv_GH': int(nv), 'weight_threshold': float(thr)}}
+        sub = geo.gauss_hermite_subbeams(cfg.sanity_check(over))
+        pts = np.stack([sub.pts_hor[sub.sub_h] + 10.0, sub.pts_ver[sub.sub_v] + 5.0], axis=1)
+        assert np.array_equal(pts, g['pts_%d' % ci])
+        assert np.array_equal(sub.sub_w, g['w_%d' % ci])
+    assert geo.get_earth_radius(7.0) == beam.earth_radius(7.0)
+    conf = cfg.sanity_check({'radar': {'coords': [46.5, 7.5, 1000], 'frequency': 5.6},
+                             'integration': {'nh_GH': 3, 'nv_GH': 3}})
+    sub = geo.gauss_hermite_subbeams(conf)
+    az = np.array([0., 33., 271.5])
+    el = np.array([1., 2., 88.])
+    traj, gt = geo.ray_tables(conf['radar']['coords'], az, el, sub)
+    for r in range(3):
+        for i in range(3):
+            k = geodesy.direct_ray_constants(46.5, 7.5, sub.pts_hor[i] + az[r])
+            exp = [k['sin_a1'], k['cos_a1'], k['sigma1'], k['sin_alpha'], k['bA'], k['B'], k['C']]
+            assert np.array_equal(gt[r, i, :7], np.array(exp, dtype=np.float64))
+        for j in range(3):
+            e = np.deg2rad(sub.pts_ver[j] + el[r])
+            assert np.array_equal(traj[r, j], [e, np.sin(e), np.cos(e)])
+
+
+def test_host_hydro_tables_follow_numpy_promotion():
+    from cosmo_pol_amd import hydrometeors as hyd
+    from cosmo_pol_amd import synthetic
+    from cosmo_pol_amd import constants as K
+    vi = {v: i for i, v in enumerate(hyd.BASE_VARIABLES + hyd.BASE_VARIABLES_2MOM)}
+    lut = synthetic.make_lut('R', 5.6, '1mom', n_e=2, n_t=2)
+    d, table, pre, dnu, aux = hyd.build_hydro('R', '1mom', lut, vi)
+    D = lut.axes[2]
+    assert D.dtype == np.float32 and pre.dtype == np.float64
+    assert np.array_equal(pre, (K.C1.N0_R * np.sqrt(D)).astype(np.float64))
+    assert np.array_equal(dnu, D.astype(np.float64))
+    assert d.dD == float(D[1] - D[0]) and d.n_d == 1024 and d.var_q == vi['QR_v']
+    lut = synthetic.make_lut('G', 5.6, '1mom', n_e=2, n_t=2)
+    d, table, pre, dnu, aux = hyd.build_hydro('G', '1mom', lut, vi)
+    assert np.all(pre == 4000.0)
+    lut = synthetic.make_lut('mS', 5.6, '1mom', n_e=2, n_t=3)
+    d, table, pre, dnu, aux = hyd.build_hydro('mS', '1mom', lut, vi)
+    assert d.second_axis_f64 == 1 and (d.r_dmin, d.r_dmax, d.s_dmin, d.s_dmax) == (0.1, 8, 0.2, 20)
+    assert hyd.hydrometeor_list({'microphysics': {'with_melting': 1, 'scheme': '2mom',
+                                                  'with_ice_crystals': 1}}) == \
+        ['R', 'S', 'G', 'mS', 'mG', 'H', 'I']
+
+
+def test_lut_file_roundtrip(tmp_path):
+    from cosmo_pol_amd import lut as plut
+    from cosmo_pol_amd import synthetic
+    from cosmo_pol_oracle import lut as olut
+    for h in ('R', 'mG'):
+        L = synthetic.make_lut(h, 5.6, '1mom', n_e=3, n_t=4)
+        fn = str(tmp_path / plut.lut_filename(h, 5.6, '1mom'))
+        plut.save_lut(L, fn)
+        for loader in (plut.load_lut, olut.load_lut):     # either side reads the format
+            M = loader(fn)
+            assert np.array_equal(M.value_table, L.value_table)
+            assert M.axes_names == L.axes_names
+            for a, b in zip(M.axes, L.axes):
+                assert np.array_equal(np.asarray(a), np.asarray(b))
+            e = np.array([0.5, 3.9, 77.0], dtype=np.float32)
+            assert np.array_equal(M.lookup_line(e=e), L.lookup_line(e=e))
+    assert os.path.basename(fn) == 'lut_SZ_mG_5_6_1mom.lut'
+    d = tmp_path / 'lut_tmatrix_masc'
+    d.mkdir()
+    plut.save_lut(synthetic.make_lut('R', 5.6, '1mom', n_e=2, n_t=2), str(d / 'lut_SZ_R_5_6_1mom.lut'))
+    out = plut.load_all_lut('1mom', ['R'], 5.6, 'tmatrix_masc', lut_dir=str(tmp_path))
+    assert out['R'].value_table.shape == (2, 2, 1024, 12)
+    with pytest.raises(IOError):
+        plut.load_all_lut('1mom', ['S'], 5.6, 'tmatrix_masc', lut_dir=str(tmp_path))
