@@ -55,8 +55,9 @@ __global__ void k_trajectory(const double *__restrict__ ray_traj,   // [n_rays][
     float *o = traj_out + (long)rv * 3 * n_gates;
     o[g] = (float)s;
     o[n_gates + g] = (float)h;
-    // np.rad2deg on float32: x * (180/pi) evaluated in float32
-    o[2 * n_gates + g] = (float)e * (float)(180.0 / 3.14159265358979323846);
+    // np.rad2deg on float32: x * (180.0f / float(pi)), constant formed in float32
+    const float rad2deg_f = 180.0f / 3.14159265358979323846f;
+    o[2 * n_gates + g] = (float)e * rad2deg_f;
 }
 
 // ---------------------------------------------------------------- gate kernel

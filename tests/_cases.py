@@ -49,7 +49,8 @@ def assert_close_nan(a, b, rtol, atol=0.0, name=''):
     assert np.array_equal(na, nb), '%s: NaN pattern differs at %s' % (name, np.where(na != nb)[0][:10])
     ok = ~na
     err = np.abs(a[ok] - b[ok])
-    tol = atol + rtol * np.abs(b[ok])
+    atol = np.broadcast_to(np.asarray(atol, dtype=np.float64), b.shape)
+    tol = atol[ok] + rtol * np.abs(b[ok])
     bad = err > tol
     assert not bad.any(), '%s: %d/%d exceed tol, worst rel %.3e' % (
         name, bad.sum(), ok.sum(), np.max(err / np.maximum(np.abs(b[ok]), 1e-300)))

@@ -167,7 +167,7 @@ def test_small_ppi_vs_oracle_and_sensitivity():
     over = _cases.gen_golden.radial_case_inputs(name)[0]
     over = {k: dict(v) for k, v in over.items()}
     over['integration'] = {'nh_GH': 3, 'nv_GH': 3, 'weight_threshold': 1.}
-    over['radar']['sensitivity'] = [5., 10000]
+    over['radar']['sensitivity'] = [35., 10000]
     conf = ocfg.make_config(over)
     op = _operator(over, luts, cube, output_variables='only_radar')
     azs = np.arange(0, 360, 15.)
