@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py -- range-gates/s of the cosmo_pol hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): 360-azimuth x 500-gate C-band PPI at 1.0 deg
+elevation, rain + snow + graupel 1-moment, 1 sub-beam, attenuation on, on the
+synthetic COSMO-1-like cube (80 x 774 x 1158) with full-size
+synthetic scattering tables.  A "step" = one complete sweep through the C ABI
+(per-ray tables H2D, all kernels, outputs left in HBM).  With N GPUs every rank
+simulates one such sweep per step (rays sharded by whole sweeps, weak scaling)
+and the output slabs are collected with ONE RCCL all-gather per step.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on
+the library's stream over the timed region (cpol_enable_timing / cpol_counters);
+`cpu_baseline` times the CPU oracle (the restatement of the reference
+algorithm, per radial, un-batched) on a bounded azimuth sample on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+OUT_FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V']
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+LUT_SLICE_BYTES = 1024 * 12 * 4   # B_l per valid item (float32 staging figure)
+
+
+def bench_config(small):
+    rng = 30000 if small else 150000
+    return {'radar': {'coords': [46.5, 7.5, 1000], 'frequency': 5.6, 'range': rng,
+                      'radial_resolution': 300, '3dB_beamwidth': 1., 'K_squared': 0.93,
+                      'type': 'ground', 'sensitivity': [-5, 10000]},
+            'refraction': {'scheme': 1},
+            'integration': {'scheme': 1, 'nh_GH': 1, 'nv_GH': 1, 'weight_threshold': 1.},
+            'doppler': {'scheme': 1},
+            'microphysics': {'scheme': '1mom', 'with_melting': 0, 'with_ice_crystals': 0,
+                             'with_attenuation': 1}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--small', action='store_true', help='small cube / tables (debugging)')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0,
+                    help='budget of the CPU-oracle baseline sample (0 = skip)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    from cosmo_pol_amd import RadarOperator, synthetic
+    conf = bench_config(args.small)
+    hyds = ('R', 'S', 'G')
+    t0 = time.time()
+    if args.small:
+        cube = synthetic.small_test_cube(hydrometeors=hyds)
+        luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
+    else:
+        cube = synthetic.make_cube(hydrometeors=hyds, **synthetic.BENCH_GRID)
+        luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    t_gen = time.time() - t0
+
+    t0 = time.time()
+    op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', device=local_rank)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    op._ctx.synchronize()
+    t_stage = time.time() - t0
+
+    az = np.arange(0, 360, 1.0)
+    el = np.full(len(az), 1.0)
+    n_rays, n_gates = len(az), len(op.constants.RANGE_RADAR)
+    stream = torch.cuda.Stream()
+    op._ctx.set_stream(stream.cuda_stream)
+    slab = torch.empty((len(OUT_FIELDS), n_rays, n_gates), dtype=torch.float32, device='cuda')
+    gathered = (torch.empty((world,) + tuple(slab.shape), dtype=torch.float32, device='cuda')
+                if world > 1 else None)
+    dev_out = {k: slab[i].data_ptr() for i, k in enumerate(OUT_FIELDS)}
+
+    def step():
+        with torch.cuda.stream(stream):
+            op.simulate_rays(az, el, device_outputs=dev_out)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, slab)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    op._ctx.enable_timing(True)          # HIP events around every stage, no extra syncs
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    cnt = op._ctx.counters()             # also surfaces a domain error, if any
+    op._ctx.enable_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    gates_per_step = world * n_rays * n_gates
+    value = gates_per_step * args.steps / elapsed
+
+    # PCIe-inclusive variant (outputs copied to host buffers every step), N = 1 only
+    value_d2h = None
+    if world == 1:
+        op.simulate_rays(az, el)
+        t0 = time.perf_counter()
+        for _ in range(max(3, args.steps // 4)):
+            op.simulate_rays(az, el)
+        value_d2h = n_rays * n_gates * max(3, args.steps // 4) / (time.perf_counter() - t0)
+
+    out = None
+    if rank == 0:
+        n_valid = int(cnt.n_valid_items)
+        n_sbg = int(cnt.n_subbeam_gates)
+        n_vars = len(op._staged_vars)
+        psd_bytes = n_valid * LUT_SLICE_BYTES
+        achieved = psd_bytes / (cnt.ms_psd * 1e-3) / 1e9 if cnt.ms_psd > 0 else None
+        sweep_bytes = (n_sbg * (4 * cube['zlevels'].shape[0] * 4 + n_vars * 8 * 4)
+                       + psd_bytes + n_rays * n_gates * 48)
+        out = {
+            'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '360-azimuth x 500-gate C-band PPI (el 1.0 deg), rain+snow+graupel '
+                                   '1-moment, 1 sub-beam, synthetic %s cube; one such sweep per GPU '
+                                   'per step' % ('x'.join(map(str, cube['zlevels'].shape))),
+                       'rays_per_gpu': n_rays, 'gates_per_ray': n_gates,
+                       'parallelism': 'rays sharded by sweep, 1 all-gather/step' if world > 1 else 'single GPU',
+                       'small': bool(args.small)},
+            'roofline': {'kernel': 'k_psd_gamma (3 launches/sweep: R, S, G)', 'bound': 'hbm',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
+                         'traffic': None,
+                         'algorithmic_bytes_per_sweep_stage': psd_bytes,
+                         'avg_stage_ms': cnt.ms_psd,
+                         'note': 'algorithmic bytes = N_valid x 49152 B (one float32 LUT slice per valid '
+                                 'item, SURVEY 8(d)); slices are shared through the scalar cache / L2, '
+                                 'so frac can exceed 1 -- see DESIGN.md'},
+            'stages_ms': {'trajectory': cnt.ms_traj, 'interp': cnt.ms_interp,
+                          'classify': cnt.ms_classify, 'bucket': cnt.ms_bucket, 'psd': cnt.ms_psd,
+                          'final': cnt.ms_final, 'device_total': cnt.ms_total},
+            'counters': {'n_subbeam_gates': n_sbg, 'n_valid_items': n_valid,
+                         'n_work_units': int(cnt.n_work_units),
+                         'sweep_algorithmic_bytes': sweep_bytes,
+                         'sweep_algorithmic_GBs': sweep_bytes / (cnt.ms_total * 1e-3) / 1e9 if cnt.ms_total else None},
+            'value_with_d2h': value_d2h,
+            'setup_s': {'synthetic_inputs': t_gen, 'stage_to_hbm': t_stage},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out['cpu_baseline'] = cpu_baseline(conf, cube, luts, az, args.cpu_seconds)
+            out['gpu_over_cpu_core'] = value / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    op.close()
+
+
+def cpu_baseline(conf, cube, luts, az, budget_s):
+    """The CPU oracle (restatement of the reference algorithm: per radial,
+    per-variable C gate kernel, float64 LUT gather + einsum) on 1 core."""
+    from cosmo_pol_oracle import beam, scatter
+    from cosmo_pol_oracle import config as ocfg
+    from cosmo_pol_oracle import lut as olut
+    oconf = ocfg.make_config(conf)
+    order = ['U', 'V', 'W', 'QR_v', 'QS_v', 'QG_v', 'QI_v', 'RHO', 'T']
+    oc = beam.ModelCube({n: cube['data'][n] for n in order}, cube['zlevels'], cube['proj_info'],
+                        cube['resolution'], order)
+    ol = {}
+    for h, s in luts.items():
+        L = olut.LookupTable()
+        L.axes, L.axes_names, L.axes_limits, L.axes_step = s.axes, s.axes_names, s.axes_limits, s.axes_step
+        L.value_table = s.value_table
+        ol[h] = L
+    # whole PPIs, azimuth by azimuth like the reference's pool.map tasks, until the
+    # budget is used (at least one full sweep when it fits, never less than 8 radials)
+    n_done, n_gates = 0, 0
+    t0 = time.perf_counter()
+    done = False
+    while not done:
+        for a in az:
+            subs = beam.interpolate_radial(oc, oconf, float(a), 1.0)
+            obs = scatter.radar_observables(subs, ol, oconf)
+            n_done += 1
+            n_gates += len(obs.values['ZH'])
+            if time.perf_counter() - t0 > budget_s and n_done >= 8:
+                done = True
+                break
+    dt = time.perf_counter() - t0
+    return {'value': n_gates / dt, 'unit': 'gates/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d radials (%.2f sweeps of 360 azimuths, in azimuth order), %d gates each, '
+                      'oracle/cosmo_pol_oracle on one host core, %.1f s'
+                      % (n_done, n_done / 360.0, n_gates // max(n_done, 1), dt),
+            'host_cpus': os.cpu_count()}
+
+
+if __name__ == '__main__':
+    os.environ.setdefault('OMP_NUM_THREADS', '1')
+    main()
