@@ -43,7 +43,7 @@ class HydroDesc(C.Structure):
         ('r_lam_exponent', C.c_double),
         ('r_dmin', C.c_double), ('r_dmax', C.c_double), ('s_dmin', C.c_double),
         ('s_dmax', C.c_double),
-        ('solid_rule', C.c_int32), ('pad_', C.c_int32),
+        ('solid_rule', C.c_int32), ('uniform_grid', C.c_int32),
     ]
 
 

@@ -306,6 +306,11 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
         ctx->err = "cpol_stage_hydro: gamma family needs pre[] and dnu[]";
         return CPOL_ERR_ARG;
     }
+    if (desc->psd_family == CPOL_PSD_GAMMA && desc->uniform_grid &&
+        (!aux || n_aux < desc->n_d + 1 || desc->n_d % CPOL_PSD_WAVES != 0)) {
+        ctx->err = "cpol_stage_hydro: uniform_grid needs aux[1 + n_d] and n_d % 8 == 0";
+        return CPOL_ERR_ARG;
+    }
     if (desc->psd_family == CPOL_PSD_ICE_FIELD && (!aux || n_aux < 3 * desc->n_d + 1)) {
         ctx->err = "cpol_stage_hydro: ice family needs aux[3*n_d+1]";
         return CPOL_ERR_ARG;
@@ -533,25 +538,32 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                        n_sbg, n_hyd);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st));
 
-    // ---- 5. PSD x scattering table (one launch per hydrometeor) ----
-    for (int j = 0; j < n_hyd; ++j) {
+    // ---- 5. PSD x scattering table: one launch per kernel flavour present ----
+    {
         PsdArgs pa{};
         pa.units = (const WorkUnit *)ctx->b_units.p;
-        pa.unit_range = (const int *)ctx->b_urange.p;
+        pa.totals = (const long long *)ctx->b_totals.p;
         pa.perm = (const int *)ctx->b_perm.p;
         pa.par = (const double *)ctx->b_par.p;
         pa.res = (double *)ctx->b_res.p;
         pa.n_sbg = n_sbg;
-        pa.j = j;
-        const HydroDev &h = ctx->hs.h[j];
-        const long max_units = n_sbg / 64 + (long)h.d.n_e * h.d.n_t + 1;
-        const dim3 grd(cdiv(max_units, 4)), blk(256);
-        switch (h.d.psd_family) {
-        case CPOL_PSD_GAMMA: hipLaunchKernelGGL(k_psd_gamma, grd, blk, 0, st, h, pa); break;
-        case CPOL_PSD_ICE_FIELD: hipLaunchKernelGGL(k_psd_ice, grd, blk, 0, st, h, pa); break;
-        case CPOL_PSD_MELTING: hipLaunchKernelGGL(k_psd_melting, grd, blk, 0, st, h, pa); break;
-        default: ctx->err = "unknown psd_family"; return CPOL_ERR_ARG;
+        bool need[4] = {false, false, false, false};
+        for (int j = 0; j < n_hyd; ++j) {
+            const cpol_hydro_desc &d = ctx->hs.h[j].d;
+            int mode = d.psd_family == CPOL_PSD_ICE_FIELD ? PSD_MODE_ICE
+                     : d.psd_family == CPOL_PSD_MELTING ? PSD_MODE_MELTING
+                     : d.uniform_grid ? PSD_MODE_GAMMA_UNIFORM : PSD_MODE_GAMMA_EXP;
+            need[mode] = true;
         }
+        const dim3 grd((unsigned)unit_cap), blk(CPOL_PSD_THREADS);
+        if (need[PSD_MODE_GAMMA_UNIFORM])
+            hipLaunchKernelGGL(k_psd<PSD_MODE_GAMMA_UNIFORM>, grd, blk, 0, st, ctx->hs, pa);
+        if (need[PSD_MODE_GAMMA_EXP])
+            hipLaunchKernelGGL(k_psd<PSD_MODE_GAMMA_EXP>, grd, blk, 0, st, ctx->hs, pa);
+        if (need[PSD_MODE_ICE])
+            hipLaunchKernelGGL(k_psd<PSD_MODE_ICE>, grd, blk, 0, st, ctx->hs, pa);
+        if (need[PSD_MODE_MELTING])
+            hipLaunchKernelGGL(k_psd<PSD_MODE_MELTING>, grd, blk, 0, st, ctx->hs, pa);
     }
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
 

@@ -287,110 +287,37 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ 
 }
 
 // ---------------------------------------------------------------- PSD x LUT
+// Work decomposition: one 512-thread workgroup (8 wavefronts) per work unit of
+// up to 64 items that share one LUT slice.  The item sits on the lane; wave w
+// integrates diameter bins [w*n_d/8, (w+1)*n_d/8); the 8 partial sums per
+// (item, column) are combined through LDS in a fixed order (deterministic).
+// All units of all hydrometeors are covered by ONE launch per kernel flavour:
+// a workgroup whose unit belongs to another flavour exits immediately.
+#define CPOL_PSD_WAVES 8
+#define CPOL_PSD_THREADS (CPOL_PSD_WAVES * CPOL_WAVE)
+
+enum { PSD_MODE_GAMMA_EXP = 0, PSD_MODE_GAMMA_UNIFORM = 1, PSD_MODE_ICE = 2, PSD_MODE_MELTING = 3 };
+
 struct PsdArgs {
     const WorkUnit *units;
-    const int *unit_range;      // [n_hydro][2]
+    const long long *totals;    // [1] = number of work units of this sweep
     const int *perm;
     const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg]
     double *res;                // [n_hydro][n_sbg][12]   sum_k sz[k][c] N[k] * dD
     long n_sbg;
-    int j;                      // hydrometeor slot
 };
 
-// Generalised gamma family: N(D_k) = (N0 * pre[k]) * exp(-(lambda * dnu[k]))
-// (hydrometeors.py:143-147; pre/dnu hold D^mu (x N0 for fixed intercepts) and
-// D^nu exactly as NumPy evaluates them on the float32 LUT diameter axis).
-__global__ __launch_bounds__(256) void k_psd_gamma(HydroDev h, PsdArgs a)
+__device__ __forceinline__ int psd_mode_of(const cpol_hydro_desc &d)
 {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = lane_id();
-    const int ubeg = a.unit_range[2 * a.j], uend = a.unit_range[2 * a.j + 1];
-    if (ubeg + wave >= uend) return;                       // wave-uniform
-    const WorkUnit *up = a.units + (ubeg + wave);
-    const int key = __builtin_amdgcn_readfirstlane(up->key);
-    const int start = __builtin_amdgcn_readfirstlane(up->start);
-    const int count = __builtin_amdgcn_readfirstlane(up->count);
-    const int n_d = h.d.n_d;
-    const bool active = lane < count;
-    const long n = a.n_sbg;
-    const int sbg = a.perm[start + (active ? lane : 0)];
-    const double *P = a.par + ((long)a.j * CPOL_MAX_PAR) * n + sbg;
-    const double lam = active ? P[0] : 0.0;
-    const double N0 = active ? P[n] : 0.0;
-    const double *__restrict__ slice = h.table + (long)(key - h.key_base) * n_d * CPOL_N_SZ;
-    const double *__restrict__ pre = h.pre;
-    const double *__restrict__ dnu = h.dnu;
-    double acc[CPOL_N_SZ];
-#pragma unroll
-    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = 0.0;
-#pragma unroll 2
-    for (int k = 0; k < n_d; ++k) {
-        const double nk = (N0 * pre[k]) * exp(-(lam * dnu[k]));
-        const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
-#pragma unroll
-        for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
-    }
-    if (active) {
-        double *o = a.res + ((long)a.j * n + sbg) * CPOL_N_SZ;
-#pragma unroll
-        for (int c = 0; c < CPOL_N_SZ; ++c) o[c] = acc[c] * h.d.dD;
-    }
+    if (d.psd_family == CPOL_PSD_ICE_FIELD) return PSD_MODE_ICE;
+    if (d.psd_family == CPOL_PSD_MELTING) return PSD_MODE_MELTING;
+    return d.uniform_grid ? PSD_MODE_GAMMA_UNIFORM : PSD_MODE_GAMMA_EXP;
 }
 
-// 1-moment ice crystals (Field et al. 2005 double-moment normalised PSD):
-//   aux[0..n_d)      D of the LUT axis (float64 of float32)
-//   aux[n_d..2n_d)   D of the normalisation grid  (hydrometeors.py:1331)
-//   aux[2n_d..3n_d)  a * D^b on the normalisation grid
-//   aux[3n_d]        dD of the normalisation grid
+// 1-moment ice crystals (Field et al. 2005 double-moment normalised PSD)
 __device__ __forceinline__ double phi23(double x)
 {
     return 490.6 * exp(-20.78 * x) + 17.46 * pow(x, 0.6357) * exp(-3.290 * x);
-}
-
-__global__ __launch_bounds__(256) void k_psd_ice(HydroDev h, PsdArgs a)
-{
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = lane_id();
-    const int ubeg = a.unit_range[2 * a.j], uend = a.unit_range[2 * a.j + 1];
-    if (ubeg + wave >= uend) return;
-    const WorkUnit *up = a.units + (ubeg + wave);
-    const int key = __builtin_amdgcn_readfirstlane(up->key);
-    const int start = __builtin_amdgcn_readfirstlane(up->start);
-    const int count = __builtin_amdgcn_readfirstlane(up->count);
-    const int n_d = h.d.n_d;
-    const bool active = lane < count;
-    const long n = a.n_sbg;
-    const int sbg = a.perm[start + (active ? lane : 0)];
-    const double *P = a.par + ((long)a.j * CPOL_MAX_PAR) * n + sbg;
-    const double lam = active ? P[0] : 1.0;
-    const double N0 = active ? P[n] : 0.0;
-    const double QM = active ? P[2 * n] : 0.0;
-    const double *__restrict__ slice = h.table + (long)(key - h.key_base) * n_d * CPOL_N_SZ;
-    const double *__restrict__ Dl = h.aux;
-    const double *__restrict__ Dn = h.aux + n_d;
-    const double *__restrict__ aDb = h.aux + 2 * n_d;
-    const double dDn = h.aux[3 * n_d];
-    double acc[CPOL_N_SZ];
-#pragma unroll
-    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = 0.0;
-    double msum = 0.0;
-#pragma unroll 1
-    for (int k = 0; k < n_d; ++k) {
-        const double xn = lam * Dn[k] / 1000.0;
-        msum += aDb[k] * (N0 * phi23(xn));                  // hydrometeors.py:1333-1337
-        const double xl = lam * Dl[k] / 1000.0;
-        const double ph = phi23(xl);
-        const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
-#pragma unroll
-        for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], ph, acc[c]);
-    }
-    if (active) {
-        const double qm_est = msum * dDn;
-        const double n0c = N0 / qm_est * QM;                // hydrometeors.py:1339
-        double *o = a.res + ((long)a.j * n + sbg) * CPOL_N_SZ;
-#pragma unroll
-        for (int c = 0; c < CPOL_N_SZ; ++c) o[c] = (n0c * acc[c]) * h.d.dD;
-    }
 }
 
 // Melting snow / graupel (hydrometeors.py:333-478): per-item diameter grid.
@@ -419,61 +346,165 @@ __device__ __forceinline__ double melt_Dr(const cpol_hydro_desc &d, const MeltIt
     return pow(rho / 1.0e-6, 1.0 / 3.0) * D;               // RHO_W = 1000/1000^3 kg mm-3
 }
 
-__global__ __launch_bounds__(256) void k_psd_melting(HydroDev h, PsdArgs a)
+template <int MODE>
+__global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a)
 {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = lane_id();
-    const int ubeg = a.unit_range[2 * a.j], uend = a.unit_range[2 * a.j + 1];
-    if (ubeg + wave >= uend) return;
-    const WorkUnit *up = a.units + (ubeg + wave);
+    // [wave][value][lane]; value 12 = normalisation sum (ice, melting)
+    __shared__ double s_part[CPOL_PSD_WAVES][CPOL_N_SZ + 1][CPOL_WAVE];
+    const int u = blockIdx.x;
+    if ((long long)u >= a.totals[1]) return;                // block-uniform
+    const WorkUnit *up = a.units + u;
     const int key = __builtin_amdgcn_readfirstlane(up->key);
     const int start = __builtin_amdgcn_readfirstlane(up->start);
     const int count = __builtin_amdgcn_readfirstlane(up->count);
+    int j = 0;
+    for (int q = 1; q < hs.n_hydro; ++q) if (key >= hs.h[q].key_base) j = q;
+    const HydroDev &h = hs.h[j];
     const cpol_hydro_desc &d = h.d;
+    if (psd_mode_of(d) != MODE) return;                     // block-uniform
+
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n_d = d.n_d;
+    const int chunk = (n_d + CPOL_PSD_WAVES - 1) / CPOL_PSD_WAVES;
+    const int k0 = wave * chunk, k1 = min(k0 + chunk, n_d);
     const bool active = lane < count;
     const long n = a.n_sbg;
     const int sbg = a.perm[start + (active ? lane : 0)];
-    const double *P = a.par + ((long)a.j * CPOL_MAX_PAR) * n + sbg;
-    const double q = active ? P[0] : 1.0;
-    MeltItem it;
-    it.fw = active ? P[n] : 0.5;
-    it.lam_r = active ? P[2 * n] : 1.0;
-    it.fw2 = it.fw * it.fw;
-    it.phi = 0.246 * it.fw + (1 - 0.246) * pow(it.fw, 7.0);
-    // hydrometeors.py:336-339 and utilities.py:158-173 (vlinspace)
-    const double d_max = it.fw * d.r_dmax + (1 - it.fw) * d.s_dmax;
-    const double d_min = it.fw * d.r_dmin + (1 - it.fw) * d.s_dmin;
-    const double step = (d_max - d_min) / (double)(n_d - 1);
-    const double dD = (d_min + step * 1.0) - (d_min + step * 0.0);
+    const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + sbg;
     const double *__restrict__ slice = h.table + (long)(key - h.key_base) * n_d * CPOL_N_SZ;
+
     double acc[CPOL_N_SZ];
 #pragma unroll
     for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = 0.0;
-    double msum = 0.0;
+    double msum = 0.0;       // normalisation integral (ice, melting)
+    double scale = 1.0;      // applied by the combining thread
+
+    if (MODE == PSD_MODE_GAMMA_EXP) {
+        // N(D_k) = (N0 * pre[k]) * exp(-(lambda * dnu[k]))   (hydrometeors.py:143-147;
+        // pre/dnu hold D^mu (x N0 for fixed intercepts) and D^nu exactly as NumPy
+        // evaluates them on the float32 LUT diameter axis)
+        const double lam = active ? P[0] : 0.0;
+        const double N0 = active ? P[n] : 0.0;
+        const double *__restrict__ pre = h.pre;
+        const double *__restrict__ dnu = h.dnu;
+#pragma unroll 2
+        for (int k = k0; k < k1; ++k) {
+            const double nk = (N0 * pre[k]) * exp(-(lam * dnu[k]));
+            const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
+        }
+    } else if (MODE == PSD_MODE_GAMMA_UNIFORM) {
+        // nu == 1 on a (nearly) uniform diameter grid: exp(-lambda D_k) follows from
+        // ONE exp per wave chunk and a geometric recurrence; the float32 rounding of
+        // the grid nodes is restored to second order:
+        //   D_k = D_k0 + (k-k0) h + dlt_k,  exp(-l D_k) = E_k0 r^(k-k0) (1 - x + x^2/2),
+        //   x = l dlt_k, |x| < 2e-5  ->  truncation < 2e-15, drift < 128 ulp(double).
+        const double lam = active ? P[0] : 0.0;
+        const double N0 = active ? P[n] : 0.0;
+        const double *__restrict__ pre = h.pre;
+        const double *__restrict__ dnu = h.dnu;
+        const double *__restrict__ dlt = h.aux + 1;
+        const double hstep = h.aux[0];
+        double A = N0 * exp(-(lam * dnu[k0 < n_d ? k0 : 0]));
+        const double r = exp(-(lam * hstep));
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) {
+            const double x = lam * dlt[k];
+            const double corr = fma(x, fma(x, 0.5, -1.0), 1.0);
+            const double nk = pre[k] * (A * corr);
+            A *= r;
+            const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
+        }
+    } else if (MODE == PSD_MODE_ICE) {
+        //   aux[0..n_d)      D of the LUT axis (float64 of float32)
+        //   aux[n_d..2n_d)   D of the normalisation grid  (hydrometeors.py:1331)
+        //   aux[2n_d..3n_d)  a * D^b on the normalisation grid
+        //   aux[3n_d]        dD of the normalisation grid
+        const double lam = active ? P[0] : 1.0;
+        const double N0 = active ? P[n] : 0.0;
+        const double *__restrict__ Dl = h.aux;
+        const double *__restrict__ Dn = h.aux + n_d;
+        const double *__restrict__ aDb = h.aux + 2 * n_d;
 #pragma unroll 1
-    for (int k = 0; k < n_d; ++k) {
-        const double D = d_min + step * (double)k;
-        const double D3 = pow(D, 3.0);
-        const double M = melt_mass(d, it, D, D3);
-        const double rho = M / (3.14159265358979323846 / 6 * D3);
-        const double Dr = pow(rho / 1.0e-6, 1.0 / 3.0) * D;
-        const double dDr = (melt_Dr(d, it, D + 0.01) - Dr) / 0.01;          // :384
-        const double sq = sqrt(Dr);
-        const double Nr = (d.r_n0 * sq) * exp(-(it.lam_r * Dr));           // rain N(D_r)
-        const double Vr = d.r_alpha * sq;                                  // rain V(D_r)
-        const double Vd = d.alpha * pow(D, d.beta);
-        const double V = it.phi * Vr + (1 - it.phi) * Vd;                  // :431-439
-        const double Nraw = Nr * Vr / V * dDr;                             // :386-387
-        msum += Nraw * M;                                                  // :478
-        const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
+        for (int k = k0; k < k1; ++k) {
+            const double xn = lam * Dn[k] / 1000.0;
+            msum += aDb[k] * (N0 * phi23(xn));              // hydrometeors.py:1333-1337
+            const double xl = lam * Dl[k] / 1000.0;
+            const double ph = phi23(xl);
+            const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
 #pragma unroll
-        for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], Nraw, acc[c]);
+            for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], ph, acc[c]);
+        }
+    } else {
+        MeltItem it;
+        it.fw = active ? P[n] : 0.5;
+        it.lam_r = active ? P[2 * n] : 1.0;
+        it.fw2 = it.fw * it.fw;
+        it.phi = 0.246 * it.fw + (1 - 0.246) * pow(it.fw, 7.0);
+        // hydrometeors.py:336-339 and utilities.py:158-173 (vlinspace)
+        const double d_max = it.fw * d.r_dmax + (1 - it.fw) * d.s_dmax;
+        const double d_min = it.fw * d.r_dmin + (1 - it.fw) * d.s_dmin;
+        const double step = (d_max - d_min) / (double)(n_d - 1);
+#pragma unroll 1
+        for (int k = k0; k < k1; ++k) {
+            const double D = d_min + step * (double)k;
+            const double D3 = pow(D, 3.0);
+            const double M = melt_mass(d, it, D, D3);
+            const double rho = M / (3.14159265358979323846 / 6 * D3);
+            const double Dr = pow(rho / 1.0e-6, 1.0 / 3.0) * D;
+            const double dDr = (melt_Dr(d, it, D + 0.01) - Dr) / 0.01;          // :384
+            const double sq = sqrt(Dr);
+            const double Nr = (d.r_n0 * sq) * exp(-(it.lam_r * Dr));           // rain N(D_r)
+            const double Vr = d.r_alpha * sq;                                  // rain V(D_r)
+            const double Vd = d.alpha * pow(D, d.beta);
+            const double V = it.phi * Vr + (1 - it.phi) * Vd;                  // :431-439
+            const double Nraw = Nr * Vr / V * dDr;                             // :386-387
+            msum += Nraw * M;                                                  // :478
+            const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], Nraw, acc[c]);
+        }
     }
-    if (active) {
-        const double prop = q / (msum * dD);                               // :1428
-        double *o = a.res + ((long)a.j * n + sbg) * CPOL_N_SZ;
+
+    // ---- combine the 8 partial sums per (item, column) in wave order ----
 #pragma unroll
-        for (int c = 0; c < CPOL_N_SZ; ++c) o[c] = (prop * acc[c]) * dD;
+    for (int c = 0; c < CPOL_N_SZ; ++c) s_part[wave][c][lane] = acc[c];
+    if (MODE == PSD_MODE_ICE || MODE == PSD_MODE_MELTING) s_part[wave][CPOL_N_SZ][lane] = msum;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < CPOL_N_SZ * CPOL_WAVE; idx += CPOL_PSD_THREADS) {
+        const int c = idx >> 6, l = idx & 63;
+        if (l >= count) continue;
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < CPOL_PSD_WAVES; ++w) sum += s_part[w][c][l];
+        const int sb = a.perm[start + l];
+        const double *Pl = a.par + ((long)j * CPOL_MAX_PAR) * n + sb;
+        if (MODE == PSD_MODE_ICE) {
+            double m = 0.0;
+#pragma unroll
+            for (int w = 0; w < CPOL_PSD_WAVES; ++w) m += s_part[w][CPOL_N_SZ][l];
+            const double qm_est = m * h.aux[3 * n_d];
+            scale = Pl[n] / qm_est * Pl[2 * n];             // N0 / QM_est * QM (:1339)
+            sum = (scale * sum) * d.dD;
+        } else if (MODE == PSD_MODE_MELTING) {
+            double m = 0.0;
+#pragma unroll
+            for (int w = 0; w < CPOL_PSD_WAVES; ++w) m += s_part[w][CPOL_N_SZ][l];
+            // the item's own grid step (same expression as above, for lane l)
+            const double fw = Pl[n];
+            const double d_max = fw * d.r_dmax + (1 - fw) * d.s_dmax;
+            const double d_min = fw * d.r_dmin + (1 - fw) * d.s_dmin;
+            const double step = (d_max - d_min) / (double)(n_d - 1);
+            const double dDl = (d_min + step * 1.0) - (d_min + step * 0.0);
+            const double prop = Pl[0] / (m * dDl);          // q / integrate_M (:1428)
+            sum = (prop * sum) * dDl;
+        } else {
+            sum = sum * d.dD;
+        }
+        a.res[((long)j * n + sb) * CPOL_N_SZ + c] = sum;
     }
 }

@@ -149,4 +149,31 @@ def build_hydro(h, scheme, lut, var_index):
         pre = np.asarray(D ** mu, dtype=np.float64)
     else:
         raise ValueError('hydrometeor %s does not exist in the %s scheme' % (h, scheme))
+    aux = _uniform_grid_aux(d, D, nu, n_d)
     return d, table, pre, dnu, aux
+
+
+PSD_WAVES = 8        # csrc/cpol_psd.inl: CPOL_PSD_WAVES (bins are split over 8 wavefronts)
+
+
+def _uniform_grid_aux(d, D, nu, n_d):
+    """nu == 1: exp(-lambda D_k) is advanced by a geometric recurrence inside each
+    wave chunk of n_d/8 bins.  aux = [h, dlt_0 .. dlt_{n_d-1}] with h the mean grid
+    step and dlt_k = D_k - D_k0 - (k-k0) h the (float32-rounding sized) departure of
+    node k from the uniform grid anchored at its chunk start k0."""
+    if float(nu) != 1.0 or n_d % PSD_WAVES != 0:
+        d.uniform_grid = 0
+        return None
+    D64 = np.asarray(D, dtype=np.float64)
+    h = (D64[-1] - D64[0]) / (n_d - 1)
+    ch = n_d // PSD_WAVES
+    k = np.arange(n_d)
+    k0 = (k // ch) * ch
+    dlt = D64 - D64[k0] - (k - k0) * h
+    # the second-order correction is accurate to ~|lambda*dlt|^3/6: require a
+    # grid that really is uniform up to float32 rounding
+    if np.max(np.abs(dlt)) > 4e-6 * max(1.0, float(np.max(np.abs(D64)))):
+        d.uniform_grid = 0
+        return None
+    d.uniform_grid = 1
+    return np.concatenate([[h], dlt]).astype(np.float64)

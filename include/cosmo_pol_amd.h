@@ -104,7 +104,8 @@ typedef struct {
     double  r_a, r_b, r_alpha, r_beta, r_n0, r_mu, r_lambda_factor, r_lam_exponent;
     double  r_dmin, r_dmax, s_dmin, s_dmax;
     int32_t solid_rule;         /* CPOL_RULE_SNOW_1MOM or _GRAUPEL_1MOM        */
-    int32_t pad_;
+    int32_t uniform_grid;       /* gamma family, nu == 1: aux[] holds the grid step
+                                   and per-bin offsets for the exp recurrence   */
 } cpol_hydro_desc;
 
 typedef struct {
