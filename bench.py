@@ -96,7 +96,7 @@ def main():
     stream = torch.cuda.Stream()
     op._ctx.set_stream(stream.cuda_stream)
     slab = torch.empty((len(OUT_FIELDS), n_rays, n_gates), dtype=torch.float32, device='cuda')
-    gathered = (torch.empty((world,) + tuple(slab.shape), dtype=torch.float32, device='cuda')
+    gathered = (torch.empty(world * slab.numel(), dtype=torch.float32, device='cuda')
                 if world > 1 else None)
     dev_out = {k: slab[i].data_ptr() for i, k in enumerate(OUT_FIELDS)}
 
@@ -104,7 +104,7 @@ def main():
         with torch.cuda.stream(stream):
             op.simulate_rays(az, el, device_outputs=dev_out)
             if world > 1:
-                dist.all_gather_into_tensor(gathered, slab)
+                dist.all_gather_into_tensor(gathered, slab.view(-1))
 
     def fence():
         torch.cuda.synchronize()

@@ -269,6 +269,10 @@ int cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro)
         base += ctx->hs.h[j].d.n_e * ctx->hs.h[j].d.n_t;
     }
     ctx->hs.n_keys = base;
+    if (base > 1024 * CPOL_SCAN_MAX_PER) {
+        ctx->err = "too many LUT slices (elevation x temperature bins) for the bucket scan";
+        return CPOL_ERR_ARG;
+    }
     return CPOL_OK;
 }
 
@@ -455,7 +459,6 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
 
     HIPCHK(hipMemsetAsync(ctx->b_count.p, 0, (size_t)n_keys * sizeof(int), st));
     HIPCHK(hipMemsetAsync(ctx->b_err.p, 0, sizeof(int), st));
-    HIPCHK(hipMemsetAsync(ctx->b_urange.p, 0, (size_t)2 * CPOL_MAX_HYDRO * sizeof(int), st));
 
     const bool tm = ctx->timing;
     if (tm) {
@@ -529,10 +532,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     sa.offset = (int *)ctx->b_offset.p;
     sa.cursor = (int *)ctx->b_cursor.p;
     sa.units = (WorkUnit *)ctx->b_units.p;
-    sa.unit_range = (int *)ctx->b_urange.p;
     sa.totals = (long long *)ctx->b_totals.p;
     sa.n_keys = n_keys;
-    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, ctx->hs, sa);
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st,
                        (const int *)ctx->b_key.p, (int *)ctx->b_cursor.p, (int *)ctx->b_perm.p,
                        n_sbg, n_hyd);

@@ -149,15 +149,31 @@ __global__ __launch_bounds__(64) void k_final_ray(ScanRayArgs a)
         }
     }
     __syncthreads();
-    if (lane == 0) {
+    // strictly sequential float32 scans; LDS is read in chunks of 8 so that the
+    // read latency is paid once per chunk, not once per dependent step
+    if (lane < 3 && (lane == 0 || a.with_attenuation)) {
+        float *sv = (lane == 0) ? s_k : (lane == 1 ? s_h : s_v);
         float c = 0.0f;
-        for (int g = 0; g < ng; ++g) { c = (g == 0) ? s_k[0] : c + s_k[g]; s_k[g] = c; }
-    } else if (lane == 1 && a.with_attenuation) {
-        float c = 1.0f;
-        for (int g = 0; g < ng; ++g) { c = (g == 0) ? s_h[0] : c * s_h[g]; s_h[g] = c; }
-    } else if (lane == 2 && a.with_attenuation) {
-        float c = 1.0f;
-        for (int g = 0; g < ng; ++g) { c = (g == 0) ? s_v[0] : c * s_v[g]; s_v[g] = c; }
+        int g = 0;
+        for (; g + 8 <= ng; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = sv[g + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (g + q == 0) c = v[0];
+                else c = (lane == 0) ? c + v[q] : c * v[q];
+                v[q] = c;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sv[g + q] = v[q];
+        }
+        for (; g < ng; ++g) {
+            float x = sv[g];
+            if (g == 0) c = x;
+            else c = (lane == 0) ? c + x : c * x;
+            sv[g] = c;
+        }
     }
     __syncthreads();
     for (int g = lane; g < ng; g += 64) {

@@ -209,65 +209,75 @@ __global__ __launch_bounds__(256) void k_classify(HydroSet hs, ClassifyArgs a)
 
 // ---------------------------------------------------------------- bucket scan
 // single block: exclusive scan of the bucket counts -> offsets / cursors, and
-// the list of 64-item work units per hydrometeor.
+// the list of 64-item work units (sorted by bucket, i.e. grouped by hydrometeor).
 struct ScanArgs {
     const int *count;
     int *offset;                // [n_keys]
     int *cursor;                // [n_keys]
     WorkUnit *units;            // capacity >= n_items/64 + n_keys
-    int *unit_range;            // [n_hydro][2]
     long long *totals;          // [0] = n_valid items, [1] = n_units
     int n_keys;
 };
 
-__global__ __launch_bounds__(1024) void k_bucket_scan(HydroSet hs, ScanArgs a)
+__device__ __forceinline__ int2 wave_inclusive_scan2(int2 v)
 {
-    __shared__ int s_items[1024];
-    __shared__ int s_units[1024];
-    const int t = threadIdx.x;
-    const int per = (a.n_keys + 1023) / 1024;
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < CPOL_WAVE; off <<= 1) {
+        int a = __shfl_up(v.x, off), b = __shfl_up(v.y, off);
+        if (lane >= off) { v.x += a; v.y += b; }
+    }
+    return v;
+}
+
+#define CPOL_SCAN_MAX_PER 32
+__global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
+{
+    __shared__ int2 s_wave[16];
+    const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
+    const int per = (a.n_keys + 1023) / 1024;               // <= CPOL_SCAN_MAX_PER (host checks)
     const int k0 = t * per, k1 = min(k0 + per, a.n_keys);
-    int items = 0, units = 0;
-    for (int k = k0; k < k1; ++k) {
-        int c = a.count[k];
-        items += c;
-        units += (c + 63) >> 6;
+    int cnt[CPOL_SCAN_MAX_PER];
+    int2 mine = make_int2(0, 0);
+#pragma unroll
+    for (int i = 0; i < CPOL_SCAN_MAX_PER; ++i) {
+        int k = k0 + i;
+        int c = (i < per && k < k1) ? a.count[k] : 0;
+        cnt[i] = c;
+        mine.x += c;
+        mine.y += (c + 63) >> 6;
     }
-    s_items[t] = items;
-    s_units[t] = units;
+    int2 inc = wave_inclusive_scan2(mine);
+    if (lane == CPOL_WAVE - 1) s_wave[wave] = inc;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int off = 1; off < 1024; off <<= 1) {
-        int vi = 0, vu = 0;
-        if (t >= off) { vi = s_items[t - off]; vu = s_units[t - off]; }
-        __syncthreads();
-        s_items[t] += vi;
-        s_units[t] += vu;
-        __syncthreads();
+    if (wave == 0) {
+        int2 w = (lane < 16) ? s_wave[lane] : make_int2(0, 0);
+        int2 wi = wave_inclusive_scan2(w);
+        if (lane < 16) s_wave[lane] = make_int2(wi.x - w.x, wi.y - w.y);   // exclusive
     }
-    int ibase = s_items[t] - items, ubase = s_units[t] - units;
-    for (int k = k0; k < k1; ++k) {
-        int c = a.count[k];
-        a.offset[k] = ibase;
-        a.cursor[k] = ibase;
-        for (int u = 0; u < ((c + 63) >> 6); ++u) {
-            WorkUnit w;
-            w.key = k;
-            w.start = ibase + u * 64;
-            w.count = min(64, c - u * 64);
-            w.pad = 0;
-            a.units[ubase + u] = w;
+    __syncthreads();
+    int ibase = s_wave[wave].x + inc.x - mine.x;
+    int ubase = s_wave[wave].y + inc.y - mine.y;
+#pragma unroll
+    for (int i = 0; i < CPOL_SCAN_MAX_PER; ++i) {
+        int k = k0 + i;
+        if (i < per && k < k1) {
+            int c = cnt[i];
+            a.offset[k] = ibase;
+            a.cursor[k] = ibase;
+            for (int u = 0; u * 64 < c; ++u) {
+                WorkUnit w;
+                w.key = k;
+                w.start = ibase + u * 64;
+                w.count = min(64, c - u * 64);
+                w.pad = 0;
+                a.units[ubase + u] = w;
+            }
+            ibase += c;
+            ubase += (c + 63) >> 6;
         }
-        // unit ranges per hydrometeor (keys are grouped by hydrometeor)
-        for (int j = 0; j < hs.n_hydro; ++j) {
-            if (k == hs.h[j].key_base) a.unit_range[2 * j] = ubase;
-            int last = (j + 1 < hs.n_hydro ? hs.h[j + 1].key_base : hs.n_keys) - 1;
-            if (k == last) a.unit_range[2 * j + 1] = ubase + ((c + 63) >> 6);
-        }
-        ibase += c;
-        ubase += (c + 63) >> 6;
     }
-    if (t == 1023) { a.totals[0] = s_items[1023]; a.totals[1] = s_units[1023]; }
+    if (t == 1023) { a.totals[0] = ibase; a.totals[1] = ubase; }
 }
 
 // scatter item ids into bucket order: perm[slot] = sbg (per hydrometeor key space)

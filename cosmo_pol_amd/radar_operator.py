@@ -94,10 +94,11 @@ class RadarScan(object):
 
 class RadarOperator(object):
     def __init__(self, options_file=None, output_variables='all', *, device=0, lut_dir=None,
-                 luts=None, config=None):
+                 luts=None, config=None, distributed=False):
         print('Reading options defined in options file')
         self._ctx = N.Context(device)         # raises if the HIP library / GPU is missing
         self.device = device
+        self.distributed = bool(distributed)   # shard the rays of every sweep over the ranks
         self.lut_dir = lut_dir
         self._user_luts = luts
         self.current_microphys_scheme = '1mom'
@@ -315,6 +316,24 @@ class RadarOperator(object):
         res['n_sub'] = sub.n_sub
         return res
 
+    def _simulate_sweep(self, az, el):
+        """All rays of a sweep: locally, or sharded over the ranks of the default
+        torch.distributed group with one all-gather (cosmo_pol_amd/distributed.py)."""
+        if not self.distributed:
+            return self.simulate_rays(az, el)
+        import torch
+        from . import distributed as D
+        if self.output_variables != 'only_radar':
+            raise NotImplementedError('distributed sweeps return the radar observables only '
+                                      "(use output_variables='only_radar')")
+        fields = ([(k, np.float32) for k in RADAR_FIELDS] + [('dist', np.float32),
+                  ('heights', np.float32), ('mask', np.float64), ('lats', np.float64),
+                  ('lons', np.float64)])
+        n_gates = len(self.constants.RANGE_RADAR)
+        dev = torch.device('cuda', self.device)
+        return D.simulate_sharded(lambda a, e: self.simulate_rays(a, e), az, el, fields, n_gates,
+                                  device=dev)
+
     def _package(self, res, az, el):
         fields = {}
         if self.output_variables in ('all', 'only_radar'):
@@ -347,7 +366,7 @@ class RadarOperator(object):
         sweeps = []
         for e in elevations:
             el = np.full(len(azimuths), float(e))
-            sweeps.append(self._package(self.simulate_rays(azimuths, el), azimuths, el))
+            sweeps.append(self._package(self._simulate_sweep(azimuths, el), azimuths, el))
         return RadarScan('ppi', list(elevations), list(azimuths), self.constants.RANGE_RADAR,
                          self.get_pos_and_time(), sweeps)
 
@@ -365,7 +384,7 @@ class RadarOperator(object):
         sweeps = []
         for a in azimuths:
             az = np.full(len(elevations), float(a))
-            sweeps.append(self._package(self.simulate_rays(az, elevations), az, elevations))
+            sweeps.append(self._package(self._simulate_sweep(az, elevations), az, elevations))
         return RadarScan('rhi', list(elevations), list(azimuths), self.constants.RANGE_RADAR,
                          self.get_pos_and_time(), sweeps)
 

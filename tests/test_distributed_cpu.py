@@ -1,0 +1,94 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo processes exercise the ray
+sharding and the single all-gather of cosmo_pol_amd.distributed with a CPU
+stand-in for the per-rank simulation (the HIP path itself needs a GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = ['ZH', 'ZDR', 'KDP', 'lats']
+DTYPES = [np.float32, np.float32, np.float32, np.float64]
+N_GATES = 37
+
+
+def fake_simulate(az, el):
+    """Deterministic function of (azimuth, elevation, gate) with NaN holes."""
+    g = np.arange(N_GATES, dtype=np.float64)[None, :]
+    base = np.sin(np.deg2rad(az))[:, None] * 100 + el[:, None] * 7 + g
+    out = {}
+    for i, k in enumerate(FIELDS):
+        v = (base * (i + 1)).astype(DTYPES[i])
+        v[:, (i + 3)::11] = np.nan
+        out[k] = v
+    return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_rays, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from cosmo_pol_amd import distributed as D
+    az = np.linspace(0, 359, n_rays)
+    el = np.full(n_rays, 1.5)
+    calls = []
+
+    def sim(a, e):
+        calls.append(len(a))
+        return fake_simulate(a, e)
+    res = D.simulate_sharded(sim, az, el, list(zip(FIELDS, DTYPES)), N_GATES)
+    lo, hi, per = D.shard_bounds(n_rays, world, rank)
+    q.put((rank, {k: v.copy() for k, v in res.items()}, calls, (lo, hi, per)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_rays', [(2, 360), (2, 361), (3, 10), (2, 1)])
+def test_sharded_sweep_equals_single_process(world, n_rays):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rays, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    az = np.linspace(0, 359, n_rays)
+    ref = fake_simulate(az, np.full(n_rays, 1.5))
+    covered = 0
+    for rank, res, calls, (lo, hi, per) in got:
+        for k in FIELDS:
+            assert res[k].shape == (n_rays, N_GATES)
+            # bitwise identical to the un-sharded result on every rank
+            assert res[k].dtype == ref[k].dtype
+            assert np.array_equal(res[k].view(np.uint8), ref[k].view(np.uint8)), (rank, k)
+        assert calls == ([hi - lo] if hi > lo else [])
+        covered += hi - lo
+    assert covered == n_rays
+
+
+def test_shard_bounds_cover_and_are_contiguous():
+    from cosmo_pol_amd.distributed import shard_bounds
+    for n in (1, 7, 360, 361, 1800):
+        for w in (1, 2, 4, 8):
+            edges = [shard_bounds(n, w, r) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            for a, b in zip(edges[:-1], edges[1:]):
+                assert a[1] == b[0] and a[2] == b[2]
+            assert all(hi - lo <= per for lo, hi, per in edges)
