@@ -54,7 +54,7 @@ struct cpol_ctx {
     // per-sweep work buffers (grow only)
     DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
-        b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err;
+        b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err, b_pos;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
@@ -151,7 +151,7 @@ void cpol_destroy(cpol_ctx *ctx)
                      &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_cursor, &ctx->b_units,
-                     &ctx->b_urange, &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_err,
+                     &ctx->b_urange, &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_err, &ctx->b_pos,
                      &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model};
     for (DevBuf *b : all) free_buf(*b);
     for (auto &b : ctx->b_out) free_buf(b);
@@ -430,13 +430,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_qmelt, (size_t)2 * n_sbg * sizeof(float));
     ENSURE(ctx->b_fwmelt, (size_t)2 * n_sbg * sizeof(double));
     ENSURE(ctx->b_key, (size_t)n_hyd * n_sbg * sizeof(int));
+    ENSURE(ctx->b_pos, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_par, (size_t)n_hyd * CPOL_MAX_PAR * n_sbg * sizeof(double));
     ENSURE(ctx->b_count, (size_t)n_keys * sizeof(int));
     ENSURE(ctx->b_offset, (size_t)n_keys * sizeof(int));
     ENSURE(ctx->b_cursor, (size_t)n_keys * sizeof(int));
     const long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
     ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
-    ENSURE(ctx->b_urange, (size_t)2 * CPOL_MAX_HYDRO * sizeof(int));
     ENSURE(ctx->b_totals, 2 * sizeof(long long));
     ENSURE(ctx->b_perm, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_res, (size_t)n_hyd * n_sbg * CPOL_N_SZ * sizeof(double));
@@ -507,6 +507,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ca.q_melt = (float *)ctx->b_qmelt.p;
     ca.fw_melt = (double *)ctx->b_fwmelt.p;
     ca.key = (int *)ctx->b_key.p;
+    ca.pos = (int *)ctx->b_pos.p;
     ca.par = (double *)ctx->b_par.p;
     ca.count = (int *)ctx->b_count.p;
     ca.n_sbg = n_sbg;
@@ -523,21 +524,23 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ctx->err = "cpol_run_sweep: melting needs 1-moment rain, snow and graupel slots";
         return CPOL_ERR_ARG;
     }
-    hipLaunchKernelGGL(k_classify, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st, ctx->hs, ca);
+    hipLaunchKernelGGL(k_classify, dim3(cdiv(n_sbg, CPOL_CLASSIFY_THREADS)),
+                       dim3(CPOL_CLASSIFY_THREADS), 0, st, ctx->hs, ca);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_CLASSIFY], st));
 
     // ---- 4. counting sort by LUT slice ----
     ScanArgs sa{};
     sa.count = (const int *)ctx->b_count.p;
     sa.offset = (int *)ctx->b_offset.p;
-    sa.cursor = (int *)ctx->b_cursor.p;
+    sa.uoffset = (int *)ctx->b_cursor.p;
     sa.units = (WorkUnit *)ctx->b_units.p;
     sa.totals = (long long *)ctx->b_totals.p;
     sa.n_keys = n_keys;
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
+    hipLaunchKernelGGL(k_make_units, dim3(cdiv((long)n_keys * 64, 256)), dim3(256), 0, st, sa);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st,
-                       (const int *)ctx->b_key.p, (int *)ctx->b_cursor.p, (int *)ctx->b_perm.p,
-                       n_sbg, n_hyd);
+                       (const int *)ctx->b_key.p, (const int *)ctx->b_pos.p,
+                       (const int *)ctx->b_offset.p, (int *)ctx->b_perm.p, n_sbg, n_hyd);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st));
 
     // ---- 5. PSD x scattering table: one launch per kernel flavour present ----
