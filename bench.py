@@ -33,6 +33,10 @@ import numpy as np  # noqa: E402
 OUT_FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V']
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 LUT_SLICE_BYTES = 1024 * 12 * 4   # B_l per valid item (float32 staging figure)
+# HBM bytes per sweep of the PSD kernel from the PMC passes committed under profiles/
+# ((2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md); refreshed
+# whenever the profile is re-taken -- see profiles/README.md
+PSD_TRAFFIC_BYTES_PER_SWEEP = None
 
 
 def bench_config(small):
@@ -149,6 +153,12 @@ def main():
         achieved = psd_bytes / (cnt.ms_psd * 1e-3) / 1e9 if cnt.ms_psd > 0 else None
         sweep_bytes = (n_sbg * (4 * cube['zlevels'].shape[0] * 4 + n_vars * 8 * 4)
                        + psd_bytes + n_rays * n_gates * 48)
+        # f64 VALU issue roofline of the PSD kernel: 18 v_*_f64 per (item, bin) in the
+        # recurrence flavour (counted in the ISA), 4 cycles per wave64 instruction on a
+        # SIMD-32, 1024 SIMDs at 2.4 GHz
+        n_units = int(cnt.n_work_units)
+        valu_cycles = n_units * 1024 * 18 * 4
+        valu_frac = valu_cycles / (1024 * 2.4e9 * cnt.ms_psd * 1e-3) if cnt.ms_psd > 0 else None
         out = {
             'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -163,8 +173,9 @@ def main():
             'roofline': {'kernel': 'k_psd_gamma (3 launches/sweep: R, S, G)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
-                         'traffic': None,
+                         'traffic': PSD_TRAFFIC_BYTES_PER_SWEEP,
                          'algorithmic_bytes_per_sweep_stage': psd_bytes,
+                         'valu_f64_frac': valu_frac,
                          'avg_stage_ms': cnt.ms_psd,
                          'note': 'algorithmic bytes = N_valid x 49152 B (one float32 LUT slice per valid '
                                  'item, SURVEY 8(d)); slices are shared through the scalar cache / L2, '
