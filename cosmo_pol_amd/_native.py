@@ -20,6 +20,7 @@ PSD_GAMMA, PSD_ICE_FIELD, PSD_MELTING = 0, 1, 2
 (RULE_RAIN_1MOM, RULE_SNOW_1MOM, RULE_GRAUPEL_1MOM, RULE_TWO_MOMENT, RULE_ICE_1MOM,
  RULE_MELTING_SNOW, RULE_MELTING_GRAUPEL) = range(7)
 Q_MODEL, Q_MELT_SNOW, Q_MELT_GRAUPEL = 0, 1, 2
+GEOM_GROUND_43, GEOM_SPACEBORNE, GEOM_HOST_PATHS = 0, 1, 2
 
 ERR_HIP, ERR_ARG, ERR_DOMAIN, ERR_NOMEM = -1, -2, -3, -4
 
@@ -53,7 +54,8 @@ class SweepParams(C.Structure):
         ('n_hnodes', C.c_int32), ('n_vnodes', C.c_int32),
         ('with_melting', C.c_int32), ('with_attenuation', C.c_int32),
         ('integrate_model', C.c_int32), ('apply_sensitivity', C.c_int32),
-        ('outputs_on_device', C.c_int32), ('simulate_doppler', C.c_int32), ('pad_', C.c_int32),
+        ('outputs_on_device', C.c_int32), ('simulate_doppler', C.c_int32),
+        ('geometry_mode', C.c_int32),
         ('radar_lat', C.c_double), ('radar_lon', C.c_double), ('radar_alt', C.c_double),
         ('range0', C.c_double), ('range_step', C.c_double),
         ('ke', C.c_double), ('re', C.c_double),
@@ -65,7 +67,8 @@ class SweepParams(C.Structure):
 
 class RayTables(C.Structure):
     _fields_ = [('traj', C.c_void_p), ('geo', C.c_void_p), ('sub_h', C.c_void_p),
-                ('sub_v', C.c_void_p), ('sub_w', C.c_void_p), ('sens_thr', C.c_void_p)]
+                ('sub_v', C.c_void_p), ('sub_w', C.c_void_p), ('sens_thr', C.c_void_p),
+                ('site', C.c_void_p), ('paths', C.c_void_p)]
 
 
 OUTPUT_FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V',
@@ -87,6 +90,7 @@ class Counters(C.Structure):
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_set_stream',
            'cpol_synchronize', 'cpol_stage_model', 'cpol_stage_hydro', 'cpol_set_num_hydro',
            'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
+           'cpol_spaceborne_first_gate',
            'cpol_enable_timing', 'cpol_debug_read']
 
 _lib = None
@@ -134,6 +138,8 @@ def load_library():
                                    C.POINTER(Outputs)]
     lib.cpol_counters.restype = C.c_int
     lib.cpol_counters.argtypes = [vp, C.POINTER(Counters)]
+    lib.cpol_spaceborne_first_gate.restype = C.c_int
+    lib.cpol_spaceborne_first_gate.argtypes = [vp, C.POINTER(SweepParams), vp, vp, vp, C.c_double, vp]
     lib.cpol_enable_timing.restype = C.c_int
     lib.cpol_enable_timing.argtypes = [vp, C.c_int]
     lib.cpol_debug_read.restype = C.c_int64
@@ -238,6 +244,17 @@ class Context(object):
     def run_sweep(self, params, tables, outputs):
         rc = self.lib.cpol_run_sweep(self.h, C.byref(params), C.byref(tables), C.byref(outputs))
         self._check(rc, 'cpol_run_sweep')
+
+    def spaceborne_first_gate(self, params, traj, site, n_cand, ceiling_m):
+        n = params.n_rays * params.n_vnodes
+        out = np.empty(n, dtype=np.int32)
+        traj = np.ascontiguousarray(traj, dtype=np.float64)
+        site = np.ascontiguousarray(site, dtype=np.float64)
+        n_cand = np.ascontiguousarray(n_cand, dtype=np.int32)
+        rc = self.lib.cpol_spaceborne_first_gate(self.h, C.byref(params), _ptr(traj), _ptr(site),
+                                                 _ptr(n_cand), float(ceiling_m), _ptr(out))
+        self._check(rc, 'cpol_spaceborne_first_gate')
+        return out.reshape(params.n_rays, params.n_vnodes)
 
     def counters(self):
         c = Counters()

@@ -52,7 +52,7 @@ struct cpol_ctx {
         d_aux[CPOL_MAX_HYDRO];
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
     // per-sweep work buffers (grow only)
-    DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj;
+    DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
         b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err, b_pos;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
@@ -148,7 +148,7 @@ void cpol_destroy(cpol_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj_in, &ctx->b_geo, &ctx->b_subh, &ctx->b_subv,
-                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_vals, &ctx->b_mask,
+                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_cursor, &ctx->b_units,
                      &ctx->b_urange, &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_err, &ctx->b_pos,
@@ -359,8 +359,8 @@ int cpol_ray_tables(const cpol_sweep_params *p, const double *az_deg, const doub
     for (int r = 0; r < p->n_rays; ++r) {
         for (int j = 0; j < p->n_vnodes; ++j) {
             double el = (pts_v_deg[j] + el_deg[r]) * CPOL_DEG;
-            double *o = traj_out + ((long)r * p->n_vnodes + j) * 3;
-            o[0] = el; o[1] = sin(el); o[2] = cos(el);
+            double *o = traj_out + ((long)r * p->n_vnodes + j) * 4;
+            o[0] = el; o[1] = sin(el); o[2] = cos(el); o[3] = pts_v_deg[j] + el_deg[r];
         }
         for (int i = 0; i < p->n_hnodes; ++i) {
             double alpha1 = (pts_h_deg[i] + az_deg[r]) * CPOL_DEG;
@@ -413,7 +413,14 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     int rc;
 
     // ---- per-sweep host tables -> device ----
-    if ((rc = upload(ctx, ctx->b_traj_in, t->traj, (size_t)n_rays * n_v * 3 * sizeof(double)))) return rc;
+    if ((rc = upload(ctx, ctx->b_traj_in, t->traj, (size_t)n_rays * n_v * 4 * sizeof(double)))) return rc;
+    if (t->site && (rc = upload(ctx, ctx->b_site, t->site, (size_t)n_rays * 8 * sizeof(double)))) return rc;
+    const int mode = p->geometry_mode;
+    if ((mode == CPOL_GEOM_SPACEBORNE && !t->site) || (mode == CPOL_GEOM_HOST_PATHS && !t->paths) ||
+        mode < 0 || mode > 2) {
+        ctx->err = "cpol_run_sweep: geometry_mode needs tables->site (spaceborne) / tables->paths (host paths)";
+        return CPOL_ERR_ARG;
+    }
     if ((rc = upload(ctx, ctx->b_geo, t->geo, (size_t)n_rays * n_h * 8 * sizeof(double)))) return rc;
     if ((rc = upload(ctx, ctx->b_subh, t->sub_h, (size_t)n_sub * sizeof(int)))) return rc;
     if ((rc = upload(ctx, ctx->b_subv, t->sub_v, (size_t)n_sub * sizeof(int)))) return rc;
@@ -472,9 +479,19 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     }
 
     // ---- 1. ray paths ----
-    hipLaunchKernelGGL(k_trajectory, dim3(cdiv(ng, 256), n_rays * n_v), dim3(256), 0, st,
-                       (const double *)ctx->b_traj_in.p, (float *)ctx->b_traj.p, n_rays, n_v, ng,
-                       p->range0, p->range_step, p->ke, p->re, p->radar_alt);
+    if (mode == CPOL_GEOM_HOST_PATHS) {
+        HIPCHK(hipMemcpyAsync(ctx->b_traj.p, t->paths, (size_t)n_rays * n_v * 3 * ng * sizeof(float),
+                              hipMemcpyHostToDevice, st));
+    } else {
+        TrajArgs ta{};
+        ta.ray_traj = (const double *)ctx->b_traj_in.p;
+        ta.site = t->site ? (const double *)ctx->b_site.p : nullptr;
+        ta.traj_out = (float *)ctx->b_traj.p;
+        ta.n_rays = n_rays; ta.n_v = n_v; ta.n_gates = ng; ta.mode = mode;
+        ta.range0 = p->range0; ta.range_step = p->range_step;
+        ta.ke = p->ke; ta.re = p->re; ta.alt = p->radar_alt;
+        hipLaunchKernelGGL(k_trajectory, dim3(cdiv(ng, 256), n_rays * n_v), dim3(256), 0, st, ta);
+    }
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_TRAJ], st));
 
     // ---- 2. gate interpolation ----
@@ -495,6 +512,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.n_rays = n_rays; ia.n_gates = ng; ia.n_sub = n_sub; ia.n_h = n_h; ia.n_v = n_v;
     ia.central_sub = n_sub / 2;
     ia.sin_u1 = p->sin_u1; ia.cos_u1 = p->cos_u1; ia.lon1 = p->radar_lon;
+    ia.site = t->site ? (const double *)ctx->b_site.p : nullptr;
     hipLaunchKernelGGL(k_interp_sweep, dim3(cdiv(ng, 256), n_sub, n_rays), dim3(256), 0, st,
                        ctx->model, ia);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
@@ -643,6 +661,33 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             return CPOL_ERR_DOMAIN;
         }
     }
+    return CPOL_OK;
+}
+
+int cpol_spaceborne_first_gate(cpol_ctx *ctx, const cpol_sweep_params *p, const double *traj,
+                               const double *site, const int32_t *n_cand, double ceiling_m,
+                               int32_t *first_gate)
+{
+    if (!ctx || !p || !traj || !site || !n_cand || !first_gate || p->n_rays < 1 || p->n_vnodes < 1) {
+        if (ctx) ctx->err = "cpol_spaceborne_first_gate: bad arguments";
+        return CPOL_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = p->n_rays * p->n_vnodes;
+    DevBuf d_tr, d_site, d_nc, d_out;
+    int rc;
+    if ((rc = upload(ctx, d_tr, traj, (size_t)n * 4 * sizeof(double)))) return rc;
+    if ((rc = upload(ctx, d_site, site, (size_t)p->n_rays * 8 * sizeof(double)))) return rc;
+    if ((rc = upload(ctx, d_nc, n_cand, (size_t)p->n_rays * sizeof(int)))) return rc;
+    if ((rc = ensure(ctx, d_out, (size_t)n * sizeof(int)))) return rc;
+    hipLaunchKernelGGL(k_spaceborne_first_gate, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
+                       (const double *)d_tr.p, (const double *)d_site.p, (const int *)d_nc.p,
+                       (int *)d_out.p, p->n_rays, p->n_vnodes, p->range0, p->range_step, ceiling_m);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(first_gate, d_out.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_buf(d_tr); free_buf(d_site); free_buf(d_nc); free_buf(d_out);
     return CPOL_OK;
 }
 

@@ -33,31 +33,90 @@ __global__ void k_stage_variable(const float *__restrict__ src, float *__restric
 }
 
 // ---------------------------------------------------------------- trajectory
+// ray_traj: [n_rays][n_v][4] = (el_rad, sin el, cos el, el_deg); site: [n_rays][8] or NULL
 // traj_out: float32 [n_rays][n_vnodes][3][n_gates]  (s, h, e_deg)
-__global__ void k_trajectory(const double *__restrict__ ray_traj,   // [n_rays][n_v][3]
-                             float *__restrict__ traj_out,
-                             int n_rays, int n_v, int n_gates,
-                             double range0, double range_step, double ke, double re, double alt)
+struct TrajArgs {
+    const double *ray_traj;
+    const double *site;         // per-ray (sin U1, cos U1, lon, alt, re, first gate, n kept, -)
+    float *traj_out;
+    int n_rays, n_v, n_gates, mode;
+    double range0, range_step, ke, re, alt;
+};
+
+// height of candidate gate k of a downward-looking (spaceborne) ray
+// (atm_refraction.py:254-255 with KE = 1; float64)
+__device__ __forceinline__ double spaceborne_height(double r, double re, double sin_el, double alt)
+{
+    double temp = sqrt(r * r + re * re + 2.0 * r * 1.0 * re * sin_el);
+    return -(temp - re) + alt;
+}
+
+__global__ void k_trajectory(TrajArgs a)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     int rv = blockIdx.y;                       // ray * n_v + vnode
-    if (g >= n_gates) return;
-    const double el = ray_traj[rv * 3 + 0];
-    const double sin_el = ray_traj[rv * 3 + 1];
-    const double cos_el = ray_traj[rv * 3 + 2];
-    const double r = range0 + (double)g * range_step;
+    if (g >= a.n_gates) return;
+    const int ray = rv / a.n_v;
+    const double el = a.ray_traj[rv * 4 + 0];
+    const double sin_el = a.ray_traj[rv * 4 + 1];
+    const double cos_el = a.ray_traj[rv * 4 + 2];
+    float *o = a.traj_out + (long)rv * 3 * a.n_gates;
+    if (a.mode == CPOL_GEOM_SPACEBORNE) {
+        const double *st = a.site + (long)ray * 8;
+        const double alt = st[3], re = st[4];
+        const int k0 = (int)st[5], n_kept = (int)st[6];
+        if (g >= n_kept) {
+            const float qnan = __builtin_nanf("");
+            o[g] = qnan; o[a.n_gates + g] = qnan; o[2 * a.n_gates + g] = qnan;
+            return;
+        }
+        const double r = a.range0 + (double)(k0 + g) * a.range_step;
+        const double h = spaceborne_height(r, re, sin_el, alt);
+        const double s = re * asin((r * cos_el) / (re + h));
+        const double e = a.ray_traj[rv * 4 + 3]
+            - atan(r * cos_el / (r * sin_el + re + alt)) * (180.0 / 3.14159265358979323846);
+        o[g] = (float)s;
+        o[a.n_gates + g] = (float)h;
+        o[2 * a.n_gates + g] = (float)e;      // degrees (the reference's second rad2deg is a bug)
+        return;
+    }
+    const double alt = a.site ? a.site[(long)ray * 8 + 3] : a.alt;
+    const double re = a.site ? a.site[(long)ray * 8 + 4] : a.re;
+    const double ke = a.ke;
+    const double r = a.range0 + (double)g * a.range_step;
     const double ke_re = ke * re;
     // atm_refraction.py:206-215, same operand order
     double temp = sqrt(r * r + ke_re * ke_re + 2.0 * r * ke * re * sin_el);
     double h = temp - ke_re + alt;
     double s = ke_re * asin((r * cos_el) / (ke_re + h));
     double e = el + atan(r * cos_el / (r * sin_el + ke_re + alt));
-    float *o = traj_out + (long)rv * 3 * n_gates;
     o[g] = (float)s;
-    o[n_gates + g] = (float)h;
+    o[a.n_gates + g] = (float)h;
     // np.rad2deg on float32: x * (180.0f / float(pi)), constant formed in float32
     const float rad2deg_f = 180.0f / 3.14159265358979323846f;
-    o[2 * n_gates + g] = (float)e * rad2deg_f;
+    o[2 * a.n_gates + g] = (float)e * rad2deg_f;
+}
+
+// first candidate gate whose height is below `ceiling` (heights decrease along a
+// downward ray): one thread per (ray, vertical node)
+__global__ void k_spaceborne_first_gate(const double *__restrict__ ray_traj,
+                                        const double *__restrict__ site,
+                                        const int *__restrict__ n_cand, int *__restrict__ first,
+                                        int n_rays, int n_v, double range0, double range_step,
+                                        double ceiling)
+{
+    int rv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rv >= n_rays * n_v) return;
+    const int ray = rv / n_v;
+    const double sin_el = ray_traj[rv * 4 + 1];
+    const double alt = site[(long)ray * 8 + 3], re = site[(long)ray * 8 + 4];
+    int lo = 0, hi = n_cand[ray];              // answer in [lo, hi]
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        double h = spaceborne_height(range0 + (double)mid * range_step, re, sin_el, alt);
+        if (h < ceiling) hi = mid; else lo = mid + 1;
+    }
+    first[rv] = lo;
 }
 
 // ---------------------------------------------------------------- gate kernel
@@ -173,6 +232,7 @@ struct InterpArgs {
     int *error_flag;
     int n_rays, n_gates, n_sub, n_h, n_v, central_sub;
     double sin_u1, cos_u1, lon1;
+    const double *site;         // per-ray site or NULL
 };
 
 __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
@@ -187,6 +247,26 @@ __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
     const float *tr = a.traj + ((long)(ray * a.n_v + jv) * 3) * a.n_gates;
     const float s32 = tr[gate], h32 = tr[a.n_gates + gate];
     float e32 = tr[2 * a.n_gates + gate];
+    const float qnan = __builtin_nanf("");
+    if (!(s32 == s32) || !(h32 == h32)) {
+        // no gate here (ray shorter than the batch: spaceborne / host paths): counts
+        // as "above the model", produces no item
+        a.mask[sbg] = 1;
+        for (int v = 0; v < m.n_vars; ++v) a.vals[(long)v * n_sbg + sbg] = qnan;
+        a.elev[sbg] = 0.0f;
+        if (a.coords) { a.coords[2 * sbg] = qnan; a.coords[2 * sbg + 1] = qnan; }
+        if (sub == a.central_sub) {
+            const long rg = (long)ray * a.n_gates + gate;
+            if (a.lats) a.lats[rg] = __builtin_nan("");
+            if (a.lons) a.lons[rg] = __builtin_nan("");
+            if (a.dist) a.dist[rg] = qnan;
+            if (a.heights) a.heights[rg] = qnan;
+        }
+        return;
+    }
+    const double sin_u1 = a.site ? a.site[(long)ray * 8 + 0] : a.sin_u1;
+    const double cos_u1 = a.site ? a.site[(long)ray * 8 + 1] : a.cos_u1;
+    const double lon1 = a.site ? a.site[(long)ray * 8 + 2] : a.lon1;
 
     // ---- WGS84 direct geodesic (Vincenty, fixed iteration count) ----
     const double *gc = a.geo + (long)(ray * a.n_h + ih) * 8;
@@ -210,14 +290,14 @@ __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
     cos2sm = cos(two_sm);
     sin_s = sin(sigma);
     cos_s = cos(sigma);
-    const double tmp = a.sin_u1 * sin_s - a.cos_u1 * cos_s * cos_a1;
-    const double lat2 = atan2(a.sin_u1 * cos_s + a.cos_u1 * sin_s * cos_a1,
+    const double tmp = sin_u1 * sin_s - cos_u1 * cos_s * cos_a1;
+    const double lat2 = atan2(sin_u1 * cos_s + cos_u1 * sin_s * cos_a1,
                               (1.0 - f) * sqrt(sin_alpha * sin_alpha + tmp * tmp));
-    const double lam = atan2(sin_s * sin_a1, a.cos_u1 * cos_s - a.sin_u1 * sin_s * cos_a1);
+    const double lam = atan2(sin_s * sin_a1, cos_u1 * cos_s - sin_u1 * sin_s * cos_a1);
     const double L = lam - (1.0 - C) * f * sin_alpha *
         (sigma + C * sin_s * (cos2sm + C * cos_s * (-1.0 + 2.0 * cos2sm * cos2sm)));
     const double lat_deg = lat2 / CPOL_DEG;
-    const double lon_deg = a.lon1 + L / CPOL_DEG;
+    const double lon_deg = lon1 + L / CPOL_DEG;
 
     // ---- rotated-pole transform (float64) -> float32 grid coordinates ----
     const double latr = lat_deg * CPOL_DEG, lonr = lon_deg * CPOL_DEG;
@@ -241,7 +321,6 @@ __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
 
     GateGeom g;
     gate_geometry(m, rlat, rlon, h32, g);
-    const float qnan = __builtin_nanf("");
     for (int v = 0; v < m.n_vars; ++v)
         a.vals[(long)v * n_sbg + sbg] = (g.status == 0) ? gate_value(m, g, h32, v) : qnan;
     a.mask[sbg] = (signed char)g.status;

@@ -82,24 +82,32 @@ def gauss_hermite_subbeams(config):
 
 
 def radar_site_constants(coords):
-    """Reduced latitude of the radar (sin U1, cos U1) for Vincenty direct."""
-    phi1 = np.float64(coords[0]) * DEG
+    """Reduced latitude of the radar (sin U1, cos U1, tan U1) for Vincenty direct;
+    `coords` = [lat, lon, alt] or an array [n_rays, 3] (one site per ray)."""
+    lat = np.asarray(coords, dtype=np.float64)[..., 0]
+    phi1 = lat * DEG
     tan_u1 = (1.0 - WGS84_F) * np.tan(phi1)
     cos_u1 = 1.0 / np.sqrt(1.0 + tan_u1 * tan_u1)
     sin_u1 = tan_u1 * cos_u1
-    return float(sin_u1), float(cos_u1), float(tan_u1)
+    if np.ndim(sin_u1) == 0:
+        return float(sin_u1), float(cos_u1), float(tan_u1)
+    return sin_u1, cos_u1, tan_u1
 
 
 def ray_tables(coords, azimuths, elevations, sub):
-    """traj [n_rays, n_v, 3] = (el_rad, sin el, cos el) and geo [n_rays, n_h, 8]
-    = (sin a1, cos a1, sigma1, sin alpha, b*A, B, C, a1) for every ray."""
+    """traj [n_rays, n_v, 4] = (el_rad, sin el, cos el, el_deg) and geo [n_rays, n_h, 8]
+    = (sin a1, cos a1, sigma1, sin alpha, b*A, B, C, a1) for every ray.  `coords` is the
+    radar site [lat, lon, alt] or one site per ray [n_rays, 3] (spaceborne)."""
     az = np.asarray(azimuths, dtype=np.float64).reshape(-1)
     el = np.asarray(elevations, dtype=np.float64).reshape(-1)
     n = len(az)
     # reference: compute_trajectory_radial(rranges, pt + elevation, ...)
-    el_nodes = np.deg2rad(sub.pts_ver[None, :] + el[:, None])
-    traj = np.stack([el_nodes, np.sin(el_nodes), np.cos(el_nodes)], axis=-1)
+    el_deg = sub.pts_ver[None, :] + el[:, None]
+    el_nodes = np.deg2rad(el_deg)
+    traj = np.stack([el_nodes, np.sin(el_nodes), np.cos(el_nodes), el_deg], axis=-1)
     sin_u1, cos_u1, tan_u1 = radar_site_constants(coords)
+    if np.ndim(sin_u1) == 1:
+        cos_u1, tan_u1 = cos_u1[:, None], tan_u1[:, None]
     a, b, f = WGS84_A, WGS84_B, WGS84_F
     alpha1 = (sub.pts_hor[None, :] + az[:, None]) * DEG
     sin_a1 = np.sin(alpha1)
@@ -112,7 +120,7 @@ def ray_tables(coords, azimuths, elevations, sub):
     B = u2 / 1024.0 * (256.0 + u2 * (-128.0 + u2 * (74.0 - 47.0 * u2)))
     C = f / 16.0 * cos2_alpha * (4.0 + f * (4.0 - 3.0 * cos2_alpha))
     geo = np.stack([sin_a1, cos_a1, sigma1, sin_alpha, b * A, B, C, alpha1], axis=-1)
-    assert traj.shape == (n, len(sub.pts_ver), 3) and geo.shape == (n, len(sub.pts_hor), 8)
+    assert traj.shape == (n, len(sub.pts_ver), 4) and geo.shape == (n, len(sub.pts_hor), 8)
     return np.ascontiguousarray(traj), np.ascontiguousarray(geo)
 
 

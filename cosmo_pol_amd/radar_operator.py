@@ -7,7 +7,8 @@ Same constructor, properties and scan methods as cosmo_pol/radar_operator.py:46
 loop (one `pool.map` task per radial, radar_operator.py:407-432) is replaced by
 ONE call into libcosmo_pol_hip.so per sweep; there is no CPU path.
 
-Keyword-only extras: `device`, `lut_dir`, `luts` (pre-built tables),
+Keyword-only extras: `device`, `lut_dir`, `luts` (pre-built tables {h: table} or a
+callable (hydrometeors, frequency, scheme) -> {h: table}),
 `load_model_arrays(...)` (pycosmo / GRIB are not available here).
 """
 import copy
@@ -160,7 +161,9 @@ class RadarOperator(object):
         scheme = conf['microphysics']['scheme']
         self.current_microphys_scheme = scheme
         hl = hyd.hydrometeor_list(conf)
-        if self._user_luts is not None:
+        if callable(self._user_luts):
+            lut = self._user_luts(hl, conf['radar']['frequency'], scheme)
+        elif self._user_luts is not None:
             missing = [h for h in hl if h not in self._user_luts]
             if missing:
                 raise IOError('no lookup table supplied for hydrometeors %s' % missing)
@@ -244,27 +247,37 @@ class RadarOperator(object):
         return True
 
     def simulate_rays(self, azimuths, elevations, on_device=False, device_outputs=None,
-                      apply_sensitivity=True):
-        """One batched launch sequence for the given rays (az[i], el[i]).
-        Returns a dict of [n_rays, n_gates] arrays (linear units, NaN = no data).
-        `device_outputs`: optional {field: device pointer} (outputs stay in HBM)."""
+                      apply_sensitivity=True, paths=None):
+        """One batched launch sequence for the given rays (az[i], el[i]) of the
+        ground radar of the configuration.  Returns a dict of [n_rays, n_gates]
+        arrays (linear units, NaN = no data).
+        `device_outputs`: optional {field: device pointer} (outputs stay in HBM).
+        `paths`: optional float32 [n_rays, n_vnodes, 3, n_gates] host-computed ray
+        paths (s, h, e_deg) replacing the 4/3-earth model (CPOL_GEOM_HOST_PATHS)."""
+        conf = self.__config
+        if conf['refraction']['scheme'] != 1 and paths is None:
+            raise NotImplementedError('refraction scheme 2 (Zeng & Blahak ODE) needs host-computed '
+                                      'ray paths: pass paths=... (SURVEY.md 8(f) rank 3)')
+        coords = conf['radar']['coords']
+        if coords[2] > K.MAX_MODEL_HEIGHT:
+            raise NotImplementedError('spaceborne geometry: use get_GPM_swath')
+        rr = self.constants.RANGE_RADAR
+        mode = N.GEOM_GROUND_43 if paths is None else N.GEOM_HOST_PATHS
+        return self._run_rays(azimuths, elevations, coords, len(rr), float(rr[0]), mode,
+                              device_outputs=device_outputs, apply_sensitivity=apply_sensitivity,
+                              paths=paths)
+
+    def _run_rays(self, azimuths, elevations, coords, n_gates, range0, mode, device_outputs=None,
+                  apply_sensitivity=True, paths=None, site=None, sub=None, tables=None):
         conf = self.__config
         az = np.ascontiguousarray(np.asarray(azimuths, dtype=np.float64).reshape(-1))
         el = np.ascontiguousarray(np.asarray(elevations, dtype=np.float64).reshape(-1))
         if az.shape != el.shape:
             raise ValueError('azimuths and elevations must have the same length')
-        if conf['refraction']['scheme'] != 1:
-            raise NotImplementedError('refraction scheme 2 (Zeng & Blahak ODE) is not implemented '
-                                      '(SURVEY.md 8(f) rank 3)')
-        coords = conf['radar']['coords']
-        if coords[2] > K.MAX_MODEL_HEIGHT:
-            raise NotImplementedError('spaceborne geometry: use get_GPM_swath')
-        rr = self.constants.RANGE_RADAR
-        n_rays, n_gates = len(az), len(rr)
-        sub = geo.gauss_hermite_subbeams(conf)
-        traj, geo_t = geo.ray_tables(coords, az, el, sub)
-        re, ke = geo.earth_radius_for_refraction(coords)
-        sin_u1, cos_u1, _ = geo.radar_site_constants(coords)
+        n_rays = len(az)
+        if sub is None:
+            sub = geo.gauss_hermite_subbeams(conf)
+        traj, geo_t = tables if tables is not None else geo.ray_tables(coords, az, el, sub)
 
         p = N.SweepParams()
         p.n_rays, p.n_gates, p.n_sub = n_rays, n_gates, sub.n_sub
@@ -275,11 +288,18 @@ class RadarOperator(object):
         p.integrate_model = int(want_model)
         p.outputs_on_device = int(device_outputs is not None)
         p.simulate_doppler = 0
-        p.radar_lat, p.radar_lon, p.radar_alt = float(coords[0]), float(coords[1]), float(coords[2])
-        p.range0 = float(rr[0])
+        p.geometry_mode = mode
+        if site is None:
+            re, ke = geo.earth_radius_for_refraction(coords)
+            sin_u1, cos_u1, _ = geo.radar_site_constants(coords)
+            p.radar_lat, p.radar_lon, p.radar_alt = (float(coords[0]), float(coords[1]),
+                                                     float(coords[2]))
+            p.ke, p.re = ke, re
+            p.sin_u1, p.cos_u1 = sin_u1, cos_u1
+        else:
+            p.ke, p.re = 1.0, 0.0
+        p.range0 = range0
         p.range_step = float(conf['radar']['radial_resolution'])
-        p.ke, p.re = ke, re
-        p.sin_u1, p.cos_u1 = sin_u1, cos_u1
         p.wavelength = float(self.constants.WAVELENGTH)
         p.k_squared = float(conf['radar']['K_squared'])
         p.radial_res = float(conf['radar']['radial_resolution'])
@@ -288,10 +308,19 @@ class RadarOperator(object):
         thr = geo.sensitivity_threshold(conf, self.constants, n_gates) if apply_sensitivity else None
         p.apply_sensitivity = int(thr is not None)
         t = N.RayTables()
-        keep = [traj, geo_t, sub.sub_h, sub.sub_v, sub.sub_w, thr]
+        if paths is not None:
+            paths = np.ascontiguousarray(paths, dtype=np.float32)
+            if paths.shape != (n_rays, p.n_vnodes, 3, n_gates):
+                raise ValueError('paths must have shape [n_rays, n_vnodes, 3, n_gates] = %s'
+                                 % ((n_rays, p.n_vnodes, 3, n_gates),))
+        if site is not None:
+            site = np.ascontiguousarray(site, dtype=np.float64)
+        keep = [traj, geo_t, sub.sub_h, sub.sub_v, sub.sub_w, thr, paths, site]
         t.traj, t.geo = traj.ctypes.data, geo_t.ctypes.data
         t.sub_h, t.sub_v, t.sub_w = sub.sub_h.ctypes.data, sub.sub_v.ctypes.data, sub.sub_w.ctypes.data
         t.sens_thr = thr.ctypes.data if thr is not None else None
+        t.site = site.ctypes.data if site is not None else None
+        t.paths = paths.ctypes.data if paths is not None else None
 
         o = N.Outputs()
         res = {}
@@ -396,6 +425,59 @@ class RadarOperator(object):
         return self.get_RHI(azimuths=[0.], elevations=[90.])
 
     def get_GPM_swath(self, GPM_file, band='Ku'):
-        raise NotImplementedError('GPM swath geometry (SURVEY.md 3.4, config 5) is scheduled '
-                                  'for a later round; the 2-moment microphysics it needs is '
-                                  'available through get_PPI / get_RHI.')
+        """Simulates a GPM-DPR swath (radar_operator.py:551-677, intended behaviour;
+        the reference's version is dead as shipped).  `GPM_file`: path
+        of a DPR HDF5 file (needs h5py) or a dict with Latitude, Longitude [N, M],
+        scLat, scLon, dprAlt [N], scPos [N, 3].  Returns a SimulatedGPM."""
+        from . import gpm
+        if not self._check_ready():
+            return
+        swath = gpm.read_swath(GPM_file, band)
+        freq, res_m = gpm.band_settings(band)
+        saved = self.config
+        conf = self.config
+        conf['radar']['frequency'] = freq
+        conf['radar']['3dB_beamwidth'] = K.GPM_3DB_BEAMWIDTH
+        conf['radar']['sensitivity'] = float(K.GPM_SENSITIVITY)
+        conf['radar']['type'] = 'GPM'
+        conf['radar']['radial_resolution'] = res_m
+        try:
+            self.config = conf                   # reloads the tables of the new frequency
+            az, el, rng, sat = gpm.swath_angles(swath)
+            dim = az.shape
+            az, el, rng = az.ravel(), el.ravel(), rng.ravel()
+            coords = np.repeat(sat, dim[1], axis=0)                      # one site per ray
+            sub = geo.gauss_hermite_subbeams(self.__config)
+            traj, geo_t = geo.ray_tables(coords, az, el, sub)
+            n_rays = len(az)
+            # candidate gates: np.arange(res/2, slant range, res) (atm_refraction.py:252)
+            n_cand = np.maximum(np.ceil((rng - res_m / 2.) / res_m), 0).astype(np.int32)
+            sin_u1, cos_u1, _ = geo.radar_site_constants(coords)
+            site = np.zeros((n_rays, 8))
+            site[:, 0], site[:, 1], site[:, 2], site[:, 3] = sin_u1, cos_u1, coords[:, 1], coords[:, 2]
+            site[:, 4] = geo.get_earth_radius(coords[:, 0])              # quirk Q1 (degrees as radians)
+            p = N.SweepParams()
+            p.n_rays, p.n_vnodes = n_rays, len(sub.pts_ver)
+            p.range0, p.range_step = res_m / 2., float(res_m)
+            first = self._ctx.spaceborne_first_gate(p, traj, site, n_cand, K.MAX_MODEL_HEIGHT)
+            k0 = first[:, sub.sub_v[sub.central]]
+            n_kept = (n_cand - k0).astype(np.int64)
+            site[:, 5], site[:, 6] = k0, n_kept
+            n_gates = int(max(1, n_kept.max()))
+            res = self._run_rays(az, el, coords, n_gates, res_m / 2., N.GEOM_SPACEBORNE,
+                                 site=site, sub=sub, tables=(traj, geo_t))
+            fields = {}
+            if self.output_variables in ('all', 'only_radar'):
+                for k in RADAR_FIELDS:
+                    fields[k] = res[k]
+            if self.output_variables in ('all', 'only_model'):
+                for i, name in enumerate(self._staged_vars):
+                    fields[name] = res['model_vars'][i]
+            out = gpm.SimulatedGPM(fields, res['mask'], res['lats'], res['lons'], n_kept, dim, band)
+            out.raw = res
+            out.n_kept = n_kept.reshape(dim)
+            out.azimuths, out.elevations, out.ranges = (az.reshape(dim), el.reshape(dim),
+                                                        rng.reshape(dim))
+            return out
+        finally:
+            self.config = saved

@@ -117,7 +117,7 @@ typedef struct {
     int32_t apply_sensitivity;  /* 1: censor with tables->sens_thr (cut_at_sensitivity) */
     int32_t outputs_on_device;  /* output pointers are device pointers          */
     int32_t simulate_doppler;   /* Doppler scheme 1 radial velocity (RVEL)      */
-    int32_t pad_;
+    int32_t geometry_mode;      /* CPOL_GEOM_*                                   */
     double  radar_lat, radar_lon, radar_alt;
     double  range0, range_step; /* RANGE_RADAR = range0 + k*range_step          */
     double  ke, re;             /* 4/3 and the earth radius (host evaluates quirk Q1) */
@@ -128,6 +128,15 @@ typedef struct {
     double  c_zh;               /* wavelength^4 / (pi^5 K^2)                     */
 } cpol_sweep_params;
 
+/* ray-path models */
+enum {
+    CPOL_GEOM_GROUND_43 = 0,    /* 4/3-earth closed form (atm_refraction.py:181-220)    */
+    CPOL_GEOM_SPACEBORNE = 1,   /* straight ray from orbit, KE = 1, gates below 35 km
+                                   (atm_refraction.py:222-272, intended behaviour)      */
+    CPOL_GEOM_HOST_PATHS = 2    /* (s, h, e) per gate supplied by the host, e.g. the
+                                   Zeng & Blahak ODE (atm_refraction.py:79-148)          */
+};
+
 /* per-ray host-side tables (cpol_ray_tables fills them) */
 typedef struct {
     const double *traj;         /* [n_rays][n_vnodes][3] : el_rad, sin el, cos el */
@@ -137,6 +146,12 @@ typedef struct {
     const int32_t *sub_v;       /* [n_sub] vertical node                        */
     const double *sub_w;        /* [n_sub] quadrature weight                    */
     const double *sens_thr;     /* [n_gates] dBZ threshold per gate or NULL      */
+    const double *site;         /* [n_rays][8] per-ray radar site or NULL (= the one
+                                   of cpol_sweep_params): sin U1, cos U1, lon [deg],
+                                   altitude [m], earth radius [m], first kept gate
+                                   index, number of kept gates, unused             */
+    const float *paths;         /* CPOL_GEOM_HOST_PATHS: [n_rays][n_vnodes][3][n_gates]
+                                   float32 (s, h, e_deg), NaN = no gate            */
 } cpol_ray_tables_t;
 
 typedef struct {
@@ -193,6 +208,13 @@ int  cpol_ray_tables(const cpol_sweep_params *p, const double *az_deg, const dou
 
 int  cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tables_t *tables,
                     cpol_outputs *out);
+
+/* CPOL_GEOM_SPACEBORNE helper: index of the first candidate gate below the
+ * model-top ceiling for each (ray, vertical node): first_gate [n_rays*n_vnodes]
+ * (host buffer).  `site` as in cpol_ray_tables_t, n_cand[n_rays] candidate gates. */
+int  cpol_spaceborne_first_gate(cpol_ctx *ctx, const cpol_sweep_params *p, const double *traj,
+                                const double *site, const int32_t *n_cand, double ceiling_m,
+                                int32_t *first_gate);
 
 int  cpol_counters(cpol_ctx *ctx, cpol_counters_t *out);
 int  cpol_enable_timing(cpol_ctx *ctx, int on);

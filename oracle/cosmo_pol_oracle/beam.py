@@ -163,13 +163,18 @@ def gate_coordinates(cube, coords_radar, azimuth, dist):
     return lats, lons, rc
 
 
-def interpolate_radial(cube, config, azimuth, elevation, which='twin'):
+def interpolate_radial(cube, config, azimuth, elevation, which='twin', trajs=None,
+                       coords_radar=None):
     """All kept sub-beams of one radial (i-major order: horizontal index outer,
-    vertical inner), each with mask coding and optional melting."""
+    vertical inner), each with mask coding and optional melting.
+    `trajs`: optional list of (s, h, e) per vertical node replacing the 4/3-earth
+    model (spaceborne rays, ODE refraction); `coords_radar`: site of this ray."""
     pts_hor, pts_ver, weights, keep = gauss_hermite_subbeams(config)
-    der = K.Derived(config)
-    coords_radar = config['radar']['coords']
-    trajs = [trajectory_4_3(der.RANGE_RADAR, pt + elevation, coords_radar) for pt in pts_ver]
+    if coords_radar is None:
+        coords_radar = config['radar']['coords']
+    if trajs is None:
+        der = K.Derived(config)
+        trajs = [trajectory_4_3(der.RANGE_RADAR, pt + elevation, coords_radar) for pt in pts_ver]
     out = []
     for i in range(len(pts_hor)):
         for j in range(len(pts_ver)):

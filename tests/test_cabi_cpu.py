@@ -130,7 +130,7 @@ def test_host_geometry_matches_oracle(golden):
             assert np.array_equal(gt[r, i, :7], np.array(exp, dtype=np.float64))
         for j in range(3):
             e = np.deg2rad(sub.pts_ver[j] + el[r])
-            assert np.array_equal(traj[r, j], [e, np.sin(e), np.cos(e)])
+            assert np.array_equal(traj[r, j], [e, np.sin(e), np.cos(e), sub.pts_ver[j] + el[r]])
 
 
 def test_host_hydro_tables_follow_numpy_promotion():

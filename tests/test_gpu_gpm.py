@@ -1,0 +1,112 @@
+"""GPU tests of the spaceborne (GPM-DPR, BASELINE config 5) and host-supplied
+ray-path geometries.  The reference's GPM branch is dead as shipped (SURVEY.md
+3.4): parity is against the oracle's restatement of the intended behaviour
+(oracle/cosmo_pol_oracle/gpm.py) -- no reference pin exists for config 5."""
+import numpy as np
+import pytest
+
+import _cases
+from cosmo_pol_amd import gpm, synthetic
+from cosmo_pol_oracle import beam, scatter
+from cosmo_pol_oracle import config as ocfg
+from cosmo_pol_oracle import gpm as ogpm
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+HYD_2MOM = ['R', 'S', 'G', 'H']
+
+
+@pytest.fixture(scope='module')
+def luts_ku():
+    return {h: synthetic.make_lut(h, 13.6, '2mom') for h in HYD_2MOM}
+
+
+def _swath():
+    return gpm.synthetic_swath(n_scans=3, n_rays=5, cross_track_deg=4.0, scan_spacing_m=6000.0)
+
+
+def test_gpm_swath_vs_oracle(luts_ku):
+    from cosmo_pol_amd import RadarOperator
+    from test_gpu_parity import _pol_tolerances
+    cube = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G'), two_moment=True,
+                                     **_cases.gen_golden.CUBE_KW)
+    base = {'radar': {'coords': [46.5, 7.5, 1000], 'frequency': 5.6, 'K_squared': 0.93},
+            'microphysics': {'scheme': '2mom', 'with_ice_crystals': 0, 'with_melting': 0},
+            'integration': {'nh_GH': 1, 'nv_GH': 3}}
+    lut_5_6 = {h: synthetic.make_lut(h, 5.6, '2mom', n_e=2, n_t=2) for h in HYD_2MOM}
+
+    def provider(hl, freq, scheme):
+        assert scheme == '2mom'
+        return {h: (luts_ku if freq == 13.6 else lut_5_6)[h] for h in hl}
+    op = RadarOperator(config=base, luts=provider, output_variables='only_radar')
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    sw = _swath()
+    op._ctx.enable_debug(True)
+    out = op.get_GPM_swath(sw, 'Ku')
+    assert op.config['radar']['frequency'] == 5.6          # configuration restored
+    N, M = sw['Latitude'].shape
+    assert out.data['ZH'].shape[:2] == (N, M) and out.band == 'Ku'
+
+    # ---- oracle: same rays, per-ray satellite site ----
+    over = {k: dict(v) for k, v in base.items()}
+    over['radar'].update(frequency=13.6, radial_resolution=125, sensitivity=12.0, type='GPM')
+    over['radar']['3dB_beamwidth'] = 0.5
+    conf = ocfg.make_config(over)
+    order = _cases.ORDER_2MOM
+    ocube = beam.ModelCube({n: cube['data'][n].copy() for n in order}, cube['zlevels'],
+                           cube['proj_info'], cube['resolution'], order)
+    olut = {h: _cases.as_oracle_lut(luts_ku[h]) for h in HYD_2MOM}
+    az, el, rng, sat = ogpm.swath_angles(sw)
+    np.testing.assert_allclose(out.azimuths, az, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(out.elevations, el, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out.ranges, rng, rtol=1e-15)
+    raw = out.raw
+    n_valid_total = 0
+    for idx in range(N * M):
+        i, j = divmod(idx, M)
+        subs, k0, n = ogpm.interpolate_swath_ray(ocube, conf, out.azimuths[i, j],
+                                                 out.elevations[i, j], out.ranges[i, j], sat[i])
+        assert n == out.n_kept[i, j], (idx, n, out.n_kept[i, j])
+        c = subs[int(len(subs) / 2)]
+        assert np.array_equal(raw['dist'][idx, :n], c.dist_profile)
+        assert np.array_equal(raw['heights'][idx, :n], c.heights_profile)
+        assert np.all(np.isnan(raw['dist'][idx, n:]))
+        o = scatter.radar_observables(subs, olut, conf, return_sz=True, doppler=False)
+        szt = np.nan_to_num(o.sz_total.astype(np.float64))
+        scatter.cut_at_sensitivity([o], conf)
+        assert np.array_equal(raw['mask'][idx, :n], o.mask)
+        for k in ['ZH', 'ZV', 'ZDR', 'RHOHV', 'KDP', 'ATT_H', 'ATT_V', 'DELTA_HV', 'PHIDP']:
+            atol = _pol_tolerances(k, o, szt, conf)
+            _cases.assert_close_nan(raw[k][idx, :n], o.values[k], rtol=RTOL, atol=atol,
+                                    name='%s ray %d' % (k, idx))
+            assert np.all(np.isnan(raw[k][idx, n:]))
+        n_valid_total += int(np.isfinite(o.values['ZH']).sum())
+    assert n_valid_total > 200
+    # packaging: beams start at the ground, gates under the topography removed
+    assert np.isfinite(out.lats[0, 0, 0]) and out.bin_surface.shape == (N, M)
+    op.close()
+
+
+def test_host_supplied_paths_equal_builtin_model():
+    """CPOL_GEOM_HOST_PATHS with the 4/3-earth paths computed on the host gives
+    bit-identical results to the built-in model (the plumbing the Zeng & Blahak
+    ODE refraction uses)."""
+    name = 'c4_subbeams'
+    conf, az, el, ocube, luts, cube = _cases.radial_case(name)
+    over = _cases.gen_golden.radial_case_inputs(name)[0]
+    from cosmo_pol_amd import RadarOperator
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar')
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    azs, els = np.array([az, az + 40.0]), np.array([el, el + 1.5])
+    ref = op.simulate_rays(azs, els)
+    from cosmo_pol_oracle import constants as OK
+    pts_hor, pts_ver, w, keep = beam.gauss_hermite_subbeams(conf)
+    rr = OK.Derived(conf).RANGE_RADAR
+    paths = np.zeros((2, len(pts_ver), 3, len(rr)), dtype=np.float32)
+    for r in range(2):
+        for j, pt in enumerate(pts_ver):
+            paths[r, j] = np.stack(beam.trajectory_4_3(rr, pt + els[r], conf['radar']['coords']))
+    got = op.simulate_rays(azs, els, paths=paths)
+    for k in ['ZH', 'ZDR', 'KDP', 'PHIDP', 'RHOHV', 'dist', 'heights', 'mask']:
+        assert np.array_equal(got[k], ref[k], equal_nan=True), k
+    op.close()
