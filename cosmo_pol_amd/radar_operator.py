@@ -207,7 +207,8 @@ class RadarOperator(object):
         scheme = '2mom' if two_mom else '1mom'
         attrs = {'z-levels': zlevels, 'proj_info': proj_info, 'resolution': resolution,
                  'time': time}
-        self.dic_vars = {k: ModelVar(k, v, attrs) for k, v in data.items()}
+        self.dic_vars = {k: ModelVar(k, v, attrs) for k, v in data.items() if k != 'N'}
+        self.N = ModelVar('N', data['N'], attrs) if 'N' in data else 0     # refractivity
         self._zlevels = zlevels
         self._proj = proj_info
         self._res = resolution
@@ -255,13 +256,23 @@ class RadarOperator(object):
         `paths`: optional float32 [n_rays, n_vnodes, 3, n_gates] host-computed ray
         paths (s, h, e_deg) replacing the 4/3-earth model (CPOL_GEOM_HOST_PATHS)."""
         conf = self.__config
-        if conf['refraction']['scheme'] != 1 and paths is None:
-            raise NotImplementedError('refraction scheme 2 (Zeng & Blahak ODE) needs host-computed '
-                                      'ray paths: pass paths=... (SURVEY.md 8(f) rank 3)')
         coords = conf['radar']['coords']
         if coords[2] > K.MAX_MODEL_HEIGHT:
             raise NotImplementedError('spaceborne geometry: use get_GPM_swath')
         rr = self.constants.RANGE_RADAR
+        if conf['refraction']['scheme'] == 2 and paths is None:
+            if self.N is None or isinstance(self.N, int):
+                # reference: falls back to the 4/3 model with a notice
+                # (interpolation.py:138-145, radar_operator.py:237-247)
+                print('Refraction scheme 2 needs the refractivity N as an additional model '
+                      'variable; 4/3 Earth model will be used instead...')
+            else:
+                from . import refraction
+                sub = geo.gauss_hermite_subbeams(conf)
+                h_col, n_col = refraction.refractivity_column(
+                    self.N.data, self._zlevels, self._proj, self._res, coords,
+                    conf['radar'].get('type', 'ground'))
+                paths = refraction.ode_paths(rr, elevations, sub.pts_ver, coords, h_col, n_col)
         mode = N.GEOM_GROUND_43 if paths is None else N.GEOM_HOST_PATHS
         return self._run_rays(azimuths, elevations, coords, len(rr), float(rr[0]), mode,
                               device_outputs=device_outputs, apply_sensitivity=apply_sensitivity,

@@ -28,6 +28,7 @@ import ref_shim  # noqa: E402
 
 warnings.simplefilter('ignore')
 
+CUBE_KW = dict(nz=30, res=0.02, half_width_deg=0.55, seed=7)
 ORDER = ['U', 'V', 'W', 'QR_v', 'QS_v', 'QG_v', 'QI_v', 'RHO', 'T']
 ORDER_2MOM = ORDER + ['QH_v', 'QNH_v', 'QNR_v', 'QNS_v', 'QNG_v', 'QNI_v']
 
@@ -100,6 +101,19 @@ def gen_trajectory(out):
         s, h, el = _ref_4_3(rr, e, [46.0, 7.0, 500])
         d['s_%d' % i], d['h_%d' % i], d['e_%d' % i] = s, h, el
     out['trajectory'] = d
+
+
+def refractivity_field(cube):
+    """Synthetic refractivity N (N-units) for the small test cube."""
+    z = cube['zlevels'].astype(np.float64)
+    return (315.0 * np.exp(-z / 7350.0) * (1 + 0.02 * np.sin(z / 900.0))).astype(np.float32)
+
+
+# NB refraction scheme 2 (_ref_ODE, atm_refraction.py:79-148) cannot be pinned by the
+# reference here: under NumPy >= 1.24 its _deriv_z returns a ragged [scalar, 1-element
+# array] list and scipy.integrate.odeint raises ValueError (an ordinary Python error of
+# the reference itself).  The oracle restatement (cosmo_pol_oracle/refraction_ode.py)
+# returns scalars; product and oracle are compared with each other in tests/.
 
 
 def gen_quadrature(out):
@@ -234,7 +248,6 @@ RADIAL_CASES = {
                  'integration': {'nh_GH': 1, 'nv_GH': 1}}, 75.0, 8.0, ('R', 'S', 'G', 'I'), True),
 }
 
-CUBE_KW = dict(nz=30, res=0.02, half_width_deg=0.55, seed=7)
 LUT_KW = dict(seed=20260301, n_e=8, n_t=None)
 
 

@@ -115,6 +115,10 @@ class _Geod(object):
 
 def _wgs_to_cosmo(coords, sp):
     from cosmo_pol_oracle import geodesy
+    if len(coords) == 3 and np.isscalar(coords[0]):
+        # single point [lat, lon, alt] (atm_refraction.py:101): 1-D (rlat, rlon)
+        return geodesy.wgs_to_rotated(np.array([float(coords[0])]), np.array([float(coords[1])]),
+                                      float(sp[0]), float(sp[1]))[0]
     lats, lons = coords
     return geodesy.wgs_to_rotated(np.asarray(lats, dtype=np.float64),
                                   np.asarray(lons, dtype=np.float64),

@@ -110,3 +110,47 @@ def test_host_supplied_paths_equal_builtin_model():
     for k in ['ZH', 'ZDR', 'KDP', 'PHIDP', 'RHOHV', 'dist', 'heights', 'mask']:
         assert np.array_equal(got[k], ref[k], equal_nan=True), k
     op.close()
+
+
+def test_refraction_scheme_2_vs_oracle():
+    """refraction/scheme: 2 -> host ODE ray paths -> GPU; against the oracle fed
+    with its own restatement of the ODE (parity unpinned vs the reference, whose
+    _ref_ODE raises under NumPy >= 1.24)."""
+    from cosmo_pol_amd import RadarOperator
+    from cosmo_pol_oracle import refraction_ode
+    from cosmo_pol_oracle import constants as OK
+    from test_gpu_parity import _pol_tolerances
+    name = 'c2_rsg'
+    conf, az, el, ocube, luts, cube = _cases.radial_case(name)
+    over = _cases.gen_golden.radial_case_inputs(name)[0]
+    over = {k: dict(v) for k, v in over.items()}
+    over['refraction'] = {'scheme': 2}
+    over['integration'] = {'nh_GH': 1, 'nv_GH': 3}
+    conf = ocfg.make_config(over)
+    Nf = _cases.gen_golden.refractivity_field(cube)
+    data = dict(cube['data'])
+    data['N'] = Nf
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar')
+    op.load_model_arrays(data, cube['zlevels'], cube['proj_info'], cube['resolution'])
+    res = op.simulate_rays([az], [el], apply_sensitivity=False)
+    rr = OK.Derived(conf).RANGE_RADAR
+    pts_hor, pts_ver, w, keep = beam.gauss_hermite_subbeams(conf)
+    trajs = [refraction_ode.trajectory_ode(rr, pt + el, conf['radar']['coords'], Nf, cube['zlevels'],
+                                           cube['proj_info'], cube['resolution']) for pt in pts_ver]
+    subs = beam.interpolate_radial(ocube, conf, az, el, trajs=trajs)
+    o = scatter.radar_observables(subs, {h: _cases.as_oracle_lut(l) for h, l in luts.items()}, conf,
+                                  return_sz=True)
+    c = subs[int(len(subs) / 2)]
+    np.testing.assert_allclose(res['heights'][0], c.heights_profile, rtol=2e-7)
+    szt = np.nan_to_num(o.sz_total.astype(np.float64))
+    for k in ['ZH', 'ZV', 'ZDR', 'RHOHV', 'KDP', 'ATT_H', 'ATT_V', 'PHIDP']:
+        # ray paths may differ by a float32 ulp between the two ODE codes: 1e-4 here
+        atol = _pol_tolerances(k, o, szt, conf)
+        _cases.assert_close_nan(res[k][0], o.values[k], rtol=1e-4, atol=10 * np.asarray(atol), name=k)
+    # and the paths really differ from the 4/3 model
+    over43 = {k: dict(v) for k, v in over.items()}
+    over43['refraction'] = {'scheme': 1}
+    op.config = over43
+    res43 = op.simulate_rays([az], [el], apply_sensitivity=False)
+    assert not np.array_equal(res43['heights'], res['heights'])
+    op.close()
