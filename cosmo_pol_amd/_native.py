@@ -45,6 +45,7 @@ class HydroDesc(C.Structure):
         ('r_dmin', C.c_double), ('r_dmax', C.c_double), ('s_dmin', C.c_double),
         ('s_dmax', C.c_double),
         ('solid_rule', C.c_int32), ('uniform_grid', C.c_int32),
+        ('numeric_intv', C.c_int32), ('pad_', C.c_int32),
     ]
 
 
@@ -62,6 +63,7 @@ class SweepParams(C.Structure):
         ('sin_u1', C.c_double), ('cos_u1', C.c_double),
         ('wavelength', C.c_double), ('k_squared', C.c_double), ('radial_res', C.c_double),
         ('c_zh', C.c_double),
+        ('var_u', C.c_int32), ('var_v', C.c_int32), ('var_w', C.c_int32), ('pad2_', C.c_int32),
     ]
 
 

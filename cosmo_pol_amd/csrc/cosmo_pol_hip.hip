@@ -54,7 +54,7 @@ struct cpol_ctx {
     // per-sweep work buffers (grow only)
     DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
-        b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err, b_pos;
+        b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err, b_pos, b_vn, b_icefirst, b_rvel;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
@@ -152,6 +152,7 @@ void cpol_destroy(cpol_ctx *ctx)
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_cursor, &ctx->b_units,
                      &ctx->b_urange, &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_err, &ctx->b_pos,
+                     &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel,
                      &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model};
     for (DevBuf *b : all) free_buf(*b);
     for (auto &b : ctx->b_out) free_buf(b);
@@ -310,13 +311,18 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
         ctx->err = "cpol_stage_hydro: gamma family needs pre[] and dnu[]";
         return CPOL_ERR_ARG;
     }
+    if (desc->psd_family == CPOL_PSD_GAMMA && desc->numeric_intv &&
+        (desc->uniform_grid || !aux || n_aux < 3 * desc->n_d + 1)) {
+        ctx->err = "cpol_stage_hydro: numeric_intv needs aux[3*n_d+1] and excludes uniform_grid";
+        return CPOL_ERR_ARG;
+    }
     if (desc->psd_family == CPOL_PSD_GAMMA && desc->uniform_grid &&
         (!aux || n_aux < desc->n_d + 1 || desc->n_d % CPOL_PSD_WAVES != 0)) {
         ctx->err = "cpol_stage_hydro: uniform_grid needs aux[1 + n_d] and n_d % 8 == 0";
         return CPOL_ERR_ARG;
     }
-    if (desc->psd_family == CPOL_PSD_ICE_FIELD && (!aux || n_aux < 3 * desc->n_d + 1)) {
-        ctx->err = "cpol_stage_hydro: ice family needs aux[3*n_d+1]";
+    if (desc->psd_family == CPOL_PSD_ICE_FIELD && (!aux || n_aux < 4 * desc->n_d + 1)) {
+        ctx->err = "cpol_stage_hydro: ice family needs aux[4*n_d+1]";
         return CPOL_ERR_ARG;
     }
     h.n_par = n_par_of(desc->rule);
@@ -448,6 +454,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_perm, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_res, (size_t)n_hyd * n_sbg * CPOL_N_SZ * sizeof(double));
     ENSURE(ctx->b_err, sizeof(int));
+    const bool doppler = p->simulate_doppler != 0;
+    if (doppler) {
+        ENSURE(ctx->b_vn, (size_t)n_hyd * n_sbg * 2 * sizeof(double));
+        ENSURE(ctx->b_icefirst, (size_t)n_rays * n_sub * sizeof(IceFirst));
+        ENSURE(ctx->b_rvel, (size_t)n_rg * sizeof(double));
+    }
     // output staging (device): 9 float fields + PHIDP
     enum { O_ZH, O_ZV, O_ZDR, O_KDP, O_DHV, O_PHIDP, O_RHOHV, O_ATTH, O_ATTV, O_MASK, O_LAT, O_LON,
            O_DIST, O_HGT };
@@ -531,6 +543,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ca.n_sbg = n_sbg;
     ca.with_melting = p->with_melting;
     ca.var_qr = ca.var_qs = ca.var_qg = -1;
+    ca.doppler = doppler ? 1 : 0;
     for (int j = 0; j < n_hyd; ++j) {
         const cpol_hydro_desc &d = ctx->hs.h[j].d;
         if (d.q_source != CPOL_Q_MODEL) continue;
@@ -569,6 +582,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         pa.perm = (const int *)ctx->b_perm.p;
         pa.par = (const double *)ctx->b_par.p;
         pa.res = (double *)ctx->b_res.p;
+        pa.vn = doppler ? (double *)ctx->b_vn.p : nullptr;
         pa.n_sbg = n_sbg;
         bool need[4] = {false, false, false, false};
         for (int j = 0; j < n_hyd; ++j) {
@@ -612,12 +626,39 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     double sum_w = 0;
     for (int s = 0; s < n_sub; ++s) sum_w += t->sub_w[s];
     fa.sum_w = sum_w;
+    fa.RVEL = nullptr;
+    if (doppler) {
+        fa.RVEL = (double *)ctx->b_rvel.p;
+        fa.par = (const double *)ctx->b_par.p;
+        fa.vn = (const double *)ctx->b_vn.p;
+        fa.ice_first = (const IceFirst *)ctx->b_icefirst.p;
+        fa.geo = (const double *)ctx->b_geo.p;
+        fa.sub_h = (const int *)ctx->b_subh.p;
+        fa.elev = (const float *)ctx->b_elev.p;
+        fa.n_h = n_h;
+        fa.var_u = p->var_u; fa.var_v = p->var_v; fa.var_w = p->var_w;
+        if (fa.var_u < 0 || fa.var_v < 0 || fa.var_w < 0 || fa.var_u >= n_vars ||
+            fa.var_v >= n_vars || fa.var_w >= n_vars) {
+            ctx->err = "cpol_run_sweep: simulate_doppler needs var_u / var_v / var_w";
+            return CPOL_ERR_ARG;
+        }
+        for (int j = 0; j < n_hyd; ++j) {
+            const cpol_hydro_desc &d = ctx->hs.h[j].d;
+            fa.vsrc[j] = d.psd_family == CPOL_PSD_MELTING ? 1
+                       : (d.psd_family == CPOL_PSD_ICE_FIELD || d.numeric_intv) ? 2 : 0;
+            if (fa.vsrc[j] == 2)
+                hipLaunchKernelGGL(k_ice_first, dim3(n_rays * n_sub), dim3(64), 0, st,
+                                   (const int *)ctx->b_key.p + (long)j * n_sbg,
+                                   (const double *)ctx->b_vn.p + (long)j * n_sbg * 2,
+                                   (IceFirst *)ctx->b_icefirst.p, ng);
+        }
+    }
     hipLaunchKernelGGL(k_final_gate, dim3(cdiv(n_rg, 256)), dim3(256), 0, st, fa);
 
     ScanRayArgs ra{};
     ra.ZH = fa.ZH; ra.ZV = fa.ZV; ra.ZDR = fa.ZDR; ra.KDP = fa.KDP; ra.DELTA_HV = fa.DELTA_HV;
     ra.PHIDP = (float *)ctx->b_out[O_PHIDP].p; ra.RHOHV = fa.RHOHV; ra.ATT_H = fa.ATT_H;
-    ra.ATT_V = fa.ATT_V; ra.RVEL = nullptr;
+    ra.ATT_V = fa.ATT_V; ra.RVEL = fa.RVEL;
     ra.sens_thr = cut ? (const double *)ctx->b_sens.p : nullptr;
     ra.n_rays = n_rays; ra.n_gates = ng; ra.with_attenuation = p->with_attenuation;
     ra.radial_res = (float)p->radial_res;
@@ -638,6 +679,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if ((rc = copy_out(ctx, out->RHOHV, ctx->b_out[O_RHOHV].p, fb, dev))) return rc;
     if ((rc = copy_out(ctx, out->ATT_H, ctx->b_out[O_ATTH].p, fb, dev))) return rc;
     if ((rc = copy_out(ctx, out->ATT_V, ctx->b_out[O_ATTV].p, fb, dev))) return rc;
+    if (doppler && (rc = copy_out(ctx, out->RVEL, ctx->b_rvel.p, dbb, dev))) return rc;
     if ((rc = copy_out(ctx, out->mask, ctx->b_out[O_MASK].p, dbb, dev))) return rc;
     if ((rc = copy_out(ctx, out->lats, ctx->b_out[O_LAT].p, dbb, dev))) return rc;
     if ((rc = copy_out(ctx, out->lons, ctx->b_out[O_LON].p, dbb, dev))) return rc;

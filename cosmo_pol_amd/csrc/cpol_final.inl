@@ -14,6 +14,45 @@
 // float32 first); libm-type float32 functions are evaluated in float64 and
 // rounded once, which reproduces a correctly rounded float32 libm.
 
+// IceParticle.integrate_V sums over ALL valid gates of a sub-beam and the result is
+// zero-padded into the first valid gate (hydrometeors.py:1256-1275 +
+// utilities.py:231-261): per (ray, sub-beam) totals and the gate that receives them
+struct IceFirst {
+    int first_gate;
+    int pad;
+    double v, n;
+};
+
+// one wavefront per (ray, sub-beam): ordered (deterministic) reduction over the gates
+__global__ __launch_bounds__(64) void k_ice_first(const int *__restrict__ key_j,
+                                                   const double *__restrict__ vn_j,
+                                                   IceFirst *__restrict__ out, int n_gates)
+{
+    const long rs = blockIdx.x;
+    const int lane = threadIdx.x;
+    double v = 0.0, nn = 0.0;
+    int first = 0x7fffffff;
+    for (int g = lane; g < n_gates; g += 64) {
+        const long sbg = rs * n_gates + g;
+        if (key_j[sbg] >= 0) {
+            v += vn_j[sbg * 2];
+            nn += vn_j[sbg * 2 + 1];
+            first = min(first, g);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        v += shfl_f64(v, (lane + off) & 63) * ((lane < off) ? 1.0 : 0.0);
+        nn += shfl_f64(nn, (lane + off) & 63) * ((lane < off) ? 1.0 : 0.0);
+        first = min(first, __shfl(first, (lane + off) & 63));
+    }
+    if (lane == 0) {
+        IceFirst r;
+        r.first_gate = first; r.pad = 0; r.v = v; r.n = nn;
+        out[rs] = r;
+    }
+}
+
 struct FinalArgs {
     const double *res;          // [n_hydro][n_sbg][12]
     const int *key;             // [n_hydro][n_sbg]
@@ -28,6 +67,16 @@ struct FinalArgs {
     int n_rays, n_gates, n_sub, n_hydro, n_vars;
     float c_zh, c_kdp, c_2w;    // wavelength^4/(pi^5 K^2), 1e-3*(180/pi)*wavelength, 2*wavelength
     double sum_w;
+    // Doppler scheme 1 (radial velocity)
+    double *RVEL;               // [n_rg] or NULL
+    const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg] (gamma: [2] = v, [3] = n)
+    const double *vn;           // [n_hydro][n_sbg][2] (melting, ice)
+    const IceFirst *ice_first;  // [n_rays*n_sub]
+    const double *geo;          // [n_rays][n_h][8]: sin / cos of the sub-beam azimuth
+    const int *sub_h;
+    const float *elev;          // folded elevation per sub-beam gate (quirk Q8)
+    int n_h, var_u, var_v, var_w;
+    int vsrc[CPOL_MAX_HYDRO];   // 0: par (analytic), 1: vn per gate, 2: ice (first valid gate)
 };
 
 __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
@@ -95,6 +144,48 @@ __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
     const float aa = t47 * t47 + t65 * t65;
     a.RHOHV[rg] = sqrtf(aa / (b * cc));
     a.DELTA_HV[rg] = (float)atan2((double)(tot[5] - tot[6]), (double)(-tot[4] - tot[7]));
+
+    // ---- radial velocity, Doppler scheme 1 (doppler_scatter.py:276-281, 313-333, 418-420) ----
+    if (a.RVEL) {
+        double rv = __builtin_nan(""), tw = 0.0;
+        for (int s = 0; s < a.n_sub; ++s) {
+            const long sbg = sbg0 + (long)s * a.n_gates;
+            double v = 0.0, nn = 0.0;
+            for (int j = 0; j < a.n_hydro; ++j) {
+                if (a.key[(long)j * n_sbg + sbg] < 0) continue;
+                double vj, nj;
+                if (a.vsrc[j] == 0) {
+                    const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n_sbg + sbg;
+                    vj = P[2 * n_sbg]; nj = P[3 * n_sbg];
+                } else if (a.vsrc[j] == 1) {
+                    vj = a.vn[((long)j * n_sbg + sbg) * 2];
+                    nj = a.vn[((long)j * n_sbg + sbg) * 2 + 1];
+                } else {
+                    const IceFirst f = a.ice_first[(long)ray * a.n_sub + s];
+                    const bool here = (f.first_gate == gate);
+                    vj = here ? f.v : 0.0;
+                    nj = here ? f.n : 0.0;
+                }
+                if (vj == vj) v += vj;                  // nansum_arr
+                if (nj == nj) nn += nj;
+            }
+            const double vh = v / nn;
+            const double *gc = a.geo + ((long)ray * a.n_h + a.sub_h[s]) * 8;
+            const float th = a.elev[sbg] * 0.017453292f;          // np.deg2rad on float32
+            const double ct = (double)(float)cos((double)th), st = (double)(float)sin((double)th);
+            const double U = (double)a.vals[(long)a.var_u * n_sbg + sbg];
+            const double V = (double)a.vals[(long)a.var_v * n_sbg + sbg];
+            const double W = (double)a.vals[(long)a.var_w * n_sbg + sbg];
+            const double proj = (U * gc[0] + V * gc[1]) * ct + (W - vh) * st;   // proj_vel :46-47
+            const double w = a.sub_w[s];
+            if (proj == proj) tw += w;
+            double x = (rv == rv) ? rv : 0.0;
+            double y = proj * w;
+            if (!(y == y)) y = 0.0;
+            rv = x + y;
+        }
+        a.RVEL[rg] = rv / tw;
+    }
 
     // ---- radial mask (doppler_scatter.py:472-477) ----
     double msum = 0.0;

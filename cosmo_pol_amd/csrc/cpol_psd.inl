@@ -139,6 +139,7 @@ struct ClassifyArgs {
     long n_sbg;
     int with_melting;
     int var_qr, var_qs, var_qg;
+    int doppler;                 // also store the analytic fall-speed moments (integrate_V)
 };
 
 #define CPOL_MAX_PAR 6
@@ -196,28 +197,35 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             key = h.key_base + eb * d.n_t + tb;
             double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
             const double q = (double)qm;
+            double lamf = 0.0, n0v = 0.0, qnv = 0.0;   // final lambda / N0 (get_N units)
             switch (d.rule) {
             case CPOL_RULE_RAIN_1MOM:
             case CPOL_RULE_GRAUPEL_1MOM:
-                P[0] = pow(d.lambda_factor / q, d.lam_exponent);
+                lamf = pow(d.lambda_factor / q, d.lam_exponent);
+                n0v = d.n0_fixed;
+                P[0] = lamf;
                 P[n] = 1.0;                                   // N0 folded into pre[]
                 break;
             case CPOL_RULE_SNOW_1MOM: {
                 // hydrometeors.py:896-899: float32 chain, then float64 from lambda_factor on
                 float n0 = 13.5f * (565000.0f * exp_f32(-0.107f * (T - 273.15f))) / 1000.0f;
                 float an0 = (float)d.a * n0;
-                P[0] = pow((double)an0 * d.lambda_factor / q, d.lam_exponent);
-                P[n] = (double)n0;
+                lamf = pow((double)an0 * d.lambda_factor / q, d.lam_exponent);
+                n0v = (double)n0;
+                P[0] = lamf;
+                P[n] = n0v;
                 break; }
             case CPOL_RULE_TWO_MOMENT: {
                 // hydrometeors.py:231-246
-                const double qn = (double)a.vals[d.var_qn * n + i];
-                double xm = q / (qn + 2.220446049250313e-16);
+                qnv = (double)a.vals[d.var_qn * n + i];
+                double xm = q / (qnv + 2.220446049250313e-16);
                 xm = fmin(fmax(xm, d.x_min), d.x_max);
                 double lam = pow(d.lambda_factor * xm, d.lam_exponent);
-                double n0 = (d.nu / d.ntot_factor) * qn * pow(lam, d.n0_exponent);
-                P[0] = lam * d.c_lam;
-                P[n] = n0 * d.c_n0;
+                double n0 = (d.nu / d.ntot_factor) * qnv * pow(lam, d.n0_exponent);
+                lamf = lam * d.c_lam;
+                n0v = n0 * d.c_n0;
+                P[0] = lamf;
+                P[n] = n0v;
                 break; }
             case CPOL_RULE_ICE_1MOM: {
                 // hydrometeors.py:1277-1299 (float32 polynomials), :1320-1328
@@ -246,6 +254,13 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 // (the dry partner's PSD does not enter get_N, hydrometeors.py:372-390)
                 break; }
             default: break;
+            }
+            if (a.doppler && d.psd_family == CPOL_PSD_GAMMA) {
+                // _Hydrometeor.integrate_V (hydrometeors.py:178-199): analytic moments
+                P[2 * n] = d.vel_factor * n0v * d.alpha / d.nu
+                           * pow(lamf, -(d.beta + d.mu + 1) / d.nu);
+                P[3 * n] = (d.rule == CPOL_RULE_TWO_MOMENT)
+                    ? qnv : d.ntot_factor * n0v / d.nu * pow(lamf, -(d.mu + 1) / d.nu);
             }
         }
         rank_reset(sh);
@@ -364,6 +379,7 @@ struct PsdArgs {
     const int *perm;
     const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg]
     double *res;                // [n_hydro][n_sbg][12]   sum_k sz[k][c] N[k] * dD
+    double *vn;                 // [n_hydro][n_sbg][2]    integral of V N dD, of N dD (or NULL)
     long n_sbg;
 };
 
@@ -410,7 +426,7 @@ template <int MODE>
 __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a)
 {
     // [wave][value][lane]; value 12 = normalisation sum (ice, melting)
-    __shared__ double s_part[CPOL_PSD_WAVES][CPOL_N_SZ + 1][CPOL_WAVE];
+    __shared__ double s_part[CPOL_PSD_WAVES][CPOL_N_SZ + 3][CPOL_WAVE];
     const int u = blockIdx.x;
     if ((long long)u >= a.totals[1]) return;                // block-uniform
     const WorkUnit *up = a.units + u;
@@ -438,6 +454,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
 #pragma unroll
     for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = 0.0;
     double msum = 0.0;       // normalisation integral (ice, melting)
+    double vsum = 0.0, nsum = 0.0;   // fall-speed moments (numeric integrate_V: ice, melting)
     double scale = 1.0;      // applied by the combining thread
 
     if (MODE == PSD_MODE_GAMMA_EXP) {
@@ -454,6 +471,17 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
+        }
+        if (d.numeric_intv && a.vn) {
+            // 2-moment ice: IceParticle.integrate_V on its own linspace grid
+            const double *__restrict__ pn = h.aux, *__restrict__ dn = h.aux + n_d;
+            const double *__restrict__ Vn = h.aux + 2 * n_d;
+#pragma unroll 1
+            for (int k = k0; k < k1; ++k) {
+                const double nk = (N0 * pn[k]) * exp(-(lam * dn[k]));
+                vsum += nk * Vn[k];
+                nsum += nk;
+            }
         }
     } else if (MODE == PSD_MODE_GAMMA_UNIFORM) {
         // nu == 1 on a (nearly) uniform diameter grid: exp(-lambda D_k) follows from
@@ -489,10 +517,14 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
         const double *__restrict__ Dl = h.aux;
         const double *__restrict__ Dn = h.aux + n_d;
         const double *__restrict__ aDb = h.aux + 2 * n_d;
+        const double *__restrict__ Vn = h.aux + 3 * n_d + 1;   // alpha * Dn^beta (get_V)
 #pragma unroll 1
         for (int k = k0; k < k1; ++k) {
             const double xn = lam * Dn[k] / 1000.0;
-            msum += aDb[k] * (N0 * phi23(xn));              // hydrometeors.py:1333-1337
+            const double phn = phi23(xn);
+            msum += aDb[k] * (N0 * phn);                    // hydrometeors.py:1333-1337
+            vsum += phn * Vn[k];                            // hydrometeors.py:1267-1271
+            nsum += phn;
             const double xl = lam * Dl[k] / 1000.0;
             const double ph = phi23(xl);
             const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
@@ -524,6 +556,8 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             const double V = it.phi * Vr + (1 - it.phi) * Vd;                  // :431-439
             const double Nraw = Nr * Vr / V * dDr;                             // :386-387
             msum += Nraw * M;                                                  // :478
+            vsum += Nraw * V;                                                  // :457
+            nsum += Nraw;                                                      // :458
             const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], Nraw, acc[c]);
@@ -533,7 +567,11 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
     // ---- combine the 8 partial sums per (item, column) in wave order ----
 #pragma unroll
     for (int c = 0; c < CPOL_N_SZ; ++c) s_part[wave][c][lane] = acc[c];
-    if (MODE == PSD_MODE_ICE || MODE == PSD_MODE_MELTING) s_part[wave][CPOL_N_SZ][lane] = msum;
+    if (MODE == PSD_MODE_ICE || MODE == PSD_MODE_MELTING || MODE == PSD_MODE_GAMMA_EXP) {
+        s_part[wave][CPOL_N_SZ][lane] = msum;
+        s_part[wave][CPOL_N_SZ + 1][lane] = vsum;
+        s_part[wave][CPOL_N_SZ + 2][lane] = nsum;
+    }
     __syncthreads();
     for (int idx = threadIdx.x; idx < CPOL_N_SZ * CPOL_WAVE; idx += CPOL_PSD_THREADS) {
         const int c = idx >> 6, l = idx & 63;
@@ -550,6 +588,12 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             const double qm_est = m * h.aux[3 * n_d];
             scale = Pl[n] / qm_est * Pl[2 * n];             // N0 / QM_est * QM (:1339)
             sum = (scale * sum) * d.dD;
+            if (a.vn && c < 2) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][CPOL_N_SZ + 1 + c][l];
+                a.vn[((long)j * n + sb) * 2 + c] = (scale * t) * h.aux[3 * n_d];
+            }
         } else if (MODE == PSD_MODE_MELTING) {
             double m = 0.0;
 #pragma unroll
@@ -562,8 +606,20 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             const double dDl = (d_min + step * 1.0) - (d_min + step * 0.0);
             const double prop = Pl[0] / (m * dDl);          // q / integrate_M (:1428)
             sum = (prop * sum) * dDl;
+            if (a.vn && c < 2) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][CPOL_N_SZ + 1 + c][l];
+                a.vn[((long)j * n + sb) * 2 + c] = (prop * t) * dDl;
+            }
         } else {
             sum = sum * d.dD;
+            if (MODE == PSD_MODE_GAMMA_EXP && d.numeric_intv && a.vn && c < 2) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][CPOL_N_SZ + 1 + c][l];
+                a.vn[((long)j * n + sb) * 2 + c] = t * h.aux[3 * n_d];
+            }
         }
         a.res[((long)j * n + sb) * CPOL_N_SZ + c] = sum;
     }

@@ -117,8 +117,10 @@ def build_hydro(h, scheme, lut, var_index):
         Dn = np.linspace(D[0], D[-1], n_d)
         aDb = c['a'] * Dn ** c['b']
         dDn = Dn[1] - Dn[0]
+        Vn = c['alpha'] * Dn ** c['beta']                # get_V on the same grid (:1267-1270)
         aux = np.concatenate([D.astype(np.float64), np.asarray(Dn, dtype=np.float64),
-                              np.asarray(aDb, dtype=np.float64), [np.float64(dDn)]])
+                              np.asarray(aDb, dtype=np.float64), [np.float64(dDn)],
+                              np.asarray(Vn, dtype=np.float64)])
         return d, table, None, None, aux
 
     d.psd_family = N.PSD_GAMMA
@@ -149,6 +151,15 @@ def build_hydro(h, scheme, lut, var_index):
         pre = np.asarray(D ** mu, dtype=np.float64)
     else:
         raise ValueError('hydrometeor %s does not exist in the %s scheme' % (h, scheme))
+    if scheme == '2mom' and h == 'I':
+        # IceParticle.integrate_V is numeric in both schemes (hydrometeors.py:1256-1275)
+        Dn = np.linspace(D[0], D[-1], n_d)
+        d.numeric_intv, d.uniform_grid = 1, 0
+        aux = np.concatenate([np.asarray(Dn ** mu, dtype=np.float64),
+                              np.asarray(Dn ** nu, dtype=np.float64),
+                              np.asarray(c['alpha'] * Dn ** c['beta'], dtype=np.float64),
+                              [np.float64(Dn[1] - Dn[0])]])
+        return d, table, pre, dnu, aux
     aux = _uniform_grid_aux(d, D, nu, n_d)
     return d, table, pre, dnu, aux
 

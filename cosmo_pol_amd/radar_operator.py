@@ -24,6 +24,7 @@ from . import hydrometeors as hyd
 from .lut import load_all_lut
 
 RADAR_FIELDS = ['ZH', 'ZDR', 'ZV', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V']
+DOPPLER_FIELDS = ['RVEL']
 _DB_FIELDS = ('ZDR', 'ZV', 'ZH')
 
 
@@ -298,7 +299,15 @@ class RadarOperator(object):
         want_model = self.output_variables in ('all', 'only_model')
         p.integrate_model = int(want_model)
         p.outputs_on_device = int(device_outputs is not None)
-        p.simulate_doppler = 0
+        # Doppler scheme 1 (analytic mean fall speed); none for GPM (doppler_scatter.py:83-87)
+        doppler = (conf['doppler']['scheme'] == 1 and conf['radar'].get('type') != 'GPM'
+                   and mode != N.GEOM_SPACEBORNE)
+        if conf['doppler']['scheme'] in (2, 3) and not getattr(self, '_warned_doppler', False):
+            print('Doppler schemes 2 and 3 are not implemented: RVEL is not simulated')
+            self._warned_doppler = True
+        p.simulate_doppler = int(doppler)
+        vi = {v: i for i, v in enumerate(self._staged_vars)}
+        p.var_u, p.var_v, p.var_w = vi['U'], vi['V'], vi['W']
         p.geometry_mode = mode
         if site is None:
             re, ke = geo.earth_radius_for_refraction(coords)
@@ -342,6 +351,8 @@ class RadarOperator(object):
             shape = (n_rays, n_gates)
             for k in RADAR_FIELDS:
                 res[k] = np.empty(shape, dtype=np.float32)
+            if doppler:
+                res['RVEL'] = np.empty(shape, dtype=np.float64)
             res['mask'] = np.empty(shape, dtype=np.float64)
             res['lats'] = np.empty(shape, dtype=np.float64)
             res['lons'] = np.empty(shape, dtype=np.float64)
@@ -369,6 +380,8 @@ class RadarOperator(object):
         fields = ([(k, np.float32) for k in RADAR_FIELDS] + [('dist', np.float32),
                   ('heights', np.float32), ('mask', np.float64), ('lats', np.float64),
                   ('lons', np.float64)])
+        if self.__config['doppler']['scheme'] == 1:
+            fields.append(('RVEL', np.float64))
         n_gates = len(self.constants.RANGE_RADAR)
         dev = torch.device('cuda', self.device)
         return D.simulate_sharded(lambda a, e: self.simulate_rays(a, e), az, el, fields, n_gates,
@@ -377,8 +390,9 @@ class RadarOperator(object):
     def _package(self, res, az, el):
         fields = {}
         if self.output_variables in ('all', 'only_radar'):
-            for k in RADAR_FIELDS:
-                fields[k] = res[k]
+            for k in RADAR_FIELDS + DOPPLER_FIELDS:
+                if k in res:
+                    fields[k] = res[k]
         if self.output_variables in ('all', 'only_model'):
             for i, name in enumerate(self._staged_vars):
                 fields[name] = res['model_vars'][i]

@@ -106,6 +106,11 @@ typedef struct {
     int32_t solid_rule;         /* CPOL_RULE_SNOW_1MOM or _GRAUPEL_1MOM        */
     int32_t uniform_grid;       /* gamma family, nu == 1: aux[] holds the grid step
                                    and per-bin offsets for the exp recurrence   */
+    int32_t numeric_intv;       /* gamma family whose fall-speed moments are summed
+                                   numerically over ALL gates (2-moment ice,
+                                   hydrometeors.py:1256-1275): aux[] = D^mu, D^nu,
+                                   V(D) on the linspace grid, then its step       */
+    int32_t pad_;
 } cpol_hydro_desc;
 
 typedef struct {
@@ -126,6 +131,8 @@ typedef struct {
     double  k_squared;
     double  radial_res;         /* m                                            */
     double  c_zh;               /* wavelength^4 / (pi^5 K^2)                     */
+    int32_t var_u, var_v, var_w; /* staged-variable indices of the wind (RVEL)    */
+    int32_t pad2_;
 } cpol_sweep_params;
 
 /* ray-path models */

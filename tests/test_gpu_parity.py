@@ -152,6 +152,11 @@ def test_radial_vs_reference_golden_and_oracle(golden, name):
         _cases.assert_close_nan(res[k][0], oobs.values[k], rtol=RTOL, atol=atol, name='oracle:' + k)
         _cases.assert_close_nan(res[k][0], g['obs_' + k], rtol=RTOL, atol=atol, name='golden:' + k)
 
+    # ---- radial velocity (Doppler scheme 1): float64, terms of O(10 m/s) that may cancel ----
+    assert 'RVEL' in res
+    _cases.assert_close_nan(res['RVEL'][0], oobs.values['RVEL'], rtol=RTOL, atol=2e-4, name='oracle:RVEL')
+    _cases.assert_close_nan(res['RVEL'][0], g['obs_RVEL'], rtol=RTOL, atol=2e-4, name='golden:RVEL')
+
     # ---- antenna-averaged model variables (integrate_radials) ----
     integ = beam.integrate_subbeams(subs)
     for i, nm in enumerate(names):
@@ -187,6 +192,8 @@ def test_small_ppi_vs_oracle_and_sensitivity():
             atol = _pol_tolerances(k, o, szt, conf)
             _cases.assert_close_nan(raw[k][r], o.values[k], rtol=RTOL, atol=atol,
                                     name='%s az=%g' % (k, az))
+        _cases.assert_close_nan(raw['RVEL'][r], o.values['RVEL'], rtol=RTOL, atol=2e-4,
+                                name='RVEL az=%g' % az)
     assert n_cut > 0, 'the sensitivity cut was not exercised'
     # dB convention of the packaged scan
     zh_db = scan.get_field(0, 'ZH')
