@@ -60,6 +60,9 @@ struct cpol_ctx {
     long last_n_sbg = 0, last_n_rg = 0;
     int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0;
     bool keep_debug = false;
+    int *last_errflag = nullptr;
+    uint64_t tables_version = 0;       // tag of the per-ray tables resident on the device
+    long tables_shape[6] = {0, 0, 0, 0, 0, 0};
     // timing: one event set per sweep since cpol_enable_timing(ctx, 1); elapsed
     // times are collected (averaged) by cpol_counters after the stream drained,
     // so recording does not serialise the timed loop.
@@ -418,21 +421,28 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (n_sbg >= (1L << 31)) { ctx->err = "cpol_run_sweep: too many sub-beam gates in one call"; return CPOL_ERR_ARG; }
     int rc;
 
-    // ---- per-sweep host tables -> device ----
-    if ((rc = upload(ctx, ctx->b_traj_in, t->traj, (size_t)n_rays * n_v * 4 * sizeof(double)))) return rc;
-    if (t->site && (rc = upload(ctx, ctx->b_site, t->site, (size_t)n_rays * 8 * sizeof(double)))) return rc;
+    // ---- per-sweep host tables -> device (skipped when the caller's tag is unchanged) ----
     const int mode = p->geometry_mode;
     if ((mode == CPOL_GEOM_SPACEBORNE && !t->site) || (mode == CPOL_GEOM_HOST_PATHS && !t->paths) ||
         mode < 0 || mode > 2) {
         ctx->err = "cpol_run_sweep: geometry_mode needs tables->site (spaceborne) / tables->paths (host paths)";
         return CPOL_ERR_ARG;
     }
-    if ((rc = upload(ctx, ctx->b_geo, t->geo, (size_t)n_rays * n_h * 8 * sizeof(double)))) return rc;
-    if ((rc = upload(ctx, ctx->b_subh, t->sub_h, (size_t)n_sub * sizeof(int)))) return rc;
-    if ((rc = upload(ctx, ctx->b_subv, t->sub_v, (size_t)n_sub * sizeof(int)))) return rc;
-    if ((rc = upload(ctx, ctx->b_subw, t->sub_w, (size_t)n_sub * sizeof(double)))) return rc;
     const bool cut = p->apply_sensitivity && t->sens_thr;
-    if (cut && (rc = upload(ctx, ctx->b_sens, t->sens_thr, (size_t)ng * sizeof(double)))) return rc;
+    const long shape[6] = {n_rays, ng, n_sub, n_h, n_v, (long)mode * 4 + (t->site ? 2 : 0) + (cut ? 1 : 0)};
+    const bool reuse = t->version != 0 && t->version == ctx->tables_version &&
+                       memcmp(shape, ctx->tables_shape, sizeof shape) == 0;
+    if (!reuse) {
+        if ((rc = upload(ctx, ctx->b_traj_in, t->traj, (size_t)n_rays * n_v * 4 * sizeof(double)))) return rc;
+        if (t->site && (rc = upload(ctx, ctx->b_site, t->site, (size_t)n_rays * 8 * sizeof(double)))) return rc;
+        if ((rc = upload(ctx, ctx->b_geo, t->geo, (size_t)n_rays * n_h * 8 * sizeof(double)))) return rc;
+        if ((rc = upload(ctx, ctx->b_subh, t->sub_h, (size_t)n_sub * sizeof(int)))) return rc;
+        if ((rc = upload(ctx, ctx->b_subv, t->sub_v, (size_t)n_sub * sizeof(int)))) return rc;
+        if ((rc = upload(ctx, ctx->b_subw, t->sub_w, (size_t)n_sub * sizeof(double)))) return rc;
+        if (cut && (rc = upload(ctx, ctx->b_sens, t->sens_thr, (size_t)ng * sizeof(double)))) return rc;
+        ctx->tables_version = t->version;
+        memcpy(ctx->tables_shape, shape, sizeof shape);
+    }
 
     // ---- work buffers ----
     ENSURE(ctx->b_traj, (size_t)n_rays * n_v * 3 * ng * sizeof(float));
@@ -445,7 +455,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_key, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_pos, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_par, (size_t)n_hyd * CPOL_MAX_PAR * n_sbg * sizeof(double));
-    ENSURE(ctx->b_count, (size_t)n_keys * sizeof(int));
+    ENSURE(ctx->b_count, (size_t)(n_keys + 1) * sizeof(int));     // [n_keys] counts + error flag
     ENSURE(ctx->b_offset, (size_t)n_keys * sizeof(int));
     ENSURE(ctx->b_cursor, (size_t)n_keys * sizeof(int));
     const long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
@@ -453,7 +463,6 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_totals, 2 * sizeof(long long));
     ENSURE(ctx->b_perm, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_res, (size_t)n_hyd * n_sbg * CPOL_N_SZ * sizeof(double));
-    ENSURE(ctx->b_err, sizeof(int));
     const bool doppler = p->simulate_doppler != 0;
     if (doppler) {
         ENSURE(ctx->b_vn, (size_t)n_hyd * n_sbg * 2 * sizeof(double));
@@ -469,6 +478,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_out[O_LON], (size_t)n_rg * sizeof(double));
     ENSURE(ctx->b_out[O_DIST], (size_t)n_rg * sizeof(float));
     ENSURE(ctx->b_out[O_HGT], (size_t)n_rg * sizeof(float));
+    // kernels write straight into caller-owned device buffers when given
+    const bool dev = p->outputs_on_device != 0;
+    void *const user_out[14] = {out->ZH, out->ZV, out->ZDR, out->KDP, out->DELTA_HV, out->PHIDP,
+                                out->RHOHV, out->ATT_H, out->ATT_V, out->mask, out->lats, out->lons,
+                                out->dist, out->heights};
+    void *T[14];
+    for (int k = 0; k < 14; ++k) T[k] = (dev && user_out[k]) ? user_out[k] : ctx->b_out[k].p;
     const bool want_szi = ctx->keep_debug;
     if (want_szi) ENSURE(ctx->b_szinteg, (size_t)n_rg * n_hyd * CPOL_N_SZ * sizeof(float));
     const bool want_szt = out->sz_total != nullptr || ctx->keep_debug;
@@ -476,8 +492,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     const bool want_model = p->integrate_model && out->model_vars;
     if (want_model) ENSURE(ctx->b_model, (size_t)n_vars * n_rg * sizeof(double));
 
-    HIPCHK(hipMemsetAsync(ctx->b_count.p, 0, (size_t)n_keys * sizeof(int), st));
-    HIPCHK(hipMemsetAsync(ctx->b_err.p, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(ctx->b_count.p, 0, (size_t)(n_keys + 1) * sizeof(int), st));
+    int *const d_errflag = (int *)ctx->b_count.p + n_keys;
 
     const bool tm = ctx->timing;
     if (tm) {
@@ -516,11 +532,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.mask = (signed char *)ctx->b_mask.p;
     ia.elev = (float *)ctx->b_elev.p;
     ia.coords = ctx->keep_debug ? (float *)ctx->b_coords.p : nullptr;
-    ia.lats = (double *)ctx->b_out[O_LAT].p;
-    ia.lons = (double *)ctx->b_out[O_LON].p;
-    ia.dist = (float *)ctx->b_out[O_DIST].p;
-    ia.heights = (float *)ctx->b_out[O_HGT].p;
-    ia.error_flag = (int *)ctx->b_err.p;
+    ia.lats = (double *)T[O_LAT];
+    ia.lons = (double *)T[O_LON];
+    ia.dist = (float *)T[O_DIST];
+    ia.heights = (float *)T[O_HGT];
+    ia.error_flag = d_errflag;
     ia.n_rays = n_rays; ia.n_gates = ng; ia.n_sub = n_sub; ia.n_h = n_h; ia.n_v = n_v;
     ia.central_sub = n_sub / 2;
     ia.sin_u1 = p->sin_u1; ia.cos_u1 = p->cos_u1; ia.lon1 = p->radar_lon;
@@ -613,11 +629,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     fa.sub_w = (const double *)ctx->b_subw.p;
     fa.sz_integ = want_szi ? (float *)ctx->b_szinteg.p : nullptr;
     fa.sz_total = want_szt ? (float *)ctx->b_sztotal.p : nullptr;
-    fa.ZH = (float *)ctx->b_out[O_ZH].p; fa.ZV = (float *)ctx->b_out[O_ZV].p;
-    fa.ZDR = (float *)ctx->b_out[O_ZDR].p; fa.KDP = (float *)ctx->b_out[O_KDP].p;
-    fa.DELTA_HV = (float *)ctx->b_out[O_DHV].p; fa.RHOHV = (float *)ctx->b_out[O_RHOHV].p;
-    fa.ATT_H = (float *)ctx->b_out[O_ATTH].p; fa.ATT_V = (float *)ctx->b_out[O_ATTV].p;
-    fa.mask = (double *)ctx->b_out[O_MASK].p;
+    fa.ZH = (float *)T[O_ZH]; fa.ZV = (float *)T[O_ZV];
+    fa.ZDR = (float *)T[O_ZDR]; fa.KDP = (float *)T[O_KDP];
+    fa.DELTA_HV = (float *)T[O_DHV]; fa.RHOHV = (float *)T[O_RHOHV];
+    fa.ATT_H = (float *)T[O_ATTH]; fa.ATT_V = (float *)T[O_ATTV];
+    fa.mask = (double *)T[O_MASK];
     fa.model_vars = want_model ? (double *)ctx->b_model.p : nullptr;
     fa.n_rays = n_rays; fa.n_gates = ng; fa.n_sub = n_sub; fa.n_hydro = n_hyd; fa.n_vars = n_vars;
     fa.c_zh = (float)p->c_zh;
@@ -657,7 +673,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
 
     ScanRayArgs ra{};
     ra.ZH = fa.ZH; ra.ZV = fa.ZV; ra.ZDR = fa.ZDR; ra.KDP = fa.KDP; ra.DELTA_HV = fa.DELTA_HV;
-    ra.PHIDP = (float *)ctx->b_out[O_PHIDP].p; ra.RHOHV = fa.RHOHV; ra.ATT_H = fa.ATT_H;
+    ra.PHIDP = (float *)T[O_PHIDP]; ra.RHOHV = fa.RHOHV; ra.ATT_H = fa.ATT_H;
     ra.ATT_V = fa.ATT_V; ra.RVEL = fa.RVEL;
     ra.sens_thr = cut ? (const double *)ctx->b_sens.p : nullptr;
     ra.n_rays = n_rays; ra.n_gates = ng; ra.with_attenuation = p->with_attenuation;
@@ -667,24 +683,14 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
     HIPCHK(hipGetLastError());
 
-    // ---- outputs ----
-    const bool dev = p->outputs_on_device != 0;
+    // ---- outputs (host buffers only; device buffers were written in place) ----
     const size_t fb = (size_t)n_rg * sizeof(float), dbb = (size_t)n_rg * sizeof(double);
-    if ((rc = copy_out(ctx, out->ZH, ctx->b_out[O_ZH].p, fb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->ZV, ctx->b_out[O_ZV].p, fb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->ZDR, ctx->b_out[O_ZDR].p, fb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->KDP, ctx->b_out[O_KDP].p, fb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->DELTA_HV, ctx->b_out[O_DHV].p, fb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->PHIDP, ctx->b_out[O_PHIDP].p, fb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->RHOHV, ctx->b_out[O_RHOHV].p, fb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->ATT_H, ctx->b_out[O_ATTH].p, fb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->ATT_V, ctx->b_out[O_ATTV].p, fb, dev))) return rc;
+    for (int k = 0; k < 14; ++k) {
+        if (!user_out[k] || T[k] == user_out[k]) continue;
+        const size_t bytes = (k == O_MASK || k == O_LAT || k == O_LON) ? dbb : fb;
+        if ((rc = copy_out(ctx, user_out[k], T[k], bytes, dev))) return rc;
+    }
     if (doppler && (rc = copy_out(ctx, out->RVEL, ctx->b_rvel.p, dbb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->mask, ctx->b_out[O_MASK].p, dbb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->lats, ctx->b_out[O_LAT].p, dbb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->lons, ctx->b_out[O_LON].p, dbb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->dist, ctx->b_out[O_DIST].p, fb, dev))) return rc;
-    if ((rc = copy_out(ctx, out->heights, ctx->b_out[O_HGT].p, fb, dev))) return rc;
     if (want_model && (rc = copy_out(ctx, out->model_vars, ctx->b_model.p, dbb * n_vars, dev))) return rc;
     if (out->sz_total && (rc = copy_out(ctx, out->sz_total, ctx->b_sztotal.p, fb * CPOL_N_SZ, dev))) return rc;
 
@@ -697,12 +703,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // host-visible results requested: wait, then surface the domain error
         HIPCHK(hipStreamSynchronize(st));
         int flag = 0;
-        HIPCHK(hipMemcpy(&flag, ctx->b_err.p, sizeof flag, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&flag, d_errflag, sizeof flag, hipMemcpyDeviceToHost));
         if (flag) {
             ctx->err = "RADAR DOMAIN IS NOT ENTIRELY CONTAINED IN COSMO SIMULATION DOMAIN";
             return CPOL_ERR_DOMAIN;
         }
     }
+    ctx->last_errflag = d_errflag;
     return CPOL_OK;
 }
 
@@ -742,7 +749,7 @@ int cpol_counters(cpol_ctx *ctx, cpol_counters_t *out)
         long long totals[2] = {0, 0};
         int flag = 0;
         HIPCHK(hipMemcpy(totals, ctx->b_totals.p, sizeof totals, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&flag, ctx->b_err.p, sizeof flag, hipMemcpyDeviceToHost));
+        if (ctx->last_errflag) HIPCHK(hipMemcpy(&flag, ctx->last_errflag, sizeof flag, hipMemcpyDeviceToHost));
         ctx->counters.n_valid_items = totals[0];
         ctx->counters.n_work_units = totals[1];
         if (ctx->ev_used > 0) {

@@ -426,7 +426,9 @@ template <int MODE>
 __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a)
 {
     // [wave][value][lane]; value 12 = normalisation sum (ice, melting)
-    __shared__ double s_part[CPOL_PSD_WAVES][CPOL_N_SZ + 3][CPOL_WAVE];
+    // the recurrence flavour needs no extra sums: 48 KB -> 3 workgroups per CU
+    constexpr int NV = (MODE == PSD_MODE_GAMMA_UNIFORM) ? CPOL_N_SZ : CPOL_N_SZ + 3;
+    __shared__ double s_part[CPOL_PSD_WAVES][NV][CPOL_WAVE];
     const int u = blockIdx.x;
     if ((long long)u >= a.totals[1]) return;                // block-uniform
     const WorkUnit *up = a.units + u;
@@ -567,10 +569,10 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
     // ---- combine the 8 partial sums per (item, column) in wave order ----
 #pragma unroll
     for (int c = 0; c < CPOL_N_SZ; ++c) s_part[wave][c][lane] = acc[c];
-    if (MODE == PSD_MODE_ICE || MODE == PSD_MODE_MELTING || MODE == PSD_MODE_GAMMA_EXP) {
-        s_part[wave][CPOL_N_SZ][lane] = msum;
-        s_part[wave][CPOL_N_SZ + 1][lane] = vsum;
-        s_part[wave][CPOL_N_SZ + 2][lane] = nsum;
+    if (MODE != PSD_MODE_GAMMA_UNIFORM) {
+        s_part[wave][NV - 3][lane] = msum;
+        s_part[wave][NV - 2][lane] = vsum;
+        s_part[wave][NV - 1][lane] = nsum;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < CPOL_N_SZ * CPOL_WAVE; idx += CPOL_PSD_THREADS) {
@@ -584,20 +586,20 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
         if (MODE == PSD_MODE_ICE) {
             double m = 0.0;
 #pragma unroll
-            for (int w = 0; w < CPOL_PSD_WAVES; ++w) m += s_part[w][CPOL_N_SZ][l];
+            for (int w = 0; w < CPOL_PSD_WAVES; ++w) m += s_part[w][NV - 3][l];
             const double qm_est = m * h.aux[3 * n_d];
             scale = Pl[n] / qm_est * Pl[2 * n];             // N0 / QM_est * QM (:1339)
             sum = (scale * sum) * d.dD;
             if (a.vn && c < 2) {
                 double t = 0.0;
 #pragma unroll
-                for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][CPOL_N_SZ + 1 + c][l];
+                for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][NV - 2 + c][l];
                 a.vn[((long)j * n + sb) * 2 + c] = (scale * t) * h.aux[3 * n_d];
             }
         } else if (MODE == PSD_MODE_MELTING) {
             double m = 0.0;
 #pragma unroll
-            for (int w = 0; w < CPOL_PSD_WAVES; ++w) m += s_part[w][CPOL_N_SZ][l];
+            for (int w = 0; w < CPOL_PSD_WAVES; ++w) m += s_part[w][NV - 3][l];
             // the item's own grid step (same expression as above, for lane l)
             const double fw = Pl[n];
             const double d_max = fw * d.r_dmax + (1 - fw) * d.s_dmax;
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             if (a.vn && c < 2) {
                 double t = 0.0;
 #pragma unroll
-                for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][CPOL_N_SZ + 1 + c][l];
+                for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][NV - 2 + c][l];
                 a.vn[((long)j * n + sb) * 2 + c] = (prop * t) * dDl;
             }
         } else {
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             if (MODE == PSD_MODE_GAMMA_EXP && d.numeric_intv && a.vn && c < 2) {
                 double t = 0.0;
 #pragma unroll
-                for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][CPOL_N_SZ + 1 + c][l];
+                for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][NV - 2 + c][l];
                 a.vn[((long)j * n + sb) * 2 + c] = t * h.aux[3 * n_d];
             }
         }

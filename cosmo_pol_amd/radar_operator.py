@@ -95,12 +95,15 @@ class RadarScan(object):
 
 
 class RadarOperator(object):
+    _table_serial = 0          # tags of per-ray table sets handed to the library
+
     def __init__(self, options_file=None, output_variables='all', *, device=0, lut_dir=None,
                  luts=None, config=None, distributed=False):
         print('Reading options defined in options file')
         self._ctx = N.Context(device)         # raises if the HIP library / GPU is missing
         self.device = device
         self.distributed = bool(distributed)   # shard the rays of every sweep over the ranks
+        self.reuse_device_tables = True        # keep per-ray tables in HBM between equal sweeps
         self.lut_dir = lut_dir
         self._user_luts = luts
         self.current_microphys_scheme = '1mom'
@@ -141,6 +144,7 @@ class RadarOperator(object):
                       or checked['microphysics']['scheme'] != old['microphysics']['scheme'])
         self.__config = checked
         self.constants = K.DerivedConstants(checked)
+        self._cache = {}                       # per-configuration host-side tables
         if reload_lut:
             if old is not None:
                 print('Reloading lookup tables...')
@@ -269,7 +273,7 @@ class RadarOperator(object):
                       'variable; 4/3 Earth model will be used instead...')
             else:
                 from . import refraction
-                sub = geo.gauss_hermite_subbeams(conf)
+                sub = self._cached('sub', lambda: geo.gauss_hermite_subbeams(conf))
                 h_col, n_col = refraction.refractivity_column(
                     self.N.data, self._zlevels, self._proj, self._res, coords,
                     conf['radar'].get('type', 'ground'))
@@ -288,8 +292,21 @@ class RadarOperator(object):
             raise ValueError('azimuths and elevations must have the same length')
         n_rays = len(az)
         if sub is None:
-            sub = geo.gauss_hermite_subbeams(conf)
-        traj, geo_t = tables if tables is not None else geo.ray_tables(coords, az, el, sub)
+            sub = self._cached('sub', lambda: geo.gauss_hermite_subbeams(conf))
+        version = 0
+        if tables is not None:
+            traj, geo_t = tables
+        else:
+            # per-ray tables depend only on (site, azimuths, elevations, quadrature nodes);
+            # `version` lets the library keep its device copies when they did not change
+            key = ('rays', az.tobytes(), el.tobytes(), tuple(np.ravel(coords)))
+
+            def make():
+                RadarOperator._table_serial += 1
+                return (RadarOperator._table_serial,) + geo.ray_tables(coords, az, el, sub)
+            version, traj, geo_t = self._cached(key, make, lru=8)
+            if paths is not None or site is not None or not self.reuse_device_tables:
+                version = 0
 
         p = N.SweepParams()
         p.n_rays, p.n_gates, p.n_sub = n_rays, n_gates, sub.n_sub
@@ -325,7 +342,9 @@ class RadarOperator(object):
         p.radial_res = float(conf['radar']['radial_resolution'])
         p.c_zh = float(self.constants.WAVELENGTH ** 4 / (np.pi ** 5 * conf['radar']['K_squared']))
 
-        thr = geo.sensitivity_threshold(conf, self.constants, n_gates) if apply_sensitivity else None
+        thr = (self._cached(('sens', n_gates),
+                            lambda: geo.sensitivity_threshold(conf, self.constants, n_gates))
+               if apply_sensitivity else None)
         p.apply_sensitivity = int(thr is not None)
         t = N.RayTables()
         if paths is not None:
@@ -341,6 +360,7 @@ class RadarOperator(object):
         t.sens_thr = thr.ctypes.data if thr is not None else None
         t.site = site.ctypes.data if site is not None else None
         t.paths = paths.ctypes.data if paths is not None else None
+        t.version = version
 
         o = N.Outputs()
         res = {}
@@ -366,6 +386,17 @@ class RadarOperator(object):
         del keep
         res['n_sub'] = sub.n_sub
         return res
+
+    def _cached(self, key, make, lru=None):
+        c = self._cache
+        if key in c:
+            return c[key]
+        if lru is not None:
+            old = [k for k in c if isinstance(k, tuple) and k and k[0] == key[0]]
+            for k in old[:max(0, len(old) - lru + 1)]:
+                del c[k]
+        c[key] = make()
+        return c[key]
 
     def _simulate_sweep(self, az, el):
         """All rays of a sweep: locally, or sharded over the ranks of the default

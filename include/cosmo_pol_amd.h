@@ -159,6 +159,10 @@ typedef struct {
                                    index, number of kept gates, unused             */
     const float *paths;         /* CPOL_GEOM_HOST_PATHS: [n_rays][n_vnodes][3][n_gates]
                                    float32 (s, h, e_deg), NaN = no gate            */
+    uint64_t version;           /* 0: tables are uploaded on every call; otherwise the
+                                   caller's tag of this table set -- an unchanged tag
+                                   means the device copies of the previous call are
+                                   reused (repeated scans of the same geometry)      */
 } cpol_ray_tables_t;
 
 typedef struct {
