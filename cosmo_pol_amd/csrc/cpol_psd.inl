@@ -390,10 +390,15 @@ __device__ __forceinline__ int psd_mode_of(const cpol_hydro_desc &d)
     return d.uniform_grid ? PSD_MODE_GAMMA_UNIFORM : PSD_MODE_GAMMA_EXP;
 }
 
+// x^y for x > 0 inside the per-bin loops of the ice / melting flavours: exp(y log x)
+// is ~4x cheaper than the < 1 ulp ocml pow and accurate to a few 1e-16 here
+// (|y log x| < 25), far inside the float32 store of the integrated sums.
+__device__ __forceinline__ double powp(double x, double y) { return exp(y * log(x)); }
+
 // 1-moment ice crystals (Field et al. 2005 double-moment normalised PSD)
 __device__ __forceinline__ double phi23(double x)
 {
-    return 490.6 * exp(-20.78 * x) + 17.46 * pow(x, 0.6357) * exp(-3.290 * x);
+    return 490.6 * exp(-20.78 * x) + 17.46 * powp(x, 0.6357) * exp(-3.290 * x);
 }
 
 // Melting snow / graupel (hydrometeors.py:333-478): per-item diameter grid.
@@ -404,7 +409,7 @@ struct MeltItem {
 
 __device__ __forceinline__ double powb(double x, double b)
 {
-    return (b == 2.0) ? x * x : pow(x, b);                  // NumPy: x**2 -> square
+    return (b == 2.0) ? x * x : powp(x, b);                 // NumPy: x**2 -> square
 }
 
 __device__ __forceinline__ double melt_mass(const cpol_hydro_desc &d, const MeltItem &it, double D,
@@ -417,9 +422,9 @@ __device__ __forceinline__ double melt_mass(const cpol_hydro_desc &d, const Melt
 __device__ __forceinline__ double melt_Dr(const cpol_hydro_desc &d, const MeltItem &it, double D)
 {
     // hydrometeors.py:382-383
-    const double D3 = pow(D, 3.0);
+    const double D3 = D * D * D;
     const double rho = melt_mass(d, it, D, D3) / (3.14159265358979323846 / 6 * D3);
-    return pow(rho / 1.0e-6, 1.0 / 3.0) * D;               // RHO_W = 1000/1000^3 kg mm-3
+    return cbrt(rho / 1.0e-6) * D;                          // RHO_W = 1000/1000^3 kg mm-3
 }
 
 template <int MODE>
@@ -546,15 +551,15 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
 #pragma unroll 1
         for (int k = k0; k < k1; ++k) {
             const double D = d_min + step * (double)k;
-            const double D3 = pow(D, 3.0);
+            const double D3 = D * D * D;
             const double M = melt_mass(d, it, D, D3);
             const double rho = M / (3.14159265358979323846 / 6 * D3);
-            const double Dr = pow(rho / 1.0e-6, 1.0 / 3.0) * D;
+            const double Dr = cbrt(rho / 1.0e-6) * D;
             const double dDr = (melt_Dr(d, it, D + 0.01) - Dr) / 0.01;          // :384
             const double sq = sqrt(Dr);
             const double Nr = (d.r_n0 * sq) * exp(-(it.lam_r * Dr));           // rain N(D_r)
             const double Vr = d.r_alpha * sq;                                  // rain V(D_r)
-            const double Vd = d.alpha * pow(D, d.beta);
+            const double Vd = d.alpha * ((d.beta == 0.25) ? sqrt(sqrt(D)) : powp(D, d.beta));
             const double V = it.phi * Vr + (1 - it.phi) * Vd;                  // :431-439
             const double Nraw = Nr * Vr / V * dDr;                             // :386-387
             msum += Nraw * M;                                                  // :478
