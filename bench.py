@@ -173,7 +173,7 @@ def main():
         # recurrence flavour (counted in the ISA), 4 cycles per wave64 instruction on a
         # SIMD-32, 1024 SIMDs at 2.4 GHz
         n_units = int(cnt.n_work_units)
-        valu_cycles = n_units * 1024 * 18 * 4
+        valu_cycles = -(-int(cnt.n_valid_items) // 64) * 1024 * 18 * 4
         valu_frac = valu_cycles / (1024 * 2.4e9 * cnt.ms_psd * 1e-3) if cnt.ms_psd > 0 else None
         out = {
             'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',

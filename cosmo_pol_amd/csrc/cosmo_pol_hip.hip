@@ -54,7 +54,7 @@ struct cpol_ctx {
     // per-sweep work buffers (grow only)
     DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
-        b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err, b_pos, b_vn, b_icefirst, b_rvel;
+        b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err, b_pos, b_vn, b_icefirst, b_rvel, b_fh, b_fv;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
@@ -155,7 +155,7 @@ void cpol_destroy(cpol_ctx *ctx)
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_cursor, &ctx->b_units,
                      &ctx->b_urange, &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_err, &ctx->b_pos,
-                     &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel,
+                     &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel, &ctx->b_fh, &ctx->b_fv,
                      &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model};
     for (DevBuf *b : all) free_buf(*b);
     for (auto &b : ctx->b_out) free_buf(b);
@@ -320,8 +320,8 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
         return CPOL_ERR_ARG;
     }
     if (desc->psd_family == CPOL_PSD_GAMMA && desc->uniform_grid &&
-        (!aux || n_aux < desc->n_d + 1 || desc->n_d % CPOL_PSD_WAVES != 0)) {
-        ctx->err = "cpol_stage_hydro: uniform_grid needs aux[1 + n_d] and n_d % 8 == 0";
+        (!aux || n_aux < 3 * desc->n_d + 1 || desc->n_d % CPOL_PSD_WAVES != 0)) {
+        ctx->err = "cpol_stage_hydro: uniform_grid needs aux[1 + 3 n_d] and n_d % 8 == 0";
         return CPOL_ERR_ARG;
     }
     if (desc->psd_family == CPOL_PSD_ICE_FIELD && (!aux || n_aux < 4 * desc->n_d + 1)) {
@@ -485,6 +485,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                                 out->dist, out->heights};
     void *T[14];
     for (int k = 0; k < 14; ++k) T[k] = (dev && user_out[k]) ? user_out[k] : ctx->b_out[k].p;
+    if (p->with_attenuation) {
+        ENSURE(ctx->b_fh, (size_t)n_rg * sizeof(float));
+        ENSURE(ctx->b_fv, (size_t)n_rg * sizeof(float));
+    }
     const bool want_szi = ctx->keep_debug;
     if (want_szi) ENSURE(ctx->b_szinteg, (size_t)n_rg * n_hyd * CPOL_N_SZ * sizeof(float));
     const bool want_szt = out->sz_total != nullptr || ctx->keep_debug;
@@ -583,6 +587,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     sa.units = (WorkUnit *)ctx->b_units.p;
     sa.totals = (long long *)ctx->b_totals.p;
     sa.n_keys = n_keys;
+    sa.n_hydro = n_hyd;
+    for (int j = 0; j < n_hyd; ++j) {
+        const cpol_hydro_desc &d = ctx->hs.h[j].d;
+        sa.key_base[j] = ctx->hs.h[j].key_base;
+        sa.unit_shift[j] = (d.psd_family == CPOL_PSD_GAMMA && d.uniform_grid) ? 7 : 6;
+    }
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
     hipLaunchKernelGGL(k_make_units, dim3(cdiv((long)n_keys * 64, 256)), dim3(256), 0, st, sa);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st,
@@ -608,7 +618,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                      : d.uniform_grid ? PSD_MODE_GAMMA_UNIFORM : PSD_MODE_GAMMA_EXP;
             need[mode] = true;
         }
-        const dim3 grd((unsigned)unit_cap), blk(CPOL_PSD_THREADS);
+        // persistent grid: up to 4 workgroups of 8 waves per CU, 256 CUs
+        const long want = unit_cap < 1024 ? unit_cap : 1024;
+        const dim3 grd((unsigned)want), blk(CPOL_PSD_THREADS);
         if (need[PSD_MODE_GAMMA_UNIFORM])
             hipLaunchKernelGGL(k_psd<PSD_MODE_GAMMA_UNIFORM>, grd, blk, 0, st, ctx->hs, pa);
         if (need[PSD_MODE_GAMMA_EXP])
@@ -642,6 +654,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     double sum_w = 0;
     for (int s = 0; s < n_sub; ++s) sum_w += t->sub_w[s];
     fa.sum_w = sum_w;
+    fa.FH = p->with_attenuation ? (float *)ctx->b_fh.p : nullptr;
+    fa.FV = p->with_attenuation ? (float *)ctx->b_fv.p : nullptr;
+    fa.res_km = (float)(p->radial_res / 1000.);
     fa.RVEL = nullptr;
     if (doppler) {
         fa.RVEL = (double *)ctx->b_rvel.p;
@@ -675,6 +690,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ra.ZH = fa.ZH; ra.ZV = fa.ZV; ra.ZDR = fa.ZDR; ra.KDP = fa.KDP; ra.DELTA_HV = fa.DELTA_HV;
     ra.PHIDP = (float *)T[O_PHIDP]; ra.RHOHV = fa.RHOHV; ra.ATT_H = fa.ATT_H;
     ra.ATT_V = fa.ATT_V; ra.RVEL = fa.RVEL;
+    ra.FH = fa.FH; ra.FV = fa.FV;
     ra.sens_thr = cut ? (const double *)ctx->b_sens.p : nullptr;
     ra.n_rays = n_rays; ra.n_gates = ng; ra.with_attenuation = p->with_attenuation;
     ra.radial_res = (float)p->radial_res;

@@ -64,6 +64,8 @@ struct FinalArgs {
     float *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *RHOHV, *ATT_H, *ATT_V;   // work / outputs
     double *mask;               // [n_rg]
     double *model_vars;         // [n_vars][n_rg] or NULL
+    float *FH, *FV;             // [n_rg] per-gate two-way attenuation factors (or NULL)
+    float res_km;               // (float)(radial_res / 1000.)
     int n_rays, n_gates, n_sub, n_hydro, n_vars;
     float c_zh, c_kdp, c_2w;    // wavelength^4/(pi^5 K^2), 1e-3*(180/pi)*wavelength, 2*wavelength
     double sum_w;
@@ -138,8 +140,17 @@ __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
     a.ZV[rg] = a.c_zh * xs_v;
     a.ZDR[rg] = xs_h / xs_v;
     a.KDP[rg] = a.c_kdp * (tot[10] - tot[8]);
-    a.ATT_H[rg] = 4.343e-3f * (a.c_2w * tot[11]);
-    a.ATT_V[rg] = 4.343e-3f * (a.c_2w * tot[9]);
+    const float att_h = 4.343e-3f * (a.c_2w * tot[11]);
+    const float att_v = 4.343e-3f * (a.c_2w * tot[9]);
+    a.ATT_H[rg] = att_h;
+    a.ATT_V[rg] = att_v;
+    if (a.FH) {
+        // 10**(-0.1*A*(radial_res/1000.)) in float32 (doppler_scatter.py:413-414); NaN -> 1
+        float fh = (float)exp10((double)(-0.1f * att_h * a.res_km));
+        float fv = (float)exp10((double)(-0.1f * att_v * a.res_km));
+        a.FH[rg] = (fh == fh) ? fh : 1.0f;
+        a.FV[rg] = (fv == fv) ? fv : 1.0f;
+    }
     const float t47 = tot[4] + tot[7], t65 = tot[6] - tot[5];
     const float aa = t47 * t47 + t65 * t65;
     a.RHOHV[rg] = sqrtf(aa / (b * cc));
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
 // lanes finish PHIDP, the attenuated ZDR and the sensitivity cut.
 struct ScanRayArgs {
     float *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *PHIDP, *RHOHV, *ATT_H, *ATT_V;
+    const float *FH, *FV;       // attenuation factors from k_final_gate
     double *RVEL;
     const double *sens_thr;     // [n_gates] or NULL
     int n_rays, n_gates, with_attenuation;
@@ -232,11 +244,8 @@ __global__ __launch_bounds__(64) void k_final_ray(ScanRayArgs a)
         float k2 = 2.0f * a.KDP[base + g];
         s_k[g] = (k2 == k2) ? k2 : 0.0f;                       // nan_cumsum
         if (a.with_attenuation) {
-            // 10**(-0.1*A*(radial_res/1000.)) in float32
-            float fh = (float)pow(10.0, (double)(-0.1f * a.ATT_H[base + g] * a.res_km));
-            float fv = (float)pow(10.0, (double)(-0.1f * a.ATT_V[base + g] * a.res_km));
-            s_h[g] = (fh == fh) ? fh : 1.0f;                   // nan_cumprod
-            s_v[g] = (fv == fv) ? fv : 1.0f;
+            s_h[g] = a.FH[base + g];                           // nan_cumprod operands
+            s_v[g] = a.FV[base + g];
         }
     }
     __syncthreads();

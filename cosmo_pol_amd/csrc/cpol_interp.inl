@@ -170,16 +170,34 @@ __device__ __forceinline__ void gate_geometry(const ModelDev &m, float rlat, flo
     float topo = g.dx * g.dy * t[0] + g.x * t[2] * g.dy + g.dx * t[1] * g.y + g.x * g.y * t[3];
     if (!(topo < h)) { g.status = -1; return; }
     g.status = 0;
+    // the four column searches advance in lockstep: 4 independent loads per step
+    // instead of 4 x 7 dependent ones (same result as interpolation_c.c:108-135)
+    const float *col[4];
+    float top[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { col[k] = m.H + g.cell[k] * nz; top[k] = col[k][0]; }
+    int idx[4] = {0, 0, 0, 0};
+    int step = 1;
+    while ((step << 1) <= nz - 2) step <<= 1;                // wave-uniform
+#pragma unroll 1
+    for (; step >= 1; step >>= 1) {
+        float v[4];
+        int j[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { j[k] = min(idx[k] + step, nz - 2); v[k] = col[k][j[k]]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (idx[k] + step <= nz - 2 && v[k] >= h) idx[k] = j[k];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float *col = m.H + g.cell[k] * nz;
-        int c1;
-        if (h > col[0]) { g.status = 1; return; }            // interpolation_c.c:70-73
-        if (h < t[k]) c1 = nz - 3;                            // :74-77 (extrapolate)
-        else c1 = min(level_search(col, nz, h), nz - 3);      // :79-81
+        if (h > top[k]) { g.status = 1; return; }            // interpolation_c.c:70-73
+        int c1 = (h < t[k]) ? nz - 3 : min(idx[k], nz - 3);   // :74-81
         g.c1[k] = c1;
-        g.z1[k] = col[c1];
-        g.z2[k] = col[c1 + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        g.z1[k] = col[k][g.c1[k]];
+        g.z2[k] = col[k][g.c1[k] + 1];
     }
 }
 

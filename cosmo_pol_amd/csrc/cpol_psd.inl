@@ -283,7 +283,17 @@ struct ScanArgs {
     WorkUnit *units;            // capacity >= n_items/64 + n_keys
     long long *totals;          // [0] = n_valid items, [1] = n_units
     int n_keys;
+    int n_hydro;
+    int key_base[CPOL_MAX_HYDRO];
+    int unit_shift[CPOL_MAX_HYDRO];   // log2(items per work unit): 6, or 7 for the 2-items-per-lane flavour
 };
+
+__device__ __forceinline__ int unit_shift_of(const ScanArgs &a, int k)
+{
+    int sh = a.unit_shift[0];
+    for (int q = 1; q < a.n_hydro; ++q) if (k >= a.key_base[q]) sh = a.unit_shift[q];
+    return sh;
+}
 
 __device__ __forceinline__ int2 wave_inclusive_scan2(int2 v)
 {
@@ -306,8 +316,9 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
     int2 mine = make_int2(0, 0);
     for (int k = k0; k < k1; ++k) {
         int c = a.count[k];
+        int sh = unit_shift_of(a, k);
         mine.x += c;
-        mine.y += (c + 63) >> 6;
+        mine.y += (c + (1 << sh) - 1) >> sh;
     }
     int2 inc = wave_inclusive_scan2(mine);
     if (lane == CPOL_WAVE - 1) s_wave[wave] = inc;
@@ -322,10 +333,11 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
     int ubase = s_wave[wave].y + inc.y - mine.y;
     for (int k = k0; k < k1; ++k) {
         int c = a.count[k];
+        int sh = unit_shift_of(a, k);
         a.offset[k] = ibase;
         a.uoffset[k] = ubase;
         ibase += c;
-        ubase += (c + 63) >> 6;
+        ubase += (c + (1 << sh) - 1) >> sh;
     }
     if (t == 1023) { a.totals[0] = ibase; a.totals[1] = ubase; }
 }
@@ -336,11 +348,12 @@ __global__ __launch_bounds__(256) void k_make_units(ScanArgs a)
     const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (k >= a.n_keys) return;
     const int c = a.count[k], ib = a.offset[k], ub = a.uoffset[k];
-    for (int u = lane_id(); u * 64 < c; u += CPOL_WAVE) {
+    const int sh = unit_shift_of(a, k), per = 1 << sh;
+    for (int u = lane_id(); u * per < c; u += CPOL_WAVE) {
         WorkUnit w;
         w.key = k;
-        w.start = ib + u * 64;
-        w.count = min(64, c - u * 64);
+        w.start = ib + u * per;
+        w.count = min(per, c - u * per);
         w.pad = 0;
         a.units[ub + u] = w;
     }
@@ -427,15 +440,27 @@ __device__ __forceinline__ double melt_Dr(const cpol_hydro_desc &d, const MeltIt
     return cbrt(rho / 1.0e-6) * D;                          // RHO_W = 1000/1000^3 kg mm-3
 }
 
+// Scattering tables and per-bin factors are immutable while a sweep runs: reading them
+// through the CONSTANT address space guarantees the scalar data path (s_load -> SGPR
+// operands) for wave-uniform addresses even when the kernel also stores to global memory.
+typedef const double __attribute__((address_space(4))) *cdouble_p;
+__device__ __forceinline__ cdouble_p as_const(const double *p) { return (cdouble_p)(uintptr_t)p; }
+
 template <int MODE>
 __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a)
 {
     // [wave][value][lane]; value 12 = normalisation sum (ice, melting)
-    // the recurrence flavour needs no extra sums: 48 KB -> 3 workgroups per CU
-    constexpr int NV = (MODE == PSD_MODE_GAMMA_UNIFORM) ? CPOL_N_SZ : CPOL_N_SZ + 3;
-    __shared__ double s_part[CPOL_PSD_WAVES][NV][CPOL_WAVE];
-    const int u = blockIdx.x;
-    if ((long long)u >= a.totals[1]) return;                // block-uniform
+    // the recurrence flavour needs no extra sums and combines its 8 partials with a
+    // 3-level tree through 24 KB of LDS (4 wave slots): 8 waves per SIMD stay resident
+    // ... and keeps TWO items per lane (128-item units): the wave-uniform table rows come
+    // through the scalar cache, whose refill rate -- not the VALU -- bounds the kernel;
+    // two items per fetched row halve that traffic
+    constexpr int NV = (MODE == PSD_MODE_GAMMA_UNIFORM) ? 2 * CPOL_N_SZ : CPOL_N_SZ + 3;
+    constexpr int NSLOT = (MODE == PSD_MODE_GAMMA_UNIFORM) ? 4 : CPOL_PSD_WAVES;
+    __shared__ double s_part[NSLOT][NV][CPOL_WAVE];
+    // persistent workgroups: a fixed grid walks the unit list (no empty launches)
+    const int n_units = (int)a.totals[1];
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
     const WorkUnit *up = a.units + u;
     const int key = __builtin_amdgcn_readfirstlane(up->key);
     const int start = __builtin_amdgcn_readfirstlane(up->start);
@@ -444,7 +469,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
     for (int q = 1; q < hs.n_hydro; ++q) if (key >= hs.h[q].key_base) j = q;
     const HydroDev &h = hs.h[j];
     const cpol_hydro_desc &d = h.d;
-    if (psd_mode_of(d) != MODE) return;                     // block-uniform
+    if (psd_mode_of(d) != MODE) continue;                   // block-uniform
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -455,7 +480,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
     const long n = a.n_sbg;
     const int sbg = a.perm[start + (active ? lane : 0)];
     const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + sbg;
-    const double *__restrict__ slice = h.table + (long)(key - h.key_base) * n_d * CPOL_N_SZ;
+    const cdouble_p slice = as_const(h.table + (long)(key - h.key_base) * n_d * CPOL_N_SZ);
 
     double acc[CPOL_N_SZ];
 #pragma unroll
@@ -470,19 +495,19 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
         // evaluates them on the float32 LUT diameter axis)
         const double lam = active ? P[0] : 0.0;
         const double N0 = active ? P[n] : 0.0;
-        const double *__restrict__ pre = h.pre;
-        const double *__restrict__ dnu = h.dnu;
+        const cdouble_p pre = as_const(h.pre);
+        const cdouble_p dnu = as_const(h.dnu);
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
             const double nk = (N0 * pre[k]) * exp(-(lam * dnu[k]));
-            const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
+            const cdouble_p row = slice + (long)k * CPOL_N_SZ;
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
         }
         if (d.numeric_intv && a.vn) {
             // 2-moment ice: IceParticle.integrate_V on its own linspace grid
-            const double *__restrict__ pn = h.aux, *__restrict__ dn = h.aux + n_d;
-            const double *__restrict__ Vn = h.aux + 2 * n_d;
+            const cdouble_p pn = as_const(h.aux), dn = as_const(h.aux + n_d);
+            const cdouble_p Vn = as_const(h.aux + 2 * n_d);
 #pragma unroll 1
             for (int k = k0; k < k1; ++k) {
                 const double nk = (N0 * pn[k]) * exp(-(lam * dn[k]));
@@ -491,29 +516,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             }
         }
     } else if (MODE == PSD_MODE_GAMMA_UNIFORM) {
-        // nu == 1 on a (nearly) uniform diameter grid: exp(-lambda D_k) follows from
-        // ONE exp per wave chunk and a geometric recurrence; the float32 rounding of
-        // the grid nodes is restored to second order:
-        //   D_k = D_k0 + (k-k0) h + dlt_k,  exp(-l D_k) = E_k0 r^(k-k0) (1 - x + x^2/2),
-        //   x = l dlt_k, |x| < 2e-5  ->  truncation < 2e-15, drift < 128 ulp(double).
-        const double lam = active ? P[0] : 0.0;
-        const double N0 = active ? P[n] : 0.0;
-        const double *__restrict__ pre = h.pre;
-        const double *__restrict__ dnu = h.dnu;
-        const double *__restrict__ dlt = h.aux + 1;
-        const double hstep = h.aux[0];
-        double A = N0 * exp(-(lam * dnu[k0 < n_d ? k0 : 0]));
-        const double r = exp(-(lam * hstep));
-#pragma unroll 4
-        for (int k = k0; k < k1; ++k) {
-            const double x = lam * dlt[k];
-            const double corr = fma(x, fma(x, 0.5, -1.0), 1.0);
-            const double nk = pre[k] * (A * corr);
-            A *= r;
-            const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
-#pragma unroll
-            for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
-        }
+        // handled below (two items per lane)
     } else if (MODE == PSD_MODE_ICE) {
         //   aux[0..n_d)      D of the LUT axis (float64 of float32)
         //   aux[n_d..2n_d)   D of the normalisation grid  (hydrometeors.py:1331)
@@ -521,10 +524,10 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
         //   aux[3n_d]        dD of the normalisation grid
         const double lam = active ? P[0] : 1.0;
         const double N0 = active ? P[n] : 0.0;
-        const double *__restrict__ Dl = h.aux;
-        const double *__restrict__ Dn = h.aux + n_d;
-        const double *__restrict__ aDb = h.aux + 2 * n_d;
-        const double *__restrict__ Vn = h.aux + 3 * n_d + 1;   // alpha * Dn^beta (get_V)
+        const cdouble_p Dl = as_const(h.aux);
+        const cdouble_p Dn = as_const(h.aux + n_d);
+        const cdouble_p aDb = as_const(h.aux + 2 * n_d);
+        const cdouble_p Vn = as_const(h.aux + 3 * n_d + 1);   // alpha * Dn^beta (get_V)
 #pragma unroll 1
         for (int k = k0; k < k1; ++k) {
             const double xn = lam * Dn[k] / 1000.0;
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             nsum += phn;
             const double xl = lam * Dl[k] / 1000.0;
             const double ph = phi23(xl);
-            const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
+            const cdouble_p row = slice + (long)k * CPOL_N_SZ;
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], ph, acc[c]);
         }
@@ -565,13 +568,87 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             msum += Nraw * M;                                                  // :478
             vsum += Nraw * V;                                                  // :457
             nsum += Nraw;                                                      // :458
-            const double *__restrict__ row = slice + (long)k * CPOL_N_SZ;
+            const cdouble_p row = slice + (long)k * CPOL_N_SZ;
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], Nraw, acc[c]);
         }
     }
 
-    // ---- combine the 8 partial sums per (item, column) in wave order ----
+    // ---- combine the 8 partial sums per (item, column), fixed order ----
+    if (MODE == PSD_MODE_GAMMA_UNIFORM) {
+        // nu == 1 on a (nearly) uniform diameter grid: exp(-lambda D_k) follows from
+        // ONE exp per wave chunk and a geometric recurrence; the float32 rounding of
+        // the grid nodes is restored to second order:
+        //   D_k = D_k0 + (k-k0) h + dlt_k,  exp(-l D_k) = E_k0 r^(k-k0) (1 - x + x^2/2),
+        //   x = l dlt_k, |x| < 2e-5  ->  truncation < 2e-15, drift < 128 ulp(double).
+        const bool act1 = lane + CPOL_WAVE < count;
+        const int sbg1 = a.perm[start + (act1 ? lane + CPOL_WAVE : 0)];
+        const double *P1 = a.par + ((long)j * CPOL_MAX_PAR) * n + sbg1;
+        const double lam0 = active ? P[0] : 0.0, lam1 = act1 ? P1[0] : 0.0;
+        const double N00 = active ? P[n] : 0.0, N01 = act1 ? P1[n] : 0.0;
+        const cdouble_p dnu = as_const(h.dnu);
+        const double hstep = h.aux[0];
+        const double d0 = dnu[k0 < n_d ? k0 : 0];
+        double A0 = N00 * exp(-(lam0 * d0)), A1 = N01 * exp(-(lam1 * d0));
+        const double r0 = exp(-(lam0 * hstep)), r1 = exp(-(lam1 * hstep));
+        double acc1[CPOL_N_SZ];
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) acc1[c] = 0.0;
+        // scalar-cache requests are the scarce resource of this loop (SQC busy > 80 %):
+        // pre[k] and dlt[k] are interleaved so that a bin costs 3 requests (x16, x8, x4)
+        const cdouble_p pd = as_const(h.aux + 1 + n_d);          // [k][2] = (pre, dlt)
+#pragma unroll 2
+        for (int k = k0; k < k1; ++k) {
+            const double pk = pd[2 * k], dl = pd[2 * k + 1];
+            const double x0 = lam0 * dl, x1 = lam1 * dl;
+            const double c0 = fma(x0, fma(x0, 0.5, -1.0), 1.0);
+            const double c1 = fma(x1, fma(x1, 0.5, -1.0), 1.0);
+            const double n0 = pk * (A0 * c0), n1 = pk * (A1 * c1);
+            A0 *= r0;
+            A1 *= r1;
+            const cdouble_p row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ; ++c) {
+                const double sz = row[c];
+                acc[c] = fma(sz, n0, acc[c]);
+                acc1[c] = fma(sz, n1, acc1[c]);
+            }
+        }
+        // tree ((w0+w4)+(w2+w6)) + ((w1+w5)+(w3+w7)) through 4 LDS wave slots; the
+        // wave that ends up with the total (wave 0) writes the results
+#pragma unroll
+        for (int half = 4; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half) {
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) {
+                    s_part[wave - half][c][lane] = acc[c];
+                    s_part[wave - half][CPOL_N_SZ + c][lane] = acc1[c];
+                }
+            }
+            __syncthreads();
+            if (wave < half) {
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) {
+                    acc[c] += s_part[wave][c][lane];
+                    acc1[c] += s_part[wave][CPOL_N_SZ + c][lane];
+                }
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            if (active) {
+                double *o = a.res + ((long)j * n + sbg) * CPOL_N_SZ;
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) o[c] = acc[c] * d.dD;
+            }
+            if (act1) {
+                double *o = a.res + ((long)j * n + sbg1) * CPOL_N_SZ;
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) o[c] = acc1[c] * d.dD;
+            }
+        }
+        continue;
+    }
 #pragma unroll
     for (int c = 0; c < CPOL_N_SZ; ++c) s_part[wave][c][lane] = acc[c];
     if (MODE != PSD_MODE_GAMMA_UNIFORM) {
@@ -629,5 +706,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             }
         }
         a.res[((long)j * n + sb) * CPOL_N_SZ + c] = sum;
+    }
+    __syncthreads();                                        // s_part is reused by the next unit
     }
 }

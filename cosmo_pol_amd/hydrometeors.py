@@ -160,18 +160,19 @@ def build_hydro(h, scheme, lut, var_index):
                               np.asarray(c['alpha'] * Dn ** c['beta'], dtype=np.float64),
                               [np.float64(Dn[1] - Dn[0])]])
         return d, table, pre, dnu, aux
-    aux = _uniform_grid_aux(d, D, nu, n_d)
+    aux = _uniform_grid_aux(d, D, nu, n_d, pre)
     return d, table, pre, dnu, aux
 
 
 PSD_WAVES = 8        # csrc/cpol_psd.inl: CPOL_PSD_WAVES (bins are split over 8 wavefronts)
 
 
-def _uniform_grid_aux(d, D, nu, n_d):
+def _uniform_grid_aux(d, D, nu, n_d, pre):
     """nu == 1: exp(-lambda D_k) is advanced by a geometric recurrence inside each
-    wave chunk of n_d/8 bins.  aux = [h, dlt_0 .. dlt_{n_d-1}] with h the mean grid
-    step and dlt_k = D_k - D_k0 - (k-k0) h the (float32-rounding sized) departure of
-    node k from the uniform grid anchored at its chunk start k0."""
+    wave chunk of n_d/8 bins.  aux = [h, dlt_0 .. dlt_{n_d-1}, (pre_0, dlt_0), (pre_1, dlt_1) ..]
+    with h the mean grid step and dlt_k = D_k - D_k0 - (k-k0) h the (float32-rounding
+    sized) departure of node k from the uniform grid anchored at its chunk start k0;
+    the interleaved (pre, dlt) pairs let the kernel fetch both with one scalar load."""
     if float(nu) != 1.0 or n_d % PSD_WAVES != 0:
         d.uniform_grid = 0
         return None
@@ -187,4 +188,5 @@ def _uniform_grid_aux(d, D, nu, n_d):
         d.uniform_grid = 0
         return None
     d.uniform_grid = 1
-    return np.concatenate([[h], dlt]).astype(np.float64)
+    pairs = np.stack([np.asarray(pre, dtype=np.float64), dlt], axis=1).ravel()
+    return np.concatenate([[h], dlt, pairs]).astype(np.float64)
