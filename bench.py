@@ -38,7 +38,7 @@ LUT_SLICE_BYTES = 1024 * 12 * 4   # B_l per valid item (float32 
 # HBM bytes per sweep of the PSD kernel from the PMC passes committed under profiles/
 # ((2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md); refreshed
 # whenever the profile is re-taken -- see profiles/README.md
-PSD_TRAFFIC_BYTES_PER_SWEEP = None
+PSD_TRAFFIC_BYTES_PER_SWEEP = 65.9e6     # profiles/r1_final_pmc_hbm.json, k_psd<1>
 
 
 def bench_config(small):
@@ -72,11 +72,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run for --gpus > 1')
         args.gpus = world
+    # debugging aids for a one-GPU box: CPOL_BENCH_BACKEND=gloo CPOL_BENCH_ONE_DEVICE=1 runs the
+    # N-rank code path with every rank on GPU 0 (never used by the driver)
+    backend = os.environ.get('CPOL_BENCH_BACKEND', 'nccl')
+    if os.environ.get('CPOL_BENCH_ONE_DEVICE'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from cosmo_pol_amd import RadarOperator, synthetic
     conf = bench_config(args.small)
@@ -186,7 +194,7 @@ def main():
                        'rays_per_gpu': n_rays, 'gates_per_ray': n_gates,
                        'parallelism': 'rays sharded by sweep, 1 all-gather/step' if world > 1 else 'single GPU',
                        'small': bool(args.small)},
-            'roofline': {'kernel': 'k_psd_gamma (3 launches/sweep: R, S, G)', 'bound': 'hbm',
+            'roofline': {'kernel': 'k_psd<1> (uniform-grid gamma flavour; 1 launch/sweep covers R, S, G)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
                          'traffic': PSD_TRAFFIC_BYTES_PER_SWEEP,
