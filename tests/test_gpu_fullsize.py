@@ -1,0 +1,94 @@
+"""Full-size (BASELINE configs[1]: 360 x 500 PPI on the 80 x 774 x 1158 bench cube)
+GPU tests through size-independent properties + a ray sample against the oracle."""
+import numpy as np
+import pytest
+
+import _cases
+import bench
+from cosmo_pol_amd import synthetic
+from cosmo_pol_oracle import beam, scatter
+from cosmo_pol_oracle import config as ocfg
+
+pytestmark = pytest.mark.gpu
+FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V', 'RVEL']
+
+
+@pytest.fixture(scope='module')
+def full():
+    from cosmo_pol_amd import RadarOperator
+    conf = bench.bench_config(False)
+    hyds = ('R', 'S', 'G')
+    cube = synthetic.make_cube(hydrometeors=hyds, **synthetic.BENCH_GRID)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    op = RadarOperator(config=conf, luts=luts, output_variables='only_radar')
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    az = np.arange(0, 360, 1.0)
+    res = op.simulate_rays(az, np.full(360, 1.0))
+    yield dict(op=op, conf=conf, cube=cube, luts=luts, az=az, res=res)
+    op.close()
+
+
+def test_full_ppi_shapes_and_counters(full):
+    res, op = full['res'], full['op']
+    assert res['ZH'].shape == (360, 500)
+    cnt = op._ctx.counters()
+    assert cnt.n_subbeam_gates == 180000 and cnt.n_gates == 180000
+    assert 100000 < cnt.n_valid_items < 540000
+    assert np.isfinite(res['ZH']).mean() > 0.5
+    assert np.all(res['ZH'][np.isfinite(res['ZH'])] > 0)
+    assert np.nanmax(res['RHOHV']) <= 1.0 + 1e-6
+
+
+def test_rays_are_independent_bitwise(full):
+    """A radial's result does not depend on which other radials share its launch
+    (batch of 360, batch of 7 in shuffled order, single ray): bitwise equal --
+    this is what makes azimuth sharding over GPUs exact."""
+    op, az, res = full['op'], full['az'], full['res']
+    pick = np.array([300, 0, 45, 179, 180, 259, 12])
+    sub = op.simulate_rays(az[pick], np.full(len(pick), 1.0))
+    one = op.simulate_rays(az[[45]], np.array([1.0]))
+    for k in FIELDS + ['mask', 'lats', 'lons', 'dist', 'heights']:
+        assert np.array_equal(sub[k], res[k][pick], equal_nan=True), k
+        assert np.array_equal(one[k][0], res[k][45], equal_nan=True), k
+    again = op.simulate_rays(az, np.full(360, 1.0))
+    for k in FIELDS:
+        assert np.array_equal(again[k], res[k], equal_nan=True), 'run-to-run ' + k
+
+
+def test_sample_of_rays_vs_oracle(full):
+    from test_gpu_parity import _pol_tolerances
+    conf = ocfg.make_config(full['conf'])
+    cube, luts, res = full['cube'], full['luts'], full['res']
+    oc = beam.ModelCube({n: cube['data'][n] for n in _cases.ORDER}, cube['zlevels'],
+                        cube['proj_info'], cube['resolution'], _cases.ORDER)
+    ol = {h: _cases.as_oracle_lut(l) for h, l in luts.items()}
+    n_valid = 0
+    for r in (0, 37, 90, 123, 181, 222, 275, 301, 359):
+        subs = beam.interpolate_radial(oc, conf, float(full['az'][r]), 1.0)
+        o = scatter.radar_observables(subs, ol, conf, return_sz=True)
+        szt = np.nan_to_num(o.sz_total.astype(np.float64))
+        scatter.cut_at_sensitivity([o], conf)
+        assert np.array_equal(res['dist'][r], subs[0].dist_profile)
+        assert np.array_equal(res['heights'][r], subs[0].heights_profile)
+        assert np.array_equal(res['mask'][r], o.mask)
+        for k in FIELDS:
+            atol = 2e-4 if k == 'RVEL' else _pol_tolerances(k, o, szt, conf)
+            _cases.assert_close_nan(res[k][r], o.values[k], rtol=1e-5, atol=atol,
+                                    name='%s ray %d' % (k, r))
+        n_valid += int(np.isfinite(o.values['ZH']).sum())
+    assert n_valid > 2000
+
+
+def test_rhi_and_vprof_api(full):
+    op = full['op']
+    rhi = op.get_RHI(azimuths=[30.0, 200.0], elevations=np.arange(0.5, 20.0, 2.5))
+    assert rhi.nsweeps == 2 and rhi.scan_type == 'rhi'
+    assert rhi.fields['ZH']['data'].shape == (16, 500)
+    assert np.allclose(rhi.fixed_angle['data'], [30.0, 200.0])
+    assert np.array_equal(rhi.sweep_start_ray_index['data'], [0, 8])
+    z = rhi.get_field(1, 'ZDR')
+    assert z.shape == (8, 500)
+    vp = op.get_VPROF()
+    assert vp.fields['KDP']['data'].shape == (1, 500)
+    # vertical beam: first gates are rain, then snow -> the profile leaves the model top
+    assert np.ma.count(vp.fields['ZH']['data']) > 20
