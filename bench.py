@@ -177,11 +177,11 @@ def main():
         achieved = psd_bytes / (cnt.ms_psd * 1e-3) / 1e9 if cnt.ms_psd > 0 else None
         sweep_bytes = (n_sbg * (4 * cube['zlevels'].shape[0] * 4 + n_vars * 8 * 4)
                        + psd_bytes + n_rays * n_gates * 48)
-        # f64 VALU issue roofline of the PSD kernel: 18 v_*_f64 per (item, bin) in the
-        # recurrence flavour (counted in the ISA), 4 cycles per wave64 instruction on a
-        # SIMD-32, 1024 SIMDs at 2.4 GHz
+        # f64 VALU issue roofline of the PSD kernel: 16 v_*_f64 per (item, bin) in the
+        # recurrence flavour (12 FMAs + 4, counted in the ISA), 4 cycles per wave64
+        # instruction on a SIMD-32, 1024 SIMDs at the 2.4 GHz peak clock
         n_units = int(cnt.n_work_units)
-        valu_cycles = -(-int(cnt.n_valid_items) // 64) * 1024 * 18 * 4
+        valu_cycles = -(-int(cnt.n_valid_items) // 64) * 1024 * 16 * 4
         valu_frac = valu_cycles / (1024 * 2.4e9 * cnt.ms_psd * 1e-3) if cnt.ms_psd > 0 else None
         out = {
             'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',

@@ -320,8 +320,8 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
         return CPOL_ERR_ARG;
     }
     if (desc->psd_family == CPOL_PSD_GAMMA && desc->uniform_grid &&
-        (!aux || n_aux < 3 * desc->n_d + 1 || desc->n_d % CPOL_PSD_WAVES != 0)) {
-        ctx->err = "cpol_stage_hydro: uniform_grid needs aux[1 + 3 n_d] and n_d % 8 == 0";
+        (!aux || n_aux < 5 * desc->n_d + 1 || desc->n_d % CPOL_PSD_WAVES != 0)) {
+        ctx->err = "cpol_stage_hydro: uniform_grid needs aux[1 + 5 n_d] and n_d % 8 == 0";
         return CPOL_ERR_ARG;
     }
     if (desc->psd_family == CPOL_PSD_ICE_FIELD && (!aux || n_aux < 4 * desc->n_d + 1)) {
