@@ -67,14 +67,15 @@ __device__ __forceinline__ void rank_reset(RankShared &sh)
         (&sh.cnt[0][0])[i] = 0;
 }
 
-// all threads of the block call this (sh reset + synced before); returns the
-// item's position inside its bucket, or -1 for invalid lanes
-__device__ __forceinline__ int block_rank(RankShared &sh, int *__restrict__ count, int key, bool valid)
+// phase A (per hydrometeor, no barrier): wave-level grouping + LDS table insert.
+// returns a packed ticket: bit 31 = final position already known (table overflow ->
+// direct global claim), else (slot << 6) | rank-in-wave; -1 for invalid lanes
+__device__ __forceinline__ int rank_insert(RankShared &sh, int *__restrict__ count, int key, bool valid)
 {
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     unsigned long long todo = __ballot(valid);
-    int slot = -1, rank = 0, direct_base = -1;
+    int ticket = -1;
     while (todo) {                                  // wave-uniform loop
         const int leader = __ffsll((long long)todo) - 1;
         const int k = __shfl(key, leader);
@@ -93,31 +94,36 @@ __device__ __forceinline__ int block_rank(RankShared &sh, int *__restrict__ coun
         sl = __shfl(sl, leader);
         db = __shfl(db, leader);
         if (valid && key == k) {
-            slot = sl;
-            direct_base = db;
-            rank = __popcll(m & ((1ull << lane) - 1ull));
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            ticket = (sl >= 0) ? ((sl << 6) | rank) : (int)(0x80000000u | (unsigned)(db + rank));
         }
         todo &= ~m;
     }
-    __syncthreads();
-    if (threadIdx.x < CPOL_RANK_SLOTS) {
-        const int t = threadIdx.x;
-        const int k = sh.key[t];
-        if (k >= 0) {
-            int run = 0;
+    return ticket;
+}
+
+// phase B (one thread per (hydrometeor, slot), after a barrier): exclusive prefix over
+// the waves and ONE returning global atomic per distinct key of the workgroup
+__device__ __forceinline__ void rank_reserve(RankShared &sh, int *__restrict__ count, int t)
+{
+    const int k = sh.key[t];
+    if (k < 0) return;
+    int run = 0;
 #pragma unroll
-            for (int w = 0; w < CPOL_RANK_WAVES; ++w) {      // exclusive prefix over waves
-                int c = sh.cnt[t][w];
-                sh.cnt[t][w] = run;
-                run += c;
-            }
-            sh.base[t] = atomicAdd(&count[k], run);
-        }
+    for (int w = 0; w < CPOL_RANK_WAVES; ++w) {
+        int c = sh.cnt[t][w];
+        sh.cnt[t][w] = run;
+        run += c;
     }
-    __syncthreads();
-    int pos = -1;
-    if (valid) pos = (slot >= 0) ? sh.base[slot] + sh.cnt[slot][wave] + rank : direct_base + rank;
-    return pos;
+    sh.base[t] = atomicAdd(&count[k], run);
+}
+
+// phase C (after a barrier): ticket -> position inside the bucket
+__device__ __forceinline__ int rank_position(const RankShared &sh, int ticket)
+{
+    if (ticket < 0) return (ticket == -1) ? -1 : (int)((unsigned)ticket & 0x7fffffffu);
+    const int slot = ticket >> 6, rank = ticket & 63;
+    return sh.base[slot] + sh.cnt[slot][threadIdx.x >> 6] + rank;
 }
 
 // float32 power via float64 (rounds to the correctly rounded float32 result in
@@ -147,7 +153,11 @@ struct ClassifyArgs {
 #define CPOL_CLASSIFY_THREADS (CPOL_RANK_WAVES * CPOL_WAVE)
 __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs, ClassifyArgs a)
 {
-    __shared__ RankShared sh;
+    // one LDS ranking table per hydrometeor: all global atomics of the workgroup are
+    // issued in ONE round (phase B) instead of one dependent round per hydrometeor
+    __shared__ RankShared sh[CPOL_MAX_HYDRO];
+    for (int j = 0; j < hs.n_hydro; ++j) rank_reset(sh[j]);
+    __syncthreads();
     const long sbg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = sbg < a.n_sbg;
     const long n = a.n_sbg;
@@ -263,14 +273,21 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                     ? qnv : d.ntot_factor * n0v / d.nu * pow(lamf, -(d.mu + 1) / d.nu);
             }
         }
-        rank_reset(sh);
-        __syncthreads();
-        const int pos = block_rank(sh, a.count, key, valid);
+        const int ticket = rank_insert(sh[j], a.count, key, valid);
         if (in) {
             a.key[(long)j * n + i] = key;
-            a.pos[(long)j * n + i] = pos;
+            a.pos[(long)j * n + i] = ticket;
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < hs.n_hydro * CPOL_RANK_SLOTS; idx += blockDim.x)
+        rank_reserve(sh[idx / CPOL_RANK_SLOTS], a.count, idx % CPOL_RANK_SLOTS);
+    __syncthreads();
+    if (in) {
+        for (int j = 0; j < hs.n_hydro; ++j) {
+            const long o = (long)j * n + i;
+            a.pos[o] = rank_position(sh[j], a.pos[o]);
+        }
     }
 }
 
