@@ -91,6 +91,7 @@ class Counters(C.Structure):
 
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_set_stream',
            'cpol_synchronize', 'cpol_stage_model', 'cpol_stage_hydro', 'cpol_set_num_hydro',
+           'cpol_stage_doppler_weights',
            'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
            'cpol_spaceborne_first_gate',
            'cpol_enable_timing', 'cpol_debug_read']
@@ -129,6 +130,8 @@ def load_library():
                                      vp, vp, vp, vp]
     lib.cpol_stage_hydro.restype = C.c_int
     lib.cpol_stage_hydro.argtypes = [vp, C.c_int, C.POINTER(HydroDesc), vp, vp, vp, vp, C.c_int]
+    lib.cpol_stage_doppler_weights.restype = C.c_int
+    lib.cpol_stage_doppler_weights.argtypes = [vp, C.c_int, vp]
     lib.cpol_set_num_hydro.restype = C.c_int
     lib.cpol_set_num_hydro.argtypes = [vp, C.c_int]
     lib.cpol_interp_points.restype = C.c_int
@@ -230,6 +233,11 @@ class Context(object):
         rc = self.lib.cpol_stage_hydro(self.h, slot, C.byref(desc), _ptr(table), _ptr(pre),
                                        _ptr(dnu), _ptr(aux), 0 if aux is None else aux.size)
         self._check(rc, 'cpol_stage_hydro')
+
+    def stage_doppler_weights(self, slot, weights):
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        self._check(self.lib.cpol_stage_doppler_weights(self.h, slot, _ptr(w)),
+                    'cpol_stage_doppler_weights')
 
     def set_num_hydro(self, n):
         self._check(self.lib.cpol_set_num_hydro(self.h, n), 'cpol_set_num_hydro')

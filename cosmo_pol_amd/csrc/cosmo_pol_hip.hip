@@ -49,7 +49,7 @@ struct cpol_ctx {
     // hydrometeors
     HydroSet hs{};
     DevBuf d_table[CPOL_MAX_HYDRO], d_pre[CPOL_MAX_HYDRO], d_dnu[CPOL_MAX_HYDRO],
-        d_aux[CPOL_MAX_HYDRO];
+        d_aux[CPOL_MAX_HYDRO], d_rcsw[CPOL_MAX_HYDRO];
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
     // per-sweep work buffers (grow only)
     DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site;
@@ -164,6 +164,7 @@ void cpol_destroy(cpol_ctx *ctx)
         free_buf(ctx->d_pre[j]);
         free_buf(ctx->d_dnu[j]);
         free_buf(ctx->d_aux[j]);
+        free_buf(ctx->d_rcsw[j]);
     }
     for (hipEvent_t *set : ctx->ev_sets) {
         for (int k = 0; k < EV_N; ++k) (void)hipEventDestroy(set[k]);
@@ -297,6 +298,7 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
     h.d = *desc;
     h.table = (const double *)ctx->d_table[slot].p;
     h.pre = h.dnu = h.aux = nullptr;
+    h.rcsw = nullptr;
     if (pre) {
         if ((rc = upload(ctx, ctx->d_pre[slot], pre, db)) != CPOL_OK) return rc;
         h.pre = (const double *)ctx->d_pre[slot].p;
@@ -333,6 +335,22 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
     ctx->hydro_staged[slot] = true;
     if (slot >= ctx->hs.n_hydro) cpol_set_num_hydro(ctx, slot + 1);
     else cpol_set_num_hydro(ctx, ctx->hs.n_hydro);
+    return CPOL_OK;
+}
+
+int cpol_stage_doppler_weights(cpol_ctx *ctx, int slot, const double *weights)
+{
+    if (!ctx || !weights || slot < 0 || slot >= CPOL_MAX_HYDRO || !ctx->hydro_staged[slot]) {
+        if (ctx) ctx->err = "cpol_stage_doppler_weights: stage the hydrometeor first";
+        return CPOL_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const cpol_hydro_desc &d = ctx->hs.h[slot].d;
+    const size_t bytes = (size_t)d.n_e * d.n_t * d.n_d * 2 * sizeof(double);
+    int rc;
+    if ((rc = upload(ctx, ctx->d_rcsw[slot], weights, bytes)) != CPOL_OK) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->hs.h[slot].rcsw = (const double *)ctx->d_rcsw[slot].p;
     return CPOL_OK;
 }
 
@@ -464,6 +482,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_perm, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_res, (size_t)n_hyd * n_sbg * CPOL_N_SZ * sizeof(double));
     const bool doppler = p->simulate_doppler != 0;
+    const bool dop2 = p->simulate_doppler == 2;
+    if (dop2)
+        for (int j = 0; j < n_hyd; ++j)
+            if (!ctx->hs.h[j].rcsw) { ctx->err = "cpol_run_sweep: Doppler scheme 2 needs cpol_stage_doppler_weights"; return CPOL_ERR_ARG; }
     if (doppler) {
         ENSURE(ctx->b_vn, (size_t)n_hyd * n_sbg * 2 * sizeof(double));
         ENSURE(ctx->b_icefirst, (size_t)n_rays * n_sub * sizeof(IceFirst));
@@ -621,14 +643,16 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // persistent grid: up to 4 workgroups of 8 waves per CU, 256 CUs
         const long want = unit_cap < 1024 ? unit_cap : 1024;
         const dim3 grd((unsigned)want), blk(CPOL_PSD_THREADS);
-        if (need[PSD_MODE_GAMMA_UNIFORM])
-            hipLaunchKernelGGL(k_psd<PSD_MODE_GAMMA_UNIFORM>, grd, blk, 0, st, ctx->hs, pa);
-        if (need[PSD_MODE_GAMMA_EXP])
-            hipLaunchKernelGGL(k_psd<PSD_MODE_GAMMA_EXP>, grd, blk, 0, st, ctx->hs, pa);
-        if (need[PSD_MODE_ICE])
-            hipLaunchKernelGGL(k_psd<PSD_MODE_ICE>, grd, blk, 0, st, ctx->hs, pa);
-        if (need[PSD_MODE_MELTING])
-            hipLaunchKernelGGL(k_psd<PSD_MODE_MELTING>, grd, blk, 0, st, ctx->hs, pa);
+#define CPOL_LAUNCH_PSD(M)                                                                   \
+        if (need[M]) {                                                                       \
+            if (dop2) hipLaunchKernelGGL((k_psd<M, true>), grd, blk, 0, st, ctx->hs, pa);    \
+            else hipLaunchKernelGGL((k_psd<M, false>), grd, blk, 0, st, ctx->hs, pa);        \
+        }
+        CPOL_LAUNCH_PSD(PSD_MODE_GAMMA_UNIFORM)
+        CPOL_LAUNCH_PSD(PSD_MODE_GAMMA_EXP)
+        CPOL_LAUNCH_PSD(PSD_MODE_ICE)
+        CPOL_LAUNCH_PSD(PSD_MODE_MELTING)
+#undef CPOL_LAUNCH_PSD
     }
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
 
@@ -675,7 +699,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         }
         for (int j = 0; j < n_hyd; ++j) {
             const cpol_hydro_desc &d = ctx->hs.h[j].d;
-            fa.vsrc[j] = d.psd_family == CPOL_PSD_MELTING ? 1
+            fa.vsrc[j] = (dop2 || d.psd_family == CPOL_PSD_MELTING) ? 1
                        : (d.psd_family == CPOL_PSD_ICE_FIELD || d.numeric_intv) ? 2 : 0;
             if (fa.vsrc[j] == 2)
                 hipLaunchKernelGGL(k_ice_first, dim3(n_rays * n_sub), dim3(64), 0, st,

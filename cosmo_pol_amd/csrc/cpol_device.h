@@ -34,6 +34,7 @@ struct HydroDev {
     const double *pre;     // [n_d]
     const double *dnu;     // [n_d]
     const double *aux;     // family specific
+    const double *rcsw;    // [n_e][n_t][n_d][2] Doppler scheme 2 weights or NULL
     int key_base;          // first bucket id of this hydrometeor
     int n_par;             // per-item parameter count
 };

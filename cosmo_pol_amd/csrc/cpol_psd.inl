@@ -463,7 +463,7 @@ __device__ __forceinline__ double melt_Dr(const cpol_hydro_desc &d, const MeltIt
 typedef const double __attribute__((address_space(4))) *cdouble_p;
 __device__ __forceinline__ cdouble_p as_const(const double *p) { return (cdouble_p)(uintptr_t)p; }
 
-template <int MODE>
+template <int MODE, bool DOP2>
 __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a)
 {
     // [wave][value][lane]; value 12 = normalisation sum (ice, melting)
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
     // ... and keeps TWO items per lane (128-item units): the wave-uniform table rows come
     // through the scalar cache, whose refill rate -- not the VALU -- bounds the kernel;
     // two items per fetched row halve that traffic
-    constexpr int NV = (MODE == PSD_MODE_GAMMA_UNIFORM) ? 2 * CPOL_N_SZ : CPOL_N_SZ + 3;
+    constexpr int NV = (MODE == PSD_MODE_GAMMA_UNIFORM) ? 2 * CPOL_N_SZ + (DOP2 ? 4 : 0) : CPOL_N_SZ + 3;
     constexpr int NSLOT = (MODE == PSD_MODE_GAMMA_UNIFORM) ? 4 : CPOL_PSD_WAVES;
     __shared__ double s_part[NSLOT][NV][CPOL_WAVE];
     // persistent workgroups: a fixed grid walks the unit list (no empty launches)
@@ -498,6 +498,8 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
     const int sbg = a.perm[start + (active ? lane : 0)];
     const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + sbg;
     const cdouble_p slice = as_const(h.table + (long)(key - h.key_base) * n_d * CPOL_N_SZ);
+    // Doppler scheme 2: (w rcs V, w rcs) per bin of this slice
+    const cdouble_p rv = as_const(DOP2 ? h.rcsw + (long)(key - h.key_base) * n_d * 2 : h.table);
 
     double acc[CPOL_N_SZ];
 #pragma unroll
@@ -520,8 +522,9 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             const cdouble_p row = slice + (long)k * CPOL_N_SZ;
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
+            if (DOP2) { vsum = fma(rv[2 * k], nk, vsum); nsum = fma(rv[2 * k + 1], nk, nsum); }
         }
-        if (d.numeric_intv && a.vn) {
+        if (!DOP2 && d.numeric_intv && a.vn) {
             // 2-moment ice: IceParticle.integrate_V on its own linspace grid
             const cdouble_p pn = as_const(h.aux), dn = as_const(h.aux + n_d);
             const cdouble_p Vn = as_const(h.aux + 2 * n_d);
@@ -550,13 +553,16 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             const double xn = lam * Dn[k] / 1000.0;
             const double phn = phi23(xn);
             msum += aDb[k] * (N0 * phn);                    // hydrometeors.py:1333-1337
-            vsum += phn * Vn[k];                            // hydrometeors.py:1267-1271
-            nsum += phn;
+            if (!DOP2) {
+                vsum += phn * Vn[k];                        // hydrometeors.py:1267-1271
+                nsum += phn;
+            }
             const double xl = lam * Dl[k] / 1000.0;
             const double ph = phi23(xl);
             const cdouble_p row = slice + (long)k * CPOL_N_SZ;
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], ph, acc[c]);
+            if (DOP2) { vsum = fma(rv[2 * k], ph, vsum); nsum = fma(rv[2 * k + 1], ph, nsum); }
         }
     } else {
         MeltItem it;
@@ -583,8 +589,14 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
             const double V = it.phi * Vr + (1 - it.phi) * Vd;                  // :431-439
             const double Nraw = Nr * Vr / V * dDr;                             // :386-387
             msum += Nraw * M;                                                  // :478
-            vsum += Nraw * V;                                                  // :457
-            nsum += Nraw;                                                      // :458
+            if (DOP2) {                        // rcs-weighted, per-item fall speed V(D)
+                const double wr = rv[2 * k + 1];
+                vsum = fma(wr * V, Nraw, vsum);
+                nsum = fma(wr, Nraw, nsum);
+            } else {
+                vsum += Nraw * V;                                              // :457
+                nsum += Nraw;                                                  // :458
+            }
             const cdouble_p row = slice + (long)k * CPOL_N_SZ;
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], Nraw, acc[c]);
@@ -611,6 +623,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
         double acc1[CPOL_N_SZ];
 #pragma unroll
         for (int c = 0; c < CPOL_N_SZ; ++c) acc1[c] = 0.0;
+        double dv0 = 0.0, dn0 = 0.0, dv1 = 0.0, dn1 = 0.0;     // Doppler scheme 2 sums
         // per bin the host supplies (pre, q1 = pre*dlt, q2 = pre*dlt^2/2), so that
         //   N_k = A_k (pre_k - lambda q1_k + lambda^2 q2_k),  A_{k+1} = A_k r
         // costs 4 f64 ops per item on top of the 12 FMAs (one 32-byte scalar request)
@@ -629,6 +642,11 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
                 acc[c] = fma(sz, n0, acc[c]);
                 acc1[c] = fma(sz, n1, acc1[c]);
             }
+            if (DOP2) {
+                const double wv = rv[2 * k], wr = rv[2 * k + 1];
+                dv0 = fma(wv, n0, dv0); dn0 = fma(wr, n0, dn0);
+                dv1 = fma(wv, n1, dv1); dn1 = fma(wr, n1, dn1);
+            }
         }
         // tree ((w0+w4)+(w2+w6)) + ((w1+w5)+(w3+w7)) through 4 LDS wave slots; the
         // wave that ends up with the total (wave 0) writes the results
@@ -640,6 +658,10 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
                     s_part[wave - half][c][lane] = acc[c];
                     s_part[wave - half][CPOL_N_SZ + c][lane] = acc1[c];
                 }
+                if (DOP2) {
+                    s_part[wave - half][NV - 4][lane] = dv0; s_part[wave - half][NV - 3][lane] = dn0;
+                    s_part[wave - half][NV - 2][lane] = dv1; s_part[wave - half][NV - 1][lane] = dn1;
+                }
             }
             __syncthreads();
             if (wave < half) {
@@ -647,6 +669,10 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
                 for (int c = 0; c < CPOL_N_SZ; ++c) {
                     acc[c] += s_part[wave][c][lane];
                     acc1[c] += s_part[wave][CPOL_N_SZ + c][lane];
+                }
+                if (DOP2) {
+                    dv0 += s_part[wave][NV - 4][lane]; dn0 += s_part[wave][NV - 3][lane];
+                    dv1 += s_part[wave][NV - 2][lane]; dn1 += s_part[wave][NV - 1][lane];
                 }
             }
             __syncthreads();
@@ -656,11 +682,13 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
                 double *o = a.res + ((long)j * n + sbg) * CPOL_N_SZ;
 #pragma unroll
                 for (int c = 0; c < CPOL_N_SZ; ++c) o[c] = acc[c] * d.dD;
+                if (DOP2) { a.vn[((long)j * n + sbg) * 2] = dv0; a.vn[((long)j * n + sbg) * 2 + 1] = dn0; }
             }
             if (act1) {
                 double *o = a.res + ((long)j * n + sbg1) * CPOL_N_SZ;
 #pragma unroll
                 for (int c = 0; c < CPOL_N_SZ; ++c) o[c] = acc1[c] * d.dD;
+                if (DOP2) { a.vn[((long)j * n + sbg1) * 2] = dv1; a.vn[((long)j * n + sbg1) * 2 + 1] = dn1; }
             }
         }
         continue;
@@ -692,7 +720,8 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
                 double t = 0.0;
 #pragma unroll
                 for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][NV - 2 + c][l];
-                a.vn[((long)j * n + sb) * 2 + c] = (scale * t) * h.aux[3 * n_d];
+                // scheme 1: integrate_V (x dD of its grid); scheme 2: unit-spaced trapezoid
+                a.vn[((long)j * n + sb) * 2 + c] = DOP2 ? scale * t : (scale * t) * h.aux[3 * n_d];
             }
         } else if (MODE == PSD_MODE_MELTING) {
             double m = 0.0;
@@ -710,15 +739,15 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
                 double t = 0.0;
 #pragma unroll
                 for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][NV - 2 + c][l];
-                a.vn[((long)j * n + sb) * 2 + c] = (prop * t) * dDl;
+                a.vn[((long)j * n + sb) * 2 + c] = DOP2 ? prop * t : (prop * t) * dDl;
             }
         } else {
             sum = sum * d.dD;
-            if (MODE == PSD_MODE_GAMMA_EXP && d.numeric_intv && a.vn && c < 2) {
+            if (MODE == PSD_MODE_GAMMA_EXP && (DOP2 || d.numeric_intv) && a.vn && c < 2) {
                 double t = 0.0;
 #pragma unroll
                 for (int w = 0; w < CPOL_PSD_WAVES; ++w) t += s_part[w][NV - 2 + c][l];
-                a.vn[((long)j * n + sb) * 2 + c] = t * h.aux[3 * n_d];
+                a.vn[((long)j * n + sb) * 2 + c] = DOP2 ? t : t * h.aux[3 * n_d];
             }
         }
         a.res[((long)j * n + sb) * CPOL_N_SZ + c] = sum;

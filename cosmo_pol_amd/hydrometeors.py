@@ -191,3 +191,25 @@ def _uniform_grid_aux(d, D, nu, n_d, pre):
     p64 = np.asarray(pre, dtype=np.float64)
     quads = np.stack([p64, p64 * dlt, p64 * dlt * dlt / 2.0, np.zeros(n_d)], axis=1).ravel()
     return np.concatenate([[h], dlt, quads]).astype(np.float64)
+
+
+def doppler_weights(h, scheme, lut):
+    """Doppler scheme 2 (doppler_scatter.py:283-296): per table slice and diameter bin
+    (w rcs V, w rcs) with rcs = 2 pi (Z11 - Z12 - Z21 + Z22), V = get_V(D) on the table's
+    diameter axis and w the unit-spaced trapezoid weights of np.trapz (1/2 at both ends).
+    Melting species evaluate V(D) per gate in the kernel: their first column is unused."""
+    t = np.asarray(lut.value_table, dtype=np.float64)
+    n_d = t.shape[2]
+    rcs = 2 * np.pi * (t[..., 0] - t[..., 1] - t[..., 2] + t[..., 3])
+    w = np.ones(n_d)
+    w[0] = w[-1] = 0.5
+    out = np.empty(t.shape[:3] + (2,), dtype=np.float64)
+    out[..., 1] = rcs * w
+    if h in ('mS', 'mG'):
+        out[..., 0] = out[..., 1]
+    else:
+        c = _consts(h, scheme)
+        D = np.asarray(lut.axes[lut.axes_names['d']])
+        V = np.asarray(c['alpha'] * D ** c['beta'], dtype=np.float64)     # _Hydrometeor.get_V
+        out[..., 0] = (V * rcs) * w
+    return out

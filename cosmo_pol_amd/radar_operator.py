@@ -141,7 +141,8 @@ class RadarOperator(object):
                       or checked['radar']['frequency'] != old['radar']['frequency']
                       or checked['microphysics']['with_melting'] != old['microphysics']['with_melting']
                       or checked['microphysics']['with_ice_crystals'] != old['microphysics']['with_ice_crystals']
-                      or checked['microphysics']['scheme'] != old['microphysics']['scheme'])
+                      or checked['microphysics']['scheme'] != old['microphysics']['scheme']
+                      or (checked['doppler']['scheme'] == 2) != (old['doppler']['scheme'] == 2))
         self.__config = checked
         self.constants = K.DerivedConstants(checked)
         self._cache = {}                       # per-configuration host-side tables
@@ -181,6 +182,8 @@ class RadarOperator(object):
         for slot, h in enumerate(hl):
             d, table, pre, dnu, aux = hyd.build_hydro(h, scheme, lut[h], var_index)
             self._ctx.stage_hydro(slot, d, table, pre, dnu, aux)
+            if conf['doppler']['scheme'] == 2:
+                self._ctx.stage_doppler_weights(slot, hyd.doppler_weights(h, scheme, lut[h]))
         self._ctx.set_num_hydro(len(hl))
         self._staged_hydro = hl
         if self._model_staged and self._staged_vars != hyd.variable_list(conf):
@@ -316,13 +319,14 @@ class RadarOperator(object):
         want_model = self.output_variables in ('all', 'only_model')
         p.integrate_model = int(want_model)
         p.outputs_on_device = int(device_outputs is not None)
-        # Doppler scheme 1 (analytic mean fall speed); none for GPM (doppler_scatter.py:83-87)
-        doppler = (conf['doppler']['scheme'] == 1 and conf['radar'].get('type') != 'GPM'
+        # Doppler schemes 1 (analytic mean fall speed) and 2 (rcs-weighted); none for GPM
+        # (doppler_scatter.py:83-87); scheme 3 (full spectrum) is out of scope
+        doppler = (conf['doppler']['scheme'] in (1, 2) and conf['radar'].get('type') != 'GPM'
                    and mode != N.GEOM_SPACEBORNE)
-        if conf['doppler']['scheme'] in (2, 3) and not getattr(self, '_warned_doppler', False):
-            print('Doppler schemes 2 and 3 are not implemented: RVEL is not simulated')
+        if conf['doppler']['scheme'] == 3 and not getattr(self, '_warned_doppler', False):
+            print('Doppler scheme 3 (Doppler spectrum) is not implemented: RVEL is not simulated')
             self._warned_doppler = True
-        p.simulate_doppler = int(doppler)
+        p.simulate_doppler = int(conf['doppler']['scheme']) if doppler else 0
         vi = {v: i for i, v in enumerate(self._staged_vars)}
         p.var_u, p.var_v, p.var_w = vi['U'], vi['V'], vi['W']
         p.geometry_mode = mode
@@ -411,7 +415,7 @@ class RadarOperator(object):
         fields = ([(k, np.float32) for k in RADAR_FIELDS] + [('dist', np.float32),
                   ('heights', np.float32), ('mask', np.float64), ('lats', np.float64),
                   ('lons', np.float64)])
-        if self.__config['doppler']['scheme'] == 1:
+        if self.__config['doppler']['scheme'] in (1, 2):
             fields.append(('RVEL', np.float64))
         n_gates = len(self.constants.RANGE_RADAR)
         dev = torch.device('cuda', self.device)

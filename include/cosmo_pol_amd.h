@@ -121,7 +121,7 @@ typedef struct {
     int32_t integrate_model;    /* also return antenna-averaged model variables */
     int32_t apply_sensitivity;  /* 1: censor with tables->sens_thr (cut_at_sensitivity) */
     int32_t outputs_on_device;  /* output pointers are device pointers          */
-    int32_t simulate_doppler;   /* Doppler scheme 1 radial velocity (RVEL)      */
+    int32_t simulate_doppler;   /* 0 off, 1 / 2 = Doppler scheme of the reference (RVEL) */
     int32_t geometry_mode;      /* CPOL_GEOM_*                                   */
     double  radar_lat, radar_lon, radar_alt;
     double  range0, range_step; /* RANGE_RADAR = range0 + k*range_step          */
@@ -205,6 +205,13 @@ int  cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc,
                       const double *table, const double *pre, const double *dnu,
                       const double *aux, int n_aux);
 int  cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro);
+
+/* Doppler scheme 2 (doppler_scatter.py:283-296): per table slice and diameter bin the
+ * trapezoid weight w_k (1/2 at both ends) times the horizontal radar cross-section
+ * 2 pi (Z11 - Z12 - Z21 + Z22), and the same times the fall speed V(D_k):
+ * weights [n_e][n_t][n_d][2] = (w rcs V, w rcs) float64.  Needed only when
+ * cpol_sweep_params.simulate_doppler == 2. */
+int  cpol_stage_doppler_weights(cpol_ctx *ctx, int slot, const double *weights);
 
 /* gate kernel on explicit points: coords [n][2] (rotated lat, lon) float32,
  * heights [n] float32 -> out [n_vars][n] float32 with the reference's

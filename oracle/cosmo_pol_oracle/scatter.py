@@ -64,8 +64,9 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True):
     scheme = mp['scheme']
     melting = mp['with_melting']
     radial_res = config['radar']['radial_resolution']
+    dop_scheme = config['doppler']['scheme']
     simulate_doppler = doppler and config['radar'].get('type', 'ground') != 'GPM' \
-        and config['doppler']['scheme'] == 1
+        and dop_scheme in (1, 2)
     hydrom_types = hydrometeor_list(config)
 
     n_sub = len(subbeams)
@@ -133,10 +134,19 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True):
 
                 sz_integ[valid, j, :] = nansum_pair(sz_integ[valid, j, :], sz_psd * sb.quad_weight)
 
-                if simulate_doppler:
+                if simulate_doppler and dop_scheme == 1:
                     vh, n = hyd[h].integrate_V()
                     v_integ[valid] = nansum_pair(v_integ[valid], vh)
                     n_integ[valid] = nansum_pair(n_integ[valid], n)
+                elif simulate_doppler:
+                    # scheme 2: fall speed weighted by N(D) x rcs_h, unit-spaced trapezoid
+                    # (doppler_scatter.py:283-296)
+                    rcs = 2 * np.pi * (sz[:, :, 0] - sz[:, :, 1] - sz[:, :, 2] + sz[:, :, 3])
+                    v_f = hyd[h].get_V(list_D)
+                    vh_w = np.trapezoid(np.multiply(v_f, N * rcs), axis=1)
+                    n_w = np.trapezoid(N * rcs, axis=1)
+                    v_integ[valid] = nansum_pair(v_integ[valid], vh_w)
+                    n_integ[valid] = nansum_pair(n_integ[valid], n_w)
 
             if simulate_doppler:
                 v_hydro = v_integ / n_integ

@@ -243,6 +243,11 @@ RADIAL_CASES = {
                                            'with_attenuation': 0},
                           'integration': {'nh_GH': 1, 'nv_GH': 3}}, 10.0, 88.0,
                          ('R', 'S', 'G'), False),
+    'c3_dop2': ({'radar': {'range': 36000, 'radial_resolution': 400},
+                 'microphysics': {'with_ice_crystals': 1, 'with_melting': 1},
+                 'doppler': {'scheme': 2},
+                 'integration': {'nh_GH': 3, 'nv_GH': 1}}, 150.0, 4.5,
+                ('R', 'S', 'G', 'I'), False),
     'c5_2mom': ({'radar': {'range': 30000, 'radial_resolution': 300, 'frequency': 13.6},
                  'microphysics': {'scheme': '2mom', 'with_ice_crystals': 1, 'with_melting': 0},
                  'integration': {'nh_GH': 1, 'nv_GH': 1}}, 75.0, 8.0, ('R', 'S', 'G', 'I'), True),
