@@ -70,7 +70,8 @@ class SweepParams(C.Structure):
 class RayTables(C.Structure):
     _fields_ = [('traj', C.c_void_p), ('geo', C.c_void_p), ('sub_h', C.c_void_p),
                 ('sub_v', C.c_void_p), ('sub_w', C.c_void_p), ('sens_thr', C.c_void_p),
-                ('site', C.c_void_p), ('paths', C.c_void_p), ('version', C.c_uint64)]
+                ('site', C.c_void_p), ('paths', C.c_void_p), ('nyquist', C.c_void_p),
+                ('version', C.c_uint64)]
 
 
 OUTPUT_FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V',

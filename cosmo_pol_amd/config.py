@@ -11,8 +11,8 @@ shipped option files is silently ignored, as upstream).
 Differences (documented): the configuration is an explicit object owned by a
 RadarOperator, not a module-global; `radar/type` defaults to 'ground' (upstream
 reads it unconditionally, global_constants.py:186, without defaulting it);
-antenna-diagram fitting (integration scheme 2) and Nyquist files are out of
-scope.
+antenna-diagram fitting (integration scheme 2) is out of scope (SURVEY.md
+section 2, item 12); a Nyquist file becomes a `nyquist.NyquistTable`.
 """
 import builtins
 import copy
@@ -157,6 +157,11 @@ def init(options_file):
 def sanity_check(config):
     """Fills defaults / replaces invalid values; raises ValueError for missing
     mandatory keys (cfg.py:190-281)."""
+    nyq_obj = None
+    if config is not None and not isinstance((config.get('radar') or {}).get('nyquist_velocity'),
+                                             (str, type(None))):
+        nyq_obj = config['radar']['nyquist_velocity']      # already a NyquistTable (re-validation)
+        config = dict(config, radar=dict(config['radar'], nyquist_velocity=None))
     config = copy.deepcopy(config) if config is not None else {}
     for section in VALID_VALUES:
         if section not in config or config[section] is None:
@@ -186,8 +191,10 @@ def sanity_check(config):
         raise NotImplementedError('integration/antenna_diagram (multi-Gaussian antenna fit, '
                                   'integration scheme 2) is out of scope of this build')
     if isinstance(config['radar']['nyquist_velocity'], str):
-        raise NotImplementedError('radar/nyquist_velocity files (RVEL aliasing) are not '
-                                  'supported yet')
+        from .nyquist import NyquistTable
+        config['radar']['nyquist_velocity'] = NyquistTable(config['radar']['nyquist_velocity'])
+    if nyq_obj is not None:
+        config['radar']['nyquist_velocity'] = nyq_obj
     if config['radar']['K_squared'] is None:
         from .dielectric import K_squared
         config['radar']['K_squared'] = float(K_squared(config['radar']['frequency']))

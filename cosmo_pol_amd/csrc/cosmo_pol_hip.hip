@@ -52,7 +52,7 @@ struct cpol_ctx {
         d_aux[CPOL_MAX_HYDRO], d_rcsw[CPOL_MAX_HYDRO];
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
     // per-sweep work buffers (grow only)
-    DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site;
+    DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site, b_nyq;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
         b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err, b_pos, b_vn, b_icefirst, b_rvel, b_fh, b_fv;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
@@ -151,7 +151,7 @@ void cpol_destroy(cpol_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj_in, &ctx->b_geo, &ctx->b_subh, &ctx->b_subv,
-                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_vals, &ctx->b_mask,
+                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_cursor, &ctx->b_units,
                      &ctx->b_urange, &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_err, &ctx->b_pos,
@@ -447,7 +447,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         return CPOL_ERR_ARG;
     }
     const bool cut = p->apply_sensitivity && t->sens_thr;
-    const long shape[6] = {n_rays, ng, n_sub, n_h, n_v, (long)mode * 4 + (t->site ? 2 : 0) + (cut ? 1 : 0)};
+    const long shape[6] = {n_rays, ng, n_sub, n_h, n_v, (long)mode * 8 + (t->nyquist ? 4 : 0) + (t->site ? 2 : 0) + (cut ? 1 : 0)};
     const bool reuse = t->version != 0 && t->version == ctx->tables_version &&
                        memcmp(shape, ctx->tables_shape, sizeof shape) == 0;
     if (!reuse) {
@@ -458,6 +458,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         if ((rc = upload(ctx, ctx->b_subv, t->sub_v, (size_t)n_sub * sizeof(int)))) return rc;
         if ((rc = upload(ctx, ctx->b_subw, t->sub_w, (size_t)n_sub * sizeof(double)))) return rc;
         if (cut && (rc = upload(ctx, ctx->b_sens, t->sens_thr, (size_t)ng * sizeof(double)))) return rc;
+        if (t->nyquist && (rc = upload(ctx, ctx->b_nyq, t->nyquist, (size_t)n_rays * sizeof(double)))) return rc;
         ctx->tables_version = t->version;
         memcpy(ctx->tables_shape, shape, sizeof shape);
     }
@@ -692,6 +693,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         fa.elev = (const float *)ctx->b_elev.p;
         fa.n_h = n_h;
         fa.var_u = p->var_u; fa.var_v = p->var_v; fa.var_w = p->var_w;
+        fa.nyquist = t->nyquist ? (const double *)ctx->b_nyq.p : nullptr;
         if (fa.var_u < 0 || fa.var_v < 0 || fa.var_w < 0 || fa.var_u >= n_vars ||
             fa.var_v >= n_vars || fa.var_w >= n_vars) {
             ctx->err = "cpol_run_sweep: simulate_doppler needs var_u / var_v / var_w";

@@ -79,6 +79,7 @@ struct FinalArgs {
     const float *elev;          // folded elevation per sub-beam gate (quirk Q8)
     int n_h, var_u, var_v, var_w;
     int vsrc[CPOL_MAX_HYDRO];   // 0: par (analytic), 1: vn per gate, 2: ice (first valid gate)
+    const double *nyquist;      // [n_rays] or NULL
 };
 
 __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
@@ -195,7 +196,15 @@ __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
             if (!(y == y)) y = 0.0;
             rv = x + y;
         }
-        a.RVEL[rg] = rv / tw;
+        rv = rv / tw;
+        if (a.nyquist) {
+            // aliasing (utilities.py:142-156)
+            const double nyq = a.nyquist[ray], pi = 3.14159265358979323846;
+            const double theta = (rv + nyq) / (2 * nyq) * pi - pi / 2.;
+            const double fold = atan(tan(theta));
+            rv = (fold + pi / 2) * (2 * nyq) / pi - nyq;
+        }
+        a.RVEL[rg] = rv;
     }
 
     // ---- radial mask (doppler_scatter.py:472-477) ----

@@ -364,6 +364,13 @@ class RadarOperator(object):
         t.sens_thr = thr.ctypes.data if thr is not None else None
         t.site = site.ctypes.data if site is not None else None
         t.paths = paths.ctypes.data if paths is not None else None
+        nyq = None
+        if doppler and conf['radar']['nyquist_velocity'] is not None:
+            # Nyquist velocity of every ray from its nominal elevation / azimuth
+            # (doppler_scatter.py:431-437: the central sub-beam's angles)
+            nyq = np.ascontiguousarray(conf['radar']['nyquist_velocity'](el, az), dtype=np.float64)
+            keep.append(nyq)
+        t.nyquist = nyq.ctypes.data if nyq is not None else None
         t.version = version
 
         o = N.Outputs()

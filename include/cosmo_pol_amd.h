@@ -159,6 +159,8 @@ typedef struct {
                                    index, number of kept gates, unused             */
     const float *paths;         /* CPOL_GEOM_HOST_PATHS: [n_rays][n_vnodes][3][n_gates]
                                    float32 (s, h, e_deg), NaN = no gate            */
+    const double *nyquist;      /* [n_rays] Nyquist velocity per ray [m/s] for the RVEL
+                                   aliasing (utilities.py:142-156) or NULL (no folding) */
     uint64_t version;           /* 0: tables are uploaded on every call; otherwise the
                                    caller's tag of this table set -- an unchanged tag
                                    means the device copies of the previous call are

@@ -58,7 +58,14 @@ def pol_from_sz(sz, config):
     return z_h, z_v, zdr, rhohv, kdp, ah, av, delta_hv
 
 
-def radar_observables(subbeams, luts, config, return_sz=False, doppler=True):
+def aliasing(v, nyquist):
+    """Velocity folding into [-nyquist, nyquist] (utilities.py:142-156)."""
+    theta = (v + nyquist) / (2 * nyquist) * np.pi - np.pi / 2.
+    theta_fold = np.arctan(np.tan(theta))
+    return (theta_fold + np.pi / 2) * (2 * nyquist) / np.pi - nyquist
+
+
+def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyquist=None):
     """One radial: list of SubBeam -> SubBeam of radar observables."""
     mp = config['microphysics']
     scheme = mp['scheme']
@@ -168,6 +175,8 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True):
             ZDR = ZH_ATT / ZV_ATT
         if simulate_doppler:
             rvel_avg /= total_weight_rvel
+            if nyquist is not None:          # doppler_scatter.py:431-437
+                rvel_avg = aliasing(rvel_avg, nyquist)
 
     obs = {'ZH': ZH, 'ZDR': ZDR, 'ZV': ZV, 'KDP': KDP, 'DELTA_HV': DELTA_HV, 'PHIDP': PHIDP,
            'RHOHV': RHOHV, 'ATT_H': AH, 'ATT_V': AV}

@@ -180,3 +180,15 @@ def test_lut_file_roundtrip(tmp_path):
     assert out['R'].value_table.shape == (2, 2, 1024, 12)
     with pytest.raises(IOError):
         plut.load_all_lut('1mom', ['S'], 5.6, 'tmatrix_masc', lut_dir=str(tmp_path))
+
+
+def test_nyquist_table(tmp_path):
+    from cosmo_pol_amd import config as cfg
+    fn = tmp_path / 'nyq.txt'
+    fn.write_text('elevation,azimuth,nyquist\n-0.2,0,8.3\n1.0,0,9.6\n1.0,180,10.5\n2.5,0,11.\n')
+    c = cfg.sanity_check({'radar': {'coords': [46.0, 7.0, 500], 'frequency': 5.6,
+                                    'nyquist_velocity': str(fn)}})
+    nyq = c['radar']['nyquist_velocity']
+    assert np.array_equal(nyq([0.9, 1.2, 2.4, -5.0], [10., 170., 300., 0.]), [9.6, 10.5, 11., 8.3])
+    c2 = cfg.sanity_check(c)                      # re-validation keeps the table object
+    assert c2['radar']['nyquist_velocity'] is nyq

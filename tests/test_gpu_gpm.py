@@ -154,3 +154,31 @@ def test_refraction_scheme_2_vs_oracle():
     res43 = op.simulate_rays([az], [el], apply_sensitivity=False)
     assert not np.array_equal(res43['heights'], res['heights'])
     op.close()
+
+
+def test_rvel_aliasing_vs_oracle(tmp_path):
+    """radar/nyquist_velocity file -> per-ray Nyquist velocity -> folded RVEL."""
+    from cosmo_pol_amd import RadarOperator
+    name = 'c2_rsg'
+    conf, az, el, ocube, luts, cube = _cases.radial_case(name)
+    over = _cases.gen_golden.radial_case_inputs(name)[0]
+    over = {k: dict(v) for k, v in over.items()}
+    fn = tmp_path / 'nyq.txt'
+    fn.write_text('elevation,azimuth,nyquist\n0.5,0,0.3\n4.0,0,3.3\n4.0,180,1.1\n9.0,0,6.\n')
+    over['radar']['nyquist_velocity'] = str(fn)
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar')
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    azs, els = np.array([az, 20.0]), np.array([el, 0.7])
+    res = op.simulate_rays(azs, els, apply_sensitivity=False)
+    olut = {h: _cases.as_oracle_lut(l) for h, l in luts.items()}
+    folded = 0
+    for r, nyq in enumerate([1.1, 0.3]):
+        subs = beam.interpolate_radial(ocube, conf, azs[r], els[r])
+        plain = scatter.radar_observables(subs, olut, conf).values['RVEL']
+        subs = beam.interpolate_radial(ocube, conf, azs[r], els[r])
+        o = scatter.radar_observables(subs, olut, conf, nyquist=nyq)
+        _cases.assert_close_nan(res['RVEL'][r], o.values['RVEL'], rtol=1e-5, atol=2e-4, name='RVEL')
+        assert np.nanmax(np.abs(res['RVEL'][r])) <= nyq + 1e-9
+        folded += int(np.nansum(np.abs(plain) > nyq))
+    assert folded > 10, 'aliasing was not exercised'
+    op.close()

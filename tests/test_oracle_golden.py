@@ -195,3 +195,11 @@ def test_radial_end_to_end(golden, name):
         # libm / SIMD differences between hosts: allow a few f32 ulps
         _cases.assert_close_nan(obs.values[n], g['obs_' + n], rtol=2e-6, atol=1e-30, name=n)
     assert np.array_equal(obs.mask, g['obs_mask'])
+
+
+def test_aliasing(golden):
+    g = golden('aliasing')
+    for i in range(3):
+        got = scatter.aliasing(g['v'].copy(), float(g['nyq_%d' % i]))
+        np.testing.assert_allclose(got, g['folded_%d' % i], rtol=0, atol=1e-12)
+        assert np.all(np.abs(got) <= float(g['nyq_%d' % i]) + 1e-9)
