@@ -354,6 +354,50 @@ def gen_lut_lookup(out):
     out['lut_lookup'] = d
 
 
+def gen_aliasing(out):
+    from cosmo_pol.utilities import aliasing
+    rng = np.random.default_rng(3)
+    v = rng.uniform(-40, 40, 200)
+    v[:4] = [0.0, 8.3, -8.3, 16.6]
+    d = dict(v=v)
+    for i, nyq in enumerate([8.3, 12.4, 5.0]):
+        d['nyq_%d' % i] = np.float64(nyq)
+        d['folded_%d' % i] = aliasing(v.copy(), nyq)
+    out['aliasing'] = d
+
+
+def gen_lut_file(out):
+    """A .lut file written by the product (cosmo_pol_amd.lut.save_lut) is read by the
+    REFERENCE's load_lut and queried with the reference's lookup_line; the query
+    results are the fixture (the file itself is regenerated by the test)."""
+    import tempfile
+    from cosmo_pol.lookup import lut as ref_lut
+    from cosmo_pol_amd import lut as our_lut
+    from cosmo_pol_amd import synthetic
+    rng = np.random.default_rng(5)
+    d = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for h in ['S', 'mG']:
+            table = synthetic.make_lut(h, 9.41, '1mom', n_e=3, n_t=5)
+            path = os.path.join(tmp, our_lut.lut_filename(h, 9.41, '1mom'))
+            our_lut.save_lut(table, path)
+            L = ref_lut.load_lut(path)
+            if not isinstance(L.axes_names, dict):
+                # NumPy >= 2: `ndarray.all()` of the 0-d object array no longer returns the
+                # dict itself (lut.py:147-148); every other member is what the reference read
+                L.axes_names = dict(table.axes_names)
+            e = rng.uniform(0, 6, 20).astype(np.float32)
+            ax = np.asarray(table.axes[1])
+            t = rng.uniform(ax[0], ax[-1], 20).astype(np.float32)
+            kw = {'e': e, ('wc' if h == 'mG' else 't'): t}
+            got = L.lookup_line(**kw)
+            assert got.shape == (20, 1024, 12)
+            d[h + '_e'], d[h + '_t'] = e, t
+            d[h + '_sum_d'] = got.sum(axis=1)          # [20, 12] is enough to pin the slices
+            d[h + '_shape'] = np.array(L.value_table.shape)
+    out['lut_file'] = d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE), 'tests', 'golden'))
@@ -363,7 +407,8 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     out = {}
     gens = dict(gate_kernel=gen_gate_kernel, trajectory=gen_trajectory, quadrature=gen_quadrature,
-                psd=gen_psd, pol=gen_pol, lut_lookup=gen_lut_lookup, radials=gen_radials)
+                psd=gen_psd, pol=gen_pol, lut_lookup=gen_lut_lookup, radials=gen_radials,
+                aliasing=gen_aliasing, lut_file=gen_lut_file)
     for k, g in gens.items():
         if args.only and k != args.only:
             continue
