@@ -71,7 +71,8 @@ class RayTables(C.Structure):
     _fields_ = [('traj', C.c_void_p), ('geo', C.c_void_p), ('sub_h', C.c_void_p),
                 ('sub_v', C.c_void_p), ('sub_w', C.c_void_p), ('sens_thr', C.c_void_p),
                 ('site', C.c_void_p), ('paths', C.c_void_p), ('nyquist', C.c_void_p),
-                ('version', C.c_uint64)]
+                ('version', C.c_uint64), ('sub_smooth', C.c_void_p), ('ml_filter', C.c_void_p),
+                ('ml_radius', C.c_int32), ('pad_', C.c_int32)]
 
 
 OUTPUT_FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V',

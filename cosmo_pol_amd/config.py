@@ -11,8 +11,9 @@ shipped option files is silently ignored, as upstream).
 Differences (documented): the configuration is an explicit object owned by a
 RadarOperator, not a module-global; `radar/type` defaults to 'ground' (upstream
 reads it unconditionally, global_constants.py:186, without defaulting it);
-antenna-diagram fitting (integration scheme 2) is out of scope (SURVEY.md
-section 2, item 12); a Nyquist file becomes a `nyquist.NyquistTable`.
+the sum-of-Gaussians antenna fit runs only for integration scheme 2 (and can
+be bypassed with `integration/antenna_params`); a Nyquist file becomes a
+`nyquist.NyquistTable`.
 """
 import builtins
 import copy
@@ -187,9 +188,15 @@ def sanity_check(config):
                 print('The default value {:s} was assigned'.format(str(DEFAULTS[section][key])))
                 config[section][key] = copy.deepcopy(DEFAULTS[section][key])
     config['radar'].setdefault('type', 'ground')
-    if config['integration'].get('antenna_diagram') is not None:
-        raise NotImplementedError('integration/antenna_diagram (multi-Gaussian antenna fit, '
-                                  'integration scheme 2) is out of scope of this build')
+    integ = config['integration']
+    if integ.get('antenna_diagram') is not None and integ['scheme'] == 2 \
+            and integ.get('antenna_params') is None:
+        # cfg.py:241-252 fits whenever a diagram is given; only scheme 2 uses the fit
+        from .quadrature import antenna_power_sq, fit_gaussians
+        print('Trying to fit sum of gaussians on the provided antenna diagram...')
+        angles, p2 = antenna_power_sq(integ['antenna_diagram'])
+        integ['antenna_params'] = fit_gaussians(angles, 10 * np.log10(p2), integ['n_gaussians'])
+        print('Fit was successful !')
     if isinstance(config['radar']['nyquist_velocity'], str):
         from .nyquist import NyquistTable
         config['radar']['nyquist_velocity'] = NyquistTable(config['radar']['nyquist_velocity'])

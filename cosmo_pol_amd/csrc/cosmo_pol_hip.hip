@@ -53,6 +53,7 @@ struct cpol_ctx {
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
     // per-sweep work buffers (grow only)
     DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site, b_nyq;
+    DevBuf b_subsmooth, b_mlfilter, b_wgate;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
         b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err, b_pos, b_vn, b_icefirst, b_rvel, b_fh, b_fv;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
@@ -151,7 +152,7 @@ void cpol_destroy(cpol_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj_in, &ctx->b_geo, &ctx->b_subh, &ctx->b_subv,
-                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_vals, &ctx->b_mask,
+                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_subsmooth, &ctx->b_mlfilter, &ctx->b_wgate, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_cursor, &ctx->b_units,
                      &ctx->b_urange, &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_err, &ctx->b_pos,
@@ -447,7 +448,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         return CPOL_ERR_ARG;
     }
     const bool cut = p->apply_sensitivity && t->sens_thr;
-    const long shape[6] = {n_rays, ng, n_sub, n_h, n_v, (long)mode * 8 + (t->nyquist ? 4 : 0) + (t->site ? 2 : 0) + (cut ? 1 : 0)};
+    const bool ml = t->sub_smooth != nullptr;
+    if (ml && (!t->ml_filter || t->ml_radius < 0 || t->ml_radius > 64)) {
+        ctx->err = "cpol_run_sweep: sub_smooth needs ml_filter / ml_radius";
+        return CPOL_ERR_ARG;
+    }
+    const long shape[6] = {n_rays, ng, n_sub, n_h, n_v, (ml ? 64 + t->ml_radius * 128L : 0) + (long)mode * 8 + (t->nyquist ? 4 : 0) + (t->site ? 2 : 0) + (cut ? 1 : 0)};
     const bool reuse = t->version != 0 && t->version == ctx->tables_version &&
                        memcmp(shape, ctx->tables_shape, sizeof shape) == 0;
     if (!reuse) {
@@ -459,6 +465,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         if ((rc = upload(ctx, ctx->b_subw, t->sub_w, (size_t)n_sub * sizeof(double)))) return rc;
         if (cut && (rc = upload(ctx, ctx->b_sens, t->sens_thr, (size_t)ng * sizeof(double)))) return rc;
         if (t->nyquist && (rc = upload(ctx, ctx->b_nyq, t->nyquist, (size_t)n_rays * sizeof(double)))) return rc;
+        if (ml && (rc = upload(ctx, ctx->b_subsmooth, t->sub_smooth, (size_t)n_sub * sizeof(int)))) return rc;
+        if (ml && (rc = upload(ctx, ctx->b_mlfilter, t->ml_filter, (size_t)(2 * t->ml_radius + 1) * sizeof(double)))) return rc;
         ctx->tables_version = t->version;
         memcpy(ctx->tables_shape, shape, sizeof shape);
     }
@@ -469,6 +477,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_mask, (size_t)n_sbg);
     ENSURE(ctx->b_elev, (size_t)n_sbg * sizeof(float));
     if (ctx->keep_debug) ENSURE(ctx->b_coords, (size_t)n_sbg * 2 * sizeof(float));
+    if (ml) ENSURE(ctx->b_wgate, (size_t)n_sbg * sizeof(double));
     ENSURE(ctx->b_qmelt, (size_t)2 * n_sbg * sizeof(float));
     ENSURE(ctx->b_fwmelt, (size_t)2 * n_sbg * sizeof(double));
     ENSURE(ctx->b_key, (size_t)n_hyd * n_sbg * sizeof(int));
@@ -598,6 +607,19 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ctx->err = "cpol_run_sweep: melting needs 1-moment rain, snow and graupel slots";
         return CPOL_ERR_ARG;
     }
+    if (ml) {
+        MlArgs ma{};
+        ma.vals = (const float *)ctx->b_vals.p;
+        ma.sub_w = (const double *)ctx->b_subw.p;
+        ma.sub_smooth = (const int *)ctx->b_subsmooth.p;
+        ma.taps = (const double *)ctx->b_mlfilter.p;
+        ma.wgate = (double *)ctx->b_wgate.p;
+        ma.n_sbg = n_sbg; ma.n_sub = n_sub; ma.n_gates = ng; ma.radius = t->ml_radius;
+        ma.with_melting = p->with_melting;
+        ma.var_qr = ca.var_qr; ma.var_qs = ca.var_qs; ma.var_qg = ca.var_qg;
+        hipLaunchKernelGGL(k_ml_weights, dim3(n_rays * n_sub), dim3(64), 0, st, ma);
+        ca.wgate = (const double *)ctx->b_wgate.p;
+    }
     hipLaunchKernelGGL(k_classify, dim3(cdiv(n_sbg, CPOL_CLASSIFY_THREADS)),
                        dim3(CPOL_CLASSIFY_THREADS), 0, st, ctx->hs, ca);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_CLASSIFY], st));
@@ -682,6 +704,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     fa.FH = p->with_attenuation ? (float *)ctx->b_fh.p : nullptr;
     fa.FV = p->with_attenuation ? (float *)ctx->b_fv.p : nullptr;
     fa.res_km = (float)(p->radial_res / 1000.);
+    fa.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
     fa.RVEL = nullptr;
     if (doppler) {
         fa.RVEL = (double *)ctx->b_rvel.p;

@@ -53,6 +53,70 @@ __global__ __launch_bounds__(64) void k_ice_first(const int *__restrict__ key_j,
     }
 }
 
+// Integration scheme 'ml': per-gate weights of every sub-beam.  One wavefront per
+// (ray, sub-beam): first / last melting-layer gate (melting.py:41, values BEFORE the
+// melting scheme zeroes them), then w x 1 (high-weight nodes) or w x the two edge
+// deltas smoothed by scipy.ndimage.gaussian_filter(sigma = 2, mode 'reflect')
+// (interpolation.py:423-436).  Summation order of correlate1d's symmetric branch:
+// centre tap, then pairs from the outermost tap inwards.
+struct MlArgs {
+    const float *vals;          // [n_vars][n_sbg], before k_classify
+    const double *sub_w;
+    const int *sub_smooth;
+    const double *taps;         // [2r+1]
+    double *wgate;              // [n_sbg]
+    long n_sbg;
+    int n_sub, n_gates, radius, with_melting;
+    int var_qr, var_qs, var_qg;
+};
+
+__device__ __forceinline__ int reflect_index(int i, int n)
+{
+    // scipy 'reflect': (d c b a | a b c d | d c b a)
+    while (i < 0 || i >= n) i = (i < 0) ? -i - 1 : 2 * n - 1 - i;
+    return i;
+}
+
+__global__ __launch_bounds__(64) void k_ml_weights(MlArgs a)
+{
+    const long rs = blockIdx.x;
+    const int s = (int)(rs % a.n_sub);
+    const int lane = threadIdx.x;
+    const long base = rs * a.n_gates;
+    const double w = a.sub_w[s];
+    if (!a.sub_smooth[s]) {
+        for (int g = lane; g < a.n_gates; g += 64) a.wgate[base + g] = w * 1.0;
+        return;
+    }
+    int first = 0x7fffffff, last = -1;
+    if (a.with_melting) {
+        for (int g = lane; g < a.n_gates; g += 64) {
+            const float qr = a.vals[a.var_qr * a.n_sbg + base + g];
+            const float qsg = a.vals[a.var_qs * a.n_sbg + base + g] + a.vals[a.var_qg * a.n_sbg + base + g];
+            if (qr > 0.f && qsg > 0.f) { first = min(first, g); last = max(last, g); }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            first = min(first, __shfl_xor(first, off));
+            last = max(last, __shfl_xor(last, off));
+        }
+    }
+    const int r = a.radius;
+    for (int g = lane; g < a.n_gates; g += 64) {
+        double m = 0.0;
+        if (last >= 0) {
+            m = ((g == first || g == last) ? 1.0 : 0.0) * a.taps[r];
+            for (int k = r; k >= 1; --k) {
+                const int lo = reflect_index(g - k, a.n_gates), hi = reflect_index(g + k, a.n_gates);
+                const double pair = ((lo == first || lo == last) ? 1.0 : 0.0)
+                                  + ((hi == first || hi == last) ? 1.0 : 0.0);
+                m += pair * a.taps[r - k];
+            }
+        }
+        a.wgate[base + g] = w * m;
+    }
+}
+
 struct FinalArgs {
     const double *res;          // [n_hydro][n_sbg][12]
     const int *key;             // [n_hydro][n_sbg]
@@ -80,6 +144,7 @@ struct FinalArgs {
     int n_h, var_u, var_v, var_w;
     int vsrc[CPOL_MAX_HYDRO];   // 0: par (analytic), 1: vn per gate, 2: ice (first valid gate)
     const double *nyquist;      // [n_rays] or NULL
+    const double *wgate;        // [n_sbg] per-gate sub-beam weights (scheme 'ml') or NULL
 };
 
 __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
@@ -92,6 +157,11 @@ __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
     const long sbg0 = (long)ray * a.n_sub * a.n_gates + gate;      // + sub * n_gates
     const float qnan = __builtin_nanf("");
 
+    // scheme 'ml': weights renormalised gate by gate (doppler_scatter.py:124-129)
+    double wtot = 0.0;
+    if (a.wgate)
+        for (int s = 0; s < a.n_sub; ++s) wtot += a.wgate[sbg0 + (long)s * a.n_gates];
+
     float tot[CPOL_N_SZ];
     for (int j = 0; j < a.n_hydro; ++j) {
         float acc[CPOL_N_SZ];
@@ -100,7 +170,7 @@ __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
         for (int s = 0; s < a.n_sub; ++s) {
             const long sbg = sbg0 + (long)s * a.n_gates;
             if (a.key[(long)j * n_sbg + sbg] < 0) continue;
-            const double w = a.sub_w[s];
+            const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
             const double *r = a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ;
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c) {
@@ -189,7 +259,7 @@ __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
             const double V = (double)a.vals[(long)a.var_v * n_sbg + sbg];
             const double W = (double)a.vals[(long)a.var_w * n_sbg + sbg];
             const double proj = (U * gc[0] + V * gc[1]) * ct + (W - vh) * st;   // proj_vel :46-47
-            const double w = a.sub_w[s];
+            const double w = a.wgate ? a.wgate[sbg] : a.sub_w[s];
             if (proj == proj) tw += w;
             double x = (rv == rv) ? rv : 0.0;
             double y = proj * w;
@@ -219,8 +289,9 @@ __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
         for (int v = 0; v < a.n_vars; ++v) {
             double acc = 0.0;
             for (int s = 0; s < a.n_sub; ++s) {
-                double y = (double)a.vals[(long)v * n_sbg + sbg0 + (long)s * a.n_gates]
-                           * a.sub_w[s] / a.sum_w;
+                const long sbg = sbg0 + (long)s * a.n_gates;
+                double y = a.wgate ? (double)a.vals[(long)v * n_sbg + sbg] * a.wgate[sbg] / wtot
+                                   : (double)a.vals[(long)v * n_sbg + sbg] * a.sub_w[s] / a.sum_w;
                 if (y == y) acc += y;
             }
             a.model_vars[(long)v * n_rg + rg] = acc;

@@ -146,6 +146,7 @@ struct ClassifyArgs {
     int with_melting;
     int var_qr, var_qs, var_qg;
     int doppler;                 // also store the analytic fall-speed moments (integrate_V)
+    const double *wgate;         // [n_sbg] per-gate sub-beam weights (scheme 'ml') or NULL
 };
 
 #define CPOL_MAX_PAR 6
@@ -196,7 +197,9 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             else if (d.q_source == CPOL_Q_MELT_SNOW) { qm = qms; fw = fws; }
             else { qm = qmg; fw = fwg; }
         }
-        const bool valid = in && (qm > 0.f);          // NaN -> false (doppler_scatter.py:185)
+        // NaN -> false (doppler_scatter.py:185); scheme 'ml': only gates where the
+        // sub-beam has a non-zero weight (:186-189)
+        const bool valid = in && (qm > 0.f) && (!a.wgate || a.wgate[i] > 0.0);
         int key = -1;
         if (valid) {
             const float T = a.vals[d.var_t * n + i];

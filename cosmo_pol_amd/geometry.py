@@ -45,6 +45,17 @@ class SubBeams(object):
         self.sub_h = ih.astype(np.int32)
         self.sub_v = jv.astype(np.int32)
         self.sub_w = np.ascontiguousarray(weights[ih, jv], dtype=np.float64)
+        # scheme 'ml' only: sub-beams whose weight is w x (smoothed melting-layer edge mask)
+        self.sub_smooth = None
+        self.ml_radius, self.ml_filter = 0, None
+
+    @classmethod
+    def from_points(cls, off_hor, off_ver, weights):
+        """Irregular quadratures (point lists): every sub-beam has its own azimuth and
+        elevation offset, i.e. horizontal node k pairs with vertical node k only."""
+        n = len(weights)
+        sb = cls(off_hor, off_ver, np.diag(np.asarray(weights, dtype=np.float64)), np.eye(n, dtype=bool))
+        return sb
 
     @property
     def n_sub(self):
@@ -56,9 +67,8 @@ class SubBeams(object):
 
 
 def gauss_hermite_subbeams(config):
-    if config['integration']['scheme'] != 1:
-        raise NotImplementedError('only antenna integration scheme 1 (Gauss-Hermite) is '
-                                  'implemented (schemes ml, 2-6: SURVEY.md 8(f) rank 3)')
+    """Scheme 1 only (kept for callers that want the plain Gauss-Hermite grid);
+    `quadrature.subbeams` dispatches on integration/scheme."""
     bw = config['radar']['3dB_beamwidth']
     nh = int(config['integration']['nh_GH'])
     nv = int(config['integration']['nv_GH'])

@@ -21,6 +21,7 @@ from . import config as cfg
 from . import constants as K
 from . import geometry as geo
 from . import hydrometeors as hyd
+from . import quadrature
 from .lut import load_all_lut
 
 RADAR_FIELDS = ['ZH', 'ZDR', 'ZV', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V']
@@ -276,7 +277,7 @@ class RadarOperator(object):
                       'variable; 4/3 Earth model will be used instead...')
             else:
                 from . import refraction
-                sub = self._cached('sub', lambda: geo.gauss_hermite_subbeams(conf))
+                sub = self._cached('sub', lambda: quadrature.subbeams(conf))
                 h_col, n_col = refraction.refractivity_column(
                     self.N.data, self._zlevels, self._proj, self._res, coords,
                     conf['radar'].get('type', 'ground'))
@@ -295,7 +296,7 @@ class RadarOperator(object):
             raise ValueError('azimuths and elevations must have the same length')
         n_rays = len(az)
         if sub is None:
-            sub = self._cached('sub', lambda: geo.gauss_hermite_subbeams(conf))
+            sub = self._cached('sub', lambda: quadrature.subbeams(conf))
         version = 0
         if tables is not None:
             traj, geo_t = tables
@@ -371,6 +372,10 @@ class RadarOperator(object):
             nyq = np.ascontiguousarray(conf['radar']['nyquist_velocity'](el, az), dtype=np.float64)
             keep.append(nyq)
         t.nyquist = nyq.ctypes.data if nyq is not None else None
+        if sub.sub_smooth is not None:        # integration scheme 'ml': per-gate weights
+            t.sub_smooth = sub.sub_smooth.ctypes.data
+            t.ml_filter = sub.ml_filter.ctypes.data
+            t.ml_radius = int(sub.ml_radius)
         t.version = version
 
         o = N.Outputs()
@@ -514,7 +519,7 @@ class RadarOperator(object):
             dim = az.shape
             az, el, rng = az.ravel(), el.ravel(), rng.ravel()
             coords = np.repeat(sat, dim[1], axis=0)                      # one site per ray
-            sub = geo.gauss_hermite_subbeams(self.__config)
+            sub = quadrature.subbeams(self.__config)
             traj, geo_t = geo.ray_tables(coords, az, el, sub)
             n_rays = len(az)
             # candidate gates: np.arange(res/2, slant range, res) (atm_refraction.py:252)

@@ -165,6 +165,14 @@ typedef struct {
                                    caller's tag of this table set -- an unchanged tag
                                    means the device copies of the previous call are
                                    reused (repeated scans of the same geometry)      */
+    /* integration scheme 'ml' (interpolation.py:168-193, 423-436; per-gate weights as in
+       doppler_scatter.py:124-129, 186-189, 259-264): NULL / 0 for scalar weights */
+    const int32_t *sub_smooth;  /* [n_sub] 1: the weight of this sub-beam is sub_w x the
+                                   Gaussian-smoothed mask of the first / last melting-layer
+                                   gate of the sub-beam; 0: sub_w at every gate          */
+    const double *ml_filter;    /* [2 * ml_radius + 1] filter taps (scipy gaussian_filter) */
+    int32_t ml_radius;
+    int32_t pad_;
 } cpol_ray_tables_t;
 
 typedef struct {

@@ -163,43 +163,62 @@ def gate_coordinates(cube, coords_radar, azimuth, dist):
     return lats, lons, rc
 
 
+def _one_subbeam(cube, config, coords_radar, az_pt, el_pt, traj, weight, which):
+    s, h, e = traj
+    lats, lons, rc = gate_coordinates(cube, coords_radar, az_pt, s)
+    vals = {}
+    mask = None
+    for k, name in enumerate(cube.order):
+        b = get_all_radar_pts(rc, h, cube.data[name], cube.zlevels, cube.llc,
+                              cube.resolution, which=which)
+        if k == 0:       # mask from the FIRST variable only (:401-409)
+            mask = np.zeros((len(b)))
+            mask[b == -9999] = 1
+            mask[np.isnan(b)] = -1
+        b[mask != 0] = np.nan
+        vals[name] = b
+    # NB the reference shares the trajectory arrays between sub-beams with
+    # the same vertical node; the in-place elevation fold (quirk Q8) is
+    # idempotent, so private copies give the same numbers.
+    sb = SubBeam(vals, mask, lats, lons, s, h, e.copy(), [az_pt, el_pt], weight)
+    if config['microphysics']['with_melting']:
+        apply_melting(sb)
+    return sb
+
+
 def interpolate_radial(cube, config, azimuth, elevation, which='twin', trajs=None,
                        coords_radar=None):
-    """All kept sub-beams of one radial (i-major order: horizontal index outer,
-    vertical inner), each with mask coding and optional melting.
-    `trajs`: optional list of (s, h, e) per vertical node replacing the 4/3-earth
-    model (spaceborne rays, ODE refraction); `coords_radar`: site of this ray."""
-    pts_hor, pts_ver, weights, keep = gauss_hermite_subbeams(config)
+    """All kept sub-beams of one radial (regular quadratures: horizontal index outer,
+    vertical inner; schemes with point lists: list order), each with mask coding and
+    optional melting.  `trajs`: optional list of (s, h, e) per vertical node (per
+    point for list quadratures) replacing the 4/3-earth model (spaceborne rays, ODE
+    refraction); `coords_radar`: site of this ray."""
+    from .quadrature import ml_edge_mask, quadrature
+    q = quadrature(config)
     if coords_radar is None:
         coords_radar = config['radar']['coords']
     if trajs is None:
         der = K.Derived(config)
-        trajs = [trajectory_4_3(der.RANGE_RADAR, pt + elevation, coords_radar) for pt in pts_ver]
+        trajs = [trajectory_4_3(der.RANGE_RADAR, pt + elevation, coords_radar) for pt in q.pts_ver]
     out = []
-    for i in range(len(pts_hor)):
-        for j in range(len(pts_ver)):
-            if not keep[i, j]:
+    if q.kind == 'list':
+        for i in range(len(q.weights)):
+            if q.weights[i] >= q.threshold:
+                out.append(_one_subbeam(cube, config, coords_radar, q.pts_hor[i] + azimuth,
+                                        q.pts_ver[i] + elevation, trajs[i], q.weights[i], which))
+        return out
+    for i in range(len(q.pts_hor)):
+        for j in range(len(q.pts_ver)):
+            if not (q.weights[i, j] >= q.threshold or not q.broadening):
                 continue
-            s, h, e = trajs[j]
-            lats, lons, rc = gate_coordinates(cube, coords_radar, pts_hor[i] + azimuth, s)
-            vals = {}
-            mask = None
-            for k, name in enumerate(cube.order):
-                b = get_all_radar_pts(rc, h, cube.data[name], cube.zlevels, cube.llc,
-                                      cube.resolution, which=which)
-                if k == 0:       # mask from the FIRST variable only (:401-409)
-                    mask = np.zeros((len(b)))
-                    mask[b == -9999] = 1
-                    mask[np.isnan(b)] = -1
-                b[mask != 0] = np.nan
-                vals[name] = b
-            # NB the reference shares the trajectory arrays between sub-beams with
-            # the same vertical node; the in-place elevation fold (quirk Q8) is
-            # idempotent, so private copies give the same numbers.
-            sb = SubBeam(vals, mask, lats, lons, s, h, e.copy(),
-                         [pts_hor[i] + azimuth, pts_ver[j] + elevation], weights[i, j])
-            if config['microphysics']['with_melting']:
-                apply_melting(sb)
+            sb = _one_subbeam(cube, config, coords_radar, q.pts_hor[i] + azimuth,
+                              q.pts_ver[j] + elevation, trajs[j], q.weights[i, j], which)
+            if q.ml_nv is not None:          # scheme 'ml' (interpolation.py:423-436)
+                n = len(sb.lats_profile)
+                if j > q.ml_nv:
+                    sb.quad_weight = sb.quad_weight * ml_edge_mask(sb.mask_ml, n)
+                else:
+                    sb.quad_weight = sb.quad_weight * np.ones(n)
             out.append(sb)
     return out
 

@@ -88,6 +88,11 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyq
         hyd[h].d_min = d_ax[:, 0] if h in ['mS', 'mG'] else d_ax[0]
         hyd[h].d_max = d_ax[:, -1] if h in ['mS', 'mG'] else d_ax[-1]
 
+    # scheme 'ml': per-gate sub-beam weights, renormalised gate by gate (:124-129)
+    array_weights = not np.isscalar(subbeams[0].quad_weight)
+    if array_weights:
+        total_weight_at_gates = np.sum(np.array([b.quad_weight for b in subbeams]), axis=0)
+
     sz_integ = np.zeros((n_gates, len(hydrom_types), 12), dtype='float32') + np.nan
     rvel_avg = np.zeros(n_gates,) + np.nan
     total_weight_rvel = np.zeros(n_gates,)
@@ -105,6 +110,8 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyq
                 T = sb.values['T']
                 QM = sb.values['Q' + h + '_v']
                 valid = QM > 0
+                if array_weights:                    # :186-189
+                    valid = np.logical_and(valid, sb.quad_weight > 0)
                 if not np.any(valid):
                     continue
                 if scheme == '1mom':
@@ -139,7 +146,12 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyq
                     sz = luts[h].lookup_line(e=elev_lut[valid], t=T[valid])
                     sz_psd = np.einsum('ijk,ij->ik', sz, N) * dD
 
-                sz_integ[valid, j, :] = nansum_pair(sz_integ[valid, j, :], sz_psd * sb.quad_weight)
+                if array_weights:                    # :259-264
+                    w = sb.quad_weight[valid] / total_weight_at_gates[valid]
+                    sz_integ[valid, j, :] = nansum_pair(sz_integ[valid, j, :], w[:, None] * sz_psd)
+                else:
+                    sz_integ[valid, j, :] = nansum_pair(sz_integ[valid, j, :],
+                                                        sz_psd * sb.quad_weight)
 
                 if simulate_doppler and dop_scheme == 1:
                     vh, n = hyd[h].integrate_V()

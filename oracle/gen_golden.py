@@ -253,7 +253,43 @@ RADIAL_CASES = {
                  'integration': {'nh_GH': 1, 'nv_GH': 1}}, 75.0, 8.0, ('R', 'S', 'G', 'I'), True),
 }
 
+ANTENNA_CSV = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'antenna_diagram.csv')
+
+# antenna quadratures other than scheme 1
+RADIAL_CASES.update({
+    'q_ml': ({'radar': {'range': 36000, 'radial_resolution': 400},
+              'microphysics': {'with_ice_crystals': 0, 'with_melting': 1},
+              'integration': {'scheme': 'ml', 'nh_GH': 1, 'nv_GH': 1}}, 120.0, 5.0,
+             ('R', 'S', 'G'), False),
+    'q_ml_thr': ({'radar': {'range': 30000, 'radial_resolution': 500},
+                  'microphysics': {'with_ice_crystals': 1, 'with_melting': 1},
+                  'integration': {'scheme': 'ml', 'nh_GH': 3, 'nv_GH': 1,
+                                  'weight_threshold': 0.9999}}, 40.0, 3.0,
+                 ('R', 'S', 'G', 'I'), False),
+    'q_legendre': ({'radar': {'range': 30000, 'radial_resolution': 500},
+                    'microphysics': {'with_ice_crystals': 0, 'with_melting': 0},
+                    'integration': {'scheme': 3, 'nh_GH': 3, 'nv_GH': 3,
+                                    'antenna_diagram': ANTENNA_CSV}}, 200.0, 4.0,
+                   ('R', 'S', 'G'), False),
+    'q_multigauss': ({'radar': {'range': 30000, 'radial_resolution': 500},
+                      'microphysics': {'with_ice_crystals': 0, 'with_melting': 0},
+                      'integration': {'scheme': 2, 'nr_GH': 3, 'na_GL': 3, 'weight_threshold': 0.99,
+                                      'antenna_params': [[0.0, 0.0, 0.42], [-25.0, 1.8, 0.3],
+                                                         [-32.0, 3.2, 0.4]]}}, 200.0, 4.0,
+                     ('R', 'S', 'G'), False),
+})
+
 LUT_KW = dict(seed=20260301, n_e=8, n_t=None)
+
+
+def write_antenna_csv(path=ANTENNA_CSV):
+    """Synthetic one-way antenna diagram (angle in deg, power in dB): Gaussian main
+    lobe of 1 deg beamwidth plus two side lobes; a data fixture for schemes 2 / 3."""
+    ang = np.round(np.arange(-5.0, 5.0 + 1e-9, 0.1), 1)
+    sig = 1.0 / (2 * np.sqrt(2 * np.log(2)))
+    p = (np.exp(-ang ** 2 / (2 * sig ** 2)) + 10 ** -2.6 * np.exp(-(np.abs(ang) - 1.9) ** 2 / (2 * 0.25 ** 2))
+         + 10 ** -3.3 * np.exp(-(np.abs(ang) - 3.4) ** 2 / (2 * 0.35 ** 2)) + 1e-5)
+    np.savetxt(path, np.column_stack([ang, 10 * np.log10(p)]), delimiter=',', fmt='%.6f')
 
 
 def radial_case_inputs(name):
@@ -270,13 +306,17 @@ def radial_case_inputs(name):
     return base, az, el, cube, two
 
 
-def gen_radials(out):
+def gen_radials(out, only_cases=None):
     from cosmo_pol_amd import synthetic
     from cosmo_pol.interpolation import get_interpolated_radial, integrate_radials
     from cosmo_pol.scatter import get_radar_observables
     from cosmo_pol_oracle.config import hydrometeor_list, make_config
     lut_cache = {}
+    if not os.path.exists(ANTENNA_CSV):
+        write_antenna_csv()
     for name in RADIAL_CASES:
+        if only_cases and name not in only_cases:
+            continue
         over, az, el, cube, two = radial_case_inputs(name)
         conf = ref_shim.configure_reference(over)
         scheme = conf['microphysics']['scheme']
@@ -294,6 +334,9 @@ def gen_radials(out):
                                       cube['proj_info'], cube['resolution'])
         subs = get_interpolated_radial(dv, az, el, N=0)
         d = dict(azimuth=az, elevation=el, n_sub=len(subs))
+        ng = len(subs[0].dist_profile)
+        d['quad_w'] = np.array([np.broadcast_to(sb.quad_weight, (ng,)) for sb in subs])
+        d['quad_pts'] = np.array([sb.quad_pt for sb in subs], dtype=np.float64)
         c = subs[int(len(subs) / 2)]
         # interpolated model variables of the central + first sub-beam
         for tag, sb in (('c', c), ('f', subs[0])):
@@ -402,6 +445,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE), 'tests', 'golden'))
     ap.add_argument('--only', default=None)
+    ap.add_argument('--cases', default=None, help='comma-separated radial case names (with --only radials)')
     args = ap.parse_args()
     ref_shim.load_reference()
     os.makedirs(args.out, exist_ok=True)
@@ -412,7 +456,10 @@ def main():
     for k, g in gens.items():
         if args.only and k != args.only:
             continue
-        g(out)
+        if k == 'radials' and args.cases:
+            g(out, args.cases.split(','))
+        else:
+            g(out)
     for name, d in out.items():
         path = os.path.join(args.out, name + '.npz')
         np.savez_compressed(path, **d)

@@ -173,6 +173,11 @@ def test_radial_end_to_end(golden, name):
     conf, az, el, cube, luts, _ = _cases.radial_case(name)
     subs = beam.interpolate_radial(cube, conf, az, el)
     assert len(subs) == int(g['n_sub'])
+    if 'quad_w' in g:           # antenna quadratures other than scheme 1
+        ng = g['quad_w'].shape[1]
+        got_w = np.array([np.broadcast_to(sb.quad_weight, (ng,)) for sb in subs])
+        np.testing.assert_allclose(got_w, g['quad_w'], rtol=1e-13, atol=1e-300)
+        np.testing.assert_allclose(np.array([sb.quad_pt for sb in subs]), g['quad_pts'], rtol=0, atol=1e-12)
     c = subs[int(len(subs) / 2)]
     for tag, sb in (('c', c), ('f', subs[0])):
         for n in sb.values:
