@@ -549,6 +549,50 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
         const double N0 = active ? P[n] : 0.0;
         const cdouble_p Dl = as_const(h.aux);
         const cdouble_p Dn = as_const(h.aux + n_d);
+        if (d.uniform_grid) {
+            // PHI_23 on two uniform grids: both exponentials by geometric recurrence from an
+            // exact exp at the chunk start, float32 node rounding restored to third order,
+            // x^0.6357 = (lambda/1000)^0.6357 D^0.6357 (host table); see
+            // hydrometeors.py::_ice_recurrence_aux.  msum carries no N0 (applied below).
+            const cdouble_p hd = as_const(h.aux + 4 * n_d + 4);
+            const cdouble_p ql = as_const(h.aux + 4 * n_d + 8);
+            const cdouble_p qn = as_const(h.aux + 4 * n_d + 8 + 4 * n_d);
+            const double lp = lam / 1000.0;
+            const double a1 = 20.78 * lp, a2 = 3.290 * lp;
+            const double B = 17.46 * powp(lp, 0.6357);
+            const double a1s = a1 * a1, a1c = a1s * a1, a2s = a2 * a2, a2c = a2s * a2;
+            const double dl0 = Dl[k0 < n_d ? k0 : 0], dn0 = Dn[k0 < n_d ? k0 : 0];
+            double E1 = exp(-(a1 * dl0)), E2 = exp(-(a2 * dl0));
+            double F1 = exp(-(a1 * dn0)), F2 = exp(-(a2 * dn0));
+            const double r1 = exp(-(a1 * hd[0])), r2 = exp(-(a2 * hd[0]));
+            const double s1 = exp(-(a1 * hd[1])), s2 = exp(-(a2 * hd[1]));
+#pragma unroll 2
+            for (int k = k0; k < k1; ++k) {
+                const double pwn = qn[4 * k], adb = qn[4 * k + 1], vk = qn[4 * k + 2];
+                const double x1 = a1 * qn[4 * k + 3], x2 = a2 * qn[4 * k + 3];
+                const double g1 = fma(x1, fma(x1, fma(x1, -1.0 / 6.0, 0.5), -1.0), 1.0);
+                const double g2 = fma(x2, fma(x2, fma(x2, -1.0 / 6.0, 0.5), -1.0), 1.0);
+                const double phn = fma(B * pwn, F2 * g2, 490.6 * (F1 * g1));
+                F1 *= s1;
+                F2 *= s2;
+                msum = fma(adb, phn, msum);
+                if (!DOP2) {
+                    vsum = fma(phn, vk, vsum);
+                    nsum += phn;
+                }
+                const double d1 = ql[4 * k], d2 = ql[4 * k + 1], d3 = ql[4 * k + 2], pw = ql[4 * k + 3];
+                const double c1 = fma(-a1, d1, fma(a1s, d2, fma(-a1c, d3, 1.0)));
+                const double c2 = fma(-a2, d1, fma(a2s, d2, fma(-a2c, d3, 1.0)));
+                const double ph = fma(B * pw, E2 * c2, 490.6 * (E1 * c1));
+                E1 *= r1;
+                E2 *= r2;
+                const cdouble_p row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], ph, acc[c]);
+                if (DOP2) { vsum = fma(rv[2 * k], ph, vsum); nsum = fma(rv[2 * k + 1], ph, nsum); }
+            }
+            msum *= N0;
+        } else {
         const cdouble_p aDb = as_const(h.aux + 2 * n_d);
         const cdouble_p Vn = as_const(h.aux + 3 * n_d + 1);   // alpha * Dn^beta (get_V)
 #pragma unroll 1
@@ -566,6 +610,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], ph, acc[c]);
             if (DOP2) { vsum = fma(rv[2 * k], ph, vsum); nsum = fma(rv[2 * k + 1], ph, nsum); }
+        }
         }
     } else {
         MeltItem it;

@@ -121,6 +121,9 @@ def build_hydro(h, scheme, lut, var_index):
         aux = np.concatenate([D.astype(np.float64), np.asarray(Dn, dtype=np.float64),
                               np.asarray(aDb, dtype=np.float64), [np.float64(dDn)],
                               np.asarray(Vn, dtype=np.float64)])
+        fast = _ice_recurrence_aux(d, D, Dn, aDb, Vn, n_d)
+        if fast is not None:
+            aux = np.concatenate([aux, fast])
         return d, table, None, None, aux
 
     d.psd_family = N.PSD_GAMMA
@@ -191,6 +194,39 @@ def _uniform_grid_aux(d, D, nu, n_d, pre):
     p64 = np.asarray(pre, dtype=np.float64)
     quads = np.stack([p64, p64 * dlt, p64 * dlt * dlt / 2.0, np.zeros(n_d)], axis=1).ravel()
     return np.concatenate([[h], dlt, quads]).astype(np.float64)
+
+
+ICE_POWER = 0.6357          # exponent of the second term of PHI_23_I (constants_1mom.py)
+
+
+def _ice_recurrence_aux(d, D, Dn, aDb, Vn, n_d):
+    """1-moment ice: PHI_23(x) = 490.6 exp(-20.78 x) + 17.46 x^0.6357 exp(-3.29 x) with
+    x = lambda D / 1000 on two (nearly) uniform grids -- the float32 table axis and the
+    normalisation grid (np.linspace between float32 end points: float32 nodes too).  Both exponentials advance by geometric recurrences inside
+    a wave chunk; x^0.6357 splits into an item factor and the per-bin table D^0.6357.
+    Appended to aux (after [D, Dn, a Dn^b, dDn, Vn] = 4 n_d + 1 values, padded to
+    4 n_d + 4): [h_lut, h_norm, 0, 0] then per bin (dlt, dlt^2/2, dlt^3/6, D^p) for the
+    table axis and (Dn^p, a Dn^b, V(Dn), dlt_n) for the normalisation grid."""
+    if n_d % PSD_WAVES != 0:
+        return None
+    ch = n_d // PSD_WAVES
+    k = np.arange(n_d)
+    k0 = (k // ch) * ch
+    D64 = np.asarray(D, dtype=np.float64)
+    Dn64 = np.asarray(Dn, dtype=np.float64)
+    h_l = (D64[-1] - D64[0]) / (n_d - 1)
+    h_n = (Dn64[-1] - Dn64[0]) / (n_d - 1)
+    dlt = D64 - D64[k0] - (k - k0) * h_l
+    dltn = Dn64 - Dn64[k0] - (k - k0) * h_n
+    scale = max(1.0, float(np.max(np.abs(D64))))
+    if np.max(np.abs(dlt)) > 4e-6 * scale or np.max(np.abs(dltn)) > 4e-6 * scale \
+            or D64[0] <= 0 or Dn64[0] <= 0:
+        return None
+    d.uniform_grid = 1
+    ql = np.stack([dlt, dlt * dlt / 2.0, dlt ** 3 / 6.0, D64 ** ICE_POWER], axis=1).ravel()
+    qn = np.stack([Dn64 ** ICE_POWER, np.asarray(aDb, dtype=np.float64),
+                   np.asarray(Vn, dtype=np.float64), dltn], axis=1).ravel()
+    return np.concatenate([[0.0, 0.0, 0.0], [h_l, h_n, 0.0, 0.0], ql, qn]).astype(np.float64)
 
 
 def doppler_weights(h, scheme, lut):
