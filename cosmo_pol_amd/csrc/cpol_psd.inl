@@ -625,15 +625,29 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
 #pragma unroll 1
         for (int k = k0; k < k1; ++k) {
             const double D = d_min + step * (double)k;
-            const double D3 = D * D * D;
-            const double M = melt_mass(d, it, D, D3);
-            const double rho = M / (3.14159265358979323846 / 6 * D3);
-            const double Dr = cbrt(rho / 1.0e-6) * D;
-            const double dDr = (melt_Dr(d, it, D + 0.01) - Dr) / 0.01;          // :384
+            const double D2 = D + 0.01;                                         // :384
+            // mass of the melting particle at D and D + 0.01 (:404-412); D^b, D^beta share
+            // one logarithm when they are not plain squares / fourth roots
+            double Db, D2b, Dbeta;
+            if (d.b == 2.0 && d.beta == 0.25) {
+                Db = D * D; D2b = D2 * D2; Dbeta = sqrt(sqrt(D));
+            } else {
+                const double L = log(D);
+                Db = (d.b == 2.0) ? D * D : exp(d.b * L);
+                D2b = powb(D2, d.b);
+                Dbeta = exp(d.beta * L);
+            }
+            const double M = it.fw2 * (d.r_a * (D * D * D)) + (1.0 - it.fw2) * (d.a * Db);
+            const double M2 = it.fw2 * (d.r_a * (D2 * D2 * D2)) + (1.0 - it.fw2) * (d.a * D2b);
+            // D_r = (rho_m / rho_w)^(1/3) D with rho_m = M / (pi/6 D^3)  ==  cbrt(6e6/pi M)
+            // (:382-383; the D^3 cancels exactly, rounding differs by ~2 ulp)
+            const double c6 = 6.0e6 / 3.14159265358979323846;
+            const double Dr = cbrt(c6 * M);
+            const double dDr = (cbrt(c6 * M2) - Dr) * 100.0;                    // /0.01, :384
             const double sq = sqrt(Dr);
             const double Nr = (d.r_n0 * sq) * exp(-(it.lam_r * Dr));           // rain N(D_r)
             const double Vr = d.r_alpha * sq;                                  // rain V(D_r)
-            const double Vd = d.alpha * ((d.beta == 0.25) ? sqrt(sqrt(D)) : powp(D, d.beta));
+            const double Vd = d.alpha * Dbeta;
             const double V = it.phi * Vr + (1 - it.phi) * Vd;                  // :431-439
             const double Nraw = Nr * Vr / V * dDr;                             // :386-387
             msum += Nraw * M;                                                  // :478
