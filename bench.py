@@ -10,7 +10,10 @@ synthetic COSMO-1-like cube (80 x 774 x 1158) with full-size
 synthetic scattering tables.  A "step" = one complete sweep through the C ABI
 (all kernels, outputs left in HBM; the per-ray tables of the unchanged scan
 geometry stay resident in HBM between steps -- `value_fresh_tables` re-uploads
-them every step).  With N GPUs every rank
+them every step).  Consecutive steps run on alternating LANES (cpol_fork: shared
+cube and tables, own stream and work buffers), so two or three sweeps are in
+flight together, as the sweeps of a volume scan are in the product; stage times
+and the roofline are measured on lane 0 under that overlap.  With N GPUs every rank
 simulates one such sweep per step (rays sharded by whole sweeps, weak scaling)
 and the output slabs are collected with ONE RCCL all-gather per step.
 
@@ -118,9 +121,16 @@ def main():
     n_rays, n_gates = len(az), len(op.constants.RANGE_RADAR)
     stream = torch.cuda.Stream()
     op._ctx.set_stream(stream.cuda_stream)
+    # lanes: contexts forked from the operator's (shared cube / tables, own stream and work
+    # buffers); consecutive steps go to alternating lanes so that the latency-bound kernels
+    # of one sweep overlap the PSD kernel of the other (CPOL_BENCH_LANES=1 disables)
+    n_lanes = max(1, int(os.environ.get('CPOL_BENCH_LANES', '3')))
+    lane_streams = [stream] + [torch.cuda.Stream() for _ in range(n_lanes - 1)]
+    for i in range(1, n_lanes):
+        op._lane(i).set_stream(lane_streams[i].cuda_stream)
     # two output slabs: the all-gather of step i (side stream) overlaps the kernels of
     # step i+1 (library stream); a slab is reused only after its gather has completed
-    n_buf = 2 if world > 1 else 1
+    n_buf = max(2, n_lanes) if world > 1 else n_lanes
     slabs = [torch.empty((len(OUT_FIELDS), n_rays, n_gates), dtype=torch.float32, device='cuda')
              for _ in range(n_buf)]
     slab = slabs[0]
@@ -134,15 +144,16 @@ def main():
 
     def step():
         b = counter[0] % n_buf
+        lane = counter[0] % n_lanes
         counter[0] += 1
         if world == 1:
-            op.simulate_rays(az, el, device_outputs=dev_outs[b])
+            op.simulate_rays(az, el, device_outputs=dev_outs[b], lane=lane)
             return
         if slab_free[b] is not None:
-            stream.wait_event(slab_free[b])
-        op.simulate_rays(az, el, device_outputs=dev_outs[b])
+            lane_streams[lane].wait_event(slab_free[b])
+        op.simulate_rays(az, el, device_outputs=dev_outs[b], lane=lane)
         computed = torch.cuda.Event()
-        computed.record(stream)
+        computed.record(lane_streams[lane])
         comm_stream.wait_event(computed)
         with torch.cuda.stream(comm_stream):
             dist.all_gather_into_tensor(gathered[b], slabs[b].view(-1))
@@ -170,6 +181,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     cnt = op._ctx.counters()             # also surfaces a domain error, if any
+    for i in range(1, n_lanes):
+        op._lane(i).counters()
     op._ctx.enable_timing(False)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
@@ -188,6 +201,17 @@ def main():
 
     gates_per_step = world * n_rays * n_gates
     value = gates_per_step * args.steps / elapsed
+
+    # the same sweep on ONE lane (no other sweep in flight): kernel durations in isolation
+    iso = None
+    if world == 1 and n_lanes > 1:
+        n_it = max(5, args.steps // 2)
+        op._ctx.enable_timing(True)
+        for _ in range(n_it):
+            op.simulate_rays(az, el, device_outputs=dev_outs[0], lane=0)
+        fence()
+        iso = op._ctx.counters()
+        op._ctx.enable_timing(False)
 
     # variant that re-uploads the per-ray tables on every step (new scan geometry each time)
     value_fresh = None
@@ -236,6 +260,7 @@ def main():
                                    '1-moment, 1 sub-beam, synthetic %s cube; one such sweep per GPU '
                                    'per step' % ('x'.join(map(str, cube['zlevels'].shape))),
                        'rays_per_gpu': n_rays, 'gates_per_ray': n_gates,
+                       'lanes': n_lanes,
                        'parallelism': ('rays sharded by sweep, 1 all-gather/step on a side stream, overlapped '
                                        'with the next step') if world > 1 else 'single GPU',
                        'small': bool(args.small)},
@@ -246,12 +271,20 @@ def main():
                          'algorithmic_bytes_per_sweep_stage': psd_bytes,
                          'valu_f64_frac': valu_frac,
                          'avg_stage_ms': cnt.ms_psd,
+                         'isolated': None if iso is None else {
+                             'avg_stage_ms': iso.ms_psd,
+                             'frac': psd_bytes / (iso.ms_psd * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'valu_f64_frac': valu_cycles / (1024 * 2.4e9 * iso.ms_psd * 1e-3),
+                             'device_total_ms': iso.ms_total,
+                             'note': 'same sweep with one lane only (no overlap with other sweeps)'},
                          'note': 'algorithmic bytes = N_valid x 49152 B (one float32 LUT slice per valid '
                                  'item, SURVEY 8(d)); slices are shared through the scalar cache / L2, '
                                  'so frac can exceed 1 -- see DESIGN.md'},
             'stages_ms': {'trajectory': cnt.ms_traj, 'interp': cnt.ms_interp,
                           'classify': cnt.ms_classify, 'bucket': cnt.ms_bucket, 'psd': cnt.ms_psd,
-                          'final': cnt.ms_final, 'device_total': cnt.ms_total},
+                          'final': cnt.ms_final, 'device_total': cnt.ms_total,
+                          'note': 'per-sweep latencies on lane 0 with %d lanes in flight; '
+                                  'throughput = steps / wall time' % n_lanes},
             'counters': {'n_subbeam_gates': n_sbg, 'n_valid_items': n_valid,
                          'n_work_units': int(cnt.n_work_units),
                          'sweep_algorithmic_bytes': sweep_bytes,

@@ -91,7 +91,7 @@ class Counters(C.Structure):
                 ('ms_total', C.c_float)]
 
 
-EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_set_stream',
+EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_fork', 'cpol_last_error', 'cpol_set_stream',
            'cpol_synchronize', 'cpol_stage_model', 'cpol_stage_hydro', 'cpol_set_num_hydro',
            'cpol_stage_doppler_weights',
            'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
@@ -119,6 +119,8 @@ def load_library():
     vp = C.c_void_p
     lib.cpol_create.restype = C.c_int
     lib.cpol_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.cpol_fork.restype = C.c_int
+    lib.cpol_fork.argtypes = [vp, C.POINTER(vp)]
     lib.cpol_destroy.restype = None
     lib.cpol_destroy.argtypes = [vp]
     lib.cpol_last_error.restype = C.c_char_p
@@ -173,6 +175,17 @@ class Context(object):
         self.device = device
         self.n_vars = 0
         self._keep = []
+
+    def fork(self):
+        """A lane: shares this context's staged model / tables, own stream and work
+        buffers (cpol_fork).  Close lanes before their parent."""
+        h = C.c_void_p()
+        self._check(self.lib.cpol_fork(self.h, C.byref(h)), 'cpol_fork')
+        lane = Context.__new__(Context)
+        lane.lib, lane.h, lane.device, lane.n_vars = self.lib, h, self.device, self.n_vars
+        lane._keep = []
+        lane._parent = self          # keeps the parent alive
+        return lane
 
     def close(self):
         if getattr(self, 'h', None):

@@ -41,6 +41,10 @@ struct cpol_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // lanes (cpol_fork): a child shares the parent's staged model / tables read-only and
+    // owns only its stream, work buffers and counters
+    cpol_ctx *parent = nullptr;
+    int n_children = 0;
     std::string err;
     // model
     bool model_staged = false;
@@ -151,6 +155,15 @@ void cpol_destroy(cpol_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->parent) {
+        // staged buffers belong to the parent
+        ctx->d_H = DevBuf(); ctx->d_V = DevBuf();
+        for (int j = 0; j < CPOL_MAX_HYDRO; ++j) {
+            ctx->d_table[j] = DevBuf(); ctx->d_pre[j] = DevBuf(); ctx->d_dnu[j] = DevBuf();
+            ctx->d_aux[j] = DevBuf(); ctx->d_rcsw[j] = DevBuf();
+        }
+        ctx->parent->n_children -= 1;
+    }
     DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj_in, &ctx->b_geo, &ctx->b_subh, &ctx->b_subv,
                      &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_subsmooth, &ctx->b_mlfilter, &ctx->b_wgate, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
@@ -173,6 +186,35 @@ void cpol_destroy(cpol_ctx *ctx)
     }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
+{
+    if (!out) return CPOL_ERR_ARG;
+    *out = nullptr;
+    if (!parent || parent->parent) {
+        if (parent) parent->err = "cpol_fork: fork the root context, not a lane";
+        return CPOL_ERR_ARG;
+    }
+    cpol_ctx *ctx = parent;            // for HIPCHK
+    HIPCHK(hipSetDevice(parent->device));
+    HIPCHK(hipStreamSynchronize(parent->stream));      // staging has landed
+    cpol_ctx *c = new cpol_ctx();
+    c->device = parent->device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        parent->err = "cpol_fork: hipStreamCreate failed";
+        return CPOL_ERR_HIP;
+    }
+    c->own_stream = true;
+    c->parent = parent;
+    c->model_staged = parent->model_staged;
+    c->model = parent->model;
+    c->hs = parent->hs;
+    for (int j = 0; j < CPOL_MAX_HYDRO; ++j) c->hydro_staged[j] = parent->hydro_staged[j];
+    parent->n_children += 1;
+    *out = c;
+    return CPOL_OK;
 }
 
 const char *cpol_last_error(cpol_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -216,6 +258,10 @@ int cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data, const 
     if (!ctx || !data || !zlevels || n_vars < 1 || n_vars > CPOL_MAX_VARS || nz < 3 || ny < 2 ||
         nx < 2) {
         if (ctx) ctx->err = "cpol_stage_model: bad arguments (need nz >= 3, ny, nx >= 2)";
+        return CPOL_ERR_ARG;
+    }
+    if (ctx->parent || ctx->n_children) {
+        ctx->err = "cpol_stage_model: not on a lane, and not while lanes of this context exist (cpol_fork)";
         return CPOL_ERR_ARG;
     }
     HIPCHK(hipSetDevice(ctx->device));
@@ -268,6 +314,10 @@ static int n_par_of(int rule)
 int cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro)
 {
     if (!ctx || n_hydro < 0 || n_hydro > CPOL_MAX_HYDRO) return CPOL_ERR_ARG;
+    if (ctx->parent || ctx->n_children) {
+        ctx->err = "cpol_set_num_hydro: not on a lane, and not while lanes of this context exist";
+        return CPOL_ERR_ARG;
+    }
     ctx->hs.n_hydro = n_hydro;
     int base = 0;
     for (int j = 0; j < n_hydro; ++j) {
@@ -288,6 +338,10 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
     if (!ctx || !desc || !table || slot < 0 || slot >= CPOL_MAX_HYDRO || desc->n_e < 1 ||
         desc->n_t < 1 || desc->n_d < 2) {
         if (ctx) ctx->err = "cpol_stage_hydro: bad arguments";
+        return CPOL_ERR_ARG;
+    }
+    if (ctx->parent || ctx->n_children) {
+        ctx->err = "cpol_stage_hydro: not on a lane, and not while lanes of this context exist (cpol_fork)";
         return CPOL_ERR_ARG;
     }
     HIPCHK(hipSetDevice(ctx->device));
@@ -343,6 +397,10 @@ int cpol_stage_doppler_weights(cpol_ctx *ctx, int slot, const double *weights)
 {
     if (!ctx || !weights || slot < 0 || slot >= CPOL_MAX_HYDRO || !ctx->hydro_staged[slot]) {
         if (ctx) ctx->err = "cpol_stage_doppler_weights: stage the hydrometeor first";
+        return CPOL_ERR_ARG;
+    }
+    if (ctx->parent || ctx->n_children) {
+        ctx->err = "cpol_stage_doppler_weights: not on a lane, and not while lanes of this context exist (cpol_fork)";
         return CPOL_ERR_ARG;
     }
     HIPCHK(hipSetDevice(ctx->device));

@@ -13,6 +13,7 @@ callable (hydrometeors, frequency, scheme) -> {h: table}),
 """
 import copy
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -99,9 +100,14 @@ class RadarOperator(object):
     _table_serial = 0          # tags of per-ray table sets handed to the library
 
     def __init__(self, options_file=None, output_variables='all', *, device=0, lut_dir=None,
-                 luts=None, config=None, distributed=False):
+                 luts=None, config=None, distributed=False, lanes=2):
         print('Reading options defined in options file')
         self._ctx = N.Context(device)         # raises if the HIP library / GPU is missing
+        # lanes: contexts forked from _ctx (shared cube / tables, own stream + work buffers);
+        # the sweeps of a volume scan are spread over them so that they overlap on the GPU
+        self.lanes = max(1, int(lanes))
+        self._lane_ctx = []
+        self._lock = threading.RLock()
         self.device = device
         self.distributed = bool(distributed)   # shard the rays of every sweep over the ranks
         self.reuse_device_tables = True        # keep per-ray tables in HBM between equal sweeps
@@ -152,8 +158,24 @@ class RadarOperator(object):
                 print('Reloading lookup tables...')
             self.set_lut()
 
+    def _drop_lanes(self):
+        for c in self._lane_ctx:
+            c.close()
+        self._lane_ctx = []
+
+    def _lane(self, i):
+        """Context of lane i (0 = the root context); lanes are forked on first use and
+        dropped whenever the staged model / tables change."""
+        if i == 0:
+            return self._ctx
+        with self._lock:
+            while len(self._lane_ctx) < i:
+                self._lane_ctx.append(self._ctx.fork())
+            return self._lane_ctx[i - 1]
+
     def close(self):
         if self._ctx is not None:
+            self._drop_lanes()
             self._ctx.close()
             self._ctx = None
         self.dic_vars = None
@@ -179,6 +201,7 @@ class RadarOperator(object):
             lut = load_all_lut(scheme, hl, conf['radar']['frequency'],
                                conf['microphysics']['scattering'], lut_dir=self.lut_dir)
         self.lut_sz = lut
+        self._drop_lanes()
         var_index = {v: i for i, v in enumerate(hyd.variable_list(conf))}
         for slot, h in enumerate(hl):
             d, table, pre, dnu, aux = hyd.build_hydro(h, scheme, lut[h], var_index)
@@ -231,6 +254,7 @@ class RadarOperator(object):
 
     def _stage_model(self):
         conf = self.__config
+        self._drop_lanes()
         names = hyd.variable_list(conf)
         p = self._proj
         llc = np.asarray((float(p['Lo1']), float(p['La1']))).astype('float32')
@@ -257,13 +281,15 @@ class RadarOperator(object):
         return True
 
     def simulate_rays(self, azimuths, elevations, on_device=False, device_outputs=None,
-                      apply_sensitivity=True, paths=None):
+                      apply_sensitivity=True, paths=None, lane=0):
         """One batched launch sequence for the given rays (az[i], el[i]) of the
         ground radar of the configuration.  Returns a dict of [n_rays, n_gates]
         arrays (linear units, NaN = no data).
         `device_outputs`: optional {field: device pointer} (outputs stay in HBM).
         `paths`: optional float32 [n_rays, n_vnodes, 3, n_gates] host-computed ray
-        paths (s, h, e_deg) replacing the 4/3-earth model (CPOL_GEOM_HOST_PATHS)."""
+        paths (s, h, e_deg) replacing the 4/3-earth model (CPOL_GEOM_HOST_PATHS).
+        `lane`: which forked context (stream + work buffers) runs the sweep; sweeps on
+        different lanes overlap on the GPU (one host thread per lane at a time)."""
         conf = self.__config
         coords = conf['radar']['coords']
         if coords[2] > K.MAX_MODEL_HEIGHT:
@@ -285,10 +311,10 @@ class RadarOperator(object):
         mode = N.GEOM_GROUND_43 if paths is None else N.GEOM_HOST_PATHS
         return self._run_rays(azimuths, elevations, coords, len(rr), float(rr[0]), mode,
                               device_outputs=device_outputs, apply_sensitivity=apply_sensitivity,
-                              paths=paths)
+                              paths=paths, lane=lane)
 
     def _run_rays(self, azimuths, elevations, coords, n_gates, range0, mode, device_outputs=None,
-                  apply_sensitivity=True, paths=None, site=None, sub=None, tables=None):
+                  apply_sensitivity=True, paths=None, site=None, sub=None, tables=None, lane=0):
         conf = self.__config
         az = np.ascontiguousarray(np.asarray(azimuths, dtype=np.float64).reshape(-1))
         el = np.ascontiguousarray(np.asarray(elevations, dtype=np.float64).reshape(-1))
@@ -398,12 +424,16 @@ class RadarOperator(object):
                 res['model_vars'] = np.empty((len(self._staged_vars),) + shape, dtype=np.float64)
             for k, a in res.items():
                 setattr(o, k, a.ctypes.data)
-        self._ctx.run_sweep(p, t, o)
+        self._lane(lane).run_sweep(p, t, o)
         del keep
         res['n_sub'] = sub.n_sub
         return res
 
     def _cached(self, key, make, lru=None):
+        with self._lock:
+            return self._cached_locked(key, make, lru)
+
+    def _cached_locked(self, key, make, lru=None):
         c = self._cache
         if key in c:
             return c[key]
@@ -414,11 +444,34 @@ class RadarOperator(object):
         c[key] = make()
         return c[key]
 
-    def _simulate_sweep(self, az, el):
+    def _simulate_sweeps(self, sweeps):
+        """[(az, el), ...] -> packaged sweeps.  The reference runs the sweeps of a scan one
+        after the other (radar_operator.py:429-432); here up to `lanes` of them are in
+        flight together, one host thread per lane (the library calls release the GIL)."""
+        n_par = 1 if self.distributed else min(self.lanes, len(sweeps))
+        if n_par <= 1:
+            return [self._package(self._simulate_sweep(az, el), az, el) for az, el in sweeps]
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+        free = queue.Queue()
+        for i in range(n_par):
+            self._lane(i)
+            free.put(i)
+
+        def one(sw):
+            lane = free.get()
+            try:
+                return self._package(self._simulate_sweep(sw[0], sw[1], lane=lane), sw[0], sw[1])
+            finally:
+                free.put(lane)
+        with ThreadPoolExecutor(max_workers=n_par) as pool:
+            return list(pool.map(one, sweeps))
+
+    def _simulate_sweep(self, az, el, lane=0):
         """All rays of a sweep: locally, or sharded over the ranks of the default
         torch.distributed group with one all-gather (cosmo_pol_amd/distributed.py)."""
         if not self.distributed:
-            return self.simulate_rays(az, el)
+            return self.simulate_rays(az, el, lane=lane)
         import torch
         from . import distributed as D
         if self.output_variables != 'only_radar':
@@ -464,10 +517,8 @@ class RadarOperator(object):
             else:
                 azimuths = np.arange(az_start, az_stop + az_step, az_step)
         azimuths = np.asarray(azimuths, dtype=float)
-        sweeps = []
-        for e in elevations:
-            el = np.full(len(azimuths), float(e))
-            sweeps.append(self._package(self._simulate_sweep(azimuths, el), azimuths, el))
+        sweeps = self._simulate_sweeps([(azimuths, np.full(len(azimuths), float(e)))
+                                        for e in elevations])
         return RadarScan('ppi', list(elevations), list(azimuths), self.constants.RANGE_RADAR,
                          self.get_pos_and_time(), sweeps)
 
@@ -482,10 +533,8 @@ class RadarOperator(object):
                 elev_step = self.__config['radar']['3dB_beamwidth']
             elevations = np.arange(elev_start, elev_stop + elev_step, elev_step)
         elevations = np.asarray(elevations, dtype=float)
-        sweeps = []
-        for a in azimuths:
-            az = np.full(len(elevations), float(a))
-            sweeps.append(self._package(self._simulate_sweep(az, elevations), az, elevations))
+        sweeps = self._simulate_sweeps([(np.full(len(elevations), float(a)), elevations)
+                                        for a in azimuths])
         return RadarScan('rhi', list(elevations), list(azimuths), self.constants.RANGE_RADAR,
                          self.get_pos_and_time(), sweeps)
 

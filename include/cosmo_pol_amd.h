@@ -196,6 +196,13 @@ typedef struct {
 
 int  cpol_create(int device, cpol_ctx **out);
 void cpol_destroy(cpol_ctx *ctx);
+/* A LANE of `parent`: a context that shares the parent's staged model cube and
+ * scattering tables (read-only, no copy) and owns its own HIP stream, work buffers and
+ * counters, so that independent sweeps (the elevations of a volume scan, consecutive
+ * scans) are in flight together -- the reference runs them one after the other
+ * (radar_operator.py:429-432).  Fork after staging; stage calls fail on a lane and on a
+ * parent with live lanes; destroy lanes before their parent.  One host thread per lane. */
+int  cpol_fork(cpol_ctx *parent, cpol_ctx **out);
 const char *cpol_last_error(cpol_ctx *ctx);
 /* use an externally created hipStream_t (e.g. torch's current stream); NULL = own stream */
 int  cpol_set_stream(cpol_ctx *ctx, void *hip_stream);

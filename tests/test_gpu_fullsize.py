@@ -92,3 +92,36 @@ def test_rhi_and_vprof_api(full):
     assert vp.fields['KDP']['data'].shape == (1, 500)
     # vertical beam: first gates are rain, then snow -> the profile leaves the model top
     assert np.ma.count(vp.fields['ZH']['data']) > 20
+
+
+def test_lanes_volume_scan_equals_sequential():
+    """Sweeps spread over forked contexts (cpol_fork, one host thread per lane) give
+    bit-identical fields to the same sweeps run one after the other."""
+    from cosmo_pol_amd import RadarOperator, synthetic
+    import bench
+    conf = bench.bench_config(True)
+    conf['microphysics'].update(with_melting=1, with_ice_crystals=1)
+    hyds = ['R', 'S', 'G', 'mS', 'mG', 'I']
+    cube = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G', 'I'))
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
+    elevs = [0.5, 1.5, 3.0, 5.0, 8.0]
+    scans = []
+    for lanes in (1, 3):
+        op = RadarOperator(config=conf, luts=luts, output_variables='all', lanes=lanes)
+        op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+        scans.append(op.get_PPI(elevs, az_step=4.0))
+        if lanes == 3:
+            assert len(op._lane_ctx) == 2
+            # staging on a context with live lanes is refused by the library; the operator
+            # drops its lanes first
+            with pytest.raises(ValueError):
+                op._ctx.set_num_hydro(len(hyds))
+            op.set_lut()
+            assert op._lane_ctx == []
+        op.close()
+    a, b = scans
+    for i in range(len(elevs)):
+        for name in a.fields:
+            x, y = np.ma.asarray(a.get_field(i, name)), np.ma.asarray(b.get_field(i, name))
+            assert np.array_equal(np.ma.getmaskarray(x), np.ma.getmaskarray(y)), name
+            assert np.array_equal(x.filled(0), y.filled(0)), name
