@@ -178,6 +178,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_submit = time.perf_counter() - t0      # host time to enqueue all steps
     fence()
     elapsed = time.perf_counter() - t0
     cnt = op._ctx.counters()             # also surfaces a domain error, if any
@@ -289,6 +290,7 @@ def main():
                          'n_work_units': int(cnt.n_work_units),
                          'sweep_algorithmic_bytes': sweep_bytes,
                          'sweep_algorithmic_GBs': sweep_bytes / (cnt.ms_total * 1e-3) / 1e9 if cnt.ms_total else None},
+            'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
             'gather_check': gather_ok,
             'value_with_d2h': value_d2h,
             'value_fresh_tables': value_fresh,

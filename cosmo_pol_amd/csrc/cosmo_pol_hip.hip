@@ -57,7 +57,7 @@ struct cpol_ctx {
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
     // per-sweep work buffers (grow only)
     DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site, b_nyq;
-    DevBuf b_subsmooth, b_mlfilter, b_wgate;
+    DevBuf b_subsmooth, b_mlfilter, b_wgate, b_clk;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
         b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err, b_pos, b_vn, b_icefirst, b_rvel, b_fh, b_fv;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
@@ -165,7 +165,7 @@ void cpol_destroy(cpol_ctx *ctx)
         ctx->parent->n_children -= 1;
     }
     DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj_in, &ctx->b_geo, &ctx->b_subh, &ctx->b_subv,
-                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_subsmooth, &ctx->b_mlfilter, &ctx->b_wgate, &ctx->b_vals, &ctx->b_mask,
+                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_subsmooth, &ctx->b_mlfilter, &ctx->b_wgate, &ctx->b_clk, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_cursor, &ctx->b_units,
                      &ctx->b_urange, &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_err, &ctx->b_pos,
@@ -713,6 +713,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         pa.res = (double *)ctx->b_res.p;
         pa.vn = doppler ? (double *)ctx->b_vn.p : nullptr;
         pa.n_sbg = n_sbg;
+        pa.clk = nullptr;
+        if (ctx->keep_debug) {
+            ENSURE(ctx->b_clk, 2048 * 4 * sizeof(long long));
+            HIPCHK(hipMemsetAsync(ctx->b_clk.p, 0, 2048 * 4 * sizeof(long long), st));
+            pa.clk = (long long *)ctx->b_clk.p;
+        }
         bool need[4] = {false, false, false, false};
         for (int j = 0; j < n_hyd; ++j) {
             const cpol_hydro_desc &d = ctx->hs.h[j].d;
@@ -721,15 +727,23 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                      : d.uniform_grid ? PSD_MODE_GAMMA_UNIFORM : PSD_MODE_GAMMA_EXP;
             need[mode] = true;
         }
-        // persistent grid: up to 4 workgroups of 8 waves per CU, 256 CUs
-        const long want = unit_cap < 1024 ? unit_cap : 1024;
-        const dim3 grd((unsigned)want), blk(CPOL_PSD_THREADS);
+        // persistent grids sized to the RESIDENT workgroups (256 CUs x 3 for the recurrence
+        // flavour at 6 waves/SIMD, x 2 for the others, LDS-limited): with a larger grid the
+        // surplus workgroups only start when the first ones retire and the static stride
+        // assignment leaves a long tail (measured with the in-kernel clock probe)
+        static const long grid_u = getenv("CPOL_PSD_GRID") ? atol(getenv("CPOL_PSD_GRID")) : 1024;
+        static const long grid_g = getenv("CPOL_PSD_GRID_GENERIC") ? atol(getenv("CPOL_PSD_GRID_GENERIC")) : 1024;
+        const dim3 grd_u((unsigned)(unit_cap < grid_u ? unit_cap : grid_u));
+        const dim3 grd((unsigned)(unit_cap < grid_g ? unit_cap : grid_g)), blk(CPOL_PSD_THREADS);
 #define CPOL_LAUNCH_PSD(M)                                                                   \
         if (need[M]) {                                                                       \
             if (dop2) hipLaunchKernelGGL((k_psd<M, true>), grd, blk, 0, st, ctx->hs, pa);    \
             else hipLaunchKernelGGL((k_psd<M, false>), grd, blk, 0, st, ctx->hs, pa);        \
         }
-        CPOL_LAUNCH_PSD(PSD_MODE_GAMMA_UNIFORM)
+        if (need[PSD_MODE_GAMMA_UNIFORM]) {
+            if (dop2) hipLaunchKernelGGL((k_psd_uniform<true>), grd_u, blk, 0, st, ctx->hs, pa);
+            else hipLaunchKernelGGL((k_psd_uniform<false>), grd_u, blk, 0, st, ctx->hs, pa);
+        }
         CPOL_LAUNCH_PSD(PSD_MODE_GAMMA_EXP)
         CPOL_LAUNCH_PSD(PSD_MODE_ICE)
         CPOL_LAUNCH_PSD(PSD_MODE_MELTING)
@@ -930,6 +944,7 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     else if (!strcmp(name, "sz_integ")) { src = ctx->b_szinteg.p; bytes = (int64_t)n_rg * n_hyd * CPOL_N_SZ * 4; }
     else if (!strcmp(name, "sz_total")) { src = ctx->b_sztotal.p; bytes = (int64_t)n_rg * CPOL_N_SZ * 4; }
     else if (!strcmp(name, "traj")) { src = ctx->b_traj.p; bytes = (int64_t)ctx->last_n_rays * ctx->last_n_v * 3 * ctx->last_n_gates * 4; }
+    else if (!strcmp(name, "psd_clock")) { src = ctx->b_clk.p; bytes = 2048 * 4 * 8; }
     else if (!strcmp(name, "bucket_count")) { src = ctx->b_count.p; bytes = (int64_t)ctx->hs.n_keys * 4; }
     else { ctx->err = std::string("cpol_debug_read: unknown buffer ") + name; return CPOL_ERR_ARG; }
     if (!src) { ctx->err = "cpol_debug_read: buffer not kept (call with name \"enable\" first)"; return CPOL_ERR_ARG; }

@@ -414,6 +414,8 @@ struct PsdArgs {
     double *res;                // [n_hydro][n_sbg][12]   sum_k sz[k][c] N[k] * dD
     double *vn;                 // [n_hydro][n_sbg][2]    integral of V N dD, of N dD (or NULL)
     long n_sbg;
+    long long *clk;             // clock probe [2048][4]: s_memtime / s_memrealtime at the start and
+                                // end of every workgroup (effective shader clock), or NULL
 };
 
 __device__ __forceinline__ int psd_mode_of(const cpol_hydro_desc &d)
@@ -467,7 +469,7 @@ typedef const double __attribute__((address_space(4))) *cdouble_p;
 __device__ __forceinline__ cdouble_p as_const(const double *p) { return (cdouble_p)(uintptr_t)p; }
 
 template <int MODE, bool DOP2>
-__global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a)
+__device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
 {
     // [wave][value][lane]; value 12 = normalisation sum (ice, melting)
     // the recurrence flavour needs no extra sums and combines its 8 partials with a
@@ -478,6 +480,15 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
     constexpr int NV = (MODE == PSD_MODE_GAMMA_UNIFORM) ? 2 * CPOL_N_SZ + (DOP2 ? 4 : 0) : CPOL_N_SZ + 3;
     constexpr int NSLOT = (MODE == PSD_MODE_GAMMA_UNIFORM) ? 4 : CPOL_PSD_WAVES;
     __shared__ double s_part[NSLOT][NV][CPOL_WAVE];
+#ifdef CPOL_CLOCK_PROBE
+    // debug build only (make PROBE=1): the stores below cost the production kernel its
+    // scalar loads of the unit list (the compiler can no longer prove them unclobbered)
+    const bool probe = a.clk && MODE == PSD_MODE_GAMMA_UNIFORM && blockIdx.x < 2048 && threadIdx.x == 0;
+    if (probe) {
+        a.clk[blockIdx.x * 4 + 0] = (long long)__builtin_readcyclecounter();
+        a.clk[blockIdx.x * 4 + 1] = (long long)wall_clock64();
+    }
+#endif
     // persistent workgroups: a fixed grid walks the unit list (no empty launches)
     const int n_units = (int)a.totals[1];
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
@@ -689,7 +700,13 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
         // per bin the host supplies (pre, q1 = pre*dlt, q2 = pre*dlt^2/2), so that
         //   N_k = A_k (pre_k - lambda q1_k + lambda^2 q2_k),  A_{k+1} = A_k r
         // costs 4 f64 ops per item on top of the 12 FMAs (one 32-byte scalar request)
-        const cdouble_p pq = as_const(h.aux + 1 + n_d);          // [k][4] = (pre, q1, q2, 0)
+        // NB the per-bin triple stays in its own small array: it is shared by every workgroup
+        // and hits in the scalar cache, whereas table rows are streamed once each -- folding
+        // it into 128-byte padded rows was measured 25 % slower (unique bytes through the
+        // scalar cache are what bounds this kernel).  Also measured and rejected: fetching
+        // columns 8..11 through the vector memory path (VGPRs 81 -> 106, occupancy 5 -> 4:
+        // 152 us vs 139 us), 6 waves per SIMD (218 us), one bin per iteration (192 us).
+        const cdouble_p pq = as_const(h.aux + 1 + n_d);          // [k][4] = (pre, q1, q2, .)
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
             const double pk = pq[4 * k], q1 = pq[4 * k + 1], q2 = pq[4 * k + 2];
@@ -816,4 +833,26 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
     }
     __syncthreads();                                        // s_part is reused by the next unit
     }
+#ifdef CPOL_CLOCK_PROBE
+    if (probe) {
+        a.clk[blockIdx.x * 4 + 2] = (long long)__builtin_readcyclecounter();
+        a.clk[blockIdx.x * 4 + 3] = (long long)wall_clock64();
+    }
+#endif
+}
+
+template <int MODE, bool DOP2>
+__global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a)
+{
+    psd_body<MODE, DOP2>(hs, a);
+}
+
+// The recurrence flavour (the dominant kernel of a sweep).  Occupancy: 81 VGPRs -> 5 waves per
+// SIMD -> two resident 8-wave workgroups per CU; forcing 6 waves (three workgroups) was
+// measured 1.6x SLOWER: every row is read by exactly one wave, so more waves only add
+// pressure on the scalar-cache -> L2 path that feeds them.
+template <bool DOP2>
+__global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_uniform(HydroSet hs, PsdArgs a)
+{
+    psd_body<PSD_MODE_GAMMA_UNIFORM, DOP2>(hs, a);
 }

@@ -173,7 +173,7 @@ PSD_WAVES = 8        # csrc/cpol_psd.inl: CPOL_PSD_WAVES (bins are split over 8 
 def _uniform_grid_aux(d, D, nu, n_d, pre):
     """nu == 1: exp(-lambda D_k) is advanced by a geometric recurrence inside each
     wave chunk of n_d/8 bins.  aux = [h, dlt_0 .. dlt_{n_d-1}, (pre_k, pre_k dlt_k,
-    pre_k dlt_k^2 / 2, 0) ...] with h the mean grid step and dlt_k = D_k - D_k0 - (k-k0) h
+    pre_k dlt_k^2 / 2, -pre_k dlt_k^3 / 6) ...] with h the mean grid step and dlt_k = D_k - D_k0 - (k-k0) h
     the (float32-rounding sized) departure of node k from the uniform grid anchored at
     its chunk start k0; the per-bin quadruple is one 32-byte scalar load in the kernel."""
     if float(nu) != 1.0 or n_d % PSD_WAVES != 0:
@@ -192,7 +192,7 @@ def _uniform_grid_aux(d, D, nu, n_d, pre):
         return None
     d.uniform_grid = 1
     p64 = np.asarray(pre, dtype=np.float64)
-    quads = np.stack([p64, p64 * dlt, p64 * dlt * dlt / 2.0, np.zeros(n_d)], axis=1).ravel()
+    quads = np.stack([p64, p64 * dlt, p64 * dlt * dlt / 2.0, -p64 * dlt ** 3 / 6.0], axis=1).ravel()
     return np.concatenate([[h], dlt, quads]).astype(np.float64)
 
 
