@@ -702,10 +702,10 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
         // costs 4 f64 ops per item on top of the 12 FMAs (one 32-byte scalar request)
         // NB the per-bin triple stays in its own small array: it is shared by every workgroup
         // and hits in the scalar cache, whereas table rows are streamed once each -- folding
-        // it into 128-byte padded rows was measured 25 % slower (unique bytes through the
-        // scalar cache are what bounds this kernel).  Also measured and rejected: fetching
-        // columns 8..11 through the vector memory path (VGPRs 81 -> 106, occupancy 5 -> 4:
-        // 152 us vs 139 us), 6 waves per SIMD (218 us), one bin per iteration (192 us).
+        // it into 128-byte padded rows (two aligned 64-byte scalar loads per bin instead of
+        // three unaligned ones, plus a third-order term) measured 142 us vs 139.7 us: neither
+        // the number nor the alignment of the scalar requests bounds the kernel.  Also
+        // measured and rejected: 6 waves per SIMD via amdgpu_waves_per_eu (190-220 us).
         const cdouble_p pq = as_const(h.aux + 1 + n_d);          // [k][4] = (pre, q1, q2, .)
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
@@ -849,8 +849,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
 
 // The recurrence flavour (the dominant kernel of a sweep).  Occupancy: 81 VGPRs -> 5 waves per
 // SIMD -> two resident 8-wave workgroups per CU; forcing 6 waves (three workgroups) was
-// measured 1.6x SLOWER: every row is read by exactly one wave, so more waves only add
-// pressure on the scalar-cache -> L2 path that feeds them.
+// measured 1.4-1.6x SLOWER (the compiler reaches 76 VGPRs only by re-loading operands).
 template <bool DOP2>
 __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_uniform(HydroSet hs, PsdArgs a)
 {
