@@ -705,7 +705,8 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
         // it into 128-byte padded rows (two aligned 64-byte scalar loads per bin instead of
         // three unaligned ones, plus a third-order term) measured 142 us vs 139.7 us: neither
         // the number nor the alignment of the scalar requests bounds the kernel.  Also
-        // measured and rejected: 6 waves per SIMD via amdgpu_waves_per_eu (190-220 us).
+        // measured and rejected: 6 waves per SIMD via amdgpu_waves_per_eu (190-220 us);
+        // prefetching the next unit's slice into L2 with dummy vector loads (160 us).
         const cdouble_p pq = as_const(h.aux + 1 + n_d);          // [k][4] = (pre, q1, q2, .)
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
