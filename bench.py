@@ -41,7 +41,7 @@ LUT_SLICE_BYTES = 1024 * 12 * 4   # B_l per valid item (float32 
 # HBM bytes per sweep of the PSD kernel from the PMC passes committed under profiles/
 # ((2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md); refreshed
 # whenever the profile is re-taken -- see profiles/README.md
-PSD_TRAFFIC_BYTES_PER_SWEEP = 65.9e6     # profiles/r1_final_pmc_hbm.json, k_psd<1>
+PSD_TRAFFIC_BYTES_PER_SWEEP = 66.9e6     # profiles/r1_final2_pmc_hbm.json, k_psd_uniform<false>
 
 
 def bench_config(small):
@@ -265,7 +265,7 @@ def main():
                        'parallelism': ('rays sharded by sweep, 1 all-gather/step on a side stream, overlapped '
                                        'with the next step') if world > 1 else 'single GPU',
                        'small': bool(args.small)},
-            'roofline': {'kernel': 'k_psd<1> (uniform-grid gamma flavour; 1 launch/sweep covers R, S, G)', 'bound': 'hbm',
+            'roofline': {'kernel': 'k_psd_uniform<false> (recurrence flavour of the PSD x table kernel; 1 launch/sweep covers R, S, G)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
                          'traffic': PSD_TRAFFIC_BYTES_PER_SWEEP,
