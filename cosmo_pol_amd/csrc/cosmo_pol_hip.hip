@@ -377,8 +377,8 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
         return CPOL_ERR_ARG;
     }
     if (desc->psd_family == CPOL_PSD_GAMMA && desc->uniform_grid &&
-        (!aux || n_aux < 5 * desc->n_d + 1 || desc->n_d % CPOL_PSD_WAVES != 0)) {
-        ctx->err = "cpol_stage_hydro: uniform_grid needs aux[1 + 5 n_d] and n_d % 8 == 0";
+        (!aux || n_aux < 5 * desc->n_d + 1)) {
+        ctx->err = "cpol_stage_hydro: uniform_grid needs aux[1 + 5 n_d]";
         return CPOL_ERR_ARG;
     }
     if (desc->psd_family == CPOL_PSD_ICE_FIELD && (!aux || n_aux < 4 * desc->n_d + 1)) {
@@ -741,8 +741,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             else hipLaunchKernelGGL((k_psd<M, false>), grd, blk, 0, st, ctx->hs, pa);        \
         }
         if (need[PSD_MODE_GAMMA_UNIFORM]) {
-            if (dop2) hipLaunchKernelGGL((k_psd_uniform<true>), grd_u, blk, 0, st, ctx->hs, pa);
-            else hipLaunchKernelGGL((k_psd_uniform<false>), grd_u, blk, 0, st, ctx->hs, pa);
+            const dim3 blk_u(CPOL_PSD_THREADS_U);
+            if (dop2) hipLaunchKernelGGL((k_psd_uniform<true>), grd_u, blk_u, 0, st, ctx->hs, pa);
+            else hipLaunchKernelGGL((k_psd_uniform<false>), grd_u, blk_u, 0, st, ctx->hs, pa);
         }
         CPOL_LAUNCH_PSD(PSD_MODE_GAMMA_EXP)
         CPOL_LAUNCH_PSD(PSD_MODE_ICE)

@@ -403,6 +403,13 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ 
 // a workgroup whose unit belongs to another flavour exits immediately.
 #define CPOL_PSD_WAVES 8
 #define CPOL_PSD_THREADS (CPOL_PSD_WAVES * CPOL_WAVE)
+// waves per workgroup of the recurrence flavour (8 or 10).  Measured: 8 waves 139.7 us,
+// 10 waves (5 waves per SIMD instead of 4) 166 us, 6 waves 204 us -- more waves in flight
+// make every wave slower, so the default stays at 8
+#ifndef CPOL_PSD_WAVES_U
+#define CPOL_PSD_WAVES_U 8
+#endif
+#define CPOL_PSD_THREADS_U (CPOL_PSD_WAVES_U * CPOL_WAVE)
 
 enum { PSD_MODE_GAMMA_EXP = 0, PSD_MODE_GAMMA_UNIFORM = 1, PSD_MODE_ICE = 2, PSD_MODE_MELTING = 3 };
 
@@ -505,7 +512,8 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n_d = d.n_d;
-    const int chunk = (n_d + CPOL_PSD_WAVES - 1) / CPOL_PSD_WAVES;
+    constexpr int NW = (MODE == PSD_MODE_GAMMA_UNIFORM) ? CPOL_PSD_WAVES_U : CPOL_PSD_WAVES;
+    const int chunk = (n_d + NW - 1) / NW;
     const int k0 = wave * chunk, k1 = min(k0 + chunk, n_d);
     const bool active = lane < count;
     const long n = a.n_sbg;
@@ -728,8 +736,35 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
                 dv1 = fma(wv, n1, dv1); dn1 = fma(wr, n1, dn1);
             }
         }
-        // tree ((w0+w4)+(w2+w6)) + ((w1+w5)+(w3+w7)) through 4 LDS wave slots; the
+        // waves beyond the eighth fold into waves 0.. first, then the tree
+        // ((w0+w4)+(w2+w6)) + ((w1+w5)+(w3+w7)) through 4 LDS wave slots; the
         // wave that ends up with the total (wave 0) writes the results
+        if (NW > 8) {
+            if (wave >= 8) {
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) {
+                    s_part[wave - 8][c][lane] = acc[c];
+                    s_part[wave - 8][CPOL_N_SZ + c][lane] = acc1[c];
+                }
+                if (DOP2) {
+                    s_part[wave - 8][NV - 4][lane] = dv0; s_part[wave - 8][NV - 3][lane] = dn0;
+                    s_part[wave - 8][NV - 2][lane] = dv1; s_part[wave - 8][NV - 1][lane] = dn1;
+                }
+            }
+            __syncthreads();
+            if (wave < NW - 8) {
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) {
+                    acc[c] += s_part[wave][c][lane];
+                    acc1[c] += s_part[wave][CPOL_N_SZ + c][lane];
+                }
+                if (DOP2) {
+                    dv0 += s_part[wave][NV - 4][lane]; dn0 += s_part[wave][NV - 3][lane];
+                    dv1 += s_part[wave][NV - 2][lane]; dn1 += s_part[wave][NV - 1][lane];
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int half = 4; half >= 1; half >>= 1) {
             if (wave >= half && wave < 2 * half) {
@@ -852,7 +887,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
 // SIMD -> two resident 8-wave workgroups per CU; forcing 6 waves (three workgroups) was
 // measured 1.4-1.6x SLOWER (the compiler reaches 76 VGPRs only by re-loading operands).
 template <bool DOP2>
-__global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_uniform(HydroSet hs, PsdArgs a)
+__global__ __launch_bounds__(CPOL_PSD_THREADS_U) void k_psd_uniform(HydroSet hs, PsdArgs a)
 {
     psd_body<PSD_MODE_GAMMA_UNIFORM, DOP2>(hs, a);
 }

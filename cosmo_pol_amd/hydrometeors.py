@@ -168,20 +168,21 @@ def build_hydro(h, scheme, lut, var_index):
 
 
 PSD_WAVES = 8        # csrc/cpol_psd.inl: CPOL_PSD_WAVES (bins are split over 8 wavefronts)
+PSD_WAVES_U = 8      # csrc/cpol_psd.inl: CPOL_PSD_WAVES_U (recurrence flavour; 8 or 10)
 
 
 def _uniform_grid_aux(d, D, nu, n_d, pre):
     """nu == 1: exp(-lambda D_k) is advanced by a geometric recurrence inside each
-    wave chunk of n_d/8 bins.  aux = [h, dlt_0 .. dlt_{n_d-1}, (pre_k, pre_k dlt_k,
+    wave chunk of ceil(n_d/10) bins.  aux = [h, dlt_0 .. dlt_{n_d-1}, (pre_k, pre_k dlt_k,
     pre_k dlt_k^2 / 2, -pre_k dlt_k^3 / 6) ...] with h the mean grid step and dlt_k = D_k - D_k0 - (k-k0) h
     the (float32-rounding sized) departure of node k from the uniform grid anchored at
     its chunk start k0; the per-bin quadruple is one 32-byte scalar load in the kernel."""
-    if float(nu) != 1.0 or n_d % PSD_WAVES != 0:
+    if float(nu) != 1.0:
         d.uniform_grid = 0
         return None
     D64 = np.asarray(D, dtype=np.float64)
     h = (D64[-1] - D64[0]) / (n_d - 1)
-    ch = n_d // PSD_WAVES
+    ch = -(-n_d // PSD_WAVES_U)             # the kernel's chunk: ceil(n_d / waves)
     k = np.arange(n_d)
     k0 = (k // ch) * ch
     dlt = D64 - D64[k0] - (k - k0) * h
