@@ -96,7 +96,7 @@ EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_fork', 'cpol_last_error', 'cpol_
            'cpol_stage_doppler_weights',
            'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
            'cpol_spaceborne_first_gate',
-           'cpol_enable_timing', 'cpol_debug_read']
+           'cpol_enable_timing', 'cpol_debug_read', 'cpol_debug_math']
 
 _lib = None
 
@@ -153,6 +153,8 @@ def load_library():
     lib.cpol_enable_timing.argtypes = [vp, C.c_int]
     lib.cpol_debug_read.restype = C.c_int64
     lib.cpol_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_int64]
+    lib.cpol_debug_math.restype = C.c_int
+    lib.cpol_debug_math.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     _lib = lib
     return lib
 
@@ -285,6 +287,13 @@ class Context(object):
         c = Counters()
         self._check(self.lib.cpol_counters(self.h, C.byref(c)), 'cpol_counters')
         return c
+
+    def debug_math(self, op, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self._check(self.lib.cpol_debug_math(self.h, int(op), _ptr(x), _ptr(y), x.size),
+                    'cpol_debug_math')
+        return y
 
     def debug_read(self, name, shape, dtype):
         out = np.empty(shape, dtype=dtype)

@@ -747,7 +747,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         }
         CPOL_LAUNCH_PSD(PSD_MODE_GAMMA_EXP)
         CPOL_LAUNCH_PSD(PSD_MODE_ICE)
-        CPOL_LAUNCH_PSD(PSD_MODE_MELTING)
+        if (need[PSD_MODE_MELTING]) {
+            if (dop2) hipLaunchKernelGGL((k_psd_melting<true>), grd, blk, 0, st, ctx->hs, pa);
+            else hipLaunchKernelGGL((k_psd_melting<false>), grd, blk, 0, st, ctx->hs, pa);
+        }
 #undef CPOL_LAUNCH_PSD
     }
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
@@ -920,6 +923,24 @@ int cpol_counters(cpol_ctx *ctx, cpol_counters_t *out)
         }
     }
     *out = ctx->counters;
+    return CPOL_OK;
+}
+
+int cpol_debug_math(cpol_ctx *ctx, int op, const double *x, double *y, int n)
+{
+    if (!ctx || !x || !y || n < 1) return CPOL_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf dx, dy;
+    int rc;
+    if ((rc = upload(ctx, dx, x, (size_t)n * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, dy, (size_t)n * sizeof(double)))) { free_buf(dx); return rc; }
+    hipLaunchKernelGGL(k_debug_math, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, op,
+                       (const double *)dx.p, (double *)dy.p, n);
+    hipError_t e = hipMemcpyAsync(y, dy.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    free_buf(dx);
+    free_buf(dy);
+    if (e != hipSuccess) { ctx->err = std::string("cpol_debug_math: ") + hipGetErrorString(e); return CPOL_ERR_HIP; }
     return CPOL_OK;
 }
 

@@ -469,6 +469,118 @@ __device__ __forceinline__ double melt_Dr(const cpol_hydro_desc &d, const MeltIt
     return cbrt(rho / 1.0e-6) * D;                          // RHO_W = 1000/1000^3 kg mm-3
 }
 
+// ---------------------------------------------------------------- per-bin math of the melting flavour
+// The melting species integrate over a per-ITEM diameter grid, so nothing can be tabulated
+// on the host: every (item, bin) needs two cube roots, a square root, an exponential, a
+// fourth root (snow) or two powers (graupel) and a division.  The OCML versions cost 32 /
+// 22 / 42 / 44 / 215 / 12 VALU instructions; the versions below reach 1e-15 relative
+// accuracy (tests/test_gpu_math.py) in 15-32, from float32 hardware seeds refined by
+// Newton steps in float64 and short polynomials.  Inputs are positive and normal here.
+__device__ __forceinline__ double cp_exp(double x)
+{
+    // x = n ln2 + r, |r| <= ln2/2; Taylor to r^12/12! (next term < 2e-16)
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(n, -0.6931471803691238, x);
+    r = fma(n, -1.9082149292705877e-10, r);
+    double p = 1.0 / 479001600.0;
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+__device__ __forceinline__ double cp_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * fma(-x, r, 2.0);
+    r = r * fma(-x, r, 2.0);
+    return r;
+}
+
+__device__ __forceinline__ double cp_log(double x)
+{
+    // x = m 2^e, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m-1)/(m+1), |s| < 0.1716
+    int e;
+    double m = frexp(x, &e);
+    if (m < 0.7071067811865476) { m *= 2.0; e -= 1; }
+    const double s = (m - 1.0) * cp_rcp(m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = fma(p, z, 1.0);
+    const double en = (double)e;
+    return fma(en, 0.6931471803691238, fma(en, 1.9082149292705877e-10, 2.0 * s * p));
+}
+
+// x^(-1/6) -> cbrt(x) = x y^4 and sqrt(cbrt(x)) = x y^5 from ONE Newton sequence
+__device__ __forceinline__ void cp_cbrt_and_sixth(double x, double &cb, double &sx)
+{
+    double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * (-1.0f / 6.0f));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y, y4 = y2 * y2;
+        y = y * fma(-x * y2, y4, 7.0) * (1.0 / 6.0);       // y (7 - x y^6) / 6
+    }
+    const double y2 = y * y, y4 = y2 * y2;
+    cb = x * y4;
+    sx = cb * y;
+}
+
+__device__ __forceinline__ double cp_cbrt(double x)
+{
+    double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * (-1.0f / 3.0f));
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+        y = y * fma(-x * y, y * y, 4.0) * (1.0 / 3.0);      // y (4 - x y^3) / 3
+    return x * (y * y);
+}
+
+__device__ __forceinline__ double cp_fourth_root(double x)
+{
+    double y = (double)__builtin_amdgcn_rsqf(__builtin_amdgcn_sqrtf((float)x));   // x^(-1/4)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y;
+        y = y * fma(-x * y2, y2, 5.0) * 0.25;               // y (5 - x y^4) / 4
+    }
+    return x * (y * y * y);
+}
+
+// test hook (cpol_debug_math): evaluates one of the functions above on the device
+__global__ void k_debug_math(int op, const double *__restrict__ x, double *__restrict__ y, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a, b;
+    switch (op) {
+    case 0: y[i] = cp_exp(x[i]); break;
+    case 1: y[i] = cp_log(x[i]); break;
+    case 2: y[i] = cp_cbrt(x[i]); break;
+    case 3: cp_cbrt_and_sixth(x[i], a, b); y[i] = a; break;
+    case 4: cp_cbrt_and_sixth(x[i], a, b); y[i] = b; break;
+    case 5: y[i] = cp_fourth_root(x[i]); break;
+    case 6: y[i] = cp_rcp(x[i]); break;
+    default: y[i] = x[i];
+    }
+}
+
 // Scattering tables and per-bin factors are immutable while a sweep runs: reading them
 // through the CONSTANT address space guarantees the scalar data path (s_load -> SGPR
 // operands) for wave-uniform addresses even when the kernel also stores to global memory.
@@ -649,26 +761,26 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
             // one logarithm when they are not plain squares / fourth roots
             double Db, D2b, Dbeta;
             if (d.b == 2.0 && d.beta == 0.25) {
-                Db = D * D; D2b = D2 * D2; Dbeta = sqrt(sqrt(D));
+                Db = D * D; D2b = D2 * D2; Dbeta = cp_fourth_root(D);
             } else {
-                const double L = log(D);
-                Db = (d.b == 2.0) ? D * D : exp(d.b * L);
-                D2b = powb(D2, d.b);
-                Dbeta = exp(d.beta * L);
+                const double L = cp_log(D);
+                Db = (d.b == 2.0) ? D * D : cp_exp(d.b * L);
+                D2b = (d.b == 2.0) ? D2 * D2 : cp_exp(d.b * cp_log(D2));
+                Dbeta = cp_exp(d.beta * L);
             }
             const double M = it.fw2 * (d.r_a * (D * D * D)) + (1.0 - it.fw2) * (d.a * Db);
             const double M2 = it.fw2 * (d.r_a * (D2 * D2 * D2)) + (1.0 - it.fw2) * (d.a * D2b);
             // D_r = (rho_m / rho_w)^(1/3) D with rho_m = M / (pi/6 D^3)  ==  cbrt(6e6/pi M)
             // (:382-383; the D^3 cancels exactly, rounding differs by ~2 ulp)
             const double c6 = 6.0e6 / 3.14159265358979323846;
-            const double Dr = cbrt(c6 * M);
-            const double dDr = (cbrt(c6 * M2) - Dr) * 100.0;                    // /0.01, :384
-            const double sq = sqrt(Dr);
-            const double Nr = (d.r_n0 * sq) * exp(-(it.lam_r * Dr));           // rain N(D_r)
+            double Dr, sq;
+            cp_cbrt_and_sixth(c6 * M, Dr, sq);                                 // D_r, sqrt(D_r)
+            const double dDr = (cp_cbrt(c6 * M2) - Dr) * 100.0;                // /0.01, :384
+            const double Nr = (d.r_n0 * sq) * cp_exp(-(it.lam_r * Dr));        // rain N(D_r)
             const double Vr = d.r_alpha * sq;                                  // rain V(D_r)
             const double Vd = d.alpha * Dbeta;
             const double V = it.phi * Vr + (1 - it.phi) * Vd;                  // :431-439
-            const double Nraw = Nr * Vr / V * dDr;                             // :386-387
+            const double Nraw = (Nr * Vr) * cp_rcp(V) * dDr;                   // :386-387
             msum += Nraw * M;                                                  // :478
             if (DOP2) {                        // rcs-weighted, per-item fall speed V(D)
                 const double wr = rv[2 * k + 1];
@@ -891,3 +1003,14 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS_U) void k_psd_uniform(HydroSet hs,
 {
     psd_body<PSD_MODE_GAMMA_UNIFORM, DOP2>(hs, a);
 }
+
+// The melting flavour: without a register cap the inlined root / exp / log polynomials keep
+// their coefficients live in ~80 VGPRs (157 in total -> 3 waves per SIMD -> ONE workgroup per
+// CU); capped at 128 VGPRs two workgroups are resident.
+template <bool DOP2>
+__global__ __launch_bounds__(CPOL_PSD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_psd_melting(HydroSet hs, PsdArgs a)
+{
+    psd_body<PSD_MODE_MELTING, DOP2>(hs, a);
+}
+

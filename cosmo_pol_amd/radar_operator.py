@@ -75,18 +75,21 @@ class RadarScan(object):
         self.fields = {}
         names = list(sweeps[0]['fields'].keys())
         for k in names:
-            with np.errstate(divide='ignore', invalid='ignore'):
-                stack = np.concatenate([np.array(s['fields'][k], copy=True) for s in sweeps], axis=0)
-                if k in _DB_FIELDS:
+            parts = [s['fields'][k] for s in sweeps]
+            stack = np.concatenate(parts, axis=0) if (len(parts) > 1 or k in _DB_FIELDS) else parts[0]
+            if k in _DB_FIELDS:
+                # dB, 0 -> NaN (pyart_wrapper.py:256-258); in place on the stacked copy
+                with np.errstate(divide='ignore', invalid='ignore'):
                     stack[stack == 0] = np.nan
-                    stack = 10 * np.log10(stack)
-            self.fields[k] = {'data': np.ma.array(stack, mask=np.isnan(stack))}
+                    np.log10(stack, out=stack)
+                    stack *= 10
+            self.fields[k] = {'data': np.ma.array(stack, mask=np.isnan(stack), copy=False)}
         for k, src in (('Latitude', 'lats'), ('Longitude', 'lons')):
             stack = np.concatenate([s[src] for s in sweeps], axis=0)
             self.fields[k] = {'data': np.ma.array(stack, mask=np.isnan(stack)),
                               'units': ['degrees']}
-        self.fields['rangearray'] = {'data': np.tile(self.range['data'],
-                                                     (len(self.elevation['data']), 1))}
+        self.fields['rangearray'] = {'data': np.broadcast_to(
+            self.range['data'], (len(self.elevation['data']), len(self.range['data'])))}
         self.nrays = len(self.azimuth['data'])
         self.ngates = len(self.range['data'])
 

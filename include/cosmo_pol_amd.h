@@ -262,6 +262,10 @@ int  cpol_enable_timing(cpol_ctx *ctx, int on);
  * [n_hydro][n_sbg][12].  Returns bytes copied or < 0. */
 int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_bytes);
 
+/* test hook: evaluates one of the device math helpers of the melting-species kernel on
+ * host arrays (op 0 exp, 1 log, 2 cbrt, 3 cbrt via x^(-1/6), 4 x^(1/6), 5 x^(1/4), 6 1/x) */
+int  cpol_debug_math(cpol_ctx *ctx, int op, const double *x, double *y, int n);
+
 #ifdef __cplusplus
 }
 #endif

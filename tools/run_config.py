@@ -62,6 +62,17 @@ def main():
     gates = len(elevs) * len(az) * res['ZH'].shape[1]
     print(json.dumps(dict(config=args.config, volume_ms=tot, gates=gates,
                           gates_per_s=gates / (tot * 1e-3))))
+    # the product path: get_PPI spreads the sweeps over lanes (host threads + forked contexts)
+    op._ctx.enable_timing(False)
+    for lanes in (1, 3):
+        op.lanes = lanes
+        op.get_PPI(elevs, azimuths=az)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            op.get_PPI(elevs, azimuths=az)
+        dt = (time.perf_counter() - t0) / args.steps
+        print(json.dumps(dict(config=args.config, api='get_PPI', lanes=lanes, volume_ms=1e3 * dt,
+                              gates_per_s=gates / dt)))
     op.close()
 
 
