@@ -153,19 +153,21 @@ class SimulatedGPM(object):
         N, M = dim
         n_rays, n_gates = mask.shape
         self.band = band
-        self.bin_surface = np.zeros((N, M))
-        self.lats = np.full((N, M, n_gates), np.nan)
-        self.lons = np.full((N, M, n_gates), np.nan)
-        self.data = {k: np.zeros((N, M, n_gates)) for k in fields}
-        for idx in range(n_rays):
-            i, j = divmod(idx, M)
-            L = int(n_kept[idx])
-            m = mask[idx, :L]
-            above = np.where(m >= 1)[0]
-            self.bin_surface[i, j] = (L - above[0]) if len(above) else 0
-            keep = m > -1
-            n = int(keep.sum())
-            self.lats[i, j, :n] = lats[idx, :L][keep][::-1]
-            self.lons[i, j, :n] = lons[idx, :L][keep][::-1]
-            for k in fields:
-                self.data[k][i, j, :n] = fields[k][idx, :L][keep][::-1]
+        n_kept = np.asarray(n_kept).reshape(-1)
+        inside = np.arange(n_gates)[None, :] < n_kept[:, None]           # gates of the ray
+        above = inside & (mask >= 1)
+        first_above = np.where(above.any(axis=1), above.argmax(axis=1), -1)
+        self.bin_surface = np.where(first_above >= 0, n_kept - first_above, 0).astype(float).reshape(N, M)
+        # kept gates (not below the topography), flipped so that index 0 is the lowest one
+        keep = inside & (mask > -1)
+        n = keep.sum(axis=1)
+        dest = (n[:, None] - np.cumsum(keep, axis=1))[keep]
+        rows = np.nonzero(keep)[0]
+
+        def pack(src, fill):
+            out = np.full((n_rays, n_gates), fill, dtype=np.float64)
+            out[rows, dest] = src[keep]
+            return out.reshape(N, M, n_gates)
+        self.lats = pack(lats, np.nan)
+        self.lons = pack(lons, np.nan)
+        self.data = {k: pack(fields[k], 0.0) for k in fields}

@@ -193,6 +193,25 @@ class RadarOperator(object):
         scheme = conf['microphysics']['scheme']
         self.current_microphys_scheme = scheme
         hl = hyd.hydrometeor_list(conf)
+        key = (scheme, conf['radar']['frequency'], conf['microphysics']['scattering'], tuple(hl),
+               conf['doppler']['scheme'] == 2)
+        cache = self.__dict__.setdefault('_lut_cache', {})
+        if key in cache:
+            # tables of a configuration seen before (e.g. the Ku / Ka / ground switches of
+            # get_GPM_swath): no file reads, no per-bin factor rebuild -- only the H2D staging
+            lut, built = cache[key]
+            self.lut_sz = lut
+            self._drop_lanes()
+            for slot, h in enumerate(hl):
+                d, table, pre, dnu, aux, dw = built[h]
+                self._ctx.stage_hydro(slot, d, table, pre, dnu, aux)
+                if dw is not None:
+                    self._ctx.stage_doppler_weights(slot, dw)
+            self._ctx.set_num_hydro(len(hl))
+            self._staged_hydro = hl
+            if self._model_staged and self._staged_vars != hyd.variable_list(conf):
+                self._stage_model()
+            return
         if callable(self._user_luts):
             lut = self._user_luts(hl, conf['radar']['frequency'], scheme)
         elif self._user_luts is not None:
@@ -206,11 +225,17 @@ class RadarOperator(object):
         self.lut_sz = lut
         self._drop_lanes()
         var_index = {v: i for i, v in enumerate(hyd.variable_list(conf))}
+        built = {}
         for slot, h in enumerate(hl):
             d, table, pre, dnu, aux = hyd.build_hydro(h, scheme, lut[h], var_index)
             self._ctx.stage_hydro(slot, d, table, pre, dnu, aux)
+            dw = None
             if conf['doppler']['scheme'] == 2:
-                self._ctx.stage_doppler_weights(slot, hyd.doppler_weights(h, scheme, lut[h]))
+                dw = hyd.doppler_weights(h, scheme, lut[h])
+                self._ctx.stage_doppler_weights(slot, dw)
+            built[h] = (d, table, pre, dnu, aux, dw)
+        if len(cache) < 4:                       # a few table sets at most (host memory)
+            cache[key] = (lut, built)
         self._ctx.set_num_hydro(len(hl))
         self._staged_hydro = hl
         if self._model_staged and self._staged_vars != hyd.variable_list(conf):

@@ -22,6 +22,8 @@ def main():
     args = ap.parse_args()
     import bench
     from cosmo_pol_amd import RadarOperator, synthetic
+    if args.config == 'c5':
+        return run_c5(args)
     conf = bench.bench_config(args.small)
     conf['microphysics'].update(with_melting=1, with_ice_crystals=1)
     if args.config == 'c4':
@@ -73,6 +75,38 @@ def main():
         dt = (time.perf_counter() - t0) / args.steps
         print(json.dumps(dict(config=args.config, api='get_PPI', lanes=lanes, volume_ms=1e3 * dt,
                               gates_per_s=gates / dt)))
+    op.close()
+
+
+def run_c5(args):
+    """C5: GPM-DPR Ku (200 x 49 rays) and Ka (200 x 25) swaths over the 2-moment bench cube."""
+    import bench
+    from cosmo_pol_amd import RadarOperator, gpm, synthetic
+    conf = bench.bench_config(False)
+    conf['radar']['type'] = 'GPM'
+    conf['microphysics'].update(scheme='2mom', with_melting=0, with_ice_crystals=1)
+    hyds = ['R', 'S', 'G', 'H', 'I']
+    t0 = time.time()
+    cube = synthetic.make_cube(hydrometeors=('R', 'S', 'G', 'H', 'I'), two_moment=True,
+                               **synthetic.BENCH_GRID)
+    luts = lambda hl, freq, scheme: synthetic.make_all_luts(hl, freq, scheme)   # noqa: E731
+    print('inputs %.1f s' % (time.time() - t0), flush=True)
+    op = RadarOperator(config=conf, luts=luts, output_variables='only_radar')
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    for band, n_rays in (('Ku', 49), ('Ka', 25)):
+        swath = gpm.synthetic_swath(n_scans=200, n_rays=n_rays, centre=(46.5, 7.5),
+                                    cross_track_deg=17.0 if band == 'Ku' else 8.5, scan_spacing_m=3000.0)
+        t0 = time.perf_counter()
+        out = op.get_GPM_swath(swath, band)            # includes the table reload of the band
+        t_first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = op.get_GPM_swath(swath, band)
+        dt = (time.perf_counter() - t0) / args.steps
+        n_gates = int(np.isfinite(out.lats).sum())
+        print(json.dumps(dict(config='c5', band=band, rays=200 * n_rays, kept_gates=n_gates,
+                              first_call_s=t_first, swath_ms=1e3 * dt, gates_per_s=n_gates / dt,
+                              finite_zh=int(np.isfinite(out.data['ZH']).sum()))), flush=True)
     op.close()
 
 
