@@ -73,12 +73,18 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyq
     radial_res = config['radar']['radial_resolution']
     dop_scheme = config['doppler']['scheme']
     simulate_doppler = doppler and config['radar'].get('type', 'ground') != 'GPM' \
-        and dop_scheme in (1, 2)
+        and dop_scheme in (1, 2, 3)
     hydrom_types = hydrometeor_list(config)
 
     n_sub = len(subbeams)
     idx_0 = int(n_sub / 2)
     n_gates = max([len(sb.dist_profile) for sb in subbeams])
+    if simulate_doppler and dop_scheme == 3:
+        from . import spectrum as SP
+        if melting:
+            raise NotImplementedError('oracle: Doppler scheme 3 with melting species')
+        varray = SP.velocity_array(config)
+        doppler_spectrum = np.zeros((n_gates, len(varray)))
 
     hyd = {}
     for h in hydrom_types:
@@ -101,6 +107,7 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyq
         for sb in subbeams:
             v_integ = np.zeros(n_gates,)
             n_integ = np.zeros(n_gates,)
+            ah_list = []
             for j, h in enumerate(hydrom_types):
                 if melting and not sb.has_melting and h in ['mS', 'mG']:
                     continue
@@ -157,6 +164,12 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyq
                     vh, n = hyd[h].integrate_V()
                     v_integ[valid] = nansum_pair(v_integ[valid], vh)
                     n_integ[valid] = nansum_pair(n_integ[valid], n)
+                elif simulate_doppler and dop_scheme == 3:
+                    # attenuation of this hydrometeor at its valid gates (:297-305)
+                    wl = K.Derived(config).WAVELENGTH
+                    ah = 4.343e-3 * 2 * wl * sz_psd[:, 11]
+                    ah *= radial_res / 1000.
+                    ah_list.append(ah)
                 elif simulate_doppler:
                     # scheme 2: fall speed weighted by N(D) x rcs_h, unit-spaced trapezoid
                     # (doppler_scatter.py:283-296)
@@ -167,7 +180,23 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyq
                     v_integ[valid] = nansum_pair(v_integ[valid], vh_w)
                     n_integ[valid] = nansum_pair(n_integ[valid], n_w)
 
-            if simulate_doppler:
+            if simulate_doppler and dop_scheme == 3:
+                beam = SP.subbeam_spectrum(sb, hydrom_types, luts, config, varray)
+                add = np.zeros(len(beam))
+                if config['doppler']['turbulence_correction']:
+                    raise NotImplementedError('oracle: turbulence correction needs EDR')
+                if config['doppler']['motion_correction']:
+                    add = add + SP.spectral_width_motion(sb.elev_profile, config)
+                if np.sum(add) > 0:
+                    beam = SP.broaden_spectrum(beam, add, varray)
+                if mp['with_attenuation']:
+                    beam = SP.apply_attenuation(beam, SP.attenuation_per_beam(ah_list, n_gates))
+                if not np.isscalar(sb.quad_weight):
+                    beam = beam * sb.quad_weight[:, None]
+                else:
+                    beam = beam * sb.quad_weight
+                doppler_spectrum += beam
+            elif simulate_doppler:
                 v_hydro = v_integ / n_integ
                 theta = np.deg2rad(sb.elev_profile)
                 phi = np.deg2rad(sb.quad_pt[0])
@@ -186,7 +215,10 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyq
             ZH_ATT *= nan_cumprod(10 ** (-0.1 * AH * (radial_res / 1000.)))
             ZDR = ZH_ATT / ZV_ATT
         if simulate_doppler:
-            rvel_avg /= total_weight_rvel
+            if dop_scheme == 3:
+                rvel_avg = SP.rvel_from_spectrum(doppler_spectrum, varray)
+            else:
+                rvel_avg /= total_weight_rvel
             if nyquist is not None:          # doppler_scatter.py:431-437
                 rvel_avg = aliasing(rvel_avg, nyquist)
 
@@ -194,6 +226,8 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyq
            'RHOHV': RHOHV, 'ATT_H': AH, 'ATT_V': AV}
     if simulate_doppler:
         obs['RVEL'] = rvel_avg
+        if dop_scheme == 3:
+            obs['DSPECTRUM'] = doppler_spectrum
 
     mask = np.zeros(n_gates,)
     for sb in subbeams:

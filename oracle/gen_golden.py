@@ -279,6 +279,20 @@ RADIAL_CASES.update({
                      ('R', 'S', 'G'), False),
 })
 
+# Doppler scheme 3 (full spectrum, doppler_c.c); FFT_length 64 keeps the fixtures small
+RADIAL_CASES.update({
+    'd3_rsg': ({'radar': {'range': 24000, 'radial_resolution': 400, 'FFT_length': 64},
+                'microphysics': {'with_ice_crystals': 0, 'with_melting': 0},
+                'doppler': {'scheme': 3},
+                'integration': {'nh_GH': 1, 'nv_GH': 1}}, 200.0, 4.0, ('R', 'S', 'G'), False),
+    'd3_2mom_sub': ({'radar': {'range': 24000, 'radial_resolution': 600, 'frequency': 13.6,
+                               'FFT_length': 32, 'PRI': 300},
+                     'microphysics': {'scheme': '2mom', 'with_ice_crystals': 1, 'with_melting': 0,
+                                      'with_attenuation': 0},
+                     'doppler': {'scheme': 3},
+                     'integration': {'nh_GH': 3, 'nv_GH': 1}}, 75.0, 8.0, ('R', 'S', 'G', 'I'), True),
+})
+
 LUT_KW = dict(seed=20260301, n_e=8, n_t=None)
 
 

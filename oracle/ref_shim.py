@@ -90,10 +90,24 @@ def _make_interp_module():
 
 def _make_doppler_module():
     lib = ctypes.CDLL(os.path.join(_HERE, "_ref", "libdoppler_ref.so"))
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.get_refl.restype = fp
+    lib.get_refl.argtypes = ([fp, ctypes.c_int] + [fp, ctypes.c_int, ctypes.c_int] * 5
+                             + [fp, ctypes.c_int] * 2)
     m = types.ModuleType("_doppler_c")
 
-    def get_refl(*args):
-        raise NotImplementedError("Doppler scheme 3 is out of scope (SURVEY #14)")
+    def get_refl(n, Da, Db, rcs, D, N, step_D, Dmin):
+        # mirrors the SWIG typemaps of doppler_c.i:16-23 (ARGOUT first, IN_ARRAYs converted
+        # to contiguous float32); returns [return value, refl] as the SWIG wrapper does
+        Da, Db, rcs, D, N, step_D, Dmin = [_c_f32(a) for a in (Da, Db, rcs, D, N, step_D, Dmin)]
+        out = np.empty(int(n), dtype=np.float32)
+
+        def P(a):
+            return a.ctypes.data_as(fp)
+        lib.get_refl(P(out), int(n), P(Da), Da.shape[0], Da.shape[1], P(Db), Db.shape[0],
+                     Db.shape[1], P(rcs), rcs.shape[0], rcs.shape[1], P(D), D.shape[0], D.shape[1],
+                     P(N), N.shape[0], N.shape[1], P(step_D), step_D.shape[0], P(Dmin), Dmin.shape[0])
+        return [None, out]
 
     m.get_refl = get_refl
     m._lib = lib
