@@ -63,7 +63,8 @@ class SweepParams(C.Structure):
         ('sin_u1', C.c_double), ('cos_u1', C.c_double),
         ('wavelength', C.c_double), ('k_squared', C.c_double), ('radial_res', C.c_double),
         ('c_zh', C.c_double),
-        ('var_u', C.c_int32), ('var_v', C.c_int32), ('var_w', C.c_int32), ('pad2_', C.c_int32),
+        ('var_u', C.c_int32), ('var_v', C.c_int32), ('var_w', C.c_int32), ('var_rho', C.c_int32),
+        ('n_vbins', C.c_int32), ('pad2_', C.c_int32), ('c_spectrum', C.c_double),
     ]
 
 
@@ -71,12 +72,14 @@ class RayTables(C.Structure):
     _fields_ = [('traj', C.c_void_p), ('geo', C.c_void_p), ('sub_h', C.c_void_p),
                 ('sub_v', C.c_void_p), ('sub_w', C.c_void_p), ('sens_thr', C.c_void_p),
                 ('site', C.c_void_p), ('paths', C.c_void_p), ('nyquist', C.c_void_p),
-                ('version', C.c_uint64), ('sub_smooth', C.c_void_p), ('ml_filter', C.c_void_p),
+                ('version', C.c_uint64), ('varray', C.c_void_p), ('sub_smooth', C.c_void_p),
+                ('ml_filter', C.c_void_p),
                 ('ml_radius', C.c_int32), ('pad_', C.c_int32)]
 
 
 OUTPUT_FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V',
-                 'RVEL', 'mask', 'lats', 'lons', 'dist', 'heights', 'model_vars', 'sz_total']
+                 'RVEL', 'mask', 'lats', 'lons', 'dist', 'heights', 'model_vars', 'sz_total',
+                 'DSPECTRUM']
 
 
 class Outputs(C.Structure):
@@ -93,7 +96,7 @@ class Counters(C.Structure):
 
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_fork', 'cpol_last_error', 'cpol_set_stream',
            'cpol_synchronize', 'cpol_stage_model', 'cpol_stage_hydro', 'cpol_set_num_hydro',
-           'cpol_stage_doppler_weights',
+           'cpol_stage_doppler_weights', 'cpol_stage_spectrum_tables',
            'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
            'cpol_spaceborne_first_gate',
            'cpol_enable_timing', 'cpol_debug_read', 'cpol_debug_math']
@@ -153,6 +156,8 @@ def load_library():
     lib.cpol_enable_timing.argtypes = [vp, C.c_int]
     lib.cpol_debug_read.restype = C.c_int64
     lib.cpol_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_int64]
+    lib.cpol_stage_spectrum_tables.restype = C.c_int
+    lib.cpol_stage_spectrum_tables.argtypes = [vp, C.c_int, vp, vp]
     lib.cpol_debug_math.restype = C.c_int
     lib.cpol_debug_math.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     _lib = lib
@@ -255,6 +260,12 @@ class Context(object):
         w = np.ascontiguousarray(weights, dtype=np.float64)
         self._check(self.lib.cpol_stage_doppler_weights(self.h, slot, _ptr(w)),
                     'cpol_stage_doppler_weights')
+
+    def stage_spectrum_tables(self, slot, rcs32, dgrid):
+        rcs32 = np.ascontiguousarray(rcs32, dtype=np.float32)
+        dgrid = np.ascontiguousarray(dgrid, dtype=np.float32)
+        self._check(self.lib.cpol_stage_spectrum_tables(self.h, int(slot), _ptr(rcs32), _ptr(dgrid)),
+                    'cpol_stage_spectrum_tables')
 
     def set_num_hydro(self, n):
         self._check(self.lib.cpol_set_num_hydro(self.h, n), 'cpol_set_num_hydro')

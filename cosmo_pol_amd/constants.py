@@ -118,6 +118,7 @@ class DerivedConstants(object):
         r = config['radar']
         self.NVEL = C_LIGHT / (4 * 1E-6 * r['PRI'] * r['frequency'] * 1E09)
         self.VRES = 2 * self.NVEL / r['FFT_length']
+        self.VARRAY = np.arange(-self.NVEL, self.NVEL + self.VRES, self.VRES)   # global_constants.py:171
         self.WAVELENGTH = C_LIGHT / (r['frequency'] * 1E09) * 1000
         self.PULSE_WIDTH = 2 * r['radial_resolution']
         self.RADAR_CONSTANT_DB = None

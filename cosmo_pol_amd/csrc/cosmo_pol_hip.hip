@@ -25,6 +25,7 @@
 #include "cpol_interp.inl"
 #include "cpol_psd.inl"
 #include "cpol_final.inl"
+#include "cpol_spectrum.inl"
 
 namespace {
 
@@ -53,11 +54,12 @@ struct cpol_ctx {
     // hydrometeors
     HydroSet hs{};
     DevBuf d_table[CPOL_MAX_HYDRO], d_pre[CPOL_MAX_HYDRO], d_dnu[CPOL_MAX_HYDRO],
-        d_aux[CPOL_MAX_HYDRO], d_rcsw[CPOL_MAX_HYDRO];
+        d_aux[CPOL_MAX_HYDRO], d_rcsw[CPOL_MAX_HYDRO], d_rcs32[CPOL_MAX_HYDRO], d_dgrid[CPOL_MAX_HYDRO];
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
     // per-sweep work buffers (grow only)
     DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site, b_nyq;
     DevBuf b_subsmooth, b_mlfilter, b_wgate, b_clk;
+    DevBuf b_varray, b_beam, b_spectrum, b_cutflag;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
         b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err, b_pos, b_vn, b_icefirst, b_rvel, b_fh, b_fv;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
@@ -161,11 +163,12 @@ void cpol_destroy(cpol_ctx *ctx)
         for (int j = 0; j < CPOL_MAX_HYDRO; ++j) {
             ctx->d_table[j] = DevBuf(); ctx->d_pre[j] = DevBuf(); ctx->d_dnu[j] = DevBuf();
             ctx->d_aux[j] = DevBuf(); ctx->d_rcsw[j] = DevBuf();
+            ctx->d_rcs32[j] = DevBuf(); ctx->d_dgrid[j] = DevBuf();
         }
         ctx->parent->n_children -= 1;
     }
     DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj_in, &ctx->b_geo, &ctx->b_subh, &ctx->b_subv,
-                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_subsmooth, &ctx->b_mlfilter, &ctx->b_wgate, &ctx->b_clk, &ctx->b_vals, &ctx->b_mask,
+                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_subsmooth, &ctx->b_mlfilter, &ctx->b_wgate, &ctx->b_clk, &ctx->b_varray, &ctx->b_beam, &ctx->b_spectrum, &ctx->b_cutflag, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_cursor, &ctx->b_units,
                      &ctx->b_urange, &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_err, &ctx->b_pos,
@@ -179,6 +182,8 @@ void cpol_destroy(cpol_ctx *ctx)
         free_buf(ctx->d_dnu[j]);
         free_buf(ctx->d_aux[j]);
         free_buf(ctx->d_rcsw[j]);
+        free_buf(ctx->d_rcs32[j]);
+        free_buf(ctx->d_dgrid[j]);
     }
     for (hipEvent_t *set : ctx->ev_sets) {
         for (int k = 0; k < EV_N; ++k) (void)hipEventDestroy(set[k]);
@@ -354,6 +359,9 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
     h.table = (const double *)ctx->d_table[slot].p;
     h.pre = h.dnu = h.aux = nullptr;
     h.rcsw = nullptr;
+    h.rcs32 = nullptr;
+    h.dgrid = nullptr;
+    h.step32 = 0.f;
     if (pre) {
         if ((rc = upload(ctx, ctx->d_pre[slot], pre, db)) != CPOL_OK) return rc;
         h.pre = (const double *)ctx->d_pre[slot].p;
@@ -410,6 +418,33 @@ int cpol_stage_doppler_weights(cpol_ctx *ctx, int slot, const double *weights)
     if ((rc = upload(ctx, ctx->d_rcsw[slot], weights, bytes)) != CPOL_OK) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->hs.h[slot].rcsw = (const double *)ctx->d_rcsw[slot].p;
+    return CPOL_OK;
+}
+
+int cpol_stage_spectrum_tables(cpol_ctx *ctx, int slot, const float *rcs32, const float *dgrid)
+{
+    if (!ctx || !rcs32 || !dgrid || slot < 0 || slot >= CPOL_MAX_HYDRO || !ctx->hydro_staged[slot]) {
+        if (ctx) ctx->err = "cpol_stage_spectrum_tables: stage the hydrometeor first";
+        return CPOL_ERR_ARG;
+    }
+    if (ctx->parent || ctx->n_children) {
+        ctx->err = "cpol_stage_spectrum_tables: not on a lane, and not while lanes of this context exist (cpol_fork)";
+        return CPOL_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    HydroDev &h = ctx->hs.h[slot];
+    if (h.d.psd_family == CPOL_PSD_MELTING) {
+        ctx->err = "cpol_stage_spectrum_tables: the Doppler spectrum covers power-law species only";
+        return CPOL_ERR_ARG;
+    }
+    const size_t nr = (size_t)h.d.n_e * h.d.n_t * h.d.n_d;
+    int rc;
+    if ((rc = upload(ctx, ctx->d_rcs32[slot], rcs32, nr * sizeof(float))) != CPOL_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_dgrid[slot], dgrid, (size_t)3 * h.d.n_d * sizeof(float))) != CPOL_OK) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    h.rcs32 = (const float *)ctx->d_rcs32[slot].p;
+    h.dgrid = (const float *)ctx->d_dgrid[slot].p;
+    h.step32 = dgrid[1] - dgrid[0];
     return CPOL_OK;
 }
 
@@ -551,6 +586,20 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_res, (size_t)n_hyd * n_sbg * CPOL_N_SZ * sizeof(double));
     const bool doppler = p->simulate_doppler != 0;
     const bool dop2 = p->simulate_doppler == 2;
+    const bool dop3 = p->simulate_doppler == 3;
+    const int n_vb = p->n_vbins;
+    if (dop3) {
+        if (n_vb < 2 || n_vb > 4097 || !t->varray || p->var_rho < 0 || p->var_rho >= n_vars || p->with_melting) {
+            ctx->err = "cpol_run_sweep: Doppler scheme 3 needs n_vbins in [2, 4097], tables->varray, var_rho and no melting species";
+            return CPOL_ERR_ARG;
+        }
+        for (int j = 0; j < n_hyd; ++j)
+            if (!ctx->hs.h[j].rcs32) { ctx->err = "cpol_run_sweep: Doppler scheme 3 needs cpol_stage_spectrum_tables"; return CPOL_ERR_ARG; }
+        if ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) * sizeof(float) > 64 * 1024) {
+            ctx->err = "cpol_run_sweep: Doppler scheme 3: n_hydro x (n_d + n_vbins) exceeds the LDS of a workgroup";
+            return CPOL_ERR_ARG;
+        }
+    }
     if (dop2)
         for (int j = 0; j < n_hyd; ++j)
             if (!ctx->hs.h[j].rcsw) { ctx->err = "cpol_run_sweep: Doppler scheme 2 needs cpol_stage_doppler_weights"; return CPOL_ERR_ARG; }
@@ -558,6 +607,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ENSURE(ctx->b_vn, (size_t)n_hyd * n_sbg * 2 * sizeof(double));
         ENSURE(ctx->b_icefirst, (size_t)n_rays * n_sub * sizeof(IceFirst));
         ENSURE(ctx->b_rvel, (size_t)n_rg * sizeof(double));
+    }
+    if (dop3) {
+        ENSURE(ctx->b_beam, (size_t)n_sbg * n_vb * sizeof(float));
+        ENSURE(ctx->b_spectrum, (size_t)n_rg * n_vb * sizeof(double));
+        ENSURE(ctx->b_cutflag, (size_t)n_rg);
+        if ((rc = upload(ctx, ctx->b_varray, t->varray, (size_t)n_vb * sizeof(double)))) return rc;
     }
     // output staging (device): 9 float fields + PHIDP
     enum { O_ZH, O_ZV, O_ZDR, O_KDP, O_DHV, O_PHIDP, O_RHOHV, O_ATTH, O_ATTV, O_MASK, O_LAT, O_LON,
@@ -713,6 +768,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         pa.res = (double *)ctx->b_res.p;
         pa.vn = doppler ? (double *)ctx->b_vn.p : nullptr;
         pa.n_sbg = n_sbg;
+        pa.par_w = dop3 ? (double *)ctx->b_par.p : nullptr;
         pa.clk = nullptr;
         if (ctx->keep_debug) {
             ENSURE(ctx->b_clk, 2048 * 4 * sizeof(long long));
@@ -798,7 +854,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             ctx->err = "cpol_run_sweep: simulate_doppler needs var_u / var_v / var_w";
             return CPOL_ERR_ARG;
         }
-        for (int j = 0; j < n_hyd; ++j) {
+        for (int j = 0; j < n_hyd && !dop3; ++j) {
             const cpol_hydro_desc &d = ctx->hs.h[j].d;
             fa.vsrc[j] = (dop2 || d.psd_family == CPOL_PSD_MELTING) ? 1
                        : (d.psd_family == CPOL_PSD_ICE_FIELD || d.numeric_intv) ? 2 : 0;
@@ -809,18 +865,63 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                                    (IceFirst *)ctx->b_icefirst.p, ng);
         }
     }
+    if (dop3) fa.RVEL = nullptr;            // RVEL comes from the spectrum below
     hipLaunchKernelGGL(k_final_gate, dim3(cdiv(n_rg, 256)), dim3(256), 0, st, fa);
+    if (dop3) {
+        // ---- 6b. Doppler spectrum (scheme 3) ----
+        SpecArgs sp{};
+        sp.vals = (const float *)ctx->b_vals.p;
+        sp.mask = (const signed char *)ctx->b_mask.p;
+        sp.elev = (const float *)ctx->b_elev.p;
+        sp.key = (const int *)ctx->b_key.p;
+        sp.par = (const double *)ctx->b_par.p;
+        sp.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
+        sp.geo = (const double *)ctx->b_geo.p;
+        sp.sub_h = (const int *)ctx->b_subh.p;
+        sp.varray = (const double *)ctx->b_varray.p;
+        sp.beam = (float *)ctx->b_beam.p;
+        sp.n_sbg = n_sbg; sp.n_gates = ng; sp.n_sub = n_sub; sp.n_h = n_h; sp.n_v = n_vb;
+        sp.var_u = p->var_u; sp.var_v = p->var_v; sp.var_w = p->var_w; sp.var_rho = p->var_rho;
+        sp.c_spec = (float)p->c_spectrum;
+        const size_t lds = (size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) * sizeof(float);
+        hipLaunchKernelGGL(k_spec_gate, dim3((unsigned)n_sbg), dim3(CPOL_SPEC_THREADS), lds, st, ctx->hs, sp);
+        if (p->with_attenuation) {
+            SpecAttenArgs sa2{};
+            sa2.key = (const int *)ctx->b_key.p;
+            sa2.res = (const double *)ctx->b_res.p;
+            sa2.beam = (float *)ctx->b_beam.p;
+            sa2.n_sbg = n_sbg; sa2.n_gates = ng; sa2.n_v = n_vb; sa2.n_hydro = n_hyd;
+            sa2.c_att = 4.343e-3 * 2 * p->wavelength;
+            sa2.res_km = p->radial_res / 1000.;
+            hipLaunchKernelGGL(k_spec_atten, dim3(n_rays * n_sub), dim3(64), (size_t)ng * sizeof(double), st, sa2);
+        }
+        SpecFinalArgs sf{};
+        sf.beam = (const float *)ctx->b_beam.p;
+        sf.sub_w = (const double *)ctx->b_subw.p;
+        sf.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
+        sf.varray = (const double *)ctx->b_varray.p;
+        sf.nyquist = t->nyquist ? (const double *)ctx->b_nyq.p : nullptr;
+        sf.spectrum = (double *)ctx->b_spectrum.p;
+        sf.RVEL = (double *)ctx->b_rvel.p;
+        sf.n_rays = n_rays; sf.n_gates = ng; sf.n_sub = n_sub; sf.n_v = n_vb;
+        hipLaunchKernelGGL(k_spec_final, dim3((unsigned)n_rg), dim3(64), 0, st, sf);
+        fa.RVEL = (double *)ctx->b_rvel.p;   // for the sensitivity cut in k_final_ray
+    }
 
     ScanRayArgs ra{};
     ra.ZH = fa.ZH; ra.ZV = fa.ZV; ra.ZDR = fa.ZDR; ra.KDP = fa.KDP; ra.DELTA_HV = fa.DELTA_HV;
     ra.PHIDP = (float *)T[O_PHIDP]; ra.RHOHV = fa.RHOHV; ra.ATT_H = fa.ATT_H;
     ra.ATT_V = fa.ATT_V; ra.RVEL = fa.RVEL;
+    ra.cutflag = (dop3 && cut) ? (unsigned char *)ctx->b_cutflag.p : nullptr;
     ra.FH = fa.FH; ra.FV = fa.FV;
     ra.sens_thr = cut ? (const double *)ctx->b_sens.p : nullptr;
     ra.n_rays = n_rays; ra.n_gates = ng; ra.with_attenuation = p->with_attenuation;
     ra.radial_res = (float)p->radial_res;
     ra.res_km = (float)(p->radial_res / 1000.);
     hipLaunchKernelGGL(k_final_ray, dim3(n_rays), dim3(64), (size_t)3 * ng * sizeof(float), st, ra);
+    if (dop3 && cut)
+        hipLaunchKernelGGL(k_spec_cut, dim3(cdiv(n_rg * n_vb, 256)), dim3(256), 0, st,
+                           (const unsigned char *)ctx->b_cutflag.p, (double *)ctx->b_spectrum.p, n_rg, n_vb);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
     HIPCHK(hipGetLastError());
 
@@ -834,6 +935,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (doppler && (rc = copy_out(ctx, out->RVEL, ctx->b_rvel.p, dbb, dev))) return rc;
     if (want_model && (rc = copy_out(ctx, out->model_vars, ctx->b_model.p, dbb * n_vars, dev))) return rc;
     if (out->sz_total && (rc = copy_out(ctx, out->sz_total, ctx->b_sztotal.p, fb * CPOL_N_SZ, dev))) return rc;
+    if (dop3 && (rc = copy_out(ctx, out->DSPECTRUM, ctx->b_spectrum.p, dbb * n_vb, dev))) return rc;
 
     ctx->last_n_sbg = n_sbg; ctx->last_n_rg = n_rg; ctx->last_n_rays = n_rays;
     ctx->last_n_gates = ng; ctx->last_n_sub = n_sub; ctx->last_n_v = n_v;

@@ -35,6 +35,12 @@ struct HydroDev {
     const double *dnu;     // [n_d]
     const double *aux;     // family specific
     const double *rcsw;    // [n_e][n_t][n_d][2] Doppler scheme 2 weights or NULL
+    // Doppler scheme 3 (spectrum): float32 radar cross sections per table bin and the
+    // float32 diameter grid of get_doppler_spectrum with its float32 powers
+    const float *rcs32;    // [n_e][n_t][n_d] or NULL
+    const float *dgrid;    // [3][n_d]: D, D^mu, D^nu (float32) or NULL
+    float step32;          // D[1] - D[0] in float32
+    int pad_spec;
     int key_base;          // first bucket id of this hydrometeor
     int n_par;             // per-item parameter count
 };

@@ -306,6 +306,7 @@ struct ScanRayArgs {
     float *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *PHIDP, *RHOHV, *ATT_H, *ATT_V;
     const float *FH, *FV;       // attenuation factors from k_final_gate
     double *RVEL;
+    unsigned char *cutflag;     // [n_rays*n_gates] 1 where the sensitivity cut applied, or NULL
     const double *sens_thr;     // [n_gates] or NULL
     int n_rays, n_gates, with_attenuation;
     float radial_res;           // float32 cast of the python scalar
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(64) void k_final_ray(ScanRayArgs a)
             float dbz = 10.0f * (float)log10((double)zh);
             cut = (double)dbz < a.sens_thr[g];
         }
+        if (a.cutflag) a.cutflag[i] = cut ? 1 : 0;
         if (cut) {
             const float qnan = __builtin_nanf("");
             a.ZH[i] = qnan; a.ZV[i] = qnan; a.KDP[i] = qnan; a.RHOHV[i] = qnan;

@@ -420,6 +420,8 @@ struct PsdArgs {
     const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg]
     double *res;                // [n_hydro][n_sbg][12]   sum_k sz[k][c] N[k] * dD
     double *vn;                 // [n_hydro][n_sbg][2]    integral of V N dD, of N dD (or NULL)
+    double *par_w;              // = par, writable: 1-moment ice stores its normalised N0 in
+                                // slot 3 for the Doppler-spectrum kernel (or NULL)
     long n_sbg;
     long long *clk;             // clock probe [2048][4]: s_memtime / s_memrealtime at the start and
                                 // end of every workgroup (effective shader clock), or NULL
@@ -942,6 +944,7 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
             for (int w = 0; w < CPOL_PSD_WAVES; ++w) m += s_part[w][NV - 3][l];
             const double qm_est = m * h.aux[3 * n_d];
             scale = Pl[n] / qm_est * Pl[2 * n];             // N0 / QM_est * QM (:1339)
+            if (a.par_w && c == 0) a.par_w[((long)j * CPOL_MAX_PAR + 3) * n + sb] = scale;
             sum = (scale * sum) * d.dD;
             if (a.vn && c < 2) {
                 double t = 0.0;

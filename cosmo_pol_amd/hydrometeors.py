@@ -197,6 +197,24 @@ def _uniform_grid_aux(d, D, nu, n_d, pre):
     return np.concatenate([[h], dlt, quads]).astype(np.float64)
 
 
+def spectrum_tables(h, scheme, lut):
+    """Doppler scheme 3 (get_doppler_spectrum, doppler_scatter.py:672-695): float32 radar
+    cross sections rcs = 2 pi (Z11 - Z12 - Z21 + Z22) of every table slice and bin, and
+    the float32 grid D = np.linspace(d_min, d_max, n_d) with D**mu, D**nu evaluated as
+    NumPy does on float32 arrays.  Returns (rcs32 [n_e, n_t, n_d], dgrid [3, n_d])."""
+    if h in ('mS', 'mG'):
+        raise NotImplementedError('Doppler scheme 3 covers the power-law species only')
+    c = _consts(h, scheme)
+    t = np.asarray(lut.value_table, dtype=np.float64)
+    rcs = (2 * np.pi * (t[..., 0] - t[..., 1] - t[..., 2] + t[..., 3])).astype(np.float32)
+    d_ax = np.asarray(lut.axes[lut.axes_names['d']])
+    D = np.zeros(t.shape[2], dtype='float32')
+    D[:] = np.linspace(d_ax[0], d_ax[-1], t.shape[2])
+    with np.errstate(divide='ignore'):
+        dgrid = np.stack([D, (D ** c['mu']).astype(np.float32), (D ** c['nu']).astype(np.float32)])
+    return np.ascontiguousarray(rcs), np.ascontiguousarray(dgrid, dtype=np.float32)
+
+
 ICE_POWER = 0.6357          # exponent of the second term of PHI_23_I (constants_1mom.py)
 
 

@@ -26,7 +26,7 @@ from . import quadrature
 from .lut import load_all_lut
 
 RADAR_FIELDS = ['ZH', 'ZDR', 'ZV', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V']
-DOPPLER_FIELDS = ['RVEL']
+DOPPLER_FIELDS = ['RVEL', 'DSPECTRUM']
 _DB_FIELDS = ('ZDR', 'ZV', 'ZH')
 
 
@@ -152,7 +152,8 @@ class RadarOperator(object):
                       or checked['microphysics']['with_melting'] != old['microphysics']['with_melting']
                       or checked['microphysics']['with_ice_crystals'] != old['microphysics']['with_ice_crystals']
                       or checked['microphysics']['scheme'] != old['microphysics']['scheme']
-                      or (checked['doppler']['scheme'] == 2) != (old['doppler']['scheme'] == 2))
+                      or (checked['doppler']['scheme'] == 2) != (old['doppler']['scheme'] == 2)
+                      or (checked['doppler']['scheme'] == 3) != (old['doppler']['scheme'] == 3))
         self.__config = checked
         self.constants = K.DerivedConstants(checked)
         self._cache = {}                       # per-configuration host-side tables
@@ -193,8 +194,14 @@ class RadarOperator(object):
         scheme = conf['microphysics']['scheme']
         self.current_microphys_scheme = scheme
         hl = hyd.hydrometeor_list(conf)
+        spectrum = conf['doppler']['scheme'] == 3
+        if spectrum and conf['microphysics']['with_melting']:
+            raise NotImplementedError(
+                'Doppler scheme 3 (Doppler spectrum) with the melting scheme: the reference inverts '
+                'the fall speed of the melting species through an interpolator that is built '
+                'once from the first gate it meets (hydrometeors.py:480-500); not reproduced')
         key = (scheme, conf['radar']['frequency'], conf['microphysics']['scattering'], tuple(hl),
-               conf['doppler']['scheme'] == 2)
+               conf['doppler']['scheme'] == 2, spectrum)
         cache = self.__dict__.setdefault('_lut_cache', {})
         if key in cache:
             # tables of a configuration seen before (e.g. the Ku / Ka / ground switches of
@@ -203,10 +210,12 @@ class RadarOperator(object):
             self.lut_sz = lut
             self._drop_lanes()
             for slot, h in enumerate(hl):
-                d, table, pre, dnu, aux, dw = built[h]
+                d, table, pre, dnu, aux, dw, st = built[h]
                 self._ctx.stage_hydro(slot, d, table, pre, dnu, aux)
                 if dw is not None:
                     self._ctx.stage_doppler_weights(slot, dw)
+                if st is not None:
+                    self._ctx.stage_spectrum_tables(slot, *st)
             self._ctx.set_num_hydro(len(hl))
             self._staged_hydro = hl
             if self._model_staged and self._staged_vars != hyd.variable_list(conf):
@@ -233,7 +242,11 @@ class RadarOperator(object):
             if conf['doppler']['scheme'] == 2:
                 dw = hyd.doppler_weights(h, scheme, lut[h])
                 self._ctx.stage_doppler_weights(slot, dw)
-            built[h] = (d, table, pre, dnu, aux, dw)
+            st = None
+            if spectrum:
+                st = hyd.spectrum_tables(h, scheme, lut[h])
+                self._ctx.stage_spectrum_tables(slot, *st)
+            built[h] = (d, table, pre, dnu, aux, dw, st)
         if len(cache) < 4:                       # a few table sets at most (host memory)
             cache[key] = (lut, built)
         self._ctx.set_num_hydro(len(hl))
@@ -376,14 +389,24 @@ class RadarOperator(object):
         p.outputs_on_device = int(device_outputs is not None)
         # Doppler schemes 1 (analytic mean fall speed) and 2 (rcs-weighted); none for GPM
         # (doppler_scatter.py:83-87); scheme 3 (full spectrum) is out of scope
-        doppler = (conf['doppler']['scheme'] in (1, 2) and conf['radar'].get('type') != 'GPM'
+        doppler = (conf['doppler']['scheme'] in (1, 2, 3) and conf['radar'].get('type') != 'GPM'
                    and mode != N.GEOM_SPACEBORNE)
-        if conf['doppler']['scheme'] == 3 and not getattr(self, '_warned_doppler', False):
-            print('Doppler scheme 3 (Doppler spectrum) is not implemented: RVEL is not simulated')
-            self._warned_doppler = True
+        spectrum = doppler and conf['doppler']['scheme'] == 3
+        if spectrum and (conf['doppler']['turbulence_correction'] or conf['doppler']['motion_correction']):
+            # both corrections are dead upstream: spectral_width_turb / _motion read a module-level
+            # CONFIG that is still None (doppler_scatter.py:24, 737, 771), EDR is never loaded
+            raise NotImplementedError('doppler/turbulence_correction and doppler/motion_correction '
+                                      'raise in the reference as well; not reproduced')
         p.simulate_doppler = int(conf['doppler']['scheme']) if doppler else 0
         vi = {v: i for i, v in enumerate(self._staged_vars)}
         p.var_u, p.var_v, p.var_w = vi['U'], vi['V'], vi['W']
+        p.var_rho = vi.get('RHO', -1)
+        varray = None
+        if spectrum:
+            varray = np.ascontiguousarray(self.constants.VARRAY, dtype=np.float64)
+            p.n_vbins = len(varray)
+            p.c_spectrum = float(self.constants.WAVELENGTH ** 4
+                                 / (np.pi ** 5 * conf['radar']['K_squared'] ** 2))
         p.geometry_mode = mode
         if site is None:
             re, ke = geo.earth_radius_for_refraction(coords)
@@ -426,6 +449,9 @@ class RadarOperator(object):
             nyq = np.ascontiguousarray(conf['radar']['nyquist_velocity'](el, az), dtype=np.float64)
             keep.append(nyq)
         t.nyquist = nyq.ctypes.data if nyq is not None else None
+        if varray is not None:
+            keep.append(varray)
+            t.varray = varray.ctypes.data
         if sub.sub_smooth is not None:        # integration scheme 'ml': per-gate weights
             t.sub_smooth = sub.sub_smooth.ctypes.data
             t.ml_filter = sub.ml_filter.ctypes.data
@@ -443,6 +469,8 @@ class RadarOperator(object):
                 res[k] = np.empty(shape, dtype=np.float32)
             if doppler:
                 res['RVEL'] = np.empty(shape, dtype=np.float64)
+            if spectrum:
+                res['DSPECTRUM'] = np.empty(shape + (len(varray),), dtype=np.float64)
             res['mask'] = np.empty(shape, dtype=np.float64)
             res['lats'] = np.empty(shape, dtype=np.float64)
             res['lons'] = np.empty(shape, dtype=np.float64)
@@ -508,7 +536,7 @@ class RadarOperator(object):
         fields = ([(k, np.float32) for k in RADAR_FIELDS] + [('dist', np.float32),
                   ('heights', np.float32), ('mask', np.float64), ('lats', np.float64),
                   ('lons', np.float64)])
-        if self.__config['doppler']['scheme'] in (1, 2):
+        if self.__config['doppler']['scheme'] in (1, 2, 3):     # (the spectrum itself is not gathered)
             fields.append(('RVEL', np.float64))
         n_gates = len(self.constants.RANGE_RADAR)
         dev = torch.device('cuda', self.device)

@@ -121,7 +121,8 @@ typedef struct {
     int32_t integrate_model;    /* also return antenna-averaged model variables */
     int32_t apply_sensitivity;  /* 1: censor with tables->sens_thr (cut_at_sensitivity) */
     int32_t outputs_on_device;  /* output pointers are device pointers          */
-    int32_t simulate_doppler;   /* 0 off, 1 / 2 = Doppler scheme of the reference (RVEL) */
+    int32_t simulate_doppler;   /* 0 off, 1 / 2 / 3 = Doppler scheme of the reference (RVEL;
+                                   3 = full Doppler spectrum, doppler_scatter.py:335-391) */
     int32_t geometry_mode;      /* CPOL_GEOM_*                                   */
     double  radar_lat, radar_lon, radar_alt;
     double  range0, range_step; /* RANGE_RADAR = range0 + k*range_step          */
@@ -132,7 +133,11 @@ typedef struct {
     double  radial_res;         /* m                                            */
     double  c_zh;               /* wavelength^4 / (pi^5 K^2)                     */
     int32_t var_u, var_v, var_w; /* staged-variable indices of the wind (RVEL)    */
+    int32_t var_rho;            /* ... of the air density (Doppler scheme 3) or -1 */
+    /* Doppler scheme 3 */
+    int32_t n_vbins;            /* len(VARRAY) = FFT_length + 1 (global_constants.py:171) */
     int32_t pad2_;
+    double  c_spectrum;         /* wavelength^4 / (pi^5 K^2 K^2)  (doppler_scatter.py:709) */
 } cpol_sweep_params;
 
 /* ray-path models */
@@ -167,6 +172,8 @@ typedef struct {
                                    reused (repeated scans of the same geometry)      */
     /* integration scheme 'ml' (interpolation.py:168-193, 423-436; per-gate weights as in
        doppler_scatter.py:124-129, 186-189, 259-264): NULL / 0 for scalar weights */
+    const double *varray;       /* [n_vbins] velocity bins of the Doppler spectrum
+                                   (Doppler scheme 3) or NULL                          */
     const int32_t *sub_smooth;  /* [n_sub] 1: the weight of this sub-beam is sub_w x the
                                    Gaussian-smoothed mask of the first / last melting-layer
                                    gate of the sub-beam; 0: sub_w at every gate          */
@@ -184,6 +191,7 @@ typedef struct {
     float  *dist, *heights;
     double *model_vars;         /* [n_vars][n_rays*n_gates] (integrate_model)   */
     float  *sz_total;           /* [n_rays*n_gates][12]  (debug / parity)       */
+    double *DSPECTRUM;          /* [n_rays*n_gates][n_vbins]  (Doppler scheme 3) */
 } cpol_outputs;
 
 typedef struct {
@@ -229,6 +237,12 @@ int  cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro);
  * weights [n_e][n_t][n_d][2] = (w rcs V, w rcs) float64.  Needed only when
  * cpol_sweep_params.simulate_doppler == 2. */
 int  cpol_stage_doppler_weights(cpol_ctx *ctx, int slot, const double *weights);
+
+/* Doppler scheme 3: per table slice and diameter bin the float32 horizontal radar cross
+ * section 2 pi (Z11 - Z12 - Z21 + Z22) (doppler_scatter.py:686-695), and the float32
+ * diameter grid np.linspace(d_min, d_max, n_d) of get_doppler_spectrum with D^mu, D^nu
+ * evaluated in float32 (:676-681): dgrid = [3][n_d].  Power-law species only. */
+int  cpol_stage_spectrum_tables(cpol_ctx *ctx, int slot, const float *rcs32, const float *dgrid);
 
 /* gate kernel on explicit points: coords [n][2] (rotated lat, lon) float32,
  * heights [n] float32 -> out [n_vars][n] float32 with the reference's

@@ -182,3 +182,41 @@ def test_rvel_aliasing_vs_oracle(tmp_path):
         folded += int(np.nansum(np.abs(plain) > nyq))
     assert folded > 10, 'aliasing was not exercised'
     op.close()
+
+
+def test_doppler_spectrum_one_moment_ice_subbeams_vs_oracle(tmp_path):
+    """Doppler scheme 3 beyond the two reference goldens: 1-moment ice (its normalised N0
+    comes from the PSD kernel), three sub-beams, attenuation on, aliasing on."""
+    from cosmo_pol_amd import RadarOperator
+    name = 'c3_melt_ice'
+    over = _cases.gen_golden.radial_case_inputs(name)[0]
+    over = {k: dict(v) for k, v in over.items()}
+    over['microphysics'].update(with_melting=0, with_ice_crystals=1)
+    over['doppler'] = {'scheme': 3}
+    over['integration'] = {'nh_GH': 3, 'nv_GH': 1, 'weight_threshold': 1.}
+    over['radar'].update(FFT_length=32, range=30000, radial_resolution=500)
+    fn = tmp_path / 'nyq.txt'
+    fn.write_text('elevation,azimuth,nyquist\n5.0,0,1.5\n')
+    over['radar']['nyquist_velocity'] = str(fn)
+    _, _, _, ocube, _, cube = _cases.radial_case(name)
+    conf = ocfg.make_config({k: {kk: vv for kk, vv in v.items() if kk != 'nyquist_velocity'}
+                             for k, v in over.items()})
+    hl = ocfg.hydrometeor_list(conf)
+    luts = {h: _cases.synthetic_lut(h, 5.6, '1mom') for h in hl}
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar')
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    azs, els = np.array([120.0, 300.0]), np.array([5.0, 9.0])
+    res = op.simulate_rays(azs, els, apply_sensitivity=False)
+    olut = {h: _cases.as_oracle_lut(l) for h, l in luts.items()}
+    n_ice = 0
+    for r in range(2):
+        subs = beam.interpolate_radial(ocube, conf, azs[r], els[r])
+        n_ice += int(sum(np.nansum(np.asarray(s.values['QI_v']) > 0) for s in subs))
+        o = scatter.radar_observables(subs, olut, conf, nyquist=1.5)
+        osp = o.values['DSPECTRUM']
+        atol = 1e-6 * np.nanmax(osp)
+        _cases.assert_close_nan(res['DSPECTRUM'][r], osp, rtol=2e-5, atol=atol, name='DSPECTRUM')
+        _cases.assert_close_nan(res['RVEL'][r], o.values['RVEL'], rtol=1e-5, atol=2e-4, name='RVEL')
+        assert np.nanmax(np.abs(res['RVEL'][r])) <= 1.5 + 1e-9
+    assert n_ice > 20, 'no ice crystals in the test rays'
+    op.close()

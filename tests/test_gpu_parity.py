@@ -161,6 +161,15 @@ def test_radial_vs_reference_golden_and_oracle(golden, name):
     _cases.assert_close_nan(res['RVEL'][0], oobs.values['RVEL'], rtol=RTOL, atol=2e-4, name='oracle:RVEL')
     _cases.assert_close_nan(res['RVEL'][0], g['obs_RVEL'], rtol=RTOL, atol=2e-4, name='golden:RVEL')
 
+    # ---- Doppler spectrum (scheme 3): float32 per-bin reflectivities, float64 sums ----
+    if 'DSPECTRUM' in oobs.values:
+        sp, osp = res['DSPECTRUM'][0], oobs.values['DSPECTRUM']
+        assert sp.shape == osp.shape == g['obs_DSPECTRUM'].shape
+        assert np.nansum(osp > 0) > 50, 'the spectrum was not exercised'
+        atol = 1e-6 * np.nanmax(osp)
+        _cases.assert_close_nan(sp, osp, rtol=2e-5, atol=atol, name='oracle:DSPECTRUM')
+        _cases.assert_close_nan(sp, g['obs_DSPECTRUM'], rtol=2e-5, atol=atol, name='golden:DSPECTRUM')
+
     # ---- antenna-averaged model variables (integrate_radials) ----
     integ = beam.integrate_subbeams(subs)
     for i, nm in enumerate(names):
