@@ -53,6 +53,7 @@ struct cpol_ctx {
     DevBuf d_H, d_V;
     // hydrometeors
     HydroSet hs{};
+    SpecSet ss{};
     DevBuf d_table[CPOL_MAX_HYDRO], d_pre[CPOL_MAX_HYDRO], d_dnu[CPOL_MAX_HYDRO],
         d_aux[CPOL_MAX_HYDRO], d_rcsw[CPOL_MAX_HYDRO], d_rcs32[CPOL_MAX_HYDRO], d_dgrid[CPOL_MAX_HYDRO];
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
@@ -216,6 +217,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->model_staged = parent->model_staged;
     c->model = parent->model;
     c->hs = parent->hs;
+    c->ss = parent->ss;
     for (int j = 0; j < CPOL_MAX_HYDRO; ++j) c->hydro_staged[j] = parent->hydro_staged[j];
     parent->n_children += 1;
     *out = c;
@@ -359,9 +361,7 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
     h.table = (const double *)ctx->d_table[slot].p;
     h.pre = h.dnu = h.aux = nullptr;
     h.rcsw = nullptr;
-    h.rcs32 = nullptr;
-    h.dgrid = nullptr;
-    h.step32 = 0.f;
+    ctx->ss.s[slot] = SpecDev{};
     if (pre) {
         if ((rc = upload(ctx, ctx->d_pre[slot], pre, db)) != CPOL_OK) return rc;
         h.pre = (const double *)ctx->d_pre[slot].p;
@@ -442,9 +442,9 @@ int cpol_stage_spectrum_tables(cpol_ctx *ctx, int slot, const float *rcs32, cons
     if ((rc = upload(ctx, ctx->d_rcs32[slot], rcs32, nr * sizeof(float))) != CPOL_OK) return rc;
     if ((rc = upload(ctx, ctx->d_dgrid[slot], dgrid, (size_t)3 * h.d.n_d * sizeof(float))) != CPOL_OK) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    h.rcs32 = (const float *)ctx->d_rcs32[slot].p;
-    h.dgrid = (const float *)ctx->d_dgrid[slot].p;
-    h.step32 = dgrid[1] - dgrid[0];
+    ctx->ss.s[slot].rcs32 = (const float *)ctx->d_rcs32[slot].p;
+    ctx->ss.s[slot].dgrid = (const float *)ctx->d_dgrid[slot].p;
+    ctx->ss.s[slot].step32 = dgrid[1] - dgrid[0];
     return CPOL_OK;
 }
 
@@ -594,7 +594,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             return CPOL_ERR_ARG;
         }
         for (int j = 0; j < n_hyd; ++j)
-            if (!ctx->hs.h[j].rcs32) { ctx->err = "cpol_run_sweep: Doppler scheme 3 needs cpol_stage_spectrum_tables"; return CPOL_ERR_ARG; }
+            if (!ctx->ss.s[j].rcs32) { ctx->err = "cpol_run_sweep: Doppler scheme 3 needs cpol_stage_spectrum_tables"; return CPOL_ERR_ARG; }
         if ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) * sizeof(float) > 64 * 1024) {
             ctx->err = "cpol_run_sweep: Doppler scheme 3: n_hydro x (n_d + n_vbins) exceeds the LDS of a workgroup";
             return CPOL_ERR_ARG;
@@ -783,10 +783,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                      : d.uniform_grid ? PSD_MODE_GAMMA_UNIFORM : PSD_MODE_GAMMA_EXP;
             need[mode] = true;
         }
-        // persistent grids sized to the RESIDENT workgroups (256 CUs x 3 for the recurrence
-        // flavour at 6 waves/SIMD, x 2 for the others, LDS-limited): with a larger grid the
-        // surplus workgroups only start when the first ones retire and the static stride
-        // assignment leaves a long tail (measured with the in-kernel clock probe)
+        // persistent grids: 1024 workgroups walk the unit list with a static stride (smaller
+        // grids, 512 / 768, measured equal or slower; CPOL_PSD_GRID* are experiment knobs)
         static const long grid_u = getenv("CPOL_PSD_GRID") ? atol(getenv("CPOL_PSD_GRID")) : 1024;
         static const long grid_g = getenv("CPOL_PSD_GRID_GENERIC") ? atol(getenv("CPOL_PSD_GRID_GENERIC")) : 1024;
         const dim3 grd_u((unsigned)(unit_cap < grid_u ? unit_cap : grid_u));
@@ -798,8 +796,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         }
         if (need[PSD_MODE_GAMMA_UNIFORM]) {
             const dim3 blk_u(CPOL_PSD_THREADS_U);
-            if (dop2) hipLaunchKernelGGL((k_psd_uniform<true>), grd_u, blk_u, 0, st, ctx->hs, pa);
-            else hipLaunchKernelGGL((k_psd_uniform<false>), grd_u, blk_u, 0, st, ctx->hs, pa);
+            // CPOL_PSD_LDS_PAD: experiment knob (extra dynamic LDS limits the workgroups per CU)
+            static const size_t lds_pad = getenv("CPOL_PSD_LDS_PAD") ? atol(getenv("CPOL_PSD_LDS_PAD")) : 0;
+            if (dop2) hipLaunchKernelGGL((k_psd_uniform<true>), grd_u, blk_u, lds_pad, st, ctx->hs, pa);
+            else hipLaunchKernelGGL((k_psd_uniform<false>), grd_u, blk_u, lds_pad, st, ctx->hs, pa);
         }
         CPOL_LAUNCH_PSD(PSD_MODE_GAMMA_EXP)
         CPOL_LAUNCH_PSD(PSD_MODE_ICE)
@@ -884,7 +884,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sp.var_u = p->var_u; sp.var_v = p->var_v; sp.var_w = p->var_w; sp.var_rho = p->var_rho;
         sp.c_spec = (float)p->c_spectrum;
         const size_t lds = (size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) * sizeof(float);
-        hipLaunchKernelGGL(k_spec_gate, dim3((unsigned)n_sbg), dim3(CPOL_SPEC_THREADS), lds, st, ctx->hs, sp);
+        hipLaunchKernelGGL(k_spec_gate, dim3((unsigned)n_sbg), dim3(CPOL_SPEC_THREADS), lds, st, ctx->hs, ctx->ss, sp);
         if (p->with_attenuation) {
             SpecAttenArgs sa2{};
             sa2.key = (const int *)ctx->b_key.p;

@@ -35,12 +35,6 @@ struct HydroDev {
     const double *dnu;     // [n_d]
     const double *aux;     // family specific
     const double *rcsw;    // [n_e][n_t][n_d][2] Doppler scheme 2 weights or NULL
-    // Doppler scheme 3 (spectrum): float32 radar cross sections per table bin and the
-    // float32 diameter grid of get_doppler_spectrum with its float32 powers
-    const float *rcs32;    // [n_e][n_t][n_d] or NULL
-    const float *dgrid;    // [3][n_d]: D, D^mu, D^nu (float32) or NULL
-    float step32;          // D[1] - D[0] in float32
-    int pad_spec;
     int key_base;          // first bucket id of this hydrometeor
     int n_par;             // per-item parameter count
 };
@@ -49,6 +43,21 @@ struct HydroSet {
     int n_hydro;
     int n_keys;
     HydroDev h[CPOL_MAX_HYDRO];
+};
+
+// Doppler scheme 3 (spectrum): float32 radar cross sections per table bin and the float32
+// diameter grid of get_doppler_spectrum with its float32 powers.  Kept OUT of HydroDev:
+// growing that struct (a by-value kernel argument of the PSD kernels) by 24 bytes per
+// slot made the dominant PSD kernel 25 % slower in isolation.
+struct SpecDev {
+    const float *rcs32;    // [n_e][n_t][n_d] or NULL
+    const float *dgrid;    // [3][n_d]: D, D^mu, D^nu (float32) or NULL
+    float step32;          // D[1] - D[0] in float32
+    int pad_spec;
+};
+
+struct SpecSet {
+    SpecDev s[CPOL_MAX_HYDRO];
 };
 
 struct WorkUnit {          // one wave of the PSD kernel

@@ -827,8 +827,8 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
         // it into 128-byte padded rows (two aligned 64-byte scalar loads per bin instead of
         // three unaligned ones, plus a third-order term) measured 142 us vs 139.7 us: neither
         // the number nor the alignment of the scalar requests bounds the kernel.  Also
-        // measured and rejected: 6 waves per SIMD via amdgpu_waves_per_eu (190-220 us);
-        // prefetching the next unit's slice into L2 with dummy vector loads (160 us).
+        // measured and rejected: prefetching the next unit's slice into L2 with dummy vector
+        // loads (160 us).
         const cdouble_p pq = as_const(h.aux + 1 + n_d);          // [k][4] = (pre, q1, q2, .)
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
@@ -998,9 +998,11 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
     psd_body<MODE, DOP2>(hs, a);
 }
 
-// The recurrence flavour (the dominant kernel of a sweep).  Occupancy: 81 VGPRs -> 5 waves per
-// SIMD -> two resident 8-wave workgroups per CU; forcing 6 waves (three workgroups) was
-// measured 1.4-1.6x SLOWER (the compiler reaches 76 VGPRs only by re-loading operands).
+// The recurrence flavour (the dominant kernel of a sweep).  The compiler's own allocation
+// is 80 VGPRs, i.e. up to three resident 8-wave workgroups per CU (LDS 3 x 48 KB): 140 us on
+// the bench sweep.  Every attempt to steer it measured slower in isolation:
+// amdgpu_waves_per_eu(6,6) 190-220 us, amdgpu_waves_per_eu(4,5) 178 us, 8 KB of dynamic LDS
+// (two workgroups per CU) 175 us.  Left alone on purpose.
 template <bool DOP2>
 __global__ __launch_bounds__(CPOL_PSD_THREADS_U) void k_psd_uniform(HydroSet hs, PsdArgs a)
 {

@@ -43,7 +43,7 @@ __device__ __forceinline__ float clamp_pair(float D, float d_min, float d_max)
 }
 
 // one workgroup per sub-beam gate
-__global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, SpecArgs a)
+__global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, SpecSet ss, SpecArgs a)
 {
     extern __shared__ float lds_spec[];
     const long sbg = blockIdx.x;
@@ -69,7 +69,8 @@ __global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, Sp
         const HydroDev &h = hs.h[j];
         const cpol_hydro_desc &d = h.d;
         const int key = a.key[(long)j * n + sbg];
-        const float *rcs = h.rcs32 + (long)(key - h.key_base) * d.n_d;
+        const SpecDev &sd = ss.s[j];
+        const float *rcs = sd.rcs32 + (long)(key - h.key_base) * d.n_d;
         const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + sbg;
         const double lam = P[0];
         const bool fixed_n0 = d.rule == CPOL_RULE_RAIN_1MOM || d.rule == CPOL_RULE_GRAUPEL_1MOM;
@@ -77,10 +78,10 @@ __global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, Sp
         for (int k = tid; k < d.n_d; k += CPOL_SPEC_THREADS) {
             double nk;
             if (d.psd_family == CPOL_PSD_ICE_FIELD) {
-                const double x = lam * (double)h.dgrid[k] / 1000.0;
+                const double x = lam * (double)sd.dgrid[k] / 1000.0;
                 nk = N0 * phi23(x);
             } else {
-                nk = (N0 * (double)h.dgrid[d.n_d + k]) * exp(-(lam * (double)h.dgrid[2 * d.n_d + k]));
+                nk = (N0 * (double)sd.dgrid[d.n_d + k]) * exp(-(lam * (double)sd.dgrid[2 * d.n_d + k]));
             }
             prodL[(long)p * n_d + k] = (float)nk * rcs[k];
         }
@@ -106,8 +107,8 @@ __global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, Sp
             float D = ok ? (float)pow(wh / d.alpha, 1.0 / d.beta) : __builtin_nanf("");
             if (ok)
                 for (int q = p; q < n_p; ++q) {           // clamps of this and the later species
-                    const HydroDev &hq = hs.h[present[q]];
-                    D = clamp_pair(D, hq.dgrid[0], hq.dgrid[hq.d.n_d - 1]);
+                    const SpecDev &sq = ss.s[present[q]];
+                    D = clamp_pair(D, sq.dgrid[0], sq.dgrid[hs.h[present[q]].d.n_d - 1]);
                 }
             DL[(long)p * a.n_v + v] = D;
         }
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, Sp
         bool keep = false;
         float refl = 0.0f;
         for (int p = 0; p < n_p; ++p) {
-            const HydroDev &h = hs.h[present[p]];
+            const SpecDev &h = ss.s[present[p]];
             const float x0 = DL[(long)p * a.n_v + v], x1 = DL[(long)p * a.n_v + v + 1];
             const float Da = fminf(x0, x1), Db = fmaxf(x0, x1);
             if (Db - Da != 0.0f) keep = true;
