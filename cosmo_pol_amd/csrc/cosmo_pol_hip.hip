@@ -641,7 +641,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     const bool want_model = p->integrate_model && out->model_vars;
     if (want_model) ENSURE(ctx->b_model, (size_t)n_vars * n_rg * sizeof(double));
 
-    HIPCHK(hipMemsetAsync(ctx->b_count.p, 0, (size_t)(n_keys + 1) * sizeof(int), st));
+    // bucket counters + error flag start at zero: cleared by k_trajectory (one launch less),
+    // or by a memset when the ray paths come from the host
+    if (mode == CPOL_GEOM_HOST_PATHS)
+        HIPCHK(hipMemsetAsync(ctx->b_count.p, 0, (size_t)(n_keys + 1) * sizeof(int), st));
     int *const d_errflag = (int *)ctx->b_count.p + n_keys;
 
     const bool tm = ctx->timing;
@@ -667,6 +670,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ta.n_rays = n_rays; ta.n_v = n_v; ta.n_gates = ng; ta.mode = mode;
         ta.range0 = p->range0; ta.range_step = p->range_step;
         ta.ke = p->ke; ta.re = p->re; ta.alt = p->radar_alt;
+        ta.zero_buf = (int *)ctx->b_count.p;
+        ta.zero_n = n_keys + 1;
         hipLaunchKernelGGL(k_trajectory, dim3(cdiv(ng, 256), n_rays * n_v), dim3(256), 0, st, ta);
     }
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_TRAJ], st));

@@ -41,6 +41,8 @@ struct TrajArgs {
     float *traj_out;
     int n_rays, n_v, n_gates, mode;
     double range0, range_step, ke, re, alt;
+    int *zero_buf;              // the sweep's bucket counters + error flag, cleared here
+    int zero_n;                 // (saves the two fill kernels of a hipMemsetAsync per sweep)
 };
 
 // height of candidate gate k of a downward-looking (spaceborne) ray
@@ -55,6 +57,12 @@ __global__ void k_trajectory(TrajArgs a)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     int rv = blockIdx.y;                       // ray * n_v + vnode
+    if (a.zero_buf) {
+        const long total = (long)gridDim.x * gridDim.y * blockDim.x;
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+             i < a.zero_n; i += total)
+            a.zero_buf[i] = 0;
+    }
     if (g >= a.n_gates) return;
     const int ray = rv / a.n_v;
     const double el = a.ray_traj[rv * 4 + 0];
