@@ -126,6 +126,122 @@ __device__ __forceinline__ int rank_position(const RankShared &sh, int ticket)
     return sh.base[slot] + sh.cnt[slot][threadIdx.x >> 6] + rank;
 }
 
+// ---------------------------------------------------------------- per-bin math of the melting flavour
+// The melting species integrate over a per-ITEM diameter grid, so nothing can be tabulated
+// on the host: every (item, bin) needs two cube roots, a square root, an exponential, a
+// fourth root (snow) or two powers (graupel) and a division.  The OCML versions cost 32 /
+// 22 / 42 / 44 / 215 / 12 VALU instructions; the versions below reach 1e-15 relative
+// accuracy (tests/test_gpu_math.py) in 15-32, from float32 hardware seeds refined by
+// Newton steps in float64 and short polynomials.  Inputs are positive and normal here.
+__device__ __forceinline__ double cp_exp(double x)
+{
+    // x = n ln2 + r, |r| <= ln2/2; Taylor to r^12/12! (next term < 2e-16)
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(n, -0.6931471803691238, x);
+    r = fma(n, -1.9082149292705877e-10, r);
+    double p = 1.0 / 479001600.0;
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+__device__ __forceinline__ double cp_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * fma(-x, r, 2.0);
+    r = r * fma(-x, r, 2.0);
+    return r;
+}
+
+__device__ __forceinline__ double cp_log(double x)
+{
+    // x = m 2^e, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m-1)/(m+1), |s| < 0.1716
+    int e;
+    double m = frexp(x, &e);
+    if (m < 0.7071067811865476) { m *= 2.0; e -= 1; }
+    const double s = (m - 1.0) * cp_rcp(m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = fma(p, z, 1.0);
+    const double en = (double)e;
+    return fma(en, 0.6931471803691238, fma(en, 1.9082149292705877e-10, 2.0 * s * p));
+}
+
+// x^(-1/6) -> cbrt(x) = x y^4 and sqrt(cbrt(x)) = x y^5 from ONE Newton sequence
+__device__ __forceinline__ void cp_cbrt_and_sixth(double x, double &cb, double &sx)
+{
+    double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * (-1.0f / 6.0f));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y, y4 = y2 * y2;
+        y = y * fma(-x * y2, y4, 7.0) * (1.0 / 6.0);       // y (7 - x y^6) / 6
+    }
+    const double y2 = y * y, y4 = y2 * y2;
+    cb = x * y4;
+    sx = cb * y;
+}
+
+__device__ __forceinline__ double cp_cbrt(double x)
+{
+    double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * (-1.0f / 3.0f));
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+        y = y * fma(-x * y, y * y, 4.0) * (1.0 / 3.0);      // y (4 - x y^3) / 3
+    return x * (y * y);
+}
+
+__device__ __forceinline__ double cp_fourth_root(double x)
+{
+    double y = (double)__builtin_amdgcn_rsqf(__builtin_amdgcn_sqrtf((float)x));   // x^(-1/4)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y;
+        y = y * fma(-x * y2, y2, 5.0) * 0.25;               // y (5 - x y^4) / 4
+    }
+    return x * (y * y * y);
+}
+
+// test hook (cpol_debug_math): evaluates one of the functions above on the device
+__global__ void k_debug_math(int op, const double *__restrict__ x, double *__restrict__ y, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a, b;
+    switch (op) {
+    case 0: y[i] = cp_exp(x[i]); break;
+    case 1: y[i] = cp_log(x[i]); break;
+    case 2: y[i] = cp_cbrt(x[i]); break;
+    case 3: cp_cbrt_and_sixth(x[i], a, b); y[i] = a; break;
+    case 4: cp_cbrt_and_sixth(x[i], a, b); y[i] = b; break;
+    case 5: y[i] = cp_fourth_root(x[i]); break;
+    case 6: y[i] = cp_rcp(x[i]); break;
+    default: y[i] = x[i];
+    }
+}
+
+// x^y for x > 0 from the short log / exp above: ~55 VALU instructions instead of the 215 of
+// the OCML pow, relative error < 1e-14 for |y log x| < 10 (PSD slopes, fall-speed moments)
+__device__ __forceinline__ double cp_pow(double x, double y) { return cp_exp(y * cp_log(x)); }
+
 // float32 power via float64 (rounds to the correctly rounded float32 result in
 // all but ~1e-8 of the cases; numpy's float32 power calls libm powf)
 __device__ __forceinline__ float pow10_f32(float x) { return (float)pow(10.0, (double)x); }
@@ -214,7 +330,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             switch (d.rule) {
             case CPOL_RULE_RAIN_1MOM:
             case CPOL_RULE_GRAUPEL_1MOM:
-                lamf = pow(d.lambda_factor / q, d.lam_exponent);
+                lamf = cp_pow(d.lambda_factor / q, d.lam_exponent);
                 n0v = d.n0_fixed;
                 P[0] = lamf;
                 P[n] = 1.0;                                   // N0 folded into pre[]
@@ -223,7 +339,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 // hydrometeors.py:896-899: float32 chain, then float64 from lambda_factor on
                 float n0 = 13.5f * (565000.0f * exp_f32(-0.107f * (T - 273.15f))) / 1000.0f;
                 float an0 = (float)d.a * n0;
-                lamf = pow((double)an0 * d.lambda_factor / q, d.lam_exponent);
+                lamf = cp_pow((double)an0 * d.lambda_factor / q, d.lam_exponent);
                 n0v = (double)n0;
                 P[0] = lamf;
                 P[n] = n0v;
@@ -233,8 +349,8 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 qnv = (double)a.vals[d.var_qn * n + i];
                 double xm = q / (qnv + 2.220446049250313e-16);
                 xm = fmin(fmax(xm, d.x_min), d.x_max);
-                double lam = pow(d.lambda_factor * xm, d.lam_exponent);
-                double n0 = (d.nu / d.ntot_factor) * qnv * pow(lam, d.n0_exponent);
+                double lam = cp_pow(d.lambda_factor * xm, d.lam_exponent);
+                double n0 = (d.nu / d.ntot_factor) * qnv * cp_pow(lam, d.n0_exponent);
                 lamf = lam * d.c_lam;
                 n0v = n0 * d.c_n0;
                 P[0] = lamf;
@@ -263,7 +379,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             case CPOL_RULE_MELTING_GRAUPEL: {
                 P[0] = q;
                 P[n] = fw;
-                P[2 * n] = pow(d.r_lambda_factor / q, d.r_lam_exponent);   // rain partner
+                P[2 * n] = cp_pow(d.r_lambda_factor / q, d.r_lam_exponent);   // rain partner
                 // (the dry partner's PSD does not enter get_N, hydrometeors.py:372-390)
                 break; }
             default: break;
@@ -271,9 +387,9 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             if (a.doppler && d.psd_family == CPOL_PSD_GAMMA) {
                 // _Hydrometeor.integrate_V (hydrometeors.py:178-199): analytic moments
                 P[2 * n] = d.vel_factor * n0v * d.alpha / d.nu
-                           * pow(lamf, -(d.beta + d.mu + 1) / d.nu);
+                           * cp_pow(lamf, -(d.beta + d.mu + 1) / d.nu);
                 P[3 * n] = (d.rule == CPOL_RULE_TWO_MOMENT)
-                    ? qnv : d.ntot_factor * n0v / d.nu * pow(lamf, -(d.mu + 1) / d.nu);
+                    ? qnv : d.ntot_factor * n0v / d.nu * cp_pow(lamf, -(d.mu + 1) / d.nu);
             }
         }
         const int ticket = rank_insert(sh[j], a.count, key, valid);
@@ -469,118 +585,6 @@ __device__ __forceinline__ double melt_Dr(const cpol_hydro_desc &d, const MeltIt
     const double D3 = D * D * D;
     const double rho = melt_mass(d, it, D, D3) / (3.14159265358979323846 / 6 * D3);
     return cbrt(rho / 1.0e-6) * D;                          // RHO_W = 1000/1000^3 kg mm-3
-}
-
-// ---------------------------------------------------------------- per-bin math of the melting flavour
-// The melting species integrate over a per-ITEM diameter grid, so nothing can be tabulated
-// on the host: every (item, bin) needs two cube roots, a square root, an exponential, a
-// fourth root (snow) or two powers (graupel) and a division.  The OCML versions cost 32 /
-// 22 / 42 / 44 / 215 / 12 VALU instructions; the versions below reach 1e-15 relative
-// accuracy (tests/test_gpu_math.py) in 15-32, from float32 hardware seeds refined by
-// Newton steps in float64 and short polynomials.  Inputs are positive and normal here.
-__device__ __forceinline__ double cp_exp(double x)
-{
-    // x = n ln2 + r, |r| <= ln2/2; Taylor to r^12/12! (next term < 2e-16)
-    const double n = rint(x * 1.4426950408889634);
-    double r = fma(n, -0.6931471803691238, x);
-    r = fma(n, -1.9082149292705877e-10, r);
-    double p = 1.0 / 479001600.0;
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
-}
-
-__device__ __forceinline__ double cp_rcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = r * fma(-x, r, 2.0);
-    r = r * fma(-x, r, 2.0);
-    return r;
-}
-
-__device__ __forceinline__ double cp_log(double x)
-{
-    // x = m 2^e, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m-1)/(m+1), |s| < 0.1716
-    int e;
-    double m = frexp(x, &e);
-    if (m < 0.7071067811865476) { m *= 2.0; e -= 1; }
-    const double s = (m - 1.0) * cp_rcp(m + 1.0);
-    const double z = s * s;
-    double p = 1.0 / 21.0;
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
-    p = fma(p, z, 1.0);
-    const double en = (double)e;
-    return fma(en, 0.6931471803691238, fma(en, 1.9082149292705877e-10, 2.0 * s * p));
-}
-
-// x^(-1/6) -> cbrt(x) = x y^4 and sqrt(cbrt(x)) = x y^5 from ONE Newton sequence
-__device__ __forceinline__ void cp_cbrt_and_sixth(double x, double &cb, double &sx)
-{
-    double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * (-1.0f / 6.0f));
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const double y2 = y * y, y4 = y2 * y2;
-        y = y * fma(-x * y2, y4, 7.0) * (1.0 / 6.0);       // y (7 - x y^6) / 6
-    }
-    const double y2 = y * y, y4 = y2 * y2;
-    cb = x * y4;
-    sx = cb * y;
-}
-
-__device__ __forceinline__ double cp_cbrt(double x)
-{
-    double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * (-1.0f / 3.0f));
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-        y = y * fma(-x * y, y * y, 4.0) * (1.0 / 3.0);      // y (4 - x y^3) / 3
-    return x * (y * y);
-}
-
-__device__ __forceinline__ double cp_fourth_root(double x)
-{
-    double y = (double)__builtin_amdgcn_rsqf(__builtin_amdgcn_sqrtf((float)x));   // x^(-1/4)
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const double y2 = y * y;
-        y = y * fma(-x * y2, y2, 5.0) * 0.25;               // y (5 - x y^4) / 4
-    }
-    return x * (y * y * y);
-}
-
-// test hook (cpol_debug_math): evaluates one of the functions above on the device
-__global__ void k_debug_math(int op, const double *__restrict__ x, double *__restrict__ y, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double a, b;
-    switch (op) {
-    case 0: y[i] = cp_exp(x[i]); break;
-    case 1: y[i] = cp_log(x[i]); break;
-    case 2: y[i] = cp_cbrt(x[i]); break;
-    case 3: cp_cbrt_and_sixth(x[i], a, b); y[i] = a; break;
-    case 4: cp_cbrt_and_sixth(x[i], a, b); y[i] = b; break;
-    case 5: y[i] = cp_fourth_root(x[i]); break;
-    case 6: y[i] = cp_rcp(x[i]); break;
-    default: y[i] = x[i];
-    }
 }
 
 // Scattering tables and per-bin factors are immutable while a sweep runs: reading them
