@@ -277,6 +277,9 @@ def main():
                              'frac': psd_bytes / (iso.ms_psd * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              'valu_f64_frac': valu_cycles / (1024 * 2.4e9 * iso.ms_psd * 1e-3),
                              'device_total_ms': iso.ms_total,
+                             'stages_ms': {'trajectory': iso.ms_traj, 'interp': iso.ms_interp,
+                                           'classify': iso.ms_classify, 'bucket': iso.ms_bucket,
+                                           'psd': iso.ms_psd, 'final': iso.ms_final},
                              'note': 'same sweep with one lane only (no overlap with other sweeps)'},
                          'note': 'algorithmic bytes = N_valid x 49152 B (one float32 LUT slice per valid '
                                  'item, SURVEY 8(d)); slices are shared through the scalar cache / L2, '

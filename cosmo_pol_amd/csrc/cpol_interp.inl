@@ -300,22 +300,30 @@ __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
     const double bA = gc[4], B = gc[5], C = gc[6];
     const double f = CPOL_WGS84_F;
     const double sigma0 = (double)s32 / bA;
-    double sigma = sigma0, two_sm, cos2sm, sin_s, cos_s;
+    double sigma = sigma0, cos2sm, sin_s, cos_s;
+    // cos(2 sigma1 + sigma) by the addition theorem from one sincos(sigma) per iteration;
+    // sigma = arc / b is a few 1e-2 rad at radar ranges, so sin / cos are short Taylor sums
+    // (next terms sigma^13/13!, sigma^12/12! < 1e-19 for |sigma| < 0.1), OCML beyond
+    double s2s1, c2s1;
+    sincos(2.0 * sigma1, &s2s1, &c2s1);
 #pragma unroll 1
-    for (int it = 0; it < CPOL_VINCENTY_ITERS; ++it) {
-        two_sm = 2.0 * sigma1 + sigma;
-        cos2sm = cos(two_sm);
-        sin_s = sin(sigma);
-        cos_s = cos(sigma);
+    for (int it = 0; it <= CPOL_VINCENTY_ITERS; ++it) {
+        if (fabs(sigma) < 0.1) {
+            const double z = sigma * sigma;
+            sin_s = sigma * fma(z, fma(z, fma(z, fma(z, fma(z, -1.0 / 39916800.0, 1.0 / 362880.0),
+                                                     -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+            cos_s = fma(z, fma(z, fma(z, fma(z, fma(z, -1.0 / 3628800.0, 1.0 / 40320.0), -1.0 / 720.0),
+                                      1.0 / 24.0), -0.5), 1.0);
+        } else {
+            sincos(sigma, &sin_s, &cos_s);
+        }
+        cos2sm = c2s1 * cos_s - s2s1 * sin_s;
+        if (it == CPOL_VINCENTY_ITERS) break;           // values of the converged sigma
         double dsig = B * sin_s * (cos2sm + B / 4.0 * (cos_s * (-1.0 + 2.0 * cos2sm * cos2sm)
                       - B / 6.0 * cos2sm * (-3.0 + 4.0 * sin_s * sin_s)
                       * (-3.0 + 4.0 * cos2sm * cos2sm)));
         sigma = sigma0 + dsig;
     }
-    two_sm = 2.0 * sigma1 + sigma;
-    cos2sm = cos(two_sm);
-    sin_s = sin(sigma);
-    cos_s = cos(sigma);
     const double tmp = sin_u1 * sin_s - cos_u1 * cos_s * cos_a1;
     const double lat2 = atan2(sin_u1 * cos_s + cos_u1 * sin_s * cos_a1,
                               (1.0 - f) * sqrt(sin_alpha * sin_alpha + tmp * tmp));
@@ -327,8 +335,10 @@ __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
 
     // ---- rotated-pole transform (float64) -> float32 grid coordinates ----
     const double latr = lat_deg * CPOL_DEG, lonr = lon_deg * CPOL_DEG;
-    const double cl = cos(latr);
-    const double x = cos(lonr) * cl, y = sin(lonr) * cl, z = sin(latr);
+    double sl, cl, slon, clon;
+    sincos(latr, &sl, &cl);
+    sincos(lonr, &slon, &clon);
+    const double x = clon * cl, y = slon * cl, z = sl;
     const double x_new = m.ctcp * x + m.ctsp * y + m.st * z;
     const double y_new = m.nsp * x + m.cp * y;
     const double z_new = m.nstcp * x - m.stsp * y + m.ct * z;
