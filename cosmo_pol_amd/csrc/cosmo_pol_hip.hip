@@ -923,7 +923,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ra.n_rays = n_rays; ra.n_gates = ng; ra.with_attenuation = p->with_attenuation;
     ra.radial_res = (float)p->radial_res;
     ra.res_km = (float)(p->radial_res / 1000.);
-    hipLaunchKernelGGL(k_final_ray, dim3(n_rays), dim3(64), (size_t)3 * ng * sizeof(float), st, ra);
+    hipLaunchKernelGGL(k_final_ray, dim3(n_rays), dim3(192), (size_t)3 * ng * sizeof(float), st, ra);
     if (dop3 && cut)
         hipLaunchKernelGGL(k_spec_cut, dim3(cdiv(n_rg * n_vb, 256)), dim3(256), 0, st,
                            (const unsigned char *)ctx->b_cutflag.p, (double *)ctx->b_spectrum.p, n_rg, n_vb);

@@ -313,15 +313,17 @@ struct ScanRayArgs {
     float res_km;               // (float)(radial_res / 1000.)
 };
 
-__global__ __launch_bounds__(64) void k_final_ray(ScanRayArgs a)
+__global__ __launch_bounds__(192) void k_final_ray(ScanRayArgs a)
 {
     extern __shared__ float lds[];          // [3][n_gates]
     const int ray = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0: KDP sum, 1: FH product, 2: FV product
     const int ng = a.n_gates;
     const long base = (long)ray * ng;
     float *s_k = lds, *s_h = lds + ng, *s_v = lds + 2 * ng;
-    for (int g = lane; g < ng; g += 64) {
+    for (int g = tid; g < ng; g += 192) {
         float k2 = 2.0f * a.KDP[base + g];
         s_k[g] = (k2 == k2) ? k2 : 0.0f;                       // nan_cumsum
         if (a.with_attenuation) {
@@ -330,34 +332,39 @@ __global__ __launch_bounds__(64) void k_final_ray(ScanRayArgs a)
         }
     }
     __syncthreads();
-    // strictly sequential float32 scans; LDS is read in chunks of 8 so that the
-    // read latency is paid once per chunk, not once per dependent step
-    if (lane < 3 && (lane == 0 || a.with_attenuation)) {
-        float *sv = (lane == 0) ? s_k : (lane == 1 ? s_h : s_v);
+    // strictly sequential float32 scans, one wavefront (lane 0) per scan so that the
+    // operation is wave-uniform; LDS is read in chunks of 8 so that the read latency is
+    // paid once per chunk, not once per dependent step
+    if (lane == 0 && (wave == 0 || a.with_attenuation)) {
+        float *sv = (wave == 0) ? s_k : (wave == 1 ? s_h : s_v);
         float c = 0.0f;
         int g = 0;
-        for (; g + 8 <= ng; g += 8) {
-            float v[8];
+        if (wave == 0) {
+            for (; g + 8 <= ng; g += 8) {
+                float v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = sv[g + q];
+                for (int q = 0; q < 8; ++q) v[q] = sv[g + q];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (g + q == 0) c = v[0];
-                else c = (lane == 0) ? c + v[q] : c * v[q];
-                v[q] = c;
+                for (int q = 0; q < 8; ++q) { c = (g + q == 0) ? v[0] : c + v[q]; v[q] = c; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sv[g + q] = v[q];
             }
+            for (; g < ng; ++g) { c = (g == 0) ? sv[g] : c + sv[g]; sv[g] = c; }
+        } else {
+            for (; g + 8 <= ng; g += 8) {
+                float v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) sv[g + q] = v[q];
-        }
-        for (; g < ng; ++g) {
-            float x = sv[g];
-            if (g == 0) c = x;
-            else c = (lane == 0) ? c + x : c * x;
-            sv[g] = c;
+                for (int q = 0; q < 8; ++q) v[q] = sv[g + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { c = (g + q == 0) ? v[0] : c * v[q]; v[q] = c; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sv[g + q] = v[q];
+            }
+            for (; g < ng; ++g) { c = (g == 0) ? sv[g] : c * sv[g]; sv[g] = c; }
         }
     }
     __syncthreads();
-    for (int g = lane; g < ng; g += 64) {
+    for (int g = tid; g < ng; g += 192) {
         const long i = base + g;
         float zh = a.ZH[i], zv = a.ZV[i];
         float phidp = s_k[g] * a.radial_res / 1000.0f + a.DELTA_HV[i];
