@@ -759,7 +759,7 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
         const double d_max = it.fw * d.r_dmax + (1 - it.fw) * d.s_dmax;
         const double d_min = it.fw * d.r_dmin + (1 - it.fw) * d.s_dmin;
         const double step = (d_max - d_min) / (double)(n_d - 1);
-#pragma unroll 1
+#pragma unroll 2
         for (int k = k0; k < k1; ++k) {
             const double D = d_min + step * (double)k;
             const double D2 = D + 0.01;                                         // :384
@@ -1017,8 +1017,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS_U) void k_psd_uniform(HydroSet hs,
 // their coefficients live in ~80 VGPRs (157 in total -> 3 waves per SIMD -> ONE workgroup per
 // CU); capped at 128 VGPRs two workgroups are resident.
 template <bool DOP2>
-__global__ __launch_bounds__(CPOL_PSD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_psd_melting(HydroSet hs, PsdArgs a)
+__global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting(HydroSet hs, PsdArgs a)
 {
     psd_body<PSD_MODE_MELTING, DOP2>(hs, a);
 }
