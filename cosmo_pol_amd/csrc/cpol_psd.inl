@@ -14,11 +14,12 @@
 // Design: the reference gathers one [1024 x 12] float64 LUT slice per valid
 // (gate, hydrometeor) item and contracts it with N(D).  Items with the same
 // (hydrometeor, elevation bin, temperature bin) share the slice, so items are
-// counting-sorted by slice ("bucket"); one 64-lane wavefront then integrates 64
-// items of ONE bucket with the item on the lane: the slice row, D^mu and D^nu
-// are wave-uniform and arrive through the scalar data path (s_load -> SGPR
-// operand of v_fma_f64), the 12 float64 accumulators stay in VGPRs and no
-// cross-lane reduction or LDS staging is needed.
+// counting-sorted by slice ("bucket") and cut into work units of up to 64 (128 in the
+// recurrence flavour) items of ONE bucket.  A workgroup of 8 wavefronts integrates a
+// unit with the item on the lane and the 1024 diameter bins split over the waves: the
+// slice row, D^mu and D^nu are wave-uniform and arrive through the scalar data path
+// (s_load -> SGPR operand of v_fma_f64), the 12 float64 accumulators per item stay in
+// VGPRs, and the only cross-wave step is the fixed-order combine of the 8 partial sums.
 
 // ---------------------------------------------------------------- helpers
 __device__ __forceinline__ int clip_bin(float q, int n)
@@ -511,12 +512,12 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ 
 }
 
 // ---------------------------------------------------------------- PSD x LUT
-// Work decomposition: one 512-thread workgroup (8 wavefronts) per work unit of
-// up to 64 items that share one LUT slice.  The item sits on the lane; wave w
-// integrates diameter bins [w*n_d/8, (w+1)*n_d/8); the 8 partial sums per
-// (item, column) are combined through LDS in a fixed order (deterministic).
-// All units of all hydrometeors are covered by ONE launch per kernel flavour:
-// a workgroup whose unit belongs to another flavour exits immediately.
+// Work decomposition: persistent 512-thread workgroups (8 wavefronts) walk the list of
+// work units (up to 64 items of one LUT slice; 128 in the recurrence flavour, two per
+// lane).  The item sits on the lane; wave w integrates diameter bins [w*n_d/8,
+// (w+1)*n_d/8); the 8 partial sums per (item, column) are combined through LDS in a
+// fixed order (deterministic).  All units of all hydrometeors are covered by ONE launch
+// per kernel flavour: a workgroup skips the units of the other flavours.
 #define CPOL_PSD_WAVES 8
 #define CPOL_PSD_THREADS (CPOL_PSD_WAVES * CPOL_WAVE)
 // waves per workgroup of the recurrence flavour (8 or 10).  Measured: 8 waves 139.7 us,
