@@ -67,3 +67,33 @@ def test_gpm_geometry_sanity():
     from cosmo_pol_oracle import geodesy
     lat2, lon2 = geodesy.wgs84_direct(46.5, 7.5, 63.0, np.array([80000.0]))
     assert abs(gpm.wgs84_inverse_azimuth(46.5, 7.5, lat2[0], lon2[0]) - 63.0) < 1e-9
+
+
+def test_simulated_gpm_packing_matches_per_ray_definition():
+    """SimulatedGPM (gpm_wrapper.py:47-141): per ray, drop the gates below the topography,
+    flip the beam so that index 0 is the lowest gate, left-align; bin_surface counts from the
+    first gate above the model top.  Vectorised packing against the per-ray definition."""
+    import numpy as np
+    from cosmo_pol_amd.gpm import SimulatedGPM
+    rng = np.random.default_rng(1)
+    N, M, G = 4, 5, 30
+    n_kept = rng.integers(0, G + 1, N * M)
+    mask = rng.choice([-1., 0., 0., 1., 0.3], size=(N * M, G))
+    lats = rng.random((N * M, G))
+    lons = rng.random((N * M, G))
+    f = {'ZH': rng.random((N * M, G)).astype(np.float32)}
+    o = SimulatedGPM(f, mask, lats, lons, n_kept, (N, M), 'Ku')
+    for idx in range(N * M):
+        i, j = divmod(idx, M)
+        L = int(n_kept[idx])
+        m = mask[idx, :L]
+        above = np.where(m >= 1)[0]
+        assert o.bin_surface[i, j] == ((L - above[0]) if len(above) else 0)
+        keep = m > -1
+        n = int(keep.sum())
+        exp = np.zeros(G)
+        exp[:n] = f['ZH'][idx, :L][keep][::-1]
+        assert np.array_equal(o.data['ZH'][i, j], exp)
+        el = np.full(G, np.nan)
+        el[:n] = lats[idx, :L][keep][::-1]
+        assert np.array_equal(o.lats[i, j], el, equal_nan=True)
