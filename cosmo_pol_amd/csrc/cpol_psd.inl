@@ -833,7 +833,7 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
         // three unaligned ones, plus a third-order term) measured 142 us vs 139.7 us: neither
         // the number nor the alignment of the scalar requests bounds the kernel.  Also
         // measured and rejected: prefetching the next unit's slice into L2 with dummy vector
-        // loads (160 us).
+        // loads (160 us); staggering half of the waves by a few hundred cycles (no change).
         const cdouble_p pq = as_const(h.aux + 1 + n_d);          // [k][4] = (pre, q1, q2, .)
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
