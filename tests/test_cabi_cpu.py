@@ -192,3 +192,29 @@ def test_nyquist_table(tmp_path):
     assert np.array_equal(nyq([0.9, 1.2, 2.4, -5.0], [10., 170., 300., 0.]), [9.6, 10.5, 11., 8.3])
     c2 = cfg.sanity_check(c)                      # re-validation keeps the table object
     assert c2['radar']['nyquist_velocity'] is nyq
+
+
+def test_ray_tables_c_side_matches_numpy():
+    """cpol_ray_tables (libm, for C / C++ hosts) against geometry.ray_tables (NumPy, what the
+    Python host uses): pure host code, callable without a GPU."""
+    import ctypes as C
+    from cosmo_pol_amd import _native as N, geometry as geo
+    lib = N.load_library()
+    conf = {'radar': {'3dB_beamwidth': 1.0}, 'integration': {'scheme': 1, 'nh_GH': 3, 'nv_GH': 5,
+                                                                'weight_threshold': 1.0}}
+    sub = geo.gauss_hermite_subbeams(conf)
+    coords = [46.5, 7.5, 1000.0]
+    az = np.array([0.0, 33.3, 181.0, 359.5])
+    el = np.array([0.5, 3.0, 45.0, 89.0])
+    traj, geo_t = geo.ray_tables(coords, az, el, sub)
+    p = N.SweepParams()
+    p.n_rays, p.n_hnodes, p.n_vnodes = len(az), len(sub.pts_hor), len(sub.pts_ver)
+    p.sin_u1, p.cos_u1, _ = geo.radar_site_constants(coords)
+    t_c = np.zeros_like(traj)
+    g_c = np.zeros_like(geo_t)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)          # noqa: E731
+    rc = lib.cpol_ray_tables(C.byref(p), ptr(az), ptr(el), ptr(np.ascontiguousarray(sub.pts_hor)),
+                             ptr(np.ascontiguousarray(sub.pts_ver)), ptr(t_c), ptr(g_c))
+    assert rc == 0
+    np.testing.assert_allclose(t_c, traj, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(g_c, geo_t, rtol=1e-15, atol=1e-15)
