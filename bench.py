@@ -18,7 +18,8 @@ simulates one such sweep per step (rays sharded by whole sweeps, weak scaling)
 and the output slabs are collected with ONE RCCL all-gather per step.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on
-the library's stream over the timed region (cpol_enable_timing / cpol_counters);
+the library's stream over the timed region (cpol_enable_timing / cpol_counters: two
+events per sweep around the PSD stage of lane 0; all stages in the single-lane pass after it);
 `cpu_baseline` times the CPU oracle (the restatement of the reference
 algorithm, per radial, un-batched) on a bounded azimuth sample on this host.
 """
@@ -59,8 +60,8 @@ def bench_config(small):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--small', action='store_true', help='small cube / tables (debugging)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0,
                     help='budget of the CPU-oracle baseline sample (0 = skip)')
@@ -119,15 +120,16 @@ def main():
     az = np.arange(0, 360, 1.0)
     el = np.full(len(az), 1.0)
     n_rays, n_gates = len(az), len(op.constants.RANGE_RADAR)
-    stream = torch.cuda.Stream()
-    op._ctx.set_stream(stream.cuda_stream)
     # lanes: contexts forked from the operator's (shared cube / tables, own stream and work
     # buffers); consecutive steps go to alternating lanes so that the latency-bound kernels
-    # of one sweep overlap the PSD kernel of the other (CPOL_BENCH_LANES=1 disables)
+    # of one sweep overlap the PSD kernel of the other (CPOL_BENCH_LANES=1 disables).  The
+    # lanes keep the library's own non-blocking streams, created back to back before any other
+    # stream of the process so that each gets its own hardware queue (measured: torch-created
+    # streams, or forking after other streams exist, cost 6-25 % through queue sharing).
     n_lanes = max(1, int(os.environ.get('CPOL_BENCH_LANES', '3')))
-    lane_streams = [stream] + [torch.cuda.Stream() for _ in range(n_lanes - 1)]
-    for i in range(1, n_lanes):
-        op._lane(i).set_stream(lane_streams[i].cuda_stream)
+    lanes = [op._lane(i) for i in range(n_lanes)]
+    lane_streams = ([torch.cuda.ExternalStream(c.stream_ptr(), device=torch.device('cuda', local_rank))
+                     for c in lanes] if world > 1 else None)
     # two output slabs: the all-gather of step i (side stream) overlaps the kernels of
     # step i+1 (library stream); a slab is reused only after its gather has completed
     n_buf = max(2, n_lanes) if world > 1 else n_lanes
@@ -161,6 +163,8 @@ def main():
             slab_free[b].record(comm_stream)
 
     def fence():
+        for c in lanes:
+            c.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -174,7 +178,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    op._ctx.enable_timing(True)          # HIP events around every stage, no extra syncs
+    op._ctx.enable_timing(2)             # HIP events around the PSD stage of lane 0 (2 per sweep)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -205,7 +209,7 @@ def main():
 
     # the same sweep on ONE lane (no other sweep in flight): kernel durations in isolation
     iso = None
-    if world == 1 and n_lanes > 1:
+    if world == 1:
         n_it = max(5, args.steps // 2)
         op._ctx.enable_timing(True)
         for _ in range(n_it):
@@ -284,15 +288,16 @@ def main():
                          'note': 'algorithmic bytes = N_valid x 49152 B (one float32 LUT slice per valid '
                                  'item, SURVEY 8(d)); slices are shared through the scalar cache / L2, '
                                  'so frac can exceed 1 -- see DESIGN.md'},
-            'stages_ms': {'trajectory': cnt.ms_traj, 'interp': cnt.ms_interp,
-                          'classify': cnt.ms_classify, 'bucket': cnt.ms_bucket, 'psd': cnt.ms_psd,
-                          'final': cnt.ms_final, 'device_total': cnt.ms_total,
-                          'note': 'per-sweep latencies on lane 0 with %d lanes in flight; '
-                                  'throughput = steps / wall time' % n_lanes},
+            'stages_ms': None if iso is None else {
+                'trajectory': iso.ms_traj, 'interp': iso.ms_interp, 'classify': iso.ms_classify,
+                'bucket': iso.ms_bucket, 'psd': iso.ms_psd, 'final': iso.ms_final,
+                'device_total': iso.ms_total, 'psd_with_lanes_in_flight': cnt.ms_psd,
+                'note': 'one sweep on one lane (the pass after the timed region); in the timed '
+                        'region only the PSD stage of lane 0 carries events (2 per sweep)'},
             'counters': {'n_subbeam_gates': n_sbg, 'n_valid_items': n_valid,
                          'n_work_units': int(cnt.n_work_units),
                          'sweep_algorithmic_bytes': sweep_bytes,
-                         'sweep_algorithmic_GBs': sweep_bytes / (cnt.ms_total * 1e-3) / 1e9 if cnt.ms_total else None},
+                         'sweep_algorithmic_GBs': sweep_bytes * world / (elapsed / args.steps) / 1e9},
             'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
             'gather_check': gather_ok,
             'value_with_d2h': value_d2h,

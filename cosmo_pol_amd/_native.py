@@ -95,6 +95,7 @@ class Counters(C.Structure):
 
 
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_fork', 'cpol_last_error', 'cpol_set_stream',
+           'cpol_get_stream',
            'cpol_synchronize', 'cpol_stage_model', 'cpol_stage_hydro', 'cpol_set_num_hydro',
            'cpol_stage_doppler_weights', 'cpol_stage_spectrum_tables',
            'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
@@ -122,6 +123,8 @@ def load_library():
     vp = C.c_void_p
     lib.cpol_create.restype = C.c_int
     lib.cpol_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.cpol_get_stream.restype = C.c_int
+    lib.cpol_get_stream.argtypes = [vp, C.POINTER(vp)]
     lib.cpol_fork.restype = C.c_int
     lib.cpol_fork.argtypes = [vp, C.POINTER(vp)]
     lib.cpol_destroy.restype = None
@@ -225,7 +228,14 @@ class Context(object):
         self._check(self.lib.cpol_synchronize(self.h), 'cpol_synchronize')
 
     def enable_timing(self, on=True):
-        self._check(self.lib.cpol_enable_timing(self.h, int(bool(on))), 'cpol_enable_timing')
+        """True / 1: events around every stage; 2: around the PSD stage only; False: off."""
+        self._check(self.lib.cpol_enable_timing(self.h, 2 if on == 2 else int(bool(on))),
+                    'cpol_enable_timing')
+
+    def stream_ptr(self):
+        h = C.c_void_p()
+        self._check(self.lib.cpol_get_stream(self.h, C.byref(h)), 'cpol_get_stream')
+        return h.value or 0
 
     def enable_debug(self, on=True):
         self.lib.cpol_debug_read(self.h, b'enable' if on else b'disable', None, 0)

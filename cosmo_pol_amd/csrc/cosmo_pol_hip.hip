@@ -46,6 +46,11 @@ struct cpol_ctx {
     // owns only its stream, work buffers and counters
     cpol_ctx *parent = nullptr;
     int n_children = 0;
+    // HIP graph of the sweep's launch sequence (device outputs, unchanged arguments)
+    bool use_graph = false;
+    hipGraphExec_t graph_exec = nullptr;
+    uint64_t graph_key = 0;
+    uint64_t stage_serial = 0;         // bumped by every staging call (kernel arguments change)
     std::string err;
     // model
     bool model_staged = false;
@@ -74,7 +79,7 @@ struct cpol_ctx {
     // timing: one event set per sweep since cpol_enable_timing(ctx, 1); elapsed
     // times are collected (averaged) by cpol_counters after the stream drained,
     // so recording does not serialise the timed loop.
-    bool timing = false;
+    int timing = 0;                    // 0 off, 1 every stage, 2 the PSD stage only
     std::vector<hipEvent_t *> ev_sets;
     size_t ev_used = 0;
     hipEvent_t *ev = nullptr;          // set of the sweep being recorded
@@ -149,6 +154,10 @@ int cpol_create(int device, cpol_ctx **out)
         return CPOL_ERR_HIP;
     }
     ctx->own_stream = true;
+    // opt-in (CPOL_USE_GRAPH=1): replaying the captured sequence cuts the host time of a sweep
+    // 4x (0.12 -> 0.03 ms) but is no faster on the device (0.232 vs 0.222 ms single lane) and
+    // slows three-lane throughput by a quarter when graph launches and plain launches mix
+    ctx->use_graph = getenv("CPOL_USE_GRAPH") && atoi(getenv("CPOL_USE_GRAPH")) != 0;
     *out = ctx;
     return CPOL_OK;
 }
@@ -190,6 +199,7 @@ void cpol_destroy(cpol_ctx *ctx)
         for (int k = 0; k < EV_N; ++k) (void)hipEventDestroy(set[k]);
         delete[] set;
     }
+    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -213,6 +223,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
         return CPOL_ERR_HIP;
     }
     c->own_stream = true;
+    c->use_graph = parent->use_graph;
     c->parent = parent;
     c->model_staged = parent->model_staged;
     c->model = parent->model;
@@ -243,6 +254,13 @@ int cpol_set_stream(cpol_ctx *ctx, void *hip_stream)
     return CPOL_OK;
 }
 
+int cpol_get_stream(cpol_ctx *ctx, void **hip_stream)
+{
+    if (!ctx || !hip_stream) return CPOL_ERR_ARG;
+    *hip_stream = (void *)ctx->stream;
+    return CPOL_OK;
+}
+
 int cpol_synchronize(cpol_ctx *ctx)
 {
     if (!ctx) return CPOL_ERR_ARG;
@@ -253,7 +271,7 @@ int cpol_synchronize(cpol_ctx *ctx)
 int cpol_enable_timing(cpol_ctx *ctx, int on)
 {
     if (!ctx) return CPOL_ERR_ARG;
-    ctx->timing = on != 0;
+    ctx->timing = (on == 2) ? 2 : (on != 0);
     ctx->ev_used = 0;                  // restart the averaging window
     return CPOL_OK;
 }
@@ -305,6 +323,7 @@ int cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data, const 
     m.ctcp = ct * cp; m.ctsp = ct * sp; m.st = st; m.nsp = -sp; m.cp = cp;
     m.nstcp = -st * cp; m.stsp = st * sp; m.ct = ct;
     ctx->model_staged = true;
+    ctx->stage_serial++;
     return CPOL_OK;
 }
 
@@ -326,6 +345,7 @@ int cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro)
         return CPOL_ERR_ARG;
     }
     ctx->hs.n_hydro = n_hydro;
+    ctx->stage_serial++;
     int base = 0;
     for (int j = 0; j < n_hydro; ++j) {
         ctx->hs.h[j].key_base = base;
@@ -396,6 +416,7 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
     h.n_par = n_par_of(desc->rule);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->hydro_staged[slot] = true;
+    ctx->stage_serial++;
     if (slot >= ctx->hs.n_hydro) cpol_set_num_hydro(ctx, slot + 1);
     else cpol_set_num_hydro(ctx, ctx->hs.n_hydro);
     return CPOL_OK;
@@ -418,6 +439,7 @@ int cpol_stage_doppler_weights(cpol_ctx *ctx, int slot, const double *weights)
     if ((rc = upload(ctx, ctx->d_rcsw[slot], weights, bytes)) != CPOL_OK) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->hs.h[slot].rcsw = (const double *)ctx->d_rcsw[slot].p;
+    ctx->stage_serial++;
     return CPOL_OK;
 }
 
@@ -647,17 +669,22 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         HIPCHK(hipMemsetAsync(ctx->b_count.p, 0, (size_t)(n_keys + 1) * sizeof(int), st));
     int *const d_errflag = (int *)ctx->b_count.p + n_keys;
 
-    const bool tm = ctx->timing;
-    if (tm) {
+    const bool tm = ctx->timing == 1;          // events around every stage
+    const bool tm_psd = ctx->timing != 0;      // ... or only around the PSD stage
+    if (tm_psd) {
         if (ctx->ev_used == ctx->ev_sets.size()) {
             hipEvent_t *set = new hipEvent_t[EV_N];
             for (int k = 0; k < EV_N; ++k) HIPCHK(hipEventCreate(&set[k]));
             ctx->ev_sets.push_back(set);
         }
         ctx->ev = ctx->ev_sets[ctx->ev_used++];
-        HIPCHK(hipEventRecord(ctx->ev[EV_T0], st));
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_T0], st));
     }
 
+    // The launch sequence of a sweep.  Opt-in (CPOL_USE_GRAPH=1): with device outputs and
+    // nothing to upload it is captured into a HIP graph and replayed while the arguments stay
+    // the same (one graph launch instead of ten kernel launches).
+    auto launch_all = [&]() -> int {
     // ---- 1. ray paths ----
     if (mode == CPOL_GEOM_HOST_PATHS) {
         HIPCHK(hipMemcpyAsync(ctx->b_traj.p, t->paths, (size_t)n_rays * n_v * 3 * ng * sizeof(float),
@@ -761,7 +788,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     hipLaunchKernelGGL(k_bucket_scatter, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st,
                        (const int *)ctx->b_key.p, (const int *)ctx->b_pos.p,
                        (const int *)ctx->b_offset.p, (int *)ctx->b_perm.p, n_sbg, n_hyd);
-    if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st));
+    if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st));
 
     // ---- 5. PSD x scattering table: one launch per kernel flavour present ----
     {
@@ -814,7 +841,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         }
 #undef CPOL_LAUNCH_PSD
     }
-    if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
+    if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
 
     // ---- 6. accumulation + polarimetric variables + scans ----
     FinalArgs fa{};
@@ -930,6 +957,52 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
     HIPCHK(hipGetLastError());
 
+    return CPOL_OK;
+    };
+
+    // graph key: every value that ends up in a kernel argument
+    const bool graphable = ctx->use_graph && dev && !tm_psd && !ctx->keep_debug && mode != CPOL_GEOM_HOST_PATHS &&
+                           !dop3 && reuse && !want_szt && !want_model;
+    if (graphable) {
+        uint64_t key = 1469598103934665603ull;
+        auto mix = [&](const void *ptr, size_t n) {
+            const unsigned char *c = (const unsigned char *)ptr;
+            for (size_t i = 0; i < n; ++i) { key ^= c[i]; key *= 1099511628211ull; }
+        };
+        mix(p, sizeof *p);
+        mix(&t->version, sizeof t->version);
+        mix(T, sizeof T);
+        mix(&ctx->stage_serial, sizeof ctx->stage_serial);
+        void *arena[] = {ctx->b_traj.p, ctx->b_vals.p, ctx->b_mask.p, ctx->b_elev.p, ctx->b_qmelt.p,
+                         ctx->b_fwmelt.p, ctx->b_key.p, ctx->b_pos.p, ctx->b_par.p, ctx->b_count.p,
+                         ctx->b_offset.p, ctx->b_cursor.p, ctx->b_units.p, ctx->b_totals.p, ctx->b_perm.p,
+                         ctx->b_res.p, ctx->b_vn.p, ctx->b_icefirst.p, ctx->b_rvel.p, ctx->b_fh.p,
+                         ctx->b_fv.p, ctx->b_wgate.p, ctx->b_traj_in.p, ctx->b_geo.p, ctx->b_subh.p,
+                         ctx->b_subv.p, ctx->b_subw.p, ctx->b_sens.p, ctx->b_site.p, ctx->b_nyq.p,
+                         ctx->b_subsmooth.p, ctx->b_mlfilter.p, (void *)st};
+        mix(arena, sizeof arena);
+        if (!ctx->graph_exec || ctx->graph_key != key) {
+            if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int lrc = launch_all();
+            const hipError_t ce = hipStreamEndCapture(st, &graph);
+            if (lrc != CPOL_OK || ce != hipSuccess || !graph) {
+                if (graph) (void)hipGraphDestroy(graph);
+                if (lrc != CPOL_OK) return lrc;
+                ctx->err = "cpol_run_sweep: stream capture failed";
+                return CPOL_ERR_HIP;
+            }
+            const hipError_t ie = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) { ctx->graph_exec = nullptr; ctx->err = "cpol_run_sweep: hipGraphInstantiate failed"; return CPOL_ERR_HIP; }
+            ctx->graph_key = key;
+        }
+        HIPCHK(hipGraphLaunch(ctx->graph_exec, st));
+    } else {
+        if ((rc = launch_all()) != CPOL_OK) return rc;
+    }
+
     // ---- outputs (host buffers only; device buffers were written in place) ----
     const size_t fb = (size_t)n_rg * sizeof(float), dbb = (size_t)n_rg * sizeof(double);
     for (int k = 0; k < 14; ++k) {
@@ -1005,12 +1078,16 @@ int cpol_counters(cpol_ctx *ctx, cpol_counters_t *out)
             double acc[EV_N] = {}, tot = 0;
             for (size_t i = 0; i < ctx->ev_used; ++i) {
                 hipEvent_t *e = ctx->ev_sets[i];
+                float ms = 0;
+                if (ctx->timing == 2) {                     // PSD stage only
+                    HIPCHK(hipEventElapsedTime(&ms, e[EV_BUCKET], e[EV_PSD]));
+                    acc[EV_PSD] += ms;
+                    continue;
+                }
                 for (int k = 1; k < EV_N; ++k) {
-                    float ms = 0;
                     HIPCHK(hipEventElapsedTime(&ms, e[k - 1], e[k]));
                     acc[k] += ms;
                 }
-                float ms = 0;
                 HIPCHK(hipEventElapsedTime(&ms, e[EV_T0], e[EV_FINAL]));
                 tot += ms;
             }

@@ -215,6 +215,9 @@ const char *cpol_last_error(cpol_ctx *ctx);
 /* use an externally created hipStream_t (e.g. torch's current stream); NULL = own stream */
 int  cpol_set_stream(cpol_ctx *ctx, void *hip_stream);
 int  cpol_synchronize(cpol_ctx *ctx);
+/* the HIP stream (hipStream_t) the context launches on: to order foreign work (copies,
+ * collectives) against a sweep with events */
+int  cpol_get_stream(cpol_ctx *ctx, void **hip_stream);
 
 /* data[v] and zlevels: [nz][ny][nx] float32, C order (x = rotated longitude
  * fastest), level 0 = model top; llc = (Lo1, La1), urc = (Lo2, La2), res =
@@ -266,6 +269,8 @@ int  cpol_spaceborne_first_gate(cpol_ctx *ctx, const cpol_sweep_params *p, const
                                 int32_t *first_gate);
 
 int  cpol_counters(cpol_ctx *ctx, cpol_counters_t *out);
+/* on = 1: HIP events around every stage of every sweep (7 per sweep); on = 2: only around the
+ * PSD x table stage (2 per sweep; ms_psd alone is filled in); on = 0: off */
 int  cpol_enable_timing(cpol_ctx *ctx, int on);
 
 /* debug / parity access to intermediate device buffers of the last sweep:

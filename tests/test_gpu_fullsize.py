@@ -125,3 +125,37 @@ def test_lanes_volume_scan_equals_sequential():
             x, y = np.ma.asarray(a.get_field(i, name)), np.ma.asarray(b.get_field(i, name))
             assert np.array_equal(np.ma.getmaskarray(x), np.ma.getmaskarray(y)), name
             assert np.array_equal(x.filled(0), y.filled(0)), name
+
+
+def test_graph_replay_equals_plain_launches(monkeypatch):
+    """Device-output sweeps are captured into a HIP graph and replayed while nothing changes;
+    the result must equal the plain launch sequence (CPOL_USE_GRAPH=0), also after the scan
+    geometry changed and changed back."""
+    import torch
+    from cosmo_pol_amd import RadarOperator, synthetic
+    conf = bench.bench_config(True)
+    hyds = ('R', 'S', 'G')
+    cube = synthetic.small_test_cube(hydrometeors=hyds)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
+    az_a, az_b = np.arange(0., 360., 3.), np.arange(1., 361., 3.)
+    el = np.full(len(az_a), 2.0)
+    fields = ['ZH', 'ZDR', 'KDP', 'RHOHV', 'PHIDP']
+    results = {}
+    for use_graph in ('1', '0'):
+        monkeypatch.setenv('CPOL_USE_GRAPH', use_graph)
+        op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
+        op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+        n_gates = len(op.constants.RANGE_RADAR)
+        slab = torch.full((len(fields), len(az_a), n_gates), -1.0, dtype=torch.float32, device='cuda')
+        ptrs = {k: slab[i].data_ptr() for i, k in enumerate(fields)}
+        snaps = []
+        for az in (az_a, az_a, az_a, az_b, az_b, az_a, az_a):
+            op.simulate_rays(az, el, device_outputs=ptrs)
+            op._ctx.synchronize()
+            snaps.append(slab.cpu().numpy().copy())
+        results[use_graph] = snaps
+        op.close()
+    for x, y in zip(results['1'], results['0']):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert np.array_equal(results['1'][0], results['1'][2], equal_nan=True)
+    assert not np.array_equal(results['1'][0], results['1'][3], equal_nan=True)
