@@ -81,15 +81,6 @@ def main():
     backend = os.environ.get('CPOL_BENCH_BACKEND', 'nccl')
     if os.environ.get('CPOL_BENCH_ONE_DEVICE'):
         local_rank = 0
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world,
-                                    device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
     from cosmo_pol_amd import RadarOperator, synthetic
     conf = bench_config(args.small)
     hyds = ('R', 'S', 'G')
@@ -128,6 +119,17 @@ def main():
     # streams, or forking after other streams exist, cost 6-25 % through queue sharing).
     n_lanes = max(1, int(os.environ.get('CPOL_BENCH_LANES', '3')))
     lanes = [op._lane(i) for i in range(n_lanes)]
+    # the process group comes AFTER the lanes so that RCCL's own streams do not take the
+    # hardware queues of the lanes
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
     lane_streams = ([torch.cuda.ExternalStream(c.stream_ptr(), device=torch.device('cuda', local_rank))
                      for c in lanes] if world > 1 else None)
     # two output slabs: the all-gather of step i (side stream) overlaps the kernels of
