@@ -10,7 +10,7 @@ out=$root/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt /tmp/pmcF /tmp/pmcW /tmp/pmcS
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $root/bench.py --steps 20 --warmup 3 --cpu-seconds 0 > $out/bench_under_rocprof.json 2> $out/kt.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $root/bench.py --steps 200 --warmup 10 --cpu-seconds 0 > $out/bench_under_rocprof.json 2> $out/kt.log
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmcF -- python3 $root/bench.py --steps 5 --warmup 1 --cpu-seconds 0 > /dev/null 2> $out/pmcF.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmcW -- python3 $root/bench.py --steps 5 --warmup 1 --cpu-seconds 0 > /dev/null 2> $out/pmcW.log
