@@ -218,3 +218,19 @@ def test_ray_tables_c_side_matches_numpy():
     assert rc == 0
     np.testing.assert_allclose(t_c, traj, rtol=0, atol=1e-15)
     np.testing.assert_allclose(g_c, geo_t, rtol=1e-15, atol=1e-15)
+
+
+def test_c_host_links_and_runs(tmp_path):
+    """The boundary is a C ABI: a plain-C translation unit includes the header, links the
+    library and runs (the GPU-free entry points; cpol_create must fail cleanly here)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, 'cosmo_pol_amd', 'csrc')
+    exe = str(tmp_path / 'host_check')
+    cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(root, 'include'),
+           os.path.join(root, 'tests', 'c_host', 'host_check.c'), '-o', exe,
+           '-L', libdir, '-lcosmo_pol_hip', '-lm', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib']
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and 'C_HOST_OK' in r.stdout, r.stdout + r.stderr
