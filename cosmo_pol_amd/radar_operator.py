@@ -103,7 +103,12 @@ class RadarOperator(object):
     _table_serial = 0          # tags of per-ray table sets handed to the library
 
     def __init__(self, options_file=None, output_variables='all', *, device=0, lut_dir=None,
-                 luts=None, config=None, distributed=False, lanes=2):
+                 luts=None, config=None, distributed=False, lanes=2, backend='hip'):
+        if backend != 'hip':
+            # by design: the product path is the HIP library or nothing (no CPU fallback)
+            raise N.NativeError("backend %r: only 'hip' exists; the CPU restatement lives under "
+                                "oracle/ as test infrastructure and is never used by the product"
+                                % (backend,))
         print('Reading options defined in options file')
         self._ctx = N.Context(device)         # raises if the HIP library / GPU is missing
         # lanes: contexts forked from _ctx (shared cube / tables, own stream + work buffers);
