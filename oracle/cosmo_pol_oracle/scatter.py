@@ -191,10 +191,12 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyq
                     beam = SP.broaden_spectrum(beam, add, varray)
                 if mp['with_attenuation']:
                     beam = SP.apply_attenuation(beam, SP.attenuation_per_beam(ah_list, n_gates))
+                # in place on the float32 spectrum, as the reference does (:386-389): the product
+                # is rounded to float32 (and underflows there) before it is accumulated
                 if not np.isscalar(sb.quad_weight):
-                    beam = beam * sb.quad_weight[:, None]
+                    beam *= sb.quad_weight[:, None]
                 else:
-                    beam = beam * sb.quad_weight
+                    beam *= sb.quad_weight
                 doppler_spectrum += beam
             elif simulate_doppler:
                 v_hydro = v_integ / n_integ
