@@ -19,10 +19,13 @@ def main():
     from cosmo_pol_oracle import beam, scatter
     from cosmo_pol_oracle import config as ocfg
     rng = np.random.default_rng(seed)
-    for _ in range(case + 1):
+    for _ in range(case + 1):          # same draws, in the same order, as fuzz_parity.main
         over, two = F.draw(rng)
         azs = rng.uniform(0, 360, 2)
         els = rng.uniform(0.5, 30, 2)
+        rng.random()                                   # cut
+        if rng.random() < 0.3:                         # nyquist
+            rng.uniform(0.5, 6.0)
     conf = ocfg.make_config(over)
     hl = ocfg.hydrometeor_list(conf)
     cube = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G', 'I'), two_moment=two, **_cases.gen_golden.CUBE_KW)
