@@ -369,8 +369,9 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                     - 0.000141f * (Tc * Tc) + (float)(0.060366 * 9) + 0.000079f * (Tc * Tc) * n3
                     + 0.000594f * Tc * 9.0f - (float)(0.003577 * 27);
                 const double qb = q / 3.0;                        // QM / BM_I
-                const double Q2 = pow(qb / (double)pa, (double)(1.0f / pb));
-                double N0 = pow(Q2, 4.0) * pow(q, -3.0);
+                const double Q2 = cp_pow(qb / (double)pa, (double)(1.0f / pb));
+                const double Q22 = Q2 * Q2;
+                double N0 = (Q22 * Q22) / (q * q * q);            // Q2^4 QM^-3 (b = 3)
                 N0 /= 100000.0;
                 P[0] = Q2 / q;                                    // lambda (exponent 1/(b-2) = 1)
                 P[n] = N0;
