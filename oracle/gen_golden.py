@@ -293,6 +293,24 @@ RADIAL_CASES.update({
                      'integration': {'nh_GH': 3, 'nv_GH': 1}}, 75.0, 8.0, ('R', 'S', 'G', 'I'), True),
 })
 
+# further combinations pinned by the reference itself
+RADIAL_CASES.update({
+    'd3_1mom_ice_sub': ({'radar': {'range': 45000, 'radial_resolution': 750, 'FFT_length': 32},
+                         'microphysics': {'with_ice_crystals': 1, 'with_melting': 0},
+                         'doppler': {'scheme': 3},
+                         'integration': {'nh_GH': 3, 'nv_GH': 1}}, 120.0, 5.0, ('R', 'S', 'G', 'I'), False),
+    'q_ml_dop2': ({'radar': {'range': 30000, 'radial_resolution': 500},
+                   'microphysics': {'with_ice_crystals': 1, 'with_melting': 1},
+                   'doppler': {'scheme': 2},
+                   'integration': {'scheme': 'ml', 'nh_GH': 1, 'nv_GH': 1}}, 300.0, 6.0,
+                  ('R', 'S', 'G', 'I'), False),
+    'c5_2mom_dop2_sub': ({'radar': {'range': 24000, 'radial_resolution': 400, 'frequency': 13.6},
+                          'microphysics': {'scheme': '2mom', 'with_ice_crystals': 1, 'with_melting': 0},
+                          'doppler': {'scheme': 2},
+                          'integration': {'nh_GH': 3, 'nv_GH': 3, 'weight_threshold': 0.999}}, 75.0, 8.0,
+                         ('R', 'S', 'G', 'I'), True),
+})
+
 LUT_KW = dict(seed=20260301, n_e=8, n_t=None)
 
 

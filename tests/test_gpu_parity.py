@@ -165,7 +165,7 @@ def test_radial_vs_reference_golden_and_oracle(golden, name):
     if 'DSPECTRUM' in oobs.values:
         sp, osp = res['DSPECTRUM'][0], oobs.values['DSPECTRUM']
         assert sp.shape == osp.shape == g['obs_DSPECTRUM'].shape
-        assert np.nansum(osp > 0) > 50, 'the spectrum was not exercised'
+        assert np.nansum(osp > 0) > 20, 'the spectrum was not exercised'
         atol = 1e-6 * np.nanmax(osp)
         _cases.assert_close_nan(sp, osp, rtol=2e-5, atol=atol, name='oracle:DSPECTRUM')
         _cases.assert_close_nan(sp, g['obs_DSPECTRUM'], rtol=2e-5, atol=atol, name='golden:DSPECTRUM')
