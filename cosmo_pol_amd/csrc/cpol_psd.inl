@@ -450,13 +450,23 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
     __shared__ int2 s_wave[16];
     const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
     const int per = (a.n_keys + 1023) / 1024;               // <= CPOL_SCAN_MAX_PER (host checks)
-    const int k0 = t * per, k1 = min(k0 + per, a.n_keys);
+    const int k0 = t * per;
+    // the thread's counts in registers: the (up to 32) loads are independent and issue together
+    int cnt[CPOL_SCAN_MAX_PER];
+#pragma unroll
+    for (int i = 0; i < CPOL_SCAN_MAX_PER; ++i) {
+        const int k = k0 + i;
+        cnt[i] = (i < per && k < a.n_keys) ? a.count[k] : 0;
+    }
     int2 mine = make_int2(0, 0);
-    for (int k = k0; k < k1; ++k) {
-        int c = a.count[k];
-        int sh = unit_shift_of(a, k);
-        mine.x += c;
-        mine.y += (c + (1 << sh) - 1) >> sh;
+#pragma unroll
+    for (int i = 0; i < CPOL_SCAN_MAX_PER; ++i) {
+        const int k = k0 + i;
+        if (i < per && k < a.n_keys) {
+            const int sh = unit_shift_of(a, k);
+            mine.x += cnt[i];
+            mine.y += (cnt[i] + (1 << sh) - 1) >> sh;
+        }
     }
     int2 inc = wave_inclusive_scan2(mine);
     if (lane == CPOL_WAVE - 1) s_wave[wave] = inc;
@@ -469,13 +479,16 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
     __syncthreads();
     int ibase = s_wave[wave].x + inc.x - mine.x;
     int ubase = s_wave[wave].y + inc.y - mine.y;
-    for (int k = k0; k < k1; ++k) {
-        int c = a.count[k];
-        int sh = unit_shift_of(a, k);
-        a.offset[k] = ibase;
-        a.uoffset[k] = ubase;
-        ibase += c;
-        ubase += (c + (1 << sh) - 1) >> sh;
+#pragma unroll
+    for (int i = 0; i < CPOL_SCAN_MAX_PER; ++i) {
+        const int k = k0 + i;
+        if (i < per && k < a.n_keys) {
+            const int sh = unit_shift_of(a, k);
+            a.offset[k] = ibase;
+            a.uoffset[k] = ubase;
+            ibase += cnt[i];
+            ubase += (cnt[i] + (1 << sh) - 1) >> sh;
+        }
     }
     if (t == 1023) { a.totals[0] = ibase; a.totals[1] = ubase; }
 }
