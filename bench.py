@@ -103,8 +103,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     t0 = time.time()
-    op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', device=local_rank)
-    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the operator's notices: stdout carries ONE JSON line
+        op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', device=local_rank)
+        op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
     op._ctx.synchronize()
     t_stage = time.time() - t0
 
