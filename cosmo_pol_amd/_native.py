@@ -99,8 +99,10 @@ EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_fork', 'cpol_last_error', 'cpol_
            'cpol_synchronize', 'cpol_stage_model', 'cpol_stage_hydro', 'cpol_set_num_hydro',
            'cpol_stage_doppler_weights', 'cpol_stage_spectrum_tables',
            'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
-           'cpol_spaceborne_first_gate',
+           'cpol_spaceborne_first_gate', 'cpol_host_alloc', 'cpol_host_free',
            'cpol_enable_timing', 'cpol_debug_read', 'cpol_debug_math']
+
+TRAJ_STRIDE, GEO_STRIDE, SITE_STRIDE = 4, 8, 8      # CPOL_*_STRIDE of the header
 
 _lib = None
 
@@ -163,6 +165,10 @@ def load_library():
     lib.cpol_stage_spectrum_tables.argtypes = [vp, C.c_int, vp, vp]
     lib.cpol_debug_math.restype = C.c_int
     lib.cpol_debug_math.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    lib.cpol_host_alloc.restype = C.c_int
+    lib.cpol_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.cpol_host_free.restype = C.c_int
+    lib.cpol_host_free.argtypes = [vp, vp]
     _lib = lib
     return lib
 
@@ -225,7 +231,19 @@ class Context(object):
         self._check(self.lib.cpol_set_stream(self.h, C.c_void_p(stream_ptr)), 'cpol_set_stream')
 
     def synchronize(self):
+        """Waits for the context's stream; raises IndexError if a sweep since the last
+        report left the model domain (deferred error of device / pinned-host outputs)."""
         self._check(self.lib.cpol_synchronize(self.h), 'cpol_synchronize')
+
+    def host_alloc(self, nbytes):
+        """uint8 array over page-locked host memory owned by the context (the target of
+        outputs_on_device = 2); valid until the context is closed."""
+        h = C.c_void_p()
+        self._check(self.lib.cpol_host_alloc(self.h, int(nbytes), C.byref(h)), 'cpol_host_alloc')
+        buf = (C.c_uint8 * int(nbytes)).from_address(h.value)
+        arr = np.frombuffer(buf, dtype=np.uint8)
+        self._keep.append(buf)
+        return arr
 
     def enable_timing(self, on=True):
         """True / 1: events around every stage; 2: around the PSD stage only; False: off."""

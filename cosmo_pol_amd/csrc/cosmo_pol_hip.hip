@@ -4,16 +4,15 @@
 // One call of cpol_run_sweep = the work of one `pool.map(worker, azimuths)`
 // of the reference (cosmo_pol/radar_operator.py:429-432) for the rays given:
 //
-//   k_trajectory      (ray, vertical node, gate)      4/3-earth ray path
-//   k_interp_sweep    (ray, sub-beam, gate)           geodesic + rotated pole +
-//                                                     trilinear gather, all vars
+//   k_interp_sweep    (ray, sub-beam, gate)           ray path (4/3 earth / orbit), geodesic,
+//                                                     rotated pole, trilinear gather, all vars
 //   k_classify        (sub-beam gate)                 melting, PSD parameters,
 //                                                     LUT bins, bucket histogram
-//   k_bucket_scan / k_bucket_scatter                  counting sort by LUT slice
-//   k_psd_{gamma,ice,melting}  (64 items per wave)    PSD x table integration
-//   k_final_gate      (ray, gate)                     sub-beam/hydrometeor sums,
-//                                                     polarimetric variables
-//   k_final_ray       (ray)                           range scans, sensitivity
+//   k_bucket_scan / k_bucket_scatter                  counting sort by LUT slice + unit list
+//   k_psd_{uniform,gamma,ice,melting}                 PSD x table integration
+//   k_final           (ray)                           sub-beam/hydrometeor sums, polarimetric
+//                                                     variables, range scans, sensitivity
+// = 6 launches for a 1-moment sweep (10 before the ray-path, unit-list and final merges).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -65,15 +64,18 @@ struct cpol_ctx {
     // per-sweep work buffers (grow only)
     DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site, b_nyq;
     DevBuf b_subsmooth, b_mlfilter, b_wgate, b_clk;
-    DevBuf b_varray, b_beam, b_spectrum, b_cutflag;
+    DevBuf b_varray, b_beam, b_spectrum;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
-        b_cursor, b_units, b_urange, b_totals, b_perm, b_res, b_err, b_pos, b_vn, b_icefirst, b_rvel, b_fh, b_fv;
+        b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
     int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0;
     bool keep_debug = false;
-    int *last_errflag = nullptr;
+    // sticky domain-error word (device): OR-ed by the kernels of every sweep, cleared only
+    // when it has been read AND reported (host-output sweeps, cpol_synchronize, cpol_counters)
+    int *d_errword = nullptr;
+    std::vector<void *> host_allocs;   // pinned host memory handed out by cpol_host_alloc
     uint64_t tables_version = 0;       // tag of the per-ray tables resident on the device
     long tables_shape[6] = {0, 0, 0, 0, 0, 0};
     // timing: one event set per sweep since cpol_enable_timing(ctx, 1); elapsed
@@ -154,6 +156,12 @@ int cpol_create(int device, cpol_ctx **out)
         return CPOL_ERR_HIP;
     }
     ctx->own_stream = true;
+    if (hipMalloc((void **)&ctx->d_errword, sizeof(int)) != hipSuccess ||
+        hipMemset(ctx->d_errword, 0, sizeof(int)) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return CPOL_ERR_HIP;
+    }
     // opt-in (CPOL_USE_GRAPH=1): replaying the captured sequence cuts the host time of a sweep
     // 4x (0.12 -> 0.03 ms) but is no faster on the device (0.232 vs 0.222 ms single lane) and
     // slows three-lane throughput by a quarter when graph launches and plain launches mix
@@ -178,11 +186,11 @@ void cpol_destroy(cpol_ctx *ctx)
         ctx->parent->n_children -= 1;
     }
     DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj_in, &ctx->b_geo, &ctx->b_subh, &ctx->b_subv,
-                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_subsmooth, &ctx->b_mlfilter, &ctx->b_wgate, &ctx->b_clk, &ctx->b_varray, &ctx->b_beam, &ctx->b_spectrum, &ctx->b_cutflag, &ctx->b_vals, &ctx->b_mask,
+                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_subsmooth, &ctx->b_mlfilter, &ctx->b_wgate, &ctx->b_clk, &ctx->b_varray, &ctx->b_beam, &ctx->b_spectrum, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
-                     &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_cursor, &ctx->b_units,
-                     &ctx->b_urange, &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_err, &ctx->b_pos,
-                     &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel, &ctx->b_fh, &ctx->b_fv,
+                     &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_units,
+                     &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_pos,
+                     &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel,
                      &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model};
     for (DevBuf *b : all) free_buf(*b);
     for (auto &b : ctx->b_out) free_buf(b);
@@ -201,6 +209,8 @@ void cpol_destroy(cpol_ctx *ctx)
     }
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->d_errword) (void)hipFree(ctx->d_errword);
+    for (void *h : ctx->host_allocs) (void)hipHostFree(h);
     delete ctx;
 }
 
@@ -223,6 +233,13 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
         return CPOL_ERR_HIP;
     }
     c->own_stream = true;
+    if (hipMalloc((void **)&c->d_errword, sizeof(int)) != hipSuccess ||
+        hipMemset(c->d_errword, 0, sizeof(int)) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        parent->err = "cpol_fork: hipMalloc failed";
+        return CPOL_ERR_NOMEM;
+    }
     c->use_graph = parent->use_graph;
     c->parent = parent;
     c->model_staged = parent->model_staged;
@@ -261,11 +278,54 @@ int cpol_get_stream(cpol_ctx *ctx, void **hip_stream)
     return CPOL_OK;
 }
 
+// reads the sticky domain-error word (the stream has drained); a set word is cleared and
+// reported ONCE as CPOL_ERR_DOMAIN -- so a sweep that left the model domain is never lost
+// behind later sweeps of the same context (the reference raises IndexError at that radial)
+static int report_domain_error(cpol_ctx *ctx)
+{
+    int flag = 0;
+    HIPCHK(hipMemcpy(&flag, ctx->d_errword, sizeof flag, hipMemcpyDeviceToHost));
+    if (!flag) return CPOL_OK;
+    HIPCHK(hipMemset(ctx->d_errword, 0, sizeof(int)));
+    ctx->err = "RADAR DOMAIN IS NOT ENTIRELY CONTAINED IN COSMO SIMULATION DOMAIN";
+    return CPOL_ERR_DOMAIN;
+}
+
 int cpol_synchronize(cpol_ctx *ctx)
 {
     if (!ctx) return CPOL_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return report_domain_error(ctx);
+}
+
+int cpol_host_alloc(cpol_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out || bytes == 0) return CPOL_ERR_ARG;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    void *h = nullptr;
+    if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess || !h) {
+        ctx->err = "cpol_host_alloc: hipHostMalloc failed";
+        return CPOL_ERR_NOMEM;
+    }
+    ctx->host_allocs.push_back(h);
+    *out = h;
     return CPOL_OK;
+}
+
+int cpol_host_free(cpol_ctx *ctx, void *p)
+{
+    if (!ctx || !p) return CPOL_ERR_ARG;
+    for (size_t i = 0; i < ctx->host_allocs.size(); ++i)
+        if (ctx->host_allocs[i] == p) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));      // no copy into it may be in flight
+            (void)hipHostFree(p);
+            ctx->host_allocs.erase(ctx->host_allocs.begin() + (long)i);
+            return CPOL_OK;
+        }
+    ctx->err = "cpol_host_free: not a cpol_host_alloc pointer of this context";
+    return CPOL_ERR_ARG;
 }
 
 int cpol_enable_timing(cpol_ctx *ctx, int on)
@@ -344,6 +404,12 @@ int cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro)
         ctx->err = "cpol_set_num_hydro: not on a lane, and not while lanes of this context exist";
         return CPOL_ERR_ARG;
     }
+    long total = 0;
+    for (int j = 0; j < n_hydro; ++j) total += (long)ctx->hs.h[j].d.n_e * ctx->hs.h[j].d.n_t;
+    if (total > 1024L * CPOL_SCAN_MAX_PER) {           // checked BEFORE any state changes
+        ctx->err = "too many LUT slices (elevation x temperature bins) for the bucket scan";
+        return CPOL_ERR_ARG;
+    }
     ctx->hs.n_hydro = n_hydro;
     ctx->stage_serial++;
     int base = 0;
@@ -352,10 +418,6 @@ int cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro)
         base += ctx->hs.h[j].d.n_e * ctx->hs.h[j].d.n_t;
     }
     ctx->hs.n_keys = base;
-    if (base > 1024 * CPOL_SCAN_MAX_PER) {
-        ctx->err = "too many LUT slices (elevation x temperature bins) for the bucket scan";
-        return CPOL_ERR_ARG;
-    }
     return CPOL_OK;
 }
 
@@ -417,8 +479,11 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->hydro_staged[slot] = true;
     ctx->stage_serial++;
-    if (slot >= ctx->hs.n_hydro) cpol_set_num_hydro(ctx, slot + 1);
-    else cpol_set_num_hydro(ctx, ctx->hs.n_hydro);
+    const int rc_n = cpol_set_num_hydro(ctx, slot >= ctx->hs.n_hydro ? slot + 1 : ctx->hs.n_hydro);
+    if (rc_n != CPOL_OK) {
+        ctx->hydro_staged[slot] = false;               // the slot does not count as staged
+        return rc_n;
+    }
     return CPOL_OK;
 }
 
@@ -553,6 +618,20 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     const long n_rg = (long)n_rays * ng;
     const long n_sbg = n_rg * n_sub;
     if (n_sbg >= (1L << 31)) { ctx->err = "cpol_run_sweep: too many sub-beam gates in one call"; return CPOL_ERR_ARG; }
+    {
+        // re-validated here: a C caller may have reached this state through cpol_stage_hydro alone
+        long total = 0;
+        for (int j = 0; j < n_hyd; ++j) total += (long)ctx->hs.h[j].d.n_e * ctx->hs.h[j].d.n_t;
+        if (total != n_keys || n_keys > 1024 * CPOL_SCAN_MAX_PER) {
+            ctx->err = "cpol_run_sweep: inconsistent / too many LUT slices for the bucket scan (restage the hydrometeors)";
+            return CPOL_ERR_ARG;
+        }
+        if ((long)n_rays * n_sub >= (1L << 31) || cdiv(ng, 256) > 65535 || p->outputs_on_device < 0 ||
+            p->outputs_on_device > 2) {
+            ctx->err = "cpol_run_sweep: launch-grid limits exceeded (n_rays * n_sub < 2^31, n_gates <= 65535 * 256) or bad outputs_on_device";
+            return CPOL_ERR_ARG;
+        }
+    }
     int rc;
 
     // ---- per-sweep host tables -> device (skipped when the caller's tag is unchanged) ----
@@ -587,7 +666,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     }
 
     // ---- work buffers ----
-    ENSURE(ctx->b_traj, (size_t)n_rays * n_v * 3 * ng * sizeof(float));
+    if (mode == CPOL_GEOM_HOST_PATHS || ctx->keep_debug)
+        ENSURE(ctx->b_traj, (size_t)n_rays * n_v * 3 * ng * sizeof(float));
     ENSURE(ctx->b_vals, (size_t)n_vars * n_sbg * sizeof(float));
     ENSURE(ctx->b_mask, (size_t)n_sbg);
     ENSURE(ctx->b_elev, (size_t)n_sbg * sizeof(float));
@@ -598,9 +678,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_key, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_pos, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_par, (size_t)n_hyd * CPOL_MAX_PAR * n_sbg * sizeof(double));
-    ENSURE(ctx->b_count, (size_t)(n_keys + 1) * sizeof(int));     // [n_keys] counts + error flag
+    ENSURE(ctx->b_count, (size_t)(n_keys + 1) * sizeof(int));
     ENSURE(ctx->b_offset, (size_t)n_keys * sizeof(int));
-    ENSURE(ctx->b_cursor, (size_t)n_keys * sizeof(int));
     const long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
     ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
     ENSURE(ctx->b_totals, 2 * sizeof(long long));
@@ -615,8 +694,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             ctx->err = "cpol_run_sweep: Doppler scheme 3 needs n_vbins in [2, 4097], tables->varray, var_rho and no melting species";
             return CPOL_ERR_ARG;
         }
-        for (int j = 0; j < n_hyd; ++j)
+        for (int j = 0; j < n_hyd; ++j) {
             if (!ctx->ss.s[j].rcs32) { ctx->err = "cpol_run_sweep: Doppler scheme 3 needs cpol_stage_spectrum_tables"; return CPOL_ERR_ARG; }
+            if (ctx->hs.h[j].d.n_d != ctx->hs.h[0].d.n_d) {     // the LDS image is sized from slot 0
+                ctx->err = "cpol_run_sweep: Doppler scheme 3 needs the same number of diameter bins in every table";
+                return CPOL_ERR_ARG;
+            }
+        }
         if ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) * sizeof(float) > 64 * 1024) {
             ctx->err = "cpol_run_sweep: Doppler scheme 3: n_hydro x (n_d + n_vbins) exceeds the LDS of a workgroup";
             return CPOL_ERR_ARG;
@@ -633,7 +717,6 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (dop3) {
         ENSURE(ctx->b_beam, (size_t)n_sbg * n_vb * sizeof(float));
         ENSURE(ctx->b_spectrum, (size_t)n_rg * n_vb * sizeof(double));
-        ENSURE(ctx->b_cutflag, (size_t)n_rg);
         if ((rc = upload(ctx, ctx->b_varray, t->varray, (size_t)n_vb * sizeof(double)))) return rc;
     }
     // output staging (device): 9 float fields + PHIDP
@@ -646,16 +729,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_out[O_DIST], (size_t)n_rg * sizeof(float));
     ENSURE(ctx->b_out[O_HGT], (size_t)n_rg * sizeof(float));
     // kernels write straight into caller-owned device buffers when given
-    const bool dev = p->outputs_on_device != 0;
+    const bool dev = p->outputs_on_device == 1;
+    const bool async_host = p->outputs_on_device == 2;    // pinned host buffers, no wait
     void *const user_out[14] = {out->ZH, out->ZV, out->ZDR, out->KDP, out->DELTA_HV, out->PHIDP,
                                 out->RHOHV, out->ATT_H, out->ATT_V, out->mask, out->lats, out->lons,
                                 out->dist, out->heights};
     void *T[14];
     for (int k = 0; k < 14; ++k) T[k] = (dev && user_out[k]) ? user_out[k] : ctx->b_out[k].p;
-    if (p->with_attenuation) {
-        ENSURE(ctx->b_fh, (size_t)n_rg * sizeof(float));
-        ENSURE(ctx->b_fv, (size_t)n_rg * sizeof(float));
-    }
     const bool want_szi = ctx->keep_debug;
     if (want_szi) ENSURE(ctx->b_szinteg, (size_t)n_rg * n_hyd * CPOL_N_SZ * sizeof(float));
     const bool want_szt = out->sz_total != nullptr || ctx->keep_debug;
@@ -663,11 +743,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     const bool want_model = p->integrate_model && out->model_vars;
     if (want_model) ENSURE(ctx->b_model, (size_t)n_vars * n_rg * sizeof(double));
 
-    // bucket counters + error flag start at zero: cleared by k_trajectory (one launch less),
-    // or by a memset when the ray paths come from the host
-    if (mode == CPOL_GEOM_HOST_PATHS)
-        HIPCHK(hipMemsetAsync(ctx->b_count.p, 0, (size_t)(n_keys + 1) * sizeof(int), st));
-    int *const d_errflag = (int *)ctx->b_count.p + n_keys;
+    // the bucket counters start at zero: cleared by k_interp_sweep (no fill kernel); the domain
+    // error word is sticky (cleared when reported)
+    int *const d_errflag = ctx->d_errword;
 
     const bool tm = ctx->timing == 1;          // events around every stage
     const bool tm_psd = ctx->timing != 0;      // ... or only around the PSD stage
@@ -685,11 +763,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // nothing to upload it is captured into a HIP graph and replayed while the arguments stay
     // the same (one graph launch instead of ten kernel launches).
     auto launch_all = [&]() -> int {
-    // ---- 1. ray paths ----
+    // ---- 1. ray paths: evaluated inside k_interp_sweep; host-supplied paths are uploaded ----
     if (mode == CPOL_GEOM_HOST_PATHS) {
         HIPCHK(hipMemcpyAsync(ctx->b_traj.p, t->paths, (size_t)n_rays * n_v * 3 * ng * sizeof(float),
                               hipMemcpyHostToDevice, st));
-    } else {
+    } else if (ctx->keep_debug) {
+        // parity access to the ray paths (cpol_debug_read "traj"): same device function
+        if ((long)n_rays * n_v > 65535) { ctx->err = "cpol_run_sweep: debug ray paths need n_rays * n_vnodes <= 65535"; return CPOL_ERR_ARG; }
         TrajArgs ta{};
         ta.ray_traj = (const double *)ctx->b_traj_in.p;
         ta.site = t->site ? (const double *)ctx->b_site.p : nullptr;
@@ -697,15 +777,20 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ta.n_rays = n_rays; ta.n_v = n_v; ta.n_gates = ng; ta.mode = mode;
         ta.range0 = p->range0; ta.range_step = p->range_step;
         ta.ke = p->ke; ta.re = p->re; ta.alt = p->radar_alt;
-        ta.zero_buf = (int *)ctx->b_count.p;
-        ta.zero_n = n_keys + 1;
         hipLaunchKernelGGL(k_trajectory, dim3(cdiv(ng, 256), n_rays * n_v), dim3(256), 0, st, ta);
     }
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_TRAJ], st));
 
     // ---- 2. gate interpolation ----
     InterpArgs ia{};
-    ia.traj = (const float *)ctx->b_traj.p;
+    ia.traj = (mode == CPOL_GEOM_HOST_PATHS) ? (const float *)ctx->b_traj.p : nullptr;
+    ia.rp.ray_traj = (const double *)ctx->b_traj_in.p;
+    ia.rp.site = t->site ? (const double *)ctx->b_site.p : nullptr;
+    ia.rp.n_v = n_v; ia.rp.mode = mode;
+    ia.rp.range0 = p->range0; ia.rp.range_step = p->range_step;
+    ia.rp.ke = p->ke; ia.rp.re = p->re; ia.rp.alt = p->radar_alt;
+    ia.zero_buf = (int *)ctx->b_count.p;
+    ia.zero_n = n_keys;
     ia.geo = (const double *)ctx->b_geo.p;
     ia.sub_h = (const int *)ctx->b_subh.p;
     ia.sub_v = (const int *)ctx->b_subv.p;
@@ -722,7 +807,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.central_sub = n_sub / 2;
     ia.sin_u1 = p->sin_u1; ia.cos_u1 = p->cos_u1; ia.lon1 = p->radar_lon;
     ia.site = t->site ? (const double *)ctx->b_site.p : nullptr;
-    hipLaunchKernelGGL(k_interp_sweep, dim3(cdiv(ng, 256), n_sub, n_rays), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_interp_sweep, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256), 0, st,
                        ctx->model, ia);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
 
@@ -773,7 +858,6 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ScanArgs sa{};
     sa.count = (const int *)ctx->b_count.p;
     sa.offset = (int *)ctx->b_offset.p;
-    sa.uoffset = (int *)ctx->b_cursor.p;
     sa.units = (WorkUnit *)ctx->b_units.p;
     sa.totals = (long long *)ctx->b_totals.p;
     sa.n_keys = n_keys;
@@ -783,8 +867,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sa.key_base[j] = ctx->hs.h[j].key_base;
         sa.unit_shift[j] = (d.psd_family == CPOL_PSD_GAMMA && d.uniform_grid) ? 7 : 6;
     }
-    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
-    hipLaunchKernelGGL(k_make_units, dim3(cdiv((long)n_keys * 64, 256)), dim3(256), 0, st, sa);
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);     // + the unit list
     hipLaunchKernelGGL(k_bucket_scatter, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st,
                        (const int *)ctx->b_key.p, (const int *)ctx->b_pos.p,
                        (const int *)ctx->b_offset.p, (int *)ctx->b_perm.p, n_sbg, n_hyd);
@@ -865,8 +948,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     double sum_w = 0;
     for (int s = 0; s < n_sub; ++s) sum_w += t->sub_w[s];
     fa.sum_w = sum_w;
-    fa.FH = p->with_attenuation ? (float *)ctx->b_fh.p : nullptr;
-    fa.FV = p->with_attenuation ? (float *)ctx->b_fv.p : nullptr;
+    fa.with_attenuation = p->with_attenuation;
     fa.res_km = (float)(p->radial_res / 1000.);
     fa.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
     fa.RVEL = nullptr;
@@ -897,10 +979,14 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                                    (IceFirst *)ctx->b_icefirst.p, ng);
         }
     }
-    if (dop3) fa.RVEL = nullptr;            // RVEL comes from the spectrum below
-    hipLaunchKernelGGL(k_final_gate, dim3(cdiv(n_rg, 256)), dim3(256), 0, st, fa);
+    ScanRayArgs ra{};
+    ra.PHIDP = (float *)T[O_PHIDP];
+    ra.RVEL = nullptr;
+    ra.sens_thr = cut ? (const double *)ctx->b_sens.p : nullptr;
+    ra.radial_res = (float)p->radial_res;
     if (dop3) {
-        // ---- 6b. Doppler spectrum (scheme 3) ----
+        // ---- 6b. Doppler spectrum (scheme 3): RVEL comes from the spectrum ----
+        fa.RVEL = nullptr;
         SpecArgs sp{};
         sp.vals = (const float *)ctx->b_vals.p;
         sp.mask = (const signed char *)ctx->b_mask.p;
@@ -936,24 +1022,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sf.spectrum = (double *)ctx->b_spectrum.p;
         sf.RVEL = (double *)ctx->b_rvel.p;
         sf.n_rays = n_rays; sf.n_gates = ng; sf.n_sub = n_sub; sf.n_v = n_vb;
+        // cut_at_sensitivity censors the spectrum bin by bin (doppler_scatter.py:839-850)
+        sf.sens_thr = cut ? (const double *)ctx->b_sens.p : nullptr;
         hipLaunchKernelGGL(k_spec_final, dim3((unsigned)n_rg), dim3(64), 0, st, sf);
-        fa.RVEL = (double *)ctx->b_rvel.p;   // for the sensitivity cut in k_final_ray
+        ra.RVEL = (double *)ctx->b_rvel.p;   // censored with the other observables in k_final
     }
-
-    ScanRayArgs ra{};
-    ra.ZH = fa.ZH; ra.ZV = fa.ZV; ra.ZDR = fa.ZDR; ra.KDP = fa.KDP; ra.DELTA_HV = fa.DELTA_HV;
-    ra.PHIDP = (float *)T[O_PHIDP]; ra.RHOHV = fa.RHOHV; ra.ATT_H = fa.ATT_H;
-    ra.ATT_V = fa.ATT_V; ra.RVEL = fa.RVEL;
-    ra.cutflag = (dop3 && cut) ? (unsigned char *)ctx->b_cutflag.p : nullptr;
-    ra.FH = fa.FH; ra.FV = fa.FV;
-    ra.sens_thr = cut ? (const double *)ctx->b_sens.p : nullptr;
-    ra.n_rays = n_rays; ra.n_gates = ng; ra.with_attenuation = p->with_attenuation;
-    ra.radial_res = (float)p->radial_res;
-    ra.res_km = (float)(p->radial_res / 1000.);
-    hipLaunchKernelGGL(k_final_ray, dim3(n_rays), dim3(192), (size_t)3 * ng * sizeof(float), st, ra);
-    if (dop3 && cut)
-        hipLaunchKernelGGL(k_spec_cut, dim3(cdiv(n_rg * n_vb, 256)), dim3(256), 0, st,
-                           (const unsigned char *)ctx->b_cutflag.p, (double *)ctx->b_spectrum.p, n_rg, n_vb);
+    if ((size_t)3 * ng * sizeof(float) > 64 * 1024) { ctx->err = "cpol_run_sweep: n_gates too large for the range scans (3 * n_gates floats of LDS)"; return CPOL_ERR_ARG; }
+    hipLaunchKernelGGL(k_final, dim3(n_rays), dim3(CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
     HIPCHK(hipGetLastError());
 
@@ -975,9 +1050,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         mix(&ctx->stage_serial, sizeof ctx->stage_serial);
         void *arena[] = {ctx->b_traj.p, ctx->b_vals.p, ctx->b_mask.p, ctx->b_elev.p, ctx->b_qmelt.p,
                          ctx->b_fwmelt.p, ctx->b_key.p, ctx->b_pos.p, ctx->b_par.p, ctx->b_count.p,
-                         ctx->b_offset.p, ctx->b_cursor.p, ctx->b_units.p, ctx->b_totals.p, ctx->b_perm.p,
-                         ctx->b_res.p, ctx->b_vn.p, ctx->b_icefirst.p, ctx->b_rvel.p, ctx->b_fh.p,
-                         ctx->b_fv.p, ctx->b_wgate.p, ctx->b_traj_in.p, ctx->b_geo.p, ctx->b_subh.p,
+                         ctx->b_offset.p, ctx->b_units.p, ctx->b_totals.p, ctx->b_perm.p,
+                         ctx->b_res.p, ctx->b_vn.p, ctx->b_icefirst.p, ctx->b_rvel.p, ctx->b_wgate.p, ctx->b_traj_in.p, ctx->b_geo.p, ctx->b_subh.p,
                          ctx->b_subv.p, ctx->b_subw.p, ctx->b_sens.p, ctx->b_site.p, ctx->b_nyq.p,
                          ctx->b_subsmooth.p, ctx->b_mlfilter.p, (void *)st};
         mix(arena, sizeof arena);
@@ -1020,17 +1094,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ctx->counters.n_subbeam_gates = n_sbg;
     ctx->counters.n_gates = n_rg;
 
-    if (!dev || ctx->keep_debug) {
-        // host-visible results requested: wait, then surface the domain error
+    if ((!dev && !async_host) || ctx->keep_debug) {
+        // blocking host outputs: wait, then surface the domain error.  Device outputs and
+        // non-blocking pinned-host outputs (outputs_on_device = 2) return at once: results
+        // are valid, and a domain error is reported, after cpol_synchronize / cpol_counters.
         HIPCHK(hipStreamSynchronize(st));
-        int flag = 0;
-        HIPCHK(hipMemcpy(&flag, d_errflag, sizeof flag, hipMemcpyDeviceToHost));
-        if (flag) {
-            ctx->err = "RADAR DOMAIN IS NOT ENTIRELY CONTAINED IN COSMO SIMULATION DOMAIN";
-            return CPOL_ERR_DOMAIN;
-        }
+        return report_domain_error(ctx);
     }
-    ctx->last_errflag = d_errflag;
     return CPOL_OK;
 }
 
@@ -1068,9 +1138,7 @@ int cpol_counters(cpol_ctx *ctx, cpol_counters_t *out)
         // device-side totals of the LAST sweep (valid once the stream drained)
         HIPCHK(hipStreamSynchronize(ctx->stream));
         long long totals[2] = {0, 0};
-        int flag = 0;
         HIPCHK(hipMemcpy(totals, ctx->b_totals.p, sizeof totals, hipMemcpyDeviceToHost));
-        if (ctx->last_errflag) HIPCHK(hipMemcpy(&flag, ctx->last_errflag, sizeof flag, hipMemcpyDeviceToHost));
         ctx->counters.n_valid_items = totals[0];
         ctx->counters.n_work_units = totals[1];
         if (ctx->ev_used > 0) {
@@ -1100,11 +1168,8 @@ int cpol_counters(cpol_ctx *ctx, cpol_counters_t *out)
             ctx->counters.ms_final = (float)(acc[EV_FINAL] * inv);
             ctx->counters.ms_total = (float)(tot * inv);
         }
-        if (flag) {
-            ctx->err = "RADAR DOMAIN IS NOT ENTIRELY CONTAINED IN COSMO SIMULATION DOMAIN";
-            *out = ctx->counters;
-            return CPOL_ERR_DOMAIN;
-        }
+        *out = ctx->counters;
+        return report_domain_error(ctx);
     }
     *out = ctx->counters;
     return CPOL_OK;

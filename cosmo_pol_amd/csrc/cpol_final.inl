@@ -128,7 +128,7 @@ struct FinalArgs {
     float *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *RHOHV, *ATT_H, *ATT_V;   // work / outputs
     double *mask;               // [n_rg]
     double *model_vars;         // [n_vars][n_rg] or NULL
-    float *FH, *FV;             // [n_rg] per-gate two-way attenuation factors (or NULL)
+    int with_attenuation;
     float res_km;               // (float)(radial_res / 1000.)
     int n_rays, n_gates, n_sub, n_hydro, n_vars;
     float c_zh, c_kdp, c_2w;    // wavelength^4/(pi^5 K^2), 1e-3*(180/pi)*wavelength, 2*wavelength
@@ -147,12 +147,13 @@ struct FinalArgs {
     const double *wgate;        // [n_sbg] per-gate sub-beam weights (scheme 'ml') or NULL
 };
 
-__global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
+// one output gate; returns the operands of the three range scans (2 KDP with NaN -> 0, and
+// the two-way attenuation factors of the gate, NaN -> 1)
+__device__ __forceinline__ void final_gate(const FinalArgs &a, int ray, int gate, float &k2_out,
+                                           float &fh_out, float &fv_out)
 {
-    const long rg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n_rg = (long)a.n_rays * a.n_gates;
-    if (rg >= n_rg) return;
-    const int ray = (int)(rg / a.n_gates), gate = (int)(rg % a.n_gates);
+    const long rg = (long)ray * a.n_gates + gate;
     const long n_sbg = n_rg * a.n_sub;
     const long sbg0 = (long)ray * a.n_sub * a.n_gates + gate;      // + sub * n_gates
     const float qnan = __builtin_nanf("");
@@ -210,17 +211,21 @@ __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
     a.ZH[rg] = a.c_zh * xs_h;
     a.ZV[rg] = a.c_zh * xs_v;
     a.ZDR[rg] = xs_h / xs_v;
-    a.KDP[rg] = a.c_kdp * (tot[10] - tot[8]);
+    const float kdp = a.c_kdp * (tot[10] - tot[8]);
+    a.KDP[rg] = kdp;
+    const float k2 = 2.0f * kdp;
+    k2_out = (k2 == k2) ? k2 : 0.0f;                           // nan_cumsum
     const float att_h = 4.343e-3f * (a.c_2w * tot[11]);
     const float att_v = 4.343e-3f * (a.c_2w * tot[9]);
     a.ATT_H[rg] = att_h;
     a.ATT_V[rg] = att_v;
-    if (a.FH) {
+    fh_out = fv_out = 1.0f;
+    if (a.with_attenuation) {
         // 10**(-0.1*A*(radial_res/1000.)) in float32 (doppler_scatter.py:413-414); NaN -> 1
         float fh = (float)exp10((double)(-0.1f * att_h * a.res_km));
         float fv = (float)exp10((double)(-0.1f * att_v * a.res_km));
-        a.FH[rg] = (fh == fh) ? fh : 1.0f;
-        a.FV[rg] = (fv == fv) ? fv : 1.0f;
+        fh_out = (fh == fh) ? fh : 1.0f;
+        fv_out = (fv == fv) ? fv : 1.0f;
     }
     const float t47 = tot[4] + tot[7], t65 = tot[6] - tot[5];
     const float aa = t47 * t47 + t65 * t65;
@@ -299,21 +304,20 @@ __global__ __launch_bounds__(256) void k_final_gate(FinalArgs a)
     }
 }
 
-// One wavefront per ray: lanes stage the ray in LDS, lanes 0..2 run the three
-// strictly sequential float32 scans (np.cumsum / np.cumprod order), then all
-// lanes finish PHIDP, the attenuated ZDR and the sensitivity cut.
+// One workgroup per ray: every thread finishes gates (final_gate), the operands of the three
+// strictly sequential float32 range scans (np.cumsum / np.cumprod order is part of the
+// numerical contract) go through LDS, lane 0 of waves 0..2 runs one scan each, then all
+// threads finish PHIDP, the attenuated ZDR and the sensitivity cut.  (One launch instead of
+// the former k_final_gate + k_final_ray pair; no global round trip of the scan operands.)
 struct ScanRayArgs {
-    float *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *PHIDP, *RHOHV, *ATT_H, *ATT_V;
-    const float *FH, *FV;       // attenuation factors from k_final_gate
-    double *RVEL;
-    unsigned char *cutflag;     // [n_rays*n_gates] 1 where the sensitivity cut applied, or NULL
+    float *PHIDP;
+    double *RVEL;               // RVEL of the spectrum kernels (Doppler scheme 3) or NULL
     const double *sens_thr;     // [n_gates] or NULL
-    int n_rays, n_gates, with_attenuation;
     float radial_res;           // float32 cast of the python scalar
-    float res_km;               // (float)(radial_res / 1000.)
 };
 
-__global__ __launch_bounds__(192) void k_final_ray(ScanRayArgs a)
+#define CPOL_FINAL_THREADS 256
+__global__ __launch_bounds__(CPOL_FINAL_THREADS) void k_final(FinalArgs a, ScanRayArgs r)
 {
     extern __shared__ float lds[];          // [3][n_gates]
     const int ray = blockIdx.x;
@@ -323,19 +327,18 @@ __global__ __launch_bounds__(192) void k_final_ray(ScanRayArgs a)
     const int ng = a.n_gates;
     const long base = (long)ray * ng;
     float *s_k = lds, *s_h = lds + ng, *s_v = lds + 2 * ng;
-    for (int g = tid; g < ng; g += 192) {
-        float k2 = 2.0f * a.KDP[base + g];
-        s_k[g] = (k2 == k2) ? k2 : 0.0f;                       // nan_cumsum
-        if (a.with_attenuation) {
-            s_h[g] = a.FH[base + g];                           // nan_cumprod operands
-            s_v[g] = a.FV[base + g];
-        }
+    for (int g = tid; g < ng; g += CPOL_FINAL_THREADS) {
+        float k2, fh, fv;
+        final_gate(a, ray, g, k2, fh, fv);
+        s_k[g] = k2;
+        s_h[g] = fh;
+        s_v[g] = fv;
     }
     __syncthreads();
     // strictly sequential float32 scans, one wavefront (lane 0) per scan so that the
     // operation is wave-uniform; LDS is read in chunks of 8 so that the read latency is
     // paid once per chunk, not once per dependent step
-    if (lane == 0 && (wave == 0 || a.with_attenuation)) {
+    if (lane == 0 && (wave == 0 || (a.with_attenuation && wave < 3))) {
         float *sv = (wave == 0) ? s_k : (wave == 1 ? s_h : s_v);
         float c = 0.0f;
         int g = 0;
@@ -364,26 +367,27 @@ __global__ __launch_bounds__(192) void k_final_ray(ScanRayArgs a)
         }
     }
     __syncthreads();
-    for (int g = tid; g < ng; g += 192) {
+    double *rvel = a.RVEL ? a.RVEL : r.RVEL;
+    for (int g = tid; g < ng; g += CPOL_FINAL_THREADS) {
         const long i = base + g;
+        // (this thread wrote these four values itself in the first loop)
         float zh = a.ZH[i], zv = a.ZV[i];
-        float phidp = s_k[g] * a.radial_res / 1000.0f + a.DELTA_HV[i];
+        float phidp = s_k[g] * r.radial_res / 1000.0f + a.DELTA_HV[i];
         float zdr = a.ZDR[i];
         if (a.with_attenuation) zdr = (zh * s_h[g]) / (zv * s_v[g]);
         bool cut = false;
-        if (a.sens_thr) {
+        if (r.sens_thr) {
             // 10*np.log10(ZH) (float32) < threshold(r) (float64)
             float dbz = 10.0f * (float)log10((double)zh);
-            cut = (double)dbz < a.sens_thr[g];
+            cut = (double)dbz < r.sens_thr[g];
         }
-        if (a.cutflag) a.cutflag[i] = cut ? 1 : 0;
         if (cut) {
             const float qnan = __builtin_nanf("");
             a.ZH[i] = qnan; a.ZV[i] = qnan; a.KDP[i] = qnan; a.RHOHV[i] = qnan;
             zdr = qnan; phidp = qnan;
-            if (a.RVEL) a.RVEL[i] = __builtin_nan("");
+            if (rvel) rvel[i] = __builtin_nan("");
         }
-        a.PHIDP[i] = phidp;
+        r.PHIDP[i] = phidp;
         a.ZDR[i] = zdr;
     }
 }

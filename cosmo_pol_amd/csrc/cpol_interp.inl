@@ -41,8 +41,6 @@ struct TrajArgs {
     float *traj_out;
     int n_rays, n_v, n_gates, mode;
     double range0, range_step, ke, re, alt;
-    int *zero_buf;              // the sweep's bucket counters + error flag, cleared here
-    int zero_n;                 // (saves the two fill kernels of a hipMemsetAsync per sweep)
 };
 
 // height of candidate gate k of a downward-looking (spaceborne) ray
@@ -53,29 +51,28 @@ __device__ __forceinline__ double spaceborne_height(double r, double re, double 
     return -(temp - re) + alt;
 }
 
-__global__ void k_trajectory(TrajArgs a)
+// (s, h, e_deg) of gate g of (ray, vertical node) rv as float32, exactly as the reference
+// casts them: shared by k_trajectory and by k_interp_sweep (which evaluates it in place,
+// one launch less per sweep).  NaN = no gate here (spaceborne rays shorter than the batch).
+struct RayPathArgs {
+    const double *ray_traj;     // [n_rays][n_v][4]
+    const double *site;         // [n_rays][8] or NULL
+    int n_v, mode;
+    double range0, range_step, ke, re, alt;
+};
+
+__device__ __forceinline__ void ray_path(const RayPathArgs &a, int ray, int rv, int g,
+                                         float &s32, float &h32, float &e32)
 {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    int rv = blockIdx.y;                       // ray * n_v + vnode
-    if (a.zero_buf) {
-        const long total = (long)gridDim.x * gridDim.y * blockDim.x;
-        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-             i < a.zero_n; i += total)
-            a.zero_buf[i] = 0;
-    }
-    if (g >= a.n_gates) return;
-    const int ray = rv / a.n_v;
     const double el = a.ray_traj[rv * 4 + 0];
     const double sin_el = a.ray_traj[rv * 4 + 1];
     const double cos_el = a.ray_traj[rv * 4 + 2];
-    float *o = a.traj_out + (long)rv * 3 * a.n_gates;
     if (a.mode == CPOL_GEOM_SPACEBORNE) {
         const double *st = a.site + (long)ray * 8;
         const double alt = st[3], re = st[4];
         const int k0 = (int)st[5], n_kept = (int)st[6];
         if (g >= n_kept) {
-            const float qnan = __builtin_nanf("");
-            o[g] = qnan; o[a.n_gates + g] = qnan; o[2 * a.n_gates + g] = qnan;
+            s32 = h32 = e32 = __builtin_nanf("");
             return;
         }
         const double r = a.range0 + (double)(k0 + g) * a.range_step;
@@ -83,9 +80,9 @@ __global__ void k_trajectory(TrajArgs a)
         const double s = re * asin((r * cos_el) / (re + h));
         const double e = a.ray_traj[rv * 4 + 3]
             - atan(r * cos_el / (r * sin_el + re + alt)) * (180.0 / 3.14159265358979323846);
-        o[g] = (float)s;
-        o[a.n_gates + g] = (float)h;
-        o[2 * a.n_gates + g] = (float)e;      // degrees (the reference's second rad2deg is a bug)
+        s32 = (float)s;
+        h32 = (float)h;
+        e32 = (float)e;                       // degrees (the reference's second rad2deg is a bug)
         return;
     }
     const double alt = a.site ? a.site[(long)ray * 8 + 3] : a.alt;
@@ -98,11 +95,28 @@ __global__ void k_trajectory(TrajArgs a)
     double h = temp - ke_re + alt;
     double s = ke_re * asin((r * cos_el) / (ke_re + h));
     double e = el + atan(r * cos_el / (r * sin_el + ke_re + alt));
-    o[g] = (float)s;
-    o[a.n_gates + g] = (float)h;
+    s32 = (float)s;
+    h32 = (float)h;
     // np.rad2deg on float32: x * (180.0f / float(pi)), constant formed in float32
     const float rad2deg_f = 180.0f / 3.14159265358979323846f;
-    o[2 * a.n_gates + g] = (float)e * rad2deg_f;
+    e32 = (float)e * rad2deg_f;
+}
+
+// debug / parity only (cpol_debug_read "traj"): the sweep kernel evaluates ray_path itself
+__global__ void k_trajectory(TrajArgs a)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    int rv = blockIdx.y;                       // ray * n_v + vnode
+    if (g >= a.n_gates) return;
+    RayPathArgs rp;
+    rp.ray_traj = a.ray_traj; rp.site = a.site; rp.n_v = a.n_v; rp.mode = a.mode;
+    rp.range0 = a.range0; rp.range_step = a.range_step; rp.ke = a.ke; rp.re = a.re; rp.alt = a.alt;
+    float s32, h32, e32;
+    ray_path(rp, rv / a.n_v, rv, g, s32, h32, e32);
+    float *o = a.traj_out + (long)rv * 3 * a.n_gates;
+    o[g] = s32;
+    o[a.n_gates + g] = h32;
+    o[2 * a.n_gates + g] = e32;
 }
 
 // first candidate gate whose height is below `ceiling` (heights decrease along a
@@ -268,9 +282,13 @@ __global__ void k_interp_points(ModelDev m, const float *__restrict__ coords,
 // ---------------------------------------------------------------- sweep kernel
 // One thread per sub-beam gate; a wave = 64 consecutive gates of ONE sub-beam
 // (gate-stride coalesced stores, neighbouring gates share grid columns).
-// grid = (ceil(n_gates/256), n_sub, n_rays)
+// grid = (n_rays * n_sub, ceil(n_gates/256)): no 65535 limit on the number of rays
 struct InterpArgs {
-    const float *traj;          // [n_rays][n_v][3][n_gates]
+    const float *traj;          // [n_rays][n_v][3][n_gates] host-supplied ray paths
+                                // (CPOL_GEOM_HOST_PATHS) or NULL: ray_path() in place
+    RayPathArgs rp;
+    int *zero_buf;              // the sweep's bucket counters, cleared here (no fill kernel)
+    int zero_n;
     const double *geo;          // [n_rays][n_h][8]
     const int *sub_h, *sub_v;
     float *vals;                // [n_vars][n_sbg]
@@ -287,16 +305,26 @@ struct InterpArgs {
 
 __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
 {
-    const int gate = blockIdx.x * blockDim.x + threadIdx.x;
-    const int sub = blockIdx.y, ray = blockIdx.z;
+    const int gate = blockIdx.y * blockDim.x + threadIdx.x;
+    const int sub = blockIdx.x % a.n_sub, ray = blockIdx.x / a.n_sub;
+    if (a.zero_buf) {
+        const long total = (long)gridDim.x * gridDim.y * blockDim.x;
+        for (long i = ((long)blockIdx.x * gridDim.y + blockIdx.y) * blockDim.x + threadIdx.x;
+             i < a.zero_n; i += total)
+            a.zero_buf[i] = 0;
+    }
     if (gate >= a.n_gates) return;
     const int ih = a.sub_h[sub], jv = a.sub_v[sub];
     const long sbg = ((long)ray * a.n_sub + sub) * a.n_gates + gate;
     const long n_sbg = (long)a.n_rays * a.n_sub * a.n_gates;
 
-    const float *tr = a.traj + ((long)(ray * a.n_v + jv) * 3) * a.n_gates;
-    const float s32 = tr[gate], h32 = tr[a.n_gates + gate];
-    float e32 = tr[2 * a.n_gates + gate];
+    float s32, h32, e32;
+    if (a.traj) {
+        const float *tr = a.traj + ((long)(ray * a.n_v + jv) * 3) * a.n_gates;
+        s32 = tr[gate]; h32 = tr[a.n_gates + gate]; e32 = tr[2 * a.n_gates + gate];
+    } else {
+        ray_path(a.rp, ray, ray * a.n_v + jv, gate, s32, h32, e32);
+    }
     const float qnan = __builtin_nanf("");
     if (!(s32 == s32) || !(h32 == h32)) {
         // no gate here (ray shorter than the batch: spaceborne / host paths): counts
@@ -372,10 +400,18 @@ __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
     // interpolation.py:572-575 (IndexError in the reference)
     if (rlon < m.llc0 || rlat < m.llc1 || rlon > m.urc0 || rlat > m.urc1 ||
         !(rlon == rlon) || !(rlat == rlat)) {
-        atomicOr(a.error_flag, 1);
+        atomicOr(a.error_flag, 1);          // sticky until reported (cpol_synchronize / cpol_counters)
         a.mask[sbg] = 2;
         for (int v = 0; v < m.n_vars; ++v) a.vals[(long)v * n_sbg + sbg] = __builtin_nanf("");
         a.elev[sbg] = e32;
+        if (a.coords) { a.coords[2 * sbg] = rlat; a.coords[2 * sbg + 1] = rlon; }
+        if (sub == a.central_sub) {         // no stale data in the caller's buffers
+            const long rg = (long)ray * a.n_gates + gate;
+            if (a.lats) a.lats[rg] = __builtin_nan("");
+            if (a.lons) a.lons[rg] = __builtin_nan("");
+            if (a.dist) a.dist[rg] = qnan;
+            if (a.heights) a.heights[rg] = qnan;
+        }
         return;
     }
 

@@ -417,7 +417,6 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
 struct ScanArgs {
     const int *count;
     int *offset;                // [n_keys] first item slot of the bucket
-    int *uoffset;               // [n_keys] first work unit of the bucket
     WorkUnit *units;            // capacity >= n_items/64 + n_keys
     long long *totals;          // [0] = n_valid items, [1] = n_units
     int n_keys;
@@ -445,12 +444,21 @@ __device__ __forceinline__ int2 wave_inclusive_scan2(int2 v)
 }
 
 #define CPOL_SCAN_MAX_PER 32
+#define CPOL_SCAN_BIG_LIST 2048
+#define CPOL_SCAN_OWN_UNITS 8
+// Single workgroup: exclusive scans of the bucket counts (items and work units), then the
+// work-unit list itself (formerly a second kernel, k_make_units).  A thread writes the first
+// few units of its own buckets straight from registers; buckets with more units go on an LDS
+// list that the whole workgroup then fills in together.
 __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
 {
     __shared__ int2 s_wave[16];
+    __shared__ int s_big[CPOL_SCAN_BIG_LIST][4];            // key, count, item base, unit base
+    __shared__ int s_nbig;
     const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
     const int per = (a.n_keys + 1023) / 1024;               // <= CPOL_SCAN_MAX_PER (host checks)
     const int k0 = t * per;
+    if (t == 0) s_nbig = 0;
     // the thread's counts in registers: the (up to 32) loads are independent and issue together
     int cnt[CPOL_SCAN_MAX_PER];
 #pragma unroll
@@ -483,30 +491,38 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
     for (int i = 0; i < CPOL_SCAN_MAX_PER; ++i) {
         const int k = k0 + i;
         if (i < per && k < a.n_keys) {
-            const int sh = unit_shift_of(a, k);
+            const int sh = unit_shift_of(a, k), pu = 1 << sh;
+            const int c = cnt[i], nu = (c + pu - 1) >> sh;
             a.offset[k] = ibase;
-            a.uoffset[k] = ubase;
-            ibase += cnt[i];
-            ubase += (cnt[i] + (1 << sh) - 1) >> sh;
+            int own = nu;
+            if (nu > CPOL_SCAN_OWN_UNITS) {
+                const int slot = atomicAdd(&s_nbig, 1);
+                if (slot < CPOL_SCAN_BIG_LIST) {
+                    s_big[slot][0] = k; s_big[slot][1] = c; s_big[slot][2] = ibase; s_big[slot][3] = ubase;
+                    own = CPOL_SCAN_OWN_UNITS;
+                }
+            }
+            for (int u = 0; u < own; ++u) {
+                WorkUnit w;
+                w.key = k; w.start = ibase + u * pu; w.count = min(pu, c - u * pu); w.pad = 0;
+                a.units[ubase + u] = w;
+            }
+            ibase += c;
+            ubase += nu;
         }
     }
     if (t == 1023) { a.totals[0] = ibase; a.totals[1] = ubase; }
-}
-
-// one wavefront per bucket writes the bucket's work units
-__global__ __launch_bounds__(256) void k_make_units(ScanArgs a)
-{
-    const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (k >= a.n_keys) return;
-    const int c = a.count[k], ib = a.offset[k], ub = a.uoffset[k];
-    const int sh = unit_shift_of(a, k), per = 1 << sh;
-    for (int u = lane_id(); u * per < c; u += CPOL_WAVE) {
-        WorkUnit w;
-        w.key = k;
-        w.start = ib + u * per;
-        w.count = min(per, c - u * per);
-        w.pad = 0;
-        a.units[ub + u] = w;
+    __syncthreads();
+    const int nbig = min(s_nbig, CPOL_SCAN_BIG_LIST);
+    for (int b = 0; b < nbig; ++b) {
+        const int k = s_big[b][0], c = s_big[b][1], ib = s_big[b][2], ub = s_big[b][3];
+        const int sh = unit_shift_of(a, k), pu = 1 << sh;
+        const int nu = (c + pu - 1) >> sh;
+        for (int u = CPOL_SCAN_OWN_UNITS + t; u < nu; u += 1024) {
+            WorkUnit w;
+            w.key = k; w.start = ib + u * pu; w.count = min(pu, c - u * pu); w.pad = 0;
+            a.units[ub + u] = w;
+        }
     }
 }
 
@@ -1032,9 +1048,8 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS_U) void k_psd_uniform(HydroSet hs,
     psd_body<PSD_MODE_GAMMA_UNIFORM, DOP2>(hs, a);
 }
 
-// The melting flavour: without a register cap the inlined root / exp / log polynomials keep
-// their coefficients live in ~80 VGPRs (157 in total -> 3 waves per SIMD -> ONE workgroup per
-// CU); capped at 128 VGPRs two workgroups are resident.
+// The melting flavour (own kernel symbol so that its register allocation is reported and can be
+// steered separately; see csrc/resource_usage.txt after `make asm`).
 template <bool DOP2>
 __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting(HydroSet hs, PsdArgs a)
 {

@@ -198,6 +198,7 @@ struct SpecFinalArgs {
     const double *wgate;        // per-gate weights (scheme 'ml') or NULL
     const double *varray;
     const double *nyquist;      // [n_rays] or NULL
+    const double *sens_thr;     // [n_gates] dBZ threshold per gate, or NULL (no sensitivity cut)
     double *spectrum;           // [n_rg][n_v]
     double *RVEL;               // [n_rg]
     int n_rays, n_gates, n_sub, n_v;
@@ -220,7 +221,12 @@ __global__ __launch_bounds__(64) void k_spec_final(SpecFinalArgs a)
             const float wb = a.wgate ? (float)((double)b * a.wgate[sbg]) : b * (float)a.sub_w[s];
             acc += (double)wb;
         }
-        a.spectrum[rg * a.n_v + v] = acc;
+        // cut_at_sensitivity as get_PPI / get_RHI call it (a list of lists of radials,
+        // doppler_scatter.py:839-850) censors the spectrum BIN BY BIN with
+        // 10 log10(spectrum) < threshold(r); the gate-level ZH mask does not touch it.  (The cut
+        // runs after RVEL was derived from the uncensored spectrum, :422-437.)
+        a.spectrum[rg * a.n_v + v] =
+            (a.sens_thr && 10.0 * log10(acc) < a.sens_thr[gate]) ? __builtin_nan("") : acc;
         if (acc == acc) { num += a.varray[v] * acc; den += acc; }
     }
 #pragma unroll
@@ -240,11 +246,3 @@ __global__ __launch_bounds__(64) void k_spec_final(SpecFinalArgs a)
     }
 }
 
-// cut_at_sensitivity also censors the spectrum rows (doppler_scatter.py:849-860)
-__global__ __launch_bounds__(256) void k_spec_cut(const unsigned char *__restrict__ cut,
-                                                  double *__restrict__ spectrum, long n_rg, int n_v)
-{
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rg * n_v) return;
-    if (cut[i / n_v]) spectrum[i] = __builtin_nan("");
-}

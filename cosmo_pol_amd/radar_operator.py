@@ -93,6 +93,13 @@ class RadarScan(object):
         self.nrays = len(self.azimuth['data'])
         self.ngates = len(self.range['data'])
 
+    def to_radials(self):
+        """The scan as the reference's list of sweeps of Radial records
+        (what cut_at_sensitivity / PyartRadop consume, radar_operator.py:445-451): linear
+        units, row views of the per-sweep arrays."""
+        from .radial import to_radials
+        return [to_radials(s) for s in self.raw]
+
     def get_field(self, sweep_idx, variable):
         i0 = int(self.sweep_start_ray_index['data'][sweep_idx])
         i1 = int(self.sweep_stop_ray_index['data'][sweep_idx]) + 1
@@ -327,7 +334,7 @@ class RadarOperator(object):
         return True
 
     def simulate_rays(self, azimuths, elevations, on_device=False, device_outputs=None,
-                      apply_sensitivity=True, paths=None, lane=0):
+                      apply_sensitivity=True, paths=None, lane=0, pinned=False):
         """One batched launch sequence for the given rays (az[i], el[i]) of the
         ground radar of the configuration.  Returns a dict of [n_rays, n_gates]
         arrays (linear units, NaN = no data).
@@ -335,7 +342,12 @@ class RadarOperator(object):
         `paths`: optional float32 [n_rays, n_vnodes, 3, n_gates] host-computed ray
         paths (s, h, e_deg) replacing the 4/3-earth model (CPOL_GEOM_HOST_PATHS).
         `lane`: which forked context (stream + work buffers) runs the sweep; sweeps on
-        different lanes overlap on the GPU (one host thread per lane at a time)."""
+        different lanes overlap on the GPU (one host thread per lane at a time).
+        `pinned`: non-blocking host outputs -- the arrays returned are views of the lane's
+        page-locked slab, filled by device-to-host copies queued behind the kernels on the
+        lane's stream; call `wait(lane)` before reading them; they stay valid until the next
+        pinned sweep on the same lane.  (The copy of one sweep then overlaps the kernels of
+        the sweeps on the other lanes.)"""
         conf = self.__config
         coords = conf['radar']['coords']
         if coords[2] > K.MAX_MODEL_HEIGHT:
@@ -357,10 +369,26 @@ class RadarOperator(object):
         mode = N.GEOM_GROUND_43 if paths is None else N.GEOM_HOST_PATHS
         return self._run_rays(azimuths, elevations, coords, len(rr), float(rr[0]), mode,
                               device_outputs=device_outputs, apply_sensitivity=apply_sensitivity,
-                              paths=paths, lane=lane)
+                              paths=paths, lane=lane, pinned=pinned)
+
+    def wait(self, lane=0):
+        """Waits for the sweeps queued on `lane` (pinned / device outputs); raises IndexError
+        if one of them left the model domain."""
+        self._lane(lane).synchronize()
+
+    def _pinned_slab(self, lane, nbytes):
+        """Page-locked host slab of a lane (grow-only; owned by the lane's context)."""
+        with self._lock:
+            slabs = self.__dict__.setdefault('_slabs', {})
+            cur = slabs.get(lane)
+            if cur is None or cur[0] is not self._lane(lane) or cur[1].nbytes < nbytes:
+                ctx = self._lane(lane)
+                slabs[lane] = (ctx, ctx.host_alloc(int(nbytes * 1.25) + 4096))
+            return slabs[lane][1]
 
     def _run_rays(self, azimuths, elevations, coords, n_gates, range0, mode, device_outputs=None,
-                  apply_sensitivity=True, paths=None, site=None, sub=None, tables=None, lane=0):
+                  apply_sensitivity=True, paths=None, site=None, sub=None, tables=None, lane=0,
+                  pinned=False):
         conf = self.__config
         az = np.ascontiguousarray(np.asarray(azimuths, dtype=np.float64).reshape(-1))
         el = np.ascontiguousarray(np.asarray(elevations, dtype=np.float64).reshape(-1))
@@ -391,7 +419,7 @@ class RadarOperator(object):
         p.with_attenuation = int(conf['microphysics']['with_attenuation'])
         want_model = self.output_variables in ('all', 'only_model')
         p.integrate_model = int(want_model)
-        p.outputs_on_device = int(device_outputs is not None)
+        p.outputs_on_device = 1 if device_outputs is not None else (2 if pinned else 0)
         # Doppler schemes 1 (analytic mean fall speed) and 2 (rcs-weighted); none for GPM
         # (doppler_scatter.py:83-87); scheme 3 (full spectrum) is out of scope
         doppler = (conf['doppler']['scheme'] in (1, 2, 3) and conf['radar'].get('type') != 'GPM'
@@ -465,28 +493,61 @@ class RadarOperator(object):
 
         o = N.Outputs()
         res = {}
+        geom = None
         if device_outputs is not None:
             for k, ptr in device_outputs.items():
                 setattr(o, k, ptr)
         else:
             shape = (n_rays, n_gates)
-            for k in RADAR_FIELDS:
-                res[k] = np.empty(shape, dtype=np.float32)
+            spec = [(k, np.float32, shape) for k in RADAR_FIELDS]
             if doppler:
-                res['RVEL'] = np.empty(shape, dtype=np.float64)
+                spec.append(('RVEL', np.float64, shape))
             if spectrum:
-                res['DSPECTRUM'] = np.empty(shape + (len(varray),), dtype=np.float64)
-            res['mask'] = np.empty(shape, dtype=np.float64)
-            res['lats'] = np.empty(shape, dtype=np.float64)
-            res['lons'] = np.empty(shape, dtype=np.float64)
-            res['dist'] = np.empty(shape, dtype=np.float32)
-            res['heights'] = np.empty(shape, dtype=np.float32)
+                spec.append(('DSPECTRUM', np.float64, shape + (len(varray),)))
+            spec.append(('mask', np.float64, shape))
+            # gate coordinates of the central sub-beam depend on the ray tables only: of an
+            # unchanged table set (version tag) they are copied from the device once
+            gkey = ('geom', version, n_gates) if version else None
+            geom = self._cache.get(gkey) if gkey else None
+            if geom is None:
+                spec += [('lats', np.float64, shape), ('lons', np.float64, shape),
+                         ('dist', np.float32, shape), ('heights', np.float32, shape)]
             if want_model:
-                res['model_vars'] = np.empty((len(self._staged_vars),) + shape, dtype=np.float64)
+                spec.append(('model_vars', np.float64, (len(self._staged_vars),) + shape))
+            if pinned:
+                geo_names = ('lats', 'lons', 'dist', 'heights')
+                pin = [x for x in spec if not (gkey and x[0] in geo_names)]
+                sizes = [-(-int(np.prod(sh)) * np.dtype(dt).itemsize // 64) * 64 for _, dt, sh in pin]
+                slab = self._pinned_slab(lane, sum(sizes))
+                off = 0
+                for (k, dt, sh), nb in zip(pin, sizes):
+                    n_el = int(np.prod(sh))
+                    res[k] = slab[off:off + n_el * np.dtype(dt).itemsize].view(dt).reshape(sh)
+                    off += nb
+                for k, dt, sh in spec:          # cacheable geometry: own arrays (first sweep only)
+                    if k not in res:
+                        res[k] = np.empty(sh, dtype=dt)
+            else:
+                for k, dt, sh in spec:
+                    res[k] = np.empty(sh, dtype=dt)
             for k, a in res.items():
                 setattr(o, k, a.ctypes.data)
         self._lane(lane).run_sweep(p, t, o)
         del keep
+        if device_outputs is None:
+            if geom is None and gkey is not None:
+                if pinned:
+                    self._lane(lane).synchronize()      # once per table set: the arrays are complete
+                geom = {k: res[k] for k in ('lats', 'lons', 'dist', 'heights')}
+                for a in geom.values():
+                    a.flags.writeable = False       # shared by every later result of this table set
+                with self._lock:
+                    old = [k for k in self._cache if isinstance(k, tuple) and k and k[0] == 'geom']
+                    for k in old[:max(0, len(old) - 7)]:
+                        del self._cache[k]
+                    self._cache[gkey] = geom
+            elif geom is not None:
+                res.update(geom)
         res['n_sub'] = sub.n_sub
         return res
 

@@ -32,6 +32,7 @@
 #ifndef COSMO_POL_AMD_H
 #define COSMO_POL_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -53,6 +54,9 @@ enum {
 #define CPOL_MAX_VARS   24
 #define CPOL_MAX_HYDRO  8
 #define CPOL_N_SZ       12      /* columns of a LUT row (compute_lut_sz.py:265-297) */
+#define CPOL_TRAJ_STRIDE 4      /* doubles per (ray, vertical node) entry of the `traj` table */
+#define CPOL_GEO_STRIDE  8      /* doubles per (ray, horizontal node) entry of the `geo` table */
+#define CPOL_SITE_STRIDE 8      /* doubles per ray of the `site` table */
 
 /* PSD families (how N(D) is evaluated on the device) */
 enum {
@@ -120,7 +124,13 @@ typedef struct {
     int32_t with_melting, with_attenuation;
     int32_t integrate_model;    /* also return antenna-averaged model variables */
     int32_t apply_sensitivity;  /* 1: censor with tables->sens_thr (cut_at_sensitivity) */
-    int32_t outputs_on_device;  /* output pointers are device pointers          */
+    int32_t outputs_on_device;  /* 0: output pointers are host buffers, the call returns when
+                                   they are filled; 1: device pointers, the kernels write
+                                   them in place, the call returns at once; 2: PINNED host
+                                   buffers (cpol_host_alloc), device-to-host copies are queued
+                                   on the context's stream and the call returns at once --
+                                   results (and a deferred CPOL_ERR_DOMAIN) after
+                                   cpol_synchronize                                        */
     int32_t simulate_doppler;   /* 0 off, 1 / 2 / 3 = Doppler scheme of the reference (RVEL;
                                    3 = full Doppler spectrum, doppler_scatter.py:335-391) */
     int32_t geometry_mode;      /* CPOL_GEOM_*                                   */
@@ -151,9 +161,10 @@ enum {
 
 /* per-ray host-side tables (cpol_ray_tables fills them) */
 typedef struct {
-    const double *traj;         /* [n_rays][n_vnodes][3] : el_rad, sin el, cos el */
-    const double *geo;          /* [n_rays][n_hnodes][8] : sin a1, cos a1, sigma1,
-                                   sin alpha, b*A, B, C, azimuth_rad            */
+    const double *traj;         /* [n_rays][n_vnodes][CPOL_TRAJ_STRIDE = 4] : el_rad,
+                                   sin el, cos el, el_deg                       */
+    const double *geo;          /* [n_rays][n_hnodes][CPOL_GEO_STRIDE = 8] : sin a1,
+                                   cos a1, sigma1, sin alpha, b*A, B, C, azimuth_rad */
     const int32_t *sub_h;       /* [n_sub] horizontal node of each kept sub-beam */
     const int32_t *sub_v;       /* [n_sub] vertical node                        */
     const double *sub_w;        /* [n_sub] quadrature weight                    */
@@ -214,7 +225,17 @@ int  cpol_fork(cpol_ctx *parent, cpol_ctx **out);
 const char *cpol_last_error(cpol_ctx *ctx);
 /* use an externally created hipStream_t (e.g. torch's current stream); NULL = own stream */
 int  cpol_set_stream(cpol_ctx *ctx, void *hip_stream);
+/* waits for the context's stream.  Also the point where a DEFERRED domain error surfaces:
+ * sweeps with outputs_on_device = 1 / 2 return before their kernels ran, so a gate outside
+ * the model domain (reference: IndexError, interpolation.py:572-580) sets a sticky error word
+ * on the device that stays set over later sweeps until cpol_synchronize or cpol_counters has
+ * reported it ONCE as CPOL_ERR_DOMAIN (then it is cleared). */
 int  cpol_synchronize(cpol_ctx *ctx);
+/* page-locked host memory owned by the context (freed by cpol_host_free / cpol_destroy): the
+ * target of outputs_on_device = 2, so that the device-to-host copy of one sweep overlaps the
+ * kernels of the next (other lanes) instead of being staged through pageable memory */
+int  cpol_host_alloc(cpol_ctx *ctx, size_t bytes, void **out);
+int  cpol_host_free(cpol_ctx *ctx, void *p);
 /* the HIP stream (hipStream_t) the context launches on: to order foreign work (copies,
  * collectives) against a sweep with events */
 int  cpol_get_stream(cpol_ctx *ctx, void **hip_stream);
@@ -253,7 +274,9 @@ int  cpol_stage_spectrum_tables(cpol_ctx *ctx, int slot, const float *rcs32, con
 int  cpol_interp_points(cpol_ctx *ctx, int n, const float *coords, const float *heights,
                         float *out);
 
-/* fills per-ray tables with libm (C callers); Python callers use numpy */
+/* fills per-ray tables with libm (C callers); Python callers use numpy.
+ * traj_out: [n_rays][n_vnodes][CPOL_TRAJ_STRIDE] doubles (el_rad, sin el, cos el, el_deg);
+ * geo_out:  [n_rays][n_hnodes][CPOL_GEO_STRIDE] doubles. */
 int  cpol_ray_tables(const cpol_sweep_params *p, const double *az_deg, const double *el_deg,
                      const double *pts_h_deg, const double *pts_v_deg,
                      double *traj_out, double *geo_out);
@@ -263,7 +286,8 @@ int  cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_ta
 
 /* CPOL_GEOM_SPACEBORNE helper: index of the first candidate gate below the
  * model-top ceiling for each (ray, vertical node): first_gate [n_rays*n_vnodes]
- * (host buffer).  `site` as in cpol_ray_tables_t, n_cand[n_rays] candidate gates. */
+ * (host buffer).  `traj` [n_rays][n_vnodes][CPOL_TRAJ_STRIDE] and `site`
+ * [n_rays][CPOL_SITE_STRIDE] as in cpol_ray_tables_t, n_cand[n_rays] candidate gates. */
 int  cpol_spaceborne_first_gate(cpol_ctx *ctx, const cpol_sweep_params *p, const double *traj,
                                 const double *site, const int32_t *n_cand, double ceiling_m,
                                 int32_t *first_gate);

@@ -18,7 +18,7 @@ source is NOT under /root/reference:
         572-575 and interpolation_c.c:43-44).
 
 PARITY UNPINNED against the real pyproj / pycosmo (neither installed nor
-vendored); pinned instead by tests/test_geodesy.py against an independent
+vendored); pinned instead by tests/test_geodesy_kat_cpu.py against an independent
 numerical integration of the geodesic ODE and a literature known answer.
 """
 import numpy as np

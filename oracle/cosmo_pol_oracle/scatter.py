@@ -264,7 +264,32 @@ def sensitivity_threshold(config, n_gates):
 
 
 def cut_at_sensitivity(radials, config):
-    """In place on a list of radials (doppler_scatter.py:804-862)."""
+    """In place (doppler_scatter.py:804-862).  Two branches, as in the reference:
+
+    * a list of LISTS of radials -- what get_PPI / get_RHI pass (radar_operator.py:432-445,
+      530-542): every simulated variable is censored with the gate mask
+      10 log10(ZH) < threshold(r), EXCEPT the Doppler spectrum, which is censored bin by bin
+      with 10 log10(DSPECTRUM) < threshold(r) (:839-850);
+    * a simple list of radials (get_GPM_swath): everything, the spectrum rows included, with
+      the gate mask (:852-861)."""
+    if len(radials) and isinstance(radials[0], list):
+        for sweep in radials:
+            for b in sweep:
+                thr = sensitivity_threshold(config, len(b.dist_profile))
+                if thr is None:
+                    return radials
+                with np.errstate(invalid='ignore', divide='ignore'):
+                    m = 10 * np.log10(b.values['ZH']) < thr
+                    for k in b.values.keys():
+                        if k not in K.SIMULATED_VARIABLES:
+                            continue
+                        if k == 'DSPECTRUM':
+                            logspectrum = 10 * np.log10(b.values[k])
+                            t2 = np.tile(thr, (logspectrum.shape[1], 1)).T
+                            b.values[k][logspectrum < t2] = np.nan
+                        else:
+                            b.values[k][m] = np.nan
+        return radials
     for b in radials:
         thr = sensitivity_threshold(config, len(b.dist_profile))
         if thr is None:

@@ -295,10 +295,11 @@ RADIAL_CASES.update({
 
 # further combinations pinned by the reference itself
 RADIAL_CASES.update({
-    'd3_1mom_ice_sub': ({'radar': {'range': 45000, 'radial_resolution': 750, 'FFT_length': 32},
+    # (35 deg elevation: the fall-speed spread projects onto several velocity bins per gate)
+    'd3_1mom_ice_sub': ({'radar': {'range': 18000, 'radial_resolution': 300, 'FFT_length': 32},
                          'microphysics': {'with_ice_crystals': 1, 'with_melting': 0},
                          'doppler': {'scheme': 3},
-                         'integration': {'nh_GH': 3, 'nv_GH': 1}}, 120.0, 5.0, ('R', 'S', 'G', 'I'), False),
+                         'integration': {'nh_GH': 3, 'nv_GH': 1}}, 120.0, 35.0, ('R', 'S', 'G', 'I'), False),
     'q_ml_dop2': ({'radar': {'range': 30000, 'radial_resolution': 500},
                    'microphysics': {'with_ice_crystals': 1, 'with_melting': 1},
                    'doppler': {'scheme': 2},
@@ -309,6 +310,20 @@ RADIAL_CASES.update({
                           'doppler': {'scheme': 2},
                           'integration': {'nh_GH': 3, 'nv_GH': 3, 'weight_threshold': 0.999}}, 75.0, 8.0,
                          ('R', 'S', 'G', 'I'), True),
+})
+
+# BASELINE configs 4 and 5 at golden size: the full 7 x 7 Gauss-Hermite antenna quadrature
+# (49 sub-beams, none dropped) over melting + ice, and the Ka-band (35.6 GHz, GPM-DPR KaPR,
+# constants/global_constants.py:152-159) half of the dual-frequency 2-moment case
+RADIAL_CASES.update({
+    'c4_7x7': ({'radar': {'range': 36000, 'radial_resolution': 600},
+                'microphysics': {'with_ice_crystals': 1, 'with_melting': 1},
+                'integration': {'nh_GH': 7, 'nv_GH': 7, 'weight_threshold': 1.}},
+               300.0, 6.0, ('R', 'S', 'G', 'I'), False),
+    'c5_ka_2mom': ({'radar': {'range': 30000, 'radial_resolution': 250, 'frequency': 35.6,
+                              '3dB_beamwidth': 0.5},
+                    'microphysics': {'scheme': '2mom', 'with_ice_crystals': 1, 'with_melting': 0},
+                    'integration': {'nh_GH': 1, 'nv_GH': 3}}, 75.0, 8.0, ('R', 'S', 'G', 'I'), True),
 })
 
 LUT_KW = dict(seed=20260301, n_e=8, n_t=None)
@@ -393,6 +408,14 @@ def gen_radials(out, only_cases=None):
             d['obs_' + n] = np.asarray(obs.values[n])
         d['obs_mask'] = obs.mask
         d['n_valid'] = np.array([n_valid[h] for h in hl])
+        # the sensitivity cut as get_PPI / get_RHI apply it: a list of LISTS of radials
+        # (radar_operator.py:432-445), i.e. the branch that censors the Doppler spectrum bin by
+        # bin (doppler_scatter.py:839-850); sensitivity of the case configuration
+        import copy as _copy
+        from cosmo_pol.scatter import cut_at_sensitivity
+        cut = cut_at_sensitivity([[_copy.deepcopy(obs)]])[0][0]
+        for n in cut.values:
+            d['cutll_' + n] = np.asarray(cut.values[n])
         print(name, 'n_sub', len(subs), 'valid items', n_valid,
               'finite ZH', int(np.isfinite(obs.values['ZH']).sum()), '/', len(obs.values['ZH']))
         out['radial_' + name] = d

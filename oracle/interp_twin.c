@@ -10,7 +10,7 @@
  * Written gate-by-gate: in the reference every gate ends up depending only on
  * itself (the "fill forward" loops at :93 and :101 are overwritten by later
  * iterations), which is what the HIP kernel exploits.  Pinned bit-for-bit
- * against the compiled reference by tests/test_oracle_interp.py.
+ * against the compiled reference by tests/test_oracle_golden.py.
  *
  * Float semantics: x86-64 SSE float32, compiled with -ffp-contract=off.
  * Sentinels: -9999 above the model top, NaN below topography.

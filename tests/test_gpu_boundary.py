@@ -1,0 +1,158 @@
+"""GPU tests of the C-ABI boundary behaviour added in round 2: the sticky (deferred) domain
+error, non-blocking pinned-host outputs, the re-validation in cpol_stage_hydro /
+cpol_run_sweep, and the sensitivity cut of the Doppler spectrum through get_PPI."""
+import copy
+
+import numpy as np
+import pytest
+
+import _cases
+from cosmo_pol_oracle import beam, scatter
+from cosmo_pol_oracle import config as ocfg
+
+pytestmark = pytest.mark.gpu
+FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V', 'RVEL', 'mask',
+          'lats', 'lons', 'dist', 'heights']
+
+
+def _op(name, over_extra=None, output_variables='only_radar', lanes=1):
+    from cosmo_pol_amd import RadarOperator
+    over = copy.deepcopy(_cases.gen_golden.radial_case_inputs(name)[0])
+    for sec, d in (over_extra or {}).items():
+        over.setdefault(sec, {}).update(d)
+    _, _, _, ocube, luts, cube = _cases.radial_case(name)
+    op = RadarOperator(config=over, luts=luts, output_variables=output_variables, lanes=lanes)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    return op, over, ocube, luts
+
+
+def test_deferred_domain_error_is_sticky_and_reported_once():
+    """A sweep with device outputs returns before its kernels ran; if it left the model domain
+    the error must survive later (clean) sweeps on the same context and surface exactly once
+    (the reference raises IndexError at that radial, interpolation.py:572-580)."""
+    import torch
+    op, over, _, _ = _op('c2_rsg')
+    n_gates = len(op.constants.RANGE_RADAR)
+    slab = torch.zeros((2, 4, n_gates), dtype=torch.float32, device='cuda')
+    ptrs = {'ZH': slab[0].data_ptr(), 'ZDR': slab[1].data_ptr()}
+    az = np.array([0., 90., 180., 270.])
+    op.simulate_rays(az, np.full(4, 2.0), device_outputs=ptrs)
+    op.wait()                                               # clean so far
+    far = copy.deepcopy(over)
+    far['radar']['range'] = 150000                          # leaves the 1.1 deg test cube
+    op.config = far
+    n_far = len(op.constants.RANGE_RADAR)
+    big = torch.zeros((2, 4, n_far), dtype=torch.float32, device='cuda')
+    op.simulate_rays(az, np.full(4, 2.0), device_outputs={'ZH': big[0].data_ptr(), 'ZDR': big[1].data_ptr()})
+    op.config = over                                        # two clean sweeps behind the bad one
+    op.simulate_rays(az, np.full(4, 2.0), device_outputs=ptrs)
+    op.simulate_rays(az, np.full(4, 3.0), device_outputs=ptrs)
+    with pytest.raises(IndexError):
+        op.wait()
+    op.wait()                                               # reported once, then cleared
+    op._ctx.counters()
+    # out-of-domain gates leave no stale coordinates in caller buffers
+    op.config = far
+    with pytest.raises(IndexError):
+        res = op.simulate_rays(az, np.full(4, 2.0))
+    op.close()
+
+
+def test_pinned_outputs_equal_blocking_outputs():
+    """outputs_on_device = 2: non-blocking device-to-host copies into the lane's page-locked slab."""
+    op, _, _, _ = _op('c3_melt_ice', lanes=2)
+    az = np.arange(0., 360., 30.)
+    el = np.full(len(az), 4.0)
+    ref = op.simulate_rays(az, el)
+    for lane in (0, 1):
+        out = op.simulate_rays(az, el, pinned=True, lane=lane)
+        op.wait(lane)
+        for k in FIELDS:
+            assert np.array_equal(out[k], ref[k], equal_nan=True), (lane, k)
+    # a second pinned sweep on the same lane reuses the slab; geometry comes from the cache
+    out = op.simulate_rays(az, np.full(len(az), 7.0), pinned=True, lane=1)
+    op.wait(1)
+    ref7 = op.simulate_rays(az, np.full(len(az), 7.0))
+    for k in FIELDS:
+        assert np.array_equal(out[k], ref7[k], equal_nan=True), k
+    assert not np.array_equal(ref7['heights'], ref['heights'])
+    op.close()
+
+
+def test_too_many_lut_slices_is_refused_by_stage_hydro():
+    """cpol_stage_hydro propagates the bucket-scan limit (n_e x n_t summed over the slots)
+    instead of leaving a context that cpol_run_sweep would mis-sort."""
+    from cosmo_pol_amd import _native as N, hydrometeors as hyd
+    op, over, _, luts = _op('c2_rsg')
+    conf = op.config
+    vi = {v: i for i, v in enumerate(hyd.variable_list(conf))}
+    d, table, pre, dnu, aux = hyd.build_hydro('R', '1mom', luts['R'], vi)
+    n_e, n_t = int(d.n_e), int(d.n_t)
+    big_e = (32768 // n_t) + 8                      # n_e * n_t alone exceeds 1024 * 32 slices
+    d2 = copy.copy(d)
+    d2.n_e = big_e
+    tbl = np.zeros((big_e, n_t, int(d.n_d), 12))
+    ctx = N.Context(0)
+    with pytest.raises(ValueError):
+        ctx.stage_hydro(0, d2, tbl, pre, dnu, aux)
+    ctx.close()
+    op.close()
+
+
+def test_spectrum_sensitivity_cut_through_get_ppi():
+    """Doppler scheme 3 with the sensitivity cut ON through get_PPI: the spectrum is censored
+    bin by bin (10 log10(S) < threshold(r)), not with the gate mask (doppler_scatter.py:839-850)."""
+    name = 'd3_rsg'
+    op, over, ocube, luts = _op(name, {'radar': {'sensitivity': [20., 10000]}})
+    conf = ocfg.make_config(over)
+    azs = np.array([200., 20.])
+    scan = op.get_PPI(elevations=[4.0], azimuths=azs)
+    raw = scan.raw[0]['fields']
+    olut = {h: _cases.as_oracle_lut(l) for h, l in luts.items()}
+    n_bins_cut = n_gate_cut = n_survivors_at_cut_gates = 0
+    for r, az in enumerate(azs):
+        subs = beam.interpolate_radial(ocube, conf, az, 4.0)
+        o = scatter.radar_observables(subs, olut, conf)
+        before = np.isnan(o.values['DSPECTRUM']).sum()
+        zh_before = np.isfinite(o.values['ZH'])
+        scatter.cut_at_sensitivity([[o]], conf)
+        osp = o.values['DSPECTRUM']
+        assert np.array_equal(np.isnan(raw['DSPECTRUM'][r]), np.isnan(osp))
+        ok = ~np.isnan(osp)
+        np.testing.assert_allclose(raw['DSPECTRUM'][r][ok], osp[ok], rtol=2e-5, atol=1e-6 * np.nanmax(osp))
+        assert np.array_equal(np.isnan(raw['ZH'][r]), np.isnan(o.values['ZH']))
+        assert np.array_equal(np.isnan(raw['RVEL'][r]), np.isnan(o.values['RVEL']))
+        n_bins_cut += int(np.isnan(osp).sum() - before)
+        cut_gates = zh_before & np.isnan(o.values['ZH'])
+        n_gate_cut += int(cut_gates.sum())
+        n_survivors_at_cut_gates += int(np.isfinite(osp[cut_gates]).sum())
+    assert n_bins_cut > 0 and n_gate_cut > 0
+    op.close()
+
+
+def test_radial_records_of_a_device_result_and_reference_style_cut():
+    """to_radials(simulate_rays(..., apply_sensitivity=False)) censored by the oracle's
+    cut_at_sensitivity (the reference's list-of-lists call, radar_operator.py:445) equals
+    the sweep censored on the device -- i.e. reference-side code that consumes lists of
+    Radial runs unchanged on the batched result (INTEGRATION.md level B)."""
+    from cosmo_pol_amd.radial import to_radials
+    op, over, _, _ = _op('c4_subbeams', {'radar': {'sensitivity': [30., 10000]}})
+    conf = ocfg.make_config(over)
+    az = np.arange(0., 360., 40.)
+    el = np.full(len(az), 4.0)
+    plain = op.simulate_rays(az, el, apply_sensitivity=False)
+    rads = to_radials(plain, azimuths=az, elevations=el)
+    assert len(rads) == len(az) and rads[0].values['ZH'].shape == (plain['ZH'].shape[1],)
+    assert np.array_equal(rads[3].dist_profile, plain['dist'][3])
+    scatter.cut_at_sensitivity([rads], conf)                # edits `plain` through the row views
+    dev = op.simulate_rays(az, el, apply_sensitivity=True)
+    n_cut = 0
+    for k in ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V', 'RVEL']:
+        assert np.array_equal(plain[k], dev[k], equal_nan=True), k
+        n_cut += int(np.isnan(dev[k]).sum())
+    assert np.isnan(dev['ZH']).sum() > np.isnan(dev['ATT_H']).sum()     # ATT_* are not censored
+    scan = op.get_PPI(elevations=[4.0], azimuths=az)
+    sweeps = scan.to_radials()
+    assert len(sweeps) == 1 and len(sweeps[0]) == len(az)
+    assert np.array_equal(sweeps[0][2].values['ZH'], dev['ZH'][2], equal_nan=True)
+    op.close()

@@ -79,6 +79,48 @@ def test_sample_of_rays_vs_oracle(full):
     assert n_valid > 2000
 
 
+def test_c3_full_size_volume_vs_oracle():
+    """BASELINE configs[2] at full size: 5 elevations x (360 x 500) on the bench cube with
+    the full 1-moment hydrometeor set (R, S, G, melting snow / graupel, ice crystals).
+    Size-independent properties (lanes == sequential is tested below; rays are independent)
+    plus sampled rays of every elevation against the oracle."""
+    from cosmo_pol_amd import RadarOperator
+    from test_gpu_parity import _pol_tolerances
+    over = bench.bench_config(False)
+    over['microphysics'].update(with_melting=1, with_ice_crystals=1)
+    hyds = ['R', 'S', 'G', 'mS', 'mG', 'I']
+    cube = synthetic.make_cube(hydrometeors=('R', 'S', 'G', 'I'), **synthetic.BENCH_GRID)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar', lanes=3)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    elevs = [0.5, 1.5, 3.0, 5.0, 8.0]
+    scan = op.get_PPI(elevs, az_step=1.0)
+    assert scan.nsweeps == 5 and scan.fields['ZH']['data'].shape == (5 * 360, 500)
+    conf = ocfg.make_config(over)
+    oc = beam.ModelCube({n: cube['data'][n] for n in _cases.ORDER}, cube['zlevels'],
+                        cube['proj_info'], cube['resolution'], _cases.ORDER)
+    ol = {h: _cases.as_oracle_lut(l) for h, l in luts.items()}
+    n_valid = n_melt = 0
+    for i, e in enumerate(elevs):
+        raw = scan.raw[i]
+        for r in ((17 + 71 * i) % 360, (200 + 53 * i) % 360):
+            subs = beam.interpolate_radial(oc, conf, float(r), e)
+            n_melt += int(np.sum(np.asarray(subs[0].values['QmS_v']) > 0)) if 'QmS_v' in subs[0].values else 0
+            o = scatter.radar_observables(subs, ol, conf, return_sz=True)
+            szt = np.nan_to_num(o.sz_total.astype(np.float64))
+            scatter.cut_at_sensitivity([[o]], conf)
+            assert np.array_equal(raw['dist'][r], subs[0].dist_profile)
+            assert np.array_equal(raw['heights'][r], subs[0].heights_profile)
+            assert np.array_equal(raw['mask'][r], o.mask)
+            for k in FIELDS:
+                atol = 2e-4 if k == 'RVEL' else _pol_tolerances(k, o, szt, conf)
+                _cases.assert_close_nan(raw['fields'][k][r], o.values[k], rtol=1e-5, atol=atol,
+                                        name='%s el %g ray %d' % (k, e, r))
+            n_valid += int(np.isfinite(o.values['ZH']).sum())
+    assert n_valid > 2000 and n_melt > 20, (n_valid, n_melt)
+    op.close()
+
+
 def test_rhi_and_vprof_api(full):
     op = full['op']
     rhi = op.get_RHI(azimuths=[30.0, 200.0], elevations=np.arange(0.5, 20.0, 2.5))

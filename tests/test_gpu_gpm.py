@@ -16,17 +16,31 @@ RTOL = 1e-5
 HYD_2MOM = ['R', 'S', 'G', 'H']
 
 
+BAND = {'Ku': (13.6, 125), 'Ka': (35.6, 250)}      # constants/global_constants.py:152-159
+
+
 @pytest.fixture(scope='module')
-def luts_ku():
-    return {h: synthetic.make_lut(h, 13.6, '2mom') for h in HYD_2MOM}
+def luts_band():
+    cache = {}
+
+    def get(band):
+        if band not in cache:
+            cache[band] = {h: synthetic.make_lut(h, BAND[band][0], '2mom') for h in HYD_2MOM}
+        return cache[band]
+    return get
 
 
 def _swath():
     return gpm.synthetic_swath(n_scans=3, n_rays=5, cross_track_deg=4.0, scan_spacing_m=6000.0)
 
 
-def test_gpm_swath_vs_oracle(luts_ku):
+@pytest.mark.parametrize('band', ['Ku', 'Ka'])
+def test_gpm_swath_vs_oracle(luts_band, band):
+    """Both halves of the dual-frequency swath of BASELINE config 5: KuPR (13.6 GHz, 125 m
+    gates) and KaPR (35.6 GHz, 250 m gates; radar_operator.py:577-588)."""
     from cosmo_pol_amd import RadarOperator
+    luts_ku = luts_band(band)
+    freq, res_m = BAND[band]
     from test_gpu_parity import _pol_tolerances
     cube = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G'), two_moment=True,
                                      **_cases.gen_golden.CUBE_KW)
@@ -35,21 +49,21 @@ def test_gpm_swath_vs_oracle(luts_ku):
             'integration': {'nh_GH': 1, 'nv_GH': 3}}
     lut_5_6 = {h: synthetic.make_lut(h, 5.6, '2mom', n_e=2, n_t=2) for h in HYD_2MOM}
 
-    def provider(hl, freq, scheme):
+    def provider(hl, freq, scheme):     # noqa: F811  (freq here: the frequency being loaded)
         assert scheme == '2mom'
-        return {h: (luts_ku if freq == 13.6 else lut_5_6)[h] for h in hl}
+        return {h: (luts_ku if freq == BAND[band][0] else lut_5_6)[h] for h in hl}
     op = RadarOperator(config=base, luts=provider, output_variables='only_radar')
     op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
     sw = _swath()
     op._ctx.enable_debug(True)
-    out = op.get_GPM_swath(sw, 'Ku')
+    out = op.get_GPM_swath(sw, band)
     assert op.config['radar']['frequency'] == 5.6          # configuration restored
     N, M = sw['Latitude'].shape
-    assert out.data['ZH'].shape[:2] == (N, M) and out.band == 'Ku'
+    assert out.data['ZH'].shape[:2] == (N, M) and out.band == band
 
     # ---- oracle: same rays, per-ray satellite site ----
     over = {k: dict(v) for k, v in base.items()}
-    over['radar'].update(frequency=13.6, radial_resolution=125, sensitivity=12.0, type='GPM')
+    over['radar'].update(frequency=freq, radial_resolution=res_m, sensitivity=12.0, type='GPM')
     over['radar']['3dB_beamwidth'] = 0.5
     conf = ocfg.make_config(over)
     order = _cases.ORDER_2MOM
@@ -81,7 +95,7 @@ def test_gpm_swath_vs_oracle(luts_ku):
                                     name='%s ray %d' % (k, idx))
             assert np.all(np.isnan(raw[k][idx, n:]))
         n_valid_total += int(np.isfinite(o.values['ZH']).sum())
-    assert n_valid_total > 200
+    assert n_valid_total > (200 if band == 'Ku' else 100)
     # packaging: beams start at the ground, gates under the topography removed
     assert np.isfinite(out.lats[0, 0, 0]) and out.bin_surface.shape == (N, M)
     op.close()

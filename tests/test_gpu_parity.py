@@ -61,6 +61,37 @@ def test_gate_kernel_bit_exact(golden):
     ctx.close()
 
 
+def _record_parity(case, var, got, ref, sz_ref=None, conf=None):
+    """Worst PURE relative deviation |got - ref| / |ref| of a variable, the number of gates
+    above 1e-5 and (KDP, PHIDP, DELTA_HV: differences of float32-stored sums) the smallest
+    cancellation factor (|sz8| + |sz10|) / |sz10 - sz8| among those gates.  Appended to
+    gpurun_out/parity_records.jsonl (the table of DESIGN.md section 4) and printed."""
+    import json
+    import os
+    got = np.asarray(got, dtype=np.float64).ravel()
+    ref = np.asarray(ref, dtype=np.float64).ravel()
+    ok = np.isfinite(ref) & np.isfinite(got) & (ref != 0)
+    rel = np.zeros(ref.shape)
+    rel[ok] = np.abs(got[ok] - ref[ok]) / np.abs(ref[ok])
+    above = rel > RTOL
+    rec = {'case': case, 'var': var, 'n': int(ok.sum()), 'worst_rel': float(rel.max()) if ok.any() else 0.0,
+           'n_above_1e-5': int(above.sum())}
+    if sz_ref is not None and above.any() and rel.shape[0] == sz_ref.shape[0]:
+        with np.errstate(divide='ignore', invalid='ignore'):
+            canc = (np.abs(sz_ref[:, 8]) + np.abs(sz_ref[:, 10])) / np.abs(sz_ref[:, 10] - sz_ref[:, 8])
+        rec['min_cancellation_above'] = float(np.nanmin(canc[above]))
+        rec['worst_rel_over_cancellation'] = float(np.nanmax(rel[above] / canc[above]))
+    print('PARITY', json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_records.jsonl'), 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass
+    return rec
+
+
 def _pol_tolerances(name, obs_ref, sz_ref, conf):
     """atol per variable following the module docstring."""
     from cosmo_pol_oracle import constants as OK
@@ -155,6 +186,16 @@ def test_radial_vs_reference_golden_and_oracle(golden, name):
         atol = _pol_tolerances(k, oobs, np.nan_to_num(oobs.sz_total.astype(np.float64)), conf)
         _cases.assert_close_nan(res[k][0], oobs.values[k], rtol=RTOL, atol=atol, name='oracle:' + k)
         _cases.assert_close_nan(res[k][0], g['obs_' + k], rtol=RTOL, atol=atol, name='golden:' + k)
+        rec = _record_parity(name, k, res[k][0], g['obs_' + k],
+                             np.nan_to_num(oobs.sz_total.astype(np.float64)), conf)
+        if k in ('ZH', 'ZV', 'ZDR', 'RHOHV', 'ATT_H', 'ATT_V'):
+            assert rec['n_above_1e-5'] == 0, rec          # pure 1e-5 relative, no scaling
+        elif k == 'KDP':
+            # a difference of two float32-stored sums (quirk Q4): what exceeds the pure 1e-5 is
+            # explained by the cancellation of the operands -- never more than 1e-6 of them.
+            # (PHIDP and DELTA_HV, built on such differences, are recorded and held to the
+            # operand-scaled tolerance above.)
+            assert rec.get('worst_rel_over_cancellation', 0.0) < 1e-6, rec
 
     # ---- radial velocity (Doppler scheme 1): float64, terms of O(10 m/s) that may cancel ----
     assert 'RVEL' in res
@@ -165,7 +206,7 @@ def test_radial_vs_reference_golden_and_oracle(golden, name):
     if 'DSPECTRUM' in oobs.values:
         sp, osp = res['DSPECTRUM'][0], oobs.values['DSPECTRUM']
         assert sp.shape == osp.shape == g['obs_DSPECTRUM'].shape
-        assert np.nansum(osp > 0) > 20, 'the spectrum was not exercised'
+        assert np.nansum(osp > 0) > 50, 'the spectrum was not exercised'
         atol = 1e-6 * np.nanmax(osp)
         _cases.assert_close_nan(sp, osp, rtol=2e-5, atol=atol, name='oracle:DSPECTRUM')
         _cases.assert_close_nan(sp, g['obs_DSPECTRUM'], rtol=2e-5, atol=atol, name='golden:DSPECTRUM')
@@ -175,6 +216,17 @@ def test_radial_vs_reference_golden_and_oracle(golden, name):
     for i, nm in enumerate(names):
         _cases.assert_close_nan(res['model_vars'][i][0], integ.values[nm], rtol=1e-12,
                                 name='model:' + nm)
+
+    # ---- sensitivity cut on the device == the reference's list-of-lists branch (the Doppler
+    # spectrum is censored bin by bin, doppler_scatter.py:839-850) ----
+    op._ctx.enable_debug(False)
+    cut = op.simulate_rays([az], [el], apply_sensitivity=True)
+    for k in ['ZH', 'ZV', 'ZDR', 'RHOHV', 'KDP', 'ATT_H', 'ATT_V', 'DELTA_HV', 'PHIDP', 'RVEL', 'DSPECTRUM']:
+        if ('cutll_' + k) not in g.files:
+            continue
+        gk = g['cutll_' + k]
+        assert np.array_equal(np.isnan(cut[k][0]), np.isnan(gk)), 'cut pattern: ' + k
+        assert np.array_equal(cut[k][0][~np.isnan(gk)], res[k][0][~np.isnan(gk)]), k
     op.close()
 
 

@@ -173,11 +173,11 @@ def test_radial_end_to_end(golden, name):
     conf, az, el, cube, luts, _ = _cases.radial_case(name)
     subs = beam.interpolate_radial(cube, conf, az, el)
     assert len(subs) == int(g['n_sub'])
-    if 'quad_w' in g:           # antenna quadratures other than scheme 1
-        ng = g['quad_w'].shape[1]
-        got_w = np.array([np.broadcast_to(sb.quad_weight, (ng,)) for sb in subs])
-        np.testing.assert_allclose(got_w, g['quad_w'], rtol=1e-13, atol=1e-300)
-        np.testing.assert_allclose(np.array([sb.quad_pt for sb in subs]), g['quad_pts'], rtol=0, atol=1e-12)
+    # every fixture carries the sub-beam weights / nodes (regenerated in round 2)
+    ng = g['quad_w'].shape[1]
+    got_w = np.array([np.broadcast_to(sb.quad_weight, (ng,)) for sb in subs])
+    np.testing.assert_allclose(got_w, g['quad_w'], rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(np.array([sb.quad_pt for sb in subs]), g['quad_pts'], rtol=0, atol=1e-12)
     c = subs[int(len(subs) / 2)]
     for tag, sb in (('c', c), ('f', subs[0])):
         for n in sb.values:
@@ -200,6 +200,17 @@ def test_radial_end_to_end(golden, name):
         # libm / SIMD differences between hosts: allow a few f32 ulps
         _cases.assert_close_nan(obs.values[n], g['obs_' + n], rtol=2e-6, atol=1e-30, name=n)
     assert np.array_equal(obs.mask, g['obs_mask'])
+    # sensitivity cut, list-of-lists branch (what get_PPI / get_RHI use; spectrum bin by bin)
+    n_cut = 0
+    cut = scatter.cut_at_sensitivity([[obs]], conf)[0][0]
+    for n in cut.values:
+        _cases.assert_close_nan(cut.values[n], g['cutll_' + n], rtol=2e-6, atol=1e-30, name='cut:' + n)
+        n_cut += int(np.isnan(g['cutll_' + n]).sum() - np.isnan(g['obs_' + n]).sum())
+    if 'DSPECTRUM' in cut.values:
+        assert n_cut > 0, 'the per-bin spectrum cut was not exercised'
+        # ... and it is NOT the gate mask: bins survive at gates, bins vanish at kept gates
+        kept = np.isfinite(g['cutll_ZH'])
+        assert np.isnan(g['cutll_DSPECTRUM'][kept]).sum() > np.isnan(g['obs_DSPECTRUM'][kept]).sum()
 
 
 def test_aliasing(golden):
