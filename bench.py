@@ -1,31 +1,49 @@
 #!/usr/bin/env python
 """bench.py -- range-gates/s of the cosmo_pol hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c4]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): 360-azimuth x 500-gate C-band PPI at 1.0 deg
-elevation, rain + snow + graupel 1-moment, 1 sub-beam, attenuation on, on the
-synthetic COSMO-1-like cube (80 x 774 x 1158) with full-size
-synthetic scattering tables.  A "step" = one complete sweep through the C ABI
-(all kernels, outputs left in HBM; the per-ray tables of the unchanged scan
-geometry stay resident in HBM between steps -- `value_fresh_tables` re-uploads
-them every step).  Consecutive steps run on alternating LANES (cpol_fork: shared
-cube and tables, own stream and work buffers), so two or three sweeps are in
-flight together, as the sweeps of a volume scan are in the product; stage times
-and the roofline are measured on lane 0 under that overlap.  With N GPUs every rank
-simulates one such sweep per step (rays sharded by whole sweeps, weak scaling)
-and the output slabs are collected with ONE RCCL all-gather per step.
+Workloads (BASELINE.json `configs`):
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on
-the library's stream over the timed region (cpol_enable_timing / cpol_counters: two
-events per sweep around the PSD stage of lane 0; all stages in the single-lane pass after it);
-`cpu_baseline` times the CPU oracle (the restatement of the reference
-algorithm, per radial, un-batched) on a bounded azimuth sample on this host.
+  c2 (default at N = 1; configs[1], the configuration the metric is quoted on)
+      360-azimuth x 500-gate C-band PPI at 1.0 deg, rain + snow + graupel 1-moment, one
+      sub-beam, attenuation on, synthetic COSMO-1-like cube (80 x 774 x 1158) and full-size
+      synthetic scattering tables.  A step = one complete sweep through the C ABI: per-sweep
+      parameters, all kernels, and the device-to-host copy of the outputs: the ten
+      radar observables and the radial mask of every gate land in the lane's page-locked host
+      slab (cpol_host_alloc; outputs_on_device = 2).  Consecutive steps run on three LANES
+      (cpol_fork: shared cube and tables, own stream and work buffers) so that the copy of
+      one sweep overlaps the kernels of the next, as the sweeps of a volume scan do in the
+      product.  The per-ray tables of the unchanged scan geometry stay resident in HBM and
+      the gate coordinates (functions of those tables only) are copied once;
+      `value_fresh_tables_full_d2h` re-uploads the tables and copies all 15 output arrays
+      every step, `value_device_resident` leaves the outputs in HBM.
+
+  c4 (default at N > 1; configs[3])
+      5-elevation volume (360 x 500 each), full 1-moment hydrometeor set with melting layer
+      and ice crystals, 7 x 7 Gauss-Hermite antenna quadrature (49 sub-beams).  STRONG
+      scaling: the 360 azimuths of every sweep are split into contiguous blocks of
+      ceil(360 / N) rays, one per rank (cosmo_pol_amd/distributed.py); every rank writes its
+      block of each sweep into a device slab and ONE all-gather per sweep (RCCL over xGMI)
+      assembles the sweep on every rank; rank 0 copies the assembled volume to page-locked
+      host memory.  A step = one volume.  After the timed region rank 0 runs the same volume
+      alone (`single_gpu_same_workload`) and compares the gathered result with it bit for bit
+      (`gather_check`).
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (the PSD x table
+stage): live HIP-event durations on the library's stream over the timed region
+(cpol_enable_timing / cpol_counters), VALU instruction counts and HBM traffic from the
+rocprofv3 PMC passes committed under profiles/ (read at run time, never hard-coded).
+`cpu_baseline` times the CPU oracle (the restatement of the reference algorithm, per radial,
+un-batched) on this host: one pinned core (median of 5 samples) and a fork pool over
+os.cpu_count() cores as radar_operator.py:402,431 does.
 """
 import argparse
+import contextlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -36,18 +54,17 @@ for p in (ROOT, os.path.join(ROOT, 'oracle')):
 
 import numpy as np  # noqa: E402
 
-OUT_FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V']
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+RADAR_FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V']
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
+N_SIMD, PEAK_CLOCK = 1024, 2.4e9  # 256 CUs x 4 SIMDs, 2.4 GHz
+VALU_F64_CYCLES = 4               # a wave64 v_*_f64 occupies its SIMD for 4 cycles
 LUT_SLICE_BYTES = 1024 * 12 * 4   # B_l per valid item (float32 staging figure)
-# HBM bytes per sweep of the PSD kernel from the PMC passes committed under profiles/
-# ((2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md); refreshed
-# whenever the profile is re-taken -- see profiles/README.md
-PSD_TRAFFIC_BYTES_PER_SWEEP = 66.9e6     # profiles/r1_final2_pmc_hbm.json, k_psd_uniform<false>
+C4_ELEVATIONS = [0.5, 1.5, 3.0, 5.0, 8.0]
 
 
-def bench_config(small):
+def bench_config(small, workload='c2'):
     rng = 30000 if small else 150000
-    return {'radar': {'coords': [46.5, 7.5, 1000], 'frequency': 5.6, 'range': rng,
+    conf = {'radar': {'coords': [46.5, 7.5, 1000], 'frequency': 5.6, 'range': rng,
                       'radial_resolution': 300, '3dB_beamwidth': 1., 'K_squared': 0.93,
                       'type': 'ground', 'sensitivity': [-5, 10000]},
             'refraction': {'scheme': 1},
@@ -55,16 +72,39 @@ def bench_config(small):
             'doppler': {'scheme': 1},
             'microphysics': {'scheme': '1mom', 'with_melting': 0, 'with_ice_crystals': 0,
                              'with_attenuation': 1}}
+    if workload in ('c3', 'c4'):
+        conf['microphysics'].update(with_melting=1, with_ice_crystals=1)
+    if workload == 'c4':
+        conf['integration'].update(nh_GH=7, nv_GH=7)
+    return conf
+
+
+def hydrometeors_of(workload):
+    return ('R', 'S', 'G') if workload == 'c2' else ('R', 'S', 'G', 'mS', 'mG', 'I')
+
+
+def load_profile_summary(workload):
+    """profiles/r2_<workload>_summary.json (tools/profile_summary.py): per kernel the mean
+    SQ_INSTS_VALU, FETCH_SIZE, WRITE_SIZE per dispatch and the kernel-trace duration."""
+    path = os.path.join(ROOT, 'profiles', 'r2_%s_summary.json' % workload)
+    try:
+        with open(path) as f:
+            return json.load(f), os.path.relpath(path, ROOT)
+    except (OSError, ValueError):
+        return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--small', action='store_true', help='small cube / tables (debugging)')
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--workload', choices=['auto', 'c2', 'c4'], default='auto',
+                    help="auto: c2 at N = 1 (the metric's configuration), c4 strong scaling at N > 1")
+    ap.add_argument('--repeats', type=int, default=5, help='repeats of the timed region (c2)')
+    ap.add_argument('--small', action='store_true', help='small cube / tables (debugging, tests)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0,
-                    help='budget of the CPU-oracle baseline sample (0 = skip)')
+                    help='budget of the one-core CPU-oracle baseline (0 = skip all CPU legs)')
     args = ap.parse_args()
 
     import torch
@@ -76,20 +116,26 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run for --gpus > 1')
         args.gpus = world
+    workload = args.workload if args.workload != 'auto' else ('c2' if world == 1 else 'c4')
+    if args.steps is None:
+        args.steps = 200 if workload == 'c2' else 10
+    if args.warmup is None:
+        args.warmup = 10 if workload == 'c2' else 2
     # debugging aids for a one-GPU box: CPOL_BENCH_BACKEND=gloo CPOL_BENCH_ONE_DEVICE=1 runs the
     # N-rank code path with every rank on GPU 0 (never used by the driver)
     backend = os.environ.get('CPOL_BENCH_BACKEND', 'nccl')
     if os.environ.get('CPOL_BENCH_ONE_DEVICE'):
         local_rank = 0
     from cosmo_pol_amd import RadarOperator, synthetic
-    conf = bench_config(args.small)
-    hyds = ('R', 'S', 'G')
+    conf = bench_config(args.small, workload)
+    hyds = hydrometeors_of(workload)
+    cube_h = tuple(h for h in hyds if h in ('R', 'S', 'G', 'I'))
     t0 = time.time()
     if args.small:
-        cube = synthetic.small_test_cube(hydrometeors=hyds)
+        cube = synthetic.small_test_cube(hydrometeors=cube_h)
         luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
     else:
-        cube = synthetic.make_cube(hydrometeors=hyds, **synthetic.BENCH_GRID)
+        cube = synthetic.make_cube(hydrometeors=cube_h, **synthetic.BENCH_GRID)
         luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
     t_gen = time.time() - t0
 
@@ -97,58 +143,76 @@ def main():
     # process initialises the GPU (HIP state does not survive a fork)
     cpu_res = None
     if world == 1 and args.cpu_seconds > 0:
-        az_cpu = np.arange(0, 360, 1.0)
-        cpu_res = cpu_baseline(conf, cube, luts, az_cpu, args.cpu_seconds)
-        cpu_res['all_cores'] = cpu_baseline_pool(conf, cube, luts, az_cpu)
+        el_cpu = 1.0 if workload == 'c2' else C4_ELEVATIONS[2]
+        cpu_res = cpu_baseline(conf, cube, luts, np.arange(0, 360, 1.0), el_cpu, args.cpu_seconds)
+        cpu_res['all_cores'] = cpu_baseline_pool(conf, cube, luts, np.arange(0, 360, 1.0), el_cpu,
+                                                 cpu_res['radials_per_s'])
 
     torch.cuda.set_device(local_rank)
     t0 = time.time()
-    import contextlib
     with contextlib.redirect_stdout(sys.stderr):      # the operator's notices: stdout carries ONE JSON line
         op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', device=local_rank)
         op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
     op._ctx.synchronize()
     t_stage = time.time() - t0
-
-    az = np.arange(0, 360, 1.0)
-    el = np.full(len(az), 1.0)
-    n_rays, n_gates = len(az), len(op.constants.RANGE_RADAR)
     # lanes: contexts forked from the operator's (shared cube / tables, own stream and work
-    # buffers); consecutive steps go to alternating lanes so that the latency-bound kernels
-    # of one sweep overlap the PSD kernel of the other (CPOL_BENCH_LANES=1 disables).  The
-    # lanes keep the library's own non-blocking streams, created back to back before any other
-    # stream of the process so that each gets its own hardware queue (measured: torch-created
-    # streams, or forking after other streams exist, cost 6-25 % through queue sharing).
+    # buffers).  They keep the library's own non-blocking streams, created back to back before
+    # any other stream of the process so that each gets its own hardware queue (measured:
+    # torch-created streams, or forking after other streams exist, cost 6-25 % through queue
+    # sharing).  The process group comes AFTER the lanes for the same reason.
     n_lanes = max(1, int(os.environ.get('CPOL_BENCH_LANES', '3')))
     lanes = [op._lane(i) for i in range(n_lanes)]
-    # the process group comes AFTER the lanes so that RCCL's own streams do not take the
-    # hardware queues of the lanes
     if world > 1:
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    env = dict(op=op, lanes=lanes, n_lanes=n_lanes, world=world, rank=rank, local_rank=local_rank,
+               args=args, cube=cube, conf=conf, torch=torch, dist=dist, workload=workload)
+    out = run_c2(env) if workload == 'c2' else run_c4(env)
+    if rank == 0:
+        out['setup_s'] = {'synthetic_inputs': t_gen, 'stage_to_hbm': t_stage}
+        if cpu_res is not None:
+            out['cpu_baseline'] = cpu_res
+            out['gpu_over_cpu_core'] = out['value'] / cpu_res['value']
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    op.close()
 
-    lane_streams = ([torch.cuda.ExternalStream(c.stream_ptr(), device=torch.device('cuda', local_rank))
-                     for c in lanes] if world > 1 else None)
-    # two output slabs: the all-gather of step i (side stream) overlaps the kernels of
-    # step i+1 (library stream); a slab is reused only after its gather has completed
-    n_buf = max(2, n_lanes) if world > 1 else n_lanes
-    slabs = [torch.empty((len(OUT_FIELDS), n_rays, n_gates), dtype=torch.float32, device='cuda')
-             for _ in range(n_buf)]
-    slab = slabs[0]
-    gathered = ([torch.empty(world * slab.numel(), dtype=torch.float32, device='cuda')
-                 for _ in range(n_buf)] if world > 1 else None)
-    dev_outs = [{k: sl[i].data_ptr() for i, k in enumerate(OUT_FIELDS)} for sl in slabs]
-    dev_out = dev_outs[0]
-    comm_stream = torch.cuda.Stream() if world > 1 else None
-    slab_free = [None] * n_buf
+
+# ------------------------------------------------------------------------------------------ c2
+def run_c2(env):
+    op, lanes, n_lanes, world, rank = env['op'], env['lanes'], env['n_lanes'], env['world'], env['rank']
+    args, torch, dist, cube = env['args'], env['torch'], env['dist'], env['cube']
+    az = np.arange(0, 360, 1.0)
+    el = np.full(len(az), 1.0)
+    n_rays, n_gates = len(az), len(op.constants.RANGE_RADAR)
+    dev = torch.device('cuda', env['local_rank'])
     counter = [0]
 
-    def step():
+    # N > 1 with this workload = weak scaling (every rank one full sweep per step, one
+    # all-gather of the device slabs per step on a side stream); kept as an option
+    lane_streams = ([torch.cuda.ExternalStream(c.stream_ptr(), device=dev) for c in lanes]
+                    if world > 1 else None)
+    n_buf = max(2, n_lanes)
+    slabs = [torch.empty((len(RADAR_FIELDS), n_rays, n_gates), dtype=torch.float32, device=dev)
+             for _ in range(n_buf)]
+    gathered = ([torch.empty(world * slabs[0].numel(), dtype=torch.float32, device=dev)
+                 for _ in range(n_buf)] if world > 1 else None)
+    dev_outs = [{k: sl[i].data_ptr() for i, k in enumerate(RADAR_FIELDS)} for sl in slabs]
+    comm_stream = torch.cuda.Stream() if world > 1 else None
+    slab_free = [None] * n_buf
+
+    def step_pinned():                      # the headline step at N = 1
+        lane = counter[0] % n_lanes
+        counter[0] += 1
+        return op.simulate_rays(az, el, pinned=True, lane=lane)
+
+    def step_device():
         b = counter[0] % n_buf
         lane = counter[0] % n_lanes
         counter[0] += 1
@@ -167,53 +231,73 @@ def main():
             slab_free[b].record(comm_stream)
 
     def fence():
-        for c in lanes:
-            c.synchronize()
+        for i in range(n_lanes):
+            op.wait(i)                      # also surfaces a deferred domain error
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(step, n):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        t_submit = time.perf_counter() - t0
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, t_submit
+
+    step = step_pinned if world == 1 else step_device
     if world > 1:
-        # communicator set-up (lazy in RCCL) belongs to the setup phase, not to a step
-        with torch.cuda.stream(comm_stream):
+        with torch.cuda.stream(comm_stream):     # communicator set-up belongs to the setup phase
             dist.all_gather_into_tensor(gathered[0], slabs[0].view(-1))
         fence()
     for _ in range(args.warmup):
         step()
     fence()
     op._ctx.enable_timing(2)             # HIP events around the PSD stage of lane 0 (2 per sweep)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_submit = time.perf_counter() - t0      # host time to enqueue all steps
-    fence()
-    elapsed = time.perf_counter() - t0
-    cnt = op._ctx.counters()             # also surfaces a domain error, if any
+    runs = [timed(step, args.steps) for _ in range(max(1, args.repeats))]
+    cnt = op._ctx.counters()
     for i in range(1, n_lanes):
         op._lane(i).counters()
     op._ctx.enable_timing(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    per_step = sorted(1e3 * e / args.steps for e, _ in runs)
+    elapsed = statistics.median(e for e, _ in runs)
+    t_submit = statistics.median(s for _, s in runs)
+    gates_per_step = world * n_rays * n_gates
+    value = gates_per_step * args.steps / elapsed
 
-    # outside the timed region: every rank simulated the same sweep, so every gathered
-    # block of the last step must equal this rank's own slab, bit for bit
     gather_ok = None
     if world > 1:
         b = (counter[0] - 1) % n_buf
         own = slabs[b].view(-1)
         blocks = gathered[b].view(world, -1)
-        same = [bool(torch.equal(torch.nan_to_num(blocks[r]), torch.nan_to_num(own))) for r in range(world)]
-        gather_ok = all(same)
+        gather_ok = all(bool(torch.equal(torch.nan_to_num(blocks[r]), torch.nan_to_num(own)))
+                        for r in range(world))
 
-    gates_per_step = world * n_rays * n_gates
-    value = gates_per_step * args.steps / elapsed
-
-    # the same sweep on ONE lane (no other sweep in flight): kernel durations in isolation
+    extra = {}
     iso = None
     if world == 1:
+        # outputs left in HBM (no device-to-host copy)
+        for _ in range(3):
+            step_device()
+        e_dev, _ = timed(step_device, args.steps)
+        extra['value_device_resident'] = gates_per_step * args.steps / e_dev
+        # per-ray tables re-uploaded and all 15 output arrays (gate coordinates included)
+        # copied on every step
+        op.reuse_device_tables = False
+        for _ in range(3):
+            step_pinned()
+        n_it = max(3, args.steps // 2)
+        e_fr, _ = timed(step_pinned, n_it)
+        extra['value_fresh_tables_full_d2h'] = gates_per_step * n_it / e_fr
+        op.reuse_device_tables = True
+        # the same sweep on ONE lane (no other sweep in flight): kernel durations in isolation
         n_it = max(5, args.steps // 2)
         op._ctx.enable_timing(True)
         for _ in range(n_it):
@@ -221,103 +305,279 @@ def main():
         fence()
         iso = op._ctx.counters()
         op._ctx.enable_timing(False)
+        # latency of ONE sweep through the API (nothing else in flight)
+        lat_rays, lat_ppi = [], []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            op.simulate_rays(az, el)
+            lat_rays.append(1e3 * (time.perf_counter() - t0))
+        with contextlib.redirect_stdout(sys.stderr):
+            for _ in range(5):
+                t0 = time.perf_counter()
+                op.get_PPI(elevations=[1.0], az_step=1.0)
+                lat_ppi.append(1e3 * (time.perf_counter() - t0))
+        extra['single_sweep_latency_ms'] = {
+            'simulate_rays_blocking_host_outputs': statistics.median(lat_rays),
+            'get_PPI_one_elevation_with_packaging': statistics.median(lat_ppi),
+            'device_only_isolated': iso.ms_total,
+            'note': 'median wall time of one call with nothing else in flight; get_PPI adds the dB / '
+                    'masked-array packaging the reference does on the host too'}
 
-    # variant that re-uploads the per-ray tables on every step (new scan geometry each time)
-    value_fresh = None
+    if rank != 0:
+        return None
+    n_valid, n_sbg = int(cnt.n_valid_items), int(cnt.n_subbeam_gates)
+    n_vars = len(op._staged_vars)
+    psd_bytes = n_valid * LUT_SLICE_BYTES
+    sweep_bytes = (n_sbg * (4 * cube['zlevels'].shape[0] * 4 + n_vars * 8 * 4) + psd_bytes
+                   + n_rays * n_gates * 48)
+    roof = roofline('c2', 'k_psd_uniform<false>', cnt.ms_psd, n_valid, psd_bytes,
+                    iso.ms_psd if iso is not None else None)
+    d2h_bytes = n_rays * n_gates * (len(RADAR_FIELDS) * 4 + 8 + 8)
+    out = {
+        'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'c2: 360-azimuth x 500-gate C-band PPI (el 1.0 deg), rain+snow+graupel '
+                               '1-moment, 1 sub-beam, synthetic %s cube; one sweep per GPU per step: '
+                               'kernels + device-to-host copy of 10 observables and the mask into '
+                               'page-locked host memory (%s)'
+                               % ('x'.join(map(str, cube['zlevels'].shape)),
+                                  'N = 1' if world == 1 else 'N > 1: outputs gathered on the devices instead'),
+                   'rays_per_gpu': n_rays, 'gates_per_ray': n_gates, 'lanes': n_lanes,
+                   'd2h_bytes_per_step': d2h_bytes if world == 1 else 0,
+                   'parallelism': ('weak scaling: one sweep per rank per step, 1 all-gather/step on a side '
+                                   'stream') if world > 1 else 'single GPU',
+                   'small': bool(args.small)},
+        'timed_region_repeats': {'n': len(runs), 'ms_per_step_min': per_step[0],
+                                 'ms_per_step_median': statistics.median(per_step),
+                                 'ms_per_step_max': per_step[-1],
+                                 'note': 'each repeat = exactly `steps` steps between two fences; '
+                                         '`value` and `ms_per_step` are the median repeat'},
+        'roofline': roof,
+        'stages_ms': None if iso is None else {
+            'trajectory(debug only)': iso.ms_traj, 'interp': iso.ms_interp, 'classify': iso.ms_classify,
+            'bucket': iso.ms_bucket, 'psd': iso.ms_psd, 'final': iso.ms_final,
+            'device_total': iso.ms_total, 'psd_with_lanes_in_flight': cnt.ms_psd,
+            'launches_per_sweep': 6,
+            'note': 'one sweep on one lane (the pass after the timed region); in the timed '
+                    'region only the PSD stage of lane 0 carries events (2 per sweep)'},
+        'counters': {'n_subbeam_gates': n_sbg, 'n_valid_items': n_valid,
+                     'n_work_units': int(cnt.n_work_units),
+                     'sweep_algorithmic_bytes': sweep_bytes,
+                     'sweep_algorithmic_GBs': sweep_bytes * world / (elapsed / args.steps) / 1e9},
+        'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
+        'gather_check': gather_ok,
+    }
+    out.update(extra)
     if world == 1:
-        op.reuse_device_tables = False
-        n_it = max(3, args.steps // 2)
-        step()
-        fence()
+        out['d2h_GBs'] = d2h_bytes * args.steps / elapsed / 1e9
+    return out
+
+
+def roofline(workload, kernel, ms_stage, n_valid, psd_bytes, ms_isolated=None):
+    """The PSD x table stage against its bound.  It is f64-VALU bound: the
+    LUT slices are shared by the items of a work unit through the scalar cache, so the HBM
+    figure the survey defines (B_alg = N_valid x 49152 B over the kernel time) exceeds the
+    HBM peak and is kept as `hbm_alg_frac` only.  frac = VALU wave-instructions per launch
+    (SQ_INSTS_VALU of the committed PMC pass; all f64, 4 cycles each on a SIMD) over the
+    instruction slots of 1024 SIMDs at 2.4 GHz during the live kernel time."""
+    prof, prof_path = load_profile_summary(workload)
+    valu = traffic = prof_us = None
+    if prof:
+        for name, c in prof.items():
+            if name.startswith('_') or kernel.split('<')[0] not in name:
+                continue
+            if kernel in name or valu is None:
+                valu = c.get('SQ_INSTS_VALU')
+                traffic = c.get('hbm_bytes')
+                prof_us = c.get('avg_us')
+    analytic = -(-n_valid // 64) * 1024 * 16          # recurrence flavour: 16 v_*_f64 per (item row, bin)
+    peak = N_SIMD * PEAK_CLOCK / VALU_F64_CYCLES / 1e9     # G wave-instructions / s
+    t = ms_stage * 1e-3 if ms_stage and ms_stage > 0 else None
+    n_inst = valu if valu else analytic
+    achieved = n_inst / t / 1e9 if t else None
+    r = {'kernel': kernel + ' (the PSD x table stage; 1 launch / sweep in c2, 3 flavours in c4)',
+         'bound': 'valu_f64', 'achieved': achieved, 'peak': peak, 'unit': 'G wave-instructions/s',
+         'frac': achieved / peak if achieved else None,
+         'traffic': traffic,
+         'valu_wave_instructions_per_launch': n_inst,
+         'valu_source': prof_path if valu else 'analytic: ceil(N_valid/64) x 1024 bins x 16 f64 ops',
+         'essential_fma_frac': (-(-n_valid // 64) * 1024 * 12 / t / 1e9 / peak) if t else None,
+         'avg_stage_ms': ms_stage,
+         'profile_avg_us': prof_us,
+         'hbm_alg_frac': (psd_bytes / t / 1e9 / HBM_PEAK_GBS) if t else None,
+         'hbm_physical_frac': (traffic / t / 1e9 / HBM_PEAK_GBS) if (t and traffic) else None,
+         'algorithmic_bytes_per_launch': psd_bytes,
+         'note': 'bound = f64 VALU issue (SIMD instruction slots); hbm_alg_frac is the survey\'s '
+                 'B_alg / t / 8 TB/s (> 1 because LUT slices are shared on chip); traffic = HBM bytes '
+                 'per launch from the PMC passes in profiles/ ((2 FETCH_SIZE + WRITE_SIZE) KiB)'}
+    if ms_isolated:
+        ti = ms_isolated * 1e-3
+        r['isolated'] = {'avg_stage_ms': ms_isolated, 'frac': n_inst / ti / 1e9 / peak,
+                         'essential_fma_frac': -(-n_valid // 64) * 1024 * 12 / ti / 1e9 / peak,
+                         'note': 'same sweep with one lane only (no overlap with other sweeps)'}
+    return r
+
+
+# ------------------------------------------------------------------------------------------ c4
+def run_c4(env):
+    """Strong scaling of the C4 volume: every sweep's azimuths sharded over the ranks."""
+    from cosmo_pol_amd.distributed import shard_bounds
+    op, lanes, n_lanes, world, rank = env['op'], env['lanes'], env['n_lanes'], env['world'], env['rank']
+    args, torch, dist, cube = env['args'], env['torch'], env['dist'], env['cube']
+    dev = torch.device('cuda', env['local_rank'])
+    az_all = np.arange(0, 360, 1.0 if not args.small else 4.0)
+    n_az, n_gates = len(az_all), len(op.constants.RANGE_RADAR)
+    lo, hi, per = shard_bounds(n_az, world, rank)
+    n_el = len(C4_ELEVATIONS)
+    nf = len(RADAR_FIELDS)
+    # per sweep: this rank's block [fields][per][gates] and the gathered sweep [world][...]
+    blocks = [torch.zeros((nf, per, n_gates), dtype=torch.float32, device=dev) for _ in range(n_el)]
+    gathered = [torch.empty((world, nf, per, n_gates), dtype=torch.float32, device=dev)
+                for _ in range(n_el)] if world > 1 else blocks
+    host = (torch.empty((n_el, world, nf, per, n_gates), dtype=torch.float32).pin_memory()
+            if rank == 0 else None)
+    ptrs = [{k: b[i].data_ptr() for i, k in enumerate(RADAR_FIELDS)} for b in blocks]
+    lane_streams = [torch.cuda.ExternalStream(c.stream_ptr(), device=dev) for c in lanes]
+    comm = torch.cuda.Stream(device=dev)
+    block_free = [None] * n_el
+    az, n_loc = az_all[lo:hi], hi - lo
+
+    def volume():
+        for e, elev in enumerate(C4_ELEVATIONS):
+            lane = e % n_lanes
+            if block_free[e] is not None:
+                lane_streams[lane].wait_event(block_free[e])      # its last gather has read it
+            if n_loc > 0:
+                op.simulate_rays(az, np.full(n_loc, elev), device_outputs=ptrs[e], lane=lane)
+            done = torch.cuda.Event()
+            done.record(lane_streams[lane])
+            comm.wait_event(done)
+            with torch.cuda.stream(comm):
+                if world > 1:
+                    dist.all_gather_into_tensor(gathered[e].view(-1), blocks[e].view(-1))
+                if rank == 0:
+                    host[e].view(-1).copy_(gathered[e].view(-1), non_blocking=True)
+                block_free[e] = torch.cuda.Event()
+                block_free[e].record(comm)
+
+    def fence():
+        for i in range(n_lanes):
+            op.wait(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world > 1:
+        with torch.cuda.stream(comm):                 # communicator set-up is setup, not a step
+            dist.all_gather_into_tensor(gathered[0].view(-1), blocks[0].view(-1))
+    fence()
+    for _ in range(args.warmup):
+        volume()
+    fence()
+    for c in lanes:
+        c.enable_timing(2)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        volume()
+    t_submit = time.perf_counter() - t0
+    fence()
+    elapsed = time.perf_counter() - t0
+    ms_psd = [c.counters().ms_psd for c in lanes]
+    for c in lanes:
+        c.enable_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    gates_per_step = n_el * n_az * n_gates
+    value = gates_per_step * args.steps / elapsed
+
+    # per-rank work of one volume (untimed pass: counters after every sweep)
+    n_valid_loc = n_units_loc = 0
+    for e, elev in enumerate(C4_ELEVATIONS):
+        if n_loc > 0:
+            op.simulate_rays(az, np.full(n_loc, elev), device_outputs=ptrs[e], lane=0)
+            c = op._ctx.counters()
+            n_valid_loc += int(c.n_valid_items)
+            n_units_loc += int(c.n_work_units)
+    per_rank = [None] * world
+    if world > 1:
+        dist.all_gather_object(per_rank, {'rank': rank, 'rays_per_sweep': n_loc, 'n_valid_items': n_valid_loc,
+                                          'n_work_units': n_units_loc})
+    else:
+        per_rank = [{'rank': 0, 'rays_per_sweep': n_loc, 'n_valid_items': n_valid_loc,
+                     'n_work_units': n_units_loc}]
+
+    # rank 0 alone: the same volume on ONE GPU (the strong-scaling reference), and the check
+    # that the gathered volume equals it bit for bit
+    single = gather_ok = None
+    fence()
+    if rank == 0:
+        full = [torch.zeros((nf, n_az, n_gates), dtype=torch.float32, device=dev) for _ in range(n_el)]
+        fptrs = [{k: b[i].data_ptr() for i, k in enumerate(RADAR_FIELDS)} for b in full]
+
+        def volume_alone():
+            for e, elev in enumerate(C4_ELEVATIONS):
+                op.simulate_rays(az_all, np.full(n_az, elev), device_outputs=fptrs[e], lane=e % n_lanes)
+        n_it = max(2, args.steps // 3)
+        volume_alone()
+        for i in range(n_lanes):
+            op.wait(i)
         t0 = time.perf_counter()
         for _ in range(n_it):
-            step()
-        fence()
-        value_fresh = n_rays * n_gates * n_it / (time.perf_counter() - t0)
-        op.reuse_device_tables = True
-
-    # PCIe-inclusive variant (outputs copied to host buffers every step), N = 1 only
-    value_d2h = None
-    if world == 1:
-        op.simulate_rays(az, el)
-        t0 = time.perf_counter()
-        for _ in range(max(3, args.steps // 4)):
-            op.simulate_rays(az, el)
-        value_d2h = n_rays * n_gates * max(3, args.steps // 4) / (time.perf_counter() - t0)
-
-    out = None
-    if rank == 0:
-        n_valid = int(cnt.n_valid_items)
-        n_sbg = int(cnt.n_subbeam_gates)
-        n_vars = len(op._staged_vars)
-        psd_bytes = n_valid * LUT_SLICE_BYTES
-        achieved = psd_bytes / (cnt.ms_psd * 1e-3) / 1e9 if cnt.ms_psd > 0 else None
-        sweep_bytes = (n_sbg * (4 * cube['zlevels'].shape[0] * 4 + n_vars * 8 * 4)
-                       + psd_bytes + n_rays * n_gates * 48)
-        # f64 VALU issue roofline of the PSD kernel: 16 v_*_f64 per (item, bin) in the
-        # recurrence flavour (12 FMAs + 4, counted in the ISA), 4 cycles per wave64
-        # instruction on a SIMD-32, 1024 SIMDs at the 2.4 GHz peak clock
-        n_units = int(cnt.n_work_units)
-        valu_cycles = -(-int(cnt.n_valid_items) // 64) * 1024 * 16 * 4
-        valu_frac = valu_cycles / (1024 * 2.4e9 * cnt.ms_psd * 1e-3) if cnt.ms_psd > 0 else None
-        out = {
-            'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '360-azimuth x 500-gate C-band PPI (el 1.0 deg), rain+snow+graupel '
-                                   '1-moment, 1 sub-beam, synthetic %s cube; one such sweep per GPU '
-                                   'per step' % ('x'.join(map(str, cube['zlevels'].shape))),
-                       'rays_per_gpu': n_rays, 'gates_per_ray': n_gates,
-                       'lanes': n_lanes,
-                       'parallelism': ('rays sharded by sweep, 1 all-gather/step on a side stream, overlapped '
-                                       'with the next step') if world > 1 else 'single GPU',
-                       'small': bool(args.small)},
-            'roofline': {'kernel': 'k_psd_uniform<false> (recurrence flavour of the PSD x table kernel; 1 launch/sweep covers R, S, G)', 'bound': 'hbm',
-                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
-                         'traffic': PSD_TRAFFIC_BYTES_PER_SWEEP,
-                         'algorithmic_bytes_per_sweep_stage': psd_bytes,
-                         'valu_f64_frac': valu_frac,
-                         'avg_stage_ms': cnt.ms_psd,
-                         'isolated': None if iso is None else {
-                             'avg_stage_ms': iso.ms_psd,
-                             'frac': psd_bytes / (iso.ms_psd * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             'valu_f64_frac': valu_cycles / (1024 * 2.4e9 * iso.ms_psd * 1e-3),
-                             'device_total_ms': iso.ms_total,
-                             'stages_ms': {'trajectory': iso.ms_traj, 'interp': iso.ms_interp,
-                                           'classify': iso.ms_classify, 'bucket': iso.ms_bucket,
-                                           'psd': iso.ms_psd, 'final': iso.ms_final},
-                             'note': 'same sweep with one lane only (no overlap with other sweeps)'},
-                         'note': 'algorithmic bytes = N_valid x 49152 B (one float32 LUT slice per valid '
-                                 'item, SURVEY 8(d)); slices are shared through the scalar cache / L2, '
-                                 'so frac can exceed 1 -- see DESIGN.md'},
-            'stages_ms': None if iso is None else {
-                'trajectory': iso.ms_traj, 'interp': iso.ms_interp, 'classify': iso.ms_classify,
-                'bucket': iso.ms_bucket, 'psd': iso.ms_psd, 'final': iso.ms_final,
-                'device_total': iso.ms_total, 'psd_with_lanes_in_flight': cnt.ms_psd,
-                'note': 'one sweep on one lane (the pass after the timed region); in the timed '
-                        'region only the PSD stage of lane 0 carries events (2 per sweep)'},
-            'counters': {'n_subbeam_gates': n_sbg, 'n_valid_items': n_valid,
-                         'n_work_units': int(cnt.n_work_units),
-                         'sweep_algorithmic_bytes': sweep_bytes,
-                         'sweep_algorithmic_GBs': sweep_bytes * world / (elapsed / args.steps) / 1e9},
-            'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
-            'gather_check': gather_ok,
-            'value_with_d2h': value_d2h,
-            'value_fresh_tables': value_fresh,
-            'setup_s': {'synthetic_inputs': t_gen, 'stage_to_hbm': t_stage},
-        }
-        if cpu_res is not None:
-            out['cpu_baseline'] = cpu_res
-            out['gpu_over_cpu_core'] = value / cpu_res['value']
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    op.close()
+            volume_alone()
+        for i in range(n_lanes):
+            op.wait(i)
+        t1 = (time.perf_counter() - t0) / n_it
+        single = {'ms_per_volume': 1e3 * t1, 'value': gates_per_step / t1,
+                  'note': 'rank 0 runs the whole 5 x 360-ray volume alone after the timed region '
+                          '(outputs left in HBM, 3 lanes)'}
+        ok = True
+        for e in range(n_el):
+            g = host[e]                                      # [world][nf][per][gates] on the host
+            asm = torch.cat([g[r, :, :max(0, min(per, n_az - r * per))] for r in range(world)], dim=1)
+            ok = ok and bool(torch.equal(torch.nan_to_num(asm), torch.nan_to_num(full[e].cpu())))
+        gather_ok = ok
+    fence()
+    if rank != 0:
+        return None
+    n_valid = sum(p['n_valid_items'] for p in per_rank)
+    ms_stage = max(ms_psd) if ms_psd else None
+    roof = roofline('c4', 'k_psd_melting<false>', ms_stage, max(p['n_valid_items'] for p in per_rank) // n_el,
+                    max(p['n_valid_items'] for p in per_rank) // n_el * LUT_SLICE_BYTES)
+    roof['note'] += ('; c4: avg_stage_ms = the PSD stage (recurrence + ice + melting flavours, launched '
+                     'on sibling streams) of one sweep of the busiest rank; the instruction count is the '
+                     'melting flavour\'s when a profile of this workload is committed')
+    return {
+        'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'c4: 5-elevation volume %s, %d x %d gates each, R,S,G,mS,mG,I 1-moment + melting '
+                               'layer, 7x7 Gauss-Hermite sub-beams (49 per radial), synthetic %s cube; one '
+                               'volume per step; sub-beam gates are not counted as gates'
+                               % (C4_ELEVATIONS, n_az, n_gates, 'x'.join(map(str, cube['zlevels'].shape))),
+                   'rays_per_gpu_per_sweep': per, 'gates_per_ray': n_gates, 'sub_beams': 49,
+                   'lanes': n_lanes,
+                   'parallelism': 'azimuths of every sweep sharded in contiguous blocks of ceil(360/N) rays; '
+                                  'one all-gather of the device blocks per sweep (RCCL), rank 0 copies the '
+                                  'assembled volume to page-locked host memory',
+                   'small': bool(args.small)},
+        'roofline': roof,
+        'per_rank': per_rank,
+        'counters': {'n_valid_items_per_volume': n_valid,
+                     'n_subbeam_gates_per_volume': n_el * n_az * n_gates * 49},
+        'single_gpu_same_workload': single,
+        'speedup_vs_single_gpu': (value / single['value']) if single else None,
+        'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
+        'gather_check': gather_ok,
+    }
 
 
+# ------------------------------------------------------------------------------- CPU baselines
 _POOL_STATE = {}
 
 
@@ -338,76 +598,86 @@ def _oracle_inputs(conf, cube, luts):
     return oconf, oc, ol
 
 
-def _pool_radial(a):
+def _one_radial(inputs, a, el):
     from cosmo_pol_oracle import beam, scatter
-    oconf, oc, ol = _POOL_STATE['inputs']
-    subs = beam.interpolate_radial(oc, oconf, float(a), 1.0)
+    oconf, oc, ol = inputs
+    subs = beam.interpolate_radial(oc, oconf, float(a), float(el))
     return len(scatter.radar_observables(subs, ol, oconf).values['ZH'])
 
 
-def cpu_baseline_pool(conf, cube, luts, az, max_procs=16):
-    """the same per-radial oracle under a fork pool mapped over the
-    azimuths of whole sweeps.  Two legs: persistent workers (the favourable one for the
-    CPU, reported as `value`) and one task per worker process as the reference's
-    `Pool(processes=P, maxtasksperchild=1).map` (radar_operator.py:402,431)."""
-    import multiprocessing as mp
-    procs = max(1, min(os.cpu_count() or 1, max_procs))
-    _POOL_STATE['inputs'] = _oracle_inputs(conf, cube, luts)     # inherited by fork, not pickled
-    ctx = mp.get_context('fork')
-    res = {}
-    for leg, kw, sweeps in (('persistent', {}, 4), ('reference_style', {'maxtasksperchild': 1}, 1)):
-        t0 = time.perf_counter()
-        with ctx.Pool(processes=procs, **kw) as pool:
-            n_gates = sum(pool.map(_pool_radial, list(az) * sweeps, chunksize=1))
-        dt = time.perf_counter() - t0
-        res[leg] = (n_gates / dt, dt, sweeps)
-    _POOL_STATE.clear()
-    v, dt, sweeps = res['persistent']
-    return {'value': v, 'unit': 'gates/s', 'cores': procs,
-            'sample': '%d sweeps of %d radials, fork pool of %d persistent worker processes, %.1f s '
-                      '(pool start-up included)' % (sweeps, len(az), procs, dt),
-            'reference_style': {'value': res['reference_style'][0],
-                                'sample': 'one sweep, Pool(%d, maxtasksperchild=1) as '
-                                          'radar_operator.py:402 (a fork per radial), %.1f s'
-                                          % (procs, res['reference_style'][1])}}
+def _pool_radial(a):
+    return _one_radial(_POOL_STATE['inputs'], a, _POOL_STATE['el'])
 
 
-def cpu_baseline(conf, cube, luts, az, budget_s):
-    """The CPU oracle (restatement of the reference algorithm: per radial,
-    per-variable C gate kernel, float64 LUT gather + einsum) on 1 core."""
-    from cosmo_pol_oracle import beam, scatter
-    from cosmo_pol_oracle import config as ocfg
-    from cosmo_pol_oracle import lut as olut
-    oconf = ocfg.make_config(conf)
-    order = ['U', 'V', 'W', 'QR_v', 'QS_v', 'QG_v', 'QI_v', 'RHO', 'T']
-    oc = beam.ModelCube({n: cube['data'][n] for n in order}, cube['zlevels'], cube['proj_info'],
-                        cube['resolution'], order)
-    ol = {}
-    for h, s in luts.items():
-        L = olut.LookupTable()
-        L.axes, L.axes_names, L.axes_limits, L.axes_step = s.axes, s.axes_names, s.axes_limits, s.axes_step
-        L.value_table = s.value_table
-        ol[h] = L
-    # whole PPIs, azimuth by azimuth like the reference's pool.map tasks, until the
-    # budget is used (at least one full sweep when it fits, never less than 8 radials)
-    n_done, n_gates = 0, 0
-    t0 = time.perf_counter()
-    done = False
-    while not done:
-        for a in az:
-            subs = beam.interpolate_radial(oc, oconf, float(a), 1.0)
-            obs = scatter.radar_observables(subs, ol, oconf)
-            n_done += 1
-            n_gates += len(obs.values['ZH'])
-            if time.perf_counter() - t0 > budget_s and n_done >= 8:
-                done = True
-                break
-    dt = time.perf_counter() - t0
-    return {'value': n_gates / dt, 'unit': 'gates/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d radials (%.2f sweeps of 360 azimuths, in azimuth order), %d gates each, '
-                      'oracle/cosmo_pol_oracle on one host core, %.1f s'
-                      % (n_done, n_done / 360.0, n_gates // max(n_done, 1), dt),
+def cpu_baseline(conf, cube, luts, az, el, budget_s, n_samples=5):
+    """the CPU oracle (restatement of the reference algorithm: per radial,
+    per-variable C gate kernel, float64 LUT gather + einsum) on ONE core: the process is pinned
+    to one CPU (sched_setaffinity, what `taskset` does), 1 warm-up radial, then `n_samples`
+    samples of budget/n_samples seconds each over consecutive azimuths; median gates/s."""
+    inputs = _oracle_inputs(conf, cube, luts)
+    old = os.sched_getaffinity(0)
+    os.sched_setaffinity(0, {sorted(old)[len(old) // 2]})
+    try:
+        _one_radial(inputs, az[0], el)
+        rates, n_done, k = [], 0, 0
+        for _ in range(n_samples):
+            t0 = time.perf_counter()
+            gates = rad = 0
+            while True:
+                gates += _one_radial(inputs, az[k % len(az)], el)
+                k += 1
+                rad += 1
+                if time.perf_counter() - t0 > budget_s / n_samples:
+                    break
+            dt = time.perf_counter() - t0
+            rates.append((gates / dt, rad / dt))
+            n_done += rad
+    finally:
+        os.sched_setaffinity(0, old)
+    rates.sort()
+    med = rates[len(rates) // 2]
+    return {'value': med[0], 'unit': 'gates/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d radials in azimuth order (el %.1f deg) in %d samples of %.1f s, median; '
+                      'oracle/cosmo_pol_oracle pinned to one host core (sched_setaffinity)'
+                      % (n_done, el, n_samples, budget_s / n_samples),
+            'samples_gates_per_s': [r[0] for r in rates], 'radials_per_s': med[1],
             'host_cpus': os.cpu_count()}
+
+
+def cpu_baseline_pool(conf, cube, luts, az, el, radials_per_s_1core, target_s=6.0):
+    """the same per-radial oracle under a fork pool of P = os.cpu_count()
+    processes mapped over azimuths, as radar_operator.py:402,431.  `value`: steady state of
+    persistent workers (pool already up; the favourable figure for the CPU); `with_pool_startup`
+    includes creating the pool, as every get_PPI call of the reference does; `reference_style`:
+    one task per worker process, `Pool(P, maxtasksperchild=1).map` exactly as the reference."""
+    import multiprocessing as mp
+    procs = max(1, os.cpu_count() or 1)
+    _POOL_STATE['inputs'] = _oracle_inputs(conf, cube, luts)     # inherited by fork, not pickled
+    _POOL_STATE['el'] = el
+    ctx = mp.get_context('fork')
+    n_rad = int(min(max(2 * procs, target_s * procs * radials_per_s_1core), 400000))
+    tasks = [az[i % len(az)] for i in range(n_rad)]
+    chunk = max(1, min(16, n_rad // (procs * 8)))
+    t0 = time.perf_counter()
+    with ctx.Pool(processes=procs) as pool:
+        pool.map(_pool_radial, [az[i % len(az)] for i in range(procs)], chunksize=1)   # warm-up
+        t1 = time.perf_counter()
+        n_gates = sum(pool.map(_pool_radial, tasks, chunksize=chunk))
+        t2 = time.perf_counter()
+    res = {'value': n_gates / (t2 - t1), 'unit': 'gates/s', 'cores': procs,
+           'sample': '%d radials (%.1f sweeps of 360), fork pool of %d persistent worker processes '
+                     '(P = os.cpu_count()), chunksize %d, %.1f s' % (n_rad, n_rad / 360.0, procs, chunk, t2 - t1),
+           'with_pool_startup': {'value': n_gates / (t2 - t0), 'seconds': t2 - t0}}
+    n_ref = min(len(az), max(procs, 64))
+    t0 = time.perf_counter()
+    with ctx.Pool(processes=procs, maxtasksperchild=1) as pool:
+        g = sum(pool.map(_pool_radial, list(az[:n_ref]), chunksize=1))
+    dt = time.perf_counter() - t0
+    res['reference_style'] = {'value': g / dt,
+                              'sample': '%d radials, Pool(%d, maxtasksperchild=1).map as '
+                                        'radar_operator.py:402,431 (a fork per radial), %.1f s' % (n_ref, procs, dt)}
+    _POOL_STATE.clear()
+    return res
 
 
 if __name__ == '__main__':

@@ -97,12 +97,14 @@ class Counters(C.Structure):
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_fork', 'cpol_last_error', 'cpol_set_stream',
            'cpol_get_stream',
            'cpol_synchronize', 'cpol_stage_model', 'cpol_stage_hydro', 'cpol_set_num_hydro',
-           'cpol_stage_doppler_weights', 'cpol_stage_spectrum_tables',
+           'cpol_stage_doppler_weights', 'cpol_stage_spectrum_tables', 'cpol_stage_t_function',
            'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
            'cpol_spaceborne_first_gate', 'cpol_host_alloc', 'cpol_host_free',
            'cpol_enable_timing', 'cpol_debug_read', 'cpol_debug_math']
 
 TRAJ_STRIDE, GEO_STRIDE, SITE_STRIDE = 4, 8, 8      # CPOL_*_STRIDE of the header
+TFUN_SNOW_N0, TFUN_ICE_MOM2_A = 0, 1
+TFUN_FIRST_BITS, TFUN_COUNT = 0x43000000, 1 << 24  # every float32 in [128, 512)
 
 _lib = None
 
@@ -165,6 +167,8 @@ def load_library():
     lib.cpol_stage_spectrum_tables.argtypes = [vp, C.c_int, vp, vp]
     lib.cpol_debug_math.restype = C.c_int
     lib.cpol_debug_math.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    lib.cpol_stage_t_function.restype = C.c_int
+    lib.cpol_stage_t_function.argtypes = [vp, C.c_int, vp]
     lib.cpol_host_alloc.restype = C.c_int
     lib.cpol_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.cpol_host_free.restype = C.c_int
@@ -294,6 +298,13 @@ class Context(object):
         dgrid = np.ascontiguousarray(dgrid, dtype=np.float32)
         self._check(self.lib.cpol_stage_spectrum_tables(self.h, int(slot), _ptr(rcs32), _ptr(dgrid)),
                     'cpol_stage_spectrum_tables')
+
+    def stage_t_function(self, which, table):
+        table = np.ascontiguousarray(table, dtype=np.float32)
+        if table.size != TFUN_COUNT:
+            raise ValueError('t-function table must have %d entries' % TFUN_COUNT)
+        self._check(self.lib.cpol_stage_t_function(self.h, int(which), _ptr(table)),
+                    'cpol_stage_t_function')
 
     def set_num_hydro(self, n):
         self._check(self.lib.cpol_set_num_hydro(self.h, n), 'cpol_set_num_hydro')

@@ -61,6 +61,8 @@ struct cpol_ctx {
     DevBuf d_table[CPOL_MAX_HYDRO], d_pre[CPOL_MAX_HYDRO], d_dnu[CPOL_MAX_HYDRO],
         d_aux[CPOL_MAX_HYDRO], d_rcsw[CPOL_MAX_HYDRO], d_rcs32[CPOL_MAX_HYDRO], d_dgrid[CPOL_MAX_HYDRO];
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
+    DevBuf d_tfun[CPOL_N_TFUN];        // host-tabulated float32 functions of T (cpol_stage_t_function)
+    const float *tfun[CPOL_N_TFUN] = {};
     // per-sweep work buffers (grow only)
     DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site, b_nyq;
     DevBuf b_subsmooth, b_mlfilter, b_wgate, b_clk;
@@ -183,8 +185,10 @@ void cpol_destroy(cpol_ctx *ctx)
             ctx->d_aux[j] = DevBuf(); ctx->d_rcsw[j] = DevBuf();
             ctx->d_rcs32[j] = DevBuf(); ctx->d_dgrid[j] = DevBuf();
         }
+        for (auto &b : ctx->d_tfun) b = DevBuf();
         ctx->parent->n_children -= 1;
     }
+    for (auto &b : ctx->d_tfun) free_buf(b);
     DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj_in, &ctx->b_geo, &ctx->b_subh, &ctx->b_subv,
                      &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_subsmooth, &ctx->b_mlfilter, &ctx->b_wgate, &ctx->b_clk, &ctx->b_varray, &ctx->b_beam, &ctx->b_spectrum, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
@@ -247,6 +251,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->hs = parent->hs;
     c->ss = parent->ss;
     for (int j = 0; j < CPOL_MAX_HYDRO; ++j) c->hydro_staged[j] = parent->hydro_staged[j];
+    for (int k = 0; k < CPOL_N_TFUN; ++k) c->tfun[k] = parent->tfun[k];
     parent->n_children += 1;
     *out = c;
     return CPOL_OK;
@@ -484,6 +489,26 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
         ctx->hydro_staged[slot] = false;               // the slot does not count as staged
         return rc_n;
     }
+    return CPOL_OK;
+}
+
+int cpol_stage_t_function(cpol_ctx *ctx, int which, const float *table)
+{
+    if (!ctx || !table || which < 0 || which >= CPOL_N_TFUN) {
+        if (ctx) ctx->err = "cpol_stage_t_function: bad arguments";
+        return CPOL_ERR_ARG;
+    }
+    if (ctx->parent || ctx->n_children) {
+        ctx->err = "cpol_stage_t_function: not on a lane, and not while lanes of this context exist (cpol_fork)";
+        return CPOL_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->d_tfun[which], table, (size_t)CPOL_TFUN_COUNT * sizeof(float))) != CPOL_OK)
+        return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->tfun[which] = (const float *)ctx->d_tfun[which].p;
+    ctx->stage_serial++;
     return CPOL_OK;
 }
 
@@ -826,6 +851,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ca.with_melting = p->with_melting;
     ca.var_qr = ca.var_qs = ca.var_qg = -1;
     ca.doppler = doppler ? 1 : 0;
+    ca.tfun_snow = ctx->tfun[CPOL_TFUN_SNOW_N0];
+    ca.tfun_ice = ctx->tfun[CPOL_TFUN_ICE_MOM2_A];
     for (int j = 0; j < n_hyd; ++j) {
         const cpol_hydro_desc &d = ctx->hs.h[j].d;
         if (d.q_source != CPOL_Q_MODEL) continue;

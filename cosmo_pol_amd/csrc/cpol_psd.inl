@@ -264,7 +264,20 @@ struct ClassifyArgs {
     int var_qr, var_qs, var_qg;
     int doppler;                 // also store the analytic fall-speed moments (integrate_V)
     const double *wgate;         // [n_sbg] per-gate sub-beam weights (scheme 'ml') or NULL
+    // float32 functions of T tabulated by the host's NumPy over every float32 in [128, 512) K
+    // (cpol_stage_t_function): the reference's float32 exp / power are 1-2 ulp off the
+    // correctly rounded value in 20-40 % of the arguments, and K_DP shows it
+    const float *tfun_snow;      // snow intercept N0(T)  (hydrometeors.py:896) or NULL
+    const float *tfun_ice;       // 10**a(T) of the Field (2005) moment relation (:1287) or NULL
 };
+
+__device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &out)
+{
+    const unsigned idx = __float_as_uint(T) - CPOL_TFUN_FIRST_BITS;
+    if (!tab || idx >= CPOL_TFUN_COUNT) return false;
+    out = tab[idx];
+    return true;
+}
 
 #define CPOL_MAX_PAR 6
 
@@ -338,7 +351,9 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 break;
             case CPOL_RULE_SNOW_1MOM: {
                 // hydrometeors.py:896-899: float32 chain, then float64 from lambda_factor on
-                float n0 = 13.5f * (565000.0f * exp_f32(-0.107f * (T - 273.15f))) / 1000.0f;
+                float n0;
+                if (!tfun_lookup(a.tfun_snow, T, n0))
+                    n0 = 13.5f * (565000.0f * exp_f32(-0.107f * (T - 273.15f))) / 1000.0f;
                 float an0 = (float)d.a * n0;
                 lamf = cp_pow((double)an0 * d.lambda_factor / q, d.lam_exponent);
                 n0v = (double)n0;
@@ -361,10 +376,13 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 // hydrometeors.py:1277-1299 (float32 polynomials), :1320-1328
                 const float Tc = T - 273.15f;
                 const float n3 = 3.0f;
-                float pa = 5.065339f - 0.062659f * Tc - (float)(3.032362 * 3) + 0.029469f * Tc * n3
-                    - 0.000285f * (Tc * Tc) + (float)(0.312550 * 9) + 0.000204f * (Tc * Tc) * n3
-                    + 0.003199f * Tc * 9.0f - (float)(0.015952 * 27);
-                pa = pow10_f32(pa);
+                float pa;
+                if (!tfun_lookup(a.tfun_ice, T, pa)) {
+                    pa = 5.065339f - 0.062659f * Tc - (float)(3.032362 * 3) + 0.029469f * Tc * n3
+                        - 0.000285f * (Tc * Tc) + (float)(0.312550 * 9) + 0.000204f * (Tc * Tc) * n3
+                        + 0.003199f * Tc * 9.0f - (float)(0.015952 * 27);
+                    pa = pow10_f32(pa);
+                }
                 float pb = 0.476221f - 0.015896f * Tc + (float)(0.165977 * 3) + 0.007468f * Tc * n3
                     - 0.000141f * (Tc * Tc) + (float)(0.060366 * 9) + 0.000079f * (Tc * Tc) * n3
                     + 0.000594f * Tc * 9.0f - (float)(0.003577 * 27);

@@ -2,13 +2,20 @@
 
 The reference farms the radials of a sweep out to a fork pool and collects
 pickled Radial objects over pipes (cosmo_pol/radar_operator.py:402-432).  Here
-the rays of a sweep (or of a whole volume) are split into contiguous blocks,
-one per rank; model cube and lookup tables are replicated in every GPU's HBM
-(staged once); every rank runs its block through the C ABI and the output
-slabs are collected with a single all-gather (RCCL over xGMI when the backend
-is "nccl", gloo on CPU for tests).  Radials never interact (all coupling -
-PHIDP / attenuation scans, sub-beam sums - is inside one radial), so the
-gathered result is bitwise identical to the single-GPU result.
+the rays of a sweep are split into contiguous blocks, one per rank; model cube
+and lookup tables are replicated in every GPU's HBM (staged once); every rank
+runs its block through the C ABI and the output blocks are collected with a
+single all-gather (RCCL over xGMI when the backend is "nccl", gloo on CPU for
+tests).  Radials never interact (all coupling - PHIDP / attenuation scans,
+sub-beam sums - is inside one radial), so the gathered result is bitwise
+identical to the single-GPU result.
+
+Block layout (what one rank contributes, `BlockLayout`): for every output field
+a [per, n_gates] array of the field's dtype, the fields one after the other at
+8-byte aligned offsets; `per` = ceil(n_rays / world) rows, the unused rows of
+the tail ranks stay zero.  The kernels write their outputs straight into the
+block on the device (`simulate_sharded_device`), the all-gather runs on device
+buffers, and ONE device-to-host copy returns the whole sweep.
 """
 import numpy as np
 
@@ -31,28 +38,56 @@ def pad_block(arr, per, fill):
     return np.concatenate([arr, pad], axis=0)
 
 
-def gather_rows(local, n_rays, group=None):
-    """All-gathers equally padded per-rank row blocks [per, row_bytes] (uint8
-    torch tensors, CPU or GPU) and trims the padding -> [n_rays, row_bytes] on
-    every rank.  ONE collective per sweep."""
+class BlockLayout(object):
+    """Byte layout of one rank's output block: field-major, [per, n_gates] per field."""
+
+    def __init__(self, fields, per, n_gates):
+        self.fields = [(k, np.dtype(dt)) for k, dt in fields]
+        self.per, self.n_gates = int(per), int(n_gates)
+        self.offsets, off = {}, 0
+        for k, dt in self.fields:
+            off = -(-off // 8) * 8
+            self.offsets[k] = off
+            off += self.per * self.n_gates * dt.itemsize
+        self.nbytes = -(-off // 8) * 8
+
+    def view(self, block, k):
+        """[per, n_gates] view of field k inside a uint8 block (numpy)."""
+        dt = dict(self.fields)[k]
+        o = self.offsets[k]
+        return block[o:o + self.per * self.n_gates * dt.itemsize].view(dt).reshape(self.per, self.n_gates)
+
+    def assemble(self, gathered, n_rays, world):
+        """[world * nbytes] uint8 (numpy) -> {field: [n_rays, n_gates]} (padding trimmed)."""
+        blocks = gathered.reshape(world, self.nbytes)
+        out = {}
+        for k, dt in self.fields:
+            parts = []
+            for r in range(world):
+                lo, hi, _ = shard_bounds(n_rays, world, r)
+                if hi > lo:
+                    parts.append(self.view(blocks[r], k)[:hi - lo])
+            out[k] = np.concatenate(parts, axis=0) if parts else np.empty((0, self.n_gates), dtype=dt)
+        return out
+
+
+def gather_blocks(local, group=None):
+    """All-gathers equally sized per-rank blocks (1-D uint8 torch tensors, CPU or GPU)
+    -> [world * nbytes] on every rank.  ONE collective per sweep."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    per, nb = local.shape
     flat = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(flat, local.contiguous().view(-1), group=group)
-    return flat.view(world * per, nb)[:n_rays]
+    return flat
 
 
 def simulate_sharded(simulate, azimuths, elevations, fields, n_gates, device=None, group=None):
-    """Runs `simulate(az_block, el_block) -> {field: [n_block, n_gates] array}`
-    on this rank's contiguous block of rays and gathers all ranks' results.
-
-    `fields`: list of (name, dtype).  All outputs of one ray are packed into
-    one byte row, so the whole sweep needs a single all-gather whatever the
-    mix of float32 / float64 fields.  `simulate` is RadarOperator.simulate_rays
-    on a GPU rank; tests inject a CPU stand-in to exercise the sharding and the
-    collective with gloo."""
+    """Host-buffer form: runs `simulate(az_block, el_block) -> {field: [n_block, n_gates]
+    array}` on this rank's contiguous block of rays and gathers all ranks' results.
+    `fields`: list of (name, dtype).  Used by the gloo tests with a CPU stand-in and by
+    callers whose per-rank results live on the host; the GPU product path is
+    `simulate_sharded_device`."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -60,24 +95,56 @@ def simulate_sharded(simulate, azimuths, elevations, fields, n_gates, device=Non
     el = np.asarray(elevations, dtype=np.float64)
     n = len(az)
     lo, hi, per = shard_bounds(n, world, rank)
-    fields = [(k, np.dtype(dt)) for k, dt in fields]
-    offs, row_bytes = [], 0
-    for k, dt in fields:
-        row_bytes = -(-row_bytes // 8) * 8
-        offs.append(row_bytes)
-        row_bytes += n_gates * dt.itemsize
-    row_bytes = -(-row_bytes // 8) * 8
-    rows = np.zeros((per, row_bytes), dtype=np.uint8)
+    lay = BlockLayout(fields, per, n_gates)
+    block = np.zeros(lay.nbytes, dtype=np.uint8)
     if hi > lo:
         res = simulate(az[lo:hi], el[lo:hi])
-        for (k, dt), o in zip(fields, offs):
-            blk = np.ascontiguousarray(res[k], dtype=dt).reshape(hi - lo, n_gates)
-            rows[:hi - lo, o:o + n_gates * dt.itemsize] = blk.view(np.uint8).reshape(hi - lo, -1)
-    t = torch.from_numpy(rows)
+        for k, dt in lay.fields:
+            lay.view(block, k)[:hi - lo] = np.ascontiguousarray(res[k], dtype=dt).reshape(hi - lo, n_gates)
+    t = torch.from_numpy(block)
     if device is not None:
         t = t.to(device)
-    full = gather_rows(t, n, group).cpu().numpy()
-    out = {}
-    for (k, dt), o in zip(fields, offs):
-        out[k] = np.ascontiguousarray(full[:, o:o + n_gates * dt.itemsize]).view(dt).reshape(n, n_gates)
-    return out
+    return lay.assemble(gather_blocks(t, group).cpu().numpy(), n, world)
+
+
+def simulate_sharded_device(run_block, stream_ptr, azimuths, elevations, fields, n_gates, device,
+                            group=None, cache=None):
+    """Device-resident form (the product path of RadarOperator(distributed=True)):
+
+      run_block(az_block, el_block, {field: device pointer})   queues the sweep of this
+          rank's rays on the library stream `stream_ptr`; the kernels write every output
+          field straight into this rank's block of the gather buffer layout;
+      one all_gather_into_tensor of the device blocks (RCCL over xGMI), ordered behind the
+          kernels with an event;
+      one device-to-host copy of the gathered sweep.
+
+    `cache`: dict owned by the caller that keeps the device block / gather buffers between
+    sweeps of the same shape."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    az = np.asarray(azimuths, dtype=np.float64)
+    el = np.asarray(elevations, dtype=np.float64)
+    n = len(az)
+    lo, hi, per = shard_bounds(n, world, rank)
+    lay = BlockLayout(fields, per, n_gates)
+    cache = {} if cache is None else cache
+    key = ('blk', lay.nbytes, world)
+    if key not in cache:
+        cache.clear()
+        cache[key] = (torch.zeros(lay.nbytes, dtype=torch.uint8, device=device),
+                      torch.empty(world * lay.nbytes, dtype=torch.uint8, device=device),
+                      torch.empty(world * lay.nbytes, dtype=torch.uint8).pin_memory()
+                      if torch.cuda.is_available() else torch.empty(world * lay.nbytes, dtype=torch.uint8))
+    block, gathered, host = cache[key]
+    lib_stream = torch.cuda.ExternalStream(stream_ptr, device=device)
+    cur = torch.cuda.current_stream(device)
+    lib_stream.wait_stream(cur)                 # the previous gather has consumed the block
+    if hi > lo:
+        base = block.data_ptr()
+        run_block(az[lo:hi], el[lo:hi], {k: base + lay.offsets[k] for k, _ in lay.fields})
+    cur.wait_stream(lib_stream)                 # gather behind the kernels
+    dist.all_gather_into_tensor(gathered, block, group=group)
+    host.copy_(gathered, non_blocking=True)
+    cur.synchronize()
+    return lay.assemble(host.numpy(), n, world)

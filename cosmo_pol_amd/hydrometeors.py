@@ -268,3 +268,34 @@ def doppler_weights(h, scheme, lut):
         V = np.asarray(c['alpha'] * D ** c['beta'], dtype=np.float64)     # _Hydrometeor.get_V
         out[..., 0] = (V * rcs) * w
     return out
+
+
+def t_function_tables(which=('snow_n0', 'ice_mom2_a')):
+    """float32 functions of the temperature over EVERY float32 value in [128 K, 512 K),
+    evaluated here with the reference's own NumPy expressions (hydrometeors.py:896 and
+    :1284-1292): NumPy's float32 exp / power are not correctly rounded (1-2 ulp off in 20-40 %
+    of the arguments), and a 1-ulp difference of the snow intercept shows up above 1e-5 in
+    K_DP.  The device looks the value up by the bit pattern of T (cpol_stage_t_function), so it
+    uses the bits the reference would have used on this host.  {name: float32 [2**24]}"""
+    out = {k: _TFUN_CACHE[k] for k in which if k in _TFUN_CACHE}       # once per process
+    which = [k for k in which if k not in out]
+    if not which:
+        return out
+    T = np.arange(N.TFUN_FIRST_BITS, N.TFUN_FIRST_BITS + N.TFUN_COUNT, dtype=np.uint32).view(np.float32)
+    with np.errstate(over='ignore', under='ignore', invalid='ignore'):
+        if 'snow_n0' in which:
+            out['snow_n0'] = 13.5 * (5.65 * 10 ** 5 * np.exp(-0.107 * (T - 273.15))) / 1000
+        if 'ice_mom2_a' in which:
+            n = 3
+            Tc = T - K.T0
+            a = 5.065339 - 0.062659 * Tc - 3.032362 * n + 0.029469 * Tc * n \
+                - 0.000285 * Tc ** 2 + 0.312550 * n ** 2 + 0.000204 * Tc ** 2 * n \
+                + 0.003199 * Tc * n ** 2 - 0.015952 * n ** 3
+            out['ice_mom2_a'] = 10 ** (a)
+    for k, v in out.items():
+        assert v.dtype == np.float32, (k, v.dtype)
+        _TFUN_CACHE[k] = v
+    return out
+
+
+_TFUN_CACHE = {}

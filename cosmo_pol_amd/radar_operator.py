@@ -221,6 +221,7 @@ class RadarOperator(object):
             lut, built = cache[key]
             self.lut_sz = lut
             self._drop_lanes()
+            self._stage_t_functions(hl, scheme)
             for slot, h in enumerate(hl):
                 d, table, pre, dnu, aux, dw, st = built[h]
                 self._ctx.stage_hydro(slot, d, table, pre, dnu, aux)
@@ -245,6 +246,7 @@ class RadarOperator(object):
                                conf['microphysics']['scattering'], lut_dir=self.lut_dir)
         self.lut_sz = lut
         self._drop_lanes()
+        self._stage_t_functions(hl, scheme)
         var_index = {v: i for i, v in enumerate(hyd.variable_list(conf))}
         built = {}
         for slot, h in enumerate(hl):
@@ -265,6 +267,21 @@ class RadarOperator(object):
         self._staged_hydro = hl
         if self._model_staged and self._staged_vars != hyd.variable_list(conf):
             self._stage_model()                 # variable set changed (1mom <-> 2mom)
+
+    def _stage_t_functions(self, hl, scheme):
+        """Host-tabulated float32 functions of the temperature (1-moment snow intercept, 1-moment
+        ice moment relation): staged once per context, only when the species is simulated."""
+        if scheme != '1mom':
+            return
+        done = self.__dict__.setdefault('_tfun_staged', set())
+        want = [(n, w) for n, w, h in (('snow_n0', N.TFUN_SNOW_N0, 'S'), ('ice_mom2_a', N.TFUN_ICE_MOM2_A, 'I'))
+                if (h in hl or (h == 'S' and 'mS' in hl)) and n not in done]
+        if not want:
+            return
+        tabs = hyd.t_function_tables([n for n, _ in want])
+        for n, w in want:
+            self._ctx.stage_t_function(w, tabs[n])
+            done.add(n)
 
     # ------------------------------------------------------------------ model
     def load_model_file(self, filename, cfilename=None):

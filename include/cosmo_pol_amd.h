@@ -255,6 +255,21 @@ int  cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc,
                       const double *aux, int n_aux);
 int  cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro);
 
+/* float32 functions of the gate temperature, TABULATED BY THE HOST over every float32 value
+ * in [128 K, 512 K) (2^24 consecutive bit patterns from CPOL_TFUN_FIRST_BITS).  The reference
+ * evaluates them with NumPy's float32 exp / power, which are not correctly rounded (1-2 ulp off
+ * in 20-40 % of the arguments); a 1-ulp difference in the snow intercept becomes > 1e-5
+ * relative in K_DP, a difference of near-equal float32 sums.  The host evaluates the
+ * reference's own expressions with its own NumPy, the device looks the value up by the bit
+ * pattern of T: the bits the reference would have used, on every host.  Optional: without a
+ * table (or outside the range) the device computes the correctly rounded value.
+ *   CPOL_TFUN_SNOW_N0     13.5*(5.65e5*exp(-0.107*(T-273.15)))/1000   hydrometeors.py:896
+ *   CPOL_TFUN_ICE_MOM2_A  10**a(T - 273.15), Field et al. (2005)      hydrometeors.py:1287-1292 */
+enum { CPOL_TFUN_SNOW_N0 = 0, CPOL_TFUN_ICE_MOM2_A = 1, CPOL_N_TFUN = 2 };
+#define CPOL_TFUN_FIRST_BITS 0x43000000u      /* 128.0f */
+#define CPOL_TFUN_COUNT      (1u << 24)       /* every float32 in [128, 512) */
+int  cpol_stage_t_function(cpol_ctx *ctx, int which, const float *table /* [CPOL_TFUN_COUNT] */);
+
 /* Doppler scheme 2 (doppler_scatter.py:283-296): per table slice and diameter bin the
  * trapezoid weight w_k (1/2 at both ends) times the horizontal radar cross-section
  * 2 pi (Z11 - Z12 - Z21 + Z22), and the same times the fall speed V(D_k):

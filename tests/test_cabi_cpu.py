@@ -234,3 +234,26 @@ def test_c_host_links_and_runs(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and 'C_HOST_OK' in r.stdout, r.stdout + r.stderr
+
+
+def test_t_function_tables_are_the_reference_expressions_bit_for_bit():
+    """hydrometeors.t_function_tables: float32 functions of T over every float32 in
+    [128, 512) K, equal to the oracle's (= the reference's) NumPy expressions bit for bit."""
+    from cosmo_pol_amd import _native as N, hydrometeors as hyd
+    from cosmo_pol_oracle import psd
+    tabs = hyd.t_function_tables()
+    assert set(tabs) == {'snow_n0', 'ice_mom2_a'}
+    rng = np.random.default_rng(2)
+    T = np.concatenate([rng.uniform(128.0, 511.9, 5000), [128.0, 200.0, 273.15, 276.0]]).astype(np.float32)
+    idx = T.view(np.uint32) - N.TFUN_FIRST_BITS
+    assert idx.max() < N.TFUN_COUNT
+    sn = psd.create_hydrometeor('S', '1mom')
+    sn.set_psd(T, np.full(T.shape, 1e-4, dtype=np.float32))
+    assert np.asarray(sn.N0).dtype == np.float32
+    assert np.array_equal(tabs['snow_n0'][idx].view(np.uint32), np.asarray(sn.N0).view(np.uint32))
+    # ice: (QM / a) ** (1 / b) with a = 10 ** poly(T): recover a from the oracle's own statement
+    n, Tc = 3, T - 273.15
+    a = 5.065339 - 0.062659 * Tc - 3.032362 * n + 0.029469 * Tc * n \
+        - 0.000285 * Tc ** 2 + 0.312550 * n ** 2 + 0.000204 * Tc ** 2 * n \
+        + 0.003199 * Tc * n ** 2 - 0.015952 * n ** 3
+    assert np.array_equal(tabs['ice_mom2_a'][idx].view(np.uint32), (10 ** a).view(np.uint32))

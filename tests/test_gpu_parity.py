@@ -188,14 +188,12 @@ def test_radial_vs_reference_golden_and_oracle(golden, name):
         _cases.assert_close_nan(res[k][0], g['obs_' + k], rtol=RTOL, atol=atol, name='golden:' + k)
         rec = _record_parity(name, k, res[k][0], g['obs_' + k],
                              np.nan_to_num(oobs.sz_total.astype(np.float64)), conf)
-        if k in ('ZH', 'ZV', 'ZDR', 'RHOHV', 'ATT_H', 'ATT_V'):
-            assert rec['n_above_1e-5'] == 0, rec          # pure 1e-5 relative, no scaling
-        elif k == 'KDP':
-            # a difference of two float32-stored sums (quirk Q4): what exceeds the pure 1e-5 is
-            # explained by the cancellation of the operands -- never more than 1e-6 of them.
-            # (PHIDP and DELTA_HV, built on such differences, are recorded and held to the
-            # operand-scaled tolerance above.)
-            assert rec.get('worst_rel_over_cancellation', 0.0) < 1e-6, rec
+        # north_star: PURE 1e-5 relative on every polarimetric variable, K_DP included.  (Round 1
+        # needed an operand-scaled tolerance for K_DP: 3 % of the gates were up to 3.4e-5 off,
+        # every one of them through a 1-ulp difference of the float32 snow intercept -- NumPy's
+        # float32 exp is not correctly rounded.  The device now looks that value up in a table
+        # evaluated by the host's NumPy, cpol_stage_t_function.)
+        assert rec['n_above_1e-5'] == 0, rec
 
     # ---- radial velocity (Doppler scheme 1): float64, terms of O(10 m/s) that may cancel ----
     assert 'RVEL' in res

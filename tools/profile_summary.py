@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Merges the rocprofv3 passes of tools/take_profiles.sh into ONE summary that bench.py reads
+(profiles/r2_<workload>_summary.json): per kernel the mean SQ_INSTS_VALU / SQ_WAVE_CYCLES /
+SQ_WAIT_ANY / FETCH_SIZE / WRITE_SIZE per dispatch, the HBM bytes per dispatch with the gfx950
+correction of MI355X_MICROARCH.md ((2 FETCH_SIZE + WRITE_SIZE) KiB) and the kernel-trace
+average duration.
+
+usage: profile_summary.py <kernel_stats.csv> <pmc_fetch_dir> <pmc_write_dir> <pmc_sq_dir> > summary.json"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def pmc(d):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                acc[row.get('Kernel_Name', '')][row['Counter_Name']].append(float(row['Counter_Value']))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+def main():
+    stats, dF, dW, dS = sys.argv[1:5]
+    out = {'_note': 'means per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE '
+                    'counts 64 B per 128-B request); avg_us from rocprofv3 --kernel-trace --stats'}
+    with open(stats) as fh:
+        for row in csv.DictReader(fh):
+            name = row.get('Name') or row.get('KernelName') or ''
+            out[name] = {'calls': int(float(row.get('Calls', 0))),
+                         'avg_us': float(row.get('AverageNs', row.get('Average', 0))) / 1e3}
+    for d, keep in ((dF, ('FETCH_SIZE',)), (dW, ('WRITE_SIZE',)),
+                    (dS, ('SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY',
+                          'SQ_ACTIVE_INST_ANY', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'))):
+        for k, cs in pmc(d).items():
+            e = out.setdefault(k, {})
+            for c in keep:
+                if c in cs:
+                    e[c] = cs[c]
+    for k, e in out.items():
+        if isinstance(e, dict) and 'FETCH_SIZE' in e and 'WRITE_SIZE' in e:
+            e['hbm_bytes'] = (2 * e['FETCH_SIZE'] + e['WRITE_SIZE']) * 1024
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == '__main__':
+    main()
