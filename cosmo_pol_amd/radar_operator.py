@@ -623,8 +623,17 @@ class RadarOperator(object):
             fields.append(('RVEL', np.float64))
         n_gates = len(self.constants.RANGE_RADAR)
         dev = torch.device('cuda', self.device)
-        return D.simulate_sharded(lambda a, e: self.simulate_rays(a, e), az, el, fields, n_gates,
-                                  device=dev)
+        # device-resident: the kernels write this rank's rays straight into its block of the
+        # gather buffer, one all-gather of device blocks, one device-to-host copy of the sweep
+        ctx = self._lane(lane)
+        cache = self.__dict__.setdefault('_dist_cache', {})
+
+        def run_block(a, e, ptrs):
+            self.simulate_rays(a, e, device_outputs=ptrs, lane=lane)
+        res = D.simulate_sharded_device(run_block, ctx.stream_ptr(), az, el, fields, n_gates, dev,
+                                        cache=cache)
+        ctx.synchronize()                                       # deferred domain error, if any
+        return res
 
     def _package(self, res, az, el):
         fields = {}

@@ -18,3 +18,25 @@ def test_two_ranks_one_gpu_bitwise_equal_to_single_process():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert 'DIST_GPU_OK world=2' in out.stdout
+
+
+def test_bench_c4_strong_scaling_mode_two_ranks_one_gpu():
+    """bench.py --workload c4 with two ranks (gloo, both on GPU 0): azimuths of every sweep
+    sharded, one all-gather per sweep, the gathered volume equals rank 0's own single-GPU
+    volume bit for bit (`gather_check`)."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1', CPOL_BENCH_BACKEND='gloo',
+               CPOL_BENCH_ONE_DEVICE='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29541',
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--small', '--steps', '2', '--warmup', '1',
+           '--cpu-seconds', '0']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    r = json.loads(line)
+    assert r['n_gpus'] == 2 and r['scaling'] == 'strong' and r['gather_check'] is True
+    assert r['config']['workload'].startswith('c4') and len(r['per_rank']) == 2
+    assert r['per_rank'][0]['rays_per_sweep'] + r['per_rank'][1]['rays_per_sweep'] == 90
+    assert r['single_gpu_same_workload']['value'] > 0 and r['value'] > 0
