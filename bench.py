@@ -144,6 +144,7 @@ def main():
     cpu_res = None
     if world == 1 and args.cpu_seconds > 0:
         el_cpu = 1.0 if workload == 'c2' else C4_ELEVATIONS[2]
+        print('[bench] CPU baseline: one pinned core ...', file=sys.stderr, flush=True)
         cpu_res = cpu_baseline(conf, cube, luts, np.arange(0, 360, 1.0), el_cpu, args.cpu_seconds)
         cpu_res['all_cores'] = cpu_baseline_pool(conf, cube, luts, np.arange(0, 360, 1.0), el_cpu,
                                                  cpu_res['radials_per_s'])
@@ -257,6 +258,9 @@ def run_c2(env):
         with torch.cuda.stream(comm_stream):     # communicator set-up belongs to the setup phase
             dist.all_gather_into_tensor(gathered[0], slabs[0].view(-1))
         fence()
+    for _ in range(2 * n_lanes):         # set-up: every lane's slabs / work buffers exist
+        step()
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -644,40 +648,70 @@ def cpu_baseline(conf, cube, luts, az, el, budget_s, n_samples=5):
             'host_cpus': os.cpu_count()}
 
 
-def cpu_baseline_pool(conf, cube, luts, az, el, radials_per_s_1core, target_s=6.0):
-    """the same per-radial oracle under a fork pool of P = os.cpu_count()
-    processes mapped over azimuths, as radar_operator.py:402,431.  `value`: steady state of
-    persistent workers (pool already up; the favourable figure for the CPU); `with_pool_startup`
-    includes creating the pool, as every get_PPI call of the reference does; `reference_style`:
-    one task per worker process, `Pool(P, maxtasksperchild=1).map` exactly as the reference."""
+def _pool_leg(ctx, procs, az, budget_s, chunk, **pool_kw):
+    """Radials per second of a fork pool of `procs` workers, time-boxed: tasks are streamed with
+    imap_unordered and the pool is terminated when the budget is used (so that a host on which
+    256 NumPy workers thrash the memory system still finishes)."""
+    def tasks():
+        i = 0
+        while True:
+            yield az[i % len(az)]
+            i += 1
+    t0 = time.perf_counter()
+    pool = ctx.Pool(processes=procs, **pool_kw)
+    try:
+        it = pool.imap_unordered(_pool_radial, tasks(), chunksize=chunk)
+        gates = n = 0
+        t1 = None
+        for g in it:
+            now = time.perf_counter()
+            if t1 is None:
+                t1, gates, n = now, 0, 0         # steady state starts at the first result
+                continue
+            gates += g
+            n += 1
+            if now - t1 > budget_s:
+                break
+        t2 = time.perf_counter()
+    finally:
+        pool.terminate()
+        pool.join()
+    return {'gates_per_s': gates / max(t2 - t1, 1e-9), 'radials': n, 'seconds': t2 - t1,
+            'startup_s': t1 - t0, 'gates_per_s_with_startup': gates / max(t2 - t0, 1e-9)}
+
+
+def cpu_baseline_pool(conf, cube, luts, az, el, radials_per_s_1core, budget_s=6.0):
+    """the same per-radial oracle under a fork pool mapped over azimuths, as
+    radar_operator.py:402,431, with P = os.cpu_count() processes (`value`, `cores`).  Every leg
+    is time-boxed (`budget_s` of steady state).  Also reported: the same with fewer workers
+    (NumPy's [n_valid, 1024, 12] float64 temporaries make the per-radial algorithm memory-bound
+    long before 256 cores are busy) and `reference_style` = one task per worker process,
+    Pool(P, maxtasksperchild=1), exactly as the reference creates its pool."""
     import multiprocessing as mp
-    procs = max(1, os.cpu_count() or 1)
+    n_cpu = max(1, os.cpu_count() or 1)
     _POOL_STATE['inputs'] = _oracle_inputs(conf, cube, luts)     # inherited by fork, not pickled
     _POOL_STATE['el'] = el
     ctx = mp.get_context('fork')
-    n_rad = int(min(max(2 * procs, target_s * procs * radials_per_s_1core), 400000))
-    tasks = [az[i % len(az)] for i in range(n_rad)]
-    chunk = max(1, min(16, n_rad // (procs * 8)))
-    t0 = time.perf_counter()
-    with ctx.Pool(processes=procs) as pool:
-        pool.map(_pool_radial, [az[i % len(az)] for i in range(procs)], chunksize=1)   # warm-up
-        t1 = time.perf_counter()
-        n_gates = sum(pool.map(_pool_radial, tasks, chunksize=chunk))
-        t2 = time.perf_counter()
-    res = {'value': n_gates / (t2 - t1), 'unit': 'gates/s', 'cores': procs,
-           'sample': '%d radials (%.1f sweeps of 360), fork pool of %d persistent worker processes '
-                     '(P = os.cpu_count()), chunksize %d, %.1f s' % (n_rad, n_rad / 360.0, procs, chunk, t2 - t1),
-           'with_pool_startup': {'value': n_gates / (t2 - t0), 'seconds': t2 - t0}}
-    n_ref = min(len(az), max(procs, 64))
-    t0 = time.perf_counter()
-    with ctx.Pool(processes=procs, maxtasksperchild=1) as pool:
-        g = sum(pool.map(_pool_radial, list(az[:n_ref]), chunksize=1))
-    dt = time.perf_counter() - t0
-    res['reference_style'] = {'value': g / dt,
-                              'sample': '%d radials, Pool(%d, maxtasksperchild=1).map as '
-                                        'radar_operator.py:402,431 (a fork per radial), %.1f s' % (n_ref, procs, dt)}
+    legs = {}
+    for procs in sorted({n_cpu, min(n_cpu, 64), min(n_cpu, 16)}, reverse=True):
+        print('[bench] CPU pool leg: %d worker processes ...' % procs, file=sys.stderr, flush=True)
+        legs[procs] = _pool_leg(ctx, procs, az, budget_s, chunk=4)
+    print('[bench] CPU pool leg: reference style (a fork per radial) ...', file=sys.stderr, flush=True)
+    ref = _pool_leg(ctx, n_cpu, az, min(budget_s, 4.0), chunk=1, maxtasksperchild=1)
     _POOL_STATE.clear()
-    return res
+    full = legs[n_cpu]
+    best_p = max(legs, key=lambda k: legs[k]['gates_per_s'])
+    return {'value': full['gates_per_s'], 'unit': 'gates/s', 'cores': n_cpu,
+            'sample': '%d radials in %.1f s of steady state, fork pool of %d persistent worker processes '
+                      '(P = os.cpu_count()), pool start-up %.1f s excluded'
+                      % (full['radials'], full['seconds'], n_cpu, full['startup_s']),
+            'with_pool_startup': full['gates_per_s_with_startup'],
+            'by_workers': {str(k): v['gates_per_s'] for k, v in sorted(legs.items())},
+            'best': {'workers': best_p, 'value': legs[best_p]['gates_per_s']},
+            'reference_style': {'value': ref['gates_per_s'],
+                                'sample': '%d radials in %.1f s, Pool(%d, maxtasksperchild=1) as '
+                                          'radar_operator.py:402,431 (a fork per radial)'
+                                          % (ref['radials'], ref['seconds'], n_cpu)}}
 
 
 if __name__ == '__main__':

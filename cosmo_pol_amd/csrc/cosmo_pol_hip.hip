@@ -64,9 +64,16 @@ struct cpol_ctx {
     DevBuf d_tfun[CPOL_N_TFUN];        // host-tabulated float32 functions of T (cpol_stage_t_function)
     const float *tfun[CPOL_N_TFUN] = {};
     // per-sweep work buffers (grow only)
-    DevBuf b_traj_in, b_geo, b_subh, b_subv, b_subw, b_sens, b_traj, b_site, b_nyq;
-    DevBuf b_subsmooth, b_mlfilter, b_wgate, b_clk;
-    DevBuf b_varray, b_beam, b_spectrum;
+    // per-sweep host tables: packed into ONE pinned staging buffer (ring of 4, an event each) and
+    // moved by ONE host-to-device copy into b_tables; v_* = views into that arena
+    DevBuf b_tables;
+    void *v_traj_in = nullptr, *v_geo = nullptr, *v_subh = nullptr, *v_subv = nullptr, *v_subw = nullptr,
+         *v_sens = nullptr, *v_site = nullptr, *v_nyq = nullptr, *v_subsmooth = nullptr,
+         *v_mlfilter = nullptr, *v_varray = nullptr;
+    struct Staging { void *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } stg[4];
+    int stg_next = 0;
+    DevBuf b_traj, b_wgate, b_clk;
+    DevBuf b_beam, b_spectrum, b_outwin;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
         b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
@@ -189,8 +196,12 @@ void cpol_destroy(cpol_ctx *ctx)
         ctx->parent->n_children -= 1;
     }
     for (auto &b : ctx->d_tfun) free_buf(b);
-    DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj_in, &ctx->b_geo, &ctx->b_subh, &ctx->b_subv,
-                     &ctx->b_subw, &ctx->b_sens, &ctx->b_traj, &ctx->b_site, &ctx->b_nyq, &ctx->b_subsmooth, &ctx->b_mlfilter, &ctx->b_wgate, &ctx->b_clk, &ctx->b_varray, &ctx->b_beam, &ctx->b_spectrum, &ctx->b_vals, &ctx->b_mask,
+    for (auto &sg : ctx->stg) {
+        if (sg.ev) (void)hipEventDestroy(sg.ev);
+        if (sg.p) (void)hipHostFree(sg.p);
+    }
+    DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_tables, &ctx->b_traj, &ctx->b_wgate, &ctx->b_clk,
+                     &ctx->b_beam, &ctx->b_spectrum, &ctx->b_outwin, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_units,
                      &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_pos,
@@ -672,20 +683,48 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ctx->err = "cpol_run_sweep: sub_smooth needs ml_filter / ml_radius";
         return CPOL_ERR_ARG;
     }
-    const long shape[6] = {n_rays, ng, n_sub, n_h, n_v, (ml ? 64 + t->ml_radius * 128L : 0) + (long)mode * 8 + (t->nyquist ? 4 : 0) + (t->site ? 2 : 0) + (cut ? 1 : 0)};
+    const long shape[6] = {n_rays, ng, n_sub, n_h, n_v, (ml ? 64 + t->ml_radius * 128L : 0) + (long)mode * 8 + (t->nyquist ? 4 : 0) + (t->site ? 2 : 0) + (cut ? 1 : 0)
+                           + (t->varray ? 16 + p->n_vbins * 65536L : 0)};
     const bool reuse = t->version != 0 && t->version == ctx->tables_version &&
                        memcmp(shape, ctx->tables_shape, sizeof shape) == 0;
     if (!reuse) {
-        if ((rc = upload(ctx, ctx->b_traj_in, t->traj, (size_t)n_rays * n_v * 4 * sizeof(double)))) return rc;
-        if (t->site && (rc = upload(ctx, ctx->b_site, t->site, (size_t)n_rays * 8 * sizeof(double)))) return rc;
-        if ((rc = upload(ctx, ctx->b_geo, t->geo, (size_t)n_rays * n_h * 8 * sizeof(double)))) return rc;
-        if ((rc = upload(ctx, ctx->b_subh, t->sub_h, (size_t)n_sub * sizeof(int)))) return rc;
-        if ((rc = upload(ctx, ctx->b_subv, t->sub_v, (size_t)n_sub * sizeof(int)))) return rc;
-        if ((rc = upload(ctx, ctx->b_subw, t->sub_w, (size_t)n_sub * sizeof(double)))) return rc;
-        if (cut && (rc = upload(ctx, ctx->b_sens, t->sens_thr, (size_t)ng * sizeof(double)))) return rc;
-        if (t->nyquist && (rc = upload(ctx, ctx->b_nyq, t->nyquist, (size_t)n_rays * sizeof(double)))) return rc;
-        if (ml && (rc = upload(ctx, ctx->b_subsmooth, t->sub_smooth, (size_t)n_sub * sizeof(int)))) return rc;
-        if (ml && (rc = upload(ctx, ctx->b_mlfilter, t->ml_filter, (size_t)(2 * t->ml_radius + 1) * sizeof(double)))) return rc;
+        // pack every table of this sweep into one pinned staging slot, one H2D copy
+        struct Item { const void *src; size_t bytes; void **view; };
+        const Item items[] = {
+            {t->traj, (size_t)n_rays * n_v * CPOL_TRAJ_STRIDE * sizeof(double), &ctx->v_traj_in},
+            {t->site, t->site ? (size_t)n_rays * CPOL_SITE_STRIDE * sizeof(double) : 0, &ctx->v_site},
+            {t->geo, (size_t)n_rays * n_h * CPOL_GEO_STRIDE * sizeof(double), &ctx->v_geo},
+            {t->sub_h, (size_t)n_sub * sizeof(int), &ctx->v_subh},
+            {t->sub_v, (size_t)n_sub * sizeof(int), &ctx->v_subv},
+            {t->sub_w, (size_t)n_sub * sizeof(double), &ctx->v_subw},
+            {cut ? t->sens_thr : nullptr, cut ? (size_t)ng * sizeof(double) : 0, &ctx->v_sens},
+            {t->nyquist, t->nyquist ? (size_t)n_rays * sizeof(double) : 0, &ctx->v_nyq},
+            {ml ? t->sub_smooth : nullptr, ml ? (size_t)n_sub * sizeof(int) : 0, &ctx->v_subsmooth},
+            {ml ? t->ml_filter : nullptr, ml ? (size_t)(2 * t->ml_radius + 1) * sizeof(double) : 0, &ctx->v_mlfilter},
+            {t->varray, t->varray ? (size_t)p->n_vbins * sizeof(double) : 0, &ctx->v_varray},
+        };
+        size_t total = 0;
+        for (const Item &it : items) total += (it.bytes + 63) & ~(size_t)63;
+        ENSURE(ctx->b_tables, total);
+        cpol_ctx::Staging &sg = ctx->stg[ctx->stg_next];
+        ctx->stg_next = (ctx->stg_next + 1) % 4;
+        if (sg.used) HIPCHK(hipEventSynchronize(sg.ev));        // its last copy has left the buffer
+        if (sg.cap < total) {
+            if (sg.p) (void)hipHostFree(sg.p);
+            sg.p = nullptr; sg.cap = 0;
+            HIPCHK(hipHostMalloc(&sg.p, total + total / 4 + 4096, hipHostMallocDefault));
+            sg.cap = total + total / 4 + 4096;
+        }
+        if (!sg.ev) HIPCHK(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
+        size_t off = 0;
+        for (const Item &it : items) {
+            *it.view = it.bytes ? (void *)((char *)ctx->b_tables.p + off) : nullptr;
+            if (it.bytes) memcpy((char *)sg.p + off, it.src, it.bytes);
+            off += (it.bytes + 63) & ~(size_t)63;
+        }
+        HIPCHK(hipMemcpyAsync(ctx->b_tables.p, sg.p, total, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipEventRecord(sg.ev, ctx->stream));
+        sg.used = true;
         ctx->tables_version = t->version;
         memcpy(ctx->tables_shape, shape, sizeof shape);
     }
@@ -737,36 +776,59 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (doppler) {
         ENSURE(ctx->b_vn, (size_t)n_hyd * n_sbg * 2 * sizeof(double));
         ENSURE(ctx->b_icefirst, (size_t)n_rays * n_sub * sizeof(IceFirst));
-        ENSURE(ctx->b_rvel, (size_t)n_rg * sizeof(double));
     }
     if (dop3) {
         ENSURE(ctx->b_beam, (size_t)n_sbg * n_vb * sizeof(float));
-        ENSURE(ctx->b_spectrum, (size_t)n_rg * n_vb * sizeof(double));
-        if ((rc = upload(ctx, ctx->b_varray, t->varray, (size_t)n_vb * sizeof(double)))) return rc;
     }
-    // output staging (device): 9 float fields + PHIDP
+    // ---- outputs: where the kernels write each array, and how it reaches the caller ----
     enum { O_ZH, O_ZV, O_ZDR, O_KDP, O_DHV, O_PHIDP, O_RHOHV, O_ATTH, O_ATTV, O_MASK, O_LAT, O_LON,
-           O_DIST, O_HGT };
-    for (int k = 0; k <= O_ATTV; ++k) ENSURE(ctx->b_out[k], (size_t)n_rg * sizeof(float));
-    ENSURE(ctx->b_out[O_MASK], (size_t)n_rg * sizeof(double));
-    ENSURE(ctx->b_out[O_LAT], (size_t)n_rg * sizeof(double));
-    ENSURE(ctx->b_out[O_LON], (size_t)n_rg * sizeof(double));
-    ENSURE(ctx->b_out[O_DIST], (size_t)n_rg * sizeof(float));
-    ENSURE(ctx->b_out[O_HGT], (size_t)n_rg * sizeof(float));
-    // kernels write straight into caller-owned device buffers when given
+           O_DIST, O_HGT, O_RVEL, O_MODEL, O_SZT, O_SPEC, O_N };
     const bool dev = p->outputs_on_device == 1;
     const bool async_host = p->outputs_on_device == 2;    // pinned host buffers, no wait
-    void *const user_out[14] = {out->ZH, out->ZV, out->ZDR, out->KDP, out->DELTA_HV, out->PHIDP,
-                                out->RHOHV, out->ATT_H, out->ATT_V, out->mask, out->lats, out->lons,
-                                out->dist, out->heights};
-    void *T[14];
-    for (int k = 0; k < 14; ++k) T[k] = (dev && user_out[k]) ? user_out[k] : ctx->b_out[k].p;
     const bool want_szi = ctx->keep_debug;
     if (want_szi) ENSURE(ctx->b_szinteg, (size_t)n_rg * n_hyd * CPOL_N_SZ * sizeof(float));
     const bool want_szt = out->sz_total != nullptr || ctx->keep_debug;
-    if (want_szt) ENSURE(ctx->b_sztotal, (size_t)n_rg * CPOL_N_SZ * sizeof(float));
     const bool want_model = p->integrate_model && out->model_vars;
-    if (want_model) ENSURE(ctx->b_model, (size_t)n_vars * n_rg * sizeof(double));
+    void *const user_out[O_N] = {out->ZH, out->ZV, out->ZDR, out->KDP, out->DELTA_HV, out->PHIDP,
+                                 out->RHOHV, out->ATT_H, out->ATT_V, out->mask, out->lats, out->lons,
+                                 out->dist, out->heights, out->RVEL, out->model_vars, out->sz_total,
+                                 out->DSPECTRUM};
+    size_t obytes[O_N];
+    bool produced[O_N];
+    DevBuf *own[O_N];
+    for (int k = 0; k < 14; ++k) {
+        obytes[k] = (size_t)n_rg * ((k == O_MASK || k == O_LAT || k == O_LON) ? sizeof(double) : sizeof(float));
+        produced[k] = true;
+        own[k] = &ctx->b_out[k];
+    }
+    obytes[O_RVEL] = (size_t)n_rg * sizeof(double);            produced[O_RVEL] = doppler;    own[O_RVEL] = &ctx->b_rvel;
+    obytes[O_MODEL] = (size_t)n_vars * n_rg * sizeof(double);  produced[O_MODEL] = want_model; own[O_MODEL] = &ctx->b_model;
+    obytes[O_SZT] = (size_t)n_rg * CPOL_N_SZ * sizeof(float);  produced[O_SZT] = want_szt;    own[O_SZT] = &ctx->b_sztotal;
+    obytes[O_SPEC] = (size_t)n_rg * n_vb * sizeof(double);     produced[O_SPEC] = dop3;       own[O_SPEC] = &ctx->b_spectrum;
+    void *T[O_N];
+    // pinned-host mode: when the requested arrays lie in one window of the caller's slab (only
+    // alignment padding between them) the kernels write into a device image of that window and
+    // ONE device-to-host copy moves it (instead of up to 18 copies of a few hundred KB each)
+    char *win_lo = nullptr, *win_hi = nullptr;
+    size_t win_sum = 0;
+    if (async_host && !ctx->keep_debug)
+        for (int k = 0; k < O_N; ++k) {
+            if (!produced[k] || !user_out[k]) continue;
+            char *a = (char *)user_out[k];
+            if (!win_lo || a < win_lo) win_lo = a;
+            if (!win_hi || a + obytes[k] > win_hi) win_hi = a + obytes[k];
+            win_sum += obytes[k];
+        }
+    const bool window = win_lo && (size_t)(win_hi - win_lo) <= win_sum + win_sum / 4 + 4096;
+    if (window) ENSURE(ctx->b_outwin, (size_t)(win_hi - win_lo));
+    for (int k = 0; k < O_N; ++k) {
+        T[k] = nullptr;
+        if (!produced[k]) continue;
+        if (dev && user_out[k] && !(ctx->keep_debug && k == O_SZT)) { T[k] = user_out[k]; continue; }   // in place
+        if (window && user_out[k]) { T[k] = (char *)ctx->b_outwin.p + ((char *)user_out[k] - win_lo); continue; }
+        ENSURE(*own[k], obytes[k]);
+        T[k] = own[k]->p;
+    }
 
     // the bucket counters start at zero: cleared by k_interp_sweep (no fill kernel); the domain
     // error word is sticky (cleared when reported)
@@ -796,8 +858,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // parity access to the ray paths (cpol_debug_read "traj"): same device function
         if ((long)n_rays * n_v > 65535) { ctx->err = "cpol_run_sweep: debug ray paths need n_rays * n_vnodes <= 65535"; return CPOL_ERR_ARG; }
         TrajArgs ta{};
-        ta.ray_traj = (const double *)ctx->b_traj_in.p;
-        ta.site = t->site ? (const double *)ctx->b_site.p : nullptr;
+        ta.ray_traj = (const double *)ctx->v_traj_in;
+        ta.site = t->site ? (const double *)ctx->v_site : nullptr;
         ta.traj_out = (float *)ctx->b_traj.p;
         ta.n_rays = n_rays; ta.n_v = n_v; ta.n_gates = ng; ta.mode = mode;
         ta.range0 = p->range0; ta.range_step = p->range_step;
@@ -809,16 +871,16 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // ---- 2. gate interpolation ----
     InterpArgs ia{};
     ia.traj = (mode == CPOL_GEOM_HOST_PATHS) ? (const float *)ctx->b_traj.p : nullptr;
-    ia.rp.ray_traj = (const double *)ctx->b_traj_in.p;
-    ia.rp.site = t->site ? (const double *)ctx->b_site.p : nullptr;
+    ia.rp.ray_traj = (const double *)ctx->v_traj_in;
+    ia.rp.site = t->site ? (const double *)ctx->v_site : nullptr;
     ia.rp.n_v = n_v; ia.rp.mode = mode;
     ia.rp.range0 = p->range0; ia.rp.range_step = p->range_step;
     ia.rp.ke = p->ke; ia.rp.re = p->re; ia.rp.alt = p->radar_alt;
     ia.zero_buf = (int *)ctx->b_count.p;
     ia.zero_n = n_keys;
-    ia.geo = (const double *)ctx->b_geo.p;
-    ia.sub_h = (const int *)ctx->b_subh.p;
-    ia.sub_v = (const int *)ctx->b_subv.p;
+    ia.geo = (const double *)ctx->v_geo;
+    ia.sub_h = (const int *)ctx->v_subh;
+    ia.sub_v = (const int *)ctx->v_subv;
     ia.vals = (float *)ctx->b_vals.p;
     ia.mask = (signed char *)ctx->b_mask.p;
     ia.elev = (float *)ctx->b_elev.p;
@@ -831,7 +893,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.n_rays = n_rays; ia.n_gates = ng; ia.n_sub = n_sub; ia.n_h = n_h; ia.n_v = n_v;
     ia.central_sub = n_sub / 2;
     ia.sin_u1 = p->sin_u1; ia.cos_u1 = p->cos_u1; ia.lon1 = p->radar_lon;
-    ia.site = t->site ? (const double *)ctx->b_site.p : nullptr;
+    ia.site = t->site ? (const double *)ctx->v_site : nullptr;
     hipLaunchKernelGGL(k_interp_sweep, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256), 0, st,
                        ctx->model, ia);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
@@ -867,9 +929,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (ml) {
         MlArgs ma{};
         ma.vals = (const float *)ctx->b_vals.p;
-        ma.sub_w = (const double *)ctx->b_subw.p;
-        ma.sub_smooth = (const int *)ctx->b_subsmooth.p;
-        ma.taps = (const double *)ctx->b_mlfilter.p;
+        ma.sub_w = (const double *)ctx->v_subw;
+        ma.sub_smooth = (const int *)ctx->v_subsmooth;
+        ma.taps = (const double *)ctx->v_mlfilter;
         ma.wgate = (double *)ctx->b_wgate.p;
         ma.n_sbg = n_sbg; ma.n_sub = n_sub; ma.n_gates = ng; ma.radius = t->ml_radius;
         ma.with_melting = p->with_melting;
@@ -959,15 +1021,15 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     fa.key = (const int *)ctx->b_key.p;
     fa.sub_mask = (const signed char *)ctx->b_mask.p;
     fa.vals = (const float *)ctx->b_vals.p;
-    fa.sub_w = (const double *)ctx->b_subw.p;
+    fa.sub_w = (const double *)ctx->v_subw;
     fa.sz_integ = want_szi ? (float *)ctx->b_szinteg.p : nullptr;
-    fa.sz_total = want_szt ? (float *)ctx->b_sztotal.p : nullptr;
+    fa.sz_total = want_szt ? (float *)T[O_SZT] : nullptr;
     fa.ZH = (float *)T[O_ZH]; fa.ZV = (float *)T[O_ZV];
     fa.ZDR = (float *)T[O_ZDR]; fa.KDP = (float *)T[O_KDP];
     fa.DELTA_HV = (float *)T[O_DHV]; fa.RHOHV = (float *)T[O_RHOHV];
     fa.ATT_H = (float *)T[O_ATTH]; fa.ATT_V = (float *)T[O_ATTV];
     fa.mask = (double *)T[O_MASK];
-    fa.model_vars = want_model ? (double *)ctx->b_model.p : nullptr;
+    fa.model_vars = want_model ? (double *)T[O_MODEL] : nullptr;
     fa.n_rays = n_rays; fa.n_gates = ng; fa.n_sub = n_sub; fa.n_hydro = n_hyd; fa.n_vars = n_vars;
     fa.c_zh = (float)p->c_zh;
     fa.c_kdp = (float)(1e-3 * (180.0 / 3.14159265358979323846) * p->wavelength);
@@ -980,16 +1042,16 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     fa.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
     fa.RVEL = nullptr;
     if (doppler) {
-        fa.RVEL = (double *)ctx->b_rvel.p;
+        fa.RVEL = (double *)T[O_RVEL];
         fa.par = (const double *)ctx->b_par.p;
         fa.vn = (const double *)ctx->b_vn.p;
         fa.ice_first = (const IceFirst *)ctx->b_icefirst.p;
-        fa.geo = (const double *)ctx->b_geo.p;
-        fa.sub_h = (const int *)ctx->b_subh.p;
+        fa.geo = (const double *)ctx->v_geo;
+        fa.sub_h = (const int *)ctx->v_subh;
         fa.elev = (const float *)ctx->b_elev.p;
         fa.n_h = n_h;
         fa.var_u = p->var_u; fa.var_v = p->var_v; fa.var_w = p->var_w;
-        fa.nyquist = t->nyquist ? (const double *)ctx->b_nyq.p : nullptr;
+        fa.nyquist = t->nyquist ? (const double *)ctx->v_nyq : nullptr;
         if (fa.var_u < 0 || fa.var_v < 0 || fa.var_w < 0 || fa.var_u >= n_vars ||
             fa.var_v >= n_vars || fa.var_w >= n_vars) {
             ctx->err = "cpol_run_sweep: simulate_doppler needs var_u / var_v / var_w";
@@ -1009,7 +1071,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ScanRayArgs ra{};
     ra.PHIDP = (float *)T[O_PHIDP];
     ra.RVEL = nullptr;
-    ra.sens_thr = cut ? (const double *)ctx->b_sens.p : nullptr;
+    ra.sens_thr = cut ? (const double *)ctx->v_sens : nullptr;
     ra.radial_res = (float)p->radial_res;
     if (dop3) {
         // ---- 6b. Doppler spectrum (scheme 3): RVEL comes from the spectrum ----
@@ -1021,9 +1083,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sp.key = (const int *)ctx->b_key.p;
         sp.par = (const double *)ctx->b_par.p;
         sp.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
-        sp.geo = (const double *)ctx->b_geo.p;
-        sp.sub_h = (const int *)ctx->b_subh.p;
-        sp.varray = (const double *)ctx->b_varray.p;
+        sp.geo = (const double *)ctx->v_geo;
+        sp.sub_h = (const int *)ctx->v_subh;
+        sp.varray = (const double *)ctx->v_varray;
         sp.beam = (float *)ctx->b_beam.p;
         sp.n_sbg = n_sbg; sp.n_gates = ng; sp.n_sub = n_sub; sp.n_h = n_h; sp.n_v = n_vb;
         sp.var_u = p->var_u; sp.var_v = p->var_v; sp.var_w = p->var_w; sp.var_rho = p->var_rho;
@@ -1042,17 +1104,17 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         }
         SpecFinalArgs sf{};
         sf.beam = (const float *)ctx->b_beam.p;
-        sf.sub_w = (const double *)ctx->b_subw.p;
+        sf.sub_w = (const double *)ctx->v_subw;
         sf.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
-        sf.varray = (const double *)ctx->b_varray.p;
-        sf.nyquist = t->nyquist ? (const double *)ctx->b_nyq.p : nullptr;
-        sf.spectrum = (double *)ctx->b_spectrum.p;
-        sf.RVEL = (double *)ctx->b_rvel.p;
+        sf.varray = (const double *)ctx->v_varray;
+        sf.nyquist = t->nyquist ? (const double *)ctx->v_nyq : nullptr;
+        sf.spectrum = (double *)T[O_SPEC];
+        sf.RVEL = (double *)T[O_RVEL];
         sf.n_rays = n_rays; sf.n_gates = ng; sf.n_sub = n_sub; sf.n_v = n_vb;
         // cut_at_sensitivity censors the spectrum bin by bin (doppler_scatter.py:839-850)
-        sf.sens_thr = cut ? (const double *)ctx->b_sens.p : nullptr;
+        sf.sens_thr = cut ? (const double *)ctx->v_sens : nullptr;
         hipLaunchKernelGGL(k_spec_final, dim3((unsigned)n_rg), dim3(64), 0, st, sf);
-        ra.RVEL = (double *)ctx->b_rvel.p;   // censored with the other observables in k_final
+        ra.RVEL = (double *)T[O_RVEL];       // censored with the other observables in k_final
     }
     if ((size_t)3 * ng * sizeof(float) > 64 * 1024) { ctx->err = "cpol_run_sweep: n_gates too large for the range scans (3 * n_gates floats of LDS)"; return CPOL_ERR_ARG; }
     hipLaunchKernelGGL(k_final, dim3(n_rays), dim3(CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra);
@@ -1078,9 +1140,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         void *arena[] = {ctx->b_traj.p, ctx->b_vals.p, ctx->b_mask.p, ctx->b_elev.p, ctx->b_qmelt.p,
                          ctx->b_fwmelt.p, ctx->b_key.p, ctx->b_pos.p, ctx->b_par.p, ctx->b_count.p,
                          ctx->b_offset.p, ctx->b_units.p, ctx->b_totals.p, ctx->b_perm.p,
-                         ctx->b_res.p, ctx->b_vn.p, ctx->b_icefirst.p, ctx->b_rvel.p, ctx->b_wgate.p, ctx->b_traj_in.p, ctx->b_geo.p, ctx->b_subh.p,
-                         ctx->b_subv.p, ctx->b_subw.p, ctx->b_sens.p, ctx->b_site.p, ctx->b_nyq.p,
-                         ctx->b_subsmooth.p, ctx->b_mlfilter.p, (void *)st};
+                         ctx->b_res.p, ctx->b_vn.p, ctx->b_icefirst.p, ctx->b_wgate.p, ctx->v_traj_in, ctx->v_geo, ctx->v_subh,
+                         ctx->v_subv, ctx->v_subw, ctx->v_sens, ctx->v_site, ctx->v_nyq,
+                         ctx->v_subsmooth, ctx->v_mlfilter, (void *)st};
         mix(arena, sizeof arena);
         if (!ctx->graph_exec || ctx->graph_key != key) {
             if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
@@ -1104,17 +1166,15 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         if ((rc = launch_all()) != CPOL_OK) return rc;
     }
 
-    // ---- outputs (host buffers only; device buffers were written in place) ----
-    const size_t fb = (size_t)n_rg * sizeof(float), dbb = (size_t)n_rg * sizeof(double);
-    for (int k = 0; k < 14; ++k) {
-        if (!user_out[k] || T[k] == user_out[k]) continue;
-        const size_t bytes = (k == O_MASK || k == O_LAT || k == O_LON) ? dbb : fb;
-        if ((rc = copy_out(ctx, user_out[k], T[k], bytes, dev))) return rc;
+    // ---- outputs that the kernels did not write in place ----
+    if (window) {
+        HIPCHK(hipMemcpyAsync(win_lo, ctx->b_outwin.p, (size_t)(win_hi - win_lo), hipMemcpyDeviceToHost, st));
+    } else {
+        for (int k = 0; k < O_N; ++k) {
+            if (!produced[k] || !user_out[k] || T[k] == user_out[k]) continue;
+            if ((rc = copy_out(ctx, user_out[k], T[k], obytes[k], dev))) return rc;
+        }
     }
-    if (doppler && (rc = copy_out(ctx, out->RVEL, ctx->b_rvel.p, dbb, dev))) return rc;
-    if (want_model && (rc = copy_out(ctx, out->model_vars, ctx->b_model.p, dbb * n_vars, dev))) return rc;
-    if (out->sz_total && (rc = copy_out(ctx, out->sz_total, ctx->b_sztotal.p, fb * CPOL_N_SZ, dev))) return rc;
-    if (dop3 && (rc = copy_out(ctx, out->DSPECTRUM, ctx->b_spectrum.p, dbb * n_vb, dev))) return rc;
 
     ctx->last_n_sbg = n_sbg; ctx->last_n_rg = n_rg; ctx->last_n_rays = n_rays;
     ctx->last_n_gates = ng; ctx->last_n_sub = n_sub; ctx->last_n_v = n_v;

@@ -130,7 +130,10 @@ typedef struct {
                                    buffers (cpol_host_alloc), device-to-host copies are queued
                                    on the context's stream and the call returns at once --
                                    results (and a deferred CPOL_ERR_DOMAIN) after
-                                   cpol_synchronize                                        */
+                                   cpol_synchronize.  Carve the arrays from ONE allocation:
+                                   when they span a window of at most 1.25 x their total
+                                   size they are moved by a single copy (which also
+                                   overwrites the padding bytes between them)               */
     int32_t simulate_doppler;   /* 0 off, 1 / 2 / 3 = Doppler scheme of the reference (RVEL;
                                    3 = full Doppler spectrum, doppler_scatter.py:335-391) */
     int32_t geometry_mode;      /* CPOL_GEOM_*                                   */
