@@ -70,6 +70,11 @@ struct cpol_ctx {
     void *v_traj_in = nullptr, *v_geo = nullptr, *v_subh = nullptr, *v_subv = nullptr, *v_subw = nullptr,
          *v_sens = nullptr, *v_site = nullptr, *v_nyq = nullptr, *v_subsmooth = nullptr,
          *v_mlfilter = nullptr, *v_varray = nullptr;
+    // sibling streams of the PSD stage: the kernel flavours of a sweep (recurrence / full-exp /
+    // ice / melting) touch disjoint items, so they run side by side (fork after the bucket
+    // sort, join before the final stage) instead of back to back
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     struct Staging { void *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } stg[4];
     int stg_next = 0;
     DevBuf b_traj, b_wgate, b_clk;
@@ -196,6 +201,11 @@ void cpol_destroy(cpol_ctx *ctx)
         ctx->parent->n_children -= 1;
     }
     for (auto &b : ctx->d_tfun) free_buf(b);
+    for (int i = 0; i < 3; ++i) {
+        if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+        if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (auto &sg : ctx->stg) {
         if (sg.ev) (void)hipEventDestroy(sg.ev);
         if (sg.p) (void)hipHostFree(sg.p);
@@ -980,12 +990,15 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             pa.clk = (long long *)ctx->b_clk.p;
         }
         bool need[4] = {false, false, false, false};
+        // CPOL_PSD_ONLY: experiment knob (tools/psd_flavours.py): bit mask of the flavours to launch
+        // (1 gamma-exp, 2 recurrence, 4 ice, 8 melting); results are then incomplete
+        static const int only = getenv("CPOL_PSD_ONLY") ? atoi(getenv("CPOL_PSD_ONLY")) : 15;
         for (int j = 0; j < n_hyd; ++j) {
             const cpol_hydro_desc &d = ctx->hs.h[j].d;
             int mode = d.psd_family == CPOL_PSD_ICE_FIELD ? PSD_MODE_ICE
                      : d.psd_family == CPOL_PSD_MELTING ? PSD_MODE_MELTING
                      : d.uniform_grid ? PSD_MODE_GAMMA_UNIFORM : PSD_MODE_GAMMA_EXP;
-            need[mode] = true;
+            if (only & (1 << mode)) need[mode] = true;
         }
         // persistent grids: 1024 workgroups walk the unit list with a static stride (smaller
         // grids, 512 / 768, measured equal or slower; CPOL_PSD_GRID* are experiment knobs)
@@ -993,25 +1006,53 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         static const long grid_g = getenv("CPOL_PSD_GRID_GENERIC") ? atol(getenv("CPOL_PSD_GRID_GENERIC")) : 1024;
         const dim3 grd_u((unsigned)(unit_cap < grid_u ? unit_cap : grid_u));
         const dim3 grd((unsigned)(unit_cap < grid_g ? unit_cap : grid_g)), blk(CPOL_PSD_THREADS);
-#define CPOL_LAUNCH_PSD(M)                                                                   \
-        if (need[M]) {                                                                       \
-            if (dop2) hipLaunchKernelGGL((k_psd<M, true>), grd, blk, 0, st, ctx->hs, pa);    \
-            else hipLaunchKernelGGL((k_psd<M, false>), grd, blk, 0, st, ctx->hs, pa);        \
+        // longest flavour first; the first one stays on the sweep's stream, the others go to
+        // sibling streams (CPOL_PSD_SIBLINGS=0: all on the sweep's stream, back to back)
+        static const bool siblings = !(getenv("CPOL_PSD_SIBLINGS") && atoi(getenv("CPOL_PSD_SIBLINGS")) == 0);
+        const int order[4] = {PSD_MODE_MELTING, PSD_MODE_ICE, PSD_MODE_GAMMA_UNIFORM, PSD_MODE_GAMMA_EXP};
+        int n_need = 0;
+        for (int m = 0; m < 4; ++m) n_need += need[m] ? 1 : 0;
+        const bool fork = siblings && n_need > 1;
+        if (fork) {
+            if (!ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ctx->ev_fork, st));
         }
-        if (need[PSD_MODE_GAMMA_UNIFORM]) {
-            const dim3 blk_u(CPOL_PSD_THREADS_U);
-            // CPOL_PSD_LDS_PAD: experiment knob (extra dynamic LDS limits the workgroups per CU)
-            static const size_t lds_pad = getenv("CPOL_PSD_LDS_PAD") ? atol(getenv("CPOL_PSD_LDS_PAD")) : 0;
-            if (dop2) hipLaunchKernelGGL((k_psd_uniform<true>), grd_u, blk_u, lds_pad, st, ctx->hs, pa);
-            else hipLaunchKernelGGL((k_psd_uniform<false>), grd_u, blk_u, lds_pad, st, ctx->hs, pa);
+        int n_aux = 0;
+        for (int q = 0, launched = 0; q < 4; ++q) {
+            const int M = order[q];
+            if (!need[M]) continue;
+            hipStream_t s_ = st;
+            if (fork && launched > 0) {
+                const int i = n_aux++;
+                if (!ctx->aux[i]) HIPCHK(hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+                if (!ctx->ev_join[i]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+                s_ = ctx->aux[i];
+                HIPCHK(hipStreamWaitEvent(s_, ctx->ev_fork, 0));
+            }
+            ++launched;
+            switch (M) {
+            case PSD_MODE_GAMMA_UNIFORM: {
+                const dim3 blk_u(CPOL_PSD_THREADS_U);
+                // CPOL_PSD_LDS_PAD: experiment knob (extra dynamic LDS limits the workgroups per CU)
+                static const size_t lds_pad = getenv("CPOL_PSD_LDS_PAD") ? atol(getenv("CPOL_PSD_LDS_PAD")) : 0;
+                if (dop2) hipLaunchKernelGGL((k_psd_uniform<true>), grd_u, blk_u, lds_pad, s_, ctx->hs, pa);
+                else hipLaunchKernelGGL((k_psd_uniform<false>), grd_u, blk_u, lds_pad, s_, ctx->hs, pa);
+                break; }
+            case PSD_MODE_GAMMA_EXP:
+                if (dop2) hipLaunchKernelGGL((k_psd<PSD_MODE_GAMMA_EXP, true>), grd, blk, 0, s_, ctx->hs, pa);
+                else hipLaunchKernelGGL((k_psd<PSD_MODE_GAMMA_EXP, false>), grd, blk, 0, s_, ctx->hs, pa);
+                break;
+            case PSD_MODE_ICE:
+                if (dop2) hipLaunchKernelGGL((k_psd<PSD_MODE_ICE, true>), grd, blk, 0, s_, ctx->hs, pa);
+                else hipLaunchKernelGGL((k_psd<PSD_MODE_ICE, false>), grd, blk, 0, s_, ctx->hs, pa);
+                break;
+            default:
+                if (dop2) hipLaunchKernelGGL((k_psd_melting<true>), grd, blk, 0, s_, ctx->hs, pa);
+                else hipLaunchKernelGGL((k_psd_melting<false>), grd, blk, 0, s_, ctx->hs, pa);
+            }
+            if (s_ != st) HIPCHK(hipEventRecord(ctx->ev_join[n_aux - 1], s_));
         }
-        CPOL_LAUNCH_PSD(PSD_MODE_GAMMA_EXP)
-        CPOL_LAUNCH_PSD(PSD_MODE_ICE)
-        if (need[PSD_MODE_MELTING]) {
-            if (dop2) hipLaunchKernelGGL((k_psd_melting<true>), grd, blk, 0, st, ctx->hs, pa);
-            else hipLaunchKernelGGL((k_psd_melting<false>), grd, blk, 0, st, ctx->hs, pa);
-        }
-#undef CPOL_LAUNCH_PSD
+        for (int i = 0; i < n_aux; ++i) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join[i], 0));
     }
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
 

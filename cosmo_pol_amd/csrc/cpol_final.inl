@@ -316,7 +316,9 @@ struct ScanRayArgs {
     float radial_res;           // float32 cast of the python scalar
 };
 
-#define CPOL_FINAL_THREADS 256
+#ifndef CPOL_FINAL_THREADS
+#define CPOL_FINAL_THREADS 512
+#endif
 __global__ __launch_bounds__(CPOL_FINAL_THREADS) void k_final(FinalArgs a, ScanRayArgs r)
 {
     extern __shared__ float lds[];          // [3][n_gates]

@@ -54,7 +54,9 @@ __device__ __forceinline__ int clip_bin64(double q, int n)
 // + rank inside the wave.  (Order inside a bucket is irrelevant: every item
 // writes its own result slot.)
 #define CPOL_RANK_SLOTS 128
+#ifndef CPOL_RANK_WAVES
 #define CPOL_RANK_WAVES 16
+#endif
 struct RankShared {
     int key[CPOL_RANK_SLOTS];
     int base[CPOL_RANK_SLOTS];
@@ -463,11 +465,14 @@ __device__ __forceinline__ int2 wave_inclusive_scan2(int2 v)
 
 #define CPOL_SCAN_MAX_PER 32
 #define CPOL_SCAN_BIG_LIST 2048
-#define CPOL_SCAN_OWN_UNITS 8
+#ifndef CPOL_SCAN_OWN_UNITS
+#define CPOL_SCAN_OWN_UNITS 512
+#endif
 // Single workgroup: exclusive scans of the bucket counts (items and work units), then the
-// work-unit list itself (formerly a second kernel, k_make_units).  A thread writes the first
-// few units of its own buckets straight from registers; buckets with more units go on an LDS
-// list that the whole workgroup then fills in together.
+// work-unit list itself (formerly a second kernel, k_make_units).  A thread writes the units of
+// its own buckets straight from registers (up to CPOL_SCAN_OWN_UNITS each: a 360 x 500 sweep
+// has at most ~100 units per bucket); giant buckets (49 sub-beams: thousands of units) go on an
+// LDS list that the whole workgroup then fills in together.
 __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
 {
     __shared__ int2 s_wave[16];

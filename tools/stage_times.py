@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Stage times of ONE isolated sweep (one lane, HIP events around every stage), C2 / C3 / C4:
+   python tools/stage_times.py --config c2 [--elev 1.0] [--steps 50]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', default='c2')
+    ap.add_argument('--elev', type=float, default=1.0)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--tag', default='')
+    args = ap.parse_args()
+    import contextlib
+    import numpy as np
+    import torch
+    import bench
+    from cosmo_pol_amd import RadarOperator, synthetic
+    wl = args.config
+    conf = bench.bench_config(False, wl)
+    hyds = list(bench.hydrometeors_of(wl))
+    cube = synthetic.make_cube(hydrometeors=tuple(h for h in hyds if h in 'RSGI'), **synthetic.BENCH_GRID)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    with contextlib.redirect_stdout(sys.stderr):
+        op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
+        op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    az = np.arange(0, 360, 1.0)
+    el = np.full(360, args.elev)
+    n_gates = len(op.constants.RANGE_RADAR)
+    slab = torch.empty((9, 360, n_gates), dtype=torch.float32, device='cuda')
+    ptrs = {k: slab[i].data_ptr() for i, k in enumerate(bench.RADAR_FIELDS)}
+    for _ in range(3):
+        op.simulate_rays(az, el, device_outputs=ptrs)
+    op.wait()
+    op._ctx.enable_timing(True)
+    for _ in range(args.steps):
+        op.simulate_rays(az, el, device_outputs=ptrs)
+    op.wait()
+    c = op._ctx.counters()
+    print(json.dumps(dict(tag=args.tag, config=wl, elev=args.elev, n_valid=int(c.n_valid_items),
+                          interp=round(c.ms_interp * 1e3, 1), classify=round(c.ms_classify * 1e3, 1),
+                          bucket=round(c.ms_bucket * 1e3, 1), psd=round(c.ms_psd * 1e3, 1),
+                          final=round(c.ms_final * 1e3, 1), total_us=round(c.ms_total * 1e3, 1))), flush=True)
+    op.close()
+
+
+if __name__ == '__main__':
+    main()
