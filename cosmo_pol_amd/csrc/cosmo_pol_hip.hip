@@ -753,7 +753,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_pos, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_par, (size_t)n_hyd * CPOL_MAX_PAR * n_sbg * sizeof(double));
     ENSURE(ctx->b_count, (size_t)(n_keys + 1) * sizeof(int));
-    ENSURE(ctx->b_offset, (size_t)n_keys * sizeof(int));
+    ENSURE(ctx->b_offset, (size_t)2 * n_keys * sizeof(int));        // item and unit offsets
     const long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
     ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
     ENSURE(ctx->b_totals, 2 * sizeof(long long));
@@ -957,6 +957,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ScanArgs sa{};
     sa.count = (const int *)ctx->b_count.p;
     sa.offset = (int *)ctx->b_offset.p;
+    sa.uoffset = (int *)ctx->b_offset.p + n_keys;
     sa.units = (WorkUnit *)ctx->b_units.p;
     sa.totals = (long long *)ctx->b_totals.p;
     sa.n_keys = n_keys;
@@ -966,10 +967,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sa.key_base[j] = ctx->hs.h[j].key_base;
         sa.unit_shift[j] = (d.psd_family == CPOL_PSD_GAMMA && d.uniform_grid) ? 7 : 6;
     }
-    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);     // + the unit list
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st,
                        (const int *)ctx->b_key.p, (const int *)ctx->b_pos.p,
-                       (const int *)ctx->b_offset.p, (int *)ctx->b_perm.p, n_sbg, n_hyd);
+                       (int *)ctx->b_perm.p, n_sbg, n_hyd, sa);      // + the work-unit list
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st));
 
     // ---- 5. PSD x scattering table: one launch per kernel flavour present ----
@@ -1006,9 +1007,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         static const long grid_g = getenv("CPOL_PSD_GRID_GENERIC") ? atol(getenv("CPOL_PSD_GRID_GENERIC")) : 1024;
         const dim3 grd_u((unsigned)(unit_cap < grid_u ? unit_cap : grid_u));
         const dim3 grd((unsigned)(unit_cap < grid_g ? unit_cap : grid_g)), blk(CPOL_PSD_THREADS);
-        // longest flavour first; the first one stays on the sweep's stream, the others go to
-        // sibling streams (CPOL_PSD_SIBLINGS=0: all on the sweep's stream, back to back)
-        static const bool siblings = !(getenv("CPOL_PSD_SIBLINGS") && atoi(getenv("CPOL_PSD_SIBLINGS")) == 0);
+        // The flavours touch disjoint items and could run side by side.  Measured (MI355X, one
+        // sweep): on sibling streams (fork after the bucket sort, join before the final stage) the
+        // PSD stage took 762 vs 734 us on C3 and 29.2 vs 27.1 ms on C4 -- every flavour is a
+        // persistent grid that fills the chip and is VALU-bound, so overlap only adds the event
+        // traffic.  Back to back on the sweep's stream is the default; CPOL_PSD_SIBLINGS=1 forks.
+        static const bool siblings = getenv("CPOL_PSD_SIBLINGS") && atoi(getenv("CPOL_PSD_SIBLINGS")) != 0;
         const int order[4] = {PSD_MODE_MELTING, PSD_MODE_ICE, PSD_MODE_GAMMA_UNIFORM, PSD_MODE_GAMMA_EXP};
         int n_need = 0;
         for (int m = 0; m < 4; ++m) n_need += need[m] ? 1 : 0;

@@ -317,7 +317,7 @@ struct ScanRayArgs {
 };
 
 #ifndef CPOL_FINAL_THREADS
-#define CPOL_FINAL_THREADS 512
+#define CPOL_FINAL_THREADS 256
 #endif
 __global__ __launch_bounds__(CPOL_FINAL_THREADS) void k_final(FinalArgs a, ScanRayArgs r)
 {

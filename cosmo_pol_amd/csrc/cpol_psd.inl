@@ -437,6 +437,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
 struct ScanArgs {
     const int *count;
     int *offset;                // [n_keys] first item slot of the bucket
+    int *uoffset;               // [n_keys] first work unit of the bucket
     WorkUnit *units;            // capacity >= n_items/64 + n_keys
     long long *totals;          // [0] = n_valid items, [1] = n_units
     int n_keys;
@@ -464,24 +465,13 @@ __device__ __forceinline__ int2 wave_inclusive_scan2(int2 v)
 }
 
 #define CPOL_SCAN_MAX_PER 32
-#define CPOL_SCAN_BIG_LIST 2048
-#ifndef CPOL_SCAN_OWN_UNITS
-#define CPOL_SCAN_OWN_UNITS 512
-#endif
-// Single workgroup: exclusive scans of the bucket counts (items and work units), then the
-// work-unit list itself (formerly a second kernel, k_make_units).  A thread writes the units of
-// its own buckets straight from registers (up to CPOL_SCAN_OWN_UNITS each: a 360 x 500 sweep
-// has at most ~100 units per bucket); giant buckets (49 sub-beams: thousands of units) go on an
-// LDS list that the whole workgroup then fills in together.
+// Single workgroup: exclusive scans of the bucket counts (items and work units).
 __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
 {
     __shared__ int2 s_wave[16];
-    __shared__ int s_big[CPOL_SCAN_BIG_LIST][4];            // key, count, item base, unit base
-    __shared__ int s_nbig;
     const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
     const int per = (a.n_keys + 1023) / 1024;               // <= CPOL_SCAN_MAX_PER (host checks)
     const int k0 = t * per;
-    if (t == 0) s_nbig = 0;
     // the thread's counts in registers: the (up to 32) loads are independent and issue together
     int cnt[CPOL_SCAN_MAX_PER];
 #pragma unroll
@@ -514,53 +504,44 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
     for (int i = 0; i < CPOL_SCAN_MAX_PER; ++i) {
         const int k = k0 + i;
         if (i < per && k < a.n_keys) {
-            const int sh = unit_shift_of(a, k), pu = 1 << sh;
-            const int c = cnt[i], nu = (c + pu - 1) >> sh;
+            const int sh = unit_shift_of(a, k);
             a.offset[k] = ibase;
-            int own = nu;
-            if (nu > CPOL_SCAN_OWN_UNITS) {
-                const int slot = atomicAdd(&s_nbig, 1);
-                if (slot < CPOL_SCAN_BIG_LIST) {
-                    s_big[slot][0] = k; s_big[slot][1] = c; s_big[slot][2] = ibase; s_big[slot][3] = ubase;
-                    own = CPOL_SCAN_OWN_UNITS;
-                }
-            }
-            for (int u = 0; u < own; ++u) {
-                WorkUnit w;
-                w.key = k; w.start = ibase + u * pu; w.count = min(pu, c - u * pu); w.pad = 0;
-                a.units[ubase + u] = w;
-            }
-            ibase += c;
-            ubase += nu;
+            a.uoffset[k] = ubase;
+            ibase += cnt[i];
+            ubase += (cnt[i] + (1 << sh) - 1) >> sh;
         }
     }
     if (t == 1023) { a.totals[0] = ibase; a.totals[1] = ubase; }
-    __syncthreads();
-    const int nbig = min(s_nbig, CPOL_SCAN_BIG_LIST);
-    for (int b = 0; b < nbig; ++b) {
-        const int k = s_big[b][0], c = s_big[b][1], ib = s_big[b][2], ub = s_big[b][3];
+}
+
+// perm[offset[key] + pos] = sub-beam gate (no atomics: pos comes from k_classify), and -- the
+// former k_make_units, folded in to save a launch -- the work-unit list: the wavefronts of the
+// grid take the buckets round-robin, one wavefront writes the units of one bucket.
+__global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ key,
+                                                         const int *__restrict__ pos,
+                                                         int *__restrict__ perm,
+                                                         long n_sbg, int n_hydro, ScanArgs a)
+{
+    const long sbg = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    for (int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < a.n_keys; k += n_waves) {
+        const int c = a.count[k];
+        if (c == 0) continue;                                   // wave-uniform
+        const int ib = a.offset[k], ub = a.uoffset[k];
         const int sh = unit_shift_of(a, k), pu = 1 << sh;
-        const int nu = (c + pu - 1) >> sh;
-        for (int u = CPOL_SCAN_OWN_UNITS + t; u < nu; u += 1024) {
+        for (int u = lane_id(); u * pu < c; u += CPOL_WAVE) {
             WorkUnit w;
-            w.key = k; w.start = ib + u * pu; w.count = min(pu, c - u * pu); w.pad = 0;
+            w.key = k;
+            w.start = ib + u * pu;
+            w.count = min(pu, c - u * pu);
+            w.pad = 0;
             a.units[ub + u] = w;
         }
     }
-}
-
-// perm[offset[key] + pos] = sub-beam gate   (no atomics: pos comes from k_classify)
-__global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ key,
-                                                         const int *__restrict__ pos,
-                                                         const int *__restrict__ offset,
-                                                         int *__restrict__ perm,
-                                                         long n_sbg, int n_hydro)
-{
-    const long sbg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (sbg >= n_sbg) return;
     for (int j = 0; j < n_hydro; ++j) {
         const int k = key[(long)j * n_sbg + sbg];
-        if (k >= 0) perm[offset[k] + pos[(long)j * n_sbg + sbg]] = (int)sbg;
+        if (k >= 0) perm[a.offset[k] + pos[(long)j * n_sbg + sbg]] = (int)sbg;
     }
 }
 
