@@ -93,6 +93,11 @@ class RadarScan(object):
         self.nrays = len(self.azimuth['data'])
         self.ngates = len(self.range['data'])
 
+    def to_pyart(self, varray=None):
+        """The scan as the reference's PyartRadop (a pyart.core.Radar); needs Py-ART."""
+        from .pyart_wrapper import as_pyart_radar
+        return as_pyart_radar(self, varray)
+
     def to_radials(self):
         """The scan as the reference's list of sweeps of Radial records
         (what cut_at_sensitivity / PyartRadop consume, radar_operator.py:445-451): linear
@@ -110,7 +115,8 @@ class RadarOperator(object):
     _table_serial = 0          # tags of per-ray table sets handed to the library
 
     def __init__(self, options_file=None, output_variables='all', *, device=0, lut_dir=None,
-                 luts=None, config=None, distributed=False, lanes=2, backend='hip'):
+                 luts=None, config=None, distributed=False, lanes=2, backend='hip',
+                 pyart_output=False):
         if backend != 'hip':
             # by design: the product path is the HIP library or nothing (no CPU fallback)
             raise N.NativeError("backend %r: only 'hip' exists; the CPU restatement lives under "
@@ -125,6 +131,7 @@ class RadarOperator(object):
         self._lock = threading.RLock()
         self.device = device
         self.distributed = bool(distributed)   # shard the rays of every sweep over the ranks
+        self.pyart_output = bool(pyart_output) # get_PPI / get_RHI return a pyart.core.Radar (needs Py-ART)
         self.reuse_device_tables = True        # keep per-ray tables in HBM between equal sweeps
         self.lut_dir = lut_dir
         self._user_luts = luts
@@ -649,6 +656,17 @@ class RadarOperator(object):
                 'lons': res['lons'], 'mask': res['mask'], 'dist': res['dist'],
                 'heights': res['heights']}
 
+    def _finish_scan(self, scan):
+        """RadarScan, or -- when `pyart_output` is set and Py-ART imports -- the reference's
+        PyartRadop built from it (cosmo_pol/radar/pyart_wrapper.py:191-342)."""
+        if getattr(self, 'pyart_output', False):
+            from . import pyart_wrapper
+            if pyart_wrapper.pyart_available():
+                va = self.constants.VARRAY if self.__config['doppler']['scheme'] == 3 else None
+                return pyart_wrapper.as_pyart_radar(scan, va)
+            print('pyart_output requested but Py-ART does not import: returning a RadarScan')
+        return scan
+
     def get_PPI(self, elevations, azimuths=None, az_step=None, az_start=0, az_stop=359):
         """Simulates PPI scan(s) (radar_operator.py:357-453); one sweep per
         elevation, returned as a RadarScan."""
@@ -667,8 +685,8 @@ class RadarOperator(object):
         azimuths = np.asarray(azimuths, dtype=float)
         sweeps = self._simulate_sweeps([(azimuths, np.full(len(azimuths), float(e)))
                                         for e in elevations])
-        return RadarScan('ppi', list(elevations), list(azimuths), self.constants.RANGE_RADAR,
-                         self.get_pos_and_time(), sweeps)
+        return self._finish_scan(RadarScan('ppi', list(elevations), list(azimuths),
+                                           self.constants.RANGE_RADAR, self.get_pos_and_time(), sweeps))
 
     def get_RHI(self, azimuths, elevations=None, elev_step=None, elev_start=0, elev_stop=90):
         """Simulates RHI scan(s) (radar_operator.py:455-549); one sweep per azimuth."""
@@ -683,8 +701,8 @@ class RadarOperator(object):
         elevations = np.asarray(elevations, dtype=float)
         sweeps = self._simulate_sweeps([(np.full(len(elevations), float(a)), elevations)
                                         for a in azimuths])
-        return RadarScan('rhi', list(elevations), list(azimuths), self.constants.RANGE_RADAR,
-                         self.get_pos_and_time(), sweeps)
+        return self._finish_scan(RadarScan('rhi', list(elevations), list(azimuths),
+                                           self.constants.RANGE_RADAR, self.get_pos_and_time(), sweeps))
 
     def get_VPROF(self):
         """90-degree vertical profile (the reference's version is broken as

@@ -97,3 +97,52 @@ def test_simulated_gpm_packing_matches_per_ray_definition():
         el = np.full(G, np.nan)
         el[:n] = lats[idx, :L][keep][::-1]
         assert np.array_equal(o.lats[i, j], el, equal_nan=True)
+
+
+def test_pyart_packaging_passes_the_reference_arguments(monkeypatch):
+    """as_pyart_radar: with a (stand-in) pyart.core.Radar present, the scan is handed over with
+    the positional arguments of the reference's PyartRadop (pyart_wrapper.py:335-339), the
+    reference's field metadata and the Doppler velocity bins."""
+    import sys
+    import types
+    from cosmo_pol_amd import pyart_wrapper as PW
+    from cosmo_pol_amd.radar_operator import RadarScan
+
+    class FakeRadar(object):
+        def __init__(self, time, _range, fields, metadata, scan_type, latitude, longitude, altitude,
+                     sweep_number, sweep_mode, fixed_angle, sweep_start_ray_index,
+                     sweep_stop_ray_index, azimuth, elevation, instrument_parameters=None):
+            self.__dict__.update(locals())
+            self.range = _range
+
+    pyart = types.ModuleType('pyart')
+    core = types.ModuleType('pyart.core')
+    core.Radar = FakeRadar
+    pyart.core = core
+    monkeypatch.setitem(sys.modules, 'pyart', pyart)
+    monkeypatch.setitem(sys.modules, 'pyart.core', core)
+    assert PW.pyart_available()
+    n_g = 6
+    rng = np.random.default_rng(0)
+
+    def sweep(n_r, el):
+        f = {k: (10 ** rng.uniform(-1, 3, (n_r, n_g))).astype(np.float32) for k in ('ZH', 'ZDR', 'KDP')}
+        f['ZH'][0, 0] = 0.0
+        f['KDP'][1, 2] = np.nan
+        return {'fields': f, 'azimuth': np.arange(n_r, dtype=float), 'elevation': np.full(n_r, el),
+                'lats': rng.normal(size=(n_r, n_g)), 'lons': rng.normal(size=(n_r, n_g)),
+                'mask': np.zeros((n_r, n_g)), 'dist': np.zeros((n_r, n_g), dtype=np.float32),
+                'heights': np.zeros((n_r, n_g), dtype=np.float32)}
+    scan = RadarScan('ppi', [1.0, 2.0], list(np.arange(3.)), np.arange(n_g) * 300.,
+                     {'latitude': 46.5, 'longitude': 7.5, 'altitude': 1000., 'time': '2026-03-01'},
+                     [sweep(3, 1.0), sweep(3, 2.0)])
+    radar = scan.to_pyart(varray=np.linspace(-8, 8, 5))
+    assert isinstance(radar, FakeRadar) and radar.scan_type == 'ppi'
+    assert radar.fields['ZH']['units'] == 'dBZ' and radar.fields['KDP']['long_name'] == 'Specific diff. phase'
+    assert radar.fields['ZH']['valid_max'] == 55 and radar.fields['Latitude']['units'] == ['degrees']
+    assert radar.fields['ZH']['data'].shape == (6, n_g) and np.ma.is_masked(radar.fields['ZH']['data'][0, 0])
+    assert np.array_equal(radar.sweep_start_ray_index['data'], [0, 3])
+    assert np.allclose(radar.fixed_angle['data'], [1.0, 2.0])
+    assert np.array_equal(radar.instrument_parameters['varray']['data'], np.linspace(-8, 8, 5))
+    assert radar.get_field(1, 'ZDR').shape == (3, n_g)
+    assert radar.fields['rangearray']['data'].shape == (6, n_g)
