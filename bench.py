@@ -379,7 +379,7 @@ def run_c2(env):
     return out
 
 
-def roofline(workload, kernel, ms_stage, n_valid, psd_bytes, ms_isolated=None):
+def roofline(workload, kernel, ms_stage, n_valid, psd_bytes, ms_isolated=None, valu_scale=1.0):
     """The PSD x table stage against its bound.  It is f64-VALU bound: the
     LUT slices are shared by the items of a work unit through the scalar cache, so the HBM
     figure the survey defines (B_alg = N_valid x 49152 B over the kernel time) exceeds the
@@ -388,14 +388,17 @@ def roofline(workload, kernel, ms_stage, n_valid, psd_bytes, ms_isolated=None):
     instruction slots of 1024 SIMDs at 2.4 GHz during the live kernel time."""
     prof, prof_path = load_profile_summary(workload)
     valu = traffic = prof_us = None
+    kernels = kernel if isinstance(kernel, (list, tuple)) else [kernel]
     if prof:
-        for name, c in prof.items():
-            if name.startswith('_') or kernel.split('<')[0] not in name:
-                continue
-            if kernel in name or valu is None:
-                valu = c.get('SQ_INSTS_VALU')
-                traffic = c.get('hbm_bytes')
-                prof_us = c.get('avg_us')
+        for want in kernels:
+            for name, c in prof.items():
+                if name.startswith('_') or want not in name or 'SQ_INSTS_VALU' not in c:
+                    continue
+                valu = (valu or 0) + c['SQ_INSTS_VALU'] * valu_scale
+                traffic = (traffic or 0) + c.get('hbm_bytes', 0) * valu_scale
+                prof_us = (prof_us or 0) + c.get('avg_us', 0)
+                break
+    kernel = ' + '.join(kernels)
     analytic = -(-n_valid // 64) * 1024 * 16          # recurrence flavour: 16 v_*_f64 per (item row, bin)
     peak = N_SIMD * PEAK_CLOCK / VALU_F64_CYCLES / 1e9     # G wave-instructions / s
     t = ms_stage * 1e-3 if ms_stage and ms_stage > 0 else None
@@ -501,19 +504,23 @@ def run_c4(env):
 
     # per-rank work of one volume (untimed pass: counters after every sweep)
     n_valid_loc = n_units_loc = 0
+    ms_psd_iso = []
     for e, elev in enumerate(C4_ELEVATIONS):
         if n_loc > 0:
+            op._ctx.enable_timing(2)
             op.simulate_rays(az, np.full(n_loc, elev), device_outputs=ptrs[e], lane=0)
             c = op._ctx.counters()
+            op._ctx.enable_timing(False)
             n_valid_loc += int(c.n_valid_items)
             n_units_loc += int(c.n_work_units)
+            ms_psd_iso.append(float(c.ms_psd))
+    mine = {'rank': rank, 'rays_per_sweep': n_loc, 'n_valid_items': n_valid_loc, 'n_work_units': n_units_loc,
+            'psd_stage_ms_per_sweep_isolated': (sum(ms_psd_iso) / len(ms_psd_iso)) if ms_psd_iso else None}
     per_rank = [None] * world
     if world > 1:
-        dist.all_gather_object(per_rank, {'rank': rank, 'rays_per_sweep': n_loc, 'n_valid_items': n_valid_loc,
-                                          'n_work_units': n_units_loc})
+        dist.all_gather_object(per_rank, mine)
     else:
-        per_rank = [{'rank': 0, 'rays_per_sweep': n_loc, 'n_valid_items': n_valid_loc,
-                     'n_work_units': n_units_loc}]
+        per_rank = [mine]
 
     # rank 0 alone: the same volume on ONE GPU (the strong-scaling reference), and the check
     # that the gathered volume equals it bit for bit
@@ -549,12 +556,19 @@ def run_c4(env):
     if rank != 0:
         return None
     n_valid = sum(p['n_valid_items'] for p in per_rank)
-    ms_stage = max(ms_psd) if ms_psd else None
-    roof = roofline('c4', 'k_psd_melting<false>', ms_stage, max(p['n_valid_items'] for p in per_rank) // n_el,
-                    max(p['n_valid_items'] for p in per_rank) // n_el * LUT_SLICE_BYTES)
-    roof['note'] += ('; c4: avg_stage_ms = the PSD stage (recurrence + ice + melting flavours, launched '
-                     'on sibling streams) of one sweep of the busiest rank; the instruction count is the '
-                     'melting flavour\'s when a profile of this workload is committed')
+    busiest = max(per_rank, key=lambda q: q['n_valid_items'])
+    prof, _ = load_profile_summary('c4')
+    scale = 1.0
+    if prof and prof.get('_meta', {}).get('n_valid_items_per_volume'):
+        scale = busiest['n_valid_items'] / float(prof['_meta']['n_valid_items_per_volume'])
+    roof = roofline('c4', ['k_psd_melting<false>', 'k_psd<2, false>', 'k_psd_uniform<false>'],
+                    busiest['psd_stage_ms_per_sweep_isolated'], busiest['n_valid_items'] // n_el,
+                    busiest['n_valid_items'] // n_el * LUT_SLICE_BYTES, valu_scale=scale)
+    roof['stage_ms_with_lanes_in_flight'] = max(ms_psd) if ms_psd else None
+    roof['note'] += ('; c4: the PSD stage = three kernel flavours back to back (melting, ice, recurrence); '
+                     'avg_stage_ms = mean over the 5 sweeps of the busiest rank, one lane at a time (the pass '
+                     'after the timed region); the instruction count is the sum of the three kernels\' '
+                     'per-launch means of the N = 1 profile scaled by this rank\'s share of the valid items')
     return {
         'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
