@@ -497,6 +497,12 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
         ctx->err = "cpol_stage_hydro: uniform_grid needs aux[1 + 5 n_d]";
         return CPOL_ERR_ARG;
     }
+    if (desc->psd_family == CPOL_PSD_MELTING && desc->melt_degree != 0 &&
+        (desc->melt_degree != CPOL_MELT_DEGREE || !aux ||
+         (long)n_aux < 2L * desc->n_t + (long)desc->n_t * desc->n_d * CPOL_MELT_FUNCS * (CPOL_MELT_DEGREE + 1))) {
+        ctx->err = "cpol_stage_hydro: melt_degree must be 0 or CPOL_MELT_DEGREE with aux[2 n_t + n_t n_d 4 (degree+1)]";
+        return CPOL_ERR_ARG;
+    }
     if (desc->psd_family == CPOL_PSD_ICE_FIELD && (!aux || n_aux < 4 * desc->n_d + 1)) {
         ctx->err = "cpol_stage_hydro: ice family needs aux[4*n_d+1]";
         return CPOL_ERR_ARG;

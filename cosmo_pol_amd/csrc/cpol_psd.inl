@@ -136,6 +136,19 @@ __device__ __forceinline__ int rank_position(const RankShared &sh, int ticket)
 // 22 / 42 / 44 / 215 / 12 VALU instructions; the versions below reach 1e-15 relative
 // accuracy (tests/test_gpu_math.py) in 15-32, from float32 hardware seeds refined by
 // Newton steps in float64 and short polynomials.  Inputs are positive and normal here.
+// a * b + c with a wave-uniform addend c taken from an SGPR pair: `v_fma_f64 dst, a, b, s[c]`.
+// Left to itself the compiler prefers the two-address form v_fmac_f64 (addend = destination)
+// and first copies a uniform / literal addend into VGPRs with one v_mov_b64 or two v_mov_b32:
+// 2-3 VALU issues per Horner step instead of one (tools/isa_loops.py: 97 v_mov_b64 per two
+// bins of the melting loop, 160 v_mov_b32 in its table-driven form).  The kernels below are
+// VALU-issue bound, so the addend goes through the scalar operand explicitly.
+__device__ __forceinline__ double fma_sc(double a, double b, double c_uniform)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+    return r;
+}
+
 __device__ __forceinline__ double cp_exp(double x)
 {
     // x = n ln2 + r, |r| <= ln2/2; Taylor to r^12/12! (next term < 2e-16)
@@ -143,15 +156,15 @@ __device__ __forceinline__ double cp_exp(double x)
     double r = fma(n, -0.6931471803691238, x);
     r = fma(n, -1.9082149292705877e-10, r);
     double p = 1.0 / 479001600.0;
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
+    p = fma_sc(p, r, 1.0 / 39916800.0);
+    p = fma_sc(p, r, 1.0 / 3628800.0);
+    p = fma_sc(p, r, 1.0 / 362880.0);
+    p = fma_sc(p, r, 1.0 / 40320.0);
+    p = fma_sc(p, r, 1.0 / 5040.0);
+    p = fma_sc(p, r, 1.0 / 720.0);
+    p = fma_sc(p, r, 1.0 / 120.0);
+    p = fma_sc(p, r, 1.0 / 24.0);
+    p = fma_sc(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -798,6 +811,46 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
         const double d_max = it.fw * d.r_dmax + (1 - it.fw) * d.s_dmax;
         const double d_min = it.fw * d.r_dmin + (1 - it.fw) * d.s_dmin;
         const double step = (d_max - d_min) / (double)(n_d - 1);
+        if (d.melt_degree == CPOL_MELT_DEGREE) {
+            // N(D_k) = G(fw, k) exp(-lambda_r D_r(fw, k)): the factors that depend on the wet
+            // fraction only -- two cube roots, a sixth / fourth root, two powers for graupel, a
+            // division: ~200 of the ~300 VALU instructions of a (item, bin) in the direct form
+            // below -- come from degree-10 polynomials in fw, tabulated per (wet-fraction bin of
+            // the unit's LUT slice, diameter bin) at staging time in extended precision
+            // (hydrometeors.py::melting_fw_tables, < 2e-15 relative); the rain slope lambda_r
+            // stays per item.  Coefficients are wave-uniform: scalar loads, like the table row.
+            constexpr int NC = CPOL_MELT_DEGREE + 1;
+            const int tb = (key - h.key_base) % d.n_t;                  // wet-fraction bin of the slice
+            const cdouble_p head = as_const(h.aux);
+            const double u = active ? (it.fw - head[2 * tb]) * head[2 * tb + 1] : 0.0;
+            const cdouble_p co = as_const(h.aux + 2 * d.n_t + (long)tb * n_d * (CPOL_MELT_FUNCS * NC));
+#pragma unroll 2
+            for (int k = k0; k < k1; ++k) {
+                const cdouble_p c = co + (long)k * (CPOL_MELT_FUNCS * NC);
+                double Dr = c[NC - 1], G = c[2 * NC - 1], GM = c[3 * NC - 1], GV = c[4 * NC - 1];
+#pragma unroll
+                for (int q = NC - 2; q >= 0; --q) {          // Horner, coefficient = scalar addend
+                    Dr = fma_sc(Dr, u, c[q]);
+                    G = fma_sc(G, u, c[NC + q]);
+                    GM = fma_sc(GM, u, c[2 * NC + q]);
+                    GV = fma_sc(GV, u, c[3 * NC + q]);
+                }
+                const double E = cp_exp(-(it.lam_r * Dr));
+                const double Nraw = G * E;
+                msum = fma(GM, E, msum);                                            // :478
+                if (DOP2) {
+                    const double wr = rv[2 * k + 1];
+                    vsum = fma(wr * GV, E, vsum);
+                    nsum = fma(wr, Nraw, nsum);
+                } else {
+                    vsum = fma(GV, E, vsum);                                        // :457
+                    nsum += Nraw;                                                   // :458
+                }
+                const cdouble_p row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+                for (int cc = 0; cc < CPOL_N_SZ; ++cc) acc[cc] = fma(row[cc], Nraw, acc[cc]);
+            }
+        } else
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
             const double D = d_min + step * (double)k;

@@ -95,7 +95,11 @@ def build_hydro(h, scheme, lut, var_index):
         d.r_dmin, d.r_dmax = cr['d_min'], cr['d_max']
         d.s_dmin, d.s_dmax = cs['d_min'], cs['d_max']
         d.dD = 0.0
-        return d, table, None, None, None
+        aux = None
+        if MELT_TABLES:
+            aux = melting_fw_tables(d, n_d, n_t, float(d.t_lo), float(d.t_step))
+            d.melt_degree = N.MELT_DEGREE
+        return d, table, None, None, aux
 
     c = _consts(h, scheme)
     D = np.asarray(lut.axes[lut.axes_names['d']])          # float32 [n_d]
@@ -299,3 +303,72 @@ def t_function_tables(which=('snow_n0', 'ice_mom2_a')):
 
 
 _TFUN_CACHE = {}
+
+
+# melting species: the fw-only factors of N(D) from polynomial tables (False: every (item, bin)
+# evaluates the melting-particle relations directly, as round 1 did)
+MELT_TABLES = True
+
+
+def _melting_factors(d, fw, n_d, dtype=np.longdouble):
+    """The four factors of the melting-particle PSD that depend on the wet fraction only
+    (hydrometeors.py:333-339, 372-439, 457-478), on the per-item diameter grid, in extended
+    precision: D_r, G = N_r0 sqrt(D_r) V_r / V dD_r/dD, G M, G V   -> each [len(fw), n_d]."""
+    fw = np.asarray(fw, dtype=dtype)[:, None]
+    k = np.arange(n_d, dtype=dtype)[None, :]
+    f = lambda x: dtype(x)                                             # noqa: E731
+    d_max = fw * f(d.r_dmax) + (1 - fw) * f(d.s_dmax)
+    d_min = fw * f(d.r_dmin) + (1 - fw) * f(d.s_dmin)
+    step = (d_max - d_min) / dtype(n_d - 1)
+    D = d_min + step * k
+    D2 = D + f(0.01)
+    fw2 = fw * fw
+    M = fw2 * (f(d.r_a) * D ** 3) + (1 - fw2) * (f(d.a) * D ** f(d.b))
+    M2 = fw2 * (f(d.r_a) * D2 ** 3) + (1 - fw2) * (f(d.a) * D2 ** f(d.b))
+    c6 = dtype(6.0e6) / dtype(np.pi)                                   # rho_w = 1e-6 kg mm-3
+    third = dtype(1) / dtype(3)
+    Dr = (c6 * M) ** third
+    sq = np.sqrt(Dr)
+    dDr = ((c6 * M2) ** third - Dr) * dtype(100)
+    Vr = f(d.r_alpha) * sq
+    Vd = f(d.alpha) * D ** f(d.beta)
+    phi = f(0.246) * fw + (1 - f(0.246)) * fw ** 7
+    V = phi * Vr + (1 - phi) * Vd
+    G = (f(d.r_n0) * sq) * Vr / V * dDr
+    return Dr, G, G * M, G * V
+
+
+def melting_fw_tables(d, n_d, n_t, t_lo, t_step, deg=None):
+    """aux[] of a melting species (cpol_stage_hydro): per wet-fraction bin b of the table's
+    second axis the centre and 1 / half-width of its fw interval, then per (b, diameter bin) the
+    monomial coefficients in u = (fw - centre) / half-width of the degree-`deg` Chebyshev
+    interpolants of D_r, G, G M, G V (nodes and transform in extended precision).  Bin 0 reaches
+    down to fw = 0 and the last bin up to fw = 1 (lookup_line clips the index, lut.py:336-341).
+    The coefficient tail of every interpolant is checked against 1e-14 of the function."""
+    from numpy.polynomial import chebyshev as cheb
+    deg = N.MELT_DEGREE if deg is None else deg
+    nn = deg + 1
+    ld = np.longdouble
+    j = np.arange(nn)
+    x = np.cos(np.pi * (j + 0.5) / nn).astype(ld)                      # Chebyshev nodes
+    Tn = np.cos(np.pi * np.outer(np.arange(nn), (j + 0.5)) / nn).astype(ld)
+    c2m = np.array([cheb.cheb2poly(np.eye(nn)[n]).tolist() + [0.0] * (nn - n - 1) for n in range(nn)])
+    c2m = c2m.astype(ld)                                               # [n][power]
+    head = np.empty((n_t, 2))
+    out = np.empty((n_t, n_d, N.MELT_FUNCS, nn))
+    worst = 0.0
+    for b in range(n_t):
+        lo = 0.0 if b == 0 else t_lo + b * t_step
+        hi = 1.0 if b == n_t - 1 else t_lo + (b + 1) * t_step
+        mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+        head[b] = mid, 1.0 / half
+        fw = ld(mid) + ld(half) * x
+        for q, F in enumerate(_melting_factors(d, fw, n_d)):
+            co = (ld(2) / nn) * (Tn @ F)                               # [n, n_d] Chebyshev coefficients
+            co[0] *= ld(0.5)
+            scale = np.max(np.abs(F), axis=0)
+            worst = max(worst, float(np.max(np.abs(co[-1]) / scale)))  # |c_deg|: the size of the first dropped terms
+            out[b, :, q, :] = (c2m.T @ co).T.astype(np.float64)       # monomial, lowest power first
+    if worst > 3e-14:
+        raise ValueError('melting fw tables: interpolation tail %.2e (degree %d too low)' % (worst, deg))
+    return np.concatenate([head.ravel(), out.ravel()])

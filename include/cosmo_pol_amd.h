@@ -114,8 +114,15 @@ typedef struct {
                                    numerically over ALL gates (2-moment ice,
                                    hydrometeors.py:1256-1275): aux[] = D^mu, D^nu,
                                    V(D) on the linspace grid, then its step       */
-    int32_t pad_;
+    int32_t melt_degree;        /* melting family: 0 = every (item, bin) evaluates the melting-
+                                   particle relations directly; CPOL_MELT_DEGREE = aux[] holds,
+                                   per wet-fraction bin of the table's second axis and diameter
+                                   bin, polynomials in the wet fraction of the four fw-only
+                                   factors of N(D) (see cpol_stage_hydro)                  */
 } cpol_hydro_desc;
+
+#define CPOL_MELT_DEGREE 10     /* degree of those polynomials (11 coefficients)           */
+#define CPOL_MELT_FUNCS  4      /* D_r, G, G*M, G*V                                        */
 
 typedef struct {
     int32_t n_rays, n_gates;
@@ -252,7 +259,17 @@ int  cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data,
                       const double south_pole[2]);
 
 /* table: float64 [n_e][n_t][n_d][12]; pre: [n_d] (or NULL) host-evaluated
- * N0*D^mu | D^mu; dnu: [n_d] D^nu; aux: family-specific per-bin tables. */
+ * N0*D^mu | D^mu; dnu: [n_d] D^nu; aux: family-specific per-bin tables.
+ * Melting family with melt_degree = CPOL_MELT_DEGREE: aux = [n_t][2] (centre and 1 / half-width
+ * of the wet-fraction interval of every bin of the second axis) followed by
+ * [n_t][n_d][CPOL_MELT_FUNCS][CPOL_MELT_DEGREE + 1] monomial coefficients in
+ * u = (fw - centre) / half-width of
+ *   D_r(fw, k)   melted-equivalent diameter of bin k      (hydrometeors.py:382-383)
+ *   G(fw, k)     N_r0 sqrt(D_r) V_r / V  dD_r/dD          (:372-390, 415-439)
+ *   G M, G V     the same times the particle mass / fall speed (:393-412, :457-478)
+ * so that N(D_k) = G exp(-lambda_r D_r): everything that depends on the wet fraction only
+ * (two cube roots, a sixth / fourth root, two powers for graupel, a division per bin) is read
+ * from the table; the rain slope lambda_r stays per item. */
 int  cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc,
                       const double *table, const double *pre, const double *dnu,
                       const double *aux, int n_aux);
