@@ -971,7 +971,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     for (int j = 0; j < n_hyd; ++j) {
         const cpol_hydro_desc &d = ctx->hs.h[j].d;
         sa.key_base[j] = ctx->hs.h[j].key_base;
-        sa.unit_shift[j] = (d.psd_family == CPOL_PSD_GAMMA && d.uniform_grid) ? 7 : 6;
+        sa.unit_shift[j] = ((d.psd_family == CPOL_PSD_GAMMA && d.uniform_grid) ||
+                            (d.psd_family == CPOL_PSD_MELTING && d.melt_degree == CPOL_MELT_DEGREE)) ? 7 : 6;
     }
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st,
@@ -1056,9 +1057,24 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                 if (dop2) hipLaunchKernelGGL((k_psd<PSD_MODE_ICE, true>), grd, blk, 0, s_, ctx->hs, pa);
                 else hipLaunchKernelGGL((k_psd<PSD_MODE_ICE, false>), grd, blk, 0, s_, ctx->hs, pa);
                 break;
-            default:
-                if (dop2) hipLaunchKernelGGL((k_psd_melting<true>), grd, blk, 0, s_, ctx->hs, pa);
-                else hipLaunchKernelGGL((k_psd_melting<false>), grd, blk, 0, s_, ctx->hs, pa);
+            default: {
+                // melting slots with fw tables go to the table-driven kernel, the others (none
+                // in the product's own staging) to the direct one; each skips foreign units
+                bool tab = false, direct = false;
+                for (int jj = 0; jj < n_hyd; ++jj) {
+                    const cpol_hydro_desc &dd = ctx->hs.h[jj].d;
+                    if (dd.psd_family != CPOL_PSD_MELTING) continue;
+                    (dd.melt_degree == CPOL_MELT_DEGREE ? tab : direct) = true;
+                }
+                if (tab) {
+                    if (dop2) hipLaunchKernelGGL((k_psd_melting_tab<true>), grd, blk, 0, s_, ctx->hs, pa);
+                    else hipLaunchKernelGGL((k_psd_melting_tab<false>), grd, blk, 0, s_, ctx->hs, pa);
+                }
+                if (direct) {
+                    if (dop2) hipLaunchKernelGGL((k_psd_melting<true>), grd, blk, 0, s_, ctx->hs, pa);
+                    else hipLaunchKernelGGL((k_psd_melting<false>), grd, blk, 0, s_, ctx->hs, pa);
+                }
+                break; }
             }
             if (s_ != st) HIPCHK(hipEventRecord(ctx->ev_join[n_aux - 1], s_));
         }

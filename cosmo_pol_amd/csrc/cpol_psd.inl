@@ -678,6 +678,7 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
     const HydroDev &h = hs.h[j];
     const cpol_hydro_desc &d = h.d;
     if (psd_mode_of(d) != MODE) continue;                   // block-uniform
+    if (MODE == PSD_MODE_MELTING && d.melt_degree == CPOL_MELT_DEGREE) continue;   // k_psd_melting_tab
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -811,46 +812,6 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
         const double d_max = it.fw * d.r_dmax + (1 - it.fw) * d.s_dmax;
         const double d_min = it.fw * d.r_dmin + (1 - it.fw) * d.s_dmin;
         const double step = (d_max - d_min) / (double)(n_d - 1);
-        if (d.melt_degree == CPOL_MELT_DEGREE) {
-            // N(D_k) = G(fw, k) exp(-lambda_r D_r(fw, k)): the factors that depend on the wet
-            // fraction only -- two cube roots, a sixth / fourth root, two powers for graupel, a
-            // division: ~200 of the ~300 VALU instructions of a (item, bin) in the direct form
-            // below -- come from degree-10 polynomials in fw, tabulated per (wet-fraction bin of
-            // the unit's LUT slice, diameter bin) at staging time in extended precision
-            // (hydrometeors.py::melting_fw_tables, < 2e-15 relative); the rain slope lambda_r
-            // stays per item.  Coefficients are wave-uniform: scalar loads, like the table row.
-            constexpr int NC = CPOL_MELT_DEGREE + 1;
-            const int tb = (key - h.key_base) % d.n_t;                  // wet-fraction bin of the slice
-            const cdouble_p head = as_const(h.aux);
-            const double u = active ? (it.fw - head[2 * tb]) * head[2 * tb + 1] : 0.0;
-            const cdouble_p co = as_const(h.aux + 2 * d.n_t + (long)tb * n_d * (CPOL_MELT_FUNCS * NC));
-#pragma unroll 2
-            for (int k = k0; k < k1; ++k) {
-                const cdouble_p c = co + (long)k * (CPOL_MELT_FUNCS * NC);
-                double Dr = c[NC - 1], G = c[2 * NC - 1], GM = c[3 * NC - 1], GV = c[4 * NC - 1];
-#pragma unroll
-                for (int q = NC - 2; q >= 0; --q) {          // Horner, coefficient = scalar addend
-                    Dr = fma_sc(Dr, u, c[q]);
-                    G = fma_sc(G, u, c[NC + q]);
-                    GM = fma_sc(GM, u, c[2 * NC + q]);
-                    GV = fma_sc(GV, u, c[3 * NC + q]);
-                }
-                const double E = cp_exp(-(it.lam_r * Dr));
-                const double Nraw = G * E;
-                msum = fma(GM, E, msum);                                            // :478
-                if (DOP2) {
-                    const double wr = rv[2 * k + 1];
-                    vsum = fma(wr * GV, E, vsum);
-                    nsum = fma(wr, Nraw, nsum);
-                } else {
-                    vsum = fma(GV, E, vsum);                                        // :457
-                    nsum += Nraw;                                                   // :458
-                }
-                const cdouble_p row = slice + (long)k * CPOL_N_SZ;
-#pragma unroll
-                for (int cc = 0; cc < CPOL_N_SZ; ++cc) acc[cc] = fma(row[cc], Nraw, acc[cc]);
-            }
-        } else
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
             const double D = d_min + step * (double)k;
@@ -1113,3 +1074,140 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting(HydroSet hs, P
     psd_body<PSD_MODE_MELTING, DOP2>(hs, a);
 }
 
+
+// ---------------------------------------------------------------- melting flavour, table driven
+// N(D_k) = G(fw, k) exp(-lambda_r D_r(fw, k)): the factors of the melting-particle PSD that depend
+// on the wet fraction only -- two cube roots, a sixth / fourth root, two powers for graupel and
+// a division per (item, bin): 214 VALU instructions per (item row, bin) in the direct form above
+// (SQ_INSTS_VALU, C4 sweep) -- come from degree-10 polynomials in fw, tabulated per (wet-fraction
+// bin of the unit's LUT slice, diameter bin) at staging time in extended precision
+// (hydrometeors.py::melting_fw_tables, < 2e-15 relative); the rain slope lambda_r stays per item.
+// Per bin the wave needs 44 coefficients + 12 table-row entries = 448 bytes of wave-uniform
+// operands through the scalar path: measured with ONE item per lane the scalar data cache is
+// 99 % busy (SQC_DCACHE_BUSY_CYCLES) and the kernel no faster than the direct form (10.1 vs
+// 10.9 ms), whether the 8 waves split the bins or walk them together; with TWO items per lane
+// (128-item units, as the recurrence flavour) every fetched operand feeds two items.
+// Same work decomposition as k_psd_uniform: bins split over the 8 waves, fixed-order tree
+// combine through 4 LDS wave slots.
+#define CPOL_MELT_NV (2 * (CPOL_N_SZ + 3))
+template <bool DOP2>
+__device__ __forceinline__ void melt_store(const cpol_hydro_desc &d, const PsdArgs &a, int j, long n, int sb,
+                                           double fw, double q, const double (&acc)[CPOL_N_SZ], double m,
+                                           double v, double s)
+{
+    // the item's own grid step (hydrometeors.py:336-339, utilities.py:158-173)
+    const double d_max = fw * d.r_dmax + (1 - fw) * d.s_dmax;
+    const double d_min = fw * d.r_dmin + (1 - fw) * d.s_dmin;
+    const double step = (d_max - d_min) / (double)(d.n_d - 1);
+    const double dDl = (d_min + step * 1.0) - (d_min + step * 0.0);
+    const double prop = q / (m * dDl);                              // q / integrate_M (:1428)
+    double *o = a.res + ((long)j * n + sb) * CPOL_N_SZ;
+#pragma unroll
+    for (int c = 0; c < CPOL_N_SZ; ++c) o[c] = (prop * acc[c]) * dDl;
+    if (a.vn) {
+        a.vn[((long)j * n + sb) * 2] = DOP2 ? prop * v : (prop * v) * dDl;
+        a.vn[((long)j * n + sb) * 2 + 1] = DOP2 ? prop * s : (prop * s) * dDl;
+    }
+}
+
+template <bool DOP2>
+__global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting_tab(HydroSet hs, PsdArgs a)
+{
+    constexpr int NC = CPOL_MELT_DEGREE + 1;
+    constexpr int NV = CPOL_MELT_NV;
+    __shared__ double s_part[4][NV][CPOL_WAVE];
+    const int n_units = (int)a.totals[1];
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const WorkUnit *up = a.units + u;
+        const int key = __builtin_amdgcn_readfirstlane(up->key);
+        const int start = __builtin_amdgcn_readfirstlane(up->start);
+        const int count = __builtin_amdgcn_readfirstlane(up->count);
+        int j = 0;
+        for (int q = 1; q < hs.n_hydro; ++q) if (key >= hs.h[q].key_base) j = q;
+        const HydroDev &h = hs.h[j];
+        const cpol_hydro_desc &d = h.d;
+        if (d.psd_family != CPOL_PSD_MELTING || d.melt_degree != CPOL_MELT_DEGREE) continue;   // block-uniform
+
+        const int lane = lane_id();
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int n_d = d.n_d;
+        const int chunk = (n_d + CPOL_PSD_WAVES - 1) / CPOL_PSD_WAVES;
+        const int k0 = wave * chunk, k1 = min(k0 + chunk, n_d);
+        const bool act0 = lane < count, act1 = lane + CPOL_WAVE < count;
+        const long n = a.n_sbg;
+        const int sbg0 = a.perm[start + (act0 ? lane : 0)];
+        const int sbg1 = a.perm[start + (act1 ? lane + CPOL_WAVE : 0)];
+        const double *P0 = a.par + ((long)j * CPOL_MAX_PAR) * n + sbg0;
+        const double *P1 = a.par + ((long)j * CPOL_MAX_PAR) * n + sbg1;
+        const int tb = (key - h.key_base) % d.n_t;                  // wet-fraction bin of the slice
+        const cdouble_p head = as_const(h.aux);
+        const double mid = head[2 * tb], inv_half = head[2 * tb + 1];
+        const double fw0 = act0 ? P0[n] : mid, fw1 = act1 ? P1[n] : mid;
+        const double lam0 = act0 ? P0[2 * n] : 1.0, lam1 = act1 ? P1[2 * n] : 1.0;
+        const double u0 = (fw0 - mid) * inv_half, u1 = (fw1 - mid) * inv_half;
+        const cdouble_p slice = as_const(h.table + (long)(key - h.key_base) * n_d * CPOL_N_SZ);
+        const cdouble_p rv = as_const(DOP2 ? h.rcsw + (long)(key - h.key_base) * n_d * 2 : h.table);
+        const cdouble_p co = as_const(h.aux + 2 * d.n_t + (long)tb * n_d * (CPOL_MELT_FUNCS * NC));
+
+        double acc0[CPOL_N_SZ], acc1[CPOL_N_SZ];
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) { acc0[c] = 0.0; acc1[c] = 0.0; }
+        double m0 = 0.0, v0 = 0.0, s0 = 0.0, m1 = 0.0, v1 = 0.0, s1 = 0.0;
+#pragma unroll 1
+        for (int k = k0; k < k1; ++k) {
+            const cdouble_p c = co + (long)k * (CPOL_MELT_FUNCS * NC);
+            double Dr0 = c[NC - 1], G0 = c[2 * NC - 1], GM0 = c[3 * NC - 1], GV0 = c[4 * NC - 1];
+            double Dr1 = Dr0, G1 = G0, GM1 = GM0, GV1 = GV0;
+#pragma unroll
+            for (int q = NC - 2; q >= 0; --q) {                     // Horner, coefficient = scalar addend
+                Dr0 = fma_sc(Dr0, u0, c[q]);           Dr1 = fma_sc(Dr1, u1, c[q]);
+                G0 = fma_sc(G0, u0, c[NC + q]);        G1 = fma_sc(G1, u1, c[NC + q]);
+                GM0 = fma_sc(GM0, u0, c[2 * NC + q]);  GM1 = fma_sc(GM1, u1, c[2 * NC + q]);
+                GV0 = fma_sc(GV0, u0, c[3 * NC + q]);  GV1 = fma_sc(GV1, u1, c[3 * NC + q]);
+            }
+            const double E0 = cp_exp(-(lam0 * Dr0)), E1 = cp_exp(-(lam1 * Dr1));
+            const double N0 = G0 * E0, N1 = G1 * E1;
+            m0 = fma(GM0, E0, m0);                                                  // :478
+            m1 = fma(GM1, E1, m1);
+            if (DOP2) {
+                const double wr = rv[2 * k + 1];
+                v0 = fma(wr * GV0, E0, v0); s0 = fma(wr, N0, s0);
+                v1 = fma(wr * GV1, E1, v1); s1 = fma(wr, N1, s1);
+            } else {
+                v0 = fma(GV0, E0, v0); s0 += N0;                                    // :457-458
+                v1 = fma(GV1, E1, v1); s1 += N1;
+            }
+            const cdouble_p row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+            for (int cc = 0; cc < CPOL_N_SZ; ++cc) {
+                const double sz = row[cc];
+                acc0[cc] = fma(sz, N0, acc0[cc]);
+                acc1[cc] = fma(sz, N1, acc1[cc]);
+            }
+        }
+        // ((w0+w4)+(w2+w6)) + ((w1+w5)+(w3+w7)): fixed order, wave 0 ends up with the totals
+#pragma unroll
+        for (int half = 4; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half) {
+                double (*sp)[CPOL_WAVE] = s_part[wave - half];
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) { sp[c][lane] = acc0[c]; sp[CPOL_N_SZ + 3 + c][lane] = acc1[c]; }
+                sp[CPOL_N_SZ][lane] = m0; sp[CPOL_N_SZ + 1][lane] = v0; sp[CPOL_N_SZ + 2][lane] = s0;
+                sp[NV - 3][lane] = m1; sp[NV - 2][lane] = v1; sp[NV - 1][lane] = s1;
+            }
+            __syncthreads();
+            if (wave < half) {
+                double (*sp)[CPOL_WAVE] = s_part[wave];
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) { acc0[c] += sp[c][lane]; acc1[c] += sp[CPOL_N_SZ + 3 + c][lane]; }
+                m0 += sp[CPOL_N_SZ][lane]; v0 += sp[CPOL_N_SZ + 1][lane]; s0 += sp[CPOL_N_SZ + 2][lane];
+                m1 += sp[NV - 3][lane]; v1 += sp[NV - 2][lane]; s1 += sp[NV - 1][lane];
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            if (act0) melt_store<DOP2>(d, a, j, n, sbg0, fw0, P0[0], acc0, m0, v0, s0);
+            if (act1) melt_store<DOP2>(d, a, j, n, sbg1, fw1, P1[0], acc1, m1, v1, s1);
+        }
+    }
+}
