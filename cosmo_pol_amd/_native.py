@@ -45,7 +45,7 @@ class HydroDesc(C.Structure):
         ('r_dmin', C.c_double), ('r_dmax', C.c_double), ('s_dmin', C.c_double),
         ('s_dmax', C.c_double),
         ('solid_rule', C.c_int32), ('uniform_grid', C.c_int32),
-        ('numeric_intv', C.c_int32), ('melt_degree', C.c_int32),
+        ('numeric_intv', C.c_int32), ('tab_degree', C.c_int32),
     ]
 
 
@@ -104,6 +104,7 @@ EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_fork', 'cpol_last_error', 'cpol_
 
 TRAJ_STRIDE, GEO_STRIDE, SITE_STRIDE = 4, 8, 8      # CPOL_*_STRIDE of the header
 MELT_DEGREE, MELT_FUNCS = 10, 4                    # CPOL_MELT_DEGREE / CPOL_MELT_FUNCS
+ICE_DEGREE, ICE_FUNCS = 10, 3                      # CPOL_ICE_DEGREE / CPOL_ICE_FUNCS
 TFUN_SNOW_N0, TFUN_ICE_MOM2_A = 0, 1
 TFUN_FIRST_BITS, TFUN_COUNT = 0x43000000, 1 << 24  # every float32 in [128, 512)
 

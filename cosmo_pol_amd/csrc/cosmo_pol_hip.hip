@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "cpol_device.h"
@@ -497,10 +498,16 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
         ctx->err = "cpol_stage_hydro: uniform_grid needs aux[1 + 5 n_d]";
         return CPOL_ERR_ARG;
     }
-    if (desc->psd_family == CPOL_PSD_MELTING && desc->melt_degree != 0 &&
-        (desc->melt_degree != CPOL_MELT_DEGREE || !aux ||
+    if (desc->psd_family == CPOL_PSD_MELTING && desc->tab_degree != 0 &&
+        (desc->tab_degree != CPOL_MELT_DEGREE || !aux ||
          (long)n_aux < 2L * desc->n_t + (long)desc->n_t * desc->n_d * CPOL_MELT_FUNCS * (CPOL_MELT_DEGREE + 1))) {
-        ctx->err = "cpol_stage_hydro: melt_degree must be 0 or CPOL_MELT_DEGREE with aux[2 n_t + n_t n_d 4 (degree+1)]";
+        ctx->err = "cpol_stage_hydro: tab_degree must be 0 or CPOL_MELT_DEGREE with aux[2 n_t + n_t n_d 4 (degree+1)]";
+        return CPOL_ERR_ARG;
+    }
+    if (desc->psd_family == CPOL_PSD_ICE_FIELD && desc->tab_degree != 0 &&
+        (desc->tab_degree != CPOL_ICE_DEGREE || !desc->uniform_grid || !aux || n_aux < 12 * desc->n_d + 12 ||
+         (long)n_aux < 12L * desc->n_d + 12 + (long)aux[12 * desc->n_d + 10] * CPOL_ICE_FUNCS * (CPOL_ICE_DEGREE + 1))) {
+        ctx->err = "cpol_stage_hydro: ice tab_degree must be 0 or CPOL_ICE_DEGREE with the lambda-panel tables behind the recurrence block of aux[]";
         return CPOL_ERR_ARG;
     }
     if (desc->psd_family == CPOL_PSD_ICE_FIELD && (!aux || n_aux < 4 * desc->n_d + 1)) {
@@ -972,7 +979,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         const cpol_hydro_desc &d = ctx->hs.h[j].d;
         sa.key_base[j] = ctx->hs.h[j].key_base;
         sa.unit_shift[j] = ((d.psd_family == CPOL_PSD_GAMMA && d.uniform_grid) ||
-                            (d.psd_family == CPOL_PSD_MELTING && d.melt_degree == CPOL_MELT_DEGREE)) ? 7 : 6;
+                            (d.psd_family == CPOL_PSD_MELTING && d.tab_degree == CPOL_MELT_DEGREE) ||
+                            (d.psd_family == CPOL_PSD_ICE_FIELD && d.uniform_grid && d.tab_degree == CPOL_ICE_DEGREE)) ? 7 : 6;
     }
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st,
@@ -992,6 +1000,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         pa.n_sbg = n_sbg;
         pa.par_w = dop3 ? (double *)ctx->b_par.p : nullptr;
         pa.clk = nullptr;
+        static const int ice_force_sum = getenv("CPOL_ICE_FORCE_SUM") ? atoi(getenv("CPOL_ICE_FORCE_SUM")) : 0;
+        pa.ice_force_sum = ice_force_sum;
         if (ctx->keep_debug) {
             ENSURE(ctx->b_clk, 2048 * 4 * sizeof(long long));
             HIPCHK(hipMemsetAsync(ctx->b_clk.p, 0, 2048 * 4 * sizeof(long long), st));
@@ -1053,10 +1063,21 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                 if (dop2) hipLaunchKernelGGL((k_psd<PSD_MODE_GAMMA_EXP, true>), grd, blk, 0, s_, ctx->hs, pa);
                 else hipLaunchKernelGGL((k_psd<PSD_MODE_GAMMA_EXP, false>), grd, blk, 0, s_, ctx->hs, pa);
                 break;
-            case PSD_MODE_ICE:
+            case PSD_MODE_ICE: {
+                // slots with lambda tables: k_psd_ice2 takes the units inside the tabulated range
+                // (all of them, in practice), k_psd<ICE> sums the others
+                bool tab = false;
+                for (int jj = 0; jj < n_hyd; ++jj) {
+                    const cpol_hydro_desc &dd = ctx->hs.h[jj].d;
+                    if (dd.psd_family == CPOL_PSD_ICE_FIELD && dd.uniform_grid && dd.tab_degree == CPOL_ICE_DEGREE) tab = true;
+                }
+                if (tab) {
+                    if (dop2) hipLaunchKernelGGL((k_psd_ice2<true>), grd, blk, 0, s_, ctx->hs, pa);
+                    else hipLaunchKernelGGL((k_psd_ice2<false>), grd, blk, 0, s_, ctx->hs, pa);
+                }
                 if (dop2) hipLaunchKernelGGL((k_psd<PSD_MODE_ICE, true>), grd, blk, 0, s_, ctx->hs, pa);
                 else hipLaunchKernelGGL((k_psd<PSD_MODE_ICE, false>), grd, blk, 0, s_, ctx->hs, pa);
-                break;
+                break; }
             default: {
                 // melting slots with fw tables go to the table-driven kernel, the others (none
                 // in the product's own staging) to the direct one; each skips foreign units
@@ -1064,7 +1085,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                 for (int jj = 0; jj < n_hyd; ++jj) {
                     const cpol_hydro_desc &dd = ctx->hs.h[jj].d;
                     if (dd.psd_family != CPOL_PSD_MELTING) continue;
-                    (dd.melt_degree == CPOL_MELT_DEGREE ? tab : direct) = true;
+                    (dd.tab_degree == CPOL_MELT_DEGREE ? tab : direct) = true;
                 }
                 if (tab) {
                     if (dop2) hipLaunchKernelGGL((k_psd_melting_tab<true>), grd, blk, 0, s_, ctx->hs, pa);

@@ -589,6 +589,8 @@ struct PsdArgs {
     long n_sbg;
     long long *clk;             // clock probe [2048][4]: s_memtime / s_memrealtime at the start and
                                 // end of every workgroup (effective shader clock), or NULL
+    int ice_force_sum;          // test hook (CPOL_ICE_FORCE_SUM=1): treat every lambda as outside the
+                                // tabulated range, i.e. sum the ice normalisation integrals directly
 };
 
 __device__ __forceinline__ int psd_mode_of(const cpol_hydro_desc &d)
@@ -641,6 +643,26 @@ __device__ __forceinline__ double melt_Dr(const cpol_hydro_desc &d, const MeltIt
 typedef const double __attribute__((address_space(4))) *cdouble_p;
 __device__ __forceinline__ cdouble_p as_const(const double *p) { return (cdouble_p)(uintptr_t)p; }
 
+// 1-moment ice, lambda tables (hydrometeors.py::ice_norm_tables): position of lambda on the panel
+// axis, and whether every item of a (up to 128-item) unit lies inside the tabulated range --
+// evaluated identically by k_psd_ice2 (takes the unit if so) and k_psd<ICE> (takes it if not).
+__device__ __forceinline__ double ice_panel_pos(const double *th, double lam)
+{
+    return (cp_log(lam) * 1.4426950408889634 - th[0]) * th[1];
+}
+
+__device__ __forceinline__ bool ice_unit_in_table(const HydroDev &h, const PsdArgs &a, int j, int start, int count)
+{
+    const double *th = h.aux + 12 * h.d.n_d + 8;
+    bool ok = !a.ice_force_sum;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const int sbg = a.perm[start + i];
+        const double pf = ice_panel_pos(th, a.par[((long)j * CPOL_MAX_PAR) * a.n_sbg + sbg]);
+        ok = ok && (pf >= 0.0 && pf < th[2]);                                  // NaN -> false
+    }
+    return __syncthreads_and(ok) != 0;
+}
+
 template <int MODE, bool DOP2>
 __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
 {
@@ -668,17 +690,28 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
     // L2 an eighth of the slices) was measured SLOWER in isolation (155-160 us vs 141 us):
     // all workgroups of an XCD then stream the same few slices at the same time.
     const int n_units = (int)a.totals[1];
-    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
-    const WorkUnit *up = a.units + u;
+    // (1-moment ice with lambda tables has 128-item units, taken by k_psd_ice2; a unit with a
+    // lambda outside the tabulated range is summed here, as two 64-item halves: uu = 2 u + half)
+    constexpr int SUB = (MODE == PSD_MODE_ICE) ? 2 : 1;
+    for (int uu = blockIdx.x; uu < SUB * n_units; uu += gridDim.x) {
+    const WorkUnit *up = a.units + uu / SUB;
     const int key = __builtin_amdgcn_readfirstlane(up->key);
-    const int start = __builtin_amdgcn_readfirstlane(up->start);
-    const int count = __builtin_amdgcn_readfirstlane(up->count);
+    int start = __builtin_amdgcn_readfirstlane(up->start);
+    int count = __builtin_amdgcn_readfirstlane(up->count);
     int j = 0;
     for (int q = 1; q < hs.n_hydro; ++q) if (key >= hs.h[q].key_base) j = q;
     const HydroDev &h = hs.h[j];
     const cpol_hydro_desc &d = h.d;
     if (psd_mode_of(d) != MODE) continue;                   // block-uniform
-    if (MODE == PSD_MODE_MELTING && d.melt_degree == CPOL_MELT_DEGREE) continue;   // k_psd_melting_tab
+    if (MODE == PSD_MODE_MELTING && d.tab_degree == CPOL_MELT_DEGREE) continue;   // k_psd_melting_tab
+    if (MODE == PSD_MODE_ICE) {
+        if (d.tab_degree == CPOL_ICE_DEGREE) {
+            if (ice_unit_in_table(h, a, j, start, count)) continue;               // k_psd_ice2
+            start += (uu % SUB) * CPOL_WAVE;
+            count = min(CPOL_WAVE, count - (uu % SUB) * CPOL_WAVE);
+            if (count <= 0) continue;
+        } else if (uu % SUB) continue;
+    }
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1126,7 +1159,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting_tab(HydroSet h
         for (int q = 1; q < hs.n_hydro; ++q) if (key >= hs.h[q].key_base) j = q;
         const HydroDev &h = hs.h[j];
         const cpol_hydro_desc &d = h.d;
-        if (d.psd_family != CPOL_PSD_MELTING || d.melt_degree != CPOL_MELT_DEGREE) continue;   // block-uniform
+        if (d.psd_family != CPOL_PSD_MELTING || d.tab_degree != CPOL_MELT_DEGREE) continue;   // block-uniform
 
         const int lane = lane_id();
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1208,6 +1241,147 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting_tab(HydroSet h
         if (wave == 0) {
             if (act0) melt_store<DOP2>(d, a, j, n, sbg0, fw0, P0[0], acc0, m0, v0, s0);
             if (act1) melt_store<DOP2>(d, a, j, n, sbg1, fw1, P1[0], acc1, m1, v1, s1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- 1-moment ice, two items per lane
+// The Field et al. (2005) PSD on the LUT diameter axis by two geometric recurrences (as the ICE
+// branch of psd_body), with the three normalisation sums of the item -- functions of its lambda
+// only -- from degree-10 polynomials on 1/8-octave panels of lambda (ice_norm_tables): 25 f64
+// operations per (item, bin) instead of 43.  With one item per lane that left the kernel bound by
+// the scalar data cache (128 bytes of wave-uniform operands per 100 VALU cycles); two items per
+// lane halve that, as in the recurrence and melting flavours.  Same decomposition: 128-item
+// units, bins split over 8 waves, fixed-order tree combine.
+#define CPOL_ICE_NV (2 * (CPOL_N_SZ + 2))
+template <bool DOP2>
+__global__ __launch_bounds__(CPOL_PSD_THREADS, 4) void k_psd_ice2(HydroSet hs, PsdArgs a)
+{
+    constexpr int NC = CPOL_ICE_DEGREE + 1;
+    constexpr int NV = CPOL_ICE_NV;                       // 2 x (12 columns + Doppler-2 v, n)
+    __shared__ double s_part[4][NV][CPOL_WAVE];
+    const int n_units = (int)a.totals[1];
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const WorkUnit *up = a.units + u;
+        const int key = __builtin_amdgcn_readfirstlane(up->key);
+        const int start = __builtin_amdgcn_readfirstlane(up->start);
+        const int count = __builtin_amdgcn_readfirstlane(up->count);
+        int j = 0;
+        for (int q = 1; q < hs.n_hydro; ++q) if (key >= hs.h[q].key_base) j = q;
+        const HydroDev &h = hs.h[j];
+        const cpol_hydro_desc &d = h.d;
+        if (d.psd_family != CPOL_PSD_ICE_FIELD || !d.uniform_grid || d.tab_degree != CPOL_ICE_DEGREE) continue;
+        if (!ice_unit_in_table(h, a, j, start, count)) continue;       // k_psd<ICE> sums this unit
+
+        const int lane = lane_id();
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int n_d = d.n_d;
+        const int chunk = (n_d + CPOL_PSD_WAVES - 1) / CPOL_PSD_WAVES;
+        const int k0 = wave * chunk, k1 = min(k0 + chunk, n_d);
+        const bool act0 = lane < count, act1 = lane + CPOL_WAVE < count;
+        const long n = a.n_sbg;
+        const int sbg0 = a.perm[start + (act0 ? lane : 0)];
+        const int sbg1 = a.perm[start + (act1 ? lane + CPOL_WAVE : 0)];
+        const double *P0 = a.par + ((long)j * CPOL_MAX_PAR) * n + sbg0;
+        const double *P1 = a.par + ((long)j * CPOL_MAX_PAR) * n + sbg1;
+        const double lam0 = act0 ? P0[0] : 1.0, lam1 = act1 ? P1[0] : 1.0;
+        const cdouble_p slice = as_const(h.table + (long)(key - h.key_base) * n_d * CPOL_N_SZ);
+        const cdouble_p rv = as_const(DOP2 ? h.rcsw + (long)(key - h.key_base) * n_d * 2 : h.table);
+        const cdouble_p Dl = as_const(h.aux);
+        const cdouble_p hd = as_const(h.aux + 4 * n_d + 4);
+        const cdouble_p ql = as_const(h.aux + 4 * n_d + 8);
+        const double lp0 = lam0 / 1000.0, lp1 = lam1 / 1000.0;
+        const double a10 = 20.78 * lp0, a20 = 3.290 * lp0, a11 = 20.78 * lp1, a21 = 3.290 * lp1;
+        const double B0 = 17.46 * powp(lp0, 0.6357), B1 = 17.46 * powp(lp1, 0.6357);
+        const double a10s = a10 * a10, a10c = a10s * a10, a20s = a20 * a20, a20c = a20s * a20;
+        const double a11s = a11 * a11, a11c = a11s * a11, a21s = a21 * a21, a21c = a21s * a21;
+        const double dl0 = Dl[k0 < n_d ? k0 : 0];
+        double E10 = exp(-(a10 * dl0)), E20 = exp(-(a20 * dl0));
+        double E11 = exp(-(a11 * dl0)), E21 = exp(-(a21 * dl0));
+        const double r10 = exp(-(a10 * hd[0])), r20 = exp(-(a20 * hd[0]));
+        const double r11 = exp(-(a11 * hd[0])), r21 = exp(-(a21 * hd[0]));
+
+        double acc0[CPOL_N_SZ], acc1[CPOL_N_SZ];
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) { acc0[c] = 0.0; acc1[c] = 0.0; }
+        double dv0 = 0.0, dn0 = 0.0, dv1 = 0.0, dn1 = 0.0;          // Doppler scheme 2 sums
+#pragma unroll 2
+        for (int k = k0; k < k1; ++k) {
+            const double d1 = ql[4 * k], d2 = ql[4 * k + 1], d3 = ql[4 * k + 2], pw = ql[4 * k + 3];
+            const double c10 = fma(-a10, d1, fma(a10s, d2, fma(-a10c, d3, 1.0)));
+            const double c20 = fma(-a20, d1, fma(a20s, d2, fma(-a20c, d3, 1.0)));
+            const double c11 = fma(-a11, d1, fma(a11s, d2, fma(-a11c, d3, 1.0)));
+            const double c21 = fma(-a21, d1, fma(a21s, d2, fma(-a21c, d3, 1.0)));
+            const double ph0 = fma(B0 * pw, E20 * c20, 490.6 * (E10 * c10));
+            const double ph1 = fma(B1 * pw, E21 * c21, 490.6 * (E11 * c11));
+            E10 *= r10; E20 *= r20;
+            E11 *= r11; E21 *= r21;
+            const cdouble_p row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ; ++c) {
+                const double sz = row[c];
+                acc0[c] = fma(sz, ph0, acc0[c]);
+                acc1[c] = fma(sz, ph1, acc1[c]);
+            }
+            if (DOP2) {
+                const double wv = rv[2 * k], wr = rv[2 * k + 1];
+                dv0 = fma(wv, ph0, dv0); dn0 = fma(wr, ph0, dn0);
+                dv1 = fma(wv, ph1, dv1); dn1 = fma(wr, ph1, dn1);
+            }
+        }
+        // ((w0+w4)+(w2+w6)) + ((w1+w5)+(w3+w7)): fixed order, wave 0 ends up with the totals
+#pragma unroll
+        for (int half = 4; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half) {
+                double (*sp)[CPOL_WAVE] = s_part[wave - half];
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) { sp[c][lane] = acc0[c]; sp[CPOL_N_SZ + 2 + c][lane] = acc1[c]; }
+                if (DOP2) { sp[CPOL_N_SZ][lane] = dv0; sp[CPOL_N_SZ + 1][lane] = dn0; sp[NV - 2][lane] = dv1; sp[NV - 1][lane] = dn1; }
+            }
+            __syncthreads();
+            if (wave < half) {
+                double (*sp)[CPOL_WAVE] = s_part[wave];
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) { acc0[c] += sp[c][lane]; acc1[c] += sp[CPOL_N_SZ + 2 + c][lane]; }
+                if (DOP2) { dv0 += sp[CPOL_N_SZ][lane]; dn0 += sp[CPOL_N_SZ + 1][lane]; dv1 += sp[NV - 2][lane]; dn1 += sp[NV - 1][lane]; }
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            const double *th = h.aux + 12 * n_d + 8;
+            const double dDn = h.aux[3 * n_d];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const bool act = it ? act1 : act0;
+                if (!act) continue;
+                const double lam = it ? lam1 : lam0;
+                const double *P = it ? P1 : P0;
+                const int sb = it ? sbg1 : sbg0;
+                // the three normalisation sums of this lambda
+                const double pf = ice_panel_pos(th, lam);
+                const int pn = (int)pf;
+                const double ut = 2.0 * (pf - (double)pn) - 1.0;
+                const double *c = th + 4 + (long)pn * (CPOL_ICE_FUNCS * NC);
+                double Sm = c[NC - 1], Sv = c[2 * NC - 1], Sn = c[3 * NC - 1];
+#pragma unroll
+                for (int q = NC - 2; q >= 0; --q) {
+                    Sm = fma(Sm, ut, c[q]);
+                    Sv = fma(Sv, ut, c[NC + q]);
+                    Sn = fma(Sn, ut, c[2 * NC + q]);
+                }
+                const double N0 = P[n];
+                const double qm_est = (N0 * Sm) * dDn;
+                const double scale = N0 / qm_est * P[2 * n];         // N0 / QM_est * QM (:1339)
+                if (a.par_w) a.par_w[((long)j * CPOL_MAX_PAR + 3) * n + sb] = scale;
+                double *o = a.res + ((long)j * n + sb) * CPOL_N_SZ;
+#pragma unroll
+                for (int cc = 0; cc < CPOL_N_SZ; ++cc) o[cc] = (scale * (it ? acc1[cc] : acc0[cc])) * d.dD;
+                if (a.vn) {
+                    // scheme 1: integrate_V (x dD of its grid); scheme 2: unit-spaced trapezoid
+                    a.vn[((long)j * n + sb) * 2] = DOP2 ? scale * (it ? dv1 : dv0) : (scale * Sv) * dDn;
+                    a.vn[((long)j * n + sb) * 2 + 1] = DOP2 ? scale * (it ? dn1 : dn0) : (scale * Sn) * dDn;
+                }
+            }
         }
     }
 }

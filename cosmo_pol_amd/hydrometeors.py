@@ -98,7 +98,7 @@ def build_hydro(h, scheme, lut, var_index):
         aux = None
         if MELT_TABLES:
             aux = melting_fw_tables(d, n_d, n_t, float(d.t_lo), float(d.t_step))
-            d.melt_degree = N.MELT_DEGREE
+            d.tab_degree = N.MELT_DEGREE
         return d, table, None, None, aux
 
     c = _consts(h, scheme)
@@ -128,6 +128,9 @@ def build_hydro(h, scheme, lut, var_index):
         fast = _ice_recurrence_aux(d, D, Dn, aDb, Vn, n_d)
         if fast is not None:
             aux = np.concatenate([aux, fast])
+            if ICE_TABLES:
+                aux = np.concatenate([aux, ice_norm_tables(Dn, aDb, Vn)])
+                d.tab_degree = N.ICE_DEGREE
         return d, table, None, None, aux
 
     d.psd_family = N.PSD_GAMMA
@@ -372,3 +375,44 @@ def melting_fw_tables(d, n_d, n_t, t_lo, t_step, deg=None):
     if worst > 3e-14:
         raise ValueError('melting fw tables: interpolation tail %.2e (degree %d too low)' % (worst, deg))
     return np.concatenate([head.ravel(), out.ravel()])
+
+
+# 1-moment ice: the three normalisation sums from polynomial tables in log2(lambda) (False: summed
+# inside the diameter-bin loop of every item, as round 1 did)
+ICE_TABLES = True
+ICE_LOG2_LO, ICE_LOG2_HI, ICE_PANELS_PER_OCTAVE = -24, 15, 8
+
+
+def ice_norm_tables(Dn, aDb, Vn, deg=None):
+    """1-moment ice crystals: the renormalisation of the Field et al. (2005) PSD
+    (hydrometeors.py:1331-1339) and IceParticle.integrate_V (:1256-1275) sum
+    phi_23(lambda D_k / 1000) x (a D_k^b | V(D_k) | 1) over the 1024 nodes of the normalisation
+    grid -- functions of the item's lambda only.  Tabulated here as degree-`deg` Chebyshev
+    interpolants (monomial coefficients in u in [-1, 1]) on panels of 1/8 octave of lambda
+    between 2^-24 and 2^15 (beyond, the kernel falls back to summing), nodes and transform in
+    extended precision: < 3e-15 relative.  -> [log2 lo, panels per octave, n_panels, 0] +
+    [n_panels][3][deg + 1]."""
+    from numpy.polynomial import chebyshev as cheb
+    deg = N.ICE_DEGREE if deg is None else deg
+    nn = deg + 1
+    ld = np.longdouble
+    ppo = ICE_PANELS_PER_OCTAVE
+    n_pan = (ICE_LOG2_HI - ICE_LOG2_LO) * ppo
+    j = np.arange(nn)
+    x = np.cos(np.pi * (j + 0.5) / nn).astype(ld)
+    Tn = np.cos(np.pi * np.outer(np.arange(nn), (j + 0.5)) / nn).astype(ld)
+    c2m = np.array([cheb.cheb2poly(np.eye(nn)[n]).tolist() + [0.0] * (nn - n - 1) for n in range(nn)]).astype(ld)
+    Dn_, aDb_, Vn_ = (np.asarray(v, dtype=np.float64).astype(ld) for v in (Dn, aDb, Vn))
+    p = np.arange(n_pan, dtype=ld)[:, None]
+    log2lam = ld(ICE_LOG2_LO) + (p + (x[None, :] + 1) / 2) / ld(ppo)          # [n_pan, nn]
+    lam = np.exp2(log2lam).reshape(-1)
+    xk = lam[:, None] * Dn_[None, :] / ld(1000)
+    phi = ld(490.6) * np.exp(-ld(20.78) * xk) + ld(17.46) * xk ** ld(ICE_POWER) * np.exp(-ld(3.290) * xk)
+    F = np.stack([(phi * aDb_).sum(1), (phi * Vn_).sum(1), phi.sum(1)]).reshape(3, n_pan, nn)
+    co = (ld(2) / nn) * np.einsum('nj,fpj->fpn', Tn, F)                        # Chebyshev coefficients
+    co[..., 0] *= ld(0.5)
+    tail = float(np.max(np.abs(co[..., -1]) / np.max(np.abs(F), axis=2)))
+    if tail > 3e-14:
+        raise ValueError('ice normalisation tables: interpolation tail %.2e' % tail)
+    mono = np.einsum('np,fqn->qfp', c2m, co).astype(np.float64)                # [n_pan, 3, nn]
+    return np.concatenate([[float(ICE_LOG2_LO), float(ppo), float(n_pan), 0.0], mono.ravel()])

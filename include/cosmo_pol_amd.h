@@ -114,15 +114,19 @@ typedef struct {
                                    numerically over ALL gates (2-moment ice,
                                    hydrometeors.py:1256-1275): aux[] = D^mu, D^nu,
                                    V(D) on the linspace grid, then its step       */
-    int32_t melt_degree;        /* melting family: 0 = every (item, bin) evaluates the melting-
-                                   particle relations directly; CPOL_MELT_DEGREE = aux[] holds,
-                                   per wet-fraction bin of the table's second axis and diameter
-                                   bin, polynomials in the wet fraction of the four fw-only
-                                   factors of N(D) (see cpol_stage_hydro)                  */
+    int32_t tab_degree;         /* 0, or the degree of the polynomial tables appended to aux[]:
+                                   melting family (CPOL_MELT_DEGREE): per wet-fraction bin of
+                                   the table's second axis and diameter bin, polynomials in
+                                   the wet fraction of the four fw-only factors of N(D);
+                                   1-moment ice (CPOL_ICE_DEGREE): per panel in log2(lambda),
+                                   polynomials of the three normalisation sums (which depend on
+                                   lambda only).  See cpol_stage_hydro                     */
 } cpol_hydro_desc;
 
 #define CPOL_MELT_DEGREE 10     /* degree of those polynomials (11 coefficients)           */
 #define CPOL_MELT_FUNCS  4      /* D_r, G, G*M, G*V                                        */
+#define CPOL_ICE_DEGREE  10     /* degree of the ice normalisation-sum polynomials         */
+#define CPOL_ICE_FUNCS   3      /* sum a D^b phi, sum V phi, sum phi over the norm. grid   */
 
 typedef struct {
     int32_t n_rays, n_gates;
@@ -260,7 +264,7 @@ int  cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data,
 
 /* table: float64 [n_e][n_t][n_d][12]; pre: [n_d] (or NULL) host-evaluated
  * N0*D^mu | D^mu; dnu: [n_d] D^nu; aux: family-specific per-bin tables.
- * Melting family with melt_degree = CPOL_MELT_DEGREE: aux = [n_t][2] (centre and 1 / half-width
+ * Melting family with tab_degree = CPOL_MELT_DEGREE: aux = [n_t][2] (centre and 1 / half-width
  * of the wet-fraction interval of every bin of the second axis) followed by
  * [n_t][n_d][CPOL_MELT_FUNCS][CPOL_MELT_DEGREE + 1] monomial coefficients in
  * u = (fw - centre) / half-width of
@@ -269,7 +273,13 @@ int  cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data,
  *   G M, G V     the same times the particle mass / fall speed (:393-412, :457-478)
  * so that N(D_k) = G exp(-lambda_r D_r): everything that depends on the wet fraction only
  * (two cube roots, a sixth / fourth root, two powers for graupel, a division per bin) is read
- * from the table; the rain slope lambda_r stays per item. */
+ * from the table; the rain slope lambda_r stays per item.
+ * 1-moment ice with tab_degree = CPOL_ICE_DEGREE (and uniform_grid): the aux block of the
+ * recurrence form (4 n_d + 8 + 8 n_d values) is followed by [log2(lambda_lo), panels per octave,
+ * n_panels, 0] and [n_panels][CPOL_ICE_FUNCS][CPOL_ICE_DEGREE + 1] monomial coefficients in
+ * u in [-1, 1] across a panel of log2(lambda): the renormalisation sums of IceParticle.set_psd /
+ * integrate_V (hydrometeors.py:1331-1339, 1256-1275) are 1024-term sums that depend on the
+ * item's lambda only, not on its LUT slice. */
 int  cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc,
                       const double *table, const double *pre, const double *dnu,
                       const double *aux, int n_aux);

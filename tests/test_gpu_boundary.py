@@ -156,3 +156,20 @@ def test_radial_records_of_a_device_result_and_reference_style_cut():
     assert len(sweeps) == 1 and len(sweeps[0]) == len(az)
     assert np.array_equal(sweeps[0][2].values['ZH'], dev['ZH'][2], equal_nan=True)
     op.close()
+
+
+def test_ice_units_outside_the_lambda_tables_are_summed_directly():
+    """1-moment ice: k_psd_ice2 takes the units whose lambdas lie inside the tabulated range, the
+    64-item kernel sums the normalisation integrals of the others bin by bin.  CPOL_ICE_FORCE_SUM=1
+    (read once per process) sends EVERY unit down that fallback: the reference-pinned radials with
+    ice crystals must still hold (one child pytest process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CPOL_ICE_FORCE_SUM='1')
+    cmd = [sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-m', 'gpu', '-q',
+           '-x', '-k', 'c3_melt_ice or d3_1mom_ice_sub or c4_7x7 or q_ml_dop2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert '4 passed' in out.stdout
