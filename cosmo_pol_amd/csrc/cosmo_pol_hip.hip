@@ -769,7 +769,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_offset, (size_t)2 * n_keys * sizeof(int));        // item and unit offsets
     const long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
     ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
-    ENSURE(ctx->b_totals, 2 * sizeof(long long));
+    ENSURE(ctx->b_totals, 4 * sizeof(long long));
     ENSURE(ctx->b_perm, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_res, (size_t)n_hyd * n_sbg * CPOL_N_SZ * sizeof(double));
     const bool doppler = p->simulate_doppler != 0;

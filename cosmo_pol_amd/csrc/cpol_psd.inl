@@ -524,7 +524,7 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
             ubase += (cnt[i] + (1 << sh) - 1) >> sh;
         }
     }
-    if (t == 1023) { a.totals[0] = ibase; a.totals[1] = ubase; }
+    if (t == 1023) { a.totals[0] = ibase; a.totals[1] = ubase; a.totals[2] = 0; }   // [2]: ice fallback flag
 }
 
 // perm[offset[key] + pos] = sub-beam gate (no atomics: pos comes from k_classify), and -- the
@@ -579,7 +579,8 @@ enum { PSD_MODE_GAMMA_EXP = 0, PSD_MODE_GAMMA_UNIFORM = 1, PSD_MODE_ICE = 2, PSD
 
 struct PsdArgs {
     const WorkUnit *units;
-    const long long *totals;    // [1] = number of work units of this sweep
+    const long long *totals;    // [1] = number of work units of this sweep; [2] != 0: k_psd_ice2 left
+                                // units (lambda outside the tables) for k_psd<ICE>
     const int *perm;
     const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg]
     double *res;                // [n_hydro][n_sbg][12]   sum_k sz[k][c] N[k] * dD
@@ -706,6 +707,7 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
     if (MODE == PSD_MODE_MELTING && d.tab_degree == CPOL_MELT_DEGREE) continue;   // k_psd_melting_tab
     if (MODE == PSD_MODE_ICE) {
         if (d.tab_degree == CPOL_ICE_DEGREE) {
+            if (a.totals[2] == 0) continue;                  // k_psd_ice2 took every unit (the rule)
             if (ice_unit_in_table(h, a, j, start, count)) continue;               // k_psd_ice2
             start += (uu % SUB) * CPOL_WAVE;
             count = min(CPOL_WAVE, count - (uu % SUB) * CPOL_WAVE);
@@ -1122,6 +1124,27 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting(HydroSet hs, P
 // (128-item units, as the recurrence flavour) every fetched operand feeds two items.
 // Same work decomposition as k_psd_uniform: bins split over the 8 waves, fixed-order tree
 // combine through 4 LDS wave slots.
+// Touches the cache lines of [p, p + bytes) with vector loads whose values are never used, so
+// that the scalar loads that follow hit L2 instead of paying an HBM round trip each.  Pays when a
+// sweep has few work units (a wave then has nobody to hide behind: C3, 25 k melting items,
+// 296 -> ~?? us); irrelevant when the chip is full (C4).  Returns a value the caller must keep
+// alive (psd_keep) until after its bin loop: the loads are still in flight.
+#ifndef CPOL_PSD_L2_TOUCH
+#define CPOL_PSD_L2_TOUCH 1
+#endif
+__device__ __forceinline__ int l2_touch(const void *p, long bytes, int lane)
+{
+    int t = 0;
+#if CPOL_PSD_L2_TOUCH
+    const char *b = (const char *)p;
+#pragma unroll 4
+    for (long off = (long)lane * 128; off < bytes; off += 64 * 128)
+        t ^= __builtin_nontemporal_load((const int *)(b + off));
+#endif
+    return t;
+}
+__device__ __forceinline__ void psd_keep(int v) { asm volatile("" :: "v"(v)); }
+
 #define CPOL_MELT_NV (2 * (CPOL_N_SZ + 3))
 template <bool DOP2>
 __device__ __forceinline__ void melt_store(const cpol_hydro_desc &d, const PsdArgs &a, int j, long n, int sb,
@@ -1186,6 +1209,10 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting_tab(HydroSet h
 #pragma unroll
         for (int c = 0; c < CPOL_N_SZ; ++c) { acc0[c] = 0.0; acc1[c] = 0.0; }
         double m0 = 0.0, v0 = 0.0, s0 = 0.0, m1 = 0.0, v1 = 0.0, s1 = 0.0;
+        const int touched = l2_touch(h.aux + 2 * d.n_t + ((long)tb * n_d + k0) * (CPOL_MELT_FUNCS * NC),
+                                     (long)(k1 - k0) * (CPOL_MELT_FUNCS * NC) * 8, lane)
+                          ^ l2_touch(h.table + ((long)(key - h.key_base) * n_d + k0) * CPOL_N_SZ,
+                                     (long)(k1 - k0) * CPOL_N_SZ * 8, lane);
 #pragma unroll 1
         for (int k = k0; k < k1; ++k) {
             const cdouble_p c = co + (long)k * (CPOL_MELT_FUNCS * NC);
@@ -1218,6 +1245,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting_tab(HydroSet h
                 acc1[cc] = fma(sz, N1, acc1[cc]);
             }
         }
+        psd_keep(touched);
         // ((w0+w4)+(w2+w6)) + ((w1+w5)+(w3+w7)): fixed order, wave 0 ends up with the totals
 #pragma unroll
         for (int half = 4; half >= 1; half >>= 1) {
@@ -1271,7 +1299,10 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS, 4) void k_psd_ice2(HydroSet hs, P
         const HydroDev &h = hs.h[j];
         const cpol_hydro_desc &d = h.d;
         if (d.psd_family != CPOL_PSD_ICE_FIELD || !d.uniform_grid || d.tab_degree != CPOL_ICE_DEGREE) continue;
-        if (!ice_unit_in_table(h, a, j, start, count)) continue;       // k_psd<ICE> sums this unit
+        if (!ice_unit_in_table(h, a, j, start, count)) {                // k_psd<ICE> sums this unit
+            if (threadIdx.x == 0) atomicOr((unsigned long long *)&a.totals[2], 1ull);
+            continue;
+        }
 
         const int lane = lane_id();
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1305,6 +1336,8 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS, 4) void k_psd_ice2(HydroSet hs, P
 #pragma unroll
         for (int c = 0; c < CPOL_N_SZ; ++c) { acc0[c] = 0.0; acc1[c] = 0.0; }
         double dv0 = 0.0, dn0 = 0.0, dv1 = 0.0, dn1 = 0.0;          // Doppler scheme 2 sums
+        const int touched = l2_touch(h.table + ((long)(key - h.key_base) * n_d + k0) * CPOL_N_SZ,
+                                     (long)(k1 - k0) * CPOL_N_SZ * 8, lane);
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
             const double d1 = ql[4 * k], d2 = ql[4 * k + 1], d3 = ql[4 * k + 2], pw = ql[4 * k + 3];
@@ -1329,6 +1362,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS, 4) void k_psd_ice2(HydroSet hs, P
                 dv1 = fma(wv, ph1, dv1); dn1 = fma(wr, ph1, dn1);
             }
         }
+        psd_keep(touched);
         // ((w0+w4)+(w2+w6)) + ((w1+w5)+(w3+w7)): fixed order, wave 0 ends up with the totals
 #pragma unroll
         for (int half = 4; half >= 1; half >>= 1) {
