@@ -1124,13 +1124,11 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting(HydroSet hs, P
 // (128-item units, as the recurrence flavour) every fetched operand feeds two items.
 // Same work decomposition as k_psd_uniform: bins split over the 8 waves, fixed-order tree
 // combine through 4 LDS wave slots.
-// Touches the cache lines of [p, p + bytes) with vector loads whose values are never used, so
-// that the scalar loads that follow hit L2 instead of paying an HBM round trip each.  Pays when a
-// sweep has few work units (a wave then has nobody to hide behind: C3, 25 k melting items,
-// 296 -> ~?? us); irrelevant when the chip is full (C4).  Returns a value the caller must keep
-// alive (psd_keep) until after its bin loop: the loads are still in flight.
+// Experiment kept as a knob (make EXTRA=-DCPOL_PSD_L2_TOUCH=1): touch the cache lines of a wave's
+// operands with vector loads before its bin loop so that the scalar loads hit L2.  Measured
+// SLOWER on both ends: PSD stage of the C3 sweep 741 vs 660 us, of the C4 sweep 20.2 vs 18.5 ms.
 #ifndef CPOL_PSD_L2_TOUCH
-#define CPOL_PSD_L2_TOUCH 1
+#define CPOL_PSD_L2_TOUCH 0
 #endif
 __device__ __forceinline__ int l2_touch(const void *p, long bytes, int lane)
 {
