@@ -91,7 +91,7 @@ class Counters(C.Structure):
                 ('n_gates', C.c_int64), ('n_work_units', C.c_int64),
                 ('ms_traj', C.c_float), ('ms_interp', C.c_float), ('ms_classify', C.c_float),
                 ('ms_bucket', C.c_float), ('ms_psd', C.c_float), ('ms_final', C.c_float),
-                ('ms_total', C.c_float)]
+                ('ms_total', C.c_float), ('n_table_items', C.c_int32), ('pad_', C.c_int32)]
 
 
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_fork', 'cpol_last_error', 'cpol_set_stream',

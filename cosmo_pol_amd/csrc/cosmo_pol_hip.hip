@@ -62,6 +62,10 @@ struct cpol_ctx {
     DevBuf d_table[CPOL_MAX_HYDRO], d_pre[CPOL_MAX_HYDRO], d_dnu[CPOL_MAX_HYDRO],
         d_aux[CPOL_MAX_HYDRO], d_rcsw[CPOL_MAX_HYDRO], d_rcs32[CPOL_MAX_HYDRO], d_dgrid[CPOL_MAX_HYDRO];
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
+    // integral tables (built on the device by build_itabs after staging; lanes share the parent's)
+    DevBuf d_itab[CPOL_MAX_HYDRO], d_itab_M;
+    ItabSet its{};
+    uint64_t itab_serial = ~0ull;      // stage_serial the tables were built for
     DevBuf d_tfun[CPOL_N_TFUN];        // host-tabulated float32 functions of T (cpol_stage_t_function)
     const float *tfun[CPOL_N_TFUN] = {};
     // per-sweep work buffers (grow only)
@@ -153,6 +157,139 @@ void free_buf(DevBuf &b)
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+int build_itabs(cpol_ctx *ctx);
+
+}  // namespace
+
+namespace {
+
+// Integral tables of every slot whose N(D) has one shape parameter (cpol_device.h: ItabDev).
+// Runs after staging, before the first sweep / fork: the PSD kernels integrate one synthetic
+// item (N0 = QM = 1) per (LUT slice, lambda panel, Chebyshev node); k_itab_fit turns the 11 node
+// values of every (slice, panel, function) into polynomial coefficients.  CPOL_ITAB=0 disables
+// (every item is then integrated bin by bin, as in round 1).
+int build_itabs(cpol_ctx *ctx)
+{
+    if (ctx->parent) return CPOL_OK;                      // lanes copy the parent's tables
+    if (ctx->itab_serial == ctx->stage_serial) return CPOL_OK;
+    static const bool enabled = !(getenv("CPOL_ITAB") && atoi(getenv("CPOL_ITAB")) == 0);
+    ctx->its = ItabSet{};
+    ctx->itab_serial = ctx->stage_serial;
+    if (!enabled) return CPOL_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int n_hyd = ctx->hs.n_hydro;
+    constexpr int NC = CPOL_ITAB_NC;
+    // M[pw][q] = sum_n c2m[n][pw] w_n T_n(x_q): node values -> monomial coefficients
+    {
+        long double T[NC][NC] = {};                       // T[n][pw]: monomial coefficients of T_n
+        T[0][0] = 1.0L;
+        if (NC > 1) T[1][1] = 1.0L;
+        for (int n = 2; n < NC; ++n)
+            for (int pw = 0; pw < NC; ++pw)
+                T[n][pw] = (pw > 0 ? 2.0L * T[n - 1][pw - 1] : 0.0L) - T[n - 2][pw];
+        const long double pi = 3.141592653589793238462643383279502884L;
+        double M[NC * NC];
+        for (int pw = 0; pw < NC; ++pw)
+            for (int q = 0; q < NC; ++q) {
+                long double acc = 0.0L;
+                for (int n = 0; n < NC; ++n)
+                    acc += T[n][pw] * (n == 0 ? 1.0L : 2.0L) / NC * cosl(pi * n * (q + 0.5L) / NC);
+                M[pw * NC + q] = (double)acc;
+            }
+        int rc = upload(ctx, ctx->d_itab_M, M, sizeof M);
+        if (rc != CPOL_OK) return rc;
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    const bool dop2 = [&] { for (int j = 0; j < n_hyd; ++j) if (!ctx->hs.h[j].rcsw) return false; return n_hyd > 0; }();
+    for (int j = 0; j < n_hyd; ++j) {
+        const HydroDev &h = ctx->hs.h[j];
+        const cpol_hydro_desc &d = h.d;
+        const bool gamma = d.psd_family == CPOL_PSD_GAMMA && h.pre && h.dnu;
+        const bool ice = d.psd_family == CPOL_PSD_ICE_FIELD && d.uniform_grid && d.tab_degree == CPOL_ICE_DEGREE;
+        if (!gamma && !ice) continue;
+        // lambda range: 2^-10 .. the lambda at which exp(-lambda D_0^nu) leaves the double range
+        // (gamma), resp. the end of the ice normalisation tables
+        double d0 = 0.0, lo = -10.0, hi = 15.0;
+        if (gamma) {
+            HIPCHK(hipMemcpy(&d0, h.dnu, sizeof d0, hipMemcpyDeviceToHost));
+            if (!(d0 > 0.0)) continue;
+            hi = floor(log2(690.0 / d0));
+            if (hi > 16.0) hi = 16.0;
+            if (hi <= lo) continue;
+        }
+        const int n_pan = (int)(hi - lo) * CPOL_ITAB_PPO;
+        const int n_slices = d.n_e * d.n_t;
+        const long n_items = (long)n_slices * n_pan * NC;
+        const int unit_items = ((gamma && d.uniform_grid) || ice) ? 128 : 64;
+        const int upers = (n_pan * NC + unit_items - 1) / unit_items;
+        const long n_units = (long)n_slices * upers;
+        if (n_items >= (1L << 31)) continue;
+        DevBuf b_par, b_perm, b_units, b_tot, b_res, b_vn;
+        int rc;
+        if ((rc = ensure(ctx, b_par, (size_t)CPOL_MAX_PAR * n_items * sizeof(double))) ||
+            (rc = ensure(ctx, b_perm, (size_t)n_items * sizeof(int))) ||
+            (rc = ensure(ctx, b_units, (size_t)n_units * sizeof(WorkUnit))) ||
+            (rc = ensure(ctx, b_tot, 4 * sizeof(long long))) ||
+            (rc = ensure(ctx, b_res, (size_t)n_items * CPOL_N_SZ * sizeof(double))) ||
+            (rc = ensure(ctx, b_vn, (size_t)n_items * 2 * sizeof(double))) ||
+            (rc = ensure(ctx, ctx->d_itab[j], (size_t)n_slices * n_pan * CPOL_ITAB_NF * NC * sizeof(double)))) {
+            free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn);
+            return rc;
+        }
+        HIPCHK(hipMemsetAsync(b_vn.p, 0, (size_t)n_items * 2 * sizeof(double), st));
+        ItabBuildArgs ba{};
+        ba.par = (double *)b_par.p; ba.perm = (int *)b_perm.p; ba.units = (WorkUnit *)b_units.p;
+        ba.totals = (long long *)b_tot.p; ba.n_items = n_items; ba.n_slices = n_slices; ba.n_pan = n_pan;
+        ba.key_base = h.key_base; ba.unit_items = unit_items; ba.log2_lo = lo;
+        hipLaunchKernelGGL(k_itab_nodes, dim3(cdiv(n_items > n_units ? n_items : n_units, 256)), dim3(256), 0, st, ba);
+        // the slot's own kernels on the synthetic items (arrays of THIS slot only: the kernels
+        // index [n_hydro][...][n] arrays with the slot number, hence the shifted bases)
+        PsdArgs pa{};
+        pa.units = (const WorkUnit *)b_units.p;
+        pa.totals = (const long long *)b_tot.p;
+        pa.perm = (const int *)b_perm.p;
+        pa.par = (const double *)b_par.p - (long)j * CPOL_MAX_PAR * n_items;
+        pa.res = (double *)b_res.p - (long)j * n_items * CPOL_N_SZ;
+        pa.vn = (double *)b_vn.p - (long)j * n_items * 2;
+        pa.par_w = (double *)b_par.p - (long)j * CPOL_MAX_PAR * n_items;
+        pa.n_sbg = n_items;
+        pa.clk = nullptr;
+        pa.ice_force_sum = 0;
+        const dim3 grd((unsigned)(n_units < 4096 ? n_units : 4096)), blk(CPOL_PSD_THREADS);
+        if (ice) {
+            if (dop2) { hipLaunchKernelGGL((k_psd_ice2<true>), grd, blk, 0, st, ctx->hs, pa);
+                        hipLaunchKernelGGL((k_psd<PSD_MODE_ICE, true>), grd, blk, 0, st, ctx->hs, pa); }
+            else { hipLaunchKernelGGL((k_psd_ice2<false>), grd, blk, 0, st, ctx->hs, pa);
+                   hipLaunchKernelGGL((k_psd<PSD_MODE_ICE, false>), grd, blk, 0, st, ctx->hs, pa); }
+        } else if (d.uniform_grid) {
+            if (dop2) hipLaunchKernelGGL((k_psd_uniform<true>), grd, dim3(CPOL_PSD_THREADS_U), 0, st, ctx->hs, pa);
+            else hipLaunchKernelGGL((k_psd_uniform<false>), grd, dim3(CPOL_PSD_THREADS_U), 0, st, ctx->hs, pa);
+        } else {
+            if (dop2) hipLaunchKernelGGL((k_psd<PSD_MODE_GAMMA_EXP, true>), grd, blk, 0, st, ctx->hs, pa);
+            else hipLaunchKernelGGL((k_psd<PSD_MODE_GAMMA_EXP, false>), grd, blk, 0, st, ctx->hs, pa);
+        }
+        ItabFitArgs fa{};
+        fa.res = (const double *)b_res.p; fa.vn = (const double *)b_vn.p; fa.par = (const double *)b_par.p;
+        fa.M = (const double *)ctx->d_itab_M.p; fa.tab = (double *)ctx->d_itab[j].p;
+        fa.n_items = n_items; fa.n_slices = n_slices; fa.n_pan = n_pan; fa.log2_lo = lo; fa.d0 = gamma ? d0 : 0.0;
+        hipLaunchKernelGGL(k_itab_fit, dim3(cdiv((long)n_slices * n_pan * CPOL_ITAB_NF, 256)), dim3(256), 0, st, fa);
+        const hipError_t e = hipStreamSynchronize(st);
+        free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn);
+        if (e != hipSuccess || hipGetLastError() != hipSuccess) {
+            ctx->err = "build_itabs: a kernel failed";
+            return CPOL_ERR_HIP;
+        }
+        ItabDev &t = ctx->its.t[j];
+        t.tab = (const double *)ctx->d_itab[j].p;
+        t.log2_lo = lo;
+        t.d0 = gamma ? d0 : 0.0;
+        t.n_pan = n_pan;
+        t.writes_vn = ice || dop2 || d.numeric_intv;
+    }
+    return CPOL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -199,9 +336,13 @@ void cpol_destroy(cpol_ctx *ctx)
             ctx->d_rcs32[j] = DevBuf(); ctx->d_dgrid[j] = DevBuf();
         }
         for (auto &b : ctx->d_tfun) b = DevBuf();
+        for (auto &b : ctx->d_itab) b = DevBuf();
+        ctx->d_itab_M = DevBuf();
         ctx->parent->n_children -= 1;
     }
     for (auto &b : ctx->d_tfun) free_buf(b);
+    for (auto &b : ctx->d_itab) free_buf(b);
+    free_buf(ctx->d_itab_M);
     for (int i = 0; i < 3; ++i) {
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
         if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
@@ -274,6 +415,12 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->ss = parent->ss;
     for (int j = 0; j < CPOL_MAX_HYDRO; ++j) c->hydro_staged[j] = parent->hydro_staged[j];
     for (int k = 0; k < CPOL_N_TFUN; ++k) c->tfun[k] = parent->tfun[k];
+    {   // the parent's integral tables are complete before any lane exists
+        const int rc_it = build_itabs(parent);
+        if (rc_it != CPOL_OK) { (void)hipStreamDestroy(c->stream); (void)hipFree(c->d_errword); delete c; return rc_it; }
+    }
+    c->its = parent->its;
+    c->itab_serial = parent->stage_serial;
     parent->n_children += 1;
     *out = c;
     return CPOL_OK;
@@ -670,6 +817,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     for (int j = 0; j < ctx->hs.n_hydro; ++j)
         if (!ctx->hydro_staged[j]) { ctx->err = "cpol_run_sweep: hydrometeor slot not staged"; return CPOL_ERR_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->parent && ctx->itab_serial != ctx->stage_serial) {
+        const int rc_it = build_itabs(ctx);                // once per staged table set
+        if (rc_it != CPOL_OK) return rc_it;
+    }
     hipStream_t st = ctx->stream;
     const int n_rays = p->n_rays, ng = p->n_gates, n_sub = p->n_sub;
     const int n_h = p->n_hnodes, n_v = p->n_vnodes;
@@ -765,7 +916,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_key, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_pos, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_par, (size_t)n_hyd * CPOL_MAX_PAR * n_sbg * sizeof(double));
-    ENSURE(ctx->b_count, (size_t)(n_keys + 1) * sizeof(int));
+    ENSURE(ctx->b_count, (size_t)(n_keys + 2) * sizeof(int));       // + [n_keys + 1]: items on integral tables
     ENSURE(ctx->b_offset, (size_t)2 * n_keys * sizeof(int));        // item and unit offsets
     const long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
     ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
@@ -900,7 +1051,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.rp.range0 = p->range0; ia.rp.range_step = p->range_step;
     ia.rp.ke = p->ke; ia.rp.re = p->re; ia.rp.alt = p->radar_alt;
     ia.zero_buf = (int *)ctx->b_count.p;
-    ia.zero_n = n_keys;
+    ia.zero_n = n_keys + 2;
     ia.geo = (const double *)ctx->v_geo;
     ia.sub_h = (const int *)ctx->v_subh;
     ia.sub_v = (const int *)ctx->v_subv;
@@ -938,6 +1089,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ca.doppler = doppler ? 1 : 0;
     ca.tfun_snow = ctx->tfun[CPOL_TFUN_SNOW_N0];
     ca.tfun_ice = ctx->tfun[CPOL_TFUN_ICE_MOM2_A];
+    // integral tables: not with Doppler scheme 3 + ice (k_spec_gate needs every item's parameters as
+    // the integrating kernels leave them; the lookup writes the same slots, so it is fine) -- always on
+    ca.n_lookup = (int *)ctx->b_count.p + n_keys + 1;
     for (int j = 0; j < n_hyd; ++j) {
         const cpol_hydro_desc &d = ctx->hs.h[j].d;
         if (d.q_source != CPOL_Q_MODEL) continue;
@@ -963,7 +1117,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ca.wgate = (const double *)ctx->b_wgate.p;
     }
     hipLaunchKernelGGL(k_classify, dim3(cdiv(n_sbg, CPOL_CLASSIFY_THREADS)),
-                       dim3(CPOL_CLASSIFY_THREADS), 0, st, ctx->hs, ca);
+                       dim3(CPOL_CLASSIFY_THREADS), 0, st, ctx->hs, ctx->its, ca);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_CLASSIFY], st));
 
     // ---- 4. counting sort by LUT slice ----
@@ -987,6 +1141,23 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                        (const int *)ctx->b_key.p, (const int *)ctx->b_pos.p,
                        (int *)ctx->b_perm.p, n_sbg, n_hyd, sa);      // + the work-unit list
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st));
+
+    // ---- 5a. items on an integral table: 15 x 11 coefficients gathered, no diameter-bin loop ----
+    {
+        bool any = false;
+        for (int j = 0; j < n_hyd; ++j) any = any || ctx->its.t[j].tab != nullptr;
+        if (any) {
+            LookupArgs la{};
+            la.key = (const int *)ctx->b_key.p;
+            la.par = (const double *)ctx->b_par.p;
+            la.par_w = dop3 ? (double *)ctx->b_par.p : nullptr;
+            la.res = (double *)ctx->b_res.p;
+            la.vn = doppler ? (double *)ctx->b_vn.p : nullptr;
+            la.n_sbg = n_sbg;
+            hipLaunchKernelGGL(k_psd_lookup, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st, ctx->hs, ctx->its, la);
+        }
+    }
+
 
     // ---- 5. PSD x scattering table: one launch per kernel flavour present ----
     {
@@ -1314,6 +1485,10 @@ int cpol_counters(cpol_ctx *ctx, cpol_counters_t *out)
         HIPCHK(hipStreamSynchronize(ctx->stream));
         long long totals[2] = {0, 0};
         HIPCHK(hipMemcpy(totals, ctx->b_totals.p, sizeof totals, hipMemcpyDeviceToHost));
+        int n_lookup = 0;
+        HIPCHK(hipMemcpy(&n_lookup, (const int *)ctx->b_count.p + ctx->hs.n_keys + 1, sizeof n_lookup, hipMemcpyDeviceToHost));
+        ctx->counters.n_table_items = n_lookup;
+        totals[0] += n_lookup;                              // valid items = integrated + looked up
         ctx->counters.n_valid_items = totals[0];
         ctx->counters.n_work_units = totals[1];
         if (ctx->ev_used > 0) {

@@ -60,6 +60,28 @@ struct SpecSet {
     SpecDev s[CPOL_MAX_HYDRO];
 };
 
+// Integral tables ("itab"), built on the device at staging time (cosmo_pol_hip.hip::build_itabs):
+// for a species whose N(D) has ONE per-item shape parameter lambda (every gamma-family species,
+// 1-moment ice) the 12 PSD-integrated scattering entries of an item are  scale_item x F_c(slice,
+// lambda): F_c is evaluated ONCE per (LUT slice, 1/8-octave panel of lambda, Chebyshev node) by
+// the PSD kernels themselves and stored as degree-10 polynomials in the position inside the panel;
+// a sweep then gathers 15 x 11 coefficients per item instead of integrating 1024 diameter bins.
+#define CPOL_ITAB_DEGREE 10
+#define CPOL_ITAB_NC     (CPOL_ITAB_DEGREE + 1)
+#define CPOL_ITAB_NF     15      // 12 columns, 2 Doppler sums (v, n), ice: normalised N0 (Doppler spectrum)
+#define CPOL_ITAB_PPO    8       // panels per octave of lambda
+struct ItabDev {
+    const double *tab;     // [n_slices][n_pan][CPOL_ITAB_NF][CPOL_ITAB_NC] monomial coefficients, or NULL
+    double log2_lo;        // lambda of panel 0, node u = -1:  2^log2_lo
+    double d0;             // gamma family: the tabulated function is exp(+lambda d0) x integral (d0 = D_0^nu)
+    int n_pan;
+    int writes_vn;         // the direct kernels of this slot write vn (Doppler scheme 2, numeric integrate_V, ice)
+};
+
+struct ItabSet {
+    ItabDev t[CPOL_MAX_HYDRO];
+};
+
 struct WorkUnit {          // one wave of the PSD kernel
     int key;               // bucket id (hydrometeor, e bin, t bin)
     int start;             // first position in perm[]

@@ -284,6 +284,7 @@ struct ClassifyArgs {
     // correctly rounded value in 20-40 % of the arguments, and K_DP shows it
     const float *tfun_snow;      // snow intercept N0(T)  (hydrometeors.py:896) or NULL
     const float *tfun_ice;       // 10**a(T) of the Field (2005) moment relation (:1287) or NULL
+    int *n_lookup;               // counter of the items taken by the integral tables (k_psd_lookup)
 };
 
 __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &out)
@@ -297,13 +298,16 @@ __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &ou
 #define CPOL_MAX_PAR 6
 
 #define CPOL_CLASSIFY_THREADS (CPOL_RANK_WAVES * CPOL_WAVE)
-__global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs, ClassifyArgs a)
+__global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs, ItabSet its, ClassifyArgs a)
 {
     // one LDS ranking table per hydrometeor: all global atomics of the workgroup are
     // issued in ONE round (phase B) instead of one dependent round per hydrometeor
     __shared__ RankShared sh[CPOL_MAX_HYDRO];
+    __shared__ int s_lookup;
     for (int j = 0; j < hs.n_hydro; ++j) rank_reset(sh[j]);
+    if (threadIdx.x == 0) s_lookup = 0;
     __syncthreads();
+    int my_lookup = 0;
     const long sbg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = sbg < a.n_sbg;
     const long n = a.n_sbg;
@@ -427,13 +431,30 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                     ? qnv : d.ntot_factor * n0v / d.nu * cp_pow(lamf, -(d.mu + 1) / d.nu);
             }
         }
-        const int ticket = rank_insert(sh[j], a.count, key, valid);
+        // items whose lambda lies on the slot's integral table are finished by k_psd_lookup
+        // (position on the panel axis in parameter slot 4); only the others are sorted by
+        // LUT slice for the integrating kernels
+        bool lookup = false;
+        if (valid && its.t[j].tab) {
+            const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
+            const double pf = (cp_log(P[0]) * 1.4426950408889634 - its.t[j].log2_lo) * (double)CPOL_ITAB_PPO;
+            lookup = pf >= 0.0 && pf < (double)its.t[j].n_pan;                   // NaN -> false
+            a.par[((long)j * CPOL_MAX_PAR + 4) * n + i] = lookup ? pf : -1.0;
+            my_lookup += lookup ? 1 : 0;
+        }
+        const int ticket = rank_insert(sh[j], a.count, key, valid && !lookup);
         if (in) {
             a.key[(long)j * n + i] = key;
             a.pos[(long)j * n + i] = ticket;
         }
     }
+    if (a.n_lookup) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) my_lookup += __shfl_xor(my_lookup, off);
+        if (lane_id() == 0 && my_lookup) atomicAdd(&s_lookup, my_lookup);
+    }
     __syncthreads();
+    if (a.n_lookup && threadIdx.x == 0 && s_lookup) atomicAdd(a.n_lookup, s_lookup);
     for (int idx = threadIdx.x; idx < hs.n_hydro * CPOL_RANK_SLOTS; idx += blockDim.x)
         rank_reserve(sh[idx / CPOL_RANK_SLOTS], a.count, idx % CPOL_RANK_SLOTS);
     __syncthreads();
@@ -554,7 +575,8 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ 
     if (sbg >= n_sbg) return;
     for (int j = 0; j < n_hydro; ++j) {
         const int k = key[(long)j * n_sbg + sbg];
-        if (k >= 0) perm[a.offset[k] + pos[(long)j * n_sbg + sbg]] = (int)sbg;
+        const int ps = pos[(long)j * n_sbg + sbg];          // < 0: the item went to an integral table
+        if (k >= 0 && ps >= 0) perm[a.offset[k] + ps] = (int)sbg;
     }
 }
 
@@ -1414,6 +1436,142 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS, 4) void k_psd_ice2(HydroSet hs, P
                     a.vn[((long)j * n + sb) * 2 + 1] = DOP2 ? scale * (it ? dn1 : dn0) : (scale * Sn) * dDn;
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- integral tables (itab)
+// Node lambda of (panel p, node q): the Chebyshev node x_q = cos(pi (q + 1/2) / NC) of the panel
+// [2^(lo + p/PPO), 2^(lo + (p+1)/PPO)] on the log2(lambda) axis.
+__device__ __forceinline__ double itab_node_lambda(double log2_lo, int p, int q)
+{
+    const double x = cos(3.14159265358979323846 * ((double)q + 0.5) / (double)CPOL_ITAB_NC);
+    return exp2(log2_lo + ((double)p + (x + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
+}
+
+// synthetic "items" of one hydrometeor slot: one per (slice, panel, node), with N0 = QM = 1
+struct ItabBuildArgs {
+    double *par;               // [CPOL_MAX_PAR][n_items] of THIS slot
+    int *perm;                 // identity
+    WorkUnit *units;
+    long long *totals;         // [1] = n_units, [2] = 0
+    long n_items;
+    int n_slices, n_pan, key_base, unit_items;
+    double log2_lo;
+};
+
+__global__ void k_itab_nodes(ItabBuildArgs b)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_slice = b.n_pan * CPOL_ITAB_NC;
+    const int upers = (per_slice + b.unit_items - 1) / b.unit_items;
+    if (i == 0) { b.totals[0] = b.n_items; b.totals[1] = (long long)b.n_slices * upers; b.totals[2] = 0; }
+    if (i < (long)b.n_slices * upers) {
+        const int s = (int)(i / upers), uu = (int)(i % upers);
+        WorkUnit w;
+        w.key = b.key_base + s;
+        w.start = s * per_slice + uu * b.unit_items;
+        w.count = min(b.unit_items, per_slice - uu * b.unit_items);
+        w.pad = 0;
+        b.units[i] = w;
+    }
+    if (i >= b.n_items) return;
+    const int r = (int)(i % per_slice);
+    b.perm[i] = (int)i;
+    b.par[i] = itab_node_lambda(b.log2_lo, r / CPOL_ITAB_NC, r % CPOL_ITAB_NC);
+    b.par[b.n_items + i] = 1.0;             // N0
+    b.par[2 * b.n_items + i] = 1.0;         // QM (ice)
+    b.par[3 * b.n_items + i] = 0.0;
+}
+
+// node values -> monomial coefficients of the degree-10 interpolant (matrix M = basis change x
+// discrete Chebyshev transform, built on the host in extended precision)
+struct ItabFitArgs {
+    const double *res;         // [n_items][12]
+    const double *vn;          // [n_items][2]
+    const double *par;         // [CPOL_MAX_PAR][n_items] (slot 3: ice normalised N0)
+    const double *M;           // [NC][NC]
+    double *tab;               // [n_slices][n_pan][NF][NC]
+    long n_items;
+    int n_slices, n_pan;
+    double log2_lo, d0;
+};
+
+__global__ void k_itab_fit(ItabFitArgs f)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n_blocks = (long)f.n_slices * f.n_pan;
+    if (t >= n_blocks * CPOL_ITAB_NF) return;
+    const long blk = t / CPOL_ITAB_NF;
+    const int fn = (int)(t % CPOL_ITAB_NF);
+    const int p = (int)(blk % f.n_pan);
+    double v[CPOL_ITAB_NC];
+#pragma unroll
+    for (int q = 0; q < CPOL_ITAB_NC; ++q) {
+        const long i = blk * CPOL_ITAB_NC + q;
+        double x = fn < CPOL_N_SZ ? f.res[i * CPOL_N_SZ + fn]
+                 : fn < CPOL_N_SZ + 2 ? f.vn[i * 2 + (fn - CPOL_N_SZ)] : f.par[3 * f.n_items + i];
+        // gamma family: tabulate exp(+lambda d0) x integral (no super-exponential decay left)
+        if (f.d0 != 0.0) x *= exp(itab_node_lambda(f.log2_lo, p, q) * f.d0);
+        v[q] = x;
+    }
+    double *o = f.tab + t * CPOL_ITAB_NC;
+#pragma unroll
+    for (int pw = 0; pw < CPOL_ITAB_NC; ++pw) {
+        double c = 0.0;
+#pragma unroll
+        for (int q = 0; q < CPOL_ITAB_NC; ++q) c = fma(f.M[pw * CPOL_ITAB_NC + q], v[q], c);
+        o[pw] = c;
+    }
+}
+
+// one thread per sub-beam gate: the items that k_classify placed on an integral table
+struct LookupArgs {
+    const int *key;             // [n_hydro][n_sbg]
+    const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg]
+    double *par_w;              // = par, writable (ice: normalised N0 for the spectrum kernels) or NULL
+    double *res;                // [n_hydro][n_sbg][12]
+    double *vn;                 // [n_hydro][n_sbg][2] or NULL
+    long n_sbg;
+};
+
+__global__ __launch_bounds__(256) void k_psd_lookup(HydroSet hs, ItabSet its, LookupArgs a)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_sbg) return;
+    const long n = a.n_sbg;
+    for (int j = 0; j < hs.n_hydro; ++j) {
+        const ItabDev &t = its.t[j];
+        if (!t.tab) continue;
+        const int key = a.key[(long)j * n + i];
+        if (key < 0) continue;
+        const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
+        const double pf = P[4 * n];
+        if (!(pf >= 0.0)) continue;
+        const int pn = min((int)pf, t.n_pan - 1);
+        const double u = 2.0 * (pf - (double)pn) - 1.0;
+        const cpol_hydro_desc &d = hs.h[j].d;
+        const double *c = t.tab + ((long)(key - hs.h[j].key_base) * t.n_pan + pn) * (CPOL_ITAB_NF * CPOL_ITAB_NC);
+        const bool ice = d.psd_family == CPOL_PSD_ICE_FIELD;
+        // gamma: N0 x exp(-lambda d0) x G(lambda);  ice: QM x R(lambda)
+        const double scale = ice ? P[2 * n] : P[n] * cp_exp(-(P[0] * t.d0));
+        double *o = a.res + ((long)j * n + i) * CPOL_N_SZ;
+        const int nf = (a.vn && t.writes_vn) ? CPOL_N_SZ + 2 : CPOL_N_SZ;
+        for (int f = 0; f < nf; ++f) {
+            const double *cf = c + f * CPOL_ITAB_NC;
+            double v = cf[CPOL_ITAB_NC - 1];
+#pragma unroll
+            for (int q = CPOL_ITAB_NC - 2; q >= 0; --q) v = fma(v, u, cf[q]);
+            v *= scale;
+            if (f < CPOL_N_SZ) o[f] = v;
+            else a.vn[((long)j * n + i) * 2 + (f - CPOL_N_SZ)] = v;
+        }
+        if (ice && a.par_w) {
+            const double *cf = c + (CPOL_N_SZ + 2) * CPOL_ITAB_NC;
+            double v = cf[CPOL_ITAB_NC - 1];
+#pragma unroll
+            for (int q = CPOL_ITAB_NC - 2; q >= 0; --q) v = fma(v, u, cf[q]);
+            a.par_w[((long)j * CPOL_MAX_PAR + 3) * n + i] = v * scale;
         }
     }
 }

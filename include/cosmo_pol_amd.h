@@ -223,8 +223,11 @@ typedef struct {
     int64_t n_subbeam_gates;    /* N_sbg                                        */
     int64_t n_valid_items;      /* N_valid: (sub-beam gate, hydrometeor), QM>0  */
     int64_t n_gates;            /* output gates                                 */
-    int64_t n_work_units;       /* 64-item wave units of the PSD kernel         */
+    int64_t n_work_units;       /* work units of the integrating PSD kernels    */
     float   ms_traj, ms_interp, ms_classify, ms_bucket, ms_psd, ms_final, ms_total;
+    int32_t n_table_items;      /* of n_valid_items: finished from the integral tables
+                                   (the others were integrated bin by bin)      */
+    int32_t pad_;
 } cpol_counters_t;
 
 int  cpol_create(int device, cpol_ctx **out);
