@@ -98,7 +98,7 @@ def build_hydro(h, scheme, lut, var_index):
         aux = None
         if MELT_TABLES:
             aux = melting_fw_tables(d, n_d, n_t, float(d.t_lo), float(d.t_step))
-            d.tab_degree = N.MELT_DEGREE
+            d.tab_degree = N.MELT_DEGREE if aux is not None else 0
         return d, table, None, None, aux
 
     c = _consts(h, scheme)
@@ -128,8 +128,9 @@ def build_hydro(h, scheme, lut, var_index):
         fast = _ice_recurrence_aux(d, D, Dn, aDb, Vn, n_d)
         if fast is not None:
             aux = np.concatenate([aux, fast])
-            if ICE_TABLES:
-                aux = np.concatenate([aux, ice_norm_tables(Dn, aDb, Vn)])
+            tabs = ice_norm_tables(Dn, aDb, Vn) if ICE_TABLES else None
+            if tabs is not None:
+                aux = np.concatenate([aux, tabs])
                 d.tab_degree = N.ICE_DEGREE
         return d, table, None, None, aux
 
@@ -373,7 +374,7 @@ def melting_fw_tables(d, n_d, n_t, t_lo, t_step, deg=None):
             worst = max(worst, float(np.max(np.abs(co[-1]) / scale)))  # |c_deg|: the size of the first dropped terms
             out[b, :, q, :] = (c2m.T @ co).T.astype(np.float64)       # monomial, lowest power first
     if worst > 3e-14:
-        raise ValueError('melting fw tables: interpolation tail %.2e (degree %d too low)' % (worst, deg))
+        return None            # wet-fraction bins too wide for this degree (coarse test tables): direct form
     return np.concatenate([head.ravel(), out.ravel()])
 
 
@@ -413,6 +414,6 @@ def ice_norm_tables(Dn, aDb, Vn, deg=None):
     co[..., 0] *= ld(0.5)
     tail = float(np.max(np.abs(co[..., -1]) / np.max(np.abs(F), axis=2)))
     if tail > 3e-14:
-        raise ValueError('ice normalisation tables: interpolation tail %.2e' % tail)
+        return None
     mono = np.einsum('np,fqn->qfp', c2m, co).astype(np.float64)                # [n_pan, 3, nn]
     return np.concatenate([[float(ICE_LOG2_LO), float(ppo), float(n_pan), 0.0], mono.ravel()])
