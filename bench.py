@@ -171,7 +171,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     env = dict(op=op, lanes=lanes, n_lanes=n_lanes, world=world, rank=rank, local_rank=local_rank,
-               args=args, cube=cube, conf=conf, torch=torch, dist=dist, workload=workload)
+               args=args, cube=cube, conf=conf, torch=torch, dist=dist, workload=workload, luts=luts)
     out = run_c2(env) if workload == 'c2' else run_c4(env)
     if rank == 0:
         out['setup_s'] = {'synthetic_inputs': t_gen, 'stage_to_hbm': t_stage}
@@ -187,6 +187,7 @@ def main():
 
 # ------------------------------------------------------------------------------------------ c2
 def run_c2(env):
+    from cosmo_pol_amd import RadarOperator
     op, lanes, n_lanes, world, rank = env['op'], env['lanes'], env['n_lanes'], env['world'], env['rank']
     args, torch, dist, cube = env['args'], env['torch'], env['dist'], env['cube']
     az = np.arange(0, 360, 1.0)
@@ -334,8 +335,34 @@ def run_c2(env):
     psd_bytes = n_valid * LUT_SLICE_BYTES
     sweep_bytes = (n_sbg * (4 * cube['zlevels'].shape[0] * 4 + n_vars * 8 * 4) + psd_bytes
                    + n_rays * n_gates * 48)
-    roof = roofline('c2', 'k_psd_uniform<false>', cnt.ms_psd, n_valid, psd_bytes,
-                    iso.ms_psd if iso is not None else None)
+    roof = roofline_lookup('c2', cnt, psd_bytes, iso, n_fields_read=12)
+    if world == 1:
+        # the integrating kernel itself (it builds the integral tables at staging time and takes the
+        # items outside them): a second operator with the tables switched off, one lane
+        os.environ['CPOL_ITAB'] = '0'
+        try:
+            with contextlib.redirect_stdout(sys.stderr):
+                op2 = RadarOperator(config=env['conf'], luts=env['luts'], output_variables='only_radar',
+                                    device=env['local_rank'], lanes=1)
+                op2.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+            for _ in range(3):
+                op2.simulate_rays(az, el, device_outputs=dev_outs[0])
+            op2.wait()
+            op2._ctx.enable_timing(True)
+            for _ in range(max(10, args.steps // 4)):
+                op2.simulate_rays(az, el, device_outputs=dev_outs[0])
+            op2.wait()
+            c2 = op2._ctx.counters()
+            op2.close()
+        finally:
+            del os.environ['CPOL_ITAB']
+        roof['integrating_kernel'] = roofline('c2', 'k_psd_uniform<false>', c2.ms_psd, int(c2.n_valid_items),
+                                              int(c2.n_valid_items) * LUT_SLICE_BYTES)
+        roof['integrating_kernel']['sweep_device_total_ms'] = c2.ms_total
+        roof['integrating_kernel']['note'] = (
+            'CPOL_ITAB=0: every item integrated over its 1024 diameter bins by k_psd_uniform (one lane, '
+            'isolated) -- the kernel that evaluates the table nodes at staging time and finishes the items '
+            'outside the tables; f64-VALU bound: ' + roof['integrating_kernel']['note'])
     d2h_bytes = n_rays * n_gates * (len(RADAR_FIELDS) * 4 + 8 + 8)
     out = {
         'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
@@ -363,11 +390,11 @@ def run_c2(env):
             'trajectory(debug only)': iso.ms_traj, 'interp': iso.ms_interp, 'classify': iso.ms_classify,
             'bucket': iso.ms_bucket, 'psd': iso.ms_psd, 'final': iso.ms_final,
             'device_total': iso.ms_total, 'psd_with_lanes_in_flight': cnt.ms_psd,
-            'launches_per_sweep': 6,
+            'launches_per_sweep': 7,
             'note': 'one sweep on one lane (the pass after the timed region); in the timed '
                     'region only the PSD stage of lane 0 carries events (2 per sweep)'},
         'counters': {'n_subbeam_gates': n_sbg, 'n_valid_items': n_valid,
-                     'n_work_units': int(cnt.n_work_units),
+                     'n_work_units': int(cnt.n_work_units), 'n_table_items': int(cnt.n_table_items),
                      'sweep_algorithmic_bytes': sweep_bytes,
                      'sweep_algorithmic_GBs': sweep_bytes * world / (elapsed / args.steps) / 1e9},
         'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
@@ -377,6 +404,43 @@ def run_c2(env):
     if world == 1:
         out['d2h_GBs'] = d2h_bytes * args.steps / elapsed / 1e9
     return out
+
+
+def roofline_lookup(workload, cnt, psd_bytes, iso, n_fields_read):
+    """The PSD x table stage when the integral tables take the items (k_psd_lookup): a gather of
+    `n_fields_read` x 11 float64 coefficients per item from the (slice, lambda-panel) block of the
+    item, three parameters and the key, 12 float64 results written -- bandwidth / latency bound,
+    no arithmetic to speak of.  achieved = those bytes over the live stage time; the blocks are shared
+    by neighbouring gates, so most of it is served by L2 (traffic = HBM bytes of the PMC pass)."""
+    prof, prof_path = load_profile_summary(workload)
+    traffic = prof_us = None
+    if prof:
+        for name, c in prof.items():
+            if 'k_psd_lookup' in name:
+                traffic, prof_us = c.get('hbm_bytes'), c.get('avg_us')
+    n_tab = int(cnt.n_table_items)
+    per_item = n_fields_read * 11 * 8 + 3 * 8 + 4 + 12 * 8
+    gather = n_tab * per_item
+    t = cnt.ms_psd * 1e-3 if cnt.ms_psd > 0 else None
+    r = {'kernel': 'k_psd_lookup (+ the integrating kernels for the %d items outside the tables)'
+                   % (int(cnt.n_valid_items) - n_tab),
+         'bound': 'hbm', 'achieved': gather / t / 1e9 if t else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+         'frac': gather / t / 1e9 / HBM_PEAK_GBS if t else None,
+         'traffic': traffic, 'traffic_source': prof_path,
+         'bytes_per_item': per_item, 'n_table_items': n_tab, 'n_valid_items': int(cnt.n_valid_items),
+         'avg_stage_ms': cnt.ms_psd, 'profile_avg_us': prof_us,
+         'hbm_physical_frac': (traffic / t / 1e9 / HBM_PEAK_GBS) if (t and traffic) else None,
+         'hbm_alg_frac': (psd_bytes / t / 1e9 / HBM_PEAK_GBS) if t else None,
+         'algorithmic_bytes_per_launch': psd_bytes,
+         'note': 'achieved = bytes this implementation gathers per launch (coefficients + parameters + '
+                 'results) / live HIP-event time of the PSD stage; hbm_alg_frac = the survey\'s B_alg '
+                 '(N_valid x 49152 B, what the reference algorithm reads) over the same time: far above 1 '
+                 'because the 1024-bin integration is replaced by a table of its result; the stage is '
+                 'latency-bound at this size (one sweep = 180 k threads)'}
+    if iso is not None and iso.ms_psd > 0:
+        r['isolated'] = {'avg_stage_ms': iso.ms_psd, 'frac': gather / (iso.ms_psd * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'note': 'same sweep with one lane only (no overlap with other sweeps)'}
+    return r
 
 
 def roofline(workload, kernel, ms_stage, n_valid, psd_bytes, ms_isolated=None, valu_scale=1.0):
@@ -561,14 +625,16 @@ def run_c4(env):
     scale = 1.0
     if prof and prof.get('_meta', {}).get('n_valid_items_per_volume'):
         scale = busiest['n_valid_items'] / float(prof['_meta']['n_valid_items_per_volume'])
-    roof = roofline('c4', ['k_psd_melting<false>', 'k_psd<2, false>', 'k_psd_uniform<false>'],
+    roof = roofline('c4', ['k_psd_melting_tab<false>', 'k_psd_lookup', 'k_psd_ice2<false>', 'k_psd_uniform<false>'],
                     busiest['psd_stage_ms_per_sweep_isolated'], busiest['n_valid_items'] // n_el,
                     busiest['n_valid_items'] // n_el * LUT_SLICE_BYTES, valu_scale=scale)
     roof['stage_ms_with_lanes_in_flight'] = max(ms_psd) if ms_psd else None
-    roof['note'] += ('; c4: the PSD stage = three kernel flavours back to back (melting, ice, recurrence); '
-                     'avg_stage_ms = mean over the 5 sweeps of the busiest rank, one lane at a time (the pass '
-                     'after the timed region); the instruction count is the sum of the three kernels\' '
-                     'per-launch means of the N = 1 profile scaled by this rank\'s share of the valid items')
+    roof['note'] += ('; c4: the PSD stage = k_psd_lookup (snow, graupel, ice from the integral tables) + '
+                     'k_psd_melting_tab (melting species: the dominant, f64-VALU bound kernel) + the integrating '
+                     'kernels for the few items outside the tables; avg_stage_ms = mean over the 5 sweeps of the '
+                     'busiest rank, one lane at a time (the pass after the timed region); the instruction count is '
+                     'the sum of those kernels\' per-launch means of the N = 1 profile scaled by this rank\'s share '
+                     'of the valid items')
     return {
         'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -172,7 +172,7 @@ int build_itabs(cpol_ctx *ctx)
 {
     if (ctx->parent) return CPOL_OK;                      // lanes copy the parent's tables
     if (ctx->itab_serial == ctx->stage_serial) return CPOL_OK;
-    static const bool enabled = !(getenv("CPOL_ITAB") && atoi(getenv("CPOL_ITAB")) == 0);
+    const bool enabled = !(getenv("CPOL_ITAB") && atoi(getenv("CPOL_ITAB")) == 0);   // read at every (re)build
     ctx->its = ItabSet{};
     ctx->itab_serial = ctx->stage_serial;
     if (!enabled) return CPOL_OK;

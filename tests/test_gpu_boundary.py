@@ -173,3 +173,30 @@ def test_ice_units_outside_the_lambda_tables_are_summed_directly():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert '4 passed' in out.stdout
+
+
+def test_integral_tables_take_the_items_and_the_integrating_kernels_stay_pinned():
+    """Default: items of the gamma-family species and of 1-moment ice are finished from the integral
+    tables (k_psd_lookup; cpol_counters_t.n_table_items).  CPOL_ITAB=0 integrates every item over
+    its 1024 diameter bins -- the kernels that also evaluate the table nodes at staging time: the
+    whole reference-pinned parity module must hold in that mode too (one child pytest process)."""
+    import os
+    import subprocess
+    import sys
+    op, _, _, _ = _op('c3_melt_ice')
+    az = np.arange(0., 360., 30.)
+    op.simulate_rays(az, np.full(len(az), 4.0))
+    c = op._ctx.counters()
+    assert 0 < c.n_table_items < c.n_valid_items          # melting species are not tabulated
+    op.close()
+    op, _, _, _ = _op('c2_rsg')
+    op.simulate_rays(az, np.full(len(az), 4.0))
+    c = op._ctx.counters()
+    assert c.n_table_items == c.n_valid_items > 0 and c.n_work_units == 0
+    op.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CPOL_ITAB='0')
+    cmd = [sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-m', 'gpu', '-q', '-x']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1100, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert ' passed' in out.stdout and 'failed' not in out.stdout
