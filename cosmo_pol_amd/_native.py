@@ -97,7 +97,7 @@ class Counters(C.Structure):
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_fork', 'cpol_last_error', 'cpol_set_stream',
            'cpol_get_stream',
            'cpol_synchronize', 'cpol_stage_model', 'cpol_stage_hydro', 'cpol_set_num_hydro',
-           'cpol_stage_doppler_weights', 'cpol_stage_spectrum_tables', 'cpol_stage_t_function',
+           'cpol_stage_doppler_weights', 'cpol_stage_spectrum_tables', 'cpol_stage_t_function', 'cpol_prepare',
            'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
            'cpol_spaceborne_first_gate', 'cpol_host_alloc', 'cpol_host_free',
            'cpol_enable_timing', 'cpol_debug_read', 'cpol_debug_math']
@@ -169,6 +169,8 @@ def load_library():
     lib.cpol_stage_spectrum_tables.argtypes = [vp, C.c_int, vp, vp]
     lib.cpol_debug_math.restype = C.c_int
     lib.cpol_debug_math.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    lib.cpol_prepare.restype = C.c_int
+    lib.cpol_prepare.argtypes = [vp]
     lib.cpol_stage_t_function.restype = C.c_int
     lib.cpol_stage_t_function.argtypes = [vp, C.c_int, vp]
     lib.cpol_host_alloc.restype = C.c_int
@@ -307,6 +309,10 @@ class Context(object):
             raise ValueError('t-function table must have %d entries' % TFUN_COUNT)
         self._check(self.lib.cpol_stage_t_function(self.h, int(which), _ptr(table)),
                     'cpol_stage_t_function')
+
+    def prepare(self):
+        """Builds the integral tables now (otherwise: at the first sweep / fork)."""
+        self._check(self.lib.cpol_prepare(self.h), 'cpol_prepare')
 
     def set_num_hydro(self, n):
         self._check(self.lib.cpol_set_num_hydro(self.h, n), 'cpol_set_num_hydro')

@@ -693,6 +693,15 @@ int cpol_stage_t_function(cpol_ctx *ctx, int which, const float *table)
     return CPOL_OK;
 }
 
+int cpol_prepare(cpol_ctx *ctx)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    if (ctx->parent) return CPOL_OK;
+    for (int j = 0; j < ctx->hs.n_hydro; ++j)
+        if (!ctx->hydro_staged[j]) { ctx->err = "cpol_prepare: hydrometeor slot not staged"; return CPOL_ERR_ARG; }
+    return build_itabs(ctx);
+}
+
 int cpol_stage_doppler_weights(cpol_ctx *ctx, int slot, const double *weights)
 {
     if (!ctx || !weights || slot < 0 || slot >= CPOL_MAX_HYDRO || !ctx->hydro_staged[slot]) {

@@ -237,6 +237,7 @@ class RadarOperator(object):
                 if st is not None:
                     self._ctx.stage_spectrum_tables(slot, *st)
             self._ctx.set_num_hydro(len(hl))
+            self._ctx.prepare()                  # integral tables of this table set (cpol_prepare)
             self._staged_hydro = hl
             if self._model_staged and self._staged_vars != hyd.variable_list(conf):
                 self._stage_model()
@@ -271,6 +272,7 @@ class RadarOperator(object):
         if len(cache) < 4:                       # a few table sets at most (host memory)
             cache[key] = (lut, built)
         self._ctx.set_num_hydro(len(hl))
+        self._ctx.prepare()                      # integral tables of this table set (cpol_prepare)
         self._staged_hydro = hl
         if self._model_staged and self._staged_vars != hyd.variable_list(conf):
             self._stage_model()                 # variable set changed (1mom <-> 2mom)

@@ -287,6 +287,18 @@ int  cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc,
                       const double *table, const double *pre, const double *dnu,
                       const double *aux, int n_aux);
 int  cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro);
+/* Finishes staging: builds the INTEGRAL TABLES now instead of at the first sweep / cpol_fork.
+ * For every species whose N(D) has one per-item shape parameter lambda (all gamma-family species,
+ * 1-moment ice) the 12 PSD-integrated entries of an item -- what get_N + lookup_line + einsum
+ * (hydrometeors.py:128-147, lut.py:309-344, doppler_scatter.py:246-251) produce -- are a per-item
+ * scale times a function of (LUT slice, lambda) only.  The integrating kernels evaluate that
+ * function once per (slice, 1/8-octave panel of lambda, Chebyshev node) and store degree-10
+ * polynomials (< 5e-15 relative); a sweep then gathers 12 x 11 coefficients per item instead of
+ * integrating 1024 diameter bins.  Items whose lambda lies outside the tabulated range, and the
+ * melting species (two parameters), are integrated as before.  Environment CPOL_ITAB=0 (read
+ * at every build) switches the tables off.  Depends on every staged table: call after the last
+ * cpol_stage_* (any later staging call invalidates the tables; they are rebuilt on demand). */
+int  cpol_prepare(cpol_ctx *ctx);
 
 /* float32 functions of the gate temperature, TABULATED BY THE HOST over every float32 value
  * in [128 K, 512 K) (2^24 consecutive bit patterns from CPOL_TFUN_FIRST_BITS).  The reference
