@@ -362,7 +362,7 @@ def run_c2(env):
             op2.close()
         finally:
             del os.environ['CPOL_ITAB']
-        roof['integrating_kernel'] = roofline('c2', 'k_psd_uniform<false>', c2.ms_psd, int(c2.n_valid_items),
+        roof['integrating_kernel'] = roofline('c2_direct', 'k_psd_uniform<false>', c2.ms_psd, int(c2.n_valid_items),
                                               int(c2.n_valid_items) * LUT_SLICE_BYTES)
         roof['integrating_kernel']['sweep_device_total_ms'] = c2.ms_total
         roof['integrating_kernel']['note'] = (
