@@ -63,7 +63,9 @@ struct cpol_ctx {
         d_aux[CPOL_MAX_HYDRO], d_rcsw[CPOL_MAX_HYDRO], d_rcs32[CPOL_MAX_HYDRO], d_dgrid[CPOL_MAX_HYDRO];
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
     // integral tables (built on the device by build_itabs after staging; lanes share the parent's)
-    DevBuf d_itab[CPOL_MAX_HYDRO], d_itab_M;
+    DevBuf d_itab[CPOL_MAX_HYDRO], d_itab_head[CPOL_MAX_HYDRO], d_itab_M;
+    double itab_check_at[CPOL_MAX_HYDRO] = {};
+    double itab_check[CPOL_MAX_HYDRO] = {};     // melting species: worst deviation at the check points (-1: table rejected)
     ItabSet its{};
     uint64_t itab_serial = ~0ull;      // stage_serial the tables were built for
     DevBuf d_tfun[CPOL_N_TFUN];        // host-tabulated float32 functions of T (cpol_stage_t_function)
@@ -201,13 +203,15 @@ int build_itabs(cpol_ctx *ctx)
         if (rc != CPOL_OK) return rc;
         HIPCHK(hipStreamSynchronize(st));
     }
+    const bool melt_enabled = !(getenv("CPOL_ITAB_MELT") && atoi(getenv("CPOL_ITAB_MELT")) == 0);
     const bool dop2 = [&] { for (int j = 0; j < n_hyd; ++j) if (!ctx->hs.h[j].rcsw) return false; return n_hyd > 0; }();
     for (int j = 0; j < n_hyd; ++j) {
         const HydroDev &h = ctx->hs.h[j];
         const cpol_hydro_desc &d = h.d;
         const bool gamma = d.psd_family == CPOL_PSD_GAMMA && h.pre && h.dnu;
         const bool ice = d.psd_family == CPOL_PSD_ICE_FIELD && d.uniform_grid && d.tab_degree == CPOL_ICE_DEGREE;
-        if (!gamma && !ice) continue;
+        const bool melt = d.psd_family == CPOL_PSD_MELTING && melt_enabled;
+        if (!gamma && !ice && !melt) continue;
         // lambda range: 2^-10 .. the lambda at which exp(-lambda D_0^nu) leaves the double range
         // (gamma), resp. the end of the ice normalisation tables
         double d0 = 0.0, lo = -10.0, hi = 15.0;
@@ -218,22 +222,44 @@ int build_itabs(cpol_ctx *ctx)
             if (hi > 16.0) hi = 16.0;
             if (hi <= lo) continue;
         }
-        const int n_pan = (int)(hi - lo) * CPOL_ITAB_PPO;
+        if (melt) {
+            // slope of the rain partner, lambda_r = (factor / QM)^(1/(4+mu)): 2^-1 (QM = 0.05 kg m-3) ..
+            // 2^6.5 (1e-11); items beyond are integrated
+            lo = -1.0; hi = 6.5;
+        }
+        const int ppo = melt ? CPOL_ITAB2_PPO : CPOL_ITAB_PPO;
+        const int n_pan = (int)((hi - lo) * ppo);
         const int n_slices = d.n_e * d.n_t;
-        const long n_items = (long)n_slices * n_pan * NC;
-        const int unit_items = ((gamma && d.uniform_grid) || ice) ? 128 : 64;
-        const int upers = (n_pan * NC + unit_items - 1) / unit_items;
+        const int per_block = melt ? CPOL_ITAB2_NODES : NC;
+        const long n_items = (long)n_slices * n_pan * per_block;
+        const bool melt_tab = melt && d.tab_degree == CPOL_MELT_DEGREE;
+        const int unit_items = ((gamma && d.uniform_grid) || ice || melt_tab) ? 128 : 64;
+        const int upers = (n_pan * per_block + unit_items - 1) / unit_items;
         const long n_units = (long)n_slices * upers;
         if (n_items >= (1L << 31)) continue;
+        const size_t tab_bytes = (size_t)n_slices * n_pan * (melt ? CPOL_ITAB2_NB : NC) * CPOL_ITAB_NFP * sizeof(double);
         DevBuf b_par, b_perm, b_units, b_tot, b_res, b_vn;
         int rc;
+        if (melt) {
+            // centre and 1 / half-width of the wet-fraction bins of the table's second axis; bin 0
+            // reaches down to fw = 0 and the last bin up to 1 (lut.py:336-341 clips the index)
+            std::vector<double> head(2 * (size_t)d.n_t);
+            for (int b = 0; b < d.n_t; ++b) {
+                const double blo = b == 0 ? 0.0 : (double)d.t_lo + b * (double)d.t_step;
+                const double bhi = b == d.n_t - 1 ? 1.0 : (double)d.t_lo + (b + 1) * (double)d.t_step;
+                head[2 * b] = 0.5 * (blo + bhi);
+                head[2 * b + 1] = 1.0 / (0.5 * (bhi - blo));
+            }
+            if ((rc = upload(ctx, ctx->d_itab_head[j], head.data(), head.size() * sizeof(double)))) return rc;
+            HIPCHK(hipStreamSynchronize(st));
+        }
         if ((rc = ensure(ctx, b_par, (size_t)CPOL_MAX_PAR * n_items * sizeof(double))) ||
             (rc = ensure(ctx, b_perm, (size_t)n_items * sizeof(int))) ||
             (rc = ensure(ctx, b_units, (size_t)n_units * sizeof(WorkUnit))) ||
             (rc = ensure(ctx, b_tot, 4 * sizeof(long long))) ||
             (rc = ensure(ctx, b_res, (size_t)n_items * CPOL_N_SZ * sizeof(double))) ||
             (rc = ensure(ctx, b_vn, (size_t)n_items * 2 * sizeof(double))) ||
-            (rc = ensure(ctx, ctx->d_itab[j], (size_t)n_slices * n_pan * CPOL_ITAB_NF * NC * sizeof(double)))) {
+            (rc = ensure(ctx, ctx->d_itab[j], tab_bytes))) {
             free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn);
             return rc;
         }
@@ -241,7 +267,8 @@ int build_itabs(cpol_ctx *ctx)
         ItabBuildArgs ba{};
         ba.par = (double *)b_par.p; ba.perm = (int *)b_perm.p; ba.units = (WorkUnit *)b_units.p;
         ba.totals = (long long *)b_tot.p; ba.n_items = n_items; ba.n_slices = n_slices; ba.n_pan = n_pan;
-        ba.key_base = h.key_base; ba.unit_items = unit_items; ba.log2_lo = lo;
+        ba.key_base = h.key_base; ba.unit_items = unit_items; ba.log2_lo = lo; ba.ppo = ppo;
+        ba.two_d = melt ? 1 : 0; ba.n_t = d.n_t; ba.head = (const double *)ctx->d_itab_head[j].p;
         hipLaunchKernelGGL(k_itab_nodes, dim3(cdiv(n_items > n_units ? n_items : n_units, 256)), dim3(256), 0, st, ba);
         // the slot's own kernels on the synthetic items (arrays of THIS slot only: the kernels
         // index [n_hydro][...][n] arrays with the slot number, hence the shifted bases)
@@ -257,7 +284,15 @@ int build_itabs(cpol_ctx *ctx)
         pa.clk = nullptr;
         pa.ice_force_sum = 0;
         const dim3 grd((unsigned)(n_units < 4096 ? n_units : 4096)), blk(CPOL_PSD_THREADS);
-        if (ice) {
+        if (melt) {
+            if (melt_tab) {
+                if (dop2) hipLaunchKernelGGL((k_psd_melting_tab<true>), grd, blk, 0, st, ctx->hs, pa);
+                else hipLaunchKernelGGL((k_psd_melting_tab<false>), grd, blk, 0, st, ctx->hs, pa);
+            } else {
+                if (dop2) hipLaunchKernelGGL((k_psd<PSD_MODE_MELTING, true>), grd, blk, 0, st, ctx->hs, pa);
+                else hipLaunchKernelGGL((k_psd<PSD_MODE_MELTING, false>), grd, blk, 0, st, ctx->hs, pa);
+            }
+        } else if (ice) {
             if (dop2) { hipLaunchKernelGGL((k_psd_ice2<true>), grd, blk, 0, st, ctx->hs, pa);
                         hipLaunchKernelGGL((k_psd<PSD_MODE_ICE, true>), grd, blk, 0, st, ctx->hs, pa); }
             else { hipLaunchKernelGGL((k_psd_ice2<false>), grd, blk, 0, st, ctx->hs, pa);
@@ -269,23 +304,55 @@ int build_itabs(cpol_ctx *ctx)
             if (dop2) hipLaunchKernelGGL((k_psd<PSD_MODE_GAMMA_EXP, true>), grd, blk, 0, st, ctx->hs, pa);
             else hipLaunchKernelGGL((k_psd<PSD_MODE_GAMMA_EXP, false>), grd, blk, 0, st, ctx->hs, pa);
         }
-        ItabFitArgs fa{};
-        fa.res = (const double *)b_res.p; fa.vn = (const double *)b_vn.p; fa.par = (const double *)b_par.p;
-        fa.M = (const double *)ctx->d_itab_M.p; fa.tab = (double *)ctx->d_itab[j].p;
-        fa.n_items = n_items; fa.n_slices = n_slices; fa.n_pan = n_pan; fa.log2_lo = lo; fa.d0 = gamma ? d0 : 0.0;
-        hipLaunchKernelGGL(k_itab_fit, dim3(cdiv((long)n_slices * n_pan * CPOL_ITAB_NF, 256)), dim3(256), 0, st, fa);
+        double worst = 0.0;
+        unsigned long long worst_bits = 0;
+        if (melt) {
+            ItabFit2Args fa{};
+            fa.res = (const double *)b_res.p; fa.vn = (const double *)b_vn.p;
+            fa.M = (const double *)ctx->d_itab_M.p; fa.tab = (double *)ctx->d_itab[j].p;
+            fa.n_blocks = (long)n_slices * n_pan;
+            fa.worst = (unsigned long long *)b_tot.p + 3;
+            HIPCHK(hipMemsetAsync(fa.worst, 0, sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(k_itab_fit2, dim3(cdiv(fa.n_blocks * CPOL_ITAB_NFP * NC, 256)), dim3(256), 0, st, fa);
+            hipLaunchKernelGGL(k_itab_check2, dim3(cdiv(fa.n_blocks * (CPOL_N_SZ + 2), 256)), dim3(256), 0, st, fa);
+            HIPCHK(hipMemcpyAsync(&worst_bits, fa.worst, sizeof worst_bits, hipMemcpyDeviceToHost, st));
+        } else {
+            ItabFitArgs fa{};
+            fa.res = (const double *)b_res.p; fa.vn = (const double *)b_vn.p; fa.par = (const double *)b_par.p;
+            fa.M = (const double *)ctx->d_itab_M.p; fa.tab = (double *)ctx->d_itab[j].p;
+            fa.n_items = n_items; fa.n_slices = n_slices; fa.n_pan = n_pan; fa.log2_lo = lo; fa.d0 = gamma ? d0 : 0.0;
+            hipLaunchKernelGGL(k_itab_fit, dim3(cdiv((long)n_slices * n_pan * CPOL_ITAB_NF, 256)), dim3(256), 0, st, fa);
+        }
         const hipError_t e = hipStreamSynchronize(st);
         free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn);
         if (e != hipSuccess || hipGetLastError() != hipSuccess) {
             ctx->err = "build_itabs: a kernel failed";
             return CPOL_ERR_HIP;
         }
+        if (melt) {
+            const unsigned long long eb = worst_bits & ~0xFFFFFFull;
+            memcpy(&worst, &eb, sizeof worst);
+            ctx->itab_check_at[j] = (double)(worst_bits & 0xFFFFFFull);      // (block x 14 + function) mod 2^24
+        }
+        ctx->itab_check[j] = worst;
+        if (melt && !(worst < CPOL_ITAB2_MAX_DEVIATION)) {
+            // the polynomial does not reproduce the integrating kernel between the nodes (wet-fraction
+            // bins too wide for the degree: coarse test tables): this species stays on the integrating path
+            ctx->itab_check[j] = -worst;
+            free_buf(ctx->d_itab[j]);
+            continue;
+        }
         ItabDev &t = ctx->its.t[j];
         t.tab = (const double *)ctx->d_itab[j].p;
+        t.head = melt ? (const double *)ctx->d_itab_head[j].p : nullptr;
         t.log2_lo = lo;
         t.d0 = gamma ? d0 : 0.0;
         t.n_pan = n_pan;
-        t.writes_vn = ice || dop2 || d.numeric_intv;
+        t.writes_vn = ice || dop2 || d.numeric_intv || melt;
+        t.ppo = ppo;
+        t.two_d = melt ? 1 : 0;
+        t.par_slot = melt ? 2 : 0;
+        t.n_t = d.n_t;
     }
     return CPOL_OK;
 }
@@ -337,11 +404,13 @@ void cpol_destroy(cpol_ctx *ctx)
         }
         for (auto &b : ctx->d_tfun) b = DevBuf();
         for (auto &b : ctx->d_itab) b = DevBuf();
+        for (auto &b : ctx->d_itab_head) b = DevBuf();
         ctx->d_itab_M = DevBuf();
         ctx->parent->n_children -= 1;
     }
     for (auto &b : ctx->d_tfun) free_buf(b);
     for (auto &b : ctx->d_itab) free_buf(b);
+    for (auto &b : ctx->d_itab_head) free_buf(b);
     free_buf(ctx->d_itab_M);
     for (int i = 0; i < 3; ++i) {
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
@@ -1163,7 +1232,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             la.res = (double *)ctx->b_res.p;
             la.vn = doppler ? (double *)ctx->b_vn.p : nullptr;
             la.n_sbg = n_sbg;
-            hipLaunchKernelGGL(k_psd_lookup, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st, ctx->hs, ctx->its, la);
+            hipLaunchKernelGGL(k_psd_lookup, dim3(cdiv(n_sbg, CPOL_LOOKUP_THREADS)), dim3(CPOL_LOOKUP_THREADS), 0, st, ctx->hs, ctx->its, la);
         }
     }
 
@@ -1557,6 +1626,18 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     if (!ctx || !name) return CPOL_ERR_ARG;
     if (!strcmp(name, "enable")) { ctx->keep_debug = true; return 0; }
     if (!strcmp(name, "disable")) { ctx->keep_debug = false; return 0; }
+    if (!strcmp(name, "itab_check")) {
+        // per hydrometeor slot: worst |polynomial - integrating kernel| / |value| over the check points
+        // of its 2-D integral table (melting species); negative: table rejected; 0: no such table
+        const cpol_ctx *own = ctx->parent ? ctx->parent : ctx;
+        if (!dst || max_bytes < (int64_t)sizeof own->itab_check) return CPOL_ERR_ARG;
+        memcpy(dst, own->itab_check, sizeof own->itab_check);
+        if (max_bytes >= 2 * (int64_t)sizeof own->itab_check) {
+            memcpy((char *)dst + sizeof own->itab_check, own->itab_check_at, sizeof own->itab_check_at);
+            return 2 * (int64_t)sizeof own->itab_check;
+        }
+        return (int64_t)sizeof own->itab_check;
+    }
     if (!dst || ctx->last_n_sbg <= 0) return CPOL_ERR_ARG;
     const long n_sbg = ctx->last_n_sbg, n_rg = ctx->last_n_rg;
     const int n_hyd = ctx->hs.n_hydro, n_vars = ctx->model.n_vars;

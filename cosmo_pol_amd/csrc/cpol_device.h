@@ -69,13 +69,34 @@ struct SpecSet {
 #define CPOL_ITAB_DEGREE 10
 #define CPOL_ITAB_NC     (CPOL_ITAB_DEGREE + 1)
 #define CPOL_ITAB_NF     15      // 12 columns, 2 Doppler sums (v, n), ice: normalised N0 (Doppler spectrum)
+#define CPOL_ITAB_NFP    16      // functions per coefficient row (padded: one row = 128 B)
 #define CPOL_ITAB_PPO    8       // panels per octave of lambda
+// Melting species: N(D) has TWO per-item parameters, the wet fraction fw (which also selects the
+// LUT slice, floor bin of the table's second axis) and the slope lambda_r of the rain partner, and
+// every integrated entry is  QM x F_c(slice, fw, lambda_r)  (the normalisation by the mass
+// integral makes F_c a ratio of two sums over the bins, a very smooth function).  F_c is stored
+// per (slice, 1/4-octave panel of lambda_r) as a degree-10 x degree-10 polynomial in (position of
+// fw inside the slice's wet-fraction bin, position inside the panel): 121 rows of 128 B.
+#define CPOL_ITAB2_PPO   4
+#define CPOL_ITAB2_NB    (CPOL_ITAB_NC * CPOL_ITAB_NC)           // coefficient rows per block
+#define CPOL_ITAB2_NODES (CPOL_ITAB2_NB + 1)                      // build items per block: the nodes + 1 check point
+#define CPOL_ITAB2_CHECK_U 0.37
+#define CPOL_ITAB2_CHECK_W (-0.61)
+#define CPOL_ITAB2_MAX_DEVIATION 1e-10   // accepted |polynomial - integrating kernel| / |value| at the check points (measured on
+                                         // the full-size tables: 1.7e-12, in a column that nearly cancels at 88 deg elevation)
 struct ItabDev {
-    const double *tab;     // [n_slices][n_pan][CPOL_ITAB_NF][CPOL_ITAB_NC] monomial coefficients, or NULL
+    const double *tab;     // 1-D: [n_slices][n_pan][CPOL_ITAB_NC][CPOL_ITAB_NFP] monomial coefficients (power-major:
+                           //   one 128-B row holds the coefficient of u^q of all functions), or NULL
+                           // 2-D: [n_slices][n_pan][NC (power of w, lambda)][NC (power of u, fw)][CPOL_ITAB_NFP]
+    const double *head;    // 2-D: [n_t][2] centre and 1 / half-width of the wet-fraction bins
     double log2_lo;        // lambda of panel 0, node u = -1:  2^log2_lo
     double d0;             // gamma family: the tabulated function is exp(+lambda d0) x integral (d0 = D_0^nu)
     int n_pan;
     int writes_vn;         // the direct kernels of this slot write vn (Doppler scheme 2, numeric integrate_V, ice)
+    int ppo;               // panels per octave
+    int two_d;             // melting species (2-D blocks)
+    int par_slot;          // parameter slot of the item that holds lambda (0; melting: 2)
+    int n_t;               // 2-D: slices per elevation (= wet-fraction bins)
 };
 
 struct ItabSet {

@@ -437,7 +437,8 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
         bool lookup = false;
         if (valid && its.t[j].tab) {
             const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
-            const double pf = (cp_log(P[0]) * 1.4426950408889634 - its.t[j].log2_lo) * (double)CPOL_ITAB_PPO;
+            const double pf = (cp_log(P[its.t[j].par_slot * n]) * 1.4426950408889634 - its.t[j].log2_lo)
+                              * (double)its.t[j].ppo;
             lookup = pf >= 0.0 && pf < (double)its.t[j].n_pan;                   // NaN -> false
             a.par[((long)j * CPOL_MAX_PAR + 4) * n + i] = lookup ? pf : -1.0;
             my_lookup += lookup ? 1 : 0;
@@ -1450,6 +1451,7 @@ __device__ __forceinline__ double itab_node_lambda(double log2_lo, int p, int q)
 }
 
 // synthetic "items" of one hydrometeor slot: one per (slice, panel, node), with N0 = QM = 1
+// (melting species: per (slice, panel) the 11 x 11 nodes in (lambda_r, fw) and one check point)
 struct ItabBuildArgs {
     double *par;               // [CPOL_MAX_PAR][n_items] of THIS slot
     int *perm;                 // identity
@@ -1458,12 +1460,21 @@ struct ItabBuildArgs {
     long n_items;
     int n_slices, n_pan, key_base, unit_items;
     double log2_lo;
+    int ppo;
+    int two_d, n_t;            // melting species
+    const double *head;        // [n_t][2]
 };
+
+__device__ __forceinline__ double cheb_node(int q)
+{
+    return cos(3.14159265358979323846 * ((double)q + 0.5) / (double)CPOL_ITAB_NC);
+}
 
 __global__ void k_itab_nodes(ItabBuildArgs b)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int per_slice = b.n_pan * CPOL_ITAB_NC;
+    const int per_block = b.two_d ? CPOL_ITAB2_NODES : CPOL_ITAB_NC;
+    const int per_slice = b.n_pan * per_block;
     const int upers = (per_slice + b.unit_items - 1) / b.unit_items;
     if (i == 0) { b.totals[0] = b.n_items; b.totals[1] = (long long)b.n_slices * upers; b.totals[2] = 0; }
     if (i < (long)b.n_slices * upers) {
@@ -1478,6 +1489,18 @@ __global__ void k_itab_nodes(ItabBuildArgs b)
     if (i >= b.n_items) return;
     const int r = (int)(i % per_slice);
     b.perm[i] = (int)i;
+    if (b.two_d) {
+        const int s = (int)(i / per_slice), tb = s % b.n_t;
+        const int p = r / per_block, node = r % per_block;
+        const bool chk = node == CPOL_ITAB2_NB;
+        const double xw = chk ? CPOL_ITAB2_CHECK_W : cheb_node(node / CPOL_ITAB_NC);
+        const double xu = chk ? CPOL_ITAB2_CHECK_U : cheb_node(node % CPOL_ITAB_NC);
+        b.par[i] = 1.0;                                                        // QM
+        b.par[b.n_items + i] = b.head[2 * tb] + xu / b.head[2 * tb + 1];       // fw
+        b.par[2 * b.n_items + i] = exp2(b.log2_lo + ((double)p + (xw + 1.0) * 0.5) / (double)b.ppo);
+        b.par[3 * b.n_items + i] = 0.0;
+        return;
+    }
     b.par[i] = itab_node_lambda(b.log2_lo, r / CPOL_ITAB_NC, r % CPOL_ITAB_NC);
     b.par[b.n_items + i] = 1.0;             // N0
     b.par[2 * b.n_items + i] = 1.0;         // QM (ice)
@@ -1515,16 +1538,101 @@ __global__ void k_itab_fit(ItabFitArgs f)
         if (f.d0 != 0.0) x *= exp(itab_node_lambda(f.log2_lo, p, q) * f.d0);
         v[q] = x;
     }
-    double *o = f.tab + t * CPOL_ITAB_NC;
+    double *o = f.tab + blk * (CPOL_ITAB_NC * CPOL_ITAB_NFP) + fn;
 #pragma unroll
     for (int pw = 0; pw < CPOL_ITAB_NC; ++pw) {
         double c = 0.0;
 #pragma unroll
         for (int q = 0; q < CPOL_ITAB_NC; ++q) c = fma(f.M[pw * CPOL_ITAB_NC + q], v[q], c);
-        o[pw] = c;
+        o[pw * CPOL_ITAB_NFP] = c;
+        if (fn == CPOL_ITAB_NF - 1) o[pw * CPOL_ITAB_NFP + 1] = 0.0;     // padding column
     }
 }
 
+// Melting species: node values V[b][a] (b: lambda_r node, a: fw node) of one function of one
+// block -> monomial coefficients C[pb][pa] = sum_b sum_a M[pb][b] M[pa][a] V[b][a].
+// One thread per (block, function, pa).
+struct ItabFit2Args {
+    const double *res;         // [n_items][12]
+    const double *vn;          // [n_items][2]
+    const double *M;           // [NC][NC]
+    double *tab;               // [n_blocks][NC][NC][NFP]
+    long n_blocks;
+    unsigned long long *worst; // check kernel: bits of the worst relative deviation at the check points
+};
+
+__global__ void k_itab_fit2(ItabFit2Args f)
+{
+    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= f.n_blocks * NFP * NC) return;
+    const int pa = (int)(t % NC);
+    const int fn = (int)((t / NC) % NFP);
+    const long blk = t / (NC * NFP);
+    double *o = f.tab + blk * (CPOL_ITAB2_NB * NFP) + (long)pa * NFP + fn;
+    if (fn >= CPOL_N_SZ + 2) {                                            // padding columns
+        for (int pb = 0; pb < NC; ++pb) o[(long)pb * NC * NFP] = 0.0;
+        return;
+    }
+    double tmp[NC];
+#pragma unroll
+    for (int b = 0; b < NC; ++b) {
+        double c = 0.0;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            const long i = blk * CPOL_ITAB2_NODES + b * NC + a;
+            const double v = fn < CPOL_N_SZ ? f.res[i * CPOL_N_SZ + fn] : f.vn[i * 2 + (fn - CPOL_N_SZ)];
+            c = fma(f.M[pa * NC + a], v, c);
+        }
+        tmp[b] = c;
+    }
+#pragma unroll
+    for (int pb = 0; pb < NC; ++pb) {
+        double c = 0.0;
+#pragma unroll
+        for (int b = 0; b < NC; ++b) c = fma(f.M[pb * NC + b], tmp[b], c);
+        o[(long)pb * NC * NFP] = c;
+    }
+}
+
+// value of function fn of a 2-D block at (u, w)
+__device__ __forceinline__ double itab2_eval(const double *blk, int fn, double u, double w)
+{
+    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
+    double outer = 0.0;
+    for (int pb = NC - 1; pb >= 0; --pb) {
+        double inner = 0.0;
+        for (int pa = NC - 1; pa >= 0; --pa) inner = fma(inner, u, blk[((long)pb * NC + pa) * NFP + fn]);
+        outer = fma(outer, w, inner);
+    }
+    return outer;
+}
+
+// the fitted polynomial against the integrating kernel at the check point of every block
+__global__ void k_itab_check2(ItabFit2Args f)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= f.n_blocks * (CPOL_N_SZ + 2)) return;
+    const int fn = (int)(t % (CPOL_N_SZ + 2));
+    const long blk = t / (CPOL_N_SZ + 2);
+    const long i = blk * CPOL_ITAB2_NODES + CPOL_ITAB2_NB;
+    const double ref = fn < CPOL_N_SZ ? f.res[i * CPOL_N_SZ + fn] : f.vn[i * 2 + (fn - CPOL_N_SZ)];
+    const double got = itab2_eval(f.tab + blk * (CPOL_ITAB2_NB * CPOL_ITAB_NFP), fn, CPOL_ITAB2_CHECK_U, CPOL_ITAB2_CHECK_W);
+    // scale: the function's size over the block (its value at the first node), so that columns
+    // that pass through zero do not raise a false alarm
+    const long i0 = blk * CPOL_ITAB2_NODES;
+    const double at0 = fn < CPOL_N_SZ ? f.res[i0 * CPOL_N_SZ + fn] : f.vn[i0 * 2 + (fn - CPOL_N_SZ)];
+    const double scale = fmax(fabs(ref), fabs(at0));
+    double err = scale > 0.0 ? fabs(got - ref) / scale : 0.0;
+    if (!(err == err) || !(ref == ref)) err = 1.0;                        // NaN
+    // 40 leading bits of the deviation | 24 bits of (block, function): one atomicMax finds both
+    if (err > 0.0)
+        atomicMax(f.worst, ((unsigned long long)__double_as_longlong(err) & ~0xFFFFFFull) | ((unsigned long long)t & 0xFFFFFFull));
+}
+
+#ifndef CPOL_LOOKUP_THREADS
+#define CPOL_LOOKUP_THREADS 256
+#endif
 // one thread per sub-beam gate: the items that k_classify placed on an integral table
 struct LookupArgs {
     const int *key;             // [n_hydro][n_sbg]
@@ -1535,43 +1643,141 @@ struct LookupArgs {
     long n_sbg;
 };
 
-__global__ __launch_bounds__(256) void k_psd_lookup(HydroSet hs, ItabSet its, LookupArgs a)
+__device__ __forceinline__ double readlane_f64(double v, int src_uniform)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_sbg) return;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_uniform);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_uniform);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int m)
+{
+    const int lo = __shfl_xor(__double2loint(v), m), hi = __shfl_xor(__double2hiint(v), m);
+    return __hiloint2double(hi, lo);
+}
+
+// 2-D block: the part of  sum_b w^b sum_a C[b][a][f] u^a  that quarter r of the wavefront owns
+// (b = r, r+4, r+8); c points at column f of the block
+__device__ __forceinline__ double itab2_quarter_sum(const double *c, int r, double ui, double wi)
+{
+    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
+    const double w2 = wi * wi, w4 = w2 * w2;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {
+        const int b = r + 4 * k;                                        // power of w of this quarter's row set
+        const double *cb = c + (long)min(b, NC - 1) * NB;
+        double inner = cb[(NC - 1) * NFP];
+#pragma unroll
+        for (int pa = NC - 2; pa >= 0; --pa) inner = fma(inner, ui, cb[pa * NFP]);
+        acc = fma(acc, w4, b < NC ? inner : 0.0);
+    }
+    return acc * ((r & 1 ? wi : 1.0) * (r & 2 ? w2 : 1.0));
+}
+
+// 1-D blocks (gamma family, 1-moment ice).  The coefficient block of an item is addressed by
+// (LUT slice, lambda panel): 11 rows of 128 B, row q = the coefficients of u^q of all functions.
+// Every lane reads the rows of ITS block as 16-B vector loads, all 12 Horner chains of an item
+// advance together, and the loads of a row are independent of the arithmetic, so the compiler
+// keeps whole rows in flight.  Lanes whose gates share a block read the same addresses.
+// Measured alternatives on the bench sweep (195 751 items) / the C4 sweep at 3 degrees (15.1 M):
+//   function-major table, one chain at a time (11 dependent 8-B loads each)   28.8 us / 1.69 ms
+//   walk over the distinct blocks of the wavefront, rows by s_load into SGPRs,
+//     v_fma_f64 with scalar addend (every row misses the scalar cache)        ~100 us / 1.6 ms
+//   the same walk with the block staged in LDS and read back by broadcast      ~43 us / 1.5 ms
+//     (a wavefront of 64 neighbouring gates spans ~7 distinct blocks, so the walk repeats)
+//   this form                                                                  ~23 us / 1.4 ms
+//
+// 2-D blocks (melting species): 121 rows of 128 B per block and neighbouring gates hardly ever
+// share one (the wet fraction crosses a 0.01-wide bin of the table per gate).  One lane per item
+// -- 847 16-B loads per lane, 64 different cache lines per instruction -- took 3.0 ms for the
+// 1.28 M melting items of the C4 sweep.  Here the WAVEFRONT takes the items of its 64 gates one
+// after the other: lane = (quarter r, function f); quarter r sums the rows of the powers
+// w^r, w^(r+4), w^(r+8), each row a full Horner chain in u, every row is read exactly once as one
+// contiguous 128-B line per quarter; two cross-lane adds join the quarters.
+__global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet hs, ItabSet its, LookupArgs a)
+{
+    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i0 < a.n_sbg;
+    const long i = in ? i0 : 0;
     const long n = a.n_sbg;
+    const int lane = lane_id();
     for (int j = 0; j < hs.n_hydro; ++j) {
         const ItabDev &t = its.t[j];
-        if (!t.tab) continue;
-        const int key = a.key[(long)j * n + i];
-        if (key < 0) continue;
+        if (!t.tab) continue;                                           // uniform
+        const int key = in ? a.key[(long)j * n + i] : -1;
         const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
-        const double pf = P[4 * n];
-        if (!(pf >= 0.0)) continue;
+        const double pf = key >= 0 ? P[4 * n] : -1.0;
+        const bool item = pf >= 0.0;                                    // NaN -> false
+        if (t.two_d) {
+            // melting species: QM x F_c(slice, fw, lambda_r), one item of the wavefront at a time
+            int blk = 0;
+            double u = 0.0, w = 0.0, q = 0.0;
+            if (item) {
+                const int pn = min((int)pf, t.n_pan - 1);
+                w = 2.0 * (pf - (double)pn) - 1.0;
+                const int sl = key - hs.h[j].key_base;
+                const int tb = sl % t.n_t;
+                u = (P[n] - t.head[2 * tb]) * t.head[2 * tb + 1];
+                q = P[0];
+                blk = sl * t.n_pan + pn;
+            }
+            unsigned long long todo = __ballot(item);
+            const int f = lane & (NFP - 1), r = lane >> 4;
+            while (todo) {
+                const int l = (int)__ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const double *c = t.tab + (long)__builtin_amdgcn_readlane(blk, l) * (CPOL_ITAB2_NB * NFP) + f;
+                double acc = itab2_quarter_sum(c, r, readlane_f64(u, l), readlane_f64(w, l));
+                acc += shfl_xor_f64(acc, 16);
+                acc += shfl_xor_f64(acc, 32);
+                acc *= readlane_f64(q, l);
+                const long o = (long)j * n + (i0 - lane) + l;
+                if (lane < CPOL_N_SZ) a.res[o * CPOL_N_SZ + lane] = acc;
+                else if (lane < CPOL_N_SZ + 2 && a.vn) a.vn[o * 2 + (lane - CPOL_N_SZ)] = acc;
+            }
+            continue;
+        }
+        if (!item) continue;
+        const cpol_hydro_desc &d = hs.h[j].d;
+        const bool ice = d.psd_family == CPOL_PSD_ICE_FIELD;
         const int pn = min((int)pf, t.n_pan - 1);
         const double u = 2.0 * (pf - (double)pn) - 1.0;
-        const cpol_hydro_desc &d = hs.h[j].d;
-        const double *c = t.tab + ((long)(key - hs.h[j].key_base) * t.n_pan + pn) * (CPOL_ITAB_NF * CPOL_ITAB_NC);
-        const bool ice = d.psd_family == CPOL_PSD_ICE_FIELD;
+        const double2 *c = reinterpret_cast<const double2 *>(
+            t.tab + ((long)(key - hs.h[j].key_base) * t.n_pan + pn) * NB);
         // gamma: N0 x exp(-lambda d0) x G(lambda);  ice: QM x R(lambda)
         const double scale = ice ? P[2 * n] : P[n] * cp_exp(-(P[0] * t.d0));
-        double *o = a.res + ((long)j * n + i) * CPOL_N_SZ;
-        const int nf = (a.vn && t.writes_vn) ? CPOL_N_SZ + 2 : CPOL_N_SZ;
-        for (int f = 0; f < nf; ++f) {
-            const double *cf = c + f * CPOL_ITAB_NC;
-            double v = cf[CPOL_ITAB_NC - 1];
+        const bool want_vn = a.vn && t.writes_vn;                       // uniform
+        const bool want_n0 = ice && a.par_w;                            // uniform
+        double2 v[CPOL_N_SZ / 2];
 #pragma unroll
-            for (int q = CPOL_ITAB_NC - 2; q >= 0; --q) v = fma(v, u, cf[q]);
-            v *= scale;
-            if (f < CPOL_N_SZ) o[f] = v;
-            else a.vn[((long)j * n + i) * 2 + (f - CPOL_N_SZ)] = v;
+        for (int f = 0; f < CPOL_N_SZ / 2; ++f) v[f] = c[(NC - 1) * (NFP / 2) + f];
+#pragma unroll
+        for (int q = NC - 2; q >= 0; --q) {
+#pragma unroll
+            for (int f = 0; f < CPOL_N_SZ / 2; ++f) {
+                const double2 cq = c[q * (NFP / 2) + f];
+                v[f].x = fma(v[f].x, u, cq.x);
+                v[f].y = fma(v[f].y, u, cq.y);
+            }
         }
-        if (ice && a.par_w) {
-            const double *cf = c + (CPOL_N_SZ + 2) * CPOL_ITAB_NC;
-            double v = cf[CPOL_ITAB_NC - 1];
+        double2 *o = reinterpret_cast<double2 *>(a.res + ((long)j * n + i) * CPOL_N_SZ);
 #pragma unroll
-            for (int q = CPOL_ITAB_NC - 2; q >= 0; --q) v = fma(v, u, cf[q]);
-            a.par_w[((long)j * CPOL_MAX_PAR + 3) * n + i] = v * scale;
+        for (int f = 0; f < CPOL_N_SZ / 2; ++f) o[f] = make_double2(v[f].x * scale, v[f].y * scale);
+        if (want_vn || want_n0) {
+            double2 w = c[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
+            double w2 = c[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2 + 1].x;
+#pragma unroll
+            for (int q = NC - 2; q >= 0; --q) {
+                const double2 cq = c[q * (NFP / 2) + CPOL_N_SZ / 2];
+                w.x = fma(w.x, u, cq.x);
+                w.y = fma(w.y, u, cq.y);
+                w2 = fma(w2, u, c[q * (NFP / 2) + CPOL_N_SZ / 2 + 1].x);
+            }
+            if (want_vn)
+                *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = make_double2(w.x * scale, w.y * scale);
+            if (want_n0) a.par_w[((long)j * CPOL_MAX_PAR + 3) * n + i] = w2 * scale;
         }
     }
 }

@@ -176,10 +176,14 @@ def test_ice_units_outside_the_lambda_tables_are_summed_directly():
 
 
 def test_integral_tables_take_the_items_and_the_integrating_kernels_stay_pinned():
-    """Default: items of the gamma-family species and of 1-moment ice are finished from the integral
-    tables (k_psd_lookup; cpol_counters_t.n_table_items).  CPOL_ITAB=0 integrates every item over
-    its 1024 diameter bins -- the kernels that also evaluate the table nodes at staging time: the
-    whole reference-pinned parity module must hold in that mode too (one child pytest process)."""
+    """Default: every item is finished from the integral tables (k_psd_lookup;
+    cpol_counters_t.n_table_items) -- 1-D blocks for the gamma-family species and 1-moment ice,
+    2-D blocks (wet fraction x rain-partner slope) for the melting species, whose fit is verified
+    at build time against the integrating kernel at one off-node point of every block.
+    CPOL_ITAB_MELT=0 keeps the melting species on the integrating kernel, CPOL_ITAB=0 integrates
+    every item over its 1024 diameter bins -- the kernels that also evaluate the table nodes at
+    staging time: the reference-pinned parity module must hold in those modes too (child pytest
+    processes: the switches are read when the tables are built)."""
     import os
     import subprocess
     import sys
@@ -187,7 +191,9 @@ def test_integral_tables_take_the_items_and_the_integrating_kernels_stay_pinned(
     az = np.arange(0., 360., 30.)
     op.simulate_rays(az, np.full(len(az), 4.0))
     c = op._ctx.counters()
-    assert 0 < c.n_table_items < c.n_valid_items          # melting species are not tabulated
+    assert c.n_table_items == c.n_valid_items > 0 and c.n_work_units == 0
+    chk = op._ctx.debug_read('itab_check', (2, 8), np.float64)[0]
+    assert (chk >= 0).all() and ((chk > 0) & (chk < 1e-10)).sum() == 2, chk     # mS, mG accepted
     op.close()
     op, _, _, _ = _op('c2_rsg')
     op.simulate_rays(az, np.full(len(az), 4.0))
@@ -195,8 +201,12 @@ def test_integral_tables_take_the_items_and_the_integrating_kernels_stay_pinned(
     assert c.n_table_items == c.n_valid_items > 0 and c.n_work_units == 0
     op.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CPOL_ITAB='0')
-    cmd = [sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-m', 'gpu', '-q', '-x']
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1100, cwd=root)
+    base = [sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-m', 'gpu', '-q', '-x']
+    out = subprocess.run(base, env=dict(os.environ, CPOL_ITAB='0'), capture_output=True, text=True,
+                         timeout=1100, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert ' passed' in out.stdout and 'failed' not in out.stdout
+    out = subprocess.run(base + ['-k', 'c3_melt_ice or c4_7x7 or q_ml_dop2'], env=dict(os.environ, CPOL_ITAB_MELT='0'),
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert '3 passed' in out.stdout, out.stdout[-500:]

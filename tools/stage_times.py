@@ -27,8 +27,11 @@ def main():
     hyds = list(bench.hydrometeors_of(wl))
     cube = synthetic.make_cube(hydrometeors=tuple(h for h in hyds if h in 'RSGI'), **synthetic.BENCH_GRID)
     luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    import time
     with contextlib.redirect_stdout(sys.stderr):
+        t0 = time.time()
         op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
+        t_tables = time.time() - t0
         op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
     az = np.arange(0, 360, 1.0)
     el = np.full(360, args.elev)
@@ -43,7 +46,12 @@ def main():
         op.simulate_rays(az, el, device_outputs=ptrs)
     op.wait()
     c = op._ctx.counters()
+    chk2 = op._ctx.debug_read('itab_check', (2, 8), np.float64)
+    chk = chk2[0]
+    print('itab_check at (block x 14 + fn):', [(int(v) // 14, int(v) % 14) for v in chk2[1][:len(hyds)]], file=sys.stderr)
     print(json.dumps(dict(tag=args.tag, config=wl, elev=args.elev, n_valid=int(c.n_valid_items),
+                          n_table=int(c.n_table_items), tables_s=round(t_tables, 2),
+                          itab_check=[float('%.2e' % v) for v in chk[:len(hyds)]],
                           interp=round(c.ms_interp * 1e3, 1), classify=round(c.ms_classify * 1e3, 1),
                           bucket=round(c.ms_bucket * 1e3, 1), psd=round(c.ms_psd * 1e3, 1),
                           final=round(c.ms_final * 1e3, 1), total_us=round(c.ms_total * 1e3, 1))), flush=True)
