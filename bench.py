@@ -412,39 +412,53 @@ def run_c2(env):
     return out
 
 
-def roofline_lookup(workload, cnt, psd_bytes, iso, n_fields_read):
-    """The PSD x table stage when the integral tables take the items (k_psd_lookup): a gather of
-    `n_fields_read` x 11 float64 coefficients per item from the (slice, lambda-panel) block of the
-    item, three parameters and the key, 12 float64 results written -- bandwidth / latency bound,
-    no arithmetic to speak of.  achieved = those bytes over the live stage time; the blocks are shared
-    by neighbouring gates, so most of it is served by L2 (traffic = HBM bytes of the PMC pass)."""
+L1_PEAK_GBS = 256 * 64 * PEAK_CLOCK / 1e9      # vector L1: 64 B / clk / CU (MI355X_MICROARCH.md)
+
+
+def roofline_lookup(workload, cnt, psd_bytes, iso, n_fields_read, traffic_scale=1.0):
+    """The PSD x table stage when the integral tables take the items (k_psd_lookup).  Per item the
+    kernel MUST move its key and three parameters in and 12 float64 results out (124 B; HBM), and it
+    gathers `n_fields_read` x 11 float64 coefficients from the (slice, lambda-panel) block of the item
+    (1056 B per lane through the vector L1; the blocks of a sweep are a few hundred KB, L2-resident).
+    achieved / frac = the 124 B per item over the live stage time against the HBM peak -- small, the
+    kernel is bound by the L1 gather and, at the size of one C2 sweep (180 k threads), by latency;
+    `l1_gather` prices the coefficient bytes against the aggregate L1 bandwidth.  traffic = HBM bytes
+    of the committed PMC pass."""
     prof, prof_path = load_profile_summary(workload)
     traffic = prof_us = None
     if prof:
         for name, c in prof.items():
             if 'k_psd_lookup' in name:
                 traffic, prof_us = c.get('hbm_bytes'), c.get('avg_us')
+                traffic = traffic * traffic_scale if traffic else traffic
     n_tab = int(cnt.n_table_items)
-    per_item = n_fields_read * 11 * 8 + 3 * 8 + 4 + 12 * 8
-    gather = n_tab * per_item
+    per_item_hbm = 4 + 3 * 8 + 12 * 8
+    per_item_l1 = n_fields_read * 11 * 8
+    must = n_tab * per_item_hbm
     t = cnt.ms_psd * 1e-3 if cnt.ms_psd > 0 else None
     r = {'kernel': 'k_psd_lookup (+ the integrating kernels for the %d items outside the tables)'
                    % (int(cnt.n_valid_items) - n_tab),
-         'bound': 'hbm', 'achieved': gather / t / 1e9 if t else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-         'frac': gather / t / 1e9 / HBM_PEAK_GBS if t else None,
+         'bound': 'hbm', 'achieved': must / t / 1e9 if t else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+         'frac': must / t / 1e9 / HBM_PEAK_GBS if t else None,
          'traffic': traffic, 'traffic_source': prof_path,
-         'bytes_per_item': per_item, 'n_table_items': n_tab, 'n_valid_items': int(cnt.n_valid_items),
+         'bytes_per_item': per_item_hbm, 'n_table_items': n_tab, 'n_valid_items': int(cnt.n_valid_items),
          'avg_stage_ms': cnt.ms_psd, 'profile_avg_us': prof_us,
          'hbm_physical_frac': (traffic / t / 1e9 / HBM_PEAK_GBS) if (t and traffic) else None,
+         'l1_gather': {'bytes_per_item': per_item_l1, 'achieved': n_tab * per_item_l1 / t / 1e9 if t else None,
+                       'peak': L1_PEAK_GBS, 'unit': 'GB/s',
+                       'frac': n_tab * per_item_l1 / t / 1e9 / L1_PEAK_GBS if t else None},
          'hbm_alg_frac': (psd_bytes / t / 1e9 / HBM_PEAK_GBS) if t else None,
          'algorithmic_bytes_per_launch': psd_bytes,
-         'note': 'achieved = bytes this implementation gathers per launch (coefficients + parameters + '
-                 'results) / live HIP-event time of the PSD stage; hbm_alg_frac = the survey\'s B_alg '
-                 '(N_valid x 49152 B, what the reference algorithm reads) over the same time: far above 1 '
-                 'because the 1024-bin integration is replaced by a table of its result; the stage is '
-                 'latency-bound at this size (one sweep = 180 k threads)'}
+         'note': 'achieved = (key + 3 parameters + 12 results) x items / live HIP-event time of the PSD stage '
+                 '(lookup + the empty integrating launch); hbm_alg_frac = the survey\'s B_alg (N_valid x 49152 B, '
+                 'what the reference algorithm reads) over the same time: far above 1 because the 1024-bin '
+                 'integration is replaced by a table of its result; the bound that was priced in round 1 and '
+                 'at the start of round 2 -- f64 VALU issue of the integrating kernel -- is reported under '
+                 'integrating_kernel'}
     if iso is not None and iso.ms_psd > 0:
-        r['isolated'] = {'avg_stage_ms': iso.ms_psd, 'frac': gather / (iso.ms_psd * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        ti = iso.ms_psd * 1e-3
+        r['isolated'] = {'avg_stage_ms': iso.ms_psd, 'frac': must / ti / 1e9 / HBM_PEAK_GBS,
+                         'l1_gather_frac': n_tab * per_item_l1 / ti / 1e9 / L1_PEAK_GBS,
                          'note': 'same sweep with one lane only (no overlap with other sweeps)'}
     return r
 
@@ -573,7 +587,7 @@ def run_c4(env):
     value = gates_per_step * args.steps / elapsed
 
     # per-rank work of one volume (untimed pass: counters after every sweep)
-    n_valid_loc = n_units_loc = 0
+    n_valid_loc = n_units_loc = n_table_loc = 0
     ms_psd_iso = []
     for e, elev in enumerate(C4_ELEVATIONS):
         if n_loc > 0:
@@ -583,8 +597,10 @@ def run_c4(env):
             op._ctx.enable_timing(False)
             n_valid_loc += int(c.n_valid_items)
             n_units_loc += int(c.n_work_units)
+            n_table_loc += int(c.n_table_items)
             ms_psd_iso.append(float(c.ms_psd))
     mine = {'rank': rank, 'rays_per_sweep': n_loc, 'n_valid_items': n_valid_loc, 'n_work_units': n_units_loc,
+            'n_table_items': n_table_loc,
             'psd_stage_ms_per_sweep_isolated': (sum(ms_psd_iso) / len(ms_psd_iso)) if ms_psd_iso else None}
     per_rank = [None] * world
     if world > 1:
@@ -631,16 +647,19 @@ def run_c4(env):
     scale = 1.0
     if prof and prof.get('_meta', {}).get('n_valid_items_per_volume'):
         scale = busiest['n_valid_items'] / float(prof['_meta']['n_valid_items_per_volume'])
-    roof = roofline('c4', ['k_psd_melting_tab<false>', 'k_psd_lookup', 'k_psd_ice2<false>', 'k_psd_uniform<false>'],
-                    busiest['psd_stage_ms_per_sweep_isolated'], busiest['n_valid_items'] // n_el,
-                    busiest['n_valid_items'] // n_el * LUT_SLICE_BYTES, valu_scale=scale)
+    class _C(object):
+        pass
+    cb = _C()
+    cb.n_table_items = busiest['n_table_items'] // n_el
+    cb.n_valid_items = busiest['n_valid_items'] // n_el
+    cb.ms_psd = busiest['psd_stage_ms_per_sweep_isolated'] or 0.0
+    roof = roofline_lookup('c4', cb, cb.n_valid_items * LUT_SLICE_BYTES, None, n_fields_read=14, traffic_scale=scale)
     roof['stage_ms_with_lanes_in_flight'] = max(ms_psd) if ms_psd else None
-    roof['note'] += ('; c4: the PSD stage = k_psd_lookup (snow, graupel, ice from the integral tables) + '
-                     'k_psd_melting_tab (melting species: the dominant, f64-VALU bound kernel) + the integrating '
-                     'kernels for the few items outside the tables; avg_stage_ms = mean over the 5 sweeps of the '
-                     'busiest rank, one lane at a time (the pass after the timed region); the instruction count is '
-                     'the sum of those kernels\' per-launch means of the N = 1 profile scaled by this rank\'s share '
-                     'of the valid items')
+    roof['note'] += ('; c4: per sweep of the busiest rank (mean over its 5 sweeps, one lane at a time, the pass '
+                     'after the timed region); snow, graupel and ice crystals read 1-D blocks (11 rows of 128 B, '
+                     'shared by neighbouring gates), the melting species 2-D blocks (121 rows, wet fraction x '
+                     'rain-partner slope, one wavefront per item: 15.5 KB per item through L1, which l1_gather '
+                     'does not count); traffic = the N = 1 profile scaled by this rank\'s share of the items')
     return {
         'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
