@@ -191,13 +191,15 @@ int build_itabs(cpol_ctx *ctx)
             for (int pw = 0; pw < NC; ++pw)
                 T[n][pw] = (pw > 0 ? 2.0L * T[n - 1][pw - 1] : 0.0L) - T[n - 2][pw];
         const long double pi = 3.141592653589793238462643383279502884L;
-        double M[NC * NC];
+        double M[3 * NC * NC];                             // M | Tm (nodes -> Chebyshev) | C2M (T_n -> monomials)
         for (int pw = 0; pw < NC; ++pw)
             for (int q = 0; q < NC; ++q) {
                 long double acc = 0.0L;
                 for (int n = 0; n < NC; ++n)
                     acc += T[n][pw] * (n == 0 ? 1.0L : 2.0L) / NC * cosl(pi * n * (q + 0.5L) / NC);
                 M[pw * NC + q] = (double)acc;
+                M[NC * NC + pw * NC + q] = (double)((pw == 0 ? 1.0L : 2.0L) / NC * cosl(pi * pw * (q + 0.5L) / NC));
+                M[2 * NC * NC + pw * NC + q] = (double)T[pw][q];
             }
         int rc = upload(ctx, ctx->d_itab_M, M, sizeof M);
         if (rc != CPOL_OK) return rc;
@@ -224,8 +226,9 @@ int build_itabs(cpol_ctx *ctx)
         }
         if (melt) {
             // slope of the rain partner, lambda_r = (factor / QM)^(1/(4+mu)): 2^-1 (QM = 0.05 kg m-3) ..
-            // 2^6.5 (1e-11); items beyond are integrated
-            lo = -1.0; hi = 6.5;
+            // 2^8.5 (3e-14: trilinear interpolation towards an empty model cell leaves such values);
+            // items beyond are integrated
+            lo = -1.0; hi = 8.5;
         }
         const int ppo = melt ? CPOL_ITAB2_PPO : CPOL_ITAB_PPO;
         const int n_pan = (int)((hi - lo) * ppo);
@@ -313,7 +316,7 @@ int build_itabs(cpol_ctx *ctx)
             fa.n_blocks = (long)n_slices * n_pan;
             fa.worst = (unsigned long long *)b_tot.p + 3;
             HIPCHK(hipMemsetAsync(fa.worst, 0, sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_itab_fit2, dim3(cdiv(fa.n_blocks * CPOL_ITAB_NFP * NC, 256)), dim3(256), 0, st, fa);
+            hipLaunchKernelGGL(k_itab_fit2, dim3(cdiv(fa.n_blocks * CPOL_ITAB_NFP, 64)), dim3(64), 0, st, fa);
             hipLaunchKernelGGL(k_itab_check2, dim3(cdiv(fa.n_blocks * (CPOL_N_SZ + 2), 256)), dim3(256), 0, st, fa);
             HIPCHK(hipMemcpyAsync(&worst_bits, fa.worst, sizeof worst_bits, hipMemcpyDeviceToHost, st));
         } else {
@@ -994,7 +997,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_key, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_pos, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_par, (size_t)n_hyd * CPOL_MAX_PAR * n_sbg * sizeof(double));
-    ENSURE(ctx->b_count, (size_t)(n_keys + 2) * sizeof(int));       // + [n_keys + 1]: items on integral tables
+    ENSURE(ctx->b_count, (size_t)(n_keys + 3) * sizeof(int));       // + [n_keys + 1]: items on integral tables, [+ 2]: items ranked
     ENSURE(ctx->b_offset, (size_t)2 * n_keys * sizeof(int));        // item and unit offsets
     const long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
     ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
@@ -1129,7 +1132,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.rp.range0 = p->range0; ia.rp.range_step = p->range_step;
     ia.rp.ke = p->ke; ia.rp.re = p->re; ia.rp.alt = p->radar_alt;
     ia.zero_buf = (int *)ctx->b_count.p;
-    ia.zero_n = n_keys + 2;
+    ia.zero_n = n_keys + 3;
     ia.geo = (const double *)ctx->v_geo;
     ia.sub_h = (const int *)ctx->v_subh;
     ia.sub_v = (const int *)ctx->v_subv;

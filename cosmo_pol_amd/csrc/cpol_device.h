@@ -75,11 +75,15 @@ struct SpecSet {
 // LUT slice, floor bin of the table's second axis) and the slope lambda_r of the rain partner, and
 // every integrated entry is  QM x F_c(slice, fw, lambda_r)  (the normalisation by the mass
 // integral makes F_c a ratio of two sums over the bins, a very smooth function).  F_c is stored
-// per (slice, 1/4-octave panel of lambda_r) as a degree-10 x degree-10 polynomial in (position of
-// fw inside the slice's wet-fraction bin, position inside the panel): 121 rows of 128 B.
+// per (slice, 1/4-octave panel of lambda_r) as a polynomial of total degree 10 in (u = position of
+// fw inside the slice's wet-fraction bin, w = position inside the panel): the 11 x 11 tensor
+// Chebyshev interpolant with the terms T_a(u) T_b(w), a + b > 10, dropped (their coefficients are of
+// the size of the 1-D tails), converted to monomials u^a w^b, a + b <= 10: 66 rows of 128 B, the
+// rows of w^b (a = 0 .. 10 - b) at row CPOL_ITAB2_ROW(b).
 #define CPOL_ITAB2_PPO   4
-#define CPOL_ITAB2_NB    (CPOL_ITAB_NC * CPOL_ITAB_NC)           // coefficient rows per block
-#define CPOL_ITAB2_NODES (CPOL_ITAB2_NB + 1)                      // build items per block: the nodes + 1 check point
+#define CPOL_ITAB2_NB    (CPOL_ITAB_NC * (CPOL_ITAB_NC + 1) / 2)       // coefficient rows per block
+#define CPOL_ITAB2_ROW(b) ((b) * CPOL_ITAB_NC - (b) * ((b) - 1) / 2)
+#define CPOL_ITAB2_NODES (CPOL_ITAB_NC * CPOL_ITAB_NC + 1)              // build items per block: the nodes + 1 check point
 #define CPOL_ITAB2_CHECK_U 0.37
 #define CPOL_ITAB2_CHECK_W (-0.61)
 #define CPOL_ITAB2_MAX_DEVIATION 1e-10   // accepted |polynomial - integrating kernel| / |value| at the check points (measured on
@@ -87,7 +91,7 @@ struct SpecSet {
 struct ItabDev {
     const double *tab;     // 1-D: [n_slices][n_pan][CPOL_ITAB_NC][CPOL_ITAB_NFP] monomial coefficients (power-major:
                            //   one 128-B row holds the coefficient of u^q of all functions), or NULL
-                           // 2-D: [n_slices][n_pan][NC (power of w, lambda)][NC (power of u, fw)][CPOL_ITAB_NFP]
+                           // 2-D: [n_slices][n_pan][CPOL_ITAB2_NB rows (w^b u^a, a + b <= 10)][CPOL_ITAB_NFP]
     const double *head;    // 2-D: [n_t][2] centre and 1 / half-width of the wet-fraction bins
     double log2_lo;        // lambda of panel 0, node u = -1:  2^log2_lo
     double d0;             // gamma family: the tabulated function is exp(+lambda d0) x integral (d0 = D_0^nu)

@@ -284,7 +284,7 @@ struct ClassifyArgs {
     // correctly rounded value in 20-40 % of the arguments, and K_DP shows it
     const float *tfun_snow;      // snow intercept N0(T)  (hydrometeors.py:896) or NULL
     const float *tfun_ice;       // 10**a(T) of the Field (2005) moment relation (:1287) or NULL
-    int *n_lookup;               // counter of the items taken by the integral tables (k_psd_lookup)
+    int *n_lookup;               // [0] items taken by the integral tables (k_psd_lookup), [1] items ranked
 };
 
 __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &out)
@@ -303,11 +303,11 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
     // one LDS ranking table per hydrometeor: all global atomics of the workgroup are
     // issued in ONE round (phase B) instead of one dependent round per hydrometeor
     __shared__ RankShared sh[CPOL_MAX_HYDRO];
-    __shared__ int s_lookup;
+    __shared__ int s_lookup, s_ranked;
     for (int j = 0; j < hs.n_hydro; ++j) rank_reset(sh[j]);
-    if (threadIdx.x == 0) s_lookup = 0;
+    if (threadIdx.x == 0) { s_lookup = 0; s_ranked = 0; }
     __syncthreads();
-    int my_lookup = 0;
+    int my_lookup = 0, my_ranked = 0;
     const long sbg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = sbg < a.n_sbg;
     const long n = a.n_sbg;
@@ -443,19 +443,26 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             a.par[((long)j * CPOL_MAX_PAR + 4) * n + i] = lookup ? pf : -1.0;
             my_lookup += lookup ? 1 : 0;
         }
+        my_ranked += (valid && !lookup) ? 1 : 0;
         const int ticket = rank_insert(sh[j], a.count, key, valid && !lookup);
         if (in) {
             a.key[(long)j * n + i] = key;
             a.pos[(long)j * n + i] = ticket;
         }
     }
-    if (a.n_lookup) {
+    // a.n_lookup[0]: items on integral tables; [1]: items ranked for the integrating kernels (0 in
+    // the normal case: k_bucket_scan / k_bucket_scatter then return at once)
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) my_lookup += __shfl_xor(my_lookup, off);
-        if (lane_id() == 0 && my_lookup) atomicAdd(&s_lookup, my_lookup);
+    for (int off = 32; off >= 1; off >>= 1) {
+        my_lookup += __shfl_xor(my_lookup, off);
+        my_ranked += __shfl_xor(my_ranked, off);
     }
+    if (lane_id() == 0 && my_lookup) atomicAdd(&s_lookup, my_lookup);
+    if (lane_id() == 0 && my_ranked) atomicAdd(&s_ranked, my_ranked);
     __syncthreads();
-    if (a.n_lookup && threadIdx.x == 0 && s_lookup) atomicAdd(a.n_lookup, s_lookup);
+    if (threadIdx.x == 0 && s_lookup) atomicAdd(a.n_lookup, s_lookup);
+    if (threadIdx.x == 0 && s_ranked) atomicAdd(a.n_lookup + 1, s_ranked);
+    if (s_ranked == 0) return;                        // workgroup-uniform: every ticket is -1
     for (int idx = threadIdx.x; idx < hs.n_hydro * CPOL_RANK_SLOTS; idx += blockDim.x)
         rank_reserve(sh[idx / CPOL_RANK_SLOTS], a.count, idx % CPOL_RANK_SLOTS);
     __syncthreads();
@@ -505,6 +512,10 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
 {
     __shared__ int2 s_wave[16];
     const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
+    if (a.count[a.n_keys + 2] == 0) {                       // no item left to the integrating kernels
+        if (t == 0) { a.totals[0] = 0; a.totals[1] = 0; a.totals[2] = 0; }
+        return;
+    }
     const int per = (a.n_keys + 1023) / 1024;               // <= CPOL_SCAN_MAX_PER (host checks)
     const int k0 = t * per;
     // the thread's counts in registers: the (up to 32) loads are independent and issue together
@@ -559,6 +570,7 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ 
 {
     const long sbg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n_waves = gridDim.x * (blockDim.x >> 6);
+    if (a.count[a.n_keys + 2] == 0) return;                 // grid-uniform: nothing was ranked
     for (int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < a.n_keys; k += n_waves) {
         const int c = a.count[k];
         if (c == 0) continue;                                   // wave-uniform
@@ -1492,7 +1504,7 @@ __global__ void k_itab_nodes(ItabBuildArgs b)
     if (b.two_d) {
         const int s = (int)(i / per_slice), tb = s % b.n_t;
         const int p = r / per_block, node = r % per_block;
-        const bool chk = node == CPOL_ITAB2_NB;
+        const bool chk = node == CPOL_ITAB2_NODES - 1;
         const double xw = chk ? CPOL_ITAB2_CHECK_W : cheb_node(node / CPOL_ITAB_NC);
         const double xu = chk ? CPOL_ITAB2_CHECK_U : cheb_node(node % CPOL_ITAB_NC);
         b.par[i] = 1.0;                                                        // QM
@@ -1550,13 +1562,13 @@ __global__ void k_itab_fit(ItabFitArgs f)
 }
 
 // Melting species: node values V[b][a] (b: lambda_r node, a: fw node) of one function of one
-// block -> monomial coefficients C[pb][pa] = sum_b sum_a M[pb][b] M[pa][a] V[b][a].
-// One thread per (block, function, pa).
+// block -> Chebyshev coefficients (Tm: discrete transform), terms of total degree > 10 dropped,
+// -> monomial coefficients (C2M[n][p]: coefficient of x^p in T_n).  One thread per (block, function).
 struct ItabFit2Args {
     const double *res;         // [n_items][12]
     const double *vn;          // [n_items][2]
-    const double *M;           // [NC][NC]
-    double *tab;               // [n_blocks][NC][NC][NFP]
+    const double *M;           // [3][NC][NC]: M (1-D fit), Tm, C2M
+    double *tab;               // [n_blocks][CPOL_ITAB2_NB][NFP]
     long n_blocks;
     unsigned long long *worst; // check kernel: bits of the worst relative deviation at the check points
 };
@@ -1565,34 +1577,47 @@ __global__ void k_itab_fit2(ItabFit2Args f)
 {
     constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= f.n_blocks * NFP * NC) return;
-    const int pa = (int)(t % NC);
-    const int fn = (int)((t / NC) % NFP);
-    const long blk = t / (NC * NFP);
-    double *o = f.tab + blk * (CPOL_ITAB2_NB * NFP) + (long)pa * NFP + fn;
+    if (t >= f.n_blocks * NFP) return;
+    const int fn = (int)(t % NFP);
+    const long blk = t / NFP;
+    double *o = f.tab + blk * (CPOL_ITAB2_NB * NFP) + fn;
     if (fn >= CPOL_N_SZ + 2) {                                            // padding columns
-        for (int pb = 0; pb < NC; ++pb) o[(long)pb * NC * NFP] = 0.0;
+        for (int row = 0; row < CPOL_ITAB2_NB; ++row) o[(long)row * NFP] = 0.0;
         return;
     }
-    double tmp[NC];
-#pragma unroll
-    for (int b = 0; b < NC; ++b) {
-        double c = 0.0;
-#pragma unroll
+    const double *Tm = f.M + NC * NC, *C2M = f.M + 2 * NC * NC;
+    double A[NC][NC], B[NC][NC];
+    for (int b = 0; b < NC; ++b)
         for (int a = 0; a < NC; ++a) {
             const long i = blk * CPOL_ITAB2_NODES + b * NC + a;
-            const double v = fn < CPOL_N_SZ ? f.res[i * CPOL_N_SZ + fn] : f.vn[i * 2 + (fn - CPOL_N_SZ)];
-            c = fma(f.M[pa * NC + a], v, c);
+            A[b][a] = fn < CPOL_N_SZ ? f.res[i * CPOL_N_SZ + fn] : f.vn[i * 2 + (fn - CPOL_N_SZ)];
         }
-        tmp[b] = c;
-    }
-#pragma unroll
-    for (int pb = 0; pb < NC; ++pb) {
-        double c = 0.0;
-#pragma unroll
-        for (int b = 0; b < NC; ++b) c = fma(f.M[pb * NC + b], tmp[b], c);
-        o[(long)pb * NC * NFP] = c;
-    }
+    // Chebyshev coefficients in u (second index), then in w (first index)
+    for (int b = 0; b < NC; ++b)
+        for (int ca = 0; ca < NC; ++ca) {
+            double c = 0.0;
+            for (int a = 0; a < NC; ++a) c = fma(Tm[ca * NC + a], A[b][a], c);
+            B[b][ca] = c;
+        }
+    for (int cb = 0; cb < NC; ++cb)
+        for (int ca = 0; ca < NC; ++ca) {
+            double c = 0.0;
+            for (int b = 0; b < NC; ++b) c = fma(Tm[cb * NC + b], B[b][ca], c);
+            A[cb][ca] = (ca + cb < NC) ? c : 0.0;                         // total degree <= 10
+        }
+    // monomials in u, then in w
+    for (int cb = 0; cb < NC; ++cb)
+        for (int pa = 0; pa < NC; ++pa) {
+            double c = 0.0;
+            for (int ca = pa; ca < NC; ++ca) c = fma(C2M[ca * NC + pa], A[cb][ca], c);
+            B[cb][pa] = c;
+        }
+    for (int pb = 0; pb < NC; ++pb)
+        for (int pa = 0; pa + pb < NC; ++pa) {
+            double c = 0.0;
+            for (int cb = pb; cb < NC; ++cb) c = fma(C2M[cb * NC + pb], B[cb][pa], c);
+            o[(long)(CPOL_ITAB2_ROW(pb) + pa) * NFP] = c;
+        }
 }
 
 // value of function fn of a 2-D block at (u, w)
@@ -1602,7 +1627,7 @@ __device__ __forceinline__ double itab2_eval(const double *blk, int fn, double u
     double outer = 0.0;
     for (int pb = NC - 1; pb >= 0; --pb) {
         double inner = 0.0;
-        for (int pa = NC - 1; pa >= 0; --pa) inner = fma(inner, u, blk[((long)pb * NC + pa) * NFP + fn]);
+        for (int pa = NC - 1 - pb; pa >= 0; --pa) inner = fma(inner, u, blk[(long)(CPOL_ITAB2_ROW(pb) + pa) * NFP + fn]);
         outer = fma(outer, w, inner);
     }
     return outer;
@@ -1615,7 +1640,7 @@ __global__ void k_itab_check2(ItabFit2Args f)
     if (t >= f.n_blocks * (CPOL_N_SZ + 2)) return;
     const int fn = (int)(t % (CPOL_N_SZ + 2));
     const long blk = t / (CPOL_N_SZ + 2);
-    const long i = blk * CPOL_ITAB2_NODES + CPOL_ITAB2_NB;
+    const long i = blk * CPOL_ITAB2_NODES + (CPOL_ITAB2_NODES - 1);
     const double ref = fn < CPOL_N_SZ ? f.res[i * CPOL_N_SZ + fn] : f.vn[i * 2 + (fn - CPOL_N_SZ)];
     const double got = itab2_eval(f.tab + blk * (CPOL_ITAB2_NB * CPOL_ITAB_NFP), fn, CPOL_ITAB2_CHECK_U, CPOL_ITAB2_CHECK_W);
     // scale: the function's size over the block (its value at the first node), so that columns
@@ -1656,21 +1681,24 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m)
     return __hiloint2double(hi, lo);
 }
 
-// 2-D block: the part of  sum_b w^b sum_a C[b][a][f] u^a  that quarter r of the wavefront owns
-// (b = r, r+4, r+8); c points at column f of the block
+// 2-D block: the part of  sum_b w^b sum_{a <= 10-b} C[b][a][f] u^a  that quarter r of the wavefront
+// owns (b = r, r+4, r+8); c points at column f of the block
 __device__ __forceinline__ double itab2_quarter_sum(const double *c, int r, double ui, double wi)
 {
-    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
+    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
     const double w2 = wi * wi, w4 = w2 * w2;
     double acc = 0.0;
 #pragma unroll
     for (int k = 2; k >= 0; --k) {
         const int b = r + 4 * k;                                        // power of w of this quarter's row set
-        const double *cb = c + (long)min(b, NC - 1) * NB;
-        double inner = cb[(NC - 1) * NFP];
+        const int bb = min(b, NC - 1);
+        const double *cb = c + (long)CPOL_ITAB2_ROW(bb) * NFP;
+        // rows u^0 .. u^(10-b); the quarters run the chain of the longest (r = 0) together, the
+        // shorter ones start with zeros
+        double inner = 0.0;
 #pragma unroll
-        for (int pa = NC - 2; pa >= 0; --pa) inner = fma(inner, ui, cb[pa * NFP]);
-        acc = fma(acc, w4, b < NC ? inner : 0.0);
+        for (int pa = NC - 1 - 4 * k; pa >= 0; --pa) inner = fma(inner, ui, pa <= NC - 1 - b ? cb[pa * NFP] : 0.0);
+        acc = fma(acc, w4, inner);
     }
     return acc * ((r & 1 ? wi : 1.0) * (r & 2 ? w2 : 1.0));
 }
@@ -1688,10 +1716,10 @@ __device__ __forceinline__ double itab2_quarter_sum(const double *c, int r, doub
 //     (a wavefront of 64 neighbouring gates spans ~7 distinct blocks, so the walk repeats)
 //   this form                                                                  ~23 us / 1.4 ms
 //
-// 2-D blocks (melting species): 121 rows of 128 B per block and neighbouring gates hardly ever
+// 2-D blocks (melting species): 66 rows of 128 B per block and neighbouring gates hardly ever
 // share one (the wet fraction crosses a 0.01-wide bin of the table per gate).  One lane per item
-// -- 847 16-B loads per lane, 64 different cache lines per instruction -- took 3.0 ms for the
-// 1.28 M melting items of the C4 sweep.  Here the WAVEFRONT takes the items of its 64 gates one
+// -- with the full 11 x 11 tensor: 847 16-B loads per lane, 64 different cache lines per
+// instruction -- took 3.0 ms for the 1.28 M melting items of the C4 sweep.  Here the WAVEFRONT takes the items of its 64 gates one
 // after the other: lane = (quarter r, function f); quarter r sums the rows of the powers
 // w^r, w^(r+4), w^(r+8), each row a full Horner chain in u, every row is read exactly once as one
 // contiguous 128-B line per quarter; two cross-lane adds join the quarters.
