@@ -1714,7 +1714,10 @@ __device__ __forceinline__ double itab2_quarter_sum(const double *c, int r, doub
 //     v_fma_f64 with scalar addend (every row misses the scalar cache)        ~100 us / 1.6 ms
 //   the same walk with the block staged in LDS and read back by broadcast      ~43 us / 1.5 ms
 //     (a wavefront of 64 neighbouring gates spans ~7 distinct blocks, so the walk repeats)
-//   this form                                                                  ~23 us / 1.4 ms
+//   this form                                                                  ~23 us / 1.1 ms
+//   this form with the lanes of a wavefront on 8 neighbouring rays x 8 gates (2-3 distinct
+//     blocks per wavefront instead of ~7): no change -- the 1056 B per lane through the
+//     vector L1 (64 B / clk / CU) bound the kernel, not the number of distinct lines
 //
 // 2-D blocks (melting species): 66 rows of 128 B per block and neighbouring gates hardly ever
 // share one (the wet fraction crosses a 0.01-wide bin of the table per gate).  One lane per item
