@@ -67,7 +67,8 @@ struct cpol_ctx {
     double itab_check_at[CPOL_MAX_HYDRO] = {};
     double itab_check[CPOL_MAX_HYDRO] = {};     // melting species: worst deviation at the check points (-1: table rejected)
     ItabSet its{};
-    uint64_t itab_serial = ~0ull;      // stage_serial the tables were built for
+    uint64_t lut_serial = 0;           // bumped by the staging calls the integral tables depend on (not the model cube)
+    uint64_t itab_serial = ~0ull;      // lut_serial the tables were built for
     DevBuf d_tfun[CPOL_N_TFUN];        // host-tabulated float32 functions of T (cpol_stage_t_function)
     const float *tfun[CPOL_N_TFUN] = {};
     // per-sweep work buffers (grow only)
@@ -173,10 +174,10 @@ namespace {
 int build_itabs(cpol_ctx *ctx)
 {
     if (ctx->parent) return CPOL_OK;                      // lanes copy the parent's tables
-    if (ctx->itab_serial == ctx->stage_serial) return CPOL_OK;
+    if (ctx->itab_serial == ctx->lut_serial) return CPOL_OK;
     const bool enabled = !(getenv("CPOL_ITAB") && atoi(getenv("CPOL_ITAB")) == 0);   // read at every (re)build
     ctx->its = ItabSet{};
-    ctx->itab_serial = ctx->stage_serial;
+    ctx->itab_serial = ctx->lut_serial;
     if (!enabled) return CPOL_OK;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -220,7 +221,7 @@ int build_itabs(cpol_ctx *ctx)
         if (gamma) {
             HIPCHK(hipMemcpy(&d0, h.dnu, sizeof d0, hipMemcpyDeviceToHost));
             if (!(d0 > 0.0)) continue;
-            hi = floor(log2(690.0 / d0));
+            hi = floor(log2(690.0 / d0) * CPOL_ITAB_PPO) / CPOL_ITAB_PPO;     // whole panels
             if (hi > 16.0) hi = 16.0;
             if (hi <= lo) continue;
         }
@@ -231,7 +232,7 @@ int build_itabs(cpol_ctx *ctx)
             lo = -1.0; hi = 8.5;
         }
         const int ppo = melt ? CPOL_ITAB2_PPO : CPOL_ITAB_PPO;
-        const int n_pan = (int)((hi - lo) * ppo);
+        const int n_pan = (int)floor((hi - lo) * ppo + 0.5);
         const int n_slices = d.n_e * d.n_t;
         const int per_block = melt ? CPOL_ITAB2_NODES : NC;
         const long n_items = (long)n_slices * n_pan * per_block;
@@ -492,7 +493,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
         if (rc_it != CPOL_OK) { (void)hipStreamDestroy(c->stream); (void)hipFree(c->d_errword); delete c; return rc_it; }
     }
     c->its = parent->its;
-    c->itab_serial = parent->stage_serial;
+    c->itab_serial = parent->lut_serial;
     parent->n_children += 1;
     *out = c;
     return CPOL_OK;
@@ -658,6 +659,7 @@ int cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro)
     }
     ctx->hs.n_hydro = n_hydro;
     ctx->stage_serial++;
+    ctx->lut_serial++;
     int base = 0;
     for (int j = 0; j < n_hydro; ++j) {
         ctx->hs.h[j].key_base = base;
@@ -737,6 +739,7 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->hydro_staged[slot] = true;
     ctx->stage_serial++;
+    ctx->lut_serial++;
     const int rc_n = cpol_set_num_hydro(ctx, slot >= ctx->hs.n_hydro ? slot + 1 : ctx->hs.n_hydro);
     if (rc_n != CPOL_OK) {
         ctx->hydro_staged[slot] = false;               // the slot does not count as staged
@@ -792,6 +795,7 @@ int cpol_stage_doppler_weights(cpol_ctx *ctx, int slot, const double *weights)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->hs.h[slot].rcsw = (const double *)ctx->d_rcsw[slot].p;
     ctx->stage_serial++;
+    ctx->lut_serial++;
     return CPOL_OK;
 }
 
@@ -898,7 +902,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     for (int j = 0; j < ctx->hs.n_hydro; ++j)
         if (!ctx->hydro_staged[j]) { ctx->err = "cpol_run_sweep: hydrometeor slot not staged"; return CPOL_ERR_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
-    if (!ctx->parent && ctx->itab_serial != ctx->stage_serial) {
+    if (!ctx->parent && ctx->itab_serial != ctx->lut_serial) {
         const int rc_it = build_itabs(ctx);                // once per staged table set
         if (rc_it != CPOL_OK) return rc_it;
     }
