@@ -105,7 +105,10 @@ def main():
     ap.add_argument('--small', action='store_true', help='small cube / tables (debugging, tests)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0,
                     help='budget of the one-core CPU-oracle baseline (0 = skip all CPU legs)')
+    ap.add_argument('--cpu-pool-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_pool_child:
+        return cpu_pool_child(args)
 
     import torch
     import torch.distributed as dist
@@ -146,8 +149,7 @@ def main():
         el_cpu = 1.0 if workload == 'c2' else C4_ELEVATIONS[2]
         print('[bench] CPU baseline: one pinned core ...', file=sys.stderr, flush=True)
         cpu_res = cpu_baseline(conf, cube, luts, np.arange(0, 360, 1.0), el_cpu, args.cpu_seconds)
-        cpu_res['all_cores'] = cpu_baseline_pool(conf, cube, luts, np.arange(0, 360, 1.0), el_cpu,
-                                                 cpu_res['radials_per_s'])
+        cpu_res['all_cores'] = cpu_baseline_pool(workload, args.small)
 
     torch.cuda.set_device(local_rank)
     t0 = time.time()
@@ -184,11 +186,37 @@ def main():
         if cpu_res is not None:
             out['cpu_baseline'] = cpu_res
             out['gpu_over_cpu_core'] = out['value'] / cpu_res['value']
-        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     op.close()
+    if rank == 0:
+        if (world == 1 and args.workload == 'auto' and not args.small
+                and not os.environ.get('CPOL_BENCH_NO_C4')):
+            out['c4_volume_one_gpu'] = c4_reference_run()
+        print(json.dumps(out))
+
+
+def c4_reference_run():
+    """N = 1, default workload only: the multi-GPU workload (c4, what `--gpus N` runs for N > 1) on
+    this one GPU, in a child process after the c2 operator is closed, so that the N = 1 line also
+    carries the single-GPU reference of the strong-scaling runs."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'c4', '--steps', '6', '--warmup', '2',
+           '--cpu-seconds', '0']
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, CPOL_BENCH_NO_C4='1'))
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode != 0 or not line:
+            return {'error': (r.stderr or r.stdout)[-400:]}
+        d = json.loads(line[-1])
+        return {'value': d['value'], 'unit': d['unit'], 'ms_per_volume': d['ms_per_step'], 'steps': d['steps'],
+                'workload': d['config']['workload'], 'gather_check': d.get('gather_check'),
+                'psd_stage_ms_per_sweep': d['roofline'].get('avg_stage_ms'),
+                'setup_s': d.get('setup_s'),
+                'note': 'python bench.py --workload c4 --steps 6 --warmup 2 on the same GPU (child process)'}
+    except Exception as e:                                   # the headline line must not depend on this extra
+        return {'error': repr(e)[:400]}
 
 
 # ------------------------------------------------------------------------------------------ c2
@@ -753,10 +781,13 @@ def cpu_baseline(conf, cube, luts, az, el, budget_s, n_samples=5):
             'host_cpus': os.cpu_count()}
 
 
-def _pool_leg(ctx, procs, az, budget_s, chunk, **pool_kw):
+def _pool_leg(ctx, procs, az, budget_s, chunk, first_result_timeout=45.0, **pool_kw):
     """Radials per second of a fork pool of `procs` workers, time-boxed: tasks are streamed with
     imap_unordered and the pool is terminated when the budget is used (so that a host on which
-    256 NumPy workers thrash the memory system still finishes)."""
+    256 NumPy workers thrash the memory system still finishes).  A leg whose first result does not
+    arrive in `first_result_timeout` seconds is given up (None)."""
+    import multiprocessing as mp
+
     def tasks():
         i = 0
         while True:
@@ -764,59 +795,111 @@ def _pool_leg(ctx, procs, az, budget_s, chunk, **pool_kw):
             i += 1
     t0 = time.perf_counter()
     pool = ctx.Pool(processes=procs, **pool_kw)
+    gates = n = 0
+    t1 = t2 = None
     try:
-        it = pool.imap_unordered(_pool_radial, tasks(), chunksize=chunk)
-        gates = n = 0
-        t1 = None
-        for g in it:
+        it = pool.imap_unordered(_pool_radial, tasks(), chunksize=1)     # (chunksize 1: next(timeout) exists)
+        while True:
+            try:
+                g = it.next(timeout=first_result_timeout if t1 is None else 20.0)
+            except mp.TimeoutError:
+                break
             now = time.perf_counter()
             if t1 is None:
-                t1, gates, n = now, 0, 0         # steady state starts at the first result
+                t1 = now                          # steady state starts at the first result
                 continue
             gates += g
             n += 1
+            t2 = now
             if now - t1 > budget_s:
                 break
-        t2 = time.perf_counter()
     finally:
         pool.terminate()
         pool.join()
+    if t1 is None or t2 is None or n == 0:
+        return None
     return {'gates_per_s': gates / max(t2 - t1, 1e-9), 'radials': n, 'seconds': t2 - t1,
             'startup_s': t1 - t0, 'gates_per_s_with_startup': gates / max(t2 - t0, 1e-9)}
 
 
-def cpu_baseline_pool(conf, cube, luts, az, el, radials_per_s_1core, budget_s=6.0):
-    """the same per-radial oracle under a fork pool mapped over azimuths, as
-    radar_operator.py:402,431, with P = os.cpu_count() processes (`value`, `cores`).  Every leg
-    is time-boxed (`budget_s` of steady state).  Also reported: the same with fewer workers
-    (NumPy's [n_valid, 1024, 12] float64 temporaries make the per-radial algorithm memory-bound
-    long before 256 cores are busy) and `reference_style` = one task per worker process,
-    Pool(P, maxtasksperchild=1), exactly as the reference creates its pool."""
+def cpu_pool_child(args):
+    """The all-core CPU legs, run in a FRESH interpreter (no torch, no GPU state, no threads to
+    inherit across fork) started by cpu_baseline_pool with a hard time limit.  SURVEY 8(d)(ii): the
+    per-radial oracle under a fork pool mapped over azimuths, as radar_operator.py:402,431, with
+    P = os.cpu_count() processes.  Also: fewer workers (NumPy's [n_valid, 1024, 12] float64
+    temporaries make the per-radial algorithm memory-bound long before 256 cores are busy) and
+    `reference_style` = Pool(P, maxtasksperchild=1), exactly as the reference creates its pool."""
     import multiprocessing as mp
+    from cosmo_pol_amd import synthetic
+    workload = args.workload if args.workload != 'auto' else 'c2'
+    conf = bench_config(args.small, workload)
+    hyds = hydrometeors_of(workload)
+    cube_h = tuple(h for h in hyds if h in ('R', 'S', 'G', 'I'))
+    if args.small:
+        cube = synthetic.small_test_cube(hydrometeors=cube_h)
+        luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
+    else:
+        cube = synthetic.make_cube(hydrometeors=cube_h, **synthetic.BENCH_GRID)
+        luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    az = np.arange(0, 360, 1.0)
+    budget_s = 6.0
     n_cpu = max(1, os.cpu_count() or 1)
     _POOL_STATE['inputs'] = _oracle_inputs(conf, cube, luts)     # inherited by fork, not pickled
-    _POOL_STATE['el'] = el
+    _POOL_STATE['el'] = 1.0 if workload == 'c2' else C4_ELEVATIONS[2]
     ctx = mp.get_context('fork')
     legs = {}
-    for procs in sorted({n_cpu, min(n_cpu, 64), min(n_cpu, 16)}, reverse=True):
+    for procs in sorted({n_cpu, min(n_cpu, 64), min(n_cpu, 16)}):       # small pools first
         print('[bench] CPU pool leg: %d worker processes ...' % procs, file=sys.stderr, flush=True)
         legs[procs] = _pool_leg(ctx, procs, az, budget_s, chunk=4)
+        print(json.dumps({'partial': {str(k): (v or {}).get('gates_per_s') for k, v in legs.items()}}), flush=True)
     print('[bench] CPU pool leg: reference style (a fork per radial) ...', file=sys.stderr, flush=True)
     ref = _pool_leg(ctx, n_cpu, az, min(budget_s, 4.0), chunk=1, maxtasksperchild=1)
-    _POOL_STATE.clear()
-    full = legs[n_cpu]
-    best_p = max(legs, key=lambda k: legs[k]['gates_per_s'])
-    return {'value': full['gates_per_s'], 'unit': 'gates/s', 'cores': n_cpu,
-            'sample': '%d radials in %.1f s of steady state, fork pool of %d persistent worker processes '
+    full = legs.get(n_cpu)
+    done = {k: v for k, v in legs.items() if v}
+    best_p = max(done, key=lambda k: done[k]['gates_per_s']) if done else None
+    out = {'value': full['gates_per_s'] if full else None, 'unit': 'gates/s', 'cores': n_cpu,
+           'sample': ('%d radials in %.1f s of steady state, fork pool of %d persistent worker processes '
                       '(P = os.cpu_count()), pool start-up %.1f s excluded'
-                      % (full['radials'], full['seconds'], n_cpu, full['startup_s']),
-            'with_pool_startup': full['gates_per_s_with_startup'],
-            'by_workers': {str(k): v['gates_per_s'] for k, v in sorted(legs.items())},
-            'best': {'workers': best_p, 'value': legs[best_p]['gates_per_s']},
-            'reference_style': {'value': ref['gates_per_s'],
-                                'sample': '%d radials in %.1f s, Pool(%d, maxtasksperchild=1) as '
-                                          'radar_operator.py:402,431 (a fork per radial)'
-                                          % (ref['radials'], ref['seconds'], n_cpu)}}
+                      % (full['radials'], full['seconds'], n_cpu, full['startup_s'])) if full
+                     else 'no result within the time box (P = %d workers)' % n_cpu,
+           'with_pool_startup': full['gates_per_s_with_startup'] if full else None,
+           'by_workers': {str(k): (v['gates_per_s'] if v else None) for k, v in sorted(legs.items())},
+           'best': {'workers': best_p, 'value': done[best_p]['gates_per_s']} if done else None,
+           'reference_style': {'value': ref['gates_per_s'],
+                               'sample': '%d radials in %.1f s, Pool(%d, maxtasksperchild=1) as '
+                                         'radar_operator.py:402,431 (a fork per radial)'
+                                         % (ref['radials'], ref['seconds'], n_cpu)} if ref else None}
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_pool(workload, small, limit_s=240.0):
+    """Runs cpu_pool_child in a child interpreter of its own session with a hard time limit; the
+    bench line never waits longer than `limit_s` for the all-core legs."""
+    import signal
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-pool-child', '--workload', workload]
+    if small:
+        cmd.append('--small')
+    print('[bench] CPU pool legs in a child interpreter (limit %.0f s) ...' % limit_s, file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, text=True, start_new_session=True,
+                         env=dict(os.environ, OMP_NUM_THREADS='1'))
+    try:
+        out, _ = p.communicate(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)          # the session this function started, nothing else
+        except OSError:
+            pass
+        out, _ = p.communicate()
+        lines = [ln for ln in (out or '').splitlines() if ln.startswith('{')]
+        part = json.loads(lines[-1]).get('partial') if lines else None
+        return {'value': None, 'unit': 'gates/s', 'cores': os.cpu_count(),
+                'error': 'all-core legs exceeded %.0f s and were stopped' % limit_s, 'by_workers': part}
+    lines = [ln for ln in (out or '').splitlines() if ln.startswith('{') and '"partial"' not in ln]
+    if p.returncode != 0 or not lines:
+        return {'value': None, 'unit': 'gates/s', 'cores': os.cpu_count(),
+                'error': 'child exited with %s' % p.returncode}
+    return json.loads(lines[-1])
 
 
 if __name__ == '__main__':

@@ -46,6 +46,7 @@ class HydroDesc(C.Structure):
         ('s_dmax', C.c_double),
         ('solid_rule', C.c_int32), ('uniform_grid', C.c_int32),
         ('numeric_intv', C.c_int32), ('tab_degree', C.c_int32),
+        ('pad_', C.c_int32), ('table_id', C.c_uint64),
     ]
 
 

@@ -36,6 +36,24 @@ struct DevBuf {
 
 enum { EV_T0 = 0, EV_TRAJ, EV_INTERP, EV_CLASSIFY, EV_BUCKET, EV_PSD, EV_FINAL, EV_N };
 
+// scattering table kept resident for a caller-supplied cpol_hydro_desc.table_id
+struct TableCacheEntry {
+    uint64_t id = 0;
+    size_t bytes = 0;
+    DevBuf buf;
+    uint64_t used = 0;
+};
+
+// integral tables kept for a caller-supplied cpol_hydro_desc.table_id
+struct ItabCacheEntry {
+    uint64_t id = 0;
+    int dop2 = 0;
+    DevBuf tab, head;
+    ItabDev t{};
+    double check = 0.0, check_at = 0.0;
+    uint64_t used = 0;          // build serial of the last use (LRU; entries of the current build are pinned)
+};
+
 }  // namespace
 
 struct cpol_ctx {
@@ -64,6 +82,10 @@ struct cpol_ctx {
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
     // integral tables (built on the device by build_itabs after staging; lanes share the parent's)
     DevBuf d_itab[CPOL_MAX_HYDRO], d_itab_head[CPOL_MAX_HYDRO], d_itab_M;
+    std::vector<ItabCacheEntry> itab_cache;
+    std::vector<TableCacheEntry> table_cache;  // staged scattering tables with a table_id
+    uint64_t table_clock = 0;
+    uint64_t itab_builds = 0;
     double itab_check_at[CPOL_MAX_HYDRO] = {};
     double itab_check[CPOL_MAX_HYDRO] = {};     // melting species: worst deviation at the check points (-1: table rejected)
     ItabSet its{};
@@ -178,6 +200,7 @@ int build_itabs(cpol_ctx *ctx)
     const bool enabled = !(getenv("CPOL_ITAB") && atoi(getenv("CPOL_ITAB")) == 0);   // read at every (re)build
     ctx->its = ItabSet{};
     ctx->itab_serial = ctx->lut_serial;
+    ctx->itab_builds++;
     if (!enabled) return CPOL_OK;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -215,6 +238,19 @@ int build_itabs(cpol_ctx *ctx)
         const bool ice = d.psd_family == CPOL_PSD_ICE_FIELD && d.uniform_grid && d.tab_degree == CPOL_ICE_DEGREE;
         const bool melt = d.psd_family == CPOL_PSD_MELTING && melt_enabled;
         if (!gamma && !ice && !melt) continue;
+        if (d.table_id) {
+            bool hit = false;
+            for (auto &e : ctx->itab_cache)
+                if (e.id == d.table_id && e.dop2 == (int)dop2) {
+                    ctx->its.t[j] = e.t;
+                    ctx->itab_check[j] = e.check;
+                    ctx->itab_check_at[j] = e.check_at;
+                    e.used = ctx->itab_builds;
+                    hit = true;
+                    break;
+                }
+            if (hit) continue;
+        }
         // lambda range: 2^-10 .. the lambda at which exp(-lambda D_0^nu) leaves the double range
         // (gamma), resp. the end of the ice normalisation tables
         double d0 = 0.0, lo = -10.0, hi = 15.0;
@@ -244,6 +280,30 @@ int build_itabs(cpol_ctx *ctx)
         const size_t tab_bytes = (size_t)n_slices * n_pan * (melt ? CPOL_ITAB2_NB : NC) * CPOL_ITAB_NFP * sizeof(double);
         DevBuf b_par, b_perm, b_units, b_tot, b_res, b_vn;
         int rc;
+        // destination: the slot's own buffers, or (table_id given) a cache entry of its own
+        ItabCacheEntry *ce = nullptr;
+        if (d.table_id) {
+            if (ctx->itab_cache.size() >= CPOL_ITAB_CACHE) {          // evict the least recently used
+                size_t victim = ctx->itab_cache.size();
+                for (size_t k = 0; k < ctx->itab_cache.size(); ++k)
+                    if (ctx->itab_cache[k].used != ctx->itab_builds &&
+                        (victim == ctx->itab_cache.size() || ctx->itab_cache[k].used < ctx->itab_cache[victim].used))
+                        victim = k;
+                if (victim < ctx->itab_cache.size()) {
+                    free_buf(ctx->itab_cache[victim].tab);
+                    free_buf(ctx->itab_cache[victim].head);
+                    ctx->itab_cache.erase(ctx->itab_cache.begin() + victim);
+                }
+            }
+            if (ctx->itab_cache.size() < CPOL_ITAB_CACHE) {
+                ctx->itab_cache.emplace_back();
+                ce = &ctx->itab_cache.back();
+                ce->id = d.table_id; ce->dop2 = (int)dop2; ce->used = ctx->itab_builds;
+            }
+        }
+        DevBuf &dst_tab = ce ? ce->tab : ctx->d_itab[j];
+        DevBuf &dst_head = ce ? ce->head : ctx->d_itab_head[j];
+        auto drop_entry = [&] { if (ce) { free_buf(ce->tab); free_buf(ce->head); ctx->itab_cache.pop_back(); ce = nullptr; } };
         if (melt) {
             // centre and 1 / half-width of the wet-fraction bins of the table's second axis; bin 0
             // reaches down to fw = 0 and the last bin up to 1 (lut.py:336-341 clips the index)
@@ -254,7 +314,7 @@ int build_itabs(cpol_ctx *ctx)
                 head[2 * b] = 0.5 * (blo + bhi);
                 head[2 * b + 1] = 1.0 / (0.5 * (bhi - blo));
             }
-            if ((rc = upload(ctx, ctx->d_itab_head[j], head.data(), head.size() * sizeof(double)))) return rc;
+            if ((rc = upload(ctx, dst_head, head.data(), head.size() * sizeof(double)))) { drop_entry(); return rc; }
             HIPCHK(hipStreamSynchronize(st));
         }
         if ((rc = ensure(ctx, b_par, (size_t)CPOL_MAX_PAR * n_items * sizeof(double))) ||
@@ -263,8 +323,9 @@ int build_itabs(cpol_ctx *ctx)
             (rc = ensure(ctx, b_tot, 4 * sizeof(long long))) ||
             (rc = ensure(ctx, b_res, (size_t)n_items * CPOL_N_SZ * sizeof(double))) ||
             (rc = ensure(ctx, b_vn, (size_t)n_items * 2 * sizeof(double))) ||
-            (rc = ensure(ctx, ctx->d_itab[j], tab_bytes))) {
+            (rc = ensure(ctx, dst_tab, tab_bytes))) {
             free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn);
+            drop_entry();
             return rc;
         }
         HIPCHK(hipMemsetAsync(b_vn.p, 0, (size_t)n_items * 2 * sizeof(double), st));
@@ -272,7 +333,7 @@ int build_itabs(cpol_ctx *ctx)
         ba.par = (double *)b_par.p; ba.perm = (int *)b_perm.p; ba.units = (WorkUnit *)b_units.p;
         ba.totals = (long long *)b_tot.p; ba.n_items = n_items; ba.n_slices = n_slices; ba.n_pan = n_pan;
         ba.key_base = h.key_base; ba.unit_items = unit_items; ba.log2_lo = lo; ba.ppo = ppo;
-        ba.two_d = melt ? 1 : 0; ba.n_t = d.n_t; ba.head = (const double *)ctx->d_itab_head[j].p;
+        ba.two_d = melt ? 1 : 0; ba.n_t = d.n_t; ba.head = (const double *)dst_head.p;
         hipLaunchKernelGGL(k_itab_nodes, dim3(cdiv(n_items > n_units ? n_items : n_units, 256)), dim3(256), 0, st, ba);
         // the slot's own kernels on the synthetic items (arrays of THIS slot only: the kernels
         // index [n_hydro][...][n] arrays with the slot number, hence the shifted bases)
@@ -313,7 +374,7 @@ int build_itabs(cpol_ctx *ctx)
         if (melt) {
             ItabFit2Args fa{};
             fa.res = (const double *)b_res.p; fa.vn = (const double *)b_vn.p;
-            fa.M = (const double *)ctx->d_itab_M.p; fa.tab = (double *)ctx->d_itab[j].p;
+            fa.M = (const double *)ctx->d_itab_M.p; fa.tab = (double *)dst_tab.p;
             fa.n_blocks = (long)n_slices * n_pan;
             fa.worst = (unsigned long long *)b_tot.p + 3;
             HIPCHK(hipMemsetAsync(fa.worst, 0, sizeof(unsigned long long), st));
@@ -323,7 +384,7 @@ int build_itabs(cpol_ctx *ctx)
         } else {
             ItabFitArgs fa{};
             fa.res = (const double *)b_res.p; fa.vn = (const double *)b_vn.p; fa.par = (const double *)b_par.p;
-            fa.M = (const double *)ctx->d_itab_M.p; fa.tab = (double *)ctx->d_itab[j].p;
+            fa.M = (const double *)ctx->d_itab_M.p; fa.tab = (double *)dst_tab.p;
             fa.n_items = n_items; fa.n_slices = n_slices; fa.n_pan = n_pan; fa.log2_lo = lo; fa.d0 = gamma ? d0 : 0.0;
             hipLaunchKernelGGL(k_itab_fit, dim3(cdiv((long)n_slices * n_pan * CPOL_ITAB_NF, 256)), dim3(256), 0, st, fa);
         }
@@ -331,6 +392,7 @@ int build_itabs(cpol_ctx *ctx)
         free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn);
         if (e != hipSuccess || hipGetLastError() != hipSuccess) {
             ctx->err = "build_itabs: a kernel failed";
+            drop_entry();
             return CPOL_ERR_HIP;
         }
         if (melt) {
@@ -343,12 +405,12 @@ int build_itabs(cpol_ctx *ctx)
             // the polynomial does not reproduce the integrating kernel between the nodes (wet-fraction
             // bins too wide for the degree: coarse test tables): this species stays on the integrating path
             ctx->itab_check[j] = -worst;
-            free_buf(ctx->d_itab[j]);
+            if (ce) drop_entry(); else free_buf(ctx->d_itab[j]);
             continue;
         }
         ItabDev &t = ctx->its.t[j];
-        t.tab = (const double *)ctx->d_itab[j].p;
-        t.head = melt ? (const double *)ctx->d_itab_head[j].p : nullptr;
+        t.tab = (const double *)dst_tab.p;
+        t.head = melt ? (const double *)dst_head.p : nullptr;
         t.log2_lo = lo;
         t.d0 = gamma ? d0 : 0.0;
         t.n_pan = n_pan;
@@ -357,6 +419,7 @@ int build_itabs(cpol_ctx *ctx)
         t.two_d = melt ? 1 : 0;
         t.par_slot = melt ? 2 : 0;
         t.n_t = d.n_t;
+        if (ce) { ce->t = t; ce->check = ctx->itab_check[j]; ce->check_at = ctx->itab_check_at[j]; }
     }
     return CPOL_OK;
 }
@@ -415,6 +478,10 @@ void cpol_destroy(cpol_ctx *ctx)
     for (auto &b : ctx->d_tfun) free_buf(b);
     for (auto &b : ctx->d_itab) free_buf(b);
     for (auto &b : ctx->d_itab_head) free_buf(b);
+    for (auto &e : ctx->itab_cache) { free_buf(e.tab); free_buf(e.head); }
+    ctx->itab_cache.clear();
+    for (auto &e : ctx->table_cache) free_buf(e.buf);
+    ctx->table_cache.clear();
     free_buf(ctx->d_itab_M);
     for (int i = 0; i < 3; ++i) {
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
@@ -685,10 +752,44 @@ int cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc, const
     const size_t tb = (size_t)desc->n_e * desc->n_t * desc->n_d * CPOL_N_SZ * sizeof(double);
     const size_t db = (size_t)desc->n_d * sizeof(double);
     int rc;
-    if ((rc = upload(ctx, ctx->d_table[slot], table, tb)) != CPOL_OK) return rc;
     HydroDev &h = ctx->hs.h[slot];
+    const double *dev_table = nullptr;
+    if (desc->table_id) {
+        // the scattering table of a known identity stays resident (CPOL_ITAB_CACHE most recent):
+        // a switch back to a table set seen before uploads only the small per-bin arrays
+        for (auto &e : ctx->table_cache)
+            if (e.id == desc->table_id && e.bytes == tb) { dev_table = (const double *)e.buf.p; e.used = ++ctx->table_clock; break; }
+        if (!dev_table) {
+            if (ctx->table_cache.size() >= CPOL_ITAB_CACHE) {
+                // evict the least recently used entry that no staged slot points at
+                size_t victim = ctx->table_cache.size();
+                for (size_t k = 0; k < ctx->table_cache.size(); ++k) {
+                    bool live = false;
+                    for (int q = 0; q < CPOL_MAX_HYDRO; ++q)
+                        live = live || (q != slot && ctx->hydro_staged[q] && ctx->hs.h[q].table == ctx->table_cache[k].buf.p);
+                    if (!live && (victim == ctx->table_cache.size() || ctx->table_cache[k].used < ctx->table_cache[victim].used))
+                        victim = k;
+                }
+                if (victim < ctx->table_cache.size()) {
+                    free_buf(ctx->table_cache[victim].buf);
+                    ctx->table_cache.erase(ctx->table_cache.begin() + victim);
+                }
+            }
+            if (ctx->table_cache.size() < CPOL_ITAB_CACHE) {
+                ctx->table_cache.emplace_back();
+                TableCacheEntry &e = ctx->table_cache.back();
+                if ((rc = upload(ctx, e.buf, table, tb)) != CPOL_OK) { ctx->table_cache.pop_back(); return rc; }
+                e.id = desc->table_id; e.bytes = tb; e.used = ++ctx->table_clock;
+                dev_table = (const double *)e.buf.p;
+            }
+        }
+    }
+    if (!dev_table) {
+        if ((rc = upload(ctx, ctx->d_table[slot], table, tb)) != CPOL_OK) return rc;
+        dev_table = (const double *)ctx->d_table[slot].p;
+    }
     h.d = *desc;
-    h.table = (const double *)ctx->d_table[slot].p;
+    h.table = dev_table;
     h.pre = h.dnu = h.aux = nullptr;
     h.rcsw = nullptr;
     ctx->ss.s[slot] = SpecDev{};

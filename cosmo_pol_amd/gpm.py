@@ -161,12 +161,13 @@ class SimulatedGPM(object):
         # kept gates (not below the topography), flipped so that index 0 is the lowest one
         keep = inside & (mask > -1)
         n = keep.sum(axis=1)
-        dest = (n[:, None] - np.cumsum(keep, axis=1))[keep]
-        rows = np.nonzero(keep)[0]
+        src_idx = np.flatnonzero(keep)                                   # flat source index of every kept gate
+        dest = (n[:, None] - np.cumsum(keep, axis=1, dtype=np.int32)).reshape(-1)[src_idx]
+        dst_idx = (src_idx // n_gates) * n_gates + dest                  # flat destination (beam flipped)
 
         def pack(src, fill):
-            out = np.full((n_rays, n_gates), fill, dtype=np.float64)
-            out[rows, dest] = src[keep]
+            out = np.full(n_rays * n_gates, fill, dtype=np.float64)
+            out[dst_idx] = np.asarray(src).reshape(-1)[src_idx]
             return out.reshape(N, M, n_gates)
         self.lats = pack(lats, np.nan)
         self.lons = pack(lons, np.nan)

@@ -121,7 +121,17 @@ typedef struct {
                                    1-moment ice (CPOL_ICE_DEGREE): per panel in log2(lambda),
                                    polynomials of the three normalisation sums (which depend on
                                    lambda only).  See cpol_stage_hydro                     */
+    int32_t pad_;
+    uint64_t table_id;          /* 0, or a caller-chosen identity of EVERYTHING staged for this
+                                   slot (descriptor, table, per-bin factors, aux, Doppler
+                                   weights): the integral tables built for an id are kept (the
+                                   CPOL_ITAB_CACHE most recent) and reused when a slot with the
+                                   same id is staged again -- a caller that switches between a
+                                   few table sets (Ku / Ka / ground radar, get_GPM_swath) pays
+                                   for their construction once.  Equal ids must mean equal
+                                   content                                                 */
 } cpol_hydro_desc;
+#define CPOL_ITAB_CACHE 24
 
 #define CPOL_MELT_DEGREE 10     /* degree of those polynomials (11 coefficients)           */
 #define CPOL_MELT_FUNCS  4      /* D_r, G, G*M, G*V                                        */
