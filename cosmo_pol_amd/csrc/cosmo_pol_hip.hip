@@ -1263,8 +1263,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ca.vals = (float *)ctx->b_vals.p;
     ca.mask = (const signed char *)ctx->b_mask.p;
     ca.elev = (const float *)ctx->b_elev.p;
-    ca.q_melt = (float *)ctx->b_qmelt.p;
-    ca.fw_melt = (double *)ctx->b_fwmelt.p;
+    ca.q_melt = ctx->keep_debug ? (float *)ctx->b_qmelt.p : nullptr;
+    ca.fw_melt = ctx->keep_debug ? (double *)ctx->b_fwmelt.p : nullptr;
     ca.key = (int *)ctx->b_key.p;
     ca.pos = (int *)ctx->b_pos.p;
     ca.par = (double *)ctx->b_par.p;

@@ -268,7 +268,7 @@ struct ClassifyArgs {
     float *vals;                 // [n_vars][n_sbg] (QR/QS/QG zeroed in place by melting)
     const signed char *mask;
     const float *elev;           // folded
-    float *q_melt;               // [2][n_sbg] QmS_v, QmG_v (float32 values)
+    float *q_melt;               // [2][n_sbg] QmS_v, QmG_v (float32 values); NULL unless debug reads are enabled
     double *fw_melt;             // [2][n_sbg] fwet_mS, fwet_mG
     int *key;                    // [n_hydro][n_sbg]
     int *pos;                    // [n_hydro][n_sbg] position inside the bucket
@@ -298,6 +298,11 @@ __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &ou
 #define CPOL_MAX_PAR 6
 
 #define CPOL_CLASSIFY_THREADS (CPOL_RANK_WAVES * CPOL_WAVE)
+// (Measured and dropped: finishing the table items inside this kernel -- the lookup fused in, the
+// parameters never leaving the registers, 2 GB less HBM traffic on the C4 sweep -- took 3.35 ms
+// against 0.69 ms + 2.21 ms for k_classify + k_psd_lookup: the lookup is bound by the vector-L1
+// gather, not by HBM, and inside the 16-wave ranking workgroups it spills; 4- and 8-wave
+// workgroups 3.6 / 4.5 ms.)
 __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs, ItabSet its, ClassifyArgs a)
 {
     // one LDS ranking table per hydrometeor: all global atomics of the workgroup are
@@ -330,10 +335,12 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             fws = (double)(qr * qs / qsg) / (double)qms;
             fwg = (double)(qr * qg / qsg) / (double)qmg;
         }
-        a.q_melt[i] = qms;
-        a.q_melt[n + i] = qmg;
-        a.fw_melt[i] = fws;
-        a.fw_melt[n + i] = fwg;
+        if (a.q_melt) {                               // parity access for the tests (debug mode only)
+            a.q_melt[i] = qms;
+            a.q_melt[n + i] = qmg;
+            a.fw_melt[i] = fws;
+            a.fw_melt[n + i] = fwg;
+        }
     }
     const float e = in ? a.elev[i] : 0.f;
     for (int j = 0; j < hs.n_hydro; ++j) {
