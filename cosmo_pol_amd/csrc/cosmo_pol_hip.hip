@@ -110,7 +110,7 @@ struct cpol_ctx {
     DevBuf b_traj, b_wgate, b_clk;
     DevBuf b_beam, b_spectrum, b_outwin;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
-        b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel;
+        b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel, b_proj;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
@@ -497,7 +497,7 @@ void cpol_destroy(cpol_ctx *ctx)
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_units,
                      &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_pos,
-                     &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel,
+                     &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel, &ctx->b_proj,
                      &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model};
     for (DevBuf *b : all) free_buf(*b);
     for (auto &b : ctx->b_out) free_buf(b);
@@ -1562,6 +1562,14 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ra.RVEL = (double *)T[O_RVEL];       // censored with the other observables in k_final
     }
     if ((size_t)3 * ng * sizeof(float) > 64 * 1024) { ctx->err = "cpol_run_sweep: n_gates too large for the range scans (3 * n_gates floats of LDS)"; return CPOL_ERR_ARG; }
+    fa.proj = nullptr;
+    if (fa.RVEL && n_sub >= 4) {
+        // the per-sub-beam velocity terms by one thread per sub-beam gate (k_final adds them in order)
+        ENSURE(ctx->b_proj, (size_t)n_sbg * sizeof(double));
+        hipLaunchKernelGGL(k_rvel_terms, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256), 0, st,
+                           fa, (double *)ctx->b_proj.p);
+        fa.proj = (const double *)ctx->b_proj.p;
+    }
     hipLaunchKernelGGL(k_final, dim3(n_rays), dim3(CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
     HIPCHK(hipGetLastError());

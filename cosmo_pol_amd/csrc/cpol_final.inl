@@ -143,12 +143,63 @@ struct FinalArgs {
     const float *elev;          // folded elevation per sub-beam gate (quirk Q8)
     int n_h, var_u, var_v, var_w;
     int vsrc[CPOL_MAX_HYDRO];   // 0: par (analytic), 1: vn per gate, 2: ice (first valid gate)
+    const double *proj;         // [n_sbg] subbeam_proj of every sub-beam gate (k_rvel_terms) or NULL: evaluated in place
     const double *nyquist;      // [n_rays] or NULL
     const double *wgate;        // [n_sbg] per-gate sub-beam weights (scheme 'ml') or NULL
 };
 
 // one output gate; returns the operands of the three range scans (2 KDP with NaN -> 0, and
 // the two-way attenuation factors of the gate, NaN -> 1)
+// Radial velocity seen by one sub-beam at one gate (doppler_scatter.py:276-281, 313-333;
+// proj_vel :46-47): mean fall speed of the hydrometeors present, wind projected on the beam.
+__device__ __forceinline__ double subbeam_proj(const FinalArgs &a, int ray, int s, int gate, long sbg, long n_sbg)
+{
+    double v = 0.0, nn = 0.0;
+    for (int j = 0; j < a.n_hydro; ++j) {
+        if (a.key[(long)j * n_sbg + sbg] < 0) continue;
+        double vj, nj;
+        if (a.vsrc[j] == 0) {
+            const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n_sbg + sbg;
+            vj = P[2 * n_sbg]; nj = P[3 * n_sbg];
+        } else if (a.vsrc[j] == 1) {
+            vj = a.vn[((long)j * n_sbg + sbg) * 2];
+            nj = a.vn[((long)j * n_sbg + sbg) * 2 + 1];
+        } else {
+            const IceFirst f = a.ice_first[(long)ray * a.n_sub + s];
+            const bool here = (f.first_gate == gate);
+            vj = here ? f.v : 0.0;
+            nj = here ? f.n : 0.0;
+        }
+        if (vj == vj) v += vj;                  // nansum_arr
+        if (nj == nj) nn += nj;
+    }
+    const double vh = v / nn;
+    const double *gc = a.geo + ((long)ray * a.n_h + a.sub_h[s]) * 8;
+    const float th = a.elev[sbg] * 0.017453292f;          // np.deg2rad on float32
+    const double ct = (double)(float)cos((double)th), st = (double)(float)sin((double)th);
+    const double U = (double)a.vals[(long)a.var_u * n_sbg + sbg];
+    const double V = (double)a.vals[(long)a.var_v * n_sbg + sbg];
+    const double W = (double)a.vals[(long)a.var_w * n_sbg + sbg];
+    return (U * gc[0] + V * gc[1]) * ct + (W - vh) * st;
+}
+
+// With many sub-beams the terms above are evaluated by one thread per sub-beam gate first (a
+// thread of k_final would walk n_sub x n_hydro dependent loads: 0.53 of its 1.13 ms on the C4
+// sweep); k_final then adds them in the reference's order.
+__global__ __launch_bounds__(256) void k_rvel_terms(FinalArgs a, double *__restrict__ out)
+{
+    const int rs = blockIdx.x;                            // ray * n_sub + sub
+    const int gate = blockIdx.y * blockDim.x + threadIdx.x;
+    if (gate >= a.n_gates) return;
+    const int ray = rs / a.n_sub, s = rs % a.n_sub;
+    const long n_sbg = (long)a.n_rays * a.n_sub * a.n_gates;
+    const long sbg = (long)rs * a.n_gates + gate;
+    out[sbg] = subbeam_proj(a, ray, s, gate, sbg, n_sbg);
+}
+
+#ifndef CPOL_SKIP_RVEL
+#define CPOL_SKIP_RVEL 0      // experiment knob (tools/variants.sh): time of the RVEL loop
+#endif
 #ifndef CPOL_FINAL_BATCH
 #define CPOL_FINAL_BATCH 2
 #endif
@@ -259,37 +310,11 @@ __device__ __forceinline__ void final_gate(const FinalArgs &a, int ray, int gate
     a.DELTA_HV[rg] = (float)atan2((double)(tot[5] - tot[6]), (double)(-tot[4] - tot[7]));
 
     // ---- radial velocity, Doppler scheme 1 (doppler_scatter.py:276-281, 313-333, 418-420) ----
-    if (a.RVEL) {
+    if (a.RVEL && !CPOL_SKIP_RVEL) {
         double rv = __builtin_nan(""), tw = 0.0;
         for (int s = 0; s < a.n_sub; ++s) {
             const long sbg = sbg0 + (long)s * a.n_gates;
-            double v = 0.0, nn = 0.0;
-            for (int j = 0; j < a.n_hydro; ++j) {
-                if (a.key[(long)j * n_sbg + sbg] < 0) continue;
-                double vj, nj;
-                if (a.vsrc[j] == 0) {
-                    const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n_sbg + sbg;
-                    vj = P[2 * n_sbg]; nj = P[3 * n_sbg];
-                } else if (a.vsrc[j] == 1) {
-                    vj = a.vn[((long)j * n_sbg + sbg) * 2];
-                    nj = a.vn[((long)j * n_sbg + sbg) * 2 + 1];
-                } else {
-                    const IceFirst f = a.ice_first[(long)ray * a.n_sub + s];
-                    const bool here = (f.first_gate == gate);
-                    vj = here ? f.v : 0.0;
-                    nj = here ? f.n : 0.0;
-                }
-                if (vj == vj) v += vj;                  // nansum_arr
-                if (nj == nj) nn += nj;
-            }
-            const double vh = v / nn;
-            const double *gc = a.geo + ((long)ray * a.n_h + a.sub_h[s]) * 8;
-            const float th = a.elev[sbg] * 0.017453292f;          // np.deg2rad on float32
-            const double ct = (double)(float)cos((double)th), st = (double)(float)sin((double)th);
-            const double U = (double)a.vals[(long)a.var_u * n_sbg + sbg];
-            const double V = (double)a.vals[(long)a.var_v * n_sbg + sbg];
-            const double W = (double)a.vals[(long)a.var_w * n_sbg + sbg];
-            const double proj = (U * gc[0] + V * gc[1]) * ct + (W - vh) * st;   // proj_vel :46-47
+            const double proj = a.proj ? a.proj[sbg] : subbeam_proj(a, ray, s, gate, sbg, n_sbg);
             const double w = a.wgate ? a.wgate[sbg] : a.sub_w[s];
             if (proj == proj) tw += w;
             double x = (rv == rv) ? rv : 0.0;
