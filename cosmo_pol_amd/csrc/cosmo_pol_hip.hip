@@ -1742,6 +1742,14 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     if (!ctx || !name) return CPOL_ERR_ARG;
     if (!strcmp(name, "enable")) { ctx->keep_debug = true; return 0; }
     if (!strcmp(name, "disable")) { ctx->keep_debug = false; return 0; }
+    if (!strcmp(name, "cache")) {
+        // [integral-table cache entries, scattering-table cache entries, integral-table builds] (table_id)
+        const cpol_ctx *own = ctx->parent ? ctx->parent : ctx;
+        const double v[3] = {(double)own->itab_cache.size(), (double)own->table_cache.size(), (double)own->itab_builds};
+        if (!dst || max_bytes < (int64_t)sizeof v) return CPOL_ERR_ARG;
+        memcpy(dst, v, sizeof v);
+        return (int64_t)sizeof v;
+    }
     if (!strcmp(name, "itab_check")) {
         // per hydrometeor slot: worst |polynomial - integrating kernel| / |value| over the check points
         // of its 2-D integral table (melting species); negative: table rejected; 0: no such table

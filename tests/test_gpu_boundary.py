@@ -210,3 +210,31 @@ def test_integral_tables_take_the_items_and_the_integrating_kernels_stay_pinned(
                          capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert '3 passed' in out.stdout, out.stdout[-500:]
+
+
+def test_table_sets_stay_resident_across_configuration_switches():
+    """cpol_hydro_desc.table_id: the operator names every slot of a cached table set; switching
+    the radar frequency and back (what get_GPM_swath does twice per call) finds the scattering
+    tables and their integral tables still on the device -- no new cache entry, identical results."""
+    op, _, _, _ = _op('c2_rsg')
+    az = np.arange(0., 360., 45.)
+    el = np.full(len(az), 4.0)
+    r1 = {k: np.array(v, copy=True) for k, v in op.simulate_rays(az, el).items() if isinstance(v, np.ndarray)}
+    c1 = op._ctx.debug_read('cache', (3,), np.float64)
+    assert c1[0] == 3 and c1[1] == 3                      # R, S, G: one entry each
+    conf = op.config
+    conf['radar']['frequency'] = 13.6
+    op.config = conf
+    r2 = op.simulate_rays(az, el)
+    c2 = op._ctx.debug_read('cache', (3,), np.float64)
+    assert c2[0] == 6 and c2[1] == 6
+    assert np.isfinite(r2['ZH']).any()
+    conf = op.config
+    conf['radar']['frequency'] = 5.6
+    op.config = conf
+    r3 = op.simulate_rays(az, el)
+    c3 = op._ctx.debug_read('cache', (3,), np.float64)
+    assert c3[0] == 6 and c3[1] == 6                      # nothing new was built or uploaded
+    for k in ('ZH', 'ZDR', 'KDP', 'RHOHV', 'PHIDP', 'ATT_H', 'RVEL'):
+        assert np.array_equal(r3[k], r1[k], equal_nan=True), k
+    op.close()
