@@ -1723,8 +1723,13 @@ __device__ __forceinline__ double itab2_quarter_sum(const double *c, int r, doub
 //     (a wavefront of 64 neighbouring gates spans ~7 distinct blocks, so the walk repeats)
 //   this form                                                                  ~23 us / 1.1 ms
 //   this form with the lanes of a wavefront on 8 neighbouring rays x 8 gates (2-3 distinct
-//     blocks per wavefront instead of ~7): no change -- the 1056 B per lane through the
-//     vector L1 (64 B / clk / CU) bound the kernel, not the number of distinct lines
+//     blocks per wavefront instead of ~7): no change
+//   the distinct blocks of the wavefront fetched once into LDS, rows gathered from LDS per lane
+//     (bank-disjoint slots): no change (1.28 ms for the 15.1 M 1-D items of the C4 sweep)
+//   keys of all species read first, parameters of species j + 1 requested before species j is
+//     evaluated: no change (1.26 ms)
+//   -> what is left is the issue rate of the 66-77 16-B gather instructions per wavefront and
+//     species (~16 cycles each in the texture-address path, whatever the addresses), 84 ps per item
 //
 // 2-D blocks (melting species): 66 rows of 128 B per block and neighbouring gates hardly ever
 // share one (the wet fraction crosses a 0.01-wide bin of the table per gate).  One lane per item
