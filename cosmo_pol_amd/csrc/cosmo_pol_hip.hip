@@ -1145,7 +1145,18 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
            O_DIST, O_HGT, O_RVEL, O_MODEL, O_SZT, O_SPEC, O_N };
     const bool dev = p->outputs_on_device == 1;
     const bool async_host = p->outputs_on_device == 2;    // pinned host buffers, no wait
-    const bool want_szi = ctx->keep_debug;
+    // the sub-beam sums by one thread per (gate, hydrometeor) with the 1-D table items evaluated in
+    // place (k_subbeam_sum); CPOL_SUBSUM=0: k_psd_lookup stores them and k_final walks the rows
+    static const bool subsum_enabled = !(getenv("CPOL_SUBSUM") && atoi(getenv("CPOL_SUBSUM")) == 0);
+    bool subsum = subsum_enabled;
+    {
+        bool any1d = false;
+        for (int j = 0; j < n_hyd; ++j) any1d = any1d || (ctx->its.t[j].tab && !ctx->its.t[j].two_d);
+        // (not with Doppler scheme 3: k_spec_atten reads every item's columns from res[]; with one
+        // sub-beam there is nothing to accumulate and the extra launch costs more than it saves)
+        subsum = subsum && any1d && !dop3 && n_sub >= 4;
+    }
+    const bool want_szi = ctx->keep_debug || subsum;
     if (want_szi) ENSURE(ctx->b_szinteg, (size_t)n_rg * n_hyd * CPOL_N_SZ * sizeof(float));
     const bool want_szt = out->sz_total != nullptr || ctx->keep_debug;
     const bool want_model = p->integrate_model && out->model_vars;
@@ -1340,6 +1351,15 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             la.res = (double *)ctx->b_res.p;
             la.vn = doppler ? (double *)ctx->b_vn.p : nullptr;
             la.n_sbg = n_sbg;
+            la.skip_res_1d = subsum ? 1 : 0;
+            bool launch = !subsum;              // with k_subbeam_sum: only for 2-D tables, vn and the ice intercept
+            for (int j = 0; j < n_hyd && !launch; ++j) {
+                const ItabDev &tj = ctx->its.t[j];
+                if (!tj.tab) continue;
+                launch = tj.two_d || (la.vn && tj.writes_vn) ||
+                         (la.par_w && ctx->hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD);
+            }
+            if (launch)
             hipLaunchKernelGGL(k_psd_lookup, dim3(cdiv(n_sbg, CPOL_LOOKUP_THREADS)), dim3(CPOL_LOOKUP_THREADS), 0, st, ctx->hs, ctx->its, la);
         }
     }
@@ -1562,6 +1582,20 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ra.RVEL = (double *)T[O_RVEL];       // censored with the other observables in k_final
     }
     if ((size_t)3 * ng * sizeof(float) > 64 * 1024) { ctx->err = "cpol_run_sweep: n_gates too large for the range scans (3 * n_gates floats of LDS)"; return CPOL_ERR_ARG; }
+    fa.pre_integ = 0;
+    if (subsum) {
+        SubsumArgs sa2{};
+        sa2.key = (const int *)ctx->b_key.p;
+        sa2.par = (const double *)ctx->b_par.p;
+        sa2.res = (const double *)ctx->b_res.p;
+        sa2.sub_w = (const double *)ctx->v_subw;
+        sa2.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
+        sa2.sz_integ = (float *)ctx->b_szinteg.p;
+        sa2.n_rays = n_rays; sa2.n_gates = ng; sa2.n_sub = n_sub; sa2.n_hydro = n_hyd;
+        hipLaunchKernelGGL(k_subbeam_sum, dim3(cdiv(n_rg, 256), n_hyd), dim3(256), 0, st, ctx->hs, ctx->its, sa2);
+        fa.sz_integ = (float *)ctx->b_szinteg.p;
+        fa.pre_integ = 1;
+    }
     fa.proj = nullptr;
     if (fa.RVEL && n_sub >= 4) {
         // the per-sub-beam velocity terms by one thread per sub-beam gate (k_final adds them in order)

@@ -124,6 +124,7 @@ struct FinalArgs {
     const float *vals;          // [n_vars][n_sbg]
     const double *sub_w;        // [n_sub]
     float *sz_integ;            // [n_rg][n_hydro][12] or NULL
+    int pre_integ;              // sz_integ already holds the sub-beam sums (k_subbeam_sum)
     float *sz_total;            // [n_rg][12] or NULL
     float *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *RHOHV, *ATT_H, *ATT_V;   // work / outputs
     double *mask;               // [n_rg]
@@ -197,6 +198,76 @@ __global__ __launch_bounds__(256) void k_rvel_terms(FinalArgs a, double *__restr
     out[sbg] = subbeam_proj(a, ray, s, gate, sbg, n_sbg);
 }
 
+// Sub-beam accumulation of one (output gate, hydrometeor) per thread (doppler_scatter.py:133-134,
+// 259-268: nansum of [float32 acc, float64 term] stored back as float32, sub-beams in order).  The
+// items on a 1-D integral table are EVALUATED here (their 12 columns never go through memory:
+// k_psd_lookup wrote 96 B per item and k_final read them back -- 2.9 GB of the 9.8 GB a C4 sweep
+// moved); items of the melting species and items integrated bin by bin are read from res[].
+struct SubsumArgs {
+    const int *key;             // [n_hydro][n_sbg]
+    const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg]
+    const double *res;          // [n_hydro][n_sbg][12]
+    const double *sub_w;        // [n_sub]
+    const double *wgate;        // [n_sbg] or NULL (scheme 'ml')
+    float *sz_integ;            // [n_rg][n_hydro][12]
+    int n_rays, n_gates, n_sub, n_hydro;
+};
+
+__global__ __launch_bounds__(256) void k_subbeam_sum(HydroSet hs, ItabSet its, SubsumArgs a)
+{
+    constexpr int NB = CPOL_ITAB_NC * CPOL_ITAB_NFP;
+    const long n_rg = (long)a.n_rays * a.n_gates;
+    const long rg = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (rg >= n_rg) return;
+    const int ray = (int)(rg / a.n_gates), gate = (int)(rg % a.n_gates);
+    const long n_sbg = n_rg * a.n_sub;
+    const long sbg0 = (long)ray * a.n_sub * a.n_gates + gate;
+    const ItabDev &t = its.t[j];
+    const bool tab1 = t.tab && !t.two_d;                                 // uniform
+    const bool ice = hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD;
+    const int key_base = hs.h[j].key_base;
+    const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n_sbg;
+    double wtot = 0.0;
+    if (a.wgate)
+        for (int s = 0; s < a.n_sub; ++s) wtot += a.wgate[sbg0 + (long)s * a.n_gates];
+    float acc[CPOL_N_SZ];
+#pragma unroll
+    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = __builtin_nanf("");
+    for (int s = 0; s < a.n_sub; ++s) {
+        const long sbg = sbg0 + (long)s * a.n_gates;
+        const int key = a.key[(long)j * n_sbg + sbg];
+        if (key < 0) continue;
+        const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
+        double2 v[CPOL_N_SZ / 2];
+        const double pf = tab1 ? P[4 * n_sbg + sbg] : -1.0;
+        if (pf >= 0.0) {
+            const int pn = min((int)pf, t.n_pan - 1);
+            const double u = 2.0 * (pf - (double)pn) - 1.0;
+            const double scale = ice ? P[2 * n_sbg + sbg] : P[n_sbg + sbg] * cp_exp(-(P[sbg] * t.d0));
+            itab1_columns(reinterpret_cast<const double2 *>(t.tab + ((long)(key - key_base) * t.n_pan + pn) * NB),
+                          u, scale, v);
+        } else {
+            const double2 *r = reinterpret_cast<const double2 *>(a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ);
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = r[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) {
+            // nansum([float32 acc, float64 term]) stored back as float32
+            double y = ((c & 1) ? v[c / 2].y : v[c / 2].x) * w;
+            double x = (double)acc[c];
+            if (!(x == x)) x = 0.0;
+            if (!(y == y)) y = 0.0;
+            acc[c] = (float)(x + y);
+        }
+    }
+    float4 *o = reinterpret_cast<float4 *>(a.sz_integ + (rg * a.n_hydro + j) * CPOL_N_SZ);
+#pragma unroll
+    for (int c4 = 0; c4 < CPOL_N_SZ / 4; ++c4)
+        o[c4] = make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
+}
+
 #ifndef CPOL_SKIP_RVEL
 #define CPOL_SKIP_RVEL 0      // experiment knob (tools/variants.sh): time of the RVEL loop
 #endif
@@ -222,6 +293,14 @@ __device__ __forceinline__ void final_gate(const FinalArgs &a, int ray, int gate
         float acc[CPOL_N_SZ];
 #pragma unroll
         for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = qnan;
+        if (a.pre_integ) {
+            const float4 *pi = reinterpret_cast<const float4 *>(a.sz_integ + (rg * a.n_hydro + j) * CPOL_N_SZ);
+#pragma unroll
+            for (int c4 = 0; c4 < CPOL_N_SZ / 4; ++c4) {
+                const float4 q4 = pi[c4];
+                acc[4 * c4] = q4.x; acc[4 * c4 + 1] = q4.y; acc[4 * c4 + 2] = q4.z; acc[4 * c4 + 3] = q4.w;
+            }
+        } else
         // sub-beams in groups of CPOL_FINAL_BATCH: the keys and the result rows of a group are read
         // before the first of them is used (independent loads in flight: a thread walks
         // n_hydro x n_sub rows, 294 with 7x7 sub-beams), the float32 accumulation keeps its order.
@@ -260,7 +339,7 @@ __device__ __forceinline__ void final_gate(const FinalArgs &a, int ray, int gate
                 }
             }
         }
-        if (a.sz_integ) {
+        if (a.sz_integ && !a.pre_integ) {
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c)
                 a.sz_integ[(rg * a.n_hydro + j) * CPOL_N_SZ + c] = acc[c];

@@ -1673,6 +1673,8 @@ struct LookupArgs {
     double *res;                // [n_hydro][n_sbg][12]
     double *vn;                 // [n_hydro][n_sbg][2] or NULL
     long n_sbg;
+    int skip_res_1d;            // the 12 columns of the 1-D species are evaluated by k_subbeam_sum instead
+                                // (nothing of them is stored); only vn / the ice intercept are written here
 };
 
 __device__ __forceinline__ double readlane_f64(double v, int src_uniform)
@@ -1708,6 +1710,25 @@ __device__ __forceinline__ double itab2_quarter_sum(const double *c, int r, doub
         acc = fma(acc, w4, inner);
     }
     return acc * ((r & 1 ? wi : 1.0) * (r & 2 ? w2 : 1.0));
+}
+
+// the 12 integrated columns of an item from its 1-D block (c) at panel position u, times its scale
+__device__ __forceinline__ void itab1_columns(const double2 *c, double u, double scale, double2 (&v)[CPOL_N_SZ / 2])
+{
+    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
+#pragma unroll
+    for (int f = 0; f < CPOL_N_SZ / 2; ++f) v[f] = c[(NC - 1) * (NFP / 2) + f];
+#pragma unroll
+    for (int q = NC - 2; q >= 0; --q) {
+#pragma unroll
+        for (int f = 0; f < CPOL_N_SZ / 2; ++f) {
+            const double2 cq = c[q * (NFP / 2) + f];
+            v[f].x = fma(v[f].x, u, cq.x);
+            v[f].y = fma(v[f].y, u, cq.y);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < CPOL_N_SZ / 2; ++f) { v[f].x *= scale; v[f].y *= scale; }
 }
 
 // 1-D blocks (gamma family, 1-moment ice).  The coefficient block of an item is addressed by
@@ -1793,21 +1814,13 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
         const double scale = ice ? P[2 * n] : P[n] * cp_exp(-(P[0] * t.d0));
         const bool want_vn = a.vn && t.writes_vn;                       // uniform
         const bool want_n0 = ice && a.par_w;                            // uniform
-        double2 v[CPOL_N_SZ / 2];
+        if (!a.skip_res_1d) {
+            double2 v[CPOL_N_SZ / 2];
+            itab1_columns(c, u, scale, v);
+            double2 *o = reinterpret_cast<double2 *>(a.res + ((long)j * n + i) * CPOL_N_SZ);
 #pragma unroll
-        for (int f = 0; f < CPOL_N_SZ / 2; ++f) v[f] = c[(NC - 1) * (NFP / 2) + f];
-#pragma unroll
-        for (int q = NC - 2; q >= 0; --q) {
-#pragma unroll
-            for (int f = 0; f < CPOL_N_SZ / 2; ++f) {
-                const double2 cq = c[q * (NFP / 2) + f];
-                v[f].x = fma(v[f].x, u, cq.x);
-                v[f].y = fma(v[f].y, u, cq.y);
-            }
+            for (int f = 0; f < CPOL_N_SZ / 2; ++f) o[f] = v[f];
         }
-        double2 *o = reinterpret_cast<double2 *>(a.res + ((long)j * n + i) * CPOL_N_SZ);
-#pragma unroll
-        for (int f = 0; f < CPOL_N_SZ / 2; ++f) o[f] = make_double2(v[f].x * scale, v[f].y * scale);
         if (want_vn || want_n0) {
             double2 w = c[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
             double w2 = c[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2 + 1].x;
