@@ -1673,6 +1673,8 @@ struct LookupArgs {
     double *res;                // [n_hydro][n_sbg][12]
     double *vn;                 // [n_hydro][n_sbg][2] or NULL
     long n_sbg;
+    int tile;                   // lanes of a wavefront = 16 neighbouring rays x 4 gates of one sub-beam index
+    int n_rays, n_sub, n_gates; // (melting species: neighbouring rays share the (slice, panel) block, gates do not)
     int skip_res_1d;            // the 12 columns of the 1-D species are evaluated by k_subbeam_sum instead
                                 // (nothing of them is stored); only vn / the ice intercept are written here
 };
@@ -1690,23 +1692,36 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m)
     return __hiloint2double(hi, lo);
 }
 
-// 2-D block: the part of  sum_b w^b sum_{a <= 10-b} C[b][a][f] u^a  that quarter r of the wavefront
-// owns (b = r, r+4, r+8); c points at column f of the block
-__device__ __forceinline__ double itab2_quarter_sum(const double *c, int r, double ui, double wi)
+// 2-D block: quarter r of the wavefront owns the rows of w^b, b = r, r+4, r+8 (u^0 .. u^(10-b) each);
+// lane (r, f) keeps ITS 21 row values of column f in registers (rows beyond 10-b: zero) ...
+#define CPOL_ITAB2_QROWS 21
+__device__ __forceinline__ void itab2_quarter_rows(const double *c, int r, double (&rows)[CPOL_ITAB2_QROWS])
 {
     constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
-    const double w2 = wi * wi, w4 = w2 * w2;
-    double acc = 0.0;
+    int idx = 0;
 #pragma unroll
     for (int k = 2; k >= 0; --k) {
         const int b = r + 4 * k;                                        // power of w of this quarter's row set
         const int bb = min(b, NC - 1);
         const double *cb = c + (long)CPOL_ITAB2_ROW(bb) * NFP;
-        // rows u^0 .. u^(10-b); the quarters run the chain of the longest (r = 0) together, the
-        // shorter ones start with zeros
+#pragma unroll
+        for (int pa = NC - 1 - 4 * k; pa >= 0; --pa) rows[idx++] = pa <= NC - 1 - b ? cb[pa * NFP] : 0.0;
+    }
+}
+
+// ... and sums  sum_b w^b sum_a rows u^a  over its b for one item: the quarters run the chain of
+// the longest (r = 0) together, the shorter ones start with zeros
+__device__ __forceinline__ double itab2_quarter_sum(const double (&rows)[CPOL_ITAB2_QROWS], int r, double ui, double wi)
+{
+    constexpr int NC = CPOL_ITAB_NC;
+    const double w2 = wi * wi, w4 = w2 * w2;
+    double acc = 0.0;
+    int idx = 0;
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {
         double inner = 0.0;
 #pragma unroll
-        for (int pa = NC - 1 - 4 * k; pa >= 0; --pa) inner = fma(inner, ui, pa <= NC - 1 - b ? cb[pa * NFP] : 0.0);
+        for (int pa = NC - 1 - 4 * k; pa >= 0; --pa) inner = fma(inner, ui, rows[idx++]);
         acc = fma(acc, w4, inner);
     }
     return acc * ((r & 1 ? wi : 1.0) * (r & 2 ? w2 : 1.0));
@@ -1762,11 +1777,19 @@ __device__ __forceinline__ void itab1_columns(const double2 *c, double u, double
 __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet hs, ItabSet its, LookupArgs a)
 {
     constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
-    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i0 < a.n_sbg;
+    long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = lane_id();
+    bool in = i0 < a.n_sbg;
+    if (a.tile) {
+        const long W = i0 >> 6;                                         // tile = wavefront
+        const int n_gt = (a.n_gates + 3) >> 2;
+        const int gt = (int)(W % n_gt), sub = (int)((W / n_gt) % a.n_sub);
+        const int ray = (int)(W / ((long)n_gt * a.n_sub)) * 16 + (lane >> 2), gate = gt * 4 + (lane & 3);
+        in = ray < a.n_rays && gate < a.n_gates;
+        i0 = ((long)ray * a.n_sub + sub) * a.n_gates + gate;
+    }
     const long i = in ? i0 : 0;
     const long n = a.n_sbg;
-    const int lane = lane_id();
     for (int j = 0; j < hs.n_hydro; ++j) {
         const ItabDev &t = its.t[j];
         if (!t.tab) continue;                                           // uniform
@@ -1787,19 +1810,30 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
                 q = P[0];
                 blk = sl * t.n_pan + pn;
             }
+            // the wavefront walks over the DISTINCT blocks of its items (16 neighbouring rays x 4
+            // gates: ~6): the rows of a block are fetched once (21 values per lane) and serve
+            // every item of the wavefront that lies on it
             unsigned long long todo = __ballot(item);
             const int f = lane & (NFP - 1), r = lane >> 4;
             while (todo) {
-                const int l = (int)__ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const double *c = t.tab + (long)__builtin_amdgcn_readlane(blk, l) * (CPOL_ITAB2_NB * NFP) + f;
-                double acc = itab2_quarter_sum(c, r, readlane_f64(u, l), readlane_f64(w, l));
-                acc += shfl_xor_f64(acc, 16);
-                acc += shfl_xor_f64(acc, 32);
-                acc *= readlane_f64(q, l);
-                const long o = (long)j * n + (i0 - lane) + l;
-                if (lane < CPOL_N_SZ) a.res[o * CPOL_N_SZ + lane] = acc;
-                else if (lane < CPOL_N_SZ + 2 && a.vn) a.vn[o * 2 + (lane - CPOL_N_SZ)] = acc;
+                const int lead = (int)__ffsll((long long)todo) - 1;
+                const int cur = __builtin_amdgcn_readlane(blk, lead);
+                unsigned long long grp = __ballot(item && blk == cur);
+                todo &= ~grp;
+                double rows[CPOL_ITAB2_QROWS];
+                itab2_quarter_rows(t.tab + (long)cur * (CPOL_ITAB2_NB * NFP) + f, r, rows);
+                while (grp) {
+                    const int l = (int)__ffsll((long long)grp) - 1;
+                    grp &= grp - 1;
+                    double acc = itab2_quarter_sum(rows, r, readlane_f64(u, l), readlane_f64(w, l));
+                    acc += shfl_xor_f64(acc, 16);
+                    acc += shfl_xor_f64(acc, 32);
+                    acc *= readlane_f64(q, l);
+                    const long o = (long)j * n + (((long)__builtin_amdgcn_readlane((int)(i >> 32), l) << 32)
+                                                 | (unsigned)__builtin_amdgcn_readlane((int)i, l));
+                    if (lane < CPOL_N_SZ) a.res[o * CPOL_N_SZ + lane] = acc;
+                    else if (lane < CPOL_N_SZ + 2 && a.vn) a.vn[o * 2 + (lane - CPOL_N_SZ)] = acc;
+                }
             }
             continue;
         }
