@@ -443,7 +443,8 @@ def run_c2(env):
 L1_PEAK_GBS = 256 * 64 * PEAK_CLOCK / 1e9      # vector L1: 64 B / clk / CU (MI355X_MICROARCH.md)
 
 
-def roofline_lookup(workload, cnt, psd_bytes, iso, n_fields_read, traffic_scale=1.0):
+def roofline_lookup(workload, cnt, psd_bytes, iso, n_fields_read, traffic_scale=1.0, per_item_hbm=None,
+                    extra_hbm=0, kernels=('k_psd_lookup',)):
     """The PSD x table stage when the integral tables take the items (k_psd_lookup).  Per item the
     kernel MUST move its key and three parameters in and 12 float64 results out (124 B; HBM), and it
     gathers `n_fields_read` x 11 float64 coefficients from the (slice, lambda-panel) block of the item
@@ -456,16 +457,16 @@ def roofline_lookup(workload, cnt, psd_bytes, iso, n_fields_read, traffic_scale=
     traffic = prof_us = None
     if prof:
         for name, c in prof.items():
-            if 'k_psd_lookup' in name:
-                traffic, prof_us = c.get('hbm_bytes'), c.get('avg_us')
-                traffic = traffic * traffic_scale if traffic else traffic
+            if any(k in name for k in kernels) and c.get('hbm_bytes'):
+                traffic = (traffic or 0) + c['hbm_bytes'] * traffic_scale
+                prof_us = (prof_us or 0) + (c.get('avg_us') or 0)
     n_tab = int(cnt.n_table_items)
-    per_item_hbm = 4 + 3 * 8 + 12 * 8
+    per_item_hbm = (4 + 3 * 8 + 12 * 8) if per_item_hbm is None else per_item_hbm
     per_item_l1 = n_fields_read * 11 * 8
-    must = n_tab * per_item_hbm
+    must = n_tab * per_item_hbm + extra_hbm
     t = cnt.ms_psd * 1e-3 if cnt.ms_psd > 0 else None
-    r = {'kernel': 'k_psd_lookup (+ the integrating kernels for the %d items outside the tables)'
-                   % (int(cnt.n_valid_items) - n_tab),
+    r = {'kernel': '%s (+ the integrating kernels for the %d items outside the tables)'
+                   % (' + '.join(kernels), int(cnt.n_valid_items) - n_tab),
          'bound': 'hbm', 'achieved': must / t / 1e9 if t else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
          'frac': must / t / 1e9 / HBM_PEAK_GBS if t else None,
          'traffic': traffic, 'traffic_source': prof_path,
@@ -681,13 +682,22 @@ def run_c4(env):
     cb.n_table_items = busiest['n_table_items'] // n_el
     cb.n_valid_items = busiest['n_valid_items'] // n_el
     cb.ms_psd = busiest['psd_stage_ms_per_sweep_isolated'] or 0.0
-    roof = roofline_lookup('c4', cb, cb.n_valid_items * LUT_SLICE_BYTES, None, n_fields_read=14, traffic_scale=scale)
+    # c4 (several sub-beams): k_subbeam_sum evaluates the 1-D table items in place and accumulates them --
+    # it must read key + 3 parameters per item and write 48 B per (gate, hydrometeor); k_psd_lookup keeps
+    # the melting species (2-D blocks) and the Doppler sums of ice
+    n_rg_loc = busiest['rays_per_sweep'] * n_gates
+    roof = roofline_lookup('c4', cb, cb.n_valid_items * LUT_SLICE_BYTES, None, n_fields_read=12, traffic_scale=scale,
+                           per_item_hbm=4 + 3 * 8, extra_hbm=n_rg_loc * len(hydrometeors_of('c4')) * 48,
+                           kernels=('k_subbeam_sum', 'k_psd_lookup'))
     roof['stage_ms_with_lanes_in_flight'] = max(ms_psd) if ms_psd else None
     roof['note'] += ('; c4: per sweep of the busiest rank (mean over its 5 sweeps, one lane at a time, the pass '
-                     'after the timed region); snow, graupel and ice crystals read 1-D blocks (11 rows of 128 B, '
-                     'shared by neighbouring gates), the melting species 2-D blocks (121 rows, wet fraction x '
-                     'rain-partner slope, one wavefront per item: 15.5 KB per item through L1, which l1_gather '
-                     'does not count); traffic = the N = 1 profile scaled by this rank\'s share of the items')
+                     'after the timed region); with 49 sub-beams the items on 1-D tables (snow, graupel, ice '
+                     'crystals: 11 rows of 128 B per block, shared by neighbouring gates) are evaluated inside '
+                     'k_subbeam_sum and accumulated over the sub-beams at once, so their 12 columns never go '
+                     'through memory: achieved counts key + 3 parameters per item and 48 B per (gate, hydrometeor); '
+                     'the melting species read 2-D blocks (66 rows, wet fraction x rain-partner slope) in '
+                     'k_psd_lookup, which l1_gather does not count; traffic = the N = 1 profile scaled by this '
+                     'rank\'s share of the items')
     return {
         'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

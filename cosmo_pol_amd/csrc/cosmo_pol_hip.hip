@@ -1484,6 +1484,18 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         }
         for (int i = 0; i < n_aux; ++i) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join[i], 0));
     }
+    // ---- 5d. sub-beam sums per (gate, hydrometeor); the items on 1-D tables are evaluated here ----
+    if (subsum) {
+        SubsumArgs sa2{};
+        sa2.key = (const int *)ctx->b_key.p;
+        sa2.par = (const double *)ctx->b_par.p;
+        sa2.res = (const double *)ctx->b_res.p;
+        sa2.sub_w = (const double *)ctx->v_subw;
+        sa2.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
+        sa2.sz_integ = (float *)ctx->b_szinteg.p;
+        sa2.n_rays = n_rays; sa2.n_gates = ng; sa2.n_sub = n_sub; sa2.n_hydro = n_hyd;
+        hipLaunchKernelGGL(k_subbeam_sum, dim3(cdiv(n_rg, 256), n_hyd), dim3(256), 0, st, ctx->hs, ctx->its, sa2);
+    }
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
 
     // ---- 6. accumulation + polarimetric variables + scans ----
@@ -1588,20 +1600,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ra.RVEL = (double *)T[O_RVEL];       // censored with the other observables in k_final
     }
     if ((size_t)3 * ng * sizeof(float) > 64 * 1024) { ctx->err = "cpol_run_sweep: n_gates too large for the range scans (3 * n_gates floats of LDS)"; return CPOL_ERR_ARG; }
-    fa.pre_integ = 0;
-    if (subsum) {
-        SubsumArgs sa2{};
-        sa2.key = (const int *)ctx->b_key.p;
-        sa2.par = (const double *)ctx->b_par.p;
-        sa2.res = (const double *)ctx->b_res.p;
-        sa2.sub_w = (const double *)ctx->v_subw;
-        sa2.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
-        sa2.sz_integ = (float *)ctx->b_szinteg.p;
-        sa2.n_rays = n_rays; sa2.n_gates = ng; sa2.n_sub = n_sub; sa2.n_hydro = n_hyd;
-        hipLaunchKernelGGL(k_subbeam_sum, dim3(cdiv(n_rg, 256), n_hyd), dim3(256), 0, st, ctx->hs, ctx->its, sa2);
-        fa.sz_integ = (float *)ctx->b_szinteg.p;
-        fa.pre_integ = 1;
-    }
+    fa.pre_integ = subsum ? 1 : 0;
+    if (subsum) fa.sz_integ = (float *)ctx->b_szinteg.p;
     fa.proj = nullptr;
     if (fa.RVEL && n_sub >= 4) {
         // the per-sub-beam velocity terms by one thread per sub-beam gate (k_final adds them in order)
