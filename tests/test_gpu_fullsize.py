@@ -121,6 +121,51 @@ def test_c3_full_size_volume_vs_oracle():
     op.close()
 
 
+def test_c4_sector_with_49_subbeams_vs_oracle():
+    """BASELINE configs[3] on a sector: 48 azimuths x 500 gates x 7 x 7 sub-beams at two elevations
+    on the bench cube, full 1-moment set with melting.  This is the path of the multi-GPU
+    workload -- the melting items grouped by table block over tiles of 16 rays x 4 gates
+    (k_psd_lookup), the items on 1-D tables evaluated inside the sub-beam accumulation
+    (k_subbeam_sum), the velocity terms in their own kernel (k_rvel_terms) -- against the oracle
+    on sampled rays; the same rays alone (one ray per call: no tiles) must give the same bits."""
+    from cosmo_pol_amd import RadarOperator
+    from test_gpu_parity import _pol_tolerances
+    over = bench.bench_config(False, 'c4')
+    hyds = list(bench.hydrometeors_of('c4'))
+    cube = synthetic.make_cube(hydrometeors=('R', 'S', 'G', 'I'), **synthetic.BENCH_GRID)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar', lanes=1)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    conf = ocfg.make_config(over)
+    oc = beam.ModelCube({n: cube['data'][n] for n in _cases.ORDER}, cube['zlevels'],
+                        cube['proj_info'], cube['resolution'], _cases.ORDER)
+    ol = {h: _cases.as_oracle_lut(l) for h, l in luts.items()}
+    az = np.arange(100.0, 148.0, 1.0)
+    n_melt = n_valid = 0
+    for e in (1.5, 5.0):
+        res = op.simulate_rays(az, np.full(len(az), e))
+        c = op._ctx.counters()
+        assert res['n_sub'] == 49 and c.n_table_items >= c.n_valid_items - 8
+        for r in (5, 30):
+            subs = beam.interpolate_radial(oc, conf, float(az[r]), e)
+            assert len(subs) == 49
+            n_melt += sum(int(np.sum(np.asarray(sb.values['QmS_v']) > 0)) for sb in subs if 'QmS_v' in sb.values)
+            o = scatter.radar_observables(subs, ol, conf, return_sz=True)
+            szt = np.nan_to_num(o.sz_total.astype(np.float64))
+            scatter.cut_at_sensitivity([[o]], conf)
+            assert np.array_equal(res['mask'][r], o.mask)
+            for k in FIELDS:
+                atol = 2e-4 if k == 'RVEL' else _pol_tolerances(k, o, szt, conf)
+                _cases.assert_close_nan(res[k][r], o.values[k], rtol=1e-5, atol=atol,
+                                        name='%s el %g ray %d' % (k, e, r))
+            n_valid += int(np.isfinite(o.values['ZH']).sum())
+            alone = op.simulate_rays(az[r:r + 1], np.full(1, e))
+            for k in FIELDS:
+                assert np.array_equal(alone[k][0], res[k][r], equal_nan=True), (k, e, r)
+    assert n_valid > 300 and n_melt > 100, (n_valid, n_melt)
+    op.close()
+
+
 def test_rhi_and_vprof_api(full):
     op = full['op']
     rhi = op.get_RHI(azimuths=[30.0, 200.0], elevations=np.arange(0.5, 20.0, 2.5))
