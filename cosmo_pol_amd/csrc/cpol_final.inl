@@ -203,6 +203,9 @@ __global__ __launch_bounds__(256) void k_rvel_terms(FinalArgs a, double *__restr
 // items on a 1-D integral table are EVALUATED here (their 12 columns never go through memory:
 // k_psd_lookup wrote 96 B per item and k_final read them back -- 2.9 GB of the 9.8 GB a C4 sweep
 // moved); items of the melting species and items integrated bin by bin are read from res[].
+// Bound: the texture-address path of the CU (66 16-B gathers per evaluation, ~16 cycles each):
+// 1.07 ms on the C4 sweep, 0.20 ms on the 45-ray share of one of 8 GPUs; requesting key and
+// parameters of the next sub-beam ahead of the gather changes neither (1.03 / 0.196 ms).
 struct SubsumArgs {
     const int *key;             // [n_hydro][n_sbg]
     const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg]

@@ -16,6 +16,7 @@ def main():
     ap.add_argument('--elev', type=float, default=1.0)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--tag', default='')
+    ap.add_argument('--rays', type=int, default=360, help='azimuths of the sweep (1 deg apart)')
     args = ap.parse_args()
     import contextlib
     import numpy as np
@@ -33,10 +34,10 @@ def main():
         op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
         t_tables = time.time() - t0
         op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
-    az = np.arange(0, 360, 1.0)
-    el = np.full(360, args.elev)
+    az = np.arange(0, args.rays, 1.0)
+    el = np.full(args.rays, args.elev)
     n_gates = len(op.constants.RANGE_RADAR)
-    slab = torch.empty((9, 360, n_gates), dtype=torch.float32, device='cuda')
+    slab = torch.empty((9, args.rays, n_gates), dtype=torch.float32, device='cuda')
     ptrs = {k: slab[i].data_ptr() for i, k in enumerate(bench.RADAR_FIELDS)}
     for _ in range(3):
         op.simulate_rays(az, el, device_outputs=ptrs)
