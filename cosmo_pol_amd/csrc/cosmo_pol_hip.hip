@@ -1494,7 +1494,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sa2.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
         sa2.sz_integ = (float *)ctx->b_szinteg.p;
         sa2.n_rays = n_rays; sa2.n_gates = ng; sa2.n_sub = n_sub; sa2.n_hydro = n_hyd;
-        hipLaunchKernelGGL(k_subbeam_sum, dim3(cdiv(n_rg, 256), n_hyd), dim3(256), 0, st, ctx->hs, ctx->its, sa2);
+        hipLaunchKernelGGL(k_subbeam_sum, dim3(cdiv(n_rg, CPOL_SUBSUM_THREADS), n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
     }
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
 
@@ -1610,7 +1610,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                            fa, (double *)ctx->b_proj.p);
         fa.proj = (const double *)ctx->b_proj.p;
     }
-    hipLaunchKernelGGL(k_final, dim3(n_rays), dim3(CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra);
+    if (n_rays <= 128 && ng > CPOL_FINAL_THREADS)
+        hipLaunchKernelGGL((k_final<2 * CPOL_FINAL_THREADS>), dim3(n_rays), dim3(2 * CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra);
+    else
+        hipLaunchKernelGGL((k_final<CPOL_FINAL_THREADS>), dim3(n_rays), dim3(CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
     HIPCHK(hipGetLastError());
 

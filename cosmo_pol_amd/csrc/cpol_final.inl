@@ -216,7 +216,10 @@ struct SubsumArgs {
     int n_rays, n_gates, n_sub, n_hydro;
 };
 
-__global__ __launch_bounds__(256) void k_subbeam_sum(HydroSet hs, ItabSet its, SubsumArgs a)
+#ifndef CPOL_SUBSUM_THREADS
+#define CPOL_SUBSUM_THREADS 64       // (measured on the C4 sweep / its 45-ray share: 64 -> 0.97 / 0.190 ms, 128 -> 1.01 / 0.192, 256 -> 1.05 / 0.205)
+#endif
+__global__ __launch_bounds__(CPOL_SUBSUM_THREADS) void k_subbeam_sum(HydroSet hs, ItabSet its, SubsumArgs a)
 {
     constexpr int NB = CPOL_ITAB_NC * CPOL_ITAB_NFP;
     const long n_rg = (long)a.n_rays * a.n_gates;
@@ -452,7 +455,10 @@ struct ScanRayArgs {
 #ifndef CPOL_FINAL_THREADS
 #define CPOL_FINAL_THREADS 256
 #endif
-__global__ __launch_bounds__(CPOL_FINAL_THREADS) void k_final(FinalArgs a, ScanRayArgs r)
+// THREADS: 256 (a gate or two per thread); 512 when the sweep has fewer rays than the GPU has CUs
+// (the share of one of N GPUs: the kernel's duration is that of ONE workgroup then)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_final(FinalArgs a, ScanRayArgs r)
 {
     extern __shared__ float lds[];          // [3][n_gates]
     const int ray = blockIdx.x;
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(CPOL_FINAL_THREADS) void k_final(FinalArgs a, ScanR
     const int ng = a.n_gates;
     const long base = (long)ray * ng;
     float *s_k = lds, *s_h = lds + ng, *s_v = lds + 2 * ng;
-    for (int g = tid; g < ng; g += CPOL_FINAL_THREADS) {
+    for (int g = tid; g < ng; g += THREADS) {
         float k2, fh, fv;
         final_gate(a, ray, g, k2, fh, fv);
         s_k[g] = k2;
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(CPOL_FINAL_THREADS) void k_final(FinalArgs a, ScanR
     }
     __syncthreads();
     double *rvel = a.RVEL ? a.RVEL : r.RVEL;
-    for (int g = tid; g < ng; g += CPOL_FINAL_THREADS) {
+    for (int g = tid; g < ng; g += THREADS) {
         const long i = base + g;
         // (this thread wrote these four values itself in the first loop)
         float zh = a.ZH[i], zv = a.ZV[i];
