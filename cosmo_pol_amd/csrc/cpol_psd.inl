@@ -1793,6 +1793,10 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
     for (int j = 0; j < hs.n_hydro; ++j) {
         const ItabDev &t = its.t[j];
         if (!t.tab) continue;                                           // uniform
+        // (k_subbeam_sum evaluates the columns of the 1-D species: nothing to do here for a species
+        // that needs neither its Doppler sums nor the ice intercept)
+        if (a.skip_res_1d && !t.two_d && !(a.vn && t.writes_vn) &&
+            !(a.par_w && hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD)) continue;
         const int key = in ? a.key[(long)j * n + i] : -1;
         const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
         const double pf = key >= 0 ? P[4 * n] : -1.0;
