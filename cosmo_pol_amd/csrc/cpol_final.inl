@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void k_rvel_terms(FinalArgs a, double *__restr
 // moved); items of the melting species and items integrated bin by bin are read from res[].
 // Bound: the texture-address path of the CU (66 16-B gathers per evaluation, ~16 cycles each):
 // 1.07 ms on the C4 sweep, 0.20 ms on the 45-ray share of one of 8 GPUs; requesting key and
-// parameters of the next sub-beam ahead of the gather changes neither (1.03 / 0.196 ms).
+// parameters of the next sub-beam ahead of the gather changes neither (1.03 / 0.196 ms); two
+// sub-beams per step with both gathers in flight is slower (1.38 / 0.36 ms, 128 VGPRs).
 struct SubsumArgs {
     const int *key;             // [n_hydro][n_sbg]
     const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg]
