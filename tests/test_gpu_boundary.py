@@ -180,7 +180,8 @@ def test_integral_tables_take_the_items_and_the_integrating_kernels_stay_pinned(
     cpol_counters_t.n_table_items) -- 1-D blocks for the gamma-family species and 1-moment ice,
     2-D blocks (wet fraction x rain-partner slope) for the melting species, whose fit is verified
     at build time against the integrating kernel at one off-node point of every block.
-    CPOL_ITAB_MELT=0 keeps the melting species on the integrating kernel, CPOL_ITAB=0 integrates
+    CPOL_ITAB_MELT=0 keeps the melting species on the integrating kernel, CPOL_SUBSUM=0 the
+    sub-beam accumulation inside k_final, CPOL_ITAB=0 integrates
     every item over its 1024 diameter bins -- the kernels that also evaluate the table nodes at
     staging time: the reference-pinned parity module must hold in those modes too (child pytest
     processes: the switches are read when the tables are built)."""
@@ -210,6 +211,11 @@ def test_integral_tables_take_the_items_and_the_integrating_kernels_stay_pinned(
                          capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert '3 passed' in out.stdout, out.stdout[-500:]
+    # ... and the sub-beam accumulation inside k_final, fed by stored columns (CPOL_SUBSUM=0)
+    out = subprocess.run(base + ['-k', 'c4_7x7 or c4_subbeams or q_ml_dop2 or c5_2mom_dop2_sub'],
+                         env=dict(os.environ, CPOL_SUBSUM='0'), capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert '4 passed' in out.stdout, out.stdout[-500:]
 
 
 def test_table_sets_stay_resident_across_configuration_switches():

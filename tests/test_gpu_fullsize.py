@@ -122,7 +122,7 @@ def test_c3_full_size_volume_vs_oracle():
 
 
 def test_c4_sector_with_49_subbeams_vs_oracle():
-    """BASELINE configs[3] on a sector: 48 azimuths x 500 gates x 7 x 7 sub-beams at two elevations
+    """BASELINE configs[3] on a sector: 45 azimuths x 500 gates x 7 x 7 sub-beams at two elevations
     on the bench cube, full 1-moment set with melting.  This is the path of the multi-GPU
     workload -- the melting items grouped by table block over tiles of 16 rays x 4 gates
     (k_psd_lookup), the items on 1-D tables evaluated inside the sub-beam accumulation
@@ -140,7 +140,7 @@ def test_c4_sector_with_49_subbeams_vs_oracle():
     oc = beam.ModelCube({n: cube['data'][n] for n in _cases.ORDER}, cube['zlevels'],
                         cube['proj_info'], cube['resolution'], _cases.ORDER)
     ol = {h: _cases.as_oracle_lut(l) for h, l in luts.items()}
-    az = np.arange(100.0, 148.0, 1.0)
+    az = np.arange(100.0, 145.0, 1.0)       # 45 rays: the last tile of 16 rays is partly empty
     n_melt = n_valid = 0
     for e in (1.5, 5.0):
         res = op.simulate_rays(az, np.full(len(az), e))
