@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Host-side profile (cProfile) of the submission of one C4 volume (5 sweeps, device outputs):
-   python tools/profile_c4_host.py [n_rays]"""
+   python tools/profile_c4_host.py [n_rays] [lanes]"""
 import contextlib
 import cProfile
 import os
@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     n_rays = int(sys.argv[1]) if len(sys.argv) > 1 else 360
+    n_lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     import numpy as np
     import torch
     import bench
@@ -23,7 +24,7 @@ def main():
     cube = synthetic.make_cube(hydrometeors=tuple(h for h in hyds if h in 'RSGI'), **synthetic.BENCH_GRID)
     luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
     with contextlib.redirect_stdout(sys.stderr):
-        op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=3)
+        op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=n_lanes)
         op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
     az = np.arange(0, n_rays, 1.0)
     ng = len(op.constants.RANGE_RADAR)
@@ -32,10 +33,10 @@ def main():
 
     def volume():
         for e, elev in enumerate(bench.C4_ELEVATIONS):
-            op.simulate_rays(az, np.full(n_rays, elev), device_outputs=ptrs[e], lane=e % 3)
+            op.simulate_rays(az, np.full(n_rays, elev), device_outputs=ptrs[e], lane=e % n_lanes)
 
     def wait():
-        for i in range(3):
+        for i in range(n_lanes):
             op.wait(i)
     for _ in range(2):
         volume()
@@ -46,6 +47,7 @@ def main():
     t_sub = (time.perf_counter() - t0) / 5
     wait()
     t_all = (time.perf_counter() - t0) / 5
+    print('lanes %d ' % n_lanes, end='')
     print('n_rays %d: host submit %.2f ms per volume, wall %.2f ms per volume' % (n_rays, 1e3 * t_sub, 1e3 * t_all))
     pr = cProfile.Profile()
     pr.enable()
