@@ -110,15 +110,62 @@ TFUN_SNOW_N0, TFUN_ICE_MOM2_A = 0, 1
 TFUN_FIRST_BITS, TFUN_COUNT = 0x43000000, 1 << 24  # every float32 in [128, 512)
 
 _lib = None
+_torch_hip = None
 
 
 class NativeError(RuntimeError):
     pass
 
 
+def hip_runtimes_mapped():
+    """Distinct libamdhip64 files mapped into this process (/proc/self/maps)."""
+    found = []
+    try:
+        with open('/proc/self/maps') as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1]
+                if 'libamdhip64' in os.path.basename(path):
+                    real = os.path.realpath(path)
+                    if real not in found:
+                        found.append(real)
+    except OSError:
+        pass
+    return found
+
+
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  libcosmo_pol_hip.so needs `libamdhip64.so.7`; a PyTorch-ROCm
+    wheel bundles its own copy of that runtime (same SONAME) and asks for it as `libamdhip64.so`.
+    If this library comes first the loader serves it from /opt/rocm and torch later maps its
+    bundled copy as well: two runtimes, and the second one to initialise finds no GPU
+    ("No HIP GPUs are available" in torch._C._cuda_init).  So when a torch wheel with a bundled
+    runtime is installed -- found without importing torch -- that copy is mapped first; this
+    library then binds to it by SONAME and a later `import torch` finds it already loaded.
+    CPOL_HIP_RUNTIME=system skips this (a process that will never touch torch.cuda)."""
+    import sys
+    if os.environ.get('CPOL_HIP_RUNTIME', '') == 'system' or hip_runtimes_mapped():
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if not os.path.exists(cand):
+        return None
+    try:
+        return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        print('cosmo_pol_amd: could not preload %s (%s); using the system HIP runtime' % (cand, e),
+              file=sys.stderr)
+        return None
+
+
 def load_library():
     """Loads the HIP shared library (never falls back to anything else)."""
-    global _lib
+    global _lib, _torch_hip
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
@@ -126,7 +173,13 @@ def load_library():
             'cosmo_pol_amd: HIP extension %s is missing. Build it with '
             '`python -c "import __graft_entry__ as g; g.build()"` or `make -C cosmo_pol_amd/csrc`. '
             'There is no CPU fallback.' % LIB_PATH)
+    _torch_hip = _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
+    if len(hip_runtimes_mapped()) > 1:
+        raise NativeError(
+            'cosmo_pol_amd: two HIP runtimes are mapped into this process (%s): the second one to '
+            'initialise will not see the GPU.  Import cosmo_pol_amd (or torch) before any other '
+            'package that loads libamdhip64, or unset CPOL_HIP_RUNTIME.' % ', '.join(hip_runtimes_mapped()))
     vp = C.c_void_p
     lib.cpol_create.restype = C.c_int
     lib.cpol_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -346,6 +399,16 @@ class Context(object):
         c = Counters()
         self._check(self.lib.cpol_counters(self.h, C.byref(c)), 'cpol_counters')
         return c
+
+    def itab_report(self):
+        """Accuracy gate of the integral tables of the staged slots (cpol_prepare): per slot the worst
+        deviation of a block's polynomial from the integrating kernel at the block's check point
+        (`check`: negative = table rejected, the slot is integrated bin by bin; 0 = no table), where it
+        was found (`at`), the number of (block, function) pairs above the limit (`n_bad`, 1-D tables)
+        and the device time of the build and of the check alone (`build_ms`, `check_ms`)."""
+        a = self.debug_read('itab_check', (3, CPOL_MAX_HYDRO), np.float64)
+        t = self.debug_read('itab_times', (CPOL_MAX_HYDRO, 2), np.float64)
+        return {'check': a[0], 'at': a[1], 'n_bad': a[2], 'build_ms': t[:, 0], 'check_ms': t[:, 1]}
 
     def debug_math(self, op, x):
         x = np.ascontiguousarray(x, dtype=np.float64)

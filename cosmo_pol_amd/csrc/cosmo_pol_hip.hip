@@ -87,7 +87,9 @@ struct cpol_ctx {
     uint64_t table_clock = 0;
     uint64_t itab_builds = 0;
     double itab_check_at[CPOL_MAX_HYDRO] = {};
-    double itab_check[CPOL_MAX_HYDRO] = {};     // melting species: worst deviation at the check points (-1: table rejected)
+    double itab_check[CPOL_MAX_HYDRO] = {};     // worst deviation at the blocks' check points (negative: table rejected)
+    double itab_ms[CPOL_MAX_HYDRO][2] = {};     // device time of the last build of the slot's table: all of it, the check alone
+    double itab_bad[CPOL_MAX_HYDRO] = {};       // 1-D tables: (block, function) pairs at or above the accepted deviation
     ItabSet its{};
     uint64_t lut_serial = 0;           // bumped by the staging calls the integral tables depend on (not the model cube)
     uint64_t itab_serial = ~0ull;      // lut_serial the tables were built for
@@ -201,6 +203,10 @@ int build_itabs(cpol_ctx *ctx)
     ctx->its = ItabSet{};
     ctx->itab_serial = ctx->lut_serial;
     ctx->itab_builds++;
+    for (int j = 0; j < CPOL_MAX_HYDRO; ++j) {
+        ctx->itab_check[j] = ctx->itab_check_at[j] = ctx->itab_bad[j] = 0.0;
+        ctx->itab_ms[j][0] = ctx->itab_ms[j][1] = 0.0;
+    }
     if (!enabled) return CPOL_OK;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -230,6 +236,9 @@ int build_itabs(cpol_ctx *ctx)
         HIPCHK(hipStreamSynchronize(st));
     }
     const bool melt_enabled = !(getenv("CPOL_ITAB_MELT") && atoi(getenv("CPOL_ITAB_MELT")) == 0);
+    // accepted deviation of a block's polynomial from the integrating kernel at the block's check point
+    // (CPOL_ITAB_MAX_DEV: test knob -- a tiny value forces the fallback to the integrating kernels)
+    const double max_dev = getenv("CPOL_ITAB_MAX_DEV") ? atof(getenv("CPOL_ITAB_MAX_DEV")) : CPOL_ITAB_MAX_DEVIATION;
     const bool dop2 = [&] { for (int j = 0; j < n_hyd; ++j) if (!ctx->hs.h[j].rcsw) return false; return n_hyd > 0; }();
     for (int j = 0; j < n_hyd; ++j) {
         const HydroDev &h = ctx->hs.h[j];
@@ -270,7 +279,7 @@ int build_itabs(cpol_ctx *ctx)
         const int ppo = melt ? CPOL_ITAB2_PPO : CPOL_ITAB_PPO;
         const int n_pan = (int)floor((hi - lo) * ppo + 0.5);
         const int n_slices = d.n_e * d.n_t;
-        const int per_block = melt ? CPOL_ITAB2_NODES : NC;
+        const int per_block = melt ? CPOL_ITAB2_NODES : CPOL_ITAB1_NODES;      // the nodes + 1 check point
         const long n_items = (long)n_slices * n_pan * per_block;
         const bool melt_tab = melt && d.tab_degree == CPOL_MELT_DEGREE;
         const int unit_items = ((gamma && d.uniform_grid) || ice || melt_tab) ? 128 : 64;
@@ -320,7 +329,7 @@ int build_itabs(cpol_ctx *ctx)
         if ((rc = ensure(ctx, b_par, (size_t)CPOL_MAX_PAR * n_items * sizeof(double))) ||
             (rc = ensure(ctx, b_perm, (size_t)n_items * sizeof(int))) ||
             (rc = ensure(ctx, b_units, (size_t)n_units * sizeof(WorkUnit))) ||
-            (rc = ensure(ctx, b_tot, 4 * sizeof(long long))) ||
+            (rc = ensure(ctx, b_tot, 6 * sizeof(long long))) ||
             (rc = ensure(ctx, b_res, (size_t)n_items * CPOL_N_SZ * sizeof(double))) ||
             (rc = ensure(ctx, b_vn, (size_t)n_items * 2 * sizeof(double))) ||
             (rc = ensure(ctx, dst_tab, tab_bytes))) {
@@ -334,6 +343,9 @@ int build_itabs(cpol_ctx *ctx)
         ba.totals = (long long *)b_tot.p; ba.n_items = n_items; ba.n_slices = n_slices; ba.n_pan = n_pan;
         ba.key_base = h.key_base; ba.unit_items = unit_items; ba.log2_lo = lo; ba.ppo = ppo;
         ba.two_d = melt ? 1 : 0; ba.n_t = d.n_t; ba.head = (const double *)dst_head.p;
+        hipEvent_t evb[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (auto &e_ : evb) (void)hipEventCreate(&e_);
+        (void)hipEventRecord(evb[0], st);
         hipLaunchKernelGGL(k_itab_nodes, dim3(cdiv(n_items > n_units ? n_items : n_units, 256)), dim3(256), 0, st, ba);
         // the slot's own kernels on the synthetic items (arrays of THIS slot only: the kernels
         // index [n_hydro][...][n] arrays with the slot number, hence the shifted bases)
@@ -371,6 +383,7 @@ int build_itabs(cpol_ctx *ctx)
         }
         double worst = 0.0;
         unsigned long long worst_bits = 0;
+        unsigned int n_bad = 0;
         if (melt) {
             ItabFit2Args fa{};
             fa.res = (const double *)b_res.p; fa.vn = (const double *)b_vn.p;
@@ -379,31 +392,56 @@ int build_itabs(cpol_ctx *ctx)
             fa.worst = (unsigned long long *)b_tot.p + 3;
             HIPCHK(hipMemsetAsync(fa.worst, 0, sizeof(unsigned long long), st));
             hipLaunchKernelGGL(k_itab_fit2, dim3(cdiv(fa.n_blocks * CPOL_ITAB_NFP, 64)), dim3(64), 0, st, fa);
+            (void)hipEventRecord(evb[1], st);
             hipLaunchKernelGGL(k_itab_check2, dim3(cdiv(fa.n_blocks * (CPOL_N_SZ + 2), 256)), dim3(256), 0, st, fa);
+            (void)hipEventRecord(evb[2], st);
             HIPCHK(hipMemcpyAsync(&worst_bits, fa.worst, sizeof worst_bits, hipMemcpyDeviceToHost, st));
         } else {
             ItabFitArgs fa{};
             fa.res = (const double *)b_res.p; fa.vn = (const double *)b_vn.p; fa.par = (const double *)b_par.p;
             fa.M = (const double *)ctx->d_itab_M.p; fa.tab = (double *)dst_tab.p;
             fa.n_items = n_items; fa.n_slices = n_slices; fa.n_pan = n_pan; fa.log2_lo = lo; fa.d0 = gamma ? d0 : 0.0;
-            hipLaunchKernelGGL(k_itab_fit, dim3(cdiv((long)n_slices * n_pan * CPOL_ITAB_NF, 256)), dim3(256), 0, st, fa);
+            fa.worst = (unsigned long long *)b_tot.p + 3;
+            fa.n_bad = (unsigned int *)((unsigned long long *)b_tot.p + 4);
+            fa.max_dev = max_dev;
+            HIPCHK(hipMemsetAsync(fa.worst, 0, 2 * sizeof(unsigned long long), st));
+            const dim3 fgrid(cdiv((long)n_slices * n_pan * CPOL_ITAB_NF, 256));
+            hipLaunchKernelGGL(k_itab_fit, fgrid, dim3(256), 0, st, fa);
+            (void)hipEventRecord(evb[1], st);
+            hipLaunchKernelGGL(k_itab_check1, fgrid, dim3(256), 0, st, fa);
+            (void)hipEventRecord(evb[2], st);
+            HIPCHK(hipMemcpyAsync(&worst_bits, fa.worst, sizeof worst_bits, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&n_bad, fa.n_bad, sizeof n_bad, hipMemcpyDeviceToHost, st));
         }
+        (void)hipEventRecord(evb[3], st);
         const hipError_t e = hipStreamSynchronize(st);
+        {
+            float ms_all = 0.f, ms_chk = 0.f;
+            if (e == hipSuccess && hipEventElapsedTime(&ms_all, evb[0], evb[3]) == hipSuccess &&
+                hipEventElapsedTime(&ms_chk, evb[1], evb[2]) == hipSuccess) {
+                // the check = its kernel + the block's extra item in the integration (1 of per_block)
+                ctx->itab_ms[j][0] = ms_all;
+                ctx->itab_ms[j][1] = ms_chk + (ms_all - ms_chk) / per_block;
+            }
+            for (auto &e_ : evb) if (e_) (void)hipEventDestroy(e_);
+        }
         free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn);
         if (e != hipSuccess || hipGetLastError() != hipSuccess) {
             ctx->err = "build_itabs: a kernel failed";
             drop_entry();
             return CPOL_ERR_HIP;
         }
-        if (melt) {
+        {
             const unsigned long long eb = worst_bits & ~0xFFFFFFull;
             memcpy(&worst, &eb, sizeof worst);
-            ctx->itab_check_at[j] = (double)(worst_bits & 0xFFFFFFull);      // (block x 14 + function) mod 2^24
+            ctx->itab_check_at[j] = (double)(worst_bits & 0xFFFFFFull);      // (block x functions + function) mod 2^24
         }
         ctx->itab_check[j] = worst;
-        if (melt && !(worst < CPOL_ITAB2_MAX_DEVIATION)) {
-            // the polynomial does not reproduce the integrating kernel between the nodes (wet-fraction
-            // bins too wide for the degree: coarse test tables): this species stays on the integrating path
+        ctx->itab_bad[j] = (double)n_bad;
+        if (!(worst < max_dev)) {
+            // the polynomial does not reproduce the integrating kernel between the nodes (melting: wet-
+            // fraction bins too wide for the degree, coarse test tables; 1-D: coefficients that cancel):
+            // this species stays on the integrating path
             ctx->itab_check[j] = -worst;
             if (ce) drop_entry(); else free_buf(ctx->d_itab[j]);
             continue;
@@ -1793,12 +1831,25 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
         memcpy(dst, v, sizeof v);
         return (int64_t)sizeof v;
     }
+    if (!strcmp(name, "itab_times")) {
+        // per hydrometeor slot: device ms of the last integral-table build, and of its accuracy check
+        const cpol_ctx *own = ctx->parent ? ctx->parent : ctx;
+        if (!dst || max_bytes < (int64_t)sizeof own->itab_ms) return CPOL_ERR_ARG;
+        memcpy(dst, own->itab_ms, sizeof own->itab_ms);
+        return (int64_t)sizeof own->itab_ms;
+    }
     if (!strcmp(name, "itab_check")) {
-        // per hydrometeor slot: worst |polynomial - integrating kernel| / |value| over the check points
-        // of its 2-D integral table (melting species); negative: table rejected; 0: no such table
+        // per hydrometeor slot: worst |polynomial - integrating kernel| / scale over the check points of its
+        // integral table (1-D and 2-D); negative: table rejected (the slot is integrated bin by bin);
+        // 0: no table.  Then (optional) where, and the number of (block, function) pairs above the limit
         const cpol_ctx *own = ctx->parent ? ctx->parent : ctx;
         if (!dst || max_bytes < (int64_t)sizeof own->itab_check) return CPOL_ERR_ARG;
         memcpy(dst, own->itab_check, sizeof own->itab_check);
+        if (max_bytes >= 3 * (int64_t)sizeof own->itab_check) {
+            memcpy((char *)dst + sizeof own->itab_check, own->itab_check_at, sizeof own->itab_check_at);
+            memcpy((char *)dst + 2 * sizeof own->itab_check, own->itab_bad, sizeof own->itab_bad);
+            return 3 * (int64_t)sizeof own->itab_check;
+        }
         if (max_bytes >= 2 * (int64_t)sizeof own->itab_check) {
             memcpy((char *)dst + sizeof own->itab_check, own->itab_check_at, sizeof own->itab_check_at);
             return 2 * (int64_t)sizeof own->itab_check;

@@ -71,6 +71,13 @@ struct SpecSet {
 #define CPOL_ITAB_NF     15      // 12 columns, 2 Doppler sums (v, n), ice: normalised N0 (Doppler spectrum)
 #define CPOL_ITAB_NFP    16      // functions per coefficient row (padded: one row = 128 B)
 #define CPOL_ITAB_PPO    8       // panels per octave of lambda
+// Every 1-D block is verified when it is built: a 12th item per (slice, panel), at the off-node
+// position CPOL_ITAB1_CHECK_U, is integrated by the same kernel and compared with the polynomial,
+// function by function, on the scale of the function over the block (k_itab_check1).  A slot whose
+// worst deviation reaches CPOL_ITAB_MAX_DEVIATION keeps its items on the integrating kernels.
+#define CPOL_ITAB1_NODES (CPOL_ITAB_NC + 1)
+#define CPOL_ITAB1_CHECK_U 0.37
+#define CPOL_ITAB_MAX_DEVIATION 1e-10
 // Melting species: N(D) has TWO per-item parameters, the wet fraction fw (which also selects the
 // LUT slice, floor bin of the table's second axis) and the slope lambda_r of the rain partner, and
 // every integrated entry is  QM x F_c(slice, fw, lambda_r)  (the normalisation by the mass
@@ -86,7 +93,7 @@ struct SpecSet {
 #define CPOL_ITAB2_NODES (CPOL_ITAB_NC * CPOL_ITAB_NC + 1)              // build items per block: the nodes + 1 check point
 #define CPOL_ITAB2_CHECK_U 0.37
 #define CPOL_ITAB2_CHECK_W (-0.61)
-#define CPOL_ITAB2_MAX_DEVIATION 1e-10   // accepted |polynomial - integrating kernel| / |value| at the check points (measured on
+#define CPOL_ITAB2_MAX_DEVIATION CPOL_ITAB_MAX_DEVIATION   // accepted |polynomial - integrating kernel| / |value| at the check points (measured on
                                          // the full-size tables: 1.7e-12, in a column that nearly cancels at 88 deg elevation)
 struct ItabDev {
     const double *tab;     // 1-D: [n_slices][n_pan][CPOL_ITAB_NC][CPOL_ITAB_NFP] monomial coefficients (power-major:

@@ -1492,7 +1492,7 @@ __device__ __forceinline__ double cheb_node(int q)
 __global__ void k_itab_nodes(ItabBuildArgs b)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int per_block = b.two_d ? CPOL_ITAB2_NODES : CPOL_ITAB_NC;
+    const int per_block = b.two_d ? CPOL_ITAB2_NODES : CPOL_ITAB1_NODES;
     const int per_slice = b.n_pan * per_block;
     const int upers = (per_slice + b.unit_items - 1) / b.unit_items;
     if (i == 0) { b.totals[0] = b.n_items; b.totals[1] = (long long)b.n_slices * upers; b.totals[2] = 0; }
@@ -1520,7 +1520,11 @@ __global__ void k_itab_nodes(ItabBuildArgs b)
         b.par[3 * b.n_items + i] = 0.0;
         return;
     }
-    b.par[i] = itab_node_lambda(b.log2_lo, r / CPOL_ITAB_NC, r % CPOL_ITAB_NC);
+    {
+        const int p = r / CPOL_ITAB1_NODES, q = r % CPOL_ITAB1_NODES;      // q == NC: the block's check point
+        b.par[i] = q < CPOL_ITAB_NC ? itab_node_lambda(b.log2_lo, p, q)
+                                    : exp2(b.log2_lo + ((double)p + (CPOL_ITAB1_CHECK_U + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
+    }
     b.par[b.n_items + i] = 1.0;             // N0
     b.par[2 * b.n_items + i] = 1.0;         // QM (ice)
     b.par[3 * b.n_items + i] = 0.0;
@@ -1537,6 +1541,9 @@ struct ItabFitArgs {
     long n_items;
     int n_slices, n_pan;
     double log2_lo, d0;
+    unsigned long long *worst; // check kernel: bits of the worst deviation | (block x NF + function) mod 2^24
+    unsigned int *n_bad;       // check kernel: (block, function) pairs at or above max_dev
+    double max_dev;
 };
 
 __global__ void k_itab_fit(ItabFitArgs f)
@@ -1550,7 +1557,7 @@ __global__ void k_itab_fit(ItabFitArgs f)
     double v[CPOL_ITAB_NC];
 #pragma unroll
     for (int q = 0; q < CPOL_ITAB_NC; ++q) {
-        const long i = blk * CPOL_ITAB_NC + q;
+        const long i = blk * CPOL_ITAB1_NODES + q;
         double x = fn < CPOL_N_SZ ? f.res[i * CPOL_N_SZ + fn]
                  : fn < CPOL_N_SZ + 2 ? f.vn[i * 2 + (fn - CPOL_N_SZ)] : f.par[3 * f.n_items + i];
         // gamma family: tabulate exp(+lambda d0) x integral (no super-exponential decay left)
@@ -1566,6 +1573,45 @@ __global__ void k_itab_fit(ItabFitArgs f)
         o[pw * CPOL_ITAB_NFP] = c;
         if (fn == CPOL_ITAB_NF - 1) o[pw * CPOL_ITAB_NFP + 1] = 0.0;     // padding column
     }
+}
+
+// The fitted 1-D polynomial against the integrating kernel at the check point of every block, one
+// thread per (block, function).  Scale: the largest |value| of the function over the block's nodes
+// (and the check point), so that a column that changes sign inside a panel raises no false alarm,
+// while a coefficient set that cancels badly (|coefficients| >> |values|) does.
+__global__ void k_itab_check1(ItabFitArgs f)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n_blocks = (long)f.n_slices * f.n_pan;
+    if (t >= n_blocks * CPOL_ITAB_NF) return;
+    const long blk = t / CPOL_ITAB_NF;
+    const int fn = (int)(t % CPOL_ITAB_NF);
+    const int p = (int)(blk % f.n_pan);
+    auto value = [&](int q, double lambda) {
+        const long i = blk * CPOL_ITAB1_NODES + q;
+        double x = fn < CPOL_N_SZ ? f.res[i * CPOL_N_SZ + fn]
+                 : fn < CPOL_N_SZ + 2 ? f.vn[i * 2 + (fn - CPOL_N_SZ)] : f.par[3 * f.n_items + i];
+        if (f.d0 != 0.0) x *= exp(lambda * f.d0);
+        return x;
+    };
+    double scale = 0.0;
+    bool nan = false;
+    for (int q = 0; q < CPOL_ITAB_NC; ++q) {
+        const double v = value(q, itab_node_lambda(f.log2_lo, p, q));
+        nan = nan || !(v == v);
+        scale = fmax(scale, fabs(v));
+    }
+    const double lam_c = exp2(f.log2_lo + ((double)p + (CPOL_ITAB1_CHECK_U + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
+    const double ref = value(CPOL_ITAB_NC, lam_c);
+    scale = fmax(scale, fabs(ref));
+    const double *c = f.tab + blk * (CPOL_ITAB_NC * CPOL_ITAB_NFP) + fn;
+    double got = c[(CPOL_ITAB_NC - 1) * CPOL_ITAB_NFP];
+    for (int q = CPOL_ITAB_NC - 2; q >= 0; --q) got = fma(got, CPOL_ITAB1_CHECK_U, c[q * CPOL_ITAB_NFP]);
+    double err = scale > 0.0 ? fabs(got - ref) / scale : 0.0;
+    if (nan || !(err == err) || !(ref == ref) || isinf(scale)) err = 1.0;
+    if (err >= f.max_dev) atomicAdd(f.n_bad, 1u);
+    if (err > 0.0)
+        atomicMax(f.worst, ((unsigned long long)__double_as_longlong(err) & ~0xFFFFFFull) | ((unsigned long long)t & 0xFFFFFFull));
 }
 
 // Melting species: node values V[b][a] (b: lambda_r node, a: fw node) of one function of one

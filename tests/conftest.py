@@ -15,19 +15,6 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 
 
-@pytest.fixture(scope='session', autouse=True)
-def _torch_gpu_first():
-    """On a GPU box: let torch initialise its HIP context before the library's first call (tests
-    that hand torch device buffers to the library otherwise depend on the test order)."""
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:
-        pass
-    yield
-
-
 @pytest.fixture(scope='session')
 def golden():
     import numpy as np

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(_native.LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()
-    lib = ctypes.CDLL(_native.LIB_PATH)
+    lib = _native.load_library()        # (not a bare CDLL: one HIP runtime per process, see below)
     declared = set(re.findall(r'\b(cpol_[a-z_]+)\s*\(', _header()))
     assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
     for name in declared:
@@ -257,3 +257,30 @@ def test_t_function_tables_are_the_reference_expressions_bit_for_bit():
         - 0.000285 * Tc ** 2 + 0.312550 * n ** 2 + 0.000204 * Tc ** 2 * n \
         + 0.003199 * Tc * n ** 2 - 0.015952 * n ** 3
     assert np.array_equal(tabs['ice_mom2_a'][idx].view(np.uint32), (10 ** a).view(np.uint32))
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """libcosmo_pol_hip.so first, torch afterwards (a user who builds a RadarOperator and then
+    touches torch.cuda): the process must map ONE libamdhip64 -- with two, the second runtime to
+    initialise reports "No HIP GPUs are available" (gpurun_out/t_r2f.log of round 2).  Fresh
+    interpreter, because the order is the point."""
+    import subprocess
+    import sys
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'from cosmo_pol_amd import _native as N\n'
+            'N.load_library()\n'
+            'assert "torch" not in sys.modules\n'
+            'first = N.hip_runtimes_mapped()\n'
+            'import torch\n'
+            'torch.cuda.is_available()\n'
+            'both = N.hip_runtimes_mapped()\n'
+            'print(len(first), len(both))\n' % ROOT)
+    out = subprocess.check_output([sys.executable, '-c', code], env=dict(os.environ, CPOL_HIP_RUNTIME=''))
+    assert out.split() == [b'1', b'1'], out
+    # the other order (what bench.py and most tests do)
+    code2 = ('import sys; sys.path.insert(0, %r)\n'
+             'import torch\n'
+             'from cosmo_pol_amd import _native as N\n'
+             'N.load_library()\n'
+             'print(len(N.hip_runtimes_mapped()))\n' % ROOT)
+    assert subprocess.check_output([sys.executable, '-c', code2]).split() == [b'1']

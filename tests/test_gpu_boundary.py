@@ -244,3 +244,34 @@ def test_table_sets_stay_resident_across_configuration_switches():
     for k in ('ZH', 'ZDR', 'KDP', 'RHOHV', 'PHIDP', 'ATT_H', 'RVEL'):
         assert np.array_equal(r3[k], r1[k], equal_nan=True), k
     op.close()
+
+
+def test_operator_first_then_torch_cuda():
+    """A RadarOperator built BEFORE torch is imported, then torch.cuda used in the same process
+    (round 2: RuntimeError "No HIP GPUs are available", two HIP runtimes mapped).  Own interpreter:
+    the import order is what is tested."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys\n'
+            'for p in (%r, %r + "/oracle", %r + "/tests"): sys.path.insert(0, p)\n'
+            'import numpy as np, _cases\n'
+            'from cosmo_pol_amd import RadarOperator, _native as N\n'
+            'assert "torch" not in sys.modules\n'
+            'over = _cases.gen_golden.radial_case_inputs("c2_rsg")[0]\n'
+            '_, az, el, _, luts, cube = _cases.radial_case("c2_rsg")\n'
+            'op = RadarOperator(config=over, luts=luts, output_variables="only_radar")\n'
+            'op.load_model_arrays(cube["data"], cube["zlevels"], cube["proj_info"], cube["resolution"])\n'
+            'a = op.simulate_rays([az], [el])\n'
+            'import torch\n'
+            'z = torch.zeros(8, device="cuda")\n'
+            'slab = torch.zeros((1, a["ZH"].shape[1]), dtype=torch.float32, device="cuda")\n'
+            'op.simulate_rays([az], [el], device_outputs={"ZH": slab.data_ptr()})\n'
+            'op.wait()\n'
+            'assert np.array_equal(slab.cpu().numpy(), a["ZH"], equal_nan=True)\n'
+            'assert len(N.hip_runtimes_mapped()) == 1, N.hip_runtimes_mapped()\n'
+            'op.close()\n'
+            'print("ok", float(z.sum()))\n' % (root, root, root))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ok 0.0' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
