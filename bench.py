@@ -1,43 +1,51 @@
 #!/usr/bin/env python
 """bench.py -- range-gates/s of the cosmo_pol hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c2|c4]
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workloads (BASELINE.json `configs`):
 
   c2 (default at N = 1; configs[1], the configuration the metric is quoted on)
-      360-azimuth x 500-gate C-band PPI at 1.0 deg, rain + snow + graupel 1-moment, one
-      sub-beam, attenuation on, synthetic COSMO-1-like cube (80 x 774 x 1158) and full-size
-      synthetic scattering tables.  A step = one complete sweep through the C ABI: per-sweep
-      parameters, all kernels, and the device-to-host copy of the outputs: the ten
-      radar observables and the radial mask of every gate land in the lane's page-locked host
-      slab (cpol_host_alloc; outputs_on_device = 2).  Consecutive steps run on three LANES
-      (cpol_fork: shared cube and tables, own stream and work buffers) so that the copy of
-      one sweep overlaps the kernels of the next, as the sweeps of a volume scan do in the
-      product.  The per-ray tables of the unchanged scan geometry stay resident in HBM and
-      the gate coordinates (functions of those tables only) are copied once;
-      `value_fresh_tables_full_d2h` re-uploads the tables and copies all 15 output arrays
-      every step, `value_device_resident` leaves the outputs in HBM.
+      360-azimuth x 500-gate C-band PPI, rain + snow + graupel 1-moment, one sub-beam,
+      attenuation on, synthetic COSMO-1-like cube (80 x 774 x 1158) and full-size synthetic
+      scattering tables.  A step = one complete sweep through the C ABI as SURVEY 8(d) counts it:
+      the per-ray tables of the sweep are computed on the host and uploaded, all kernels run, and
+      EVERY output array of the sweep -- nine polarimetric observables, RVEL, the radial mask and
+      the gate coordinates (lats, lons, dist, heights): 15 arrays, 76 B per gate -- is copied to
+      page-locked host memory.  The elevation CHANGES every step (1.0 + 0.05 k deg, k = step mod
+      16; more elevations than the operator's host cache of ray tables holds), so nothing that
+      depends on the scan geometry is reused on the host or on the device.  Consecutive steps run
+      on three LANES (cpol_fork: shared cube and tables, own stream and work buffers) so that the
+      copy of one sweep overlaps the kernels of the next, as the sweeps of a volume scan do in
+      the product.  Extras of the same line: `value_cached_geometry` (round 2's headline: one
+      fixed elevation, per-ray tables resident, gate coordinates copied once) and
+      `value_device_resident` (outputs left in HBM).
 
-  c4 (default at N > 1; configs[3])
-      5-elevation volume (360 x 500 each), full 1-moment hydrometeor set with melting layer
-      and ice crystals, 7 x 7 Gauss-Hermite antenna quadrature (49 sub-beams).  STRONG
-      scaling: the 360 azimuths of every sweep are split into contiguous blocks of
-      ceil(360 / N) rays, one per rank (cosmo_pol_amd/distributed.py); every rank writes its
-      block of each sweep into a device slab and ONE all-gather per sweep (RCCL over xGMI)
-      assembles the sweep on every rank; rank 0 copies the assembled volume to page-locked
-      host memory.  A step = one volume.  After the timed region rank 0 runs the same volume
-      alone (`single_gpu_same_workload`) and compares the gathered result with it bit for bit
+  c3 (configs[2])   5-elevation volume (360 x 500 each), R,S,G,mS,mG,I with melting layer and ice
+      crystals, one sub-beam.  A step = one volume: per-sweep tables up, kernels, all outputs down.
+  c4 (default at N > 1; configs[3])   the c3 volume with the 7 x 7 Gauss-Hermite antenna
+      quadrature (49 sub-beams).  STRONG scaling: the 360 azimuths of every sweep are split into
+      contiguous blocks of ceil(360 / N) rays, one per rank (cosmo_pol_amd/distributed.py); a
+      rank runs its rays of ALL five sweeps as one launch sequence and ONE all-gather per volume
+      (RCCL over xGMI) assembles the volume on every rank; rank 0 copies it to page-locked host
+      memory.  A step = one volume.  After the timed region rank 0 runs the same volume alone
+      (`single_gpu_same_workload`) and compares the gathered result with it bit for bit
       (`gather_check`).
+  c5 (configs[4])   GPM-DPR Ku (200 x 49 rays) and Ka (200 x 25) swaths over the 2-moment cube
+      through RadarOperator.get_GPM_swath.  A step = both swaths; gates = the gates kept (h < 35 km).
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (the PSD x table
-stage): live HIP-event durations on the library's stream over the timed region
-(cpol_enable_timing / cpol_counters), VALU instruction counts and HBM traffic from the
-rocprofv3 PMC passes committed under profiles/ (read at run time, never hard-coded).
-`cpu_baseline` times the CPU oracle (the restatement of the reference algorithm, per radial,
-un-batched) on this host: one pinned core (median of 5 samples) and a fork pool over
-os.cpu_count() cores as radar_operator.py:402,431 does.
+At N = 1 with the default workload the line also carries `c3`, `c4_volume_one_gpu` and `c5`:
+the same script run with --workload c3 / c4 / c5 in child processes after the c2 operator is
+closed (driver-timed like the rest of the run).
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the workload:
+`achieved` = algorithmic bytes per launch over the live HIP-event duration on the
+library's stream (cpol_enable_timing / cpol_counters), `traffic` = HBM bytes per launch of the
+rocprofv3 PMC passes committed under profiles/ (read at run time, never hard-coded), `frac` =
+traffic over the live duration against the 8 TB/s HBM peak.  `cpu_baseline` times the CPU oracle
+(the restatement of the reference algorithm, per radial, un-batched) on this host: one pinned core
+(median of 5 samples) and a fork pool over os.cpu_count() cores as radar_operator.py:402,431 does.
 """
 import argparse
 import contextlib
@@ -76,22 +84,101 @@ def bench_config(small, workload='c2'):
         conf['microphysics'].update(with_melting=1, with_ice_crystals=1)
     if workload == 'c4':
         conf['integration'].update(nh_GH=7, nv_GH=7)
+    if workload == 'c5':
+        conf['radar']['type'] = 'GPM'
+        conf['microphysics'].update(scheme='2mom', with_melting=0, with_ice_crystals=1)
     return conf
 
 
 def hydrometeors_of(workload):
+    if workload == 'c5':
+        return ('R', 'S', 'G', 'H', 'I')
     return ('R', 'S', 'G') if workload == 'c2' else ('R', 'S', 'G', 'mS', 'mG', 'I')
 
 
 def load_profile_summary(workload):
-    """profiles/r2_<workload>_summary.json (tools/profile_summary.py): per kernel the mean
-    SQ_INSTS_VALU, FETCH_SIZE, WRITE_SIZE per dispatch and the kernel-trace duration."""
-    path = os.path.join(ROOT, 'profiles', 'r2_%s_summary.json' % workload)
-    try:
-        with open(path) as f:
-            return json.load(f), os.path.relpath(path, ROOT)
-    except (OSError, ValueError):
-        return None, None
+    """profiles/r3_<workload>_summary.json (tools/profile_summary.py; r2_* if this round's file is
+    missing): per kernel the mean FETCH_SIZE / WRITE_SIZE / SQ counters per dispatch, `hbm_bytes`
+    (FETCH_SIZE weighted per kernel as profiles/README.md states, + WRITE_SIZE) and the
+    kernel-trace duration."""
+    for tag in ('r3', 'r2'):
+        path = os.path.join(ROOT, 'profiles', '%s_%s_summary.json' % (tag, workload))
+        try:
+            with open(path) as f:
+                return json.load(f), os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
+# stage of the launch sequence (cpol_counters_t.ms_*) -> its kernels in the rocprofv3 summaries
+STAGE_KERNELS = {'interp': ('k_interp_sweep',), 'classify': ('k_classify', 'k_ml_weights'),
+                 'bucket': ('k_bucket_scan', 'k_bucket_scatter'),
+                 'psd': ('k_psd_lookup', 'k_subbeam_sum'),     # (+ the integrating kernels: empty launches in a sweep)
+                 'final': ('k_final', 'k_rvel_terms', 'k_ice_first')}
+TABLE_BUILD_KERNELS = ('k_itab_', 'k_stage_')      # cpol_prepare / cpol_stage_model: not part of a sweep
+
+
+def stage_rooflines(prof_name, stage_ms, n_sbg, n_valid, n_gates, n_vars, nz, launches_per_run=1):
+    """Every stage of ONE sweep against the HBM roofline.  Per stage: live HIP-event duration
+    (cpol_counters_t, one isolated sweep on one lane), HBM bytes per sweep of its kernels from the
+    committed rocprofv3 PMC passes of the SAME isolated sweep (profiles/<prof_name>_summary.json),
+    `frac` = those bytes / live duration / 8 TB/s, and the ALGORITHMIC bytes of SURVEY 8(d):
+    interp N_sbg x (4 nz 4 + n_vars 8 4) B, psd N_valid x 49152 B, final N_gates x 48 B."""
+    prof, prof_path = load_profile_summary(prof_name)
+    alg = {'interp': n_sbg * (4 * nz * 4 + n_vars * 8 * 4), 'psd': n_valid * LUT_SLICE_BYTES,
+           'final': n_gates * 48, 'classify': 0, 'bucket': 0}
+    out = {}
+    for st, kernels in STAGE_KERNELS.items():
+        ms = stage_ms.get(st)
+        traffic = prof_us = None
+        used = []
+        if prof:
+            for name, c in prof.items():
+                if name.startswith('_') or not isinstance(c, dict) or not any(k in name for k in kernels):
+                    continue
+                if c.get('hbm_bytes') is None:
+                    continue
+                per_sweep = c.get('per_sweep', 1.0)          # dispatches of this kernel per sweep
+                traffic = (traffic or 0.0) + c['hbm_bytes'] * per_sweep
+                prof_us = (prof_us or 0.0) + (c.get('avg_us') or 0.0) * per_sweep
+                used.append(name.split('(')[0])
+        t = ms * 1e-3 if ms and ms > 0 else None
+        out[st] = {'kernels': used, 'live_ms': ms, 'profile_us': prof_us, 'traffic': traffic,
+                   'achieved': traffic / t / 1e9 if (t and traffic) else None,
+                   'frac': traffic / t / 1e9 / HBM_PEAK_GBS if (t and traffic) else None,
+                   'algorithmic_bytes': alg[st],
+                   'hbm_alg_frac': alg[st] / t / 1e9 / HBM_PEAK_GBS if (t and alg[st]) else None}
+    return out, prof_path
+
+
+def roofline_of_dominant_stage(prof_name, stage_ms, n_sbg, n_valid, n_gates, n_vars, nz, note=''):
+    """The bench line's `roofline`: the stage with the longest live duration."""
+    stages, prof_path = stage_rooflines(prof_name, stage_ms, n_sbg, n_valid, n_gates, n_vars, nz)
+    live = {k: v['live_ms'] for k, v in stages.items() if v['live_ms']}
+    if not live:
+        return {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None,
+                'traffic': None, 'stages': stages}
+    dom = max(live, key=live.get)
+    d = stages[dom]
+    total_ms = sum(live.values())
+    total_traffic = sum(v['traffic'] or 0.0 for v in stages.values())
+    total_alg = sum(v['algorithmic_bytes'] for v in stages.values())
+    return {'kernel': ' + '.join(d['kernels']) or dom, 'stage': dom, 'bound': 'hbm',
+            'achieved': d['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': d['frac'],
+            'traffic': d['traffic'], 'traffic_source': prof_path,
+            'avg_launch_ms': d['live_ms'], 'profile_avg_us': d['profile_us'],
+            'algorithmic_bytes_per_launch': d['algorithmic_bytes'], 'hbm_alg_frac': d['hbm_alg_frac'],
+            'whole_sweep': {'live_ms': total_ms, 'traffic': total_traffic,
+                            'frac': total_traffic / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if total_traffic else None,
+                            'algorithmic_bytes': total_alg,
+                            'hbm_alg_frac': total_alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            'stages': stages,
+            'note': ('frac = HBM bytes per launch of the PMC passes (profiles/) / live HIP-event duration of the '
+                     'stage (one isolated sweep, one lane) / 8 TB/s; achieved = the same in GB/s.  hbm_alg_frac = '
+                     'SURVEY 8(d) algorithmic bytes over the same duration: > 1 for the PSD stage, because the '
+                     'integral tables replace the gather of a 49152-B table slice per item by 1056 B of polynomial '
+                     'coefficients (the slices are read once, at staging).  ' + note)}
 
 
 def main():
@@ -99,7 +186,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
-    ap.add_argument('--workload', choices=['auto', 'c2', 'c4'], default='auto',
+    ap.add_argument('--workload', choices=['auto', 'c2', 'c3', 'c4', 'c5'], default='auto',
                     help="auto: c2 at N = 1 (the metric's configuration), c4 strong scaling at N > 1")
     ap.add_argument('--repeats', type=int, default=5, help='repeats of the timed region (c2)')
     ap.add_argument('--small', action='store_true', help='small cube / tables (debugging, tests)')
@@ -121,9 +208,11 @@ def main():
         args.gpus = world
     workload = args.workload if args.workload != 'auto' else ('c2' if world == 1 else 'c4')
     if args.steps is None:
-        args.steps = 200 if workload == 'c2' else 10
+        args.steps = {'c2': 200, 'c3': 20, 'c4': 10, 'c5': 5}[workload]
     if args.warmup is None:
-        args.warmup = 10 if workload == 'c2' else 2
+        args.warmup = {'c2': 10, 'c3': 3, 'c4': 2, 'c5': 1}[workload]
+    if workload in ('c3', 'c5') and world > 1:
+        raise SystemExit('--workload %s is a single-GPU extra; the multi-GPU workloads are c4 (strong) and c2 (weak)' % workload)
     # debugging aids for a one-GPU box: CPOL_BENCH_BACKEND=gloo CPOL_BENCH_ONE_DEVICE=1 runs the
     # N-rank code path with every rank on GPU 0 (never used by the driver)
     backend = os.environ.get('CPOL_BENCH_BACKEND', 'nccl')
@@ -132,9 +221,14 @@ def main():
     from cosmo_pol_amd import RadarOperator, synthetic
     conf = bench_config(args.small, workload)
     hyds = hydrometeors_of(workload)
-    cube_h = tuple(h for h in hyds if h in ('R', 'S', 'G', 'I'))
+    cube_h = tuple(h for h in hyds if h in ('R', 'S', 'G', 'H', 'I'))
     t0 = time.time()
-    if args.small:
+    n_e = 8 if args.small else None
+    if workload == 'c5':
+        cube = (synthetic.small_test_cube(hydrometeors=cube_h, two_moment=True) if args.small
+                else synthetic.make_cube(hydrometeors=cube_h, two_moment=True, **synthetic.BENCH_GRID))
+        luts = lambda hl, freq, scheme: synthetic.make_all_luts(hl, freq, scheme, n_e=n_e)   # noqa: E731 (Ku / Ka / C sets)
+    elif args.small:
         cube = synthetic.small_test_cube(hydrometeors=cube_h)
         luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
     else:
@@ -145,7 +239,7 @@ def main():
     # CPU baselines first: the all-core leg forks workers, which must happen before this
     # process initialises the GPU (HIP state does not survive a fork)
     cpu_res = None
-    if world == 1 and args.cpu_seconds > 0:
+    if world == 1 and args.cpu_seconds > 0 and workload != 'c5':
         el_cpu = 1.0 if workload == 'c2' else C4_ELEVATIONS[2]
         print('[bench] CPU baseline: one pinned core ...', file=sys.stderr, flush=True)
         cpu_res = cpu_baseline(conf, cube, luts, np.arange(0, 360, 1.0), el_cpu, args.cpu_seconds)
@@ -179,7 +273,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     env = dict(op=op, lanes=lanes, n_lanes=n_lanes, world=world, rank=rank, local_rank=local_rank,
                args=args, cube=cube, conf=conf, torch=torch, dist=dist, workload=workload, luts=luts)
-    out = run_c2(env) if workload == 'c2' else run_c4(env)
+    out = {'c2': run_c2, 'c3': run_c3, 'c4': run_c4, 'c5': run_c5}[workload](env)
     if rank == 0:
         out['setup_s'] = {'synthetic_inputs': t_gen, 'stage_to_hbm': t_stage,
                           'of_which_scattering_and_integral_tables': t_tables, 'prepare_again': t_rebuild}
@@ -191,41 +285,57 @@ def main():
         dist.destroy_process_group()
     op.close()
     if rank == 0:
-        if (world == 1 and args.workload == 'auto' and not args.small
-                and not os.environ.get('CPOL_BENCH_NO_C4')):
-            out['c4_volume_one_gpu'] = c4_reference_run()
+        if world == 1 and args.workload == 'auto' and not os.environ.get('CPOL_BENCH_NO_EXTRAS'):
+            # the other BASELINE configurations on this GPU, one child process each (after the c2
+            # operator is closed): driver-timed like the rest of the run
+            small = ['--small'] if args.small else []
+            out['c3'] = child_run('c3', ['--steps', '20', '--warmup', '3'] + small)
+            out['c4_volume_one_gpu'] = child_run('c4', ['--steps', '6', '--warmup', '2'] + small)
+            out['c5'] = child_run('c5', ['--steps', '3', '--warmup', '1'] + small)
         print(json.dumps(out))
 
 
-def c4_reference_run():
-    """N = 1, default workload only: the multi-GPU workload (c4, what `--gpus N` runs for N > 1) on
-    this one GPU, in a child process after the c2 operator is closed, so that the N = 1 line also
-    carries the single-GPU reference of the strong-scaling runs."""
+def child_run(workload, flags):
+    """N = 1, default workload only: `bench.py --workload <workload>` on this GPU in a child process, so
+    that the N = 1 line also carries the other BASELINE configurations (c4 = the single-GPU reference
+    of the strong-scaling runs)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'c4', '--steps', '6', '--warmup', '2',
-           '--cpu-seconds', '0']
+    cmd = [sys.executable, os.path.abspath(__file__), '--workload', workload, '--cpu-seconds', '0'] + flags
+    t0 = time.time()
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, CPOL_BENCH_NO_C4='1'))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, CPOL_BENCH_NO_EXTRAS='1'))
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
         if r.returncode != 0 or not line:
             return {'error': (r.stderr or r.stdout)[-400:]}
         d = json.loads(line[-1])
-        return {'value': d['value'], 'unit': d['unit'], 'ms_per_volume': d['ms_per_step'], 'steps': d['steps'],
-                'workload': d['config']['workload'], 'gather_check': d.get('gather_check'),
-                'psd_stage_ms_per_sweep': d['roofline'].get('avg_stage_ms'),
-                'setup_s': d.get('setup_s'),
-                'note': 'python bench.py --workload c4 --steps 6 --warmup 2 on the same GPU (child process)'}
-    except Exception as e:                                   # the headline line must not depend on this extra
+        keep = {k: d.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'gather_check',
+                                      'roofline', 'setup_s', 'stages_ms', 'counters', 'api_ms', 'per_band',
+                                      'single_sweep_ms', 'host_submit_ms_per_step') if k in d}
+        keep['workload'] = d['config']['workload']
+        keep['child_wall_s'] = time.time() - t0
+        keep['command'] = 'python bench.py ' + ' '.join(cmd[2:])
+        return keep
+    except Exception as e:                                   # the headline line must not depend on an extra
         return {'error': repr(e)[:400]}
 
 
 # ------------------------------------------------------------------------------------------ c2
+C2_ELEVATIONS = [1.0 + 0.05 * k for k in range(16)]     # one per step, round robin (> the host cache of ray tables)
+GEOM_FIELDS = ['lats', 'lons', 'dist', 'heights']
+
+
+def stage_ms_of(c):
+    return {'interp': c.ms_interp, 'classify': c.ms_classify, 'bucket': c.ms_bucket, 'psd': c.ms_psd,
+            'final': c.ms_final}
+
+
 def run_c2(env):
     from cosmo_pol_amd import RadarOperator
     op, lanes, n_lanes, world, rank = env['op'], env['lanes'], env['n_lanes'], env['world'], env['rank']
     args, torch, dist, cube = env['args'], env['torch'], env['dist'], env['cube']
     az = np.arange(0, 360, 1.0)
     el = np.full(len(az), 1.0)
+    els = [np.full(len(az), e) for e in C2_ELEVATIONS]
     n_rays, n_gates = len(az), len(op.constants.RANGE_RADAR)
     dev = torch.device('cuda', env['local_rank'])
     counter = [0]
@@ -243,7 +353,14 @@ def run_c2(env):
     comm_stream = torch.cuda.Stream() if world > 1 else None
     slab_free = [None] * n_buf
 
-    def step_pinned():                      # the headline step at N = 1
+    def step_full():
+        """The headline step at N = 1: a NEW elevation, its per-ray tables computed
+        on the host and uploaded, all kernels, all 15 output arrays to page-locked host memory."""
+        k = counter[0]
+        counter[0] += 1
+        return op.simulate_rays(az, els[k % len(els)], pinned=True, lane=k % n_lanes)
+
+    def step_cached():                      # round 2's headline: fixed geometry, tables resident
         lane = counter[0] % n_lanes
         counter[0] += 1
         return op.simulate_rays(az, el, pinned=True, lane=lane)
@@ -288,28 +405,25 @@ def run_c2(env):
             elapsed = float(tt.item())
         return elapsed, t_submit
 
-    step = step_pinned if world == 1 else step_device
+    step = step_full if world == 1 else step_device
     if world > 1:
         with torch.cuda.stream(comm_stream):     # communicator set-up belongs to the setup phase
             dist.all_gather_into_tensor(gathered[0], slabs[0].view(-1))
         fence()
+    op.reuse_device_tables = world > 1          # N = 1: nothing of the scan geometry stays on the device
     for _ in range(2 * n_lanes):         # set-up: every lane's slabs / work buffers exist
         step()
     fence()
     for _ in range(args.warmup):
         step()
     fence()
-    op._ctx.enable_timing(2)             # HIP events around the PSD stage of lane 0 (2 per sweep)
     runs = [timed(step, args.steps) for _ in range(max(1, args.repeats))]
-    cnt = op._ctx.counters()
-    for i in range(1, n_lanes):
-        op._lane(i).counters()
-    op._ctx.enable_timing(False)
     per_step = sorted(1e3 * e / args.steps for e, _ in runs)
     elapsed = statistics.median(e for e, _ in runs)
     t_submit = statistics.median(s for _, s in runs)
     gates_per_step = world * n_rays * n_gates
     value = gates_per_step * args.steps / elapsed
+    op.reuse_device_tables = True
 
     gather_ok = None
     if world > 1:
@@ -320,24 +434,26 @@ def run_c2(env):
                         for r in range(world))
 
     extra = {}
-    iso = None
+    iso = cnt = None
     if world == 1:
+        # round 2's headline: fixed elevation, per-ray tables resident, gate coordinates copied once
+        for _ in range(2 * n_lanes):
+            step_cached()
+        e_c, _ = timed(step_cached, args.steps)
+        extra['value_cached_geometry'] = gates_per_step * args.steps / e_c
         # outputs left in HBM (no device-to-host copy)
         for _ in range(3):
             step_device()
         e_dev, _ = timed(step_device, args.steps)
         extra['value_device_resident'] = gates_per_step * args.steps / e_dev
-        # per-ray tables re-uploaded and all 15 output arrays (gate coordinates included)
-        # copied on every step
-        op.reuse_device_tables = False
-        for _ in range(3):
-            step_pinned()
-        n_it = max(3, args.steps // 2)
-        e_fr, _ = timed(step_pinned, n_it)
-        extra['value_fresh_tables_full_d2h'] = gates_per_step * n_it / e_fr
-        op.reuse_device_tables = True
-        # the same sweep on ONE lane (no other sweep in flight): kernel durations in isolation
-        n_it = max(5, args.steps // 2)
+        # the PSD stage with three sweeps in flight (events on lane 0 only, 2 per sweep)
+        op._ctx.enable_timing(2)
+        timed(step_device, args.steps)
+        cnt = op._ctx.counters()
+        op._ctx.enable_timing(False)
+        # ONE sweep at a time on ONE lane, events around every stage: the durations the roofline
+        # uses, and what profiles/r3_c2_iso_* profiles (tools/stage_times.py --config c2)
+        n_it = max(20, args.steps // 2)
         op._ctx.enable_timing(True)
         for _ in range(n_it):
             op.simulate_rays(az, el, device_outputs=dev_outs[0], lane=0)
@@ -361,15 +477,22 @@ def run_c2(env):
             'device_only_isolated': iso.ms_total,
             'note': 'median wall time of one call with nothing else in flight; get_PPI adds the dB / '
                     'masked-array packaging the reference does on the host too'}
+    else:
+        op._ctx.enable_timing(True)
+        for _ in range(5):
+            op.simulate_rays(az, el, device_outputs=dev_outs[0], lane=0)
+        fence()
+        iso = cnt = op._ctx.counters()
+        op._ctx.enable_timing(False)
 
     if rank != 0:
         return None
-    n_valid, n_sbg = int(cnt.n_valid_items), int(cnt.n_subbeam_gates)
-    n_vars = len(op._staged_vars)
-    psd_bytes = n_valid * LUT_SLICE_BYTES
-    sweep_bytes = (n_sbg * (4 * cube['zlevels'].shape[0] * 4 + n_vars * 8 * 4) + psd_bytes
-                   + n_rays * n_gates * 48)
-    roof = roofline_lookup('c2', cnt, psd_bytes, iso, n_fields_read=12)
+    n_valid, n_sbg = int(iso.n_valid_items), int(iso.n_subbeam_gates)
+    n_vars, nz = len(op._staged_vars), cube['zlevels'].shape[0]
+    roof = roofline_of_dominant_stage(
+        'c2_iso', stage_ms_of(iso), n_sbg, n_valid, n_rays * n_gates, n_vars, nz,
+        note='c2 sweep at 1.0 deg elevation: %d valid items, all on integral tables (%d).' % (n_valid, int(iso.n_table_items)))
+    roof['psd_stage_ms_with_three_lanes_in_flight'] = cnt.ms_psd
     if world == 1:
         # the integrating kernel itself (it builds the integral tables at staging time and takes the
         # items outside them): a second operator with the tables switched off, one lane
@@ -397,20 +520,21 @@ def run_c2(env):
             'CPOL_ITAB=0: every item integrated over its 1024 diameter bins by k_psd_uniform (one lane, '
             'isolated) -- the kernel that evaluates the table nodes at staging time and finishes the items '
             'outside the tables; f64-VALU bound: ' + roof['integrating_kernel']['note'])
-    d2h_bytes = n_rays * n_gates * (len(RADAR_FIELDS) * 4 + 8 + 8)
+    d2h_full = n_rays * n_gates * (len(RADAR_FIELDS) * 4 + 8 + 8 + 8 + 8 + 4 + 4)
     out = {
         'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': 'c2: 360-azimuth x 500-gate C-band PPI (el 1.0 deg), rain+snow+graupel '
-                               '1-moment, 1 sub-beam, synthetic %s cube; one sweep per GPU per step: '
-                               'kernels + device-to-host copy of 10 observables and the mask into '
-                               'page-locked host memory (%s)'
+        'config': {'workload': 'c2: 360-azimuth x 500-gate C-band PPI, rain+snow+graupel 1-moment, 1 sub-beam, '
+                               'synthetic %s cube; one sweep per GPU per step %s'
                                % ('x'.join(map(str, cube['zlevels'].shape)),
-                                  'N = 1' if world == 1 else 'N > 1: outputs gathered on the devices instead'),
+                                  '(N = 1): a new elevation every step (1.0 + 0.05 k deg, k = step mod 16), per-ray '
+                                  'tables computed on the host and uploaded, all kernels, all 15 output arrays '
+                                  '(9 observables, RVEL, mask, lats, lons, dist, heights) copied to page-locked host memory'
+                                  if world == 1 else '(N > 1: fixed elevation, outputs gathered on the devices)'),
                    'rays_per_gpu': n_rays, 'gates_per_ray': n_gates, 'lanes': n_lanes,
-                   'd2h_bytes_per_step': d2h_bytes if world == 1 else 0,
+                   'd2h_bytes_per_step': d2h_full if world == 1 else 0,
                    'parallelism': ('weak scaling: one sweep per rank per step, 1 all-gather/step on a side '
                                    'stream') if world > 1 else 'single GPU',
                    'small': bool(args.small)},
@@ -420,23 +544,19 @@ def run_c2(env):
                                  'note': 'each repeat = exactly `steps` steps between two fences; '
                                          '`value` and `ms_per_step` are the median repeat'},
         'roofline': roof,
-        'stages_ms': None if iso is None else {
-            'trajectory(debug only)': iso.ms_traj, 'interp': iso.ms_interp, 'classify': iso.ms_classify,
-            'bucket': iso.ms_bucket, 'psd': iso.ms_psd, 'final': iso.ms_final,
-            'device_total': iso.ms_total, 'psd_with_lanes_in_flight': cnt.ms_psd,
-            'launches_per_sweep': 7,
-            'note': 'one sweep on one lane (the pass after the timed region); in the timed '
-                    'region only the PSD stage of lane 0 carries events (2 per sweep)'},
+        'stages_ms': {'interp': iso.ms_interp, 'classify': iso.ms_classify,
+                      'bucket': iso.ms_bucket, 'psd': iso.ms_psd, 'final': iso.ms_final,
+                      'device_total': iso.ms_total, 'launches_per_sweep': 7,
+                      'note': 'one sweep at a time on one lane, HIP events around every stage (the pass after '
+                              'the timed region)'},
         'counters': {'n_subbeam_gates': n_sbg, 'n_valid_items': n_valid,
-                     'n_work_units': int(cnt.n_work_units), 'n_table_items': int(cnt.n_table_items),
-                     'sweep_algorithmic_bytes': sweep_bytes,
-                     'sweep_algorithmic_GBs': sweep_bytes * world / (elapsed / args.steps) / 1e9},
+                     'n_work_units': int(iso.n_work_units), 'n_table_items': int(iso.n_table_items)},
         'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
         'gather_check': gather_ok,
     }
     out.update(extra)
     if world == 1:
-        out['d2h_GBs'] = d2h_bytes * args.steps / elapsed / 1e9
+        out['d2h_GBs'] = d2h_full * args.steps / elapsed / 1e9
     return out
 
 
@@ -538,6 +658,150 @@ def roofline(workload, kernel, ms_stage, n_valid, psd_bytes, ms_isolated=None, v
                          'essential_fma_frac': -(-n_valid // 64) * 1024 * 12 / ti / 1e9 / peak,
                          'note': 'same sweep with one lane only (no overlap with other sweeps)'}
     return r
+
+
+# ------------------------------------------------------------------------------------------ c3
+def run_c3(env):
+    """BASELINE configs[2] on one GPU: 5 elevations x (360 x 500), R,S,G,mS,mG,I, one sub-beam.  A step
+    = one volume through the C ABI: per sweep the per-ray tables up, the kernels, all 15 output arrays
+    down into page-locked host memory; every sweep on a lane of its own (5 lanes), so that the arrays
+    of a volume stay valid until the next volume starts.  `api_ms`: the same volume through
+    RadarOperator.get_PPI (the drop-in call: + dB fields, masked arrays, scan container)."""
+    op, args, torch, cube = env['op'], env['args'], env['torch'], env['cube']
+    az = np.arange(0, 360, 1.0 if not args.small else 4.0)
+    n_el, n_rays, n_gates = len(C4_ELEVATIONS), len(az), len(op.constants.RANGE_RADAR)
+    els = [np.full(n_rays, e) for e in C4_ELEVATIONS]
+    for i in range(n_el):
+        op._lane(i)
+    op.reuse_device_tables = False
+
+    def volume():
+        return [op.simulate_rays(az, els[e], pinned=True, lane=e) for e in range(n_el)]
+
+    def fence():
+        for i in range(n_el):
+            op.wait(i)
+        torch.cuda.synchronize()
+
+    for _ in range(2):
+        volume()
+    fence()
+    for _ in range(args.warmup):
+        volume()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        volume()
+    t_submit = time.perf_counter() - t0
+    fence()
+    elapsed = time.perf_counter() - t0
+    op.reuse_device_tables = True
+    gates = n_el * n_rays * n_gates
+    # one sweep at a time, events around every stage (3 deg: what profiles/r3_c3_el3_iso_* profiles)
+    slab = torch.empty((len(RADAR_FIELDS), n_rays, n_gates), dtype=torch.float32, device='cuda')
+    ptrs = {k: slab[i].data_ptr() for i, k in enumerate(RADAR_FIELDS)}
+    per_sweep, iso3 = [], None
+    for e in range(n_el):
+        for _ in range(2):
+            op.simulate_rays(az, els[e], device_outputs=ptrs, lane=0)
+        op.wait(0)
+        op._ctx.enable_timing(True)
+        for _ in range(5):
+            op.simulate_rays(az, els[e], device_outputs=ptrs, lane=0)
+        op.wait(0)
+        c = op._ctx.counters()
+        op._ctx.enable_timing(False)
+        per_sweep.append({'elevation': C4_ELEVATIONS[e], 'device_ms': c.ms_total, 'n_valid_items': int(c.n_valid_items),
+                          'n_table_items': int(c.n_table_items)})
+        if C4_ELEVATIONS[e] == 3.0:
+            iso3 = c
+    api = []
+    with contextlib.redirect_stdout(sys.stderr):
+        op.lanes = 3
+        op.get_PPI(C4_ELEVATIONS, azimuths=az)
+        for _ in range(max(3, args.steps // 4)):
+            t0 = time.perf_counter()
+            op.get_PPI(C4_ELEVATIONS, azimuths=az)
+            api.append(1e3 * (time.perf_counter() - t0))
+    n_vars, nz = len(op._staged_vars), cube['zlevels'].shape[0]
+    roof = roofline_of_dominant_stage('c3_el3_iso', stage_ms_of(iso3), int(iso3.n_subbeam_gates), int(iso3.n_valid_items),
+                                      n_rays * n_gates, n_vars, nz, note='c3 sweep at 3 deg elevation.')
+    d2h = gates * (len(RADAR_FIELDS) * 4 + 8 + 8 + 8 + 8 + 4 + 4)
+    return {
+        'metric': 'range-gates/sec', 'value': gates * args.steps / elapsed, 'unit': 'gates/s', 'n_gpus': 1,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'c3: 5-elevation volume %s, %d x %d gates each, R,S,G,mS,mG,I 1-moment + melting layer, '
+                               '1 sub-beam; one volume per step through the C ABI: per-ray tables up, kernels, all 15 '
+                               'output arrays of every sweep to page-locked host memory; 5 lanes'
+                               % (C4_ELEVATIONS, n_rays, n_gates),
+                   'd2h_bytes_per_step': d2h, 'lanes': n_el, 'small': bool(args.small)},
+        'roofline': roof,
+        'stages_ms': dict(stage_ms_of(iso3), device_total=iso3.ms_total, sweep='3 deg'),
+        'single_sweep_ms': per_sweep,
+        'api_ms': {'get_PPI_volume_median': statistics.median(api), 'get_PPI_volume_min': min(api), 'lanes': 3,
+                   'note': 'RadarOperator.get_PPI(5 elevations): the same volume through the drop-in call, host '
+                           'packaging (dB fields, masked arrays, RadarScan) included'},
+        'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
+    }
+
+
+# ------------------------------------------------------------------------------------------ c5
+def run_c5(env):
+    """BASELINE configs[4] on one GPU: GPM-DPR Ku (200 scans x 49 rays, 125 m gates) and Ka (200 x 25,
+    250 m) swaths over the 2-moment cube (R,S,G,H,I) through RadarOperator.get_GPM_swath -- each call
+    switches the table set to the band's frequency (tables of a set seen before stay resident).  A step
+    = both swaths; gates = the gates kept (below 35 km, above the topography of the reference's cut)."""
+    from cosmo_pol_amd import gpm
+    op, args, torch = env['op'], env['args'], env['torch']
+    n_scans = 200 if not args.small else 12
+    centre = (46.5, 7.5)
+    swaths = {'Ku': gpm.synthetic_swath(n_scans=n_scans, n_rays=49, centre=centre, cross_track_deg=17.0,
+                                        scan_spacing_m=3000.0 if not args.small else 1500.0),
+              'Ka': gpm.synthetic_swath(n_scans=n_scans, n_rays=25, centre=centre, cross_track_deg=8.5,
+                                        scan_spacing_m=3000.0 if not args.small else 1500.0)}
+    if args.small:
+        for sw in swaths.values():                  # keep the footprints inside the small test cube
+            for k in ('Latitude', 'Longitude'):
+                c0 = centre[0] if k == 'Latitude' else centre[1]
+                sw[k] = c0 + (sw[k] - c0) * 0.12
+    per_band, first = {}, {}
+    with contextlib.redirect_stdout(sys.stderr):
+        for band, sw in swaths.items():
+            t0 = time.perf_counter()
+            out = op.get_GPM_swath(sw, band)         # first call: this band's tables are built and staged
+            first[band] = time.perf_counter() - t0
+            per_band[band] = {'rays': int(out.azimuths.size), 'kept_gates': int(np.sum(out.n_kept)),
+                              'finite_ZH': int(np.isfinite(out.raw['ZH']).sum()), 'first_call_s': first[band]}
+        for _ in range(args.warmup):
+            for band, sw in swaths.items():
+                op.get_GPM_swath(sw, band)
+        torch.cuda.synchronize()
+        t_band = {b: 0.0 for b in swaths}
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            for band, sw in swaths.items():
+                t1 = time.perf_counter()
+                op.get_GPM_swath(sw, band)
+                t_band[band] += time.perf_counter() - t1
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    for b in swaths:
+        per_band[b]['swath_ms'] = 1e3 * t_band[b] / args.steps
+        per_band[b]['gates_per_s'] = per_band[b]['kept_gates'] * args.steps / t_band[b]
+    gates = sum(v['kept_gates'] for v in per_band.values())
+    return {
+        'metric': 'range-gates/sec', 'value': gates * args.steps / elapsed, 'unit': 'gates/s', 'n_gpus': 1,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'c5: GPM-DPR Ku (%d x 49 rays, 125 m gates) + Ka (%d x 25, 250 m) swaths over the 2-moment '
+                               'cube (R,S,G,H,I) through RadarOperator.get_GPM_swath (blocking host outputs, SimulatedGPM '
+                               'packaging included); one step = both swaths; gates = gates kept below 35 km'
+                               % (n_scans, n_scans), 'small': bool(args.small)},
+        'roofline': {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
+                     'note': 'an API-level figure (host packaging included); the kernels are those of c2 / c3'},
+        'per_band': per_band,
+    }
 
 
 # ------------------------------------------------------------------------------------------ c4

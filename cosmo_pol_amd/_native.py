@@ -410,6 +410,24 @@ class Context(object):
         t = self.debug_read('itab_times', (CPOL_MAX_HYDRO, 2), np.float64)
         return {'check': a[0], 'at': a[1], 'n_bad': a[2], 'build_ms': t[:, 0], 'check_ms': t[:, 1]}
 
+    def itab_detail(self, slot):
+        """1-D integral table of `slot`: {'log2_lo', 'ppo', 'd0', 'n_pan', 'by_fn' [15], 'by_pan'
+        [n_pan], 'accepted_panels'} -- the worst deviation at the check points per function and per
+        lambda panel (panel p covers lambda in 2^(log2_lo + [p, p + 1] / ppo)) and the run of panels
+        [lo, hi) that passed the gate (None: table rejected); None for a slot without such a table."""
+        n = self.lib.cpol_debug_read(self.h, ('itab_detail%d' % slot).encode(), None, 0)
+        if n == 0:
+            return None
+        nb = -int(n) - 1000
+        if nb <= 0:
+            self._check(int(n), 'cpol_debug_read(itab_detail)')
+        v = self.debug_read('itab_detail%d' % slot, (nb // 8,), np.float64)
+        n_pan = int(v[3])
+        acc = v[19 + n_pan:19 + n_pan + 2]
+        return {'log2_lo': v[0], 'ppo': int(v[1]), 'd0': v[2], 'n_pan': n_pan, 'by_fn': v[4:19],
+                'by_pan': v[19:19 + n_pan],
+                'accepted_panels': (int(acc[0]), int(acc[1])) if len(acc) == 2 else None}
+
     def debug_math(self, op, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.empty_like(x)

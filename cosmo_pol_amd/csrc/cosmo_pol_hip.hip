@@ -88,6 +88,7 @@ struct cpol_ctx {
     uint64_t itab_builds = 0;
     double itab_check_at[CPOL_MAX_HYDRO] = {};
     double itab_check[CPOL_MAX_HYDRO] = {};     // worst deviation at the blocks' check points (negative: table rejected)
+    std::vector<double> itab_detail[CPOL_MAX_HYDRO];   // 1-D tables: [log2_lo, ppo, d0, n_pan, worst per function (NF), worst per panel (n_pan)]
     double itab_ms[CPOL_MAX_HYDRO][2] = {};     // device time of the last build of the slot's table: all of it, the check alone
     double itab_bad[CPOL_MAX_HYDRO] = {};       // 1-D tables: (block, function) pairs at or above the accepted deviation
     ItabSet its{};
@@ -287,7 +288,8 @@ int build_itabs(cpol_ctx *ctx)
         const long n_units = (long)n_slices * upers;
         if (n_items >= (1L << 31)) continue;
         const size_t tab_bytes = (size_t)n_slices * n_pan * (melt ? CPOL_ITAB2_NB : NC) * CPOL_ITAB_NFP * sizeof(double);
-        DevBuf b_par, b_perm, b_units, b_tot, b_res, b_vn;
+        DevBuf b_par, b_perm, b_units, b_tot, b_res, b_vn, b_det;
+        std::vector<unsigned long long> det_bits;
         int rc;
         // destination: the slot's own buffers, or (table_id given) a cache entry of its own
         ItabCacheEntry *ce = nullptr;
@@ -332,8 +334,9 @@ int build_itabs(cpol_ctx *ctx)
             (rc = ensure(ctx, b_tot, 6 * sizeof(long long))) ||
             (rc = ensure(ctx, b_res, (size_t)n_items * CPOL_N_SZ * sizeof(double))) ||
             (rc = ensure(ctx, b_vn, (size_t)n_items * 2 * sizeof(double))) ||
+            (rc = ensure(ctx, b_det, (size_t)(n_pan + CPOL_ITAB_NF) * sizeof(unsigned long long))) ||
             (rc = ensure(ctx, dst_tab, tab_bytes))) {
-            free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn);
+            free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn); free_buf(b_det);
             drop_entry();
             return rc;
         }
@@ -404,14 +407,19 @@ int build_itabs(cpol_ctx *ctx)
             fa.worst = (unsigned long long *)b_tot.p + 3;
             fa.n_bad = (unsigned int *)((unsigned long long *)b_tot.p + 4);
             fa.max_dev = max_dev;
+            HIPCHK(hipMemsetAsync(b_det.p, 0, (size_t)(n_pan + CPOL_ITAB_NF) * sizeof(unsigned long long), st));
+            fa.by_fn = (unsigned long long *)b_det.p;
+            fa.by_pan = fa.by_fn + CPOL_ITAB_NF;
+            det_bits.resize((size_t)n_pan + CPOL_ITAB_NF);
             HIPCHK(hipMemsetAsync(fa.worst, 0, 2 * sizeof(unsigned long long), st));
             const dim3 fgrid(cdiv((long)n_slices * n_pan * CPOL_ITAB_NF, 256));
-            hipLaunchKernelGGL(k_itab_fit, fgrid, dim3(256), 0, st, fa);
+            // (the check is part of the fit kernel: its share of the build = the 12th item of every block)
             (void)hipEventRecord(evb[1], st);
-            hipLaunchKernelGGL(k_itab_check1, fgrid, dim3(256), 0, st, fa);
             (void)hipEventRecord(evb[2], st);
+            hipLaunchKernelGGL(k_itab_fit, fgrid, dim3(256), 0, st, fa);
             HIPCHK(hipMemcpyAsync(&worst_bits, fa.worst, sizeof worst_bits, hipMemcpyDeviceToHost, st));
             HIPCHK(hipMemcpyAsync(&n_bad, fa.n_bad, sizeof n_bad, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(det_bits.data(), b_det.p, det_bits.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         }
         (void)hipEventRecord(evb[3], st);
         const hipError_t e = hipStreamSynchronize(st);
@@ -425,7 +433,12 @@ int build_itabs(cpol_ctx *ctx)
             }
             for (auto &e_ : evb) if (e_) (void)hipEventDestroy(e_);
         }
-        free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn);
+        free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn); free_buf(b_det);
+        ctx->itab_detail[j].clear();
+        if (!det_bits.empty()) {
+            ctx->itab_detail[j] = {lo, (double)ppo, gamma ? d0 : 0.0, (double)n_pan};     // (+ [pan_lo, pan_hi) at the end)
+            for (unsigned long long b : det_bits) { double v; memcpy(&v, &b, sizeof v); ctx->itab_detail[j].push_back(v); }
+        }
         if (e != hipSuccess || hipGetLastError() != hipSuccess) {
             ctx->err = "build_itabs: a kernel failed";
             drop_entry();
@@ -438,6 +451,26 @@ int build_itabs(cpol_ctx *ctx)
         }
         ctx->itab_check[j] = worst;
         ctx->itab_bad[j] = (double)n_bad;
+        int pan_lo = 0, pan_hi = n_pan;
+        if (!melt && !(worst < max_dev)) {
+            // 1-D table: keep the longest run of lambda panels whose blocks all pass (in practice everything
+            // but the last panel, where exp(-lambda D^nu) of the bins behind the first one goes subnormal);
+            // items with lambda outside the run are integrated bin by bin like items outside the table
+            const std::vector<double> &dv = ctx->itab_detail[j];
+            int best_lo = 0, best_n = 0, run_lo = 0;
+            for (int p = 0; p <= n_pan; ++p) {
+                const bool ok = p < n_pan && dv[4 + CPOL_ITAB_NF + p] < max_dev;
+                if (ok) continue;
+                if (p - run_lo > best_n) { best_n = p - run_lo; best_lo = run_lo; }
+                run_lo = p + 1;
+            }
+            if (2 * best_n >= n_pan) {
+                pan_lo = best_lo; pan_hi = best_lo + best_n;
+                worst = 0.0;
+                for (int p = pan_lo; p < pan_hi; ++p) worst = fmax(worst, dv[4 + CPOL_ITAB_NF + p]);
+                ctx->itab_check[j] = worst;
+            }
+        }
         if (!(worst < max_dev)) {
             // the polynomial does not reproduce the integrating kernel between the nodes (melting: wet-
             // fraction bins too wide for the degree, coarse test tables; 1-D: coefficients that cancel):
@@ -452,6 +485,8 @@ int build_itabs(cpol_ctx *ctx)
         t.log2_lo = lo;
         t.d0 = gamma ? d0 : 0.0;
         t.n_pan = n_pan;
+        t.pan_lo = pan_lo; t.pan_hi = pan_hi;
+        if (!ctx->itab_detail[j].empty()) { ctx->itab_detail[j].push_back(pan_lo); ctx->itab_detail[j].push_back(pan_hi); }
         t.writes_vn = ice || dop2 || d.numeric_intv || melt;
         t.ppo = ppo;
         t.two_d = melt ? 1 : 0;
@@ -1830,6 +1865,16 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
         if (!dst || max_bytes < (int64_t)sizeof v) return CPOL_ERR_ARG;
         memcpy(dst, v, sizeof v);
         return (int64_t)sizeof v;
+    }
+    if (!strncmp(name, "itab_detail", 11) && name[11] >= '0' && name[11] < '0' + CPOL_MAX_HYDRO && !name[12]) {
+        // slot j ("itab_detail<j>"): log2_lo, panels per octave, d0, n_pan, then the worst deviation at the
+        // check points per function (CPOL_ITAB_NF values) and per lambda panel (n_pan values); 1-D tables only
+        const cpol_ctx *own = ctx->parent ? ctx->parent : ctx;
+        const std::vector<double> &v = own->itab_detail[name[11] - '0'];
+        const int64_t nb = (int64_t)(v.size() * sizeof(double));
+        if (!dst || max_bytes < nb) return nb ? -nb - 1000 : 0;      // (size query: -(bytes) - 1000)
+        if (nb) memcpy(dst, v.data(), (size_t)nb);
+        return nb;
     }
     if (!strcmp(name, "itab_times")) {
         // per hydrometeor slot: device ms of the last integral-table build, and of its accuracy check

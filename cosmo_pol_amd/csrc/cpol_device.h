@@ -73,7 +73,7 @@ struct SpecSet {
 #define CPOL_ITAB_PPO    8       // panels per octave of lambda
 // Every 1-D block is verified when it is built: a 12th item per (slice, panel), at the off-node
 // position CPOL_ITAB1_CHECK_U, is integrated by the same kernel and compared with the polynomial,
-// function by function, on the scale of the function over the block (k_itab_check1).  A slot whose
+// function by function, on the scale of the function over the block (end of k_itab_fit).  A slot whose
 // worst deviation reaches CPOL_ITAB_MAX_DEVIATION keeps its items on the integrating kernels.
 #define CPOL_ITAB1_NODES (CPOL_ITAB_NC + 1)
 #define CPOL_ITAB1_CHECK_U 0.37
@@ -102,7 +102,8 @@ struct ItabDev {
     const double *head;    // 2-D: [n_t][2] centre and 1 / half-width of the wet-fraction bins
     double log2_lo;        // lambda of panel 0, node u = -1:  2^log2_lo
     double d0;             // gamma family: the tabulated function is exp(+lambda d0) x integral (d0 = D_0^nu)
-    int n_pan;
+    int n_pan;             // panels per slice in the table (its stride)
+    int pan_lo, pan_hi;    // panels [pan_lo, pan_hi) passed the accuracy gate: items with lambda outside are integrated
     int writes_vn;         // the direct kernels of this slot write vn (Doppler scheme 2, numeric integrate_V, ice)
     int ppo;               // panels per octave
     int two_d;             // melting species (2-D blocks)

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
             const double pf = (cp_log(P[its.t[j].par_slot * n]) * 1.4426950408889634 - its.t[j].log2_lo)
                               * (double)its.t[j].ppo;
-            lookup = pf >= 0.0 && pf < (double)its.t[j].n_pan;                   // NaN -> false
+            lookup = pf >= (double)its.t[j].pan_lo && pf < (double)its.t[j].pan_hi;   // NaN -> false
             a.par[((long)j * CPOL_MAX_PAR + 4) * n + i] = lookup ? pf : -1.0;
             my_lookup += lookup ? 1 : 0;
         }
@@ -1544,42 +1544,11 @@ struct ItabFitArgs {
     unsigned long long *worst; // check kernel: bits of the worst deviation | (block x NF + function) mod 2^24
     unsigned int *n_bad;       // check kernel: (block, function) pairs at or above max_dev
     double max_dev;
+    unsigned long long *by_pan;   // check kernel: [n_pan] bits of the worst deviation per lambda panel
+    unsigned long long *by_fn;    // check kernel: [CPOL_ITAB_NF] ... per function
 };
 
 __global__ void k_itab_fit(ItabFitArgs f)
-{
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n_blocks = (long)f.n_slices * f.n_pan;
-    if (t >= n_blocks * CPOL_ITAB_NF) return;
-    const long blk = t / CPOL_ITAB_NF;
-    const int fn = (int)(t % CPOL_ITAB_NF);
-    const int p = (int)(blk % f.n_pan);
-    double v[CPOL_ITAB_NC];
-#pragma unroll
-    for (int q = 0; q < CPOL_ITAB_NC; ++q) {
-        const long i = blk * CPOL_ITAB1_NODES + q;
-        double x = fn < CPOL_N_SZ ? f.res[i * CPOL_N_SZ + fn]
-                 : fn < CPOL_N_SZ + 2 ? f.vn[i * 2 + (fn - CPOL_N_SZ)] : f.par[3 * f.n_items + i];
-        // gamma family: tabulate exp(+lambda d0) x integral (no super-exponential decay left)
-        if (f.d0 != 0.0) x *= exp(itab_node_lambda(f.log2_lo, p, q) * f.d0);
-        v[q] = x;
-    }
-    double *o = f.tab + blk * (CPOL_ITAB_NC * CPOL_ITAB_NFP) + fn;
-#pragma unroll
-    for (int pw = 0; pw < CPOL_ITAB_NC; ++pw) {
-        double c = 0.0;
-#pragma unroll
-        for (int q = 0; q < CPOL_ITAB_NC; ++q) c = fma(f.M[pw * CPOL_ITAB_NC + q], v[q], c);
-        o[pw * CPOL_ITAB_NFP] = c;
-        if (fn == CPOL_ITAB_NF - 1) o[pw * CPOL_ITAB_NFP + 1] = 0.0;     // padding column
-    }
-}
-
-// The fitted 1-D polynomial against the integrating kernel at the check point of every block, one
-// thread per (block, function).  Scale: the largest |value| of the function over the block's nodes
-// (and the check point), so that a column that changes sign inside a panel raises no false alarm,
-// while a coefficient set that cancels badly (|coefficients| >> |values|) does.
-__global__ void k_itab_check1(ItabFitArgs f)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n_blocks = (long)f.n_slices * f.n_pan;
@@ -1591,27 +1560,52 @@ __global__ void k_itab_check1(ItabFitArgs f)
         const long i = blk * CPOL_ITAB1_NODES + q;
         double x = fn < CPOL_N_SZ ? f.res[i * CPOL_N_SZ + fn]
                  : fn < CPOL_N_SZ + 2 ? f.vn[i * 2 + (fn - CPOL_N_SZ)] : f.par[3 * f.n_items + i];
+        // gamma family: tabulate exp(+lambda d0) x integral (no super-exponential decay left)
         if (f.d0 != 0.0) x *= exp(lambda * f.d0);
         return x;
     };
+    double v[CPOL_ITAB_NC];
     double scale = 0.0;
     bool nan = false;
+#pragma unroll
     for (int q = 0; q < CPOL_ITAB_NC; ++q) {
-        const double v = value(q, itab_node_lambda(f.log2_lo, p, q));
-        nan = nan || !(v == v);
-        scale = fmax(scale, fabs(v));
+        v[q] = value(q, itab_node_lambda(f.log2_lo, p, q));
+        nan = nan || !(v[q] == v[q]);
+        scale = fmax(scale, fabs(v[q]));
     }
+    double *o = f.tab + blk * (CPOL_ITAB_NC * CPOL_ITAB_NFP) + fn;
+    double c[CPOL_ITAB_NC];
+#pragma unroll
+    for (int pw = 0; pw < CPOL_ITAB_NC; ++pw) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < CPOL_ITAB_NC; ++q) acc = fma(f.M[pw * CPOL_ITAB_NC + q], v[q], acc);
+        c[pw] = acc;
+        o[pw * CPOL_ITAB_NFP] = acc;
+        if (fn == CPOL_ITAB_NF - 1) o[pw * CPOL_ITAB_NFP + 1] = 0.0;     // padding column
+    }
+    // ---- the accuracy gate: the polynomial against the integrating kernel at the block's check point
+    // (the 12th item of the block), on the scale of the function over the block -- the largest |value|
+    // at the nodes and the check point -- so that a column that changes sign inside a panel raises no
+    // false alarm, while node values that are rounding noise of a cancelling sum do ----
     const double lam_c = exp2(f.log2_lo + ((double)p + (CPOL_ITAB1_CHECK_U + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
     const double ref = value(CPOL_ITAB_NC, lam_c);
     scale = fmax(scale, fabs(ref));
-    const double *c = f.tab + blk * (CPOL_ITAB_NC * CPOL_ITAB_NFP) + fn;
-    double got = c[(CPOL_ITAB_NC - 1) * CPOL_ITAB_NFP];
-    for (int q = CPOL_ITAB_NC - 2; q >= 0; --q) got = fma(got, CPOL_ITAB1_CHECK_U, c[q * CPOL_ITAB_NFP]);
+    double got = c[CPOL_ITAB_NC - 1];
+#pragma unroll
+    for (int q = CPOL_ITAB_NC - 2; q >= 0; --q) got = fma(got, CPOL_ITAB1_CHECK_U, c[q]);
     double err = scale > 0.0 ? fabs(got - ref) / scale : 0.0;
     if (nan || !(err == err) || !(ref == ref) || isinf(scale)) err = 1.0;
     if (err >= f.max_dev) atomicAdd(f.n_bad, 1u);
-    if (err > 0.0)
-        atomicMax(f.worst, ((unsigned long long)__double_as_longlong(err) & ~0xFFFFFFull) | ((unsigned long long)t & 0xFFFFFFull));
+    if (err > 0.0) {
+        // running maxima: a plain load first -- only a thread that would raise the maximum issues the
+        // atomic (5 M threads on ~200 addresses otherwise: 10 ms instead of 1)
+        const unsigned long long eb = (unsigned long long)__double_as_longlong(err);   // (positive doubles order like their bits)
+        const unsigned long long tagged = (eb & ~0xFFFFFFull) | ((unsigned long long)t & 0xFFFFFFull);
+        if (tagged > __builtin_nontemporal_load(f.worst)) atomicMax(f.worst, tagged);
+        if (eb > __builtin_nontemporal_load(f.by_pan + p)) atomicMax(f.by_pan + p, eb);
+        if (eb > __builtin_nontemporal_load(f.by_fn + fn)) atomicMax(f.by_fn + fn, eb);
+    }
 }
 
 // Melting species: node values V[b][a] (b: lambda_r node, a: fw node) of one function of one

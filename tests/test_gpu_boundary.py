@@ -194,7 +194,7 @@ def test_integral_tables_take_the_items_and_the_integrating_kernels_stay_pinned(
     c = op._ctx.counters()
     assert c.n_table_items == c.n_valid_items > 0 and c.n_work_units == 0
     chk = op._ctx.debug_read('itab_check', (2, 8), np.float64)[0]
-    assert (chk >= 0).all() and ((chk > 0) & (chk < 1e-10)).sum() == 2, chk     # mS, mG accepted
+    assert (chk >= 0).all() and ((chk > 0) & (chk < 1e-10)).sum() == 6, chk     # every table passed its gate
     op.close()
     op, _, _, _ = _op('c2_rsg')
     op.simulate_rays(az, np.full(len(az), 4.0))

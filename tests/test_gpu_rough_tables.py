@@ -51,6 +51,7 @@ def _run_hip(over, luts, cube, az, el, itab):
         cnt = op._ctx.counters()
         out['n_table_items'], out['n_valid_items'] = int(cnt.n_table_items), int(cnt.n_valid_items)
         out['report'] = op._ctx.itab_report()
+        out['detail'] = [op._ctx.itab_detail(j) for j in range(n_hyd)]
         out['hydro'] = list(op._staged_hydro)
         op.close()
         return out
@@ -107,17 +108,24 @@ def test_rough_tables_itab_vs_direct_vs_oracle(name, kind):
     assert hl == ocfg.hydrometeor_list(conf)
     rep = on['report']
     # ---- the accuracy gate: every slot has a verdict; accepted tables passed at 1e-10 ----
-    accepted = []
+    accepted, ranges = [], {}
     for j, h in enumerate(hl):
         chk = float(rep['check'][j])
         assert chk != 0.0, 'slot %s has no verdict' % h
         if chk > 0:
             assert chk < 1e-10, (h, chk)
-            assert rep['n_bad'][j] == 0
+            d = on['detail'][j]
+            if d is not None:                    # 1-D table: the run of lambda panels that passed the gate
+                lo, hi = d['accepted_panels']
+                assert np.all(d['by_pan'][lo:hi] < 1e-10) and 2 * (hi - lo) >= d['n_pan'], (h, lo, hi)
+                # all but the last panels -- except for 'alternating', where node values that are
+                # rounding noise of a 1e10-fold cancellation must make the gate cut the range
+                assert kind == 'alternating' or (lo == 0 and hi >= d['n_pan'] - 2), (h, lo, hi)
+                ranges[h] = (lo, hi, d['n_pan'])
             accepted.append(h)
     assert off['n_table_items'] == 0 and off['n_valid_items'] == on['n_valid_items']
     assert np.all(off['report']['check'] == 0)
-    if accepted:
+    if accepted and kind != 'alternating':       # ('alternating': the items may all lie in panels the gate cut)
         assert on['n_table_items'] > 0
     # ---- PSD-integrated entries: pure 1e-5, tables on and off, against the oracle ----
     assert np.isfinite(o.sz_integ).sum() > 200, 'the case was not exercised'
@@ -139,6 +147,10 @@ def test_rough_tables_itab_vs_direct_vs_oracle(name, kind):
         worst[k] = _worst_rel(on[k][well], o.values[k][well])
         n_cmp[k] = int((well & finite).sum())
     assert n_cmp['ZH'] >= 0.3 * finite.sum() and n_cmp['ATT_H'] >= 0.3 * finite.sum(), (n_cmp, int(finite.sum()))
+    if kind == 'alternating':
+        # the gate engaged: part of the items went to the integrating kernels
+        assert any(r[0] > 0 or r[1] < r[2] - 2 for r in ranges.values()) or len(accepted) < len(hl), ranges
+        assert on['n_table_items'] <= on['n_valid_items']
     from cosmo_pol_oracle import constants as OK
     kdp_atol = RTOL * 1e-3 * (180.0 / np.pi) * OK.Derived(conf).WAVELENGTH * (opabs[:, 8] + opabs[:, 10])
     for tag, r in (('on', on), ('off', off)):
@@ -156,7 +168,7 @@ def test_rough_tables_itab_vs_direct_vs_oracle(name, kind):
         worst['RHOHV'] = _worst_rel(on['RHOHV'][well], o.values['RHOHV'][well])
     _record({'case': name, 'kind': kind, 'hydro': hl,
              'itab_check': [float(x) for x in rep['check'][:len(hl)]],
-             'accepted': accepted, 'n_table_items': on['n_table_items'], 'n_valid_items': on['n_valid_items'],
+             'accepted': accepted, 'accepted_panels': ranges, 'n_table_items': on['n_table_items'], 'n_valid_items': on['n_valid_items'],
              'sz_integ_worst_rel_on': _worst_rel(on['sz_integ'], o.sz_integ),
              'sz_integ_worst_rel_off': _worst_rel(off['sz_integ'], o.sz_integ),
              'sz_integ_worst_rel_on_vs_off': _worst_rel(on['sz_integ'], off['sz_integ']),
@@ -200,11 +212,21 @@ def test_check_costs_little_on_full_size_tables():
     op._ctx.synchronize()
     t_prepare = 1e3 * (time.perf_counter() - t0)             # stage_hydro + cpol_prepare of the three slots
     rep = op._ctx.itab_report()
+    det = [op._ctx.itab_detail(j) for j in range(3)]
     op.close()
+    for d in det:
+        # the gate drops at most the last panels (exp(-lambda D^nu) of the bins behind the first goes
+        # subnormal there: lambda D_0^nu > 650, a mass density far below anything a model cell holds)
+        lo, hi = d['accepted_panels']
+        assert lo == 0 and hi >= d['n_pan'] - 2, d['accepted_panels']
+        assert np.all(d['by_pan'][lo:hi] < 1e-10)
     chk, ms_chk, ms_all = rep['check'][:3], rep['check_ms'][:3], rep['build_ms'][:3]
     _record({'case': 'bench R,S,G full-size tables', 'itab_check': [float(x) for x in chk],
              'build_ms': [float(x) for x in ms_all], 'check_ms': [float(x) for x in ms_chk],
+             'accepted_panels': [d['accepted_panels'] + (d['n_pan'],) for d in det],
+             'worst_by_function': [[float(x) for x in d['by_fn']] for d in det],
              'set_lut_wall_ms': t_prepare})
-    assert np.all(chk > 0) and np.all(chk < 1e-12), chk
+    assert np.all(chk > 0) and np.all(chk < 1e-10), chk
+    # the gate = one more item per block of 11 nodes (the comparison itself rides in the fit kernel)
     assert ms_chk.sum() < 0.05 * t_prepare, (ms_chk, t_prepare)
-    assert ms_chk.sum() < 0.25 * ms_all.sum(), (ms_chk, ms_all)
+    assert ms_chk.sum() < 0.10 * ms_all.sum(), (ms_chk, ms_all)
