@@ -560,58 +560,6 @@ def run_c2(env):
     return out
 
 
-L1_PEAK_GBS = 256 * 64 * PEAK_CLOCK / 1e9      # vector L1: 64 B / clk / CU (MI355X_MICROARCH.md)
-
-
-def roofline_lookup(workload, cnt, psd_bytes, iso, n_fields_read, traffic_scale=1.0, per_item_hbm=None,
-                    extra_hbm=0, kernels=('k_psd_lookup',)):
-    """The PSD x table stage when the integral tables take the items (k_psd_lookup).  Per item the
-    kernel MUST move its key and three parameters in and 12 float64 results out (124 B; HBM), and it
-    gathers `n_fields_read` x 11 float64 coefficients from the (slice, lambda-panel) block of the item
-    (1056 B per lane through the vector L1; the blocks of a sweep are a few hundred KB, L2-resident).
-    achieved / frac = the 124 B per item over the live stage time against the HBM peak -- small, the
-    kernel is bound by the L1 gather and, at the size of one C2 sweep (180 k threads), by latency;
-    `l1_gather` prices the coefficient bytes against the aggregate L1 bandwidth.  traffic = HBM bytes
-    of the committed PMC pass."""
-    prof, prof_path = load_profile_summary(workload)
-    traffic = prof_us = None
-    if prof:
-        for name, c in prof.items():
-            if any(k in name for k in kernels) and c.get('hbm_bytes'):
-                traffic = (traffic or 0) + c['hbm_bytes'] * traffic_scale
-                prof_us = (prof_us or 0) + (c.get('avg_us') or 0)
-    n_tab = int(cnt.n_table_items)
-    per_item_hbm = (4 + 3 * 8 + 12 * 8) if per_item_hbm is None else per_item_hbm
-    per_item_l1 = n_fields_read * 11 * 8
-    must = n_tab * per_item_hbm + extra_hbm
-    t = cnt.ms_psd * 1e-3 if cnt.ms_psd > 0 else None
-    r = {'kernel': '%s (+ the integrating kernels for the %d items outside the tables)'
-                   % (' + '.join(kernels), int(cnt.n_valid_items) - n_tab),
-         'bound': 'hbm', 'achieved': must / t / 1e9 if t else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-         'frac': must / t / 1e9 / HBM_PEAK_GBS if t else None,
-         'traffic': traffic, 'traffic_source': prof_path,
-         'bytes_per_item': per_item_hbm, 'n_table_items': n_tab, 'n_valid_items': int(cnt.n_valid_items),
-         'avg_stage_ms': cnt.ms_psd, 'profile_avg_us': prof_us,
-         'hbm_physical_frac': (traffic / t / 1e9 / HBM_PEAK_GBS) if (t and traffic) else None,
-         'l1_gather': {'bytes_per_item': per_item_l1, 'achieved': n_tab * per_item_l1 / t / 1e9 if t else None,
-                       'peak': L1_PEAK_GBS, 'unit': 'GB/s',
-                       'frac': n_tab * per_item_l1 / t / 1e9 / L1_PEAK_GBS if t else None},
-         'hbm_alg_frac': (psd_bytes / t / 1e9 / HBM_PEAK_GBS) if t else None,
-         'algorithmic_bytes_per_launch': psd_bytes,
-         'note': 'achieved = (key + 3 parameters + 12 results) x items / live HIP-event time of the PSD stage '
-                 '(lookup + the empty integrating launch); hbm_alg_frac = the survey\'s B_alg (N_valid x 49152 B, '
-                 'what the reference algorithm reads) over the same time: far above 1 because the 1024-bin '
-                 'integration is replaced by a table of its result; the bound that was priced in round 1 and '
-                 'at the start of round 2 -- f64 VALU issue of the integrating kernel -- is reported under '
-                 'integrating_kernel'}
-    if iso is not None and iso.ms_psd > 0:
-        ti = iso.ms_psd * 1e-3
-        r['isolated'] = {'avg_stage_ms': iso.ms_psd, 'frac': must / ti / 1e9 / HBM_PEAK_GBS,
-                         'l1_gather_frac': n_tab * per_item_l1 / ti / 1e9 / L1_PEAK_GBS,
-                         'note': 'same sweep with one lane only (no overlap with other sweeps)'}
-    return r
-
-
 def roofline(workload, kernel, ms_stage, n_valid, psd_bytes, ms_isolated=None, valu_scale=1.0):
     """The PSD x table stage against its bound.  It is f64-VALU bound: the
     LUT slices are shared by the items of a work unit through the scalar cache, so the HBM
@@ -806,45 +754,72 @@ def run_c5(env):
 
 # ------------------------------------------------------------------------------------------ c4
 def run_c4(env):
-    """Strong scaling of the C4 volume: every sweep's azimuths sharded over the ranks."""
-    from cosmo_pol_amd.distributed import shard_bounds
+    """Strong scaling of the C4 volume: the azimuths of every sweep sharded over the ranks; a rank
+    runs its rays of all five sweeps as ONE launch sequence, ONE all-gather per volume."""
+    from cosmo_pol_amd.distributed import VolumeLayout
     op, lanes, n_lanes, world, rank = env['op'], env['lanes'], env['n_lanes'], env['world'], env['rank']
     args, torch, dist, cube = env['args'], env['torch'], env['dist'], env['cube']
     dev = torch.device('cuda', env['local_rank'])
     az_all = np.arange(0, 360, 1.0 if not args.small else 4.0)
     n_az, n_gates = len(az_all), len(op.constants.RANGE_RADAR)
-    lo, hi, per = shard_bounds(n_az, world, rank)
     n_el = len(C4_ELEVATIONS)
-    nf = len(RADAR_FIELDS)
-    # per sweep: this rank's block [fields][per][gates] and the gathered sweep [world][...]
-    blocks = [torch.zeros((nf, per, n_gates), dtype=torch.float32, device=dev) for _ in range(n_el)]
-    gathered = [torch.empty((world, nf, per, n_gates), dtype=torch.float32, device=dev)
-                for _ in range(n_el)] if world > 1 else blocks
-    host = (torch.empty((n_el, world, nf, per, n_gates), dtype=torch.float32).pin_memory()
-            if rank == 0 else None)
-    ptrs = [{k: b[i].data_ptr() for i, k in enumerate(RADAR_FIELDS)} for b in blocks]
+    sweeps = [(az_all, np.full(n_az, e)) for e in C4_ELEVATIONS]
+    fields = [(k, np.float32) for k in RADAR_FIELDS]
+    lay = VolumeLayout(fields, [n_az] * n_el, world, n_gates)
+    nb = lay.block.nbytes
+    az, el = lay.local_rays(rank, sweeps)
+    n_loc = len(az) // n_el
+    # CPOL_BENCH_C4_MODE=sweeps: round 2's form (one launch sequence and one all-gather per sweep, the
+    # sweeps of a volume on alternating lanes) for comparison
+    per_sweep_mode = os.environ.get('CPOL_BENCH_C4_MODE', 'volume') == 'sweeps'
+    n_buf = max(2, n_lanes)
+    blocks = [torch.zeros(nb, dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+    gathered = [torch.empty(world * nb, dtype=torch.uint8, device=dev) for _ in range(n_buf)] if world > 1 else blocks
+    host = torch.empty(world * nb, dtype=torch.uint8).pin_memory() if rank == 0 else None
+    ptrs = [{k: b.data_ptr() + lay.block.offsets[k] for k, _ in fields} for b in blocks]
     lane_streams = [torch.cuda.ExternalStream(c.stream_ptr(), device=dev) for c in lanes]
     comm = torch.cuda.Stream(device=dev)
-    block_free = [None] * n_el
-    az, n_loc = az_all[lo:hi], hi - lo
+    block_free = [None] * n_buf
+    counter = [0]
+
+    def sweep_ptrs(b, e):
+        row = e * n_loc * n_gates * 4
+        return {k: p + row for k, p in ptrs[b].items()}
 
     def volume():
-        for e, elev in enumerate(C4_ELEVATIONS):
-            lane = e % n_lanes
-            if block_free[e] is not None:
-                lane_streams[lane].wait_event(block_free[e])      # its last gather has read it
+        k = counter[0]
+        counter[0] += 1
+        b = k % n_buf
+        if per_sweep_mode:
+            used = []
+            for e in range(n_el):
+                lane = (k * n_el + e) % n_lanes
+                if block_free[b] is not None:
+                    lane_streams[lane].wait_event(block_free[b])
+                if n_loc > 0:
+                    op.simulate_rays(az[e * n_loc:(e + 1) * n_loc], el[e * n_loc:(e + 1) * n_loc],
+                                     device_outputs=sweep_ptrs(b, e), lane=lane)
+                used.append(lane)
+            for lane in set(used):
+                done = torch.cuda.Event()
+                done.record(lane_streams[lane])
+                comm.wait_event(done)
+        else:
+            lane = k % n_lanes
+            if block_free[b] is not None:
+                lane_streams[lane].wait_event(block_free[b])          # its last gather has read the block
             if n_loc > 0:
-                op.simulate_rays(az, np.full(n_loc, elev), device_outputs=ptrs[e], lane=lane)
+                op.simulate_rays(az, el, device_outputs=ptrs[b], lane=lane)   # 5 elevations, one launch sequence
             done = torch.cuda.Event()
             done.record(lane_streams[lane])
             comm.wait_event(done)
-            with torch.cuda.stream(comm):
-                if world > 1:
-                    dist.all_gather_into_tensor(gathered[e].view(-1), blocks[e].view(-1))
-                if rank == 0:
-                    host[e].view(-1).copy_(gathered[e].view(-1), non_blocking=True)
-                block_free[e] = torch.cuda.Event()
-                block_free[e].record(comm)
+        with torch.cuda.stream(comm):
+            if world > 1:
+                dist.all_gather_into_tensor(gathered[b], blocks[b])   # ONE collective per volume
+            if rank == 0:
+                host.copy_(gathered[b], non_blocking=True)
+            block_free[b] = torch.cuda.Event()
+            block_free[b].record(comm)
 
     def fence():
         for i in range(n_lanes):
@@ -856,22 +831,17 @@ def run_c4(env):
 
     if world > 1:
         with torch.cuda.stream(comm):                 # communicator set-up is setup, not a step
-            dist.all_gather_into_tensor(gathered[0].view(-1), blocks[0].view(-1))
+            dist.all_gather_into_tensor(gathered[0], blocks[0])
     fence()
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, n_lanes)):        # (every lane's work buffers exist)
         volume()
     fence()
-    for c in lanes:
-        c.enable_timing(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         volume()
     t_submit = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
-    ms_psd = [c.counters().ms_psd for c in lanes]
-    for c in lanes:
-        c.enable_timing(False)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -879,22 +849,19 @@ def run_c4(env):
     gates_per_step = n_el * n_az * n_gates
     value = gates_per_step * args.steps / elapsed
 
-    # per-rank work of one volume (untimed pass: counters after every sweep)
-    n_valid_loc = n_units_loc = n_table_loc = 0
-    ms_psd_iso = []
-    for e, elev in enumerate(C4_ELEVATIONS):
-        if n_loc > 0:
-            op._ctx.enable_timing(2)
-            op.simulate_rays(az, np.full(n_loc, elev), device_outputs=ptrs[e], lane=0)
-            c = op._ctx.counters()
-            op._ctx.enable_timing(False)
-            n_valid_loc += int(c.n_valid_items)
-            n_units_loc += int(c.n_work_units)
-            n_table_loc += int(c.n_table_items)
-            ms_psd_iso.append(float(c.ms_psd))
-    mine = {'rank': rank, 'rays_per_sweep': n_loc, 'n_valid_items': n_valid_loc, 'n_work_units': n_units_loc,
-            'n_table_items': n_table_loc,
-            'psd_stage_ms_per_sweep_isolated': (sum(ms_psd_iso) / len(ms_psd_iso)) if ms_psd_iso else None}
+    # per-rank work of one volume (untimed pass, one lane, events around every stage)
+    mine = {'rank': rank, 'rays_per_sweep': n_loc}
+    iso = None
+    if n_loc > 0:
+        op._ctx.enable_timing(True)
+        for _ in range(3):
+            op.simulate_rays(az, el, device_outputs=ptrs[0], lane=0)
+        op.wait(0)
+        iso = op._ctx.counters()
+        op._ctx.enable_timing(False)
+        mine.update(n_valid_items=int(iso.n_valid_items), n_table_items=int(iso.n_table_items),
+                    n_work_units=int(iso.n_work_units), volume_device_ms_isolated=float(iso.ms_total),
+                    stages_ms=stage_ms_of(iso))
     per_rank = [None] * world
     if world > 1:
         dist.all_gather_object(per_rank, mine)
@@ -906,62 +873,36 @@ def run_c4(env):
     single = gather_ok = None
     fence()
     if rank == 0:
-        full = [torch.zeros((nf, n_az, n_gates), dtype=torch.float32, device=dev) for _ in range(n_el)]
-        fptrs = [{k: b[i].data_ptr() for i, k in enumerate(RADAR_FIELDS)} for b in full]
-
-        def volume_alone():
-            for e, elev in enumerate(C4_ELEVATIONS):
-                op.simulate_rays(az_all, np.full(n_az, elev), device_outputs=fptrs[e], lane=e % n_lanes)
+        lay1 = VolumeLayout(fields, [n_az] * n_el, 1, n_gates)
+        full = torch.zeros(lay1.block.nbytes, dtype=torch.uint8, device=dev)
+        fptrs = {k: full.data_ptr() + lay1.block.offsets[k] for k, _ in fields}
+        az1, el1 = lay1.local_rays(0, sweeps)
         n_it = max(2, args.steps // 3)
-        volume_alone()
-        for i in range(n_lanes):
-            op.wait(i)
+        op.simulate_rays(az1, el1, device_outputs=fptrs, lane=0)
+        op.wait(0)
         t0 = time.perf_counter()
         for _ in range(n_it):
-            volume_alone()
-        for i in range(n_lanes):
-            op.wait(i)
+            op.simulate_rays(az1, el1, device_outputs=fptrs, lane=0)
+        op.wait(0)
         t1 = (time.perf_counter() - t0) / n_it
         single = {'ms_per_volume': 1e3 * t1, 'value': gates_per_step / t1,
-                  'note': 'rank 0 runs the whole 5 x 360-ray volume alone after the timed region '
-                          '(outputs left in HBM, 3 lanes)'}
-        ok = True
-        for e in range(n_el):
-            g = host[e]                                      # [world][nf][per][gates] on the host
-            asm = torch.cat([g[r, :, :max(0, min(per, n_az - r * per))] for r in range(world)], dim=1)
-            ok = ok and bool(torch.equal(torch.nan_to_num(asm), torch.nan_to_num(full[e].cpu())))
-        gather_ok = ok
+                  'note': 'rank 0 runs the whole 5 x %d-ray volume alone after the timed region (one launch '
+                          'sequence, outputs left in HBM)' % n_az}
+        ref = lay1.assemble(full.cpu().numpy())
+        got = lay.assemble(host.numpy())
+        gather_ok = all(np.array_equal(got[s][k], ref[s][k], equal_nan=True) for s in range(n_el) for k, _ in fields)
     fence()
     if rank != 0:
         return None
-    n_valid = sum(p['n_valid_items'] for p in per_rank)
-    busiest = max(per_rank, key=lambda q: q['n_valid_items'])
-    prof, _ = load_profile_summary('c4')
-    scale = 1.0
-    if prof and prof.get('_meta', {}).get('n_valid_items_per_volume'):
-        scale = busiest['n_valid_items'] / float(prof['_meta']['n_valid_items_per_volume'])
-    class _C(object):
-        pass
-    cb = _C()
-    cb.n_table_items = busiest['n_table_items'] // n_el
-    cb.n_valid_items = busiest['n_valid_items'] // n_el
-    cb.ms_psd = busiest['psd_stage_ms_per_sweep_isolated'] or 0.0
-    # c4 (several sub-beams): k_subbeam_sum evaluates the 1-D table items in place and accumulates them --
-    # it must read key + 3 parameters per item and write 48 B per (gate, hydrometeor); k_psd_lookup keeps
-    # the melting species (2-D blocks) and the Doppler sums of ice
-    n_rg_loc = busiest['rays_per_sweep'] * n_gates
-    roof = roofline_lookup('c4', cb, cb.n_valid_items * LUT_SLICE_BYTES, None, n_fields_read=12, traffic_scale=scale,
-                           per_item_hbm=4 + 3 * 8, extra_hbm=n_rg_loc * len(hydrometeors_of('c4')) * 48,
-                           kernels=('k_subbeam_sum', 'k_psd_lookup'))
-    roof['stage_ms_with_lanes_in_flight'] = max(ms_psd) if ms_psd else None
-    roof['note'] += ('; c4: per sweep of the busiest rank (mean over its 5 sweeps, one lane at a time, the pass '
-                     'after the timed region); with 49 sub-beams the items on 1-D tables (snow, graupel, ice '
-                     'crystals: 11 rows of 128 B per block, shared by neighbouring gates) are evaluated inside '
-                     'k_subbeam_sum and accumulated over the sub-beams at once, so their 12 columns never go '
-                     'through memory: achieved counts key + 3 parameters per item and 48 B per (gate, hydrometeor); '
-                     'the melting species read 2-D blocks (66 rows, wet fraction x rain-partner slope) in '
-                     'k_psd_lookup, which l1_gather does not count; traffic = the N = 1 profile scaled by this '
-                     'rank\'s share of the items')
+    busiest = max((q for q in per_rank if q.get('n_valid_items')), key=lambda q: q['n_valid_items'])
+    n_vars, nz = len(op._staged_vars), cube['zlevels'].shape[0]
+    n_sbg_b = n_el * busiest['rays_per_sweep'] * 49 * n_gates
+    roof = roofline_of_dominant_stage(
+        'c4_volume_iso' if world == 1 else 'c4_share%d_iso' % world, busiest['stages_ms'], n_sbg_b,
+        busiest['n_valid_items'], n_el * busiest['rays_per_sweep'] * n_gates, n_vars, nz,
+        note='c4: the five-elevation launch sequence of the busiest rank (%d rays per sweep), one lane, the pass '
+             'after the timed region; traffic from the profile of the same launch sequence when committed '
+             '(N = 1: profiles/r3_c4_volume_iso_*).' % busiest['rays_per_sweep'])
     return {
         'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -971,15 +912,17 @@ def run_c4(env):
                                'layer, 7x7 Gauss-Hermite sub-beams (49 per radial), synthetic %s cube; one '
                                'volume per step; sub-beam gates are not counted as gates'
                                % (C4_ELEVATIONS, n_az, n_gates, 'x'.join(map(str, cube['zlevels'].shape))),
-                   'rays_per_gpu_per_sweep': per, 'gates_per_ray': n_gates, 'sub_beams': 49,
-                   'lanes': n_lanes,
-                   'parallelism': 'azimuths of every sweep sharded in contiguous blocks of ceil(360/N) rays; '
-                                  'one all-gather of the device blocks per sweep (RCCL), rank 0 copies the '
-                                  'assembled volume to page-locked host memory',
+                   'rays_per_gpu_per_sweep': lay.bounds[0][0][1] - lay.bounds[0][0][0], 'gates_per_ray': n_gates,
+                   'sub_beams': 49, 'lanes': n_lanes,
+                   'parallelism': ('azimuths of every sweep sharded in contiguous blocks of ceil(360/N) rays; a rank runs '
+                                   'its rays of all 5 sweeps as one launch sequence (consecutive volumes on alternating '
+                                   'lanes); ONE all-gather of the device blocks per volume (RCCL), rank 0 copies the '
+                                   'assembled volume to page-locked host memory') if not per_sweep_mode else
+                                  'CPOL_BENCH_C4_MODE=sweeps: one launch sequence and one all-gather per sweep',
                    'small': bool(args.small)},
         'roofline': roof,
         'per_rank': per_rank,
-        'counters': {'n_valid_items_per_volume': n_valid,
+        'counters': {'n_valid_items_per_volume': sum(q.get('n_valid_items', 0) for q in per_rank),
                      'n_subbeam_gates_per_volume': n_el * n_az * n_gates * 49},
         'single_gpu_same_workload': single,
         'speedup_vs_single_gpu': (value / single['value']) if single else None,
@@ -1146,7 +1089,7 @@ def cpu_pool_child(args):
     print(json.dumps(out), flush=True)
 
 
-def cpu_baseline_pool(workload, small, limit_s=240.0):
+def cpu_baseline_pool(workload, small, limit_s=150.0):
     """Runs cpu_pool_child in a child interpreter of its own session with a hard time limit; the
     bench line never waits longer than `limit_s` for the all-core legs."""
     import signal

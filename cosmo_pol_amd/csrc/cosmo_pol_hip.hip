@@ -113,11 +113,12 @@ struct cpol_ctx {
     DevBuf b_traj, b_wgate, b_clk;
     DevBuf b_beam, b_spectrum, b_outwin;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
-        b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel, b_proj;
+        b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel, b_proj, b_blkranked, b_rec, b_vmask;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
-    int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0;
+    int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0, last_n_keys = 0;
+    bool last_subsum = false;          // the 1-D table items of the last sweep never went through res[] (k_subbeam_sum)
     bool keep_debug = false;
     // sticky domain-error word (device): OR-ed by the kernels of every sweep, cleared only
     // when it has been read AND reported (host-output sweeps, cpol_synchronize, cpol_counters)
@@ -570,7 +571,7 @@ void cpol_destroy(cpol_ctx *ctx)
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_units,
                      &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_pos,
-                     &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel, &ctx->b_proj,
+                     &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel, &ctx->b_proj, &ctx->b_blkranked, &ctx->b_rec, &ctx->b_vmask,
                      &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model};
     for (DevBuf *b : all) free_buf(*b);
     for (auto &b : ctx->b_out) free_buf(b);
@@ -1176,6 +1177,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_pos, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_par, (size_t)n_hyd * CPOL_MAX_PAR * n_sbg * sizeof(double));
     ENSURE(ctx->b_count, (size_t)(n_keys + 3) * sizeof(int));       // + [n_keys + 1]: items on integral tables, [+ 2]: items ranked
+    ENSURE(ctx->b_blkranked, (size_t)cdiv(n_sbg, CPOL_CLASSIFY_THREADS) * sizeof(int));
+    ENSURE(ctx->b_rec, (size_t)n_hyd * n_sbg * sizeof(double2));
+    ENSURE(ctx->b_vmask, (size_t)n_sbg);
     ENSURE(ctx->b_offset, (size_t)2 * n_keys * sizeof(int));        // item and unit offsets
     const long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
     ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
@@ -1362,6 +1366,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // integral tables: not with Doppler scheme 3 + ice (k_spec_gate needs every item's parameters as
     // the integrating kernels leave them; the lookup writes the same slots, so it is fine) -- always on
     ca.n_lookup = (int *)ctx->b_count.p + n_keys + 1;
+    ca.blk_ranked = (int *)ctx->b_blkranked.p;
+    ca.rec = (double2 *)ctx->b_rec.p;
+    ca.vmask = (unsigned char *)ctx->b_vmask.p;
+    ca.vn = (doppler && !dop2 && !dop3) ? (double *)ctx->b_vn.p : nullptr;     // analytic moments (Doppler scheme 1)
+    ca.keep_par = (ctx->keep_debug || dop3) ? 1 : 0;
     for (int j = 0; j < n_hyd; ++j) {
         const cpol_hydro_desc &d = ctx->hs.h[j].d;
         if (d.q_source != CPOL_Q_MODEL) continue;
@@ -1409,7 +1418,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st,
                        (const int *)ctx->b_key.p, (const int *)ctx->b_pos.p,
-                       (int *)ctx->b_perm.p, n_sbg, n_hyd, sa);      // + the work-unit list
+                       (int *)ctx->b_perm.p, (const int *)ctx->b_blkranked.p, n_sbg, n_hyd, sa);      // + the work-unit list
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st));
 
     // ---- 5a. items on an integral table: 15 x 11 coefficients gathered, no diameter-bin loop ----
@@ -1419,6 +1428,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         if (any) {
             LookupArgs la{};
             la.key = (const int *)ctx->b_key.p;
+            la.rec = (const double2 *)ctx->b_rec.p;
             la.par = (const double *)ctx->b_par.p;
             la.par_w = dop3 ? (double *)ctx->b_par.p : nullptr;
             la.res = (double *)ctx->b_res.p;
@@ -1561,7 +1571,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (subsum) {
         SubsumArgs sa2{};
         sa2.key = (const int *)ctx->b_key.p;
-        sa2.par = (const double *)ctx->b_par.p;
+        sa2.rec = (const double2 *)ctx->b_rec.p;
         sa2.res = (const double *)ctx->b_res.p;
         sa2.sub_w = (const double *)ctx->v_subw;
         sa2.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
@@ -1575,6 +1585,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     FinalArgs fa{};
     fa.res = (const double *)ctx->b_res.p;
     fa.key = (const int *)ctx->b_key.p;
+    fa.vmask = (const unsigned char *)ctx->b_vmask.p;
     fa.sub_mask = (const signed char *)ctx->b_mask.p;
     fa.vals = (const float *)ctx->b_vals.p;
     fa.sub_w = (const double *)ctx->v_subw;
@@ -1599,7 +1610,6 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     fa.RVEL = nullptr;
     if (doppler) {
         fa.RVEL = (double *)T[O_RVEL];
-        fa.par = (const double *)ctx->b_par.p;
         fa.vn = (const double *)ctx->b_vn.p;
         fa.ice_first = (const IceFirst *)ctx->b_icefirst.p;
         fa.geo = (const double *)ctx->v_geo;
@@ -1615,8 +1625,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         }
         for (int j = 0; j < n_hyd && !dop3; ++j) {
             const cpol_hydro_desc &d = ctx->hs.h[j].d;
+            // 1: vn[] per gate -- written by the PSD stage (scheme 2, melting species) or, for the analytic
+            // moments of the gamma species under scheme 1, by k_classify; 2: summed over the ray (1-moment
+            // ice, numeric integrate_V) and credited to the first valid gate
             fa.vsrc[j] = (dop2 || d.psd_family == CPOL_PSD_MELTING) ? 1
-                       : (d.psd_family == CPOL_PSD_ICE_FIELD || d.numeric_intv) ? 2 : 0;
+                       : (d.psd_family == CPOL_PSD_ICE_FIELD || d.numeric_intv) ? 2 : 1;
             if (fa.vsrc[j] == 2)
                 hipLaunchKernelGGL(k_ice_first, dim3(n_rays * n_sub), dim3(64), 0, st,
                                    (const int *)ctx->b_key.p + (long)j * n_sbg,
@@ -1709,7 +1722,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         void *arena[] = {ctx->b_traj.p, ctx->b_vals.p, ctx->b_mask.p, ctx->b_elev.p, ctx->b_qmelt.p,
                          ctx->b_fwmelt.p, ctx->b_key.p, ctx->b_pos.p, ctx->b_par.p, ctx->b_count.p,
                          ctx->b_offset.p, ctx->b_units.p, ctx->b_totals.p, ctx->b_perm.p,
-                         ctx->b_res.p, ctx->b_vn.p, ctx->b_icefirst.p, ctx->b_wgate.p, ctx->v_traj_in, ctx->v_geo, ctx->v_subh,
+                         ctx->b_res.p, ctx->b_vn.p, ctx->b_icefirst.p, ctx->b_wgate.p, ctx->b_blkranked.p, ctx->b_rec.p,
+                         ctx->b_vmask.p, ctx->v_traj_in, ctx->v_geo, ctx->v_subh,
                          ctx->v_subv, ctx->v_subw, ctx->v_sens, ctx->v_site, ctx->v_nyq,
                          ctx->v_subsmooth, ctx->v_mlfilter, (void *)st};
         mix(arena, sizeof arena);
@@ -1747,6 +1761,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
 
     ctx->last_n_sbg = n_sbg; ctx->last_n_rg = n_rg; ctx->last_n_rays = n_rays;
     ctx->last_n_gates = ng; ctx->last_n_sub = n_sub; ctx->last_n_v = n_v;
+    ctx->last_n_keys = n_keys; ctx->last_subsum = subsum;
     ctx->counters.n_subbeam_gates = n_sbg;
     ctx->counters.n_gates = n_rg;
 
@@ -1796,7 +1811,7 @@ int cpol_counters(cpol_ctx *ctx, cpol_counters_t *out)
         long long totals[2] = {0, 0};
         HIPCHK(hipMemcpy(totals, ctx->b_totals.p, sizeof totals, hipMemcpyDeviceToHost));
         int n_lookup = 0;
-        HIPCHK(hipMemcpy(&n_lookup, (const int *)ctx->b_count.p + ctx->hs.n_keys + 1, sizeof n_lookup, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&n_lookup, (const int *)ctx->b_count.p + ctx->last_n_keys + 1, sizeof n_lookup, hipMemcpyDeviceToHost));
         ctx->counters.n_table_items = n_lookup;
         totals[0] += n_lookup;                              // valid items = integrated + looked up
         ctx->counters.n_valid_items = totals[0];
@@ -1911,7 +1926,15 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     else if (!strcmp(name, "sub_elev")) { src = ctx->b_elev.p; bytes = n_sbg * 4; }
     else if (!strcmp(name, "sub_coords")) { src = ctx->b_coords.p; bytes = n_sbg * 8; }
     else if (!strcmp(name, "item_key")) { src = ctx->b_key.p; bytes = (int64_t)n_hyd * n_sbg * 4; }
-    else if (!strcmp(name, "item_res")) { src = ctx->b_res.p; bytes = (int64_t)n_hyd * n_sbg * CPOL_N_SZ * 8; }
+    else if (!strcmp(name, "item_res")) {
+        if (ctx->last_subsum) {
+            ctx->err = "cpol_debug_read: item_res is incomplete after a sweep with >= 4 sub-beams (the items on 1-D integral "
+                       "tables are evaluated inside k_subbeam_sum and never stored; CPOL_SUBSUM=0 keeps them)";
+            return CPOL_ERR_ARG;
+        }
+        src = ctx->b_res.p; bytes = (int64_t)n_hyd * n_sbg * CPOL_N_SZ * 8;
+    }
+    else if (!strcmp(name, "item_rec")) { src = ctx->b_rec.p; bytes = (int64_t)n_hyd * n_sbg * 16; }
     else if (!strcmp(name, "item_par")) { src = ctx->b_par.p; bytes = (int64_t)n_hyd * CPOL_MAX_PAR * n_sbg * 8; }
     else if (!strcmp(name, "q_melt")) { src = ctx->b_qmelt.p; bytes = 2 * n_sbg * 4; }
     else if (!strcmp(name, "fw_melt")) { src = ctx->b_fwmelt.p; bytes = 2 * n_sbg * 8; }
@@ -1919,7 +1942,7 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     else if (!strcmp(name, "sz_total")) { src = ctx->b_sztotal.p; bytes = (int64_t)n_rg * CPOL_N_SZ * 4; }
     else if (!strcmp(name, "traj")) { src = ctx->b_traj.p; bytes = (int64_t)ctx->last_n_rays * ctx->last_n_v * 3 * ctx->last_n_gates * 4; }
     else if (!strcmp(name, "psd_clock")) { src = ctx->b_clk.p; bytes = 2048 * 4 * 8; }
-    else if (!strcmp(name, "bucket_count")) { src = ctx->b_count.p; bytes = (int64_t)ctx->hs.n_keys * 4; }
+    else if (!strcmp(name, "bucket_count")) { src = ctx->b_count.p; bytes = (int64_t)ctx->last_n_keys * 4; }
     else { ctx->err = std::string("cpol_debug_read: unknown buffer ") + name; return CPOL_ERR_ARG; }
     if (!src) { ctx->err = "cpol_debug_read: buffer not kept (call with name \"enable\" first)"; return CPOL_ERR_ARG; }
     if (bytes > max_bytes) { ctx->err = "cpol_debug_read: destination too small"; return CPOL_ERR_ARG; }

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(64) void k_ml_weights(MlArgs a)
 struct FinalArgs {
     const double *res;          // [n_hydro][n_sbg][12]
     const int *key;             // [n_hydro][n_sbg]
+    const unsigned char *vmask; // [n_sbg] bit j: hydrometeor j present
     const signed char *sub_mask;
     const float *vals;          // [n_vars][n_sbg]
     const double *sub_w;        // [n_sub]
@@ -136,14 +137,13 @@ struct FinalArgs {
     double sum_w;
     // Doppler scheme 1 (radial velocity)
     double *RVEL;               // [n_rg] or NULL
-    const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg] (gamma: [2] = v, [3] = n)
-    const double *vn;           // [n_hydro][n_sbg][2] (melting, ice)
+    const double *vn;           // [n_hydro][n_sbg][2] fall-speed moments of every item
     const IceFirst *ice_first;  // [n_rays*n_sub]
     const double *geo;          // [n_rays][n_h][8]: sin / cos of the sub-beam azimuth
     const int *sub_h;
     const float *elev;          // folded elevation per sub-beam gate (quirk Q8)
     int n_h, var_u, var_v, var_w;
-    int vsrc[CPOL_MAX_HYDRO];   // 0: par (analytic), 1: vn per gate, 2: ice (first valid gate)
+    int vsrc[CPOL_MAX_HYDRO];   // 1: vn per gate, 2: ice (first valid gate)
     const double *proj;         // [n_sbg] subbeam_proj of every sub-beam gate (k_rvel_terms) or NULL: evaluated in place
     const double *nyquist;      // [n_rays] or NULL
     const double *wgate;        // [n_sbg] per-gate sub-beam weights (scheme 'ml') or NULL
@@ -156,15 +156,14 @@ struct FinalArgs {
 __device__ __forceinline__ double subbeam_proj(const FinalArgs &a, int ray, int s, int gate, long sbg, long n_sbg)
 {
     double v = 0.0, nn = 0.0;
+    const unsigned present = a.vmask[sbg];
     for (int j = 0; j < a.n_hydro; ++j) {
-        if (a.key[(long)j * n_sbg + sbg] < 0) continue;
+        if (!((present >> j) & 1u)) continue;
         double vj, nj;
-        if (a.vsrc[j] == 0) {
-            const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n_sbg + sbg;
-            vj = P[2 * n_sbg]; nj = P[3 * n_sbg];
-        } else if (a.vsrc[j] == 1) {
-            vj = a.vn[((long)j * n_sbg + sbg) * 2];
-            nj = a.vn[((long)j * n_sbg + sbg) * 2 + 1];
+        if (a.vsrc[j] == 1) {
+            // (gamma species, Doppler scheme 1: the analytic moments, written by k_classify)
+            const double2 w = *reinterpret_cast<const double2 *>(a.vn + ((long)j * n_sbg + sbg) * 2);
+            vj = w.x; nj = w.y;
         } else {
             const IceFirst f = a.ice_first[(long)ray * a.n_sub + s];
             const bool here = (f.first_gate == gate);
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(256) void k_rvel_terms(FinalArgs a, double *__restr
 // sub-beams per step with both gathers in flight is slower (1.38 / 0.36 ms, 128 VGPRs).
 struct SubsumArgs {
     const int *key;             // [n_hydro][n_sbg]
-    const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg]
+    const double2 *rec;         // [n_hydro][n_sbg] {panel position (-1: not on the table), scale}
     const double *res;          // [n_hydro][n_sbg][12]
     const double *sub_w;        // [n_sub]
     const double *wgate;        // [n_sbg] or NULL (scheme 'ml')
@@ -232,9 +231,8 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) void k_subbeam_sum(HydroSet hs
     const long sbg0 = (long)ray * a.n_sub * a.n_gates + gate;
     const ItabDev &t = its.t[j];
     const bool tab1 = t.tab && !t.two_d;                                 // uniform
-    const bool ice = hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD;
     const int key_base = hs.h[j].key_base;
-    const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n_sbg;
+    const double2 *R = a.rec + (long)j * n_sbg;
     double wtot = 0.0;
     if (a.wgate)
         for (int s = 0; s < a.n_sub; ++s) wtot += a.wgate[sbg0 + (long)s * a.n_gates];
@@ -247,13 +245,12 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) void k_subbeam_sum(HydroSet hs
         if (key < 0) continue;
         const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
         double2 v[CPOL_N_SZ / 2];
-        const double pf = tab1 ? P[4 * n_sbg + sbg] : -1.0;
-        if (pf >= 0.0) {
-            const int pn = min((int)pf, t.n_pan - 1);
-            const double u = 2.0 * (pf - (double)pn) - 1.0;
-            const double scale = ice ? P[2 * n_sbg + sbg] : P[n_sbg + sbg] * cp_exp(-(P[sbg] * t.d0));
+        const double2 rc = tab1 ? R[sbg] : make_double2(-1.0, 0.0);
+        if (rc.x >= 0.0) {
+            const int pn = min((int)rc.x, t.n_pan - 1);
+            const double u = 2.0 * (rc.x - (double)pn) - 1.0;
             itab1_columns(reinterpret_cast<const double2 *>(t.tab + ((long)(key - key_base) * t.n_pan + pn) * NB),
-                          u, scale, v);
+                          u, rc.y, v);
         } else {
             const double2 *r = reinterpret_cast<const double2 *>(a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ);
 #pragma unroll

@@ -285,6 +285,16 @@ struct ClassifyArgs {
     const float *tfun_snow;      // snow intercept N0(T)  (hydrometeors.py:896) or NULL
     const float *tfun_ice;       // 10**a(T) of the Field (2005) moment relation (:1287) or NULL
     int *n_lookup;               // [0] items taken by the integral tables (k_psd_lookup), [1] items ranked
+    double2 *rec;                // [n_hydro][n_sbg] items of a slot with an integral table: {panel position (-1: not
+                                 // on the table), scale}
+    double *vn;                  // [n_hydro][n_sbg][2] analytic fall-speed moments of the gamma species (Doppler
+                                 // scheme 1) or NULL
+    unsigned char *vmask;        // [n_sbg] bit j: hydrometeor j present (what the kernels that only ask
+                                 // "key >= 0 ?" read instead of n_hydro keys)
+    int keep_par;                // also write par[] of the table items (debug reads, Doppler scheme 3)
+    int *blk_ranked;             // [gridDim.x] items of this workgroup's gates ranked for the integrating kernels
+                                 // (k_bucket_scatter skips the gates of a workgroup without any; pos[] is only
+                                 // written where there are some)
 };
 
 __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &out)
@@ -313,6 +323,8 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
     if (threadIdx.x == 0) { s_lookup = 0; s_ranked = 0; }
     __syncthreads();
     int my_lookup = 0, my_ranked = 0;
+    unsigned ranked_mask = 0;                         // bit j: item j of this gate goes to the integrating kernels
+    unsigned vbits = 0;                               // bit j: hydrometeor j is present at this gate (key >= 0)
     const long sbg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = sbg < a.n_sbg;
     const long n = a.n_sbg;
@@ -357,6 +369,8 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
         // sub-beam has a non-zero weight (:186-189)
         const bool valid = in && (qm > 0.f) && (!a.wgate || a.wgate[i] > 0.0);
         int key = -1;
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, dv = 0.0, dn = 0.0;
+        bool gamma_vn = false;
         if (valid) {
             const float T = a.vals[d.var_t * n + i];
             // lut.py:336-341: float32 arithmetic for float32 queries
@@ -364,16 +378,17 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             int tb = d.second_axis_f64 ? clip_bin64((fw - (double)d.t_lo) / (double)d.t_step, d.n_t)
                                        : clip_bin((T - d.t_lo) / d.t_step, d.n_t);
             key = h.key_base + eb * d.n_t + tb;
-            double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
             const double q = (double)qm;
             double lamf = 0.0, n0v = 0.0, qnv = 0.0;   // final lambda / N0 (get_N units)
+            // the item's parameters (slots 0..2 of par[], read by the integrating kernels; slot 1 by
+            // the 2-D lookup of the melting species)
             switch (d.rule) {
             case CPOL_RULE_RAIN_1MOM:
             case CPOL_RULE_GRAUPEL_1MOM:
                 lamf = cp_pow(d.lambda_factor / q, d.lam_exponent);
                 n0v = d.n0_fixed;
-                P[0] = lamf;
-                P[n] = 1.0;                                   // N0 folded into pre[]
+                p0 = lamf;
+                p1 = 1.0;                                     // N0 folded into pre[]
                 break;
             case CPOL_RULE_SNOW_1MOM: {
                 // hydrometeors.py:896-899: float32 chain, then float64 from lambda_factor on
@@ -383,8 +398,8 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 float an0 = (float)d.a * n0;
                 lamf = cp_pow((double)an0 * d.lambda_factor / q, d.lam_exponent);
                 n0v = (double)n0;
-                P[0] = lamf;
-                P[n] = n0v;
+                p0 = lamf;
+                p1 = n0v;
                 break; }
             case CPOL_RULE_TWO_MOMENT: {
                 // hydrometeors.py:231-246
@@ -395,8 +410,8 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 double n0 = (d.nu / d.ntot_factor) * qnv * cp_pow(lam, d.n0_exponent);
                 lamf = lam * d.c_lam;
                 n0v = n0 * d.c_n0;
-                P[0] = lamf;
-                P[n] = n0v;
+                p0 = lamf;
+                p1 = n0v;
                 break; }
             case CPOL_RULE_ICE_1MOM: {
                 // hydrometeors.py:1277-1299 (float32 polynomials), :1320-1328
@@ -417,46 +432,67 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 const double Q22 = Q2 * Q2;
                 double N0 = (Q22 * Q22) / (q * q * q);            // Q2^4 QM^-3 (b = 3)
                 N0 /= 100000.0;
-                P[0] = Q2 / q;                                    // lambda (exponent 1/(b-2) = 1)
-                P[n] = N0;
-                P[2 * n] = q;
+                p0 = Q2 / q;                                      // lambda (exponent 1/(b-2) = 1)
+                p1 = N0;
+                p2 = q;
                 break; }
             case CPOL_RULE_MELTING_SNOW:
             case CPOL_RULE_MELTING_GRAUPEL: {
-                P[0] = q;
-                P[n] = fw;
-                P[2 * n] = cp_pow(d.r_lambda_factor / q, d.r_lam_exponent);   // rain partner
+                p0 = q;
+                p1 = fw;
+                p2 = cp_pow(d.r_lambda_factor / q, d.r_lam_exponent);   // rain partner
                 // (the dry partner's PSD does not enter get_N, hydrometeors.py:372-390)
                 break; }
             default: break;
             }
-            if (a.doppler && d.psd_family == CPOL_PSD_GAMMA) {
-                // _Hydrometeor.integrate_V (hydrometeors.py:178-199): analytic moments
-                P[2 * n] = d.vel_factor * n0v * d.alpha / d.nu
-                           * cp_pow(lamf, -(d.beta + d.mu + 1) / d.nu);
-                P[3 * n] = (d.rule == CPOL_RULE_TWO_MOMENT)
+            if (a.doppler && d.psd_family == CPOL_PSD_GAMMA && !d.numeric_intv) {
+                // _Hydrometeor.integrate_V (hydrometeors.py:178-199): analytic moments (a species with
+                // numeric_intv gets its sums from the PSD stage instead)
+                gamma_vn = true;
+                dv = d.vel_factor * n0v * d.alpha / d.nu * cp_pow(lamf, -(d.beta + d.mu + 1) / d.nu);
+                dn = (d.rule == CPOL_RULE_TWO_MOMENT)
                     ? qnv : d.ntot_factor * n0v / d.nu * cp_pow(lamf, -(d.mu + 1) / d.nu);
             }
         }
-        // items whose lambda lies on the slot's integral table are finished by k_psd_lookup
-        // (position on the panel axis in parameter slot 4); only the others are sorted by
-        // LUT slice for the integrating kernels
+        // items whose lambda lies on the slot's integral table are finished by k_psd_lookup /
+        // k_subbeam_sum from ONE 16-byte record {position on the panel axis, scale of the item}; only
+        // the others are sorted by LUT slice for the integrating kernels
         bool lookup = false;
-        if (valid && its.t[j].tab) {
-            const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
-            const double pf = (cp_log(P[its.t[j].par_slot * n]) * 1.4426950408889634 - its.t[j].log2_lo)
-                              * (double)its.t[j].ppo;
-            lookup = pf >= (double)its.t[j].pan_lo && pf < (double)its.t[j].pan_hi;   // NaN -> false
-            a.par[((long)j * CPOL_MAX_PAR + 4) * n + i] = lookup ? pf : -1.0;
+        double pf = -1.0;
+        const ItabDev &tj = its.t[j];
+        if (valid && tj.tab) {
+            pf = (cp_log(tj.par_slot == 2 ? p2 : p0) * 1.4426950408889634 - tj.log2_lo) * (double)tj.ppo;
+            lookup = pf >= (double)tj.pan_lo && pf < (double)tj.pan_hi;   // NaN -> false
+            // scale: gamma N0 exp(-lambda d0) (the table holds exp(+lambda d0) x integral); ice and melting: QM
+            const double scale = tj.two_d ? p0 : d.psd_family == CPOL_PSD_ICE_FIELD ? p2 : p1 * cp_exp(-(p0 * tj.d0));
+            a.rec[(long)j * n + i] = make_double2(lookup ? pf : -1.0, scale);
             my_lookup += lookup ? 1 : 0;
+        }
+        if (valid) {
+            double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
+            if (!lookup || a.keep_par) {                     // read by the integrating kernels / the spectrum kernels
+                P[0] = p0;
+                P[n] = p1;
+                if (h.n_par >= 3) P[2 * n] = p2;
+                if (tj.tab) P[4 * n] = lookup ? pf : -1.0;    // (debug reads)
+            } else if (tj.two_d) {
+                P[n] = p1;                                    // wet fraction: position inside the 2-D block
+            }
+            if (gamma_vn) {
+                if (a.vn) *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = make_double2(dv, dn);
+                if (a.keep_par) { P[2 * n] = dv; P[3 * n] = dn; }
+            }
+            vbits |= 1u << j;
         }
         my_ranked += (valid && !lookup) ? 1 : 0;
         const int ticket = rank_insert(sh[j], a.count, key, valid && !lookup);
-        if (in) {
-            a.key[(long)j * n + i] = key;
+        if (in) a.key[(long)j * n + i] = key;
+        if (valid && !lookup) {                       // (rare: pos[] is written only where an item is ranked)
             a.pos[(long)j * n + i] = ticket;
+            ranked_mask |= 1u << j;
         }
     }
+    if (in) a.vmask[i] = (unsigned char)vbits;
     // a.n_lookup[0]: items on integral tables; [1]: items ranked for the integrating kernels (0 in
     // the normal case: k_bucket_scan / k_bucket_scatter then return at once)
 #pragma unroll
@@ -469,14 +505,16 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
     __syncthreads();
     if (threadIdx.x == 0 && s_lookup) atomicAdd(a.n_lookup, s_lookup);
     if (threadIdx.x == 0 && s_ranked) atomicAdd(a.n_lookup + 1, s_ranked);
-    if (s_ranked == 0) return;                        // workgroup-uniform: every ticket is -1
+    if (threadIdx.x == 0) a.blk_ranked[blockIdx.x] = s_ranked;
+    if (s_ranked == 0) return;                        // workgroup-uniform: every ticket is -1; pos[] stays unwritten
     for (int idx = threadIdx.x; idx < hs.n_hydro * CPOL_RANK_SLOTS; idx += blockDim.x)
         rank_reserve(sh[idx / CPOL_RANK_SLOTS], a.count, idx % CPOL_RANK_SLOTS);
     __syncthreads();
     if (in) {
+        // this workgroup ranked something: k_bucket_scatter reads pos[] of all its gates
         for (int j = 0; j < hs.n_hydro; ++j) {
             const long o = (long)j * n + i;
-            a.pos[o] = rank_position(sh[j], a.pos[o]);
+            a.pos[o] = ((ranked_mask >> j) & 1u) ? rank_position(sh[j], a.pos[o]) : -1;
         }
     }
 }
@@ -573,6 +611,7 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(ScanArgs a)
 __global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ key,
                                                          const int *__restrict__ pos,
                                                          int *__restrict__ perm,
+                                                         const int *__restrict__ blk_ranked,
                                                          long n_sbg, int n_hydro, ScanArgs a)
 {
     const long sbg = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -593,6 +632,9 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ 
         }
     }
     if (sbg >= n_sbg) return;
+    // the k_classify workgroup of these gates ranked nothing (the rule: a handful of items per volume
+    // lie outside the integral tables): neither key[] nor pos[] (unwritten there) is read
+    if (blk_ranked[sbg / CPOL_CLASSIFY_THREADS] == 0) return;      // uniform per workgroup (256 divides 1024)
     for (int j = 0; j < n_hydro; ++j) {
         const int k = key[(long)j * n_sbg + sbg];
         const int ps = pos[(long)j * n_sbg + sbg];          // < 0: the item went to an integral table
@@ -1708,7 +1750,8 @@ __global__ void k_itab_check2(ItabFit2Args f)
 // one thread per sub-beam gate: the items that k_classify placed on an integral table
 struct LookupArgs {
     const int *key;             // [n_hydro][n_sbg]
-    const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg]
+    const double2 *rec;         // [n_hydro][n_sbg] {panel position (-1: not on the table), scale} (k_classify)
+    const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg] (melting species: slot 1 = wet fraction)
     double *par_w;              // = par, writable (ice: normalised N0 for the spectrum kernels) or NULL
     double *res;                // [n_hydro][n_sbg][12]
     double *vn;                 // [n_hydro][n_sbg][2] or NULL
@@ -1839,7 +1882,8 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
             !(a.par_w && hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD)) continue;
         const int key = in ? a.key[(long)j * n + i] : -1;
         const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
-        const double pf = key >= 0 ? P[4 * n] : -1.0;
+        const double2 rc = key >= 0 ? a.rec[(long)j * n + i] : make_double2(-1.0, 0.0);
+        const double pf = rc.x;
         const bool item = pf >= 0.0;                                    // NaN -> false
         if (t.two_d) {
             // melting species: QM x F_c(slice, fw, lambda_r), one item of the wavefront at a time
@@ -1851,7 +1895,7 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
                 const int sl = key - hs.h[j].key_base;
                 const int tb = sl % t.n_t;
                 u = (P[n] - t.head[2 * tb]) * t.head[2 * tb + 1];
-                q = P[0];
+                q = rc.y;
                 blk = sl * t.n_pan + pn;
             }
             // the wavefront walks over the DISTINCT blocks of its items (16 neighbouring rays x 4
@@ -1888,8 +1932,8 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
         const double u = 2.0 * (pf - (double)pn) - 1.0;
         const double2 *c = reinterpret_cast<const double2 *>(
             t.tab + ((long)(key - hs.h[j].key_base) * t.n_pan + pn) * NB);
-        // gamma: N0 x exp(-lambda d0) x G(lambda);  ice: QM x R(lambda)
-        const double scale = ice ? P[2 * n] : P[n] * cp_exp(-(P[0] * t.d0));
+        // gamma: N0 x exp(-lambda d0) x G(lambda);  ice: QM x R(lambda)  (the scale comes with the record)
+        const double scale = rc.y;
         const bool want_vn = a.vn && t.writes_vn;                       // uniform
         const bool want_n0 = ice && a.par_w;                            // uniform
         if (!a.skip_res_1d) {

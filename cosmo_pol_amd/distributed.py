@@ -1,4 +1,4 @@
-"""Multi-GPU sweeps: one process per GPU, rays sharded, one collective per sweep.
+"""Multi-GPU scans: one process per GPU, rays sharded, ONE collective per scan (volume).
 
 The reference farms the radials of a sweep out to a fork pool and collects
 pickled Radial objects over pipes (cosmo_pol/radar_operator.py:402-432).  Here
@@ -16,6 +16,13 @@ a [per, n_gates] array of the field's dtype, the fields one after the other at
 the tail ranks stay zero.  The kernels write their outputs straight into the
 block on the device (`simulate_sharded_device`), the all-gather runs on device
 buffers, and ONE device-to-host copy returns the whole sweep.
+
+A scan of several sweeps (a PPI volume, a set of RHIs) is sharded as a whole
+(`VolumeLayout`, `simulate_sharded_volume_device`): a rank takes its contiguous ray block
+of EVERY sweep, runs them as one launch sequence (rays of different elevations in one
+cpol_run_sweep call), and a single all-gather at the end of the volume assembles all
+sweeps on every rank -- 10 kernel launches and one collective per volume instead of 10
+launches and one collective per sweep.
 """
 import numpy as np
 
@@ -148,3 +155,96 @@ def simulate_sharded_device(run_block, stream_ptr, azimuths, elevations, fields,
     host.copy_(gathered, non_blocking=True)
     cur.synchronize()
     return lay.assemble(host.numpy(), n, world)
+
+
+class VolumeLayout(object):
+    """Sharding of a scan of several sweeps: rank r owns rays [lo, hi) of every sweep
+    (`shard_bounds` per sweep) and stores them sweep after sweep in ONE block of
+    `BlockLayout(fields, per, n_gates)` rows, per = the largest row count of a rank."""
+
+    def __init__(self, fields, rays_per_sweep, world, n_gates):
+        self.world = int(world)
+        self.n_rays = [int(n) for n in rays_per_sweep]
+        self.bounds = [[shard_bounds(n, self.world, r)[:2] for r in range(self.world)] for n in self.n_rays]
+        self.rows = [sum(hi - lo for lo, hi in (b[r] for b in self.bounds)) for r in range(self.world)]
+        self.per = max(1, max(self.rows))
+        self.block = BlockLayout(fields, self.per, n_gates)
+        self.n_gates = int(n_gates)
+
+    def local_rays(self, rank, sweeps):
+        """Concatenated (azimuths, elevations) of `rank`: its block of sweep 0, of sweep 1, ..."""
+        az = [np.asarray(a, dtype=np.float64)[lo:hi] for (a, _), (lo, hi) in
+              zip(sweeps, (b[rank] for b in self.bounds))]
+        el = [np.asarray(e, dtype=np.float64)[lo:hi] for (_, e), (lo, hi) in
+              zip(sweeps, (b[rank] for b in self.bounds))]
+        return (np.concatenate(az) if az else np.empty(0)), (np.concatenate(el) if el else np.empty(0))
+
+    def assemble(self, gathered):
+        """[world * nbytes] uint8 (numpy) -> [{field: [n_rays_s, n_gates]} for every sweep s]."""
+        blocks = gathered.reshape(self.world, self.block.nbytes)
+        out = [dict() for _ in self.n_rays]
+        for k, dt in self.block.fields:
+            views = [self.block.view(blocks[r], k) for r in range(self.world)]
+            row = [0] * self.world
+            for s, b in enumerate(self.bounds):
+                parts = []
+                for r, (lo, hi) in enumerate(b):
+                    if hi > lo:
+                        parts.append(views[r][row[r]:row[r] + hi - lo])
+                        row[r] += hi - lo
+                out[s][k] = (np.concatenate(parts, axis=0) if parts
+                             else np.empty((0, self.n_gates), dtype=dt))
+        return out
+
+
+def simulate_sharded_volume(simulate, sweeps, fields, n_gates, device=None, group=None):
+    """Host-buffer form of the volume sharding (gloo tests, CPU stand-ins): `simulate(az, el) ->
+    {field: [n, n_gates]}` is called ONCE with this rank's rays of all sweeps; ONE all-gather."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lay = VolumeLayout(fields, [len(a) for a, _ in sweeps], world, n_gates)
+    block = np.zeros(lay.block.nbytes, dtype=np.uint8)
+    az, el = lay.local_rays(rank, sweeps)
+    if len(az):
+        res = simulate(az, el)
+        for k, dt in lay.block.fields:
+            lay.block.view(block, k)[:len(az)] = np.ascontiguousarray(res[k], dtype=dt).reshape(len(az), n_gates)
+    t = torch.from_numpy(block)
+    if device is not None:
+        t = t.to(device)
+    return lay.assemble(gather_blocks(t, group).cpu().numpy())
+
+
+def simulate_sharded_volume_device(run_block, stream_ptr, sweeps, fields, n_gates, device, group=None,
+                                   cache=None):
+    """Device-resident volume sharding (the product path of RadarOperator(distributed=True)):
+    `run_block(az, el, {field: device pointer})` queues ONE launch sequence for this rank's rays of
+    all sweeps on the library stream; one all_gather_into_tensor of the device blocks (RCCL over
+    xGMI) behind it; one device-to-host copy of the gathered volume.  -> list of per-sweep dicts."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lay = VolumeLayout(fields, [len(a) for a, _ in sweeps], world, n_gates)
+    nb = lay.block.nbytes
+    cache = {} if cache is None else cache
+    key = ('blk', nb, world)
+    if key not in cache:
+        cache.clear()
+        cache[key] = (torch.zeros(nb, dtype=torch.uint8, device=device),
+                      torch.empty(world * nb, dtype=torch.uint8, device=device),
+                      torch.empty(world * nb, dtype=torch.uint8).pin_memory()
+                      if torch.cuda.is_available() else torch.empty(world * nb, dtype=torch.uint8))
+    block, gathered, host = cache[key]
+    lib_stream = torch.cuda.ExternalStream(stream_ptr, device=device)
+    cur = torch.cuda.current_stream(device)
+    lib_stream.wait_stream(cur)                 # the previous gather has consumed the block
+    az, el = lay.local_rays(rank, sweeps)
+    if len(az):
+        base = block.data_ptr()
+        run_block(az, el, {k: base + lay.block.offsets[k] for k, _ in lay.block.fields})
+    cur.wait_stream(lib_stream)                 # gather behind the kernels
+    dist.all_gather_into_tensor(gathered, block, group=group)
+    host.copy_(gathered, non_blocking=True)
+    cur.synchronize()
+    return lay.assemble(host.numpy())

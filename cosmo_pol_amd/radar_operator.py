@@ -608,7 +608,9 @@ class RadarOperator(object):
         """[(az, el), ...] -> packaged sweeps.  The reference runs the sweeps of a scan one
         after the other (radar_operator.py:429-432); here up to `lanes` of them are in
         flight together, one host thread per lane (the library calls release the GIL)."""
-        n_par = 1 if self.distributed else min(self.lanes, len(sweeps))
+        if self.distributed:
+            return [self._package(r, az, el) for r, (az, el) in zip(self._simulate_volume_sharded(sweeps), sweeps)]
+        n_par = min(self.lanes, len(sweeps))
         if n_par <= 1:
             return [self._package(self._simulate_sweep(az, el), az, el) for az, el in sweeps]
         import queue
@@ -628,10 +630,13 @@ class RadarOperator(object):
             return list(pool.map(one, sweeps))
 
     def _simulate_sweep(self, az, el, lane=0):
-        """All rays of a sweep: locally, or sharded over the ranks of the default
-        torch.distributed group with one all-gather (cosmo_pol_amd/distributed.py)."""
-        if not self.distributed:
-            return self.simulate_rays(az, el, lane=lane)
+        """All rays of a sweep on this GPU."""
+        return self.simulate_rays(az, el, lane=lane)
+
+    def _simulate_volume_sharded(self, sweeps, lane=0):
+        """All sweeps of a scan, the rays of every sweep sharded over the ranks of the default
+        torch.distributed group: this rank's rays of ALL sweeps in one launch sequence and ONE
+        all-gather per scan (cosmo_pol_amd/distributed.py).  -> list of per-sweep result dicts."""
         import torch
         from . import distributed as D
         if self.output_variables != 'only_radar':
@@ -645,15 +650,18 @@ class RadarOperator(object):
         n_gates = len(self.constants.RANGE_RADAR)
         dev = torch.device('cuda', self.device)
         # device-resident: the kernels write this rank's rays straight into its block of the
-        # gather buffer, one all-gather of device blocks, one device-to-host copy of the sweep
+        # gather buffer, one all-gather of device blocks, one device-to-host copy of the volume
         ctx = self._lane(lane)
         cache = self.__dict__.setdefault('_dist_cache', {})
 
         def run_block(a, e, ptrs):
             self.simulate_rays(a, e, device_outputs=ptrs, lane=lane)
-        res = D.simulate_sharded_device(run_block, ctx.stream_ptr(), az, el, fields, n_gates, dev,
-                                        cache=cache)
+        res = D.simulate_sharded_volume_device(run_block, ctx.stream_ptr(), sweeps, fields, n_gates, dev,
+                                               cache=cache)
         ctx.synchronize()                                       # deferred domain error, if any
+        sub = self._cached('sub', lambda: quadrature.subbeams(self.__config))
+        for r in res:
+            r['n_sub'] = sub.n_sub
         return res
 
     def _package(self, res, az, el):

@@ -27,18 +27,26 @@ def test_cpu_pool_child_reports_every_leg():
     assert 'torch' not in r.stderr.lower() or 'error' not in r.stderr.lower()
 
 
-def test_lookup_roofline_prices_the_bytes_the_kernel_must_move():
+def test_stage_roofline_is_recomputable_from_the_committed_profile(tmp_path, monkeypatch):
+    """roofline.frac of the bench line = HBM bytes per launch of the committed PMC summary / live
+    duration / 8 TB/s for the dominant stage; hbm_alg_frac = SURVEY 8(d) bytes over the same time."""
     import bench
-
-    class C(object):
-        n_table_items = 195751
-        n_valid_items = 195751
-        ms_psd = 0.030
-
-    r = bench.roofline_lookup('c2', C(), 195751 * bench.LUT_SLICE_BYTES, None, n_fields_read=12)
-    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
-    must = 195751 * 124
-    assert abs(r['achieved'] - must / 0.030e-3 / 1e9) < 1e-6
-    assert 0 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
-    assert r['l1_gather']['bytes_per_item'] == 12 * 11 * 8 and 0 < r['l1_gather']['frac'] < 1
-    assert r['hbm_alg_frac'] > 1                      # the survey's B_alg: what the reference algorithm reads
+    prof = {'_note': 'x',
+            'k_psd_lookup(HydroSet, ItabSet, LookupArgs)': {'avg_us': 25.0, 'hbm_bytes': 29.0e6},
+            'k_final<256>(FinalArgs, ScanRayArgs)': {'avg_us': 30.0, 'hbm_bytes': 41.0e6},
+            'k_interp_sweep(ModelDev, InterpArgs)': {'avg_us': 22.0, 'hbm_bytes': 51.0e6},
+            'k_itab_fit(ItabFitArgs)': {'avg_us': 300.0, 'hbm_bytes': 9e8}}
+    (tmp_path / 'profiles').mkdir()
+    (tmp_path / 'profiles' / 'r3_c2_iso_summary.json').write_text(json.dumps(prof))
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    ms = {'interp': 0.022, 'classify': 0.016, 'bucket': 0.008, 'psd': 0.026, 'final': 0.031}
+    r = bench.roofline_of_dominant_stage('c2_iso', ms, 180000, 195751, 180000, 9, 80)
+    assert r['stage'] == 'final' and r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['traffic'] - 41.0e6) < 1 and abs(r['achieved'] - 41.0e6 / 0.031e-3 / 1e9) < 1e-6
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0 < r['frac'] < 1
+    assert r['algorithmic_bytes_per_launch'] == 180000 * 48
+    st = r['stages']
+    assert st['psd']['algorithmic_bytes'] == 195751 * bench.LUT_SLICE_BYTES and st['psd']['hbm_alg_frac'] > 1
+    assert st['interp']['algorithmic_bytes'] == 180000 * (4 * 80 * 4 + 9 * 8 * 4)
+    assert st['classify']['traffic'] is None and 'k_itab_fit' not in str(st)
+    assert abs(r['whole_sweep']['traffic'] - (29.0e6 + 41.0e6 + 51.0e6)) < 1

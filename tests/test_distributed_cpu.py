@@ -92,3 +92,48 @@ def test_shard_bounds_cover_and_are_contiguous():
             for a, b in zip(edges[:-1], edges[1:]):
                 assert a[1] == b[0] and a[2] == b[2]
             assert all(hi - lo <= per for lo, hi, per in edges)
+
+
+def _worker_volume(rank, world, port, rays_per_sweep, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from cosmo_pol_amd import distributed as D
+    sweeps = [(np.linspace(0, 359, n), np.full(n, 0.5 + 1.5 * s)) for s, n in enumerate(rays_per_sweep)]
+    calls = []
+
+    def sim(a, e):
+        calls.append(len(a))
+        return fake_simulate(a, e)
+    res = D.simulate_sharded_volume(sim, sweeps, list(zip(FIELDS, DTYPES)), N_GATES)
+    q.put((rank, [{k: v.copy() for k, v in r.items()} for r in res], calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,rays', [(2, (360, 360, 360)), (3, (10, 7, 1, 4)), (2, (1, 1))])
+def test_sharded_volume_one_call_one_gather_equals_single_process(world, rays):
+    """A scan of several sweeps sharded as a whole: every rank runs its rays of ALL sweeps in one
+    call and one all-gather assembles every sweep on every rank, bitwise equal to the un-sharded
+    sweeps (the bench's c4 mode and RadarOperator(distributed=True).get_PPI)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_volume, args=(r, world, port, rays, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from cosmo_pol_amd.distributed import shard_bounds
+    for rank, res, calls in got:
+        mine = sum(shard_bounds(n, world, rank)[1] - shard_bounds(n, world, rank)[0] for n in rays)
+        assert calls == ([mine] if mine else [])
+        assert len(res) == len(rays)
+        for s, n in enumerate(rays):
+            ref = fake_simulate(np.linspace(0, 359, n), np.full(n, 0.5 + 1.5 * s))
+            for k in FIELDS:
+                assert res[s][k].shape == (n, N_GATES) and res[s][k].dtype == ref[k].dtype
+                assert np.array_equal(res[s][k].view(np.uint8), ref[k].view(np.uint8)), (rank, s, k)

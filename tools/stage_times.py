@@ -17,6 +17,8 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--tag', default='')
     ap.add_argument('--rays', type=int, default=360, help='azimuths of the sweep (1 deg apart)')
+    ap.add_argument('--volume', action='store_true',
+                    help='the five elevations of the c3 / c4 volume in ONE launch sequence (rays x 5 rays)')
     args = ap.parse_args()
     import contextlib
     import numpy as np
@@ -36,8 +38,11 @@ def main():
         op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
     az = np.arange(0, args.rays, 1.0)
     el = np.full(args.rays, args.elev)
+    if args.volume:
+        az = np.tile(az, len(bench.C4_ELEVATIONS))
+        el = np.repeat(np.asarray(bench.C4_ELEVATIONS, dtype=float), args.rays)
     n_gates = len(op.constants.RANGE_RADAR)
-    slab = torch.empty((9, args.rays, n_gates), dtype=torch.float32, device='cuda')
+    slab = torch.empty((9, len(az), n_gates), dtype=torch.float32, device='cuda')
     ptrs = {k: slab[i].data_ptr() for i, k in enumerate(bench.RADAR_FIELDS)}
     for _ in range(3):
         op.simulate_rays(az, el, device_outputs=ptrs)
@@ -47,10 +52,8 @@ def main():
         op.simulate_rays(az, el, device_outputs=ptrs)
     op.wait()
     c = op._ctx.counters()
-    chk2 = op._ctx.debug_read('itab_check', (2, 8), np.float64)
-    chk = chk2[0]
-    print('itab_check at (block x 14 + fn):', [(int(v) // 14, int(v) % 14) for v in chk2[1][:len(hyds)]], file=sys.stderr)
-    print(json.dumps(dict(tag=args.tag, config=wl, elev=args.elev, n_valid=int(c.n_valid_items),
+    chk = op._ctx.itab_report()['check']
+    print(json.dumps(dict(tag=args.tag, config=wl, elev='volume' if args.volume else args.elev, rays=len(az), n_valid=int(c.n_valid_items),
                           n_table=int(c.n_table_items), tables_s=round(t_tables, 2),
                           itab_check=[float('%.2e' % v) for v in chk[:len(hyds)]],
                           interp=round(c.ms_interp * 1e3, 1), classify=round(c.ms_classify * 1e3, 1),
