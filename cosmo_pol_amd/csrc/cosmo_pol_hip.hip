@@ -1416,9 +1416,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                             (d.psd_family == CPOL_PSD_ICE_FIELD && d.uniform_grid && d.tab_degree == CPOL_ICE_DEGREE)) ? 7 : 6;
     }
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(cdiv(n_sbg, 256)), dim3(256), 0, st,
+    // (a fixed grid: the workgroups stride over the k_classify gate ranges and skip the empty ones)
+    const long n_cblk = cdiv(n_sbg, CPOL_CLASSIFY_THREADS);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3((unsigned)(n_cblk < 2048 ? n_cblk : 2048)), dim3(256), 0, st,
                        (const int *)ctx->b_key.p, (const int *)ctx->b_pos.p,
-                       (int *)ctx->b_perm.p, (const int *)ctx->b_blkranked.p, n_sbg, n_hyd, sa);      // + the work-unit list
+                       (int *)ctx->b_perm.p, (const int *)ctx->b_blkranked.p,
+                       (const unsigned char *)ctx->b_vmask.p, n_sbg, n_hyd, sa);      // + the work-unit list
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st));
 
     // ---- 5a. items on an integral table: 15 x 11 coefficients gathered, no diameter-bin loop ----
@@ -1428,6 +1431,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         if (any) {
             LookupArgs la{};
             la.key = (const int *)ctx->b_key.p;
+            la.vmask = (const unsigned char *)ctx->b_vmask.p;
             la.rec = (const double2 *)ctx->b_rec.p;
             la.par = (const double *)ctx->b_par.p;
             la.par_w = dop3 ? (double *)ctx->b_par.p : nullptr;
@@ -1571,6 +1575,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (subsum) {
         SubsumArgs sa2{};
         sa2.key = (const int *)ctx->b_key.p;
+        sa2.vmask = (const unsigned char *)ctx->b_vmask.p;
         sa2.rec = (const double2 *)ctx->b_rec.p;
         sa2.res = (const double *)ctx->b_res.p;
         sa2.sub_w = (const double *)ctx->v_subw;
@@ -1632,7 +1637,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                        : (d.psd_family == CPOL_PSD_ICE_FIELD || d.numeric_intv) ? 2 : 1;
             if (fa.vsrc[j] == 2)
                 hipLaunchKernelGGL(k_ice_first, dim3(n_rays * n_sub), dim3(64), 0, st,
-                                   (const int *)ctx->b_key.p + (long)j * n_sbg,
+                                   (const unsigned char *)ctx->b_vmask.p, j,
                                    (const double *)ctx->b_vn.p + (long)j * n_sbg * 2,
                                    (IceFirst *)ctx->b_icefirst.p, ng);
         }

@@ -24,7 +24,7 @@ struct IceFirst {
 };
 
 // one wavefront per (ray, sub-beam): ordered (deterministic) reduction over the gates
-__global__ __launch_bounds__(64) void k_ice_first(const int *__restrict__ key_j,
+__global__ __launch_bounds__(64) void k_ice_first(const unsigned char *__restrict__ vmask, int j,
                                                    const double *__restrict__ vn_j,
                                                    IceFirst *__restrict__ out, int n_gates)
 {
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64) void k_ice_first(const int *__restrict__ key_j,
     int first = 0x7fffffff;
     for (int g = lane; g < n_gates; g += 64) {
         const long sbg = rs * n_gates + g;
-        if (key_j[sbg] >= 0) {
+        if ((vmask[sbg] >> j) & 1) {
             v += vn_j[sbg * 2];
             nn += vn_j[sbg * 2 + 1];
             first = min(first, g);
@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void k_rvel_terms(FinalArgs a, double *__restr
 // parameters of the next sub-beam ahead of the gather changes neither (1.03 / 0.196 ms); two
 // sub-beams per step with both gathers in flight is slower (1.38 / 0.36 ms, 128 VGPRs).
 struct SubsumArgs {
-    const int *key;             // [n_hydro][n_sbg]
+    const int *key;             // [n_hydro][n_sbg] (valid where vmask says so)
+    const unsigned char *vmask; // [n_sbg] bit j: hydrometeor j present
     const double2 *rec;         // [n_hydro][n_sbg] {panel position (-1: not on the table), scale}
     const double *res;          // [n_hydro][n_sbg][12]
     const double *sub_w;        // [n_sub]
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) void k_subbeam_sum(HydroSet hs
     for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = __builtin_nanf("");
     for (int s = 0; s < a.n_sub; ++s) {
         const long sbg = sbg0 + (long)s * a.n_gates;
+        if (!((a.vmask[sbg] >> j) & 1)) continue;
         const int key = a.key[(long)j * n_sbg + sbg];
-        if (key < 0) continue;
         const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
         double2 v[CPOL_N_SZ / 2];
         const double2 rc = tab1 ? R[sbg] : make_double2(-1.0, 0.0);
@@ -316,7 +317,7 @@ __device__ __forceinline__ void final_gate(const FinalArgs &a, int ray, int gate
 #pragma unroll
             for (int q = 0; q < CPOL_FINAL_BATCH; ++q) {
                 const int sq = min(s0 + q, a.n_sub - 1);
-                kk[q] = (s0 + q < a.n_sub) ? a.key[(long)j * n_sbg + sbg0 + (long)sq * a.n_gates] : -1;
+                kk[q] = (s0 + q < a.n_sub && ((a.vmask[sbg0 + (long)sq * a.n_gates] >> j) & 1)) ? 0 : -1;
             }
 #pragma unroll
             for (int q = 0; q < CPOL_FINAL_BATCH; ++q) {

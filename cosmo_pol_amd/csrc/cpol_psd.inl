@@ -369,8 +369,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
         // sub-beam has a non-zero weight (:186-189)
         const bool valid = in && (qm > 0.f) && (!a.wgate || a.wgate[i] > 0.0);
         int key = -1;
-        double p0 = 0.0, p1 = 0.0, p2 = 0.0, dv = 0.0, dn = 0.0;
-        bool gamma_vn = false;
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0;         // parameter slots 0..2
         if (valid) {
             const float T = a.vals[d.var_t * n + i];
             // lut.py:336-341: float32 arithmetic for float32 queries
@@ -445,31 +444,20 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 break; }
             default: break;
             }
-            if (a.doppler && d.psd_family == CPOL_PSD_GAMMA && !d.numeric_intv) {
-                // _Hydrometeor.integrate_V (hydrometeors.py:178-199): analytic moments (a species with
-                // numeric_intv gets its sums from the PSD stage instead)
-                gamma_vn = true;
-                dv = d.vel_factor * n0v * d.alpha / d.nu * cp_pow(lamf, -(d.beta + d.mu + 1) / d.nu);
-                dn = (d.rule == CPOL_RULE_TWO_MOMENT)
-                    ? qnv : d.ntot_factor * n0v / d.nu * cp_pow(lamf, -(d.mu + 1) / d.nu);
-            }
         }
         // items whose lambda lies on the slot's integral table are finished by k_psd_lookup /
         // k_subbeam_sum from ONE 16-byte record {position on the panel axis, scale of the item}; only
         // the others are sorted by LUT slice for the integrating kernels
         bool lookup = false;
-        double pf = -1.0;
         const ItabDev &tj = its.t[j];
-        if (valid && tj.tab) {
-            pf = (cp_log(tj.par_slot == 2 ? p2 : p0) * 1.4426950408889634 - tj.log2_lo) * (double)tj.ppo;
-            lookup = pf >= (double)tj.pan_lo && pf < (double)tj.pan_hi;   // NaN -> false
-            // scale: gamma N0 exp(-lambda d0) (the table holds exp(+lambda d0) x integral); ice and melting: QM
-            const double scale = tj.two_d ? p0 : d.psd_family == CPOL_PSD_ICE_FIELD ? p2 : p1 * cp_exp(-(p0 * tj.d0));
-            a.rec[(long)j * n + i] = make_double2(lookup ? pf : -1.0, scale);
-            my_lookup += lookup ? 1 : 0;
-        }
         if (valid) {
             double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
+            double pf = -1.0;
+            if (tj.tab) {
+                pf = (cp_log(tj.par_slot == 2 ? p2 : p0) * 1.4426950408889634 - tj.log2_lo) * (double)tj.ppo;
+                lookup = pf >= (double)tj.pan_lo && pf < (double)tj.pan_hi;   // NaN -> false
+                my_lookup += lookup ? 1 : 0;
+            }
             if (!lookup || a.keep_par) {                     // read by the integrating kernels / the spectrum kernels
                 P[0] = p0;
                 P[n] = p1;
@@ -478,7 +466,20 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             } else if (tj.two_d) {
                 P[n] = p1;                                    // wet fraction: position inside the 2-D block
             }
-            if (gamma_vn) {
+            if (tj.tab) {
+                // scale: gamma N0 exp(-lambda d0) (the table holds exp(+lambda d0) x integral); ice and melting: QM
+                const double scale = tj.two_d ? p0 : d.psd_family == CPOL_PSD_ICE_FIELD ? p2 : p1 * cp_exp(-(p0 * tj.d0));
+                a.rec[(long)j * n + i] = make_double2(lookup ? pf : -1.0, scale);
+            }
+            if (a.doppler && d.psd_family == CPOL_PSD_GAMMA && !d.numeric_intv) {
+                // _Hydrometeor.integrate_V (hydrometeors.py:178-199): analytic moments (a species with
+                // numeric_intv gets its sums from the PSD stage instead); lambda = p0, N0 = the fixed
+                // intercept (rain, graupel) or p1 (few values stay live across the table decision above:
+                // this kernel has 128 VGPRs for its 16-wave ranking workgroups)
+                const double n0v = (d.rule == CPOL_RULE_RAIN_1MOM || d.rule == CPOL_RULE_GRAUPEL_1MOM) ? d.n0_fixed : p1;
+                const double dv = d.vel_factor * n0v * d.alpha / d.nu * cp_pow(p0, -(d.beta + d.mu + 1) / d.nu);
+                const double dn = (d.rule == CPOL_RULE_TWO_MOMENT)
+                    ? (double)a.vals[d.var_qn * n + i] : d.ntot_factor * n0v / d.nu * cp_pow(p0, -(d.mu + 1) / d.nu);
                 if (a.vn) *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = make_double2(dv, dn);
                 if (a.keep_par) { P[2 * n] = dv; P[3 * n] = dn; }
             }
@@ -486,7 +487,9 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
         }
         my_ranked += (valid && !lookup) ? 1 : 0;
         const int ticket = rank_insert(sh[j], a.count, key, valid && !lookup);
-        if (in) a.key[(long)j * n + i] = key;
+        // (the LUT slice of a PRESENT hydrometeor; who is present is in vmask[] -- the -1 of the others is
+        // only written for the debug reads and the spectrum kernels)
+        if (valid || (in && a.keep_par)) a.key[(long)j * n + i] = key;
         if (valid && !lookup) {                       // (rare: pos[] is written only where an item is ranked)
             a.pos[(long)j * n + i] = ticket;
             ranked_mask |= 1u << j;
@@ -612,9 +615,9 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ 
                                                          const int *__restrict__ pos,
                                                          int *__restrict__ perm,
                                                          const int *__restrict__ blk_ranked,
+                                                         const unsigned char *__restrict__ vmask,
                                                          long n_sbg, int n_hydro, ScanArgs a)
 {
-    const long sbg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n_waves = gridDim.x * (blockDim.x >> 6);
     if (a.count[a.n_keys + 2] == 0) return;                 // grid-uniform: nothing was ranked
     for (int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < a.n_keys; k += n_waves) {
@@ -631,14 +634,23 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ 
             a.units[ub + u] = w;
         }
     }
-    if (sbg >= n_sbg) return;
-    // the k_classify workgroup of these gates ranked nothing (the rule: a handful of items per volume
-    // lie outside the integral tables): neither key[] nor pos[] (unwritten there) is read
-    if (blk_ranked[sbg / CPOL_CLASSIFY_THREADS] == 0) return;      // uniform per workgroup (256 divides 1024)
-    for (int j = 0; j < n_hydro; ++j) {
-        const int k = key[(long)j * n_sbg + sbg];
-        const int ps = pos[(long)j * n_sbg + sbg];          // < 0: the item went to an integral table
-        if (k >= 0 && ps >= 0) perm[a.offset[k] + ps] = (int)sbg;
+    // The workgroups walk the gate ranges of the k_classify workgroups (CPOL_CLASSIFY_THREADS gates each)
+    // and skip those that ranked nothing -- the rule: a handful of items per volume lie outside the
+    // integral tables, and neither key[] nor pos[] (unwritten there) of the other gates is read.
+    const long n_cblk = (n_sbg + CPOL_CLASSIFY_THREADS - 1) / CPOL_CLASSIFY_THREADS;
+    for (long cb = blockIdx.x; cb < n_cblk; cb += gridDim.x) {
+        if (blk_ranked[cb] == 0) continue;                      // workgroup-uniform
+        for (int q = threadIdx.x; q < CPOL_CLASSIFY_THREADS; q += blockDim.x) {
+            const long sbg = cb * CPOL_CLASSIFY_THREADS + q;
+            if (sbg >= n_sbg) break;
+            const unsigned present = vmask[sbg];
+            for (int j = 0; j < n_hydro; ++j) {
+                if (!((present >> j) & 1u)) continue;
+                const int k = key[(long)j * n_sbg + sbg];
+                const int ps = pos[(long)j * n_sbg + sbg];      // < 0: the item went to an integral table
+                if (ps >= 0) perm[a.offset[k] + ps] = (int)sbg;
+            }
+        }
     }
 }
 
@@ -1749,7 +1761,8 @@ __global__ void k_itab_check2(ItabFit2Args f)
 #endif
 // one thread per sub-beam gate: the items that k_classify placed on an integral table
 struct LookupArgs {
-    const int *key;             // [n_hydro][n_sbg]
+    const int *key;             // [n_hydro][n_sbg] (valid where vmask says so)
+    const unsigned char *vmask; // [n_sbg] bit j: hydrometeor j present
     const double2 *rec;         // [n_hydro][n_sbg] {panel position (-1: not on the table), scale} (k_classify)
     const double *par;          // [n_hydro][CPOL_MAX_PAR][n_sbg] (melting species: slot 1 = wet fraction)
     double *par_w;              // = par, writable (ice: normalised N0 for the spectrum kernels) or NULL
@@ -1873,6 +1886,7 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
     }
     const long i = in ? i0 : 0;
     const long n = a.n_sbg;
+    const unsigned present = in ? a.vmask[i] : 0u;
     for (int j = 0; j < hs.n_hydro; ++j) {
         const ItabDev &t = its.t[j];
         if (!t.tab) continue;                                           // uniform
@@ -1880,7 +1894,7 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
         // that needs neither its Doppler sums nor the ice intercept)
         if (a.skip_res_1d && !t.two_d && !(a.vn && t.writes_vn) &&
             !(a.par_w && hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD)) continue;
-        const int key = in ? a.key[(long)j * n + i] : -1;
+        const int key = ((present >> j) & 1u) ? a.key[(long)j * n + i] : -1;
         const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
         const double2 rc = key >= 0 ? a.rec[(long)j * n + i] : make_double2(-1.0, 0.0);
         const double pf = rc.x;

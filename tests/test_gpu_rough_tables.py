@@ -128,6 +128,10 @@ def test_rough_tables_itab_vs_direct_vs_oracle(name, kind):
     if accepted and kind != 'alternating':       # ('alternating': the items may all lie in panels the gate cut)
         assert on['n_table_items'] > 0
     # ---- PSD-integrated entries: pure 1e-5, tables on and off, against the oracle ----
+    # ('alternating': the odd columns are 1024-term float64 sums that cancel up to 1e10-fold, i.e. defined
+    # to ~1e-6 .. 1e-4 of their value whatever the summation order -- NumPy's pairwise einsum and the
+    # device's chunked sums differ by that much; the point of that kind is the gate, checked above)
+    RTOL = 1e-3 if kind == 'alternating' else 1e-5              # (shadows the module's 1e-5 inside this test)
     assert np.isfinite(o.sz_integ).sum() > 200, 'the case was not exercised'
     _cases.assert_close_nan(on['sz_integ'], o.sz_integ, rtol=RTOL, name='tables on: sz_integ')
     _cases.assert_close_nan(off['sz_integ'], o.sz_integ, rtol=RTOL, name='tables off: sz_integ')
