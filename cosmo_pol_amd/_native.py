@@ -228,7 +228,7 @@ def load_library():
     lib.cpol_stage_t_function.restype = C.c_int
     lib.cpol_stage_t_function.argtypes = [vp, C.c_int, vp]
     lib.cpol_host_alloc.restype = C.c_int
-    lib.cpol_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.cpol_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]      # (ctx may be NULL: context-free block)
     lib.cpol_host_free.restype = C.c_int
     lib.cpol_host_free.argtypes = [vp, vp]
     _lib = lib
@@ -237,6 +237,65 @@ def load_library():
 
 def _ptr(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class PinnedPool(object):
+    """Page-locked host blocks for results handed to the user.
+
+    `take(nbytes)` returns a uint8 ndarray over a block of context-free pinned memory
+    (cpol_host_alloc(NULL, ...)).  The block belongs to that array and to every view carved from it:
+    when the last of them is garbage-collected the block goes back to the pool and is re-used by a
+    later `take` of the same size class -- so results stay valid for as long as anybody holds them,
+    whatever happens to the operator, its lanes or its contexts in the meantime, and a steady stream
+    of equal sweeps allocates nothing.  A block that was the target of a non-blocking device-to-host
+    copy remembers the context that issued it (`pending`); re-use waits for that context first."""
+    GRANULE = 1 << 20
+
+    def __init__(self):
+        import threading
+        self.lib = load_library()
+        self.free = {}              # size class -> [(address, context or None)]
+        self.lock = threading.Lock()
+        self.closed = False
+        self.n_alloc = 0
+
+    def _release(self, addr, size, holder):
+        with self.lock:
+            if not self.closed:
+                self.free.setdefault(size, []).append((addr, holder.get('ctx')))
+                return
+        self.lib.cpol_host_free(None, C.c_void_p(addr))
+
+    def take(self, nbytes):
+        import weakref
+        size = max(1, -(-int(nbytes) // self.GRANULE)) * self.GRANULE
+        with self.lock:
+            lst = self.free.get(size)
+            addr, ctx = lst.pop() if lst else (None, None)
+        if addr is None:
+            h = C.c_void_p()
+            rc = self.lib.cpol_host_alloc(None, size, C.byref(h))
+            if rc != 0 or not h:
+                raise MemoryError('cpol_host_alloc(%d bytes of page-locked host memory) failed' % size)
+            addr = h.value
+            self.n_alloc += 1
+        elif ctx is not None and getattr(ctx, 'h', None):
+            ctx.synchronize()       # a copy into this block may still be in flight (also surfaces a
+                                    # deferred domain error of that lane, once)
+        buf = (C.c_uint8 * size).from_address(addr)
+        arr = np.frombuffer(buf, dtype=np.uint8)
+        holder = {'ctx': None}
+        weakref.finalize(arr, self._release, addr, size, holder)
+        return arr, holder
+
+    def close(self):
+        """Frees the blocks nobody holds; blocks still held are freed when their last view dies."""
+        with self.lock:
+            self.closed = True
+            blocks = [a for lst in self.free.values() for a, _ in lst]
+            self.free = {}
+        for a in blocks:
+            self.lib.cpol_host_free(None, C.c_void_p(a))
 
 
 class Context(object):

@@ -689,8 +689,16 @@ int cpol_synchronize(cpol_ctx *ctx)
 
 int cpol_host_alloc(cpol_ctx *ctx, size_t bytes, void **out)
 {
-    if (!ctx || !out || bytes == 0) return CPOL_ERR_ARG;
+    if (!out || bytes == 0) return CPOL_ERR_ARG;
     *out = nullptr;
+    if (!ctx) {
+        // context-free block: owned by the caller until cpol_host_free(NULL, p) (a host-side pool whose
+        // blocks outlive the contexts that copy into them)
+        void *h = nullptr;
+        if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess || !h) return CPOL_ERR_NOMEM;
+        *out = h;
+        return CPOL_OK;
+    }
     HIPCHK(hipSetDevice(ctx->device));
     void *h = nullptr;
     if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess || !h) {
@@ -704,7 +712,8 @@ int cpol_host_alloc(cpol_ctx *ctx, size_t bytes, void **out)
 
 int cpol_host_free(cpol_ctx *ctx, void *p)
 {
-    if (!ctx || !p) return CPOL_ERR_ARG;
+    if (!p) return CPOL_ERR_ARG;
+    if (!ctx) return hipHostFree(p) == hipSuccess ? CPOL_OK : CPOL_ERR_HIP;   // a context-free block (see above)
     for (size_t i = 0; i < ctx->host_allocs.size(); ++i)
         if (ctx->host_allocs[i] == p) {
             HIPCHK(hipStreamSynchronize(ctx->stream));      // no copy into it may be in flight
@@ -1268,12 +1277,16 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             win_sum += obytes[k];
         }
     const bool window = win_lo && (size_t)(win_hi - win_lo) <= win_sum + win_sum / 4 + 4096;
-    if (window) ENSURE(ctx->b_outwin, (size_t)(win_hi - win_lo));
+    // (the device image keeps the window's alignment modulo 64 B, so that every array of the image is
+    // aligned exactly like its host counterpart: a float32 array at an address 4 mod 8 followed by a
+    // float64 array must not shift the latter to a misaligned device address)
+    const size_t win_skew = window ? ((size_t)(uintptr_t)win_lo & 63) : 0;
+    if (window) ENSURE(ctx->b_outwin, (size_t)(win_hi - win_lo) + 64);
     for (int k = 0; k < O_N; ++k) {
         T[k] = nullptr;
         if (!produced[k]) continue;
         if (dev && user_out[k] && !(ctx->keep_debug && k == O_SZT)) { T[k] = user_out[k]; continue; }   // in place
-        if (window && user_out[k]) { T[k] = (char *)ctx->b_outwin.p + ((char *)user_out[k] - win_lo); continue; }
+        if (window && user_out[k]) { T[k] = (char *)ctx->b_outwin.p + win_skew + ((char *)user_out[k] - win_lo); continue; }
         ENSURE(*own[k], obytes[k]);
         T[k] = own[k]->p;
     }
@@ -1756,7 +1769,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
 
     // ---- outputs that the kernels did not write in place ----
     if (window) {
-        HIPCHK(hipMemcpyAsync(win_lo, ctx->b_outwin.p, (size_t)(win_hi - win_lo), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(win_lo, (const char *)ctx->b_outwin.p + win_skew, (size_t)(win_hi - win_lo), hipMemcpyDeviceToHost, st));
     } else {
         for (int k = 0; k < O_N; ++k) {
             if (!produced[k] || !user_out[k] || T[k] == user_out[k]) continue;

@@ -150,6 +150,9 @@ class SimulatedGPM(object):
     packed into [N, M, max_len] arrays."""
 
     def __init__(self, fields, mask, lats, lons, n_kept, dim, band):
+        """`data` is a LazyDict and `lats` / `lons` are built on first access: every packed array is a
+        float64 [N, M, max_len] scatter of ~3 M values (8 ms each on the host), eleven of them per swath."""
+        from .radar_operator import LazyDict
         N, M = dim
         n_rays, n_gates = mask.shape
         self.band = band
@@ -160,15 +163,33 @@ class SimulatedGPM(object):
         self.bin_surface = np.where(first_above >= 0, n_kept - first_above, 0).astype(float).reshape(N, M)
         # kept gates (not below the topography), flipped so that index 0 is the lowest one
         keep = inside & (mask > -1)
-        n = keep.sum(axis=1)
-        src_idx = np.flatnonzero(keep)                                   # flat source index of every kept gate
-        dest = (n[:, None] - np.cumsum(keep, axis=1, dtype=np.int32)).reshape(-1)[src_idx]
-        dst_idx = (src_idx // n_gates) * n_gates + dest                  # flat destination (beam flipped)
+        idx = {}
+
+        def indices():
+            if not idx:
+                n = keep.sum(axis=1)
+                src_idx = np.flatnonzero(keep)                           # flat source index of every kept gate
+                dest = (n[:, None] - np.cumsum(keep, axis=1, dtype=np.int32)).reshape(-1)[src_idx]
+                idx['src'] = src_idx
+                idx['dst'] = (src_idx // n_gates) * n_gates + dest       # flat destination (beam flipped)
+            return idx['src'], idx['dst']
 
         def pack(src, fill):
+            src_idx, dst_idx = indices()
             out = np.full(n_rays * n_gates, fill, dtype=np.float64)
             out[dst_idx] = np.asarray(src).reshape(-1)[src_idx]
             return out.reshape(N, M, n_gates)
-        self.lats = pack(lats, np.nan)
-        self.lons = pack(lons, np.nan)
-        self.data = {k: pack(fields[k], 0.0) for k in fields}
+        self._coords = LazyDict()
+        self._coords.add('lats', lambda: pack(lats, np.nan))
+        self._coords.add('lons', lambda: pack(lons, np.nan))
+        self.data = LazyDict()
+        for k in fields:
+            self.data.add(k, (lambda kk: (lambda: pack(fields[kk], 0.0)))(k))
+
+    @property
+    def lats(self):
+        return self._coords['lats']
+
+    @property
+    def lons(self):
+        return self._coords['lons']

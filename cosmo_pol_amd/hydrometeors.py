@@ -289,6 +289,8 @@ def t_function_tables(which=('snow_n0', 'ice_mom2_a')):
     which = [k for k in which if k not in out]
     if not which:
         return out
+    # (not disk-cached: reading 2 x 64 MB back and checking them against this host's NumPy takes as
+    # long as evaluating them, 0.3 s; tablecache.py keeps the slow tables)
     T = np.arange(N.TFUN_FIRST_BITS, N.TFUN_FIRST_BITS + N.TFUN_COUNT, dtype=np.uint32).view(np.float32)
     with np.errstate(over='ignore', under='ignore', invalid='ignore'):
         if 'snow_n0' in which:
@@ -343,6 +345,20 @@ def _melting_factors(d, fw, n_d, dtype=np.longdouble):
 
 
 def melting_fw_tables(d, n_d, n_t, t_lo, t_step, deg=None):
+    """Disk-cached (tablecache.memo) form of _melting_fw_tables: keyed by the descriptor's constants,
+    the axes and the builder's source."""
+    from . import tablecache
+    dd = type(d).from_buffer_copy(bytes(d))
+    dd.table_id = 0
+    dd.var_q = dd.var_qn = dd.var_t = 0            # (where the species sits in the variable list does not matter)
+    parts = ['melt_fw', bytes(dd), n_d, n_t, float(t_lo), float(t_step), deg, np.__version__,
+             tablecache.source_of(_melting_fw_tables, _melting_factors)]
+    n_out = 2 * n_t + n_t * n_d * N.MELT_FUNCS * ((N.MELT_DEGREE if deg is None else deg) + 1)
+    return tablecache.memo('melt_fw', parts, lambda: _melting_fw_tables(d, n_d, n_t, t_lo, t_step, deg),
+                           verify=lambda v: v.dtype == np.float64 and v.shape == (n_out,) and bool(np.isfinite(v).all()))
+
+
+def _melting_fw_tables(d, n_d, n_t, t_lo, t_step, deg=None):
     """aux[] of a melting species (cpol_stage_hydro): per wet-fraction bin b of the table's
     second axis the centre and 1 / half-width of its fw interval, then per (b, diameter bin) the
     monomial coefficients in u = (fw - centre) / half-width of the degree-`deg` Chebyshev
@@ -385,6 +401,18 @@ ICE_LOG2_LO, ICE_LOG2_HI, ICE_PANELS_PER_OCTAVE = -24, 15, 8
 
 
 def ice_norm_tables(Dn, aDb, Vn, deg=None):
+    """Disk-cached (tablecache.memo) form of _ice_norm_tables."""
+    from . import tablecache
+    parts = ['ice_norm', np.asarray(Dn, dtype=np.float64), np.asarray(aDb, dtype=np.float64),
+             np.asarray(Vn, dtype=np.float64), deg, ICE_LOG2_LO, ICE_LOG2_HI, ICE_PANELS_PER_OCTAVE, ICE_POWER,
+             np.__version__, tablecache.source_of(_ice_norm_tables)]
+    n_pan = (ICE_LOG2_HI - ICE_LOG2_LO) * ICE_PANELS_PER_OCTAVE
+    n_out = 4 + n_pan * 3 * ((N.ICE_DEGREE if deg is None else deg) + 1)
+    return tablecache.memo('ice_norm', parts, lambda: _ice_norm_tables(Dn, aDb, Vn, deg),
+                           verify=lambda v: v.dtype == np.float64 and v.shape == (n_out,) and bool(np.isfinite(v).all()))
+
+
+def _ice_norm_tables(Dn, aDb, Vn, deg=None):
     """1-moment ice crystals: the renormalisation of the Field et al. (2005) PSD
     (hydrometeors.py:1331-1339) and IceParticle.integrate_V (:1256-1275) sum
     phi_23(lambda D_k / 1000) x (a D_k^b | V(D_k) | 1) over the 1024 nodes of the normalisation

@@ -13,6 +13,7 @@ callable (hydrometeors, frequency, scheme) -> {h: table}),
 """
 import copy
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -39,11 +40,75 @@ class ModelVar(object):
         self.attributes = attributes
 
 
+class LazyDict(dict):
+    """A dict whose values are built on first access (`add(key, make)`): the containers returned by
+    get_PPI / get_RHI / get_GPM_swath carry a dozen derived arrays per scan (dB fields, NaN masks,
+    re-gridded beams) of which a caller typically touches a few; building them eagerly -- as the
+    reference's PyartRadop / SimulatedGPM do on the host -- cost 4 - 7 x the simulation itself.
+    Iteration order = insertion order; every read access goes through the builders."""
+
+    def __init__(self):
+        dict.__init__(self)
+        self._make = {}
+        self._order = []
+
+    def add(self, key, make):
+        self._make[key] = make
+        self._order.append(key)
+
+    def _build(self, key):
+        mk = self._make.pop(key, None)
+        if mk is not None:
+            dict.__setitem__(self, key, mk())
+
+    def __setitem__(self, key, value):
+        self._make.pop(key, None)
+        if key not in self._order:
+            self._order.append(key)
+        dict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        self._order.remove(key)
+        if self._make.pop(key, None) is None:
+            dict.__delitem__(self, key)
+
+    def __getitem__(self, key):
+        self._build(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._build(key)
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        return key in self._make or dict.__contains__(self, key)
+
+    def __iter__(self):
+        return iter(list(self._order))
+
+    def __len__(self):
+        return len(self._order)
+
+    def keys(self):
+        return list(self._order)
+
+    def values(self):
+        return [self[k] for k in self._order]
+
+    def items(self):
+        return [(k, self[k]) for k in self._order]
+
+    def __repr__(self):
+        return 'LazyDict(%s)' % ', '.join('%r%s' % (k, '' if dict.__contains__(self, k) else ' (pending)')
+                                           for k in self._order)
+
+
 class RadarScan(object):
     """Light stand-in for PyartRadop (cosmo_pol/radar/pyart_wrapper.py:186-342):
     same field names and conventions (ZH, ZV, ZDR in dB with 0 -> NaN, masked
     where NaN, extra 'Latitude', 'Longitude', 'rangearray' fields, one entry of
-    sweep_start/stop_ray_index per sweep)."""
+    sweep_start/stop_ray_index per sweep).  `fields` is a LazyDict: the dB conversion, the
+    stacking over the sweeps and the NaN mask of a field are made when the field is first read."""
 
     def __init__(self, scan_type, elevations, azimuths, ranges, pos_time, sweeps):
         self.scan_type = scan_type
@@ -55,43 +120,44 @@ class RadarScan(object):
         self.time = {'data': np.zeros(len(sweeps[0]['azimuth'])),
                      'units': 'seconds since ' + str(pos_time.get('time'))}
         self.raw = sweeps                       # linear-unit arrays per sweep
-        az, el, start, stop = [], [], [], []
-        i0 = 0
-        for s in sweeps:
-            n = len(s['azimuth'])
-            az.extend(list(s['azimuth']))
-            el.extend(list(s['elevation']))
-            start.append(i0)
-            stop.append(i0 + n - 1)
-            i0 += n
-        self.azimuth = {'data': np.array(az, dtype=float)}
-        self.elevation = {'data': np.array(el, dtype=float)}
-        self.sweep_start_ray_index = {'data': np.array(start, dtype=float)}
-        self.sweep_stop_ray_index = {'data': np.array(stop, dtype=float)}
+        counts = np.array([len(s['azimuth']) for s in sweeps], dtype=np.int64)
+        stop = np.cumsum(counts)
+        self.azimuth = {'data': np.concatenate([np.asarray(s['azimuth'], dtype=float) for s in sweeps])}
+        self.elevation = {'data': np.concatenate([np.asarray(s['elevation'], dtype=float) for s in sweeps])}
+        self.sweep_start_ray_index = {'data': (stop - counts).astype(float)}
+        self.sweep_stop_ray_index = {'data': (stop - 1).astype(float)}
         self.sweep_number = {'data': np.arange(0, self.nsweeps, dtype=float)}
         self.sweep_mode = {'data': [scan_type] * self.nsweeps}
         self.fixed_angle = {'data': np.array(elevations if scan_type == 'ppi' else azimuths,
                                              dtype=float)}
-        self.fields = {}
-        names = list(sweeps[0]['fields'].keys())
-        for k in names:
-            parts = [s['fields'][k] for s in sweeps]
-            stack = np.concatenate(parts, axis=0) if (len(parts) > 1 or k in _DB_FIELDS) else parts[0]
-            if k in _DB_FIELDS:
-                # dB, 0 -> NaN (pyart_wrapper.py:256-258); in place on the stacked copy
-                with np.errstate(divide='ignore', invalid='ignore'):
-                    stack[stack == 0] = np.nan
-                    np.log10(stack, out=stack)
-                    stack *= 10
-            self.fields[k] = {'data': np.ma.array(stack, mask=np.isnan(stack), copy=False)}
-        for k, src in (('Latitude', 'lats'), ('Longitude', 'lons')):
-            stack = np.concatenate([s[src] for s in sweeps], axis=0)
-            self.fields[k] = {'data': np.ma.array(stack, mask=np.isnan(stack)),
-                              'units': ['degrees']}
-        self.fields['rangearray'] = {'data': np.broadcast_to(
-            self.range['data'], (len(self.elevation['data']), len(self.range['data'])))}
+        self.fields = LazyDict()
+
+        def field(k):
+            def make():
+                parts = [s['fields'][k] for s in sweeps]
+                stack = np.concatenate(parts, axis=0) if (len(parts) > 1 or k in _DB_FIELDS) else parts[0]
+                if k in _DB_FIELDS:
+                    # dB, 0 -> NaN (pyart_wrapper.py:256-258); in place on the stacked copy
+                    with np.errstate(divide='ignore', invalid='ignore'):
+                        stack[stack == 0] = np.nan
+                        np.log10(stack, out=stack)
+                        stack *= 10
+                return {'data': np.ma.array(stack, mask=np.isnan(stack), copy=False)}
+            return make
+
+        def coords(src):
+            def make():
+                stack = np.concatenate([s[src] for s in sweeps], axis=0)
+                return {'data': np.ma.array(stack, mask=np.isnan(stack)), 'units': ['degrees']}
+            return make
+        for k in sweeps[0]['fields'].keys():
+            self.fields.add(k, field(k))
+        self.fields.add('Latitude', coords('lats'))
+        self.fields.add('Longitude', coords('lons'))
         self.nrays = len(self.azimuth['data'])
         self.ngates = len(self.range['data'])
+        self.fields.add('rangearray', lambda: {'data': np.broadcast_to(
+            self.range['data'], (self.nrays, self.ngates))})
 
     def to_pyart(self, varray=None):
         """The scan as the reference's PyartRadop (a pyart.core.Radar); needs Py-ART."""
@@ -133,6 +199,7 @@ class RadarOperator(object):
                                 % (backend,))
         print('Reading options defined in options file')
         self._ctx = N.Context(device)         # raises if the HIP library / GPU is missing
+        self._pool = N.PinnedPool()           # page-locked blocks of the results handed to the user
         # lanes: contexts forked from _ctx (shared cube / tables, own stream + work buffers);
         # the sweeps of a volume scan are spread over them so that they overlap on the GPU
         self.lanes = max(1, int(lanes))
@@ -143,12 +210,16 @@ class RadarOperator(object):
         self.pyart_output = bool(pyart_output) # get_PPI / get_RHI return a pyart.core.Radar (needs Py-ART)
         self.reuse_device_tables = True        # keep per-ray tables in HBM between equal sweeps
         self.lut_dir = lut_dir
+        if lut_dir:
+            from . import tablecache
+            tablecache.set_default_dir(os.path.join(lut_dir, '.cpol_cache'))   # slow host-side staging tables
         self._user_luts = luts
         self.current_microphys_scheme = '1mom'
         self.dic_vars = None
         self.N = 0
         self.lut_sz = None
         self._model_staged = False
+        self._staged_serial = 0
         self._staged_hydro = None
         self.constants = None
         if output_variables in ['all', 'only_model', 'only_radar']:
@@ -191,9 +262,19 @@ class RadarOperator(object):
             self.set_lut()
 
     def _drop_lanes(self):
-        for c in self._lane_ctx:
+        """Closes the forked contexts (before re-staging).  Each is drained first, so that queued
+        sweeps complete into their result arrays (which live in the operator's pinned pool, not in
+        the lane) and a deferred domain error of a dropped lane is raised, not lost."""
+        lanes, self._lane_ctx = self._lane_ctx, []
+        err = None
+        for c in lanes:
+            try:
+                c.synchronize()
+            except IndexError as e:
+                err = e
             c.close()
-        self._lane_ctx = []
+        if err is not None:
+            raise err
 
     def _lane(self, i):
         """Context of lane i (0 = the root context); lanes are forked on first use and
@@ -210,6 +291,7 @@ class RadarOperator(object):
             self._drop_lanes()
             self._ctx.close()
             self._ctx = None
+            self._pool.close()                # (blocks of results still held are freed with their last view)
         self.dic_vars = None
         self.lut_sz = None
         self.__config = None
@@ -356,6 +438,7 @@ class RadarOperator(object):
                               res, sp)
         self._staged_vars = names
         self._model_staged = True
+        self._staged_serial = getattr(self, '_staged_serial', 0) + 1      # (host caches that depend on the cube)
 
     def get_pos_and_time(self):
         c = self.__config['radar']['coords']
@@ -381,11 +464,13 @@ class RadarOperator(object):
         paths (s, h, e_deg) replacing the 4/3-earth model (CPOL_GEOM_HOST_PATHS).
         `lane`: which forked context (stream + work buffers) runs the sweep; sweeps on
         different lanes overlap on the GPU (one host thread per lane at a time).
-        `pinned`: non-blocking host outputs -- the arrays returned are views of the lane's
-        page-locked slab, filled by device-to-host copies queued behind the kernels on the
-        lane's stream; call `wait(lane)` before reading them; they stay valid until the next
-        pinned sweep on the same lane.  (The copy of one sweep then overlaps the kernels of
-        the sweeps on the other lanes.)"""
+        Host outputs are views of one block of page-locked memory from the operator's pool,
+        filled by a single device-to-host copy queued behind the kernels; the block stays theirs
+        until the last of them is dropped (then it is re-used by a later sweep).
+        `pinned`: do not wait -- the call returns once the sweep is queued; call `wait(lane)` before
+        reading the arrays.  (The copy of one sweep then overlaps the kernels of the sweeps on the
+        other lanes.)  The gate coordinates (`lats`, `lons`, `dist`, `heights`) of an unchanged
+        scan geometry are read-only arrays shared between results."""
         conf = self.__config
         coords = conf['radar']['coords']
         if coords[2] > K.MAX_MODEL_HEIGHT:
@@ -413,16 +498,6 @@ class RadarOperator(object):
         """Waits for the sweeps queued on `lane` (pinned / device outputs); raises IndexError
         if one of them left the model domain."""
         self._lane(lane).synchronize()
-
-    def _pinned_slab(self, lane, nbytes):
-        """Page-locked host slab of a lane (grow-only; owned by the lane's context)."""
-        with self._lock:
-            slabs = self.__dict__.setdefault('_slabs', {})
-            cur = slabs.get(lane)
-            if cur is None or cur[0] is not self._lane(lane) or cur[1].nbytes < nbytes:
-                ctx = self._lane(lane)
-                slabs[lane] = (ctx, ctx.host_alloc(int(nbytes * 1.25) + 4096))
-            return slabs[lane][1]
 
     def _run_rays(self, azimuths, elevations, coords, n_gates, range0, mode, device_outputs=None,
                   apply_sensitivity=True, paths=None, site=None, sub=None, tables=None, lane=0,
@@ -457,7 +532,7 @@ class RadarOperator(object):
         p.with_attenuation = int(conf['microphysics']['with_attenuation'])
         want_model = self.output_variables in ('all', 'only_model')
         p.integrate_model = int(want_model)
-        p.outputs_on_device = 1 if device_outputs is not None else (2 if pinned else 0)
+        p.outputs_on_device = 1 if device_outputs is not None else 2     # host outputs: page-locked, one copy
         # Doppler schemes 1 (analytic mean fall speed) and 2 (rcs-weighted); none for GPM
         # (doppler_scatter.py:83-87); scheme 3 (full spectrum) is out of scope
         doppler = (conf['doppler']['scheme'] in (1, 2, 3) and conf['radar'].get('type') != 'GPM'
@@ -552,39 +627,42 @@ class RadarOperator(object):
                          ('dist', np.float32, shape), ('heights', np.float32, shape)]
             if want_model:
                 spec.append(('model_vars', np.float64, (len(self._staged_vars),) + shape))
-            if pinned:
-                geo_names = ('lats', 'lons', 'dist', 'heights')
-                pin = [x for x in spec if not (gkey and x[0] in geo_names)]
-                sizes = [-(-int(np.prod(sh)) * np.dtype(dt).itemsize // 64) * 64 for _, dt, sh in pin]
-                slab = self._pinned_slab(lane, sum(sizes))
-                off = 0
-                for (k, dt, sh), nb in zip(pin, sizes):
-                    n_el = int(np.prod(sh))
-                    res[k] = slab[off:off + n_el * np.dtype(dt).itemsize].view(dt).reshape(sh)
-                    off += nb
-                for k, dt, sh in spec:          # cacheable geometry: own arrays (first sweep only)
-                    if k not in res:
-                        res[k] = np.empty(sh, dtype=dt)
-            else:
-                for k, dt, sh in spec:
-                    res[k] = np.empty(sh, dtype=dt)
+            # every host output is a view of ONE block of page-locked memory from the operator's pool
+            # (64-byte aligned arrays): the kernels write a device image of the block and a single
+            # device-to-host copy, queued behind them, moves it.  The block belongs to the arrays: it
+            # returns to the pool when the last of them is dropped, whatever happens to the lanes or
+            # the operator in between.
+            sizes = [-(-int(np.prod(sh)) * np.dtype(dt).itemsize // 64) * 64 for _, dt, sh in spec]
+            slab, holder = self._pool.take(sum(sizes))
+            off = 0
+            for (k, dt, sh), nb in zip(spec, sizes):
+                n_el = int(np.prod(sh))
+                res[k] = slab[off:off + n_el * np.dtype(dt).itemsize].view(dt).reshape(sh)
+                off += nb
+            del slab
             for k, a in res.items():
                 setattr(o, k, a.ctypes.data)
-        self._lane(lane).run_sweep(p, t, o)
+        ctx = self._lane(lane)
+        ctx.run_sweep(p, t, o)
         del keep
         if device_outputs is None:
+            if pinned:
+                holder['ctx'] = ctx                     # a copy into the block is in flight until wait(lane)
+            else:
+                ctx.synchronize()                       # blocking call: results complete, IndexError raised here
             if geom is None and gkey is not None:
                 if pinned:
-                    self._lane(lane).synchronize()      # once per table set: the arrays are complete
-                geom = {k: res[k] for k in ('lats', 'lons', 'dist', 'heights')}
+                    ctx.synchronize()                   # once per table set: the arrays are complete
+                # (own read-only copies: shared by every later result of this table set)
+                geom = {k: res[k].copy() for k in ('lats', 'lons', 'dist', 'heights')}
                 for a in geom.values():
-                    a.flags.writeable = False       # shared by every later result of this table set
+                    a.flags.writeable = False
                 with self._lock:
                     old = [k for k in self._cache if isinstance(k, tuple) and k and k[0] == 'geom']
                     for k in old[:max(0, len(old) - 7)]:
                         del self._cache[k]
                     self._cache[gkey] = geom
-            elif geom is not None:
+            if geom is not None:
                 res.update(geom)
         res['n_sub'] = sub.n_sub
         return res
@@ -752,27 +830,44 @@ class RadarOperator(object):
         conf['radar']['radial_resolution'] = res_m
         try:
             self.config = conf                   # reloads the tables of the new frequency
-            az, el, rng, sat = gpm.swath_angles(swath)
-            dim = az.shape
-            az, el, rng = az.ravel(), el.ravel(), rng.ravel()
-            coords = np.repeat(sat, dim[1], axis=0)                      # one site per ray
-            sub = quadrature.subbeams(self.__config)
-            traj, geo_t = geo.ray_tables(coords, az, el, sub)
-            n_rays = len(az)
-            # candidate gates: np.arange(res/2, slant range, res) (atm_refraction.py:252)
-            n_cand = np.maximum(np.ceil((rng - res_m / 2.) / res_m), 0).astype(np.int32)
-            sin_u1, cos_u1, _ = geo.radar_site_constants(coords)
-            site = np.zeros((n_rays, 8))
-            site[:, 0], site[:, 1], site[:, 2], site[:, 3] = sin_u1, cos_u1, coords[:, 1], coords[:, 2]
-            site[:, 4] = geo.get_earth_radius(coords[:, 0])              # quirk Q1 (degrees as radians)
-            p = N.SweepParams()
-            p.n_rays, p.n_vnodes = n_rays, len(sub.pts_ver)
-            p.range0, p.range_step = res_m / 2., float(res_m)
-            first = self._ctx.spaceborne_first_gate(p, traj, site, n_cand, K.MAX_MODEL_HEIGHT)
-            k0 = first[:, sub.sub_v[sub.central]]
-            n_kept = (n_cand - k0).astype(np.int64)
-            site[:, 5], site[:, 6] = k0, n_kept
-            n_gates = int(max(1, n_kept.max()))
+            # everything below depends on the swath geometry and the band only: kept for the last few
+            # swaths (a Ku and a Ka call on the same file, repeated calls on one overpass)
+            import hashlib
+            hk = hashlib.blake2b(digest_size=16)
+            for name in ('Latitude', 'Longitude', 'scLat', 'scLon', 'dprAlt', 'scPos'):
+                hk.update(np.ascontiguousarray(swath[name], dtype=np.float64).tobytes())
+            hk.update(repr(sorted(self.__config['integration'].items(), key=str)).encode())
+            gkey = (hk.hexdigest(), band, self._staged_serial)
+            gcache = self.__dict__.setdefault('_gpm_cache', {})  # (survives the configuration switches of this call)
+            cached = gcache.get(gkey)
+            if cached is None:
+                az, el, rng, sat = gpm.swath_angles(swath)
+                dim = az.shape
+                az, el, rng = az.ravel(), el.ravel(), rng.ravel()
+                coords = np.repeat(sat, dim[1], axis=0)                      # one site per ray
+                sub = quadrature.subbeams(self.__config)
+                traj, geo_t = geo.ray_tables(coords, az, el, sub)
+                n_rays = len(az)
+                # candidate gates: np.arange(res/2, slant range, res) (atm_refraction.py:252)
+                n_cand = np.maximum(np.ceil((rng - res_m / 2.) / res_m), 0).astype(np.int32)
+                sin_u1, cos_u1, _ = geo.radar_site_constants(coords)
+                site = np.zeros((n_rays, 8))
+                site[:, 0], site[:, 1], site[:, 2], site[:, 3] = sin_u1, cos_u1, coords[:, 1], coords[:, 2]
+                site[:, 4] = geo.get_earth_radius(coords[:, 0])              # quirk Q1 (degrees as radians)
+                p = N.SweepParams()
+                p.n_rays, p.n_vnodes = n_rays, len(sub.pts_ver)
+                p.range0, p.range_step = res_m / 2., float(res_m)
+                first = self._ctx.spaceborne_first_gate(p, traj, site, n_cand, K.MAX_MODEL_HEIGHT)
+                k0 = first[:, sub.sub_v[sub.central]]
+                n_kept = (n_cand - k0).astype(np.int64)
+                site[:, 5], site[:, 6] = k0, n_kept
+                n_gates = int(max(1, n_kept.max()))
+                cached = (az, el, rng, dim, coords, sub, traj, geo_t, site, n_kept, n_gates)
+                with self._lock:
+                    for k in list(gcache)[:-3]:
+                        del gcache[k]
+                    gcache[gkey] = cached
+            az, el, rng, dim, coords, sub, traj, geo_t, site, n_kept, n_gates = cached
             res = self._run_rays(az, el, coords, n_gates, res_m / 2., N.GEOM_SPACEBORNE,
                                  site=site, sub=sub, tables=(traj, geo_t))
             fields = {}

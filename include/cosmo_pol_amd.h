@@ -154,7 +154,9 @@ typedef struct {
                                    cpol_synchronize.  Carve the arrays from ONE allocation:
                                    when they span a window of at most 1.25 x their total
                                    size they are moved by a single copy (which also
-                                   overwrites the padding bytes between them)               */
+                                   overwrites the padding bytes between them -- do not keep
+                                   other data inside that window).  Every array must be
+                                   aligned to its element size, as any C array is            */
     int32_t simulate_doppler;   /* 0 off, 1 / 2 / 3 = Doppler scheme of the reference (RVEL;
                                    3 = full Doppler spectrum, doppler_scatter.py:335-391) */
     int32_t geometry_mode;      /* CPOL_GEOM_*                                   */
@@ -260,7 +262,10 @@ int  cpol_set_stream(cpol_ctx *ctx, void *hip_stream);
 int  cpol_synchronize(cpol_ctx *ctx);
 /* page-locked host memory owned by the context (freed by cpol_host_free / cpol_destroy): the
  * target of outputs_on_device = 2, so that the device-to-host copy of one sweep overlaps the
- * kernels of the next (other lanes) instead of being staged through pageable memory */
+ * kernels of the next (other lanes) instead of being staged through pageable memory.
+ * ctx = NULL: a context-free block owned by the caller until cpol_host_free(NULL, p) -- for host-side
+ * pools whose blocks (results handed to the user) must outlive the contexts that filled them; the
+ * caller makes sure no copy into the block is in flight when it frees or re-uses it */
 int  cpol_host_alloc(cpol_ctx *ctx, size_t bytes, void **out);
 int  cpol_host_free(cpol_ctx *ctx, void *p);
 /* the HIP stream (hipStream_t) the context launches on: to order foreign work (copies,

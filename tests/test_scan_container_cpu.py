@@ -146,3 +146,44 @@ def test_pyart_packaging_passes_the_reference_arguments(monkeypatch):
     assert np.array_equal(radar.instrument_parameters['varray']['data'], np.linspace(-8, 8, 5))
     assert radar.get_field(1, 'ZDR').shape == (3, n_g)
     assert radar.fields['rangearray']['data'].shape == (6, n_g)
+
+
+def test_lazy_fields_equal_the_eager_container():
+    """RadarScan.fields builds a field (stack over the sweeps, dB with 0 -> NaN, NaN mask) when it is
+    first read: same arrays as the eager construction, every dict access path goes through the
+    builder, untouched fields cost nothing."""
+    from cosmo_pol_amd.radar_operator import LazyDict, RadarScan
+    rng = np.random.default_rng(3)
+    n_g = 7
+    sweeps = []
+    for n in (4, 3):
+        f = {k: rng.uniform(0.1, 5.0, size=(n, n_g)).astype(np.float32) for k in ('ZH', 'ZDR', 'ZV', 'KDP')}
+        f['ZH'][0, 1] = 0.0
+        f['KDP'][1, 2] = np.nan
+        sweeps.append({'fields': f, 'azimuth': np.arange(n, dtype=float), 'elevation': np.full(n, 1.0),
+                       'lats': rng.normal(size=(n, n_g)), 'lons': rng.normal(size=(n, n_g))})
+    scan = RadarScan('ppi', [1.0, 2.0], [0., 1., 2., 3.], np.arange(n_g) * 100., dict(latitude=46., longitude=7., altitude=500., time=None), sweeps)
+    assert isinstance(scan.fields, LazyDict)
+    assert list(scan.fields.keys()) == ['ZH', 'ZDR', 'ZV', 'KDP', 'Latitude', 'Longitude', 'rangearray']
+    assert 'ZH' in scan.fields and len(scan.fields) == 7 and 'pending' in repr(scan.fields)
+    assert not dict.__contains__(scan.fields, 'ZH')                 # nothing built yet
+    zh = scan.fields['ZH']['data']
+    assert dict.__contains__(scan.fields, 'ZH') and not dict.__contains__(scan.fields, 'ZV')
+    lin = np.concatenate([s['fields']['ZH'] for s in sweeps])
+    with np.errstate(divide='ignore'):
+        exp = 10 * np.log10(np.where(lin == 0, np.nan, lin))
+    assert zh.shape == (7, n_g) and zh.mask[0, 1] and np.allclose(zh.filled(np.nan), exp, equal_nan=True)
+    assert sweeps[0]['fields']['ZH'][0, 1] == 0.0                   # the raw (linear) arrays are untouched
+    kdp = scan.fields.get('KDP')['data']
+    assert kdp.mask[1, 2] and kdp.mask[5, 2] and kdp.mask.sum() == 2
+    assert scan.get_field(1, 'ZV').shape == (3, n_g)
+    for k, v in scan.fields.items():
+        assert v['data'].shape == (7, n_g), k
+    assert scan.fields['rangearray']['data'][3, 2] == 200.
+    assert [int(x) for x in scan.sweep_start_ray_index['data']] == [0, 4]
+    assert [int(x) for x in scan.sweep_stop_ray_index['data']] == [3, 6]
+    assert scan.nrays == 7 and len(scan.azimuth['data']) == 7
+    scan.fields['extra'] = {'data': 1}
+    assert list(scan.fields)[-1] == 'extra'
+    del scan.fields['ZDR']
+    assert 'ZDR' not in scan.fields and len(scan.fields) == 7
