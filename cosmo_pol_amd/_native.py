@@ -250,6 +250,7 @@ class PinnedPool(object):
     of equal sweeps allocates nothing.  A block that was the target of a non-blocking device-to-host
     copy remembers the context that issued it (`pending`); re-use waits for that context first."""
     GRANULE = 1 << 20
+    MAX_PENDING = 8             # blocks of one size class that may wait for foreign copies before the pool waits
 
     def __init__(self):
         import threading
@@ -262,16 +263,41 @@ class PinnedPool(object):
     def _release(self, addr, size, holder):
         with self.lock:
             if not self.closed:
-                self.free.setdefault(size, []).append((addr, holder.get('ctx')))
+                ctx = holder.get('ctx')
+                self.free.setdefault(size, []).append((addr, ctx, holder.get('serial', 0)))
                 return
         self.lib.cpol_host_free(None, C.c_void_p(addr))
 
-    def take(self, nbytes):
+    @staticmethod
+    def _clean(ctx, serial):
+        """No copy into the block can still be in flight."""
+        return ctx is None or not getattr(ctx, 'h', None) or ctx.completed >= serial
+
+    def take(self, nbytes, writer=None):
+        """-> (uint8 array over a block of >= nbytes, holder).  `writer`: the context whose stream
+        will copy into the block.  A block whose last copy (queued by context C, not yet waited for)
+        may still be in flight is handed out again without waiting only to C itself -- copies on one
+        stream stay in order, and nobody holds the old arrays any more; for another writer the pool
+        prefers a clean block, then a new one (up to MAX_PENDING blocks in flight), then waits for C.
+        After queueing a non-blocking copy set holder['ctx'], holder['serial'] = context, its
+        `submitted` count."""
         import weakref
         size = max(1, -(-int(nbytes) // self.GRANULE)) * self.GRANULE
+        addr = wait_for = None
         with self.lock:
-            lst = self.free.get(size)
-            addr, ctx = lst.pop() if lst else (None, None)
+            lst = self.free.get(size) or []
+            pick = None
+            for i, (a, c, ser) in enumerate(lst):                    # oldest first
+                if c is writer or self._clean(c, ser):
+                    pick = i
+                    break
+            if pick is None and lst and len(lst) >= self.MAX_PENDING:
+                pick = 0
+                wait_for = lst[0][1]
+            if pick is not None:
+                addr = lst.pop(pick)[0]
+        if wait_for is not None:
+            wait_for.synchronize()  # (also surfaces a deferred domain error of that lane, once)
         if addr is None:
             h = C.c_void_p()
             rc = self.lib.cpol_host_alloc(None, size, C.byref(h))
@@ -279,12 +305,9 @@ class PinnedPool(object):
                 raise MemoryError('cpol_host_alloc(%d bytes of page-locked host memory) failed' % size)
             addr = h.value
             self.n_alloc += 1
-        elif ctx is not None and getattr(ctx, 'h', None):
-            ctx.synchronize()       # a copy into this block may still be in flight (also surfaces a
-                                    # deferred domain error of that lane, once)
         buf = (C.c_uint8 * size).from_address(addr)
         arr = np.frombuffer(buf, dtype=np.uint8)
-        holder = {'ctx': None}
+        holder = {'ctx': None, 'serial': 0}
         weakref.finalize(arr, self._release, addr, size, holder)
         return arr, holder
 
@@ -292,7 +315,7 @@ class PinnedPool(object):
         """Frees the blocks nobody holds; blocks still held are freed when their last view dies."""
         with self.lock:
             self.closed = True
-            blocks = [a for lst in self.free.values() for a, _ in lst]
+            blocks = [e[0] for lst in self.free.values() for e in lst]
             self.free = {}
         for a in blocks:
             self.lib.cpol_host_free(None, C.c_void_p(a))
@@ -312,6 +335,7 @@ class Context(object):
         self.device = device
         self.n_vars = 0
         self._keep = []
+        self.submitted = self.completed = 0     # sweeps queued / known to have completed (synchronize)
 
     def fork(self):
         """A lane: shares this context's staged model / tables, own stream and work
@@ -321,6 +345,7 @@ class Context(object):
         lane = Context.__new__(Context)
         lane.lib, lane.h, lane.device, lane.n_vars = self.lib, h, self.device, self.n_vars
         lane._keep = []
+        lane.submitted = lane.completed = 0
         lane._parent = self          # keeps the parent alive
         return lane
 
@@ -354,7 +379,10 @@ class Context(object):
     def synchronize(self):
         """Waits for the context's stream; raises IndexError if a sweep since the last
         report left the model domain (deferred error of device / pinned-host outputs)."""
-        self._check(self.lib.cpol_synchronize(self.h), 'cpol_synchronize')
+        n = self.submitted
+        rc = self.lib.cpol_synchronize(self.h)
+        self.completed = max(self.completed, n)          # (the stream has drained, error or not)
+        self._check(rc, 'cpol_synchronize')
 
     def host_alloc(self, nbytes):
         """uint8 array over page-locked host memory owned by the context (the target of
@@ -440,6 +468,7 @@ class Context(object):
         return out
 
     def run_sweep(self, params, tables, outputs):
+        self.submitted += 1
         rc = self.lib.cpol_run_sweep(self.h, C.byref(params), C.byref(tables), C.byref(outputs))
         self._check(rc, 'cpol_run_sweep')
 

@@ -156,8 +156,11 @@ class RadarScan(object):
         self.fields.add('Longitude', coords('lons'))
         self.nrays = len(self.azimuth['data'])
         self.ngates = len(self.range['data'])
-        self.fields.add('rangearray', lambda: {'data': np.broadcast_to(
-            self.range['data'], (self.nrays, self.ngates))})
+        # (the builders capture locals, never `self`: a scan must not be part of a reference cycle, or the
+        # page-locked block of its arrays would wait for the cyclic garbage collector instead of
+        # returning to the operator's pool when the scan is dropped)
+        rng, shape = self.range['data'], (self.nrays, self.ngates)
+        self.fields.add('rangearray', lambda: {'data': np.broadcast_to(rng, shape)})
 
     def to_pyart(self, varray=None):
         """The scan as the reference's PyartRadop (a pyart.core.Radar); needs Py-ART."""
@@ -633,7 +636,7 @@ class RadarOperator(object):
             # returns to the pool when the last of them is dropped, whatever happens to the lanes or
             # the operator in between.
             sizes = [-(-int(np.prod(sh)) * np.dtype(dt).itemsize // 64) * 64 for _, dt, sh in spec]
-            slab, holder = self._pool.take(sum(sizes))
+            slab, holder = self._pool.take(sum(sizes), writer=self._lane(lane))
             off = 0
             for (k, dt, sh), nb in zip(spec, sizes):
                 n_el = int(np.prod(sh))
@@ -647,7 +650,7 @@ class RadarOperator(object):
         del keep
         if device_outputs is None:
             if pinned:
-                holder['ctx'] = ctx                     # a copy into the block is in flight until wait(lane)
+                holder['ctx'], holder['serial'] = ctx, ctx.submitted    # a copy into the block is in flight until wait(lane)
             else:
                 ctx.synchronize()                       # blocking call: results complete, IndexError raised here
             if geom is None and gkey is not None:

@@ -1,9 +1,9 @@
 """Refraction scheme 2: ray paths from the Zeng & Blahak (2014) ODE.
 
 Host-side, one solve per distinct (elevation + vertical quadrature node), exactly
-as the reference does it with scipy's LSODA (cosmo_pol/interpolation/
-atm_refraction.py:56-148): the resulting float32 (s, h, e) tables are handed to
-the GPU through CPOL_GEOM_HOST_PATHS.  Quirks kept: the refractivity column is
+as the reference does it -- scipy's LSODA over scipy's interp1d of the refractivity column,
+on the dtypes the model fields come in (cosmo_pol/interpolation/atm_refraction.py:56-179):
+the resulting float32 (s, h, e) tables are handed to the GPU through CPOL_GEOM_HOST_PATHS.  Quirks kept: the refractivity column is
 read at [round(p0), round(p0)] (the row index is used for both axes, :113-117)
 and the earth radius is evaluated with the radar LATITUDE in degrees fed to
 cos/sin (:120, utilities.py:126-139).
@@ -32,11 +32,14 @@ def wgs_to_rotated(lat_deg, lon_deg, sp_lat_deg, sp_lon_deg):
 
 class _PiecewiseLinear(object):
     """Linear interpolation with linear extrapolation beyond both ends
-    (atm_refraction.py:151-179)."""
+    (atm_refraction.py:151-179): scipy's interp1d inside the table, as the reference builds it --
+    LSODA's step control amplifies a last-bit difference of the right-hand side into float32-ulp
+    differences of the path, so the interpolant is the reference's own, not a re-derivation."""
 
     def __init__(self, x, y):
-        self.x = np.asarray(x, dtype=np.float64)
-        self.y = np.asarray(y, dtype=np.float64)
+        from scipy.interpolate import interp1d
+        self.f = interp1d(x, y)                 # (dtypes as given: a float32 column interpolates with float32 slopes)
+        self.x, self.y = self.f.x, self.f.y
 
     def __call__(self, v):
         x, y = self.x, self.y
@@ -44,11 +47,7 @@ class _PiecewiseLinear(object):
             return y[0] + (v - x[0]) * (y[1] - y[0]) / (x[1] - x[0])
         if v > x[-1]:
             return y[-1] + (v - x[-1]) * (y[-1] - y[-2]) / (x[-1] - x[-2])
-        # scipy.interpolate.interp1d (linear): searchsorted 'left', clip to [1, n-1]
-        hi = min(max(int(np.searchsorted(x, v, side='left')), 1), len(x) - 1)
-        lo = hi - 1
-        slope = (y[hi] - y[lo]) / (x[hi] - x[lo])
-        return slope * (v - x[lo]) + y[lo]
+        return float(self.f(v))
 
 
 def refractivity_column(N_data, zlevels, proj_info, resolution, coords_radar, radar_type='ground'):
@@ -63,7 +62,9 @@ def refractivity_column(N_data, zlevels, proj_info, resolution, coords_radar, ra
     h = zlevels[:, i, i]
     if radar_type == 'ground':
         h, n_prof = h[::-1], n_prof[::-1]
-    return np.asarray(h, dtype=np.float64), np.asarray(n_prof, dtype=np.float64)
+    # (dtypes as the reference leaves them: float32 model fields give a float32 column, and the slopes
+    # diff(n) / diff(h) of ode_path are then float32 quotients, atm_refraction.py:122-123)
+    return np.asarray(h), np.asarray(n_prof)
 
 
 def ode_path(range_vec, elevation_deg, coords_radar, h_col, n_col):

@@ -246,3 +246,54 @@ def test_graph_replay_equals_plain_launches(monkeypatch):
         assert np.array_equal(x, y, equal_nan=True)
     assert np.array_equal(results['1'][0], results['1'][2], equal_nan=True)
     assert not np.array_equal(results['1'][0], results['1'][3], equal_nan=True)
+
+
+def test_c4_volume_in_one_launch_sequence_90_azimuths_all_elevations_vs_oracle():
+    """BASELINE configs[3] as the multi-GPU bench runs it: the five elevations of the volume in ONE
+    launch sequence (rays of different elevations in one cpol_run_sweep call), 90 azimuths x 5
+    elevations x 49 sub-beams x 500 gates on the bench cube -- what two ranks of eight compute.
+    Two rays of every elevation against the oracle (rays through the melting layer included), and
+    the whole block bit-identical to the same rays computed sweep by sweep."""
+    from cosmo_pol_amd import RadarOperator
+    from test_gpu_parity import _pol_tolerances
+    over = bench.bench_config(False, 'c4')
+    hyds = list(bench.hydrometeors_of('c4'))
+    cube = synthetic.make_cube(hydrometeors=('R', 'S', 'G', 'I'), **synthetic.BENCH_GRID)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar', lanes=1)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    conf = ocfg.make_config(over)
+    oc = beam.ModelCube({n: cube['data'][n] for n in _cases.ORDER}, cube['zlevels'],
+                        cube['proj_info'], cube['resolution'], _cases.ORDER)
+    ol = {h: _cases.as_oracle_lut(l) for h, l in luts.items()}
+    az1 = np.arange(0.0, 360.0, 4.0)                                    # 90 azimuths
+    elevs = bench.C4_ELEVATIONS
+    az = np.tile(az1, len(elevs))
+    el = np.repeat(np.asarray(elevs, dtype=float), len(az1))
+    res = op.simulate_rays(az, el)
+    c = op._ctx.counters()
+    assert res['ZH'].shape == (450, 500) and res['n_sub'] == 49
+    assert c.n_subbeam_gates == 450 * 49 * 500 and c.n_table_items >= c.n_valid_items - 64
+    n_melt = n_valid = 0
+    for i, e in enumerate(elevs):
+        for r1 in ((7 + 19 * i) % 90, (52 + 11 * i) % 90):
+            r = i * 90 + r1
+            subs = beam.interpolate_radial(oc, conf, float(az[r]), float(e))
+            n_melt += sum(int(np.sum(np.asarray(sb.values['QmS_v']) > 0)) for sb in subs if 'QmS_v' in sb.values)
+            o = scatter.radar_observables(subs, ol, conf, return_sz=True)
+            szt = np.nan_to_num(o.sz_total.astype(np.float64))
+            scatter.cut_at_sensitivity([[o]], conf)
+            assert np.array_equal(res['mask'][r], o.mask)
+            assert np.array_equal(res['heights'][r], subs[24].heights_profile)
+            for k in FIELDS:
+                atol = 2e-4 if k == 'RVEL' else _pol_tolerances(k, o, szt, conf)
+                _cases.assert_close_nan(res[k][r], o.values[k], rtol=1e-5, atol=atol,
+                                        name='%s el %g az %g' % (k, e, az[r]))
+            n_valid += int(np.isfinite(o.values['ZH']).sum())
+    assert n_valid > 1500 and n_melt > 500, (n_valid, n_melt)
+    # sweep by sweep (what a single-GPU get_PPI does): the same bits
+    for i, e in enumerate(elevs):
+        one = op.simulate_rays(az1, np.full(len(az1), float(e)))
+        for k in FIELDS + ['mask', 'lats', 'lons', 'dist', 'heights']:
+            assert np.array_equal(one[k], res[k][i * 90:(i + 1) * 90], equal_nan=True), (k, e)
+    op.close()

@@ -155,12 +155,15 @@ def test_refraction_scheme_2_vs_oracle():
     o = scatter.radar_observables(subs, {h: _cases.as_oracle_lut(l) for h, l in luts.items()}, conf,
                                   return_sz=True)
     c = subs[int(len(subs) / 2)]
-    np.testing.assert_allclose(res['heights'][0], c.heights_profile, rtol=2e-7)
+    # the ray paths of product and oracle are the same bits (tests/test_refraction_cpu.py), so everything
+    # downstream holds the contract's 1e-5 (parity with the REFERENCE stays unpinned: its _ref_ODE raises
+    # inside scipy.odeint under NumPy >= 1.24, oracle/gen_golden.py)
+    assert np.array_equal(res['heights'][0], c.heights_profile) and np.array_equal(res['dist'][0], c.dist_profile)
+    assert np.array_equal(res['mask'][0], o.mask)
     szt = np.nan_to_num(o.sz_total.astype(np.float64))
-    for k in ['ZH', 'ZV', 'ZDR', 'RHOHV', 'KDP', 'ATT_H', 'ATT_V', 'PHIDP']:
-        # ray paths may differ by a float32 ulp between the two ODE codes: 1e-4 here
+    for k in ['ZH', 'ZV', 'ZDR', 'RHOHV', 'KDP', 'ATT_H', 'ATT_V', 'DELTA_HV', 'PHIDP']:
         atol = _pol_tolerances(k, o, szt, conf)
-        _cases.assert_close_nan(res[k][0], o.values[k], rtol=1e-4, atol=10 * np.asarray(atol), name=k)
+        _cases.assert_close_nan(res[k][0], o.values[k], rtol=1e-5, atol=atol, name=k)
     # and the paths really differ from the 4/3 model
     over43 = {k: dict(v) for k, v in over.items()}
     over43['refraction'] = {'scheme': 1}
@@ -233,4 +236,74 @@ def test_doppler_spectrum_one_moment_ice_subbeams_vs_oracle(tmp_path):
         _cases.assert_close_nan(res['RVEL'][r], o.values['RVEL'], rtol=1e-5, atol=2e-4, name='RVEL')
         assert np.nanmax(np.abs(res['RVEL'][r])) <= 1.5 + 1e-9
     assert n_ice > 20, 'no ice crystals in the test rays'
+    op.close()
+
+
+def test_c5_bench_size_swaths_sampled_rays_vs_oracle():
+    """BASELINE configs[4] at the bench's size: Ku 200 x 49 and Ka 200 x 25 rays over the 2-moment
+    bench cube (R,S,G,H,I, full-size tables) through get_GPM_swath -- what `bench.py --workload c5`
+    times.  Eight sampled rays per band against the oracle (gate bookkeeping bit-exact, observables
+    at 1e-5); no reference pin exists for config 5."""
+    import bench
+    from cosmo_pol_amd import RadarOperator
+    from test_gpu_parity import _pol_tolerances
+    hyd = ['R', 'S', 'G', 'H', 'I']
+    conf0 = bench.bench_config(False, 'c5')
+    cube = synthetic.make_cube(hydrometeors=tuple(hyd), two_moment=True, **synthetic.BENCH_GRID)
+    sets = {}
+
+    def provider(hl, freq, scheme):
+        if freq not in sets:
+            sets[freq] = synthetic.make_all_luts(hl, freq, scheme)
+        return {h: sets[freq][h] for h in hl}
+    op = RadarOperator(config=conf0, luts=provider, output_variables='only_radar')
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    order = _cases.ORDER_2MOM
+    ocube = beam.ModelCube({n: cube['data'][n] for n in order}, cube['zlevels'],
+                           cube['proj_info'], cube['resolution'], order)
+    for band, n_rays, cross in (('Ku', 49, 17.0), ('Ka', 25, 8.5)):
+        freq, res_m = BAND[band]
+        sw = gpm.synthetic_swath(n_scans=200, n_rays=n_rays, centre=(46.5, 7.5), cross_track_deg=cross,
+                                 scan_spacing_m=3000.0)
+        out = op.get_GPM_swath(sw, band)
+        N, M = sw['Latitude'].shape
+        assert (N, M) == (200, n_rays) and out.raw['ZH'].shape[0] == N * M
+        over = {k: dict(v) for k, v in conf0.items()}
+        over['radar'].update(frequency=freq, radial_resolution=res_m, sensitivity=12.0, type='GPM')
+        over['radar']['3dB_beamwidth'] = 0.5
+        conf = ocfg.make_config(over)
+        olut = {h: _cases.as_oracle_lut(sets[freq][h]) for h in hyd}
+        az, el, rng, sat = ogpm.swath_angles(sw)
+        raw = out.raw
+        # rays with the most precipitation along the swath centre and edges, spread over the scans
+        finite = np.isfinite(raw['ZH']).sum(axis=1).reshape(N, M)
+        picks = []
+        for i in (3, 40, 77, 101, 133, 160, 181, 197):
+            j = int(np.argmax(finite[i]))
+            picks.append((i, j))
+        n_valid_total = 0
+        for i, j in picks:
+            idx = i * M + j
+            subs, k0, n = ogpm.interpolate_swath_ray(ocube, conf, az[i, j], el[i, j], rng[i, j], sat[i])
+            assert n == out.n_kept[i, j]
+            cc = subs[int(len(subs) / 2)]
+            assert np.array_equal(raw['dist'][idx, :n], cc.dist_profile)
+            assert np.array_equal(raw['heights'][idx, :n], cc.heights_profile)
+            o = scatter.radar_observables(subs, olut, conf, return_sz=True, doppler=False)
+            szt = np.nan_to_num(o.sz_total.astype(np.float64))
+            scatter.cut_at_sensitivity([o], conf)
+            assert np.array_equal(raw['mask'][idx, :n], o.mask)
+            for k in ['ZH', 'ZV', 'ZDR', 'RHOHV', 'KDP', 'ATT_H', 'ATT_V', 'DELTA_HV', 'PHIDP']:
+                atol = _pol_tolerances(k, o, szt, conf)
+                _cases.assert_close_nan(raw[k][idx, :n], o.values[k], rtol=RTOL, atol=atol,
+                                        name='%s %s ray (%d, %d)' % (band, k, i, j))
+            n_valid_total += int(np.isfinite(o.values['ZH']).sum())
+        assert n_valid_total > 200, (band, n_valid_total)
+        # the lazily packed container: beams flipped to start at the ground
+        i, j = picks[0]
+        n = int(out.n_kept[i, j])
+        zh = out.data['ZH'][i, j]
+        keep = raw['mask'][i * M + j, :n] > -1
+        assert np.array_equal(zh[:keep.sum()], raw['ZH'][i * M + j, :n][keep][::-1].astype(np.float64), equal_nan=True)
+        assert np.all(zh[keep.sum():] == 0)
     op.close()
