@@ -1714,7 +1714,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                            fa, (double *)ctx->b_proj.p);
         fa.proj = (const double *)ctx->b_proj.p;
     }
-    if (n_rays <= 128 && ng > CPOL_FINAL_THREADS)
+    // (one workgroup per ray: with no more rays than CUs the kernel lasts as long as ONE workgroup -- 512
+    // threads halve its gate loop; the share of one of 8 GPUs of a 5 x 360-ray volume is 225 rays)
+    if (n_rays <= 256 && ng > CPOL_FINAL_THREADS)
         hipLaunchKernelGGL((k_final<2 * CPOL_FINAL_THREADS>), dim3(n_rays), dim3(2 * CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra);
     else
         hipLaunchKernelGGL((k_final<CPOL_FINAL_THREADS>), dim3(n_rays), dim3(CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra);
