@@ -308,11 +308,30 @@ int  cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro);
  * (hydrometeors.py:128-147, lut.py:309-344, doppler_scatter.py:246-251) produce -- are a per-item
  * scale times a function of (LUT slice, lambda) only.  The integrating kernels evaluate that
  * function once per (slice, 1/8-octave panel of lambda, Chebyshev node) and store degree-10
- * polynomials (< 5e-15 relative); a sweep then gathers 12 x 11 coefficients per item instead of
- * integrating 1024 diameter bins.  Items whose lambda lies outside the tabulated range, and the
- * melting species (two parameters), are integrated as before.  Environment CPOL_ITAB=0 (read
- * at every build) switches the tables off.  Depends on every staged table: call after the last
- * cpol_stage_* (any later staging call invalidates the tables; they are rebuilt on demand). */
+ * polynomials ("1-D blocks": 11 rows of 16 float64 per (slice, panel)); a sweep then gathers
+ * 12 x 11 coefficients per item instead of integrating 1024 diameter bins.
+ * The melting species (wet fraction fw and rain-partner slope lambda_r) get "2-D blocks": per (slice,
+ * 1/4-octave panel of lambda_r) the polynomial of total degree 10 in (fw inside the slice's wet-
+ * fraction bin, position inside the panel), 66 rows of 16 float64; a sweep evaluates 14 functions
+ * (12 columns + 2 Doppler sums) per item.
+ * ACCURACY GATE: every block carries one more item at an off-node point, integrated by the same
+ * kernel and compared with the polynomial function by function on the scale of the function over
+ * the block.  1-D tables keep the longest run of lambda panels whose blocks all stay below 1e-10
+ * (in practice all but the last panel, where exp(-lambda D^nu) of the bins behind the first goes
+ * subnormal); a 1-D table with less than half of its panels left, and a 2-D table with any block
+ * above 1e-10, is dropped.  Items outside the accepted ranges are integrated bin by bin as in round
+ * 1.  cpol_debug_read("itab_check"): per slot the worst accepted deviation (negative: table dropped;
+ * 0: none), then where it was found, then the number of (block, function) pairs above the limit;
+ * "itab_detail<slot>": per lambda panel and per function; "itab_times": device ms of build / gate.
+ * Environment (read at every build): CPOL_ITAB=0 no tables at all, CPOL_ITAB_MELT=0 none for the
+ * melting species, CPOL_ITAB_MAX_DEV=<x> another limit than 1e-10.  (Per sweep: CPOL_SUBSUM=0,
+ * CPOL_LOOKUP_TILE=0, see INTEGRATION.md.)
+ * COST: a few ms of kernels per gamma / ice slot, ~90 ms per melting slot on full-size tables
+ * (46 x 100 slices); TRANSIENT device memory of the build = n_e * n_t * n_panels * 12 (1-D) or
+ * * 122 (2-D) synthetic items x ~164 B: 1 GB for a gamma slot, ~3.5 GB for a melting slot of that
+ * size; RESIDENT tables 0.3 - 0.5 GB per 1-D slot, 1.5 GB per melting slot.
+ * Depends on every staged table: call after the last cpol_stage_* (any later staging call
+ * invalidates the tables; they are rebuilt on demand). */
 int  cpol_prepare(cpol_ctx *ctx);
 
 /* float32 functions of the gate temperature, TABULATED BY THE HOST over every float32 value
