@@ -1452,12 +1452,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             la.vn = doppler ? (double *)ctx->b_vn.p : nullptr;
             la.n_sbg = n_sbg;
             la.skip_res_1d = subsum ? 1 : 0;
-            bool launch = !subsum;              // with k_subbeam_sum: only for 2-D tables, vn and the ice intercept
+            bool launch = !subsum;              // with k_subbeam_sum: only for 2-D tables and the ice intercept
             for (int j = 0; j < n_hyd && !launch; ++j) {
                 const ItabDev &tj = ctx->its.t[j];
                 if (!tj.tab) continue;
-                launch = tj.two_d || (la.vn && tj.writes_vn) ||
-                         (la.par_w && ctx->hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD);
+                launch = tj.two_d || (la.par_w && ctx->hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD);
             }
             bool two_d = false;
             for (int j = 0; j < n_hyd; ++j) two_d = two_d || (ctx->its.t[j].tab && ctx->its.t[j].two_d);
@@ -1591,6 +1590,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sa2.vmask = (const unsigned char *)ctx->b_vmask.p;
         sa2.rec = (const double2 *)ctx->b_rec.p;
         sa2.res = (const double *)ctx->b_res.p;
+        sa2.vn = doppler ? (double *)ctx->b_vn.p : nullptr;
         sa2.sub_w = (const double *)ctx->v_subw;
         sa2.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
         sa2.sz_integ = (float *)ctx->b_szinteg.p;

@@ -211,6 +211,9 @@ struct SubsumArgs {
     const unsigned char *vmask; // [n_sbg] bit j: hydrometeor j present
     const double2 *rec;         // [n_hydro][n_sbg] {panel position (-1: not on the table), scale}
     const double *res;          // [n_hydro][n_sbg][12]
+    double *vn;                 // [n_hydro][n_sbg][2] or NULL: the Doppler sums of the 1-D table items of a slot whose
+                                // table carries them (1-moment ice, Doppler scheme 2, numeric integrate_V) are
+                                // evaluated here too (functions 12, 13 of the block: one more 16-B load per row)
     const double *sub_w;        // [n_sub]
     const double *wgate;        // [n_sbg] or NULL (scheme 'ml')
     float *sz_integ;            // [n_rg][n_hydro][12]
@@ -220,7 +223,18 @@ struct SubsumArgs {
 #ifndef CPOL_SUBSUM_THREADS
 #define CPOL_SUBSUM_THREADS 64       // (measured on the C4 sweep / its 45-ray share: 64 -> 0.97 / 0.190 ms, 128 -> 1.01 / 0.192, 256 -> 1.05 / 0.205)
 #endif
-__global__ __launch_bounds__(CPOL_SUBSUM_THREADS) void k_subbeam_sum(HydroSet hs, ItabSet its, SubsumArgs a)
+#ifndef CPOL_SUBSUM_WPE
+#define CPOL_SUBSUM_WPE 0            // experiment knob: minimum waves per SIMD asked of the register allocator (0: its own choice, 4)
+#endif
+#ifndef CPOL_SUBSUM_WPE_MAX
+#define CPOL_SUBSUM_WPE_MAX 8
+#endif
+#if CPOL_SUBSUM_WPE
+#define CPOL_SUBSUM_ATTR __attribute__((amdgpu_waves_per_eu(CPOL_SUBSUM_WPE, CPOL_SUBSUM_WPE_MAX)))
+#else
+#define CPOL_SUBSUM_ATTR
+#endif
+__global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbeam_sum(HydroSet hs, ItabSet its, SubsumArgs a)
 {
     constexpr int NB = CPOL_ITAB_NC * CPOL_ITAB_NFP;
     const long n_rg = (long)a.n_rays * a.n_gates;
@@ -234,6 +248,7 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) void k_subbeam_sum(HydroSet hs
     const bool tab1 = t.tab && !t.two_d;                                 // uniform
     const int key_base = hs.h[j].key_base;
     const double2 *R = a.rec + (long)j * n_sbg;
+    const bool want_vn = tab1 && a.vn && t.writes_vn;                    // uniform
     double wtot = 0.0;
     if (a.wgate)
         for (int s = 0; s < a.n_sub; ++s) wtot += a.wgate[sbg0 + (long)s * a.n_gates];
@@ -250,8 +265,19 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) void k_subbeam_sum(HydroSet hs
         if (rc.x >= 0.0) {
             const int pn = min((int)rc.x, t.n_pan - 1);
             const double u = 2.0 * (rc.x - (double)pn) - 1.0;
-            itab1_columns(reinterpret_cast<const double2 *>(t.tab + ((long)(key - key_base) * t.n_pan + pn) * NB),
-                          u, rc.y, v);
+            const double2 *blk = reinterpret_cast<const double2 *>(t.tab + ((long)(key - key_base) * t.n_pan + pn) * NB);
+            itab1_columns(blk, u, rc.y, v);
+            if (want_vn) {
+                constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
+                double2 w = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
+#pragma unroll
+                for (int q = NC - 2; q >= 0; --q) {
+                    const double2 cq = blk[q * (NFP / 2) + CPOL_N_SZ / 2];
+                    w.x = fma(w.x, u, cq.x);
+                    w.y = fma(w.y, u, cq.y);
+                }
+                *reinterpret_cast<double2 *>(a.vn + ((long)j * n_sbg + sbg) * 2) = make_double2(w.x * rc.y, w.y * rc.y);
+            }
         } else {
             const double2 *r = reinterpret_cast<const double2 *>(a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ);
 #pragma unroll
@@ -278,6 +304,9 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) void k_subbeam_sum(HydroSet hs
 #endif
 #ifndef CPOL_FINAL_BATCH
 #define CPOL_FINAL_BATCH 2
+#endif
+#ifndef CPOL_FINAL_SBATCH
+#define CPOL_FINAL_SBATCH 7          // sub-beams whose RVEL terms / masks are requested together (experiment knob)
 #endif
 __device__ __forceinline__ void final_gate(const FinalArgs &a, int ray, int gate, float &k2_out,
                                            float &fh_out, float &fv_out)
@@ -396,15 +425,27 @@ __device__ __forceinline__ void final_gate(const FinalArgs &a, int ray, int gate
     // ---- radial velocity, Doppler scheme 1 (doppler_scatter.py:276-281, 313-333, 418-420) ----
     if (a.RVEL && !CPOL_SKIP_RVEL) {
         double rv = __builtin_nan(""), tw = 0.0;
-        for (int s = 0; s < a.n_sub; ++s) {
-            const long sbg = sbg0 + (long)s * a.n_gates;
-            const double proj = a.proj ? a.proj[sbg] : subbeam_proj(a, ray, s, gate, sbg, n_sbg);
-            const double w = a.wgate ? a.wgate[sbg] : a.sub_w[s];
-            if (proj == proj) tw += w;
-            double x = (rv == rv) ? rv : 0.0;
-            double y = proj * w;
-            if (!(y == y)) y = 0.0;
-            rv = x + y;
+        // sub-beams in groups of CPOL_FINAL_SBATCH: the terms (and per-gate weights) of a group are
+        // requested together, the float64 accumulation keeps the reference's order
+        for (int s0 = 0; s0 < a.n_sub; s0 += CPOL_FINAL_SBATCH) {
+            double pj[CPOL_FINAL_SBATCH], wj[CPOL_FINAL_SBATCH];
+#pragma unroll
+            for (int q = 0; q < CPOL_FINAL_SBATCH; ++q) {
+                const int s = min(s0 + q, a.n_sub - 1);
+                const long sbg = sbg0 + (long)s * a.n_gates;
+                pj[q] = a.proj ? a.proj[sbg] : subbeam_proj(a, ray, s, gate, sbg, n_sbg);
+                wj[q] = a.wgate ? a.wgate[sbg] : a.sub_w[s];
+            }
+#pragma unroll
+            for (int q = 0; q < CPOL_FINAL_SBATCH; ++q) {
+                if (s0 + q >= a.n_sub) break;
+                const double proj = pj[q], w = wj[q];
+                if (proj == proj) tw += w;
+                double x = (rv == rv) ? rv : 0.0;
+                double y = proj * w;
+                if (!(y == y)) y = 0.0;
+                rv = x + y;
+            }
         }
         rv = rv / tw;
         if (a.nyquist) {
@@ -419,7 +460,15 @@ __device__ __forceinline__ void final_gate(const FinalArgs &a, int ray, int gate
 
     // ---- radial mask (doppler_scatter.py:472-477) ----
     double msum = 0.0;
-    for (int s = 0; s < a.n_sub; ++s) msum += (double)a.sub_mask[sbg0 + (long)s * a.n_gates];
+    for (int s0 = 0; s0 < a.n_sub; s0 += CPOL_FINAL_SBATCH) {
+        signed char mj[CPOL_FINAL_SBATCH];
+#pragma unroll
+        for (int q = 0; q < CPOL_FINAL_SBATCH; ++q)
+            mj[q] = a.sub_mask[sbg0 + (long)min(s0 + q, a.n_sub - 1) * a.n_gates];
+#pragma unroll
+        for (int q = 0; q < CPOL_FINAL_SBATCH; ++q)
+            if (s0 + q < a.n_sub) msum += (double)mj[q];
+    }
     msum /= (double)a.n_sub;
     if (msum > -1.0 && msum <= 0.0) msum = 0.0;
     if (a.mask) a.mask[rg] = msum;

@@ -1890,9 +1890,9 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
     for (int j = 0; j < hs.n_hydro; ++j) {
         const ItabDev &t = its.t[j];
         if (!t.tab) continue;                                           // uniform
-        // (k_subbeam_sum evaluates the columns of the 1-D species: nothing to do here for a species
-        // that needs neither its Doppler sums nor the ice intercept)
-        if (a.skip_res_1d && !t.two_d && !(a.vn && t.writes_vn) &&
+        // (k_subbeam_sum evaluates the columns AND the Doppler sums of the 1-D species: nothing to do
+        // here for a species that does not need the ice intercept of the spectrum kernels)
+        if (a.skip_res_1d && !t.two_d &&
             !(a.par_w && hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD)) continue;
         const int key = ((present >> j) & 1u) ? a.key[(long)j * n + i] : -1;
         const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
@@ -1948,7 +1948,7 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
             t.tab + ((long)(key - hs.h[j].key_base) * t.n_pan + pn) * NB);
         // gamma: N0 x exp(-lambda d0) x G(lambda);  ice: QM x R(lambda)  (the scale comes with the record)
         const double scale = rc.y;
-        const bool want_vn = a.vn && t.writes_vn;                       // uniform
+        const bool want_vn = a.vn && t.writes_vn && !a.skip_res_1d;     // uniform (k_subbeam_sum writes them otherwise)
         const bool want_n0 = ice && a.par_w;                            // uniform
         if (!a.skip_res_1d) {
             double2 v[CPOL_N_SZ / 2];

@@ -180,13 +180,15 @@ class RadarScan(object):
         return self.fields[variable]['data'][i0:i1]
 
 
-def _table_identity(key, h, slot, table):
-    """64-bit identity (never 0) of one staged hydrometeor slot: configuration key of the table
-    set, species, slot and the address of the (cached, immutable) table array."""
-    import hashlib
-    dg = hashlib.blake2b(repr((key, h, slot, table.__array_interface__['data'][0], table.shape)).encode(),
-                         digest_size=8).digest()
-    return int.from_bytes(dg, 'little') or 1
+_table_serial = [0]
+
+
+def _table_identity():
+    """64-bit identity (never 0) of one staged hydrometeor slot for the library's table caches
+    (cpol_hydro_desc.table_id): a process-wide serial stored with the operator's cache entry of the table
+    set -- never derived from a memory address, which a later array of other content could re-use."""
+    _table_serial[0] += 1
+    return (os.getpid() << 32) | _table_serial[0]
 
 
 class RadarOperator(object):
@@ -355,7 +357,7 @@ class RadarOperator(object):
             d, table, pre, dnu, aux = hyd.build_hydro(h, scheme, lut[h], var_index)
             # identity of this slot's content for the library's integral-table cache: the table
             # set is kept alive (and unchanged) by _lut_cache below
-            d.table_id = _table_identity(key, h, slot, table) if len(cache) < 4 else 0
+            d.table_id = _table_identity() if len(cache) < 4 else 0
             self._ctx.stage_hydro(slot, d, table, pre, dnu, aux)
             dw = None
             if conf['doppler']['scheme'] == 2:
