@@ -187,17 +187,19 @@ __device__ __forceinline__ double cp_log(double x)
     if (m < 0.7071067811865476) { m *= 2.0; e -= 1; }
     const double s = (m - 1.0) * cp_rcp(m + 1.0);
     const double z = s * s;
+    // (addends through the scalar operand, as in cp_exp: as VGPR literals the compiler hoists them out
+    // of k_classify's hydrometeor loop and holds 20 registers across it -- that kernel has 128)
     double p = 1.0 / 21.0;
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
-    p = fma(p, z, 1.0);
+    p = fma_sc(p, z, 1.0 / 19.0);
+    p = fma_sc(p, z, 1.0 / 17.0);
+    p = fma_sc(p, z, 1.0 / 15.0);
+    p = fma_sc(p, z, 1.0 / 13.0);
+    p = fma_sc(p, z, 1.0 / 11.0);
+    p = fma_sc(p, z, 1.0 / 9.0);
+    p = fma_sc(p, z, 1.0 / 7.0);
+    p = fma_sc(p, z, 1.0 / 5.0);
+    p = fma_sc(p, z, 1.0 / 3.0);
+    p = fma_sc(p, z, 1.0);
     const double en = (double)e;
     return fma(en, 0.6931471803691238, fma(en, 1.9082149292705877e-10, 2.0 * s * p));
 }
@@ -256,7 +258,11 @@ __global__ void k_debug_math(int op, const double *__restrict__ x, double *__res
 
 // x^y for x > 0 from the short log / exp above: ~55 VALU instructions instead of the 215 of
 // the OCML pow, relative error < 1e-14 for |y log x| < 10 (PSD slopes, fall-speed moments)
+#ifdef CPOL_POW_NOINLINE
+__device__ __attribute__((noinline)) double cp_pow(double x, double y) { return cp_exp(y * cp_log(x)); }
+#else
 __device__ __forceinline__ double cp_pow(double x, double y) { return cp_exp(y * cp_log(x)); }
+#endif
 
 // float32 power via float64 (rounds to the correctly rounded float32 result in
 // all but ~1e-8 of the cases; numpy's float32 power calls libm powf)
