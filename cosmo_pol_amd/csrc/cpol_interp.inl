@@ -303,6 +303,9 @@ struct InterpArgs {
     const double *site;         // per-ray site or NULL
 };
 
+#ifndef CPOL_INTERP_FAST_SUB
+#define CPOL_INTERP_FAST_SUB 1       // 0: every sub-beam through atan2 -> degrees -> sincos like the central one
+#endif
 __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
 {
     const int gate = blockIdx.y * blockDim.x + threadIdx.x;
@@ -377,19 +380,47 @@ __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
         sigma = sigma0 + dsig;
     }
     const double tmp = sin_u1 * sin_s - cos_u1 * cos_s * cos_a1;
-    const double lat2 = atan2(sin_u1 * cos_s + cos_u1 * sin_s * cos_a1,
-                              (1.0 - f) * sqrt(sin_alpha * sin_alpha + tmp * tmp));
-    const double lam = atan2(sin_s * sin_a1, cos_u1 * cos_s - sin_u1 * sin_s * cos_a1);
-    const double L = lam - (1.0 - C) * f * sin_alpha *
+    const double lat_num = sin_u1 * cos_s + cos_u1 * sin_s * cos_a1;
+    const double lat_den = (1.0 - f) * sqrt(sin_alpha * sin_alpha + tmp * tmp);
+    const double lam_y = sin_s * sin_a1, lam_x = cos_u1 * cos_s - sin_u1 * sin_s * cos_a1;
+    // L = lam - dlon: the ellipsoidal correction of the longitude difference (|dlon| < f sigma ~ 1e-4 rad)
+    const double dlon = (1.0 - C) * f * sin_alpha *
         (sigma + C * sin_s * (cos2sm + C * cos_s * (-1.0 + 2.0 * cos2sm * cos2sm)));
-    const double lat_deg = lat2 / CPOL_DEG;
-    const double lon_deg = lon1 + L / CPOL_DEG;
+    double lat_deg = 0.0, lon_deg = 0.0;
+    double sl, cl, slon, clon;                    // sin / cos of the geographic latitude and longitude
+#if CPOL_INTERP_FAST_SUB
+    if (sub != a.central_sub) {
+        // Sub-beams other than the central one (wave-uniform: a wavefront walks ONE sub-beam) need the
+        // geographic coordinates only as sin / cos for the rotated-pole transform: taken straight from the
+        // arguments of the two atan2 (sin = y / hypot, cos = x / hypot) and the addition theorem, instead of
+        // atan2 -> degrees -> radians -> sincos.  Same values to a few ulp (float64) before the float32 cast
+        // of the rotated coordinates, i.e. the same float32 coordinate in all but ~1e-8 of the cases, like
+        // the device's Taylor sums above; 4 OCML calls of ~100 instructions fewer per sub-beam gate.
+        const double hl = 1.0 / sqrt(lat_num * lat_num + lat_den * lat_den);
+        sl = lat_num * hl; cl = lat_den * hl;
+        const double hm = 1.0 / sqrt(lam_y * lam_y + lam_x * lam_x);
+        const double sm = lam_y * hm, cm = lam_x * hm;                      // sin / cos of lam
+        const double d2 = dlon * dlon;
+        const double sd = dlon * fma(d2, -1.0 / 6.0, 1.0);                   // |dlon| < 2e-4: next terms < 1e-21
+        const double cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+        const double sL = sm * cd - cm * sd, cL = cm * cd + sm * sd;        // lam - dlon
+        double s1, c1;
+        sincos(lon1 * CPOL_DEG, &s1, &c1);
+        slon = s1 * cL + c1 * sL; clon = c1 * cL - s1 * sL;
+    } else
+#endif
+    {
+        const double lat2 = atan2(lat_num, lat_den);
+        const double lam = atan2(lam_y, lam_x);
+        const double L = lam - dlon;
+        lat_deg = lat2 / CPOL_DEG;
+        lon_deg = lon1 + L / CPOL_DEG;
+        const double latr = lat_deg * CPOL_DEG, lonr = lon_deg * CPOL_DEG;
+        sincos(latr, &sl, &cl);
+        sincos(lonr, &slon, &clon);
+    }
 
     // ---- rotated-pole transform (float64) -> float32 grid coordinates ----
-    const double latr = lat_deg * CPOL_DEG, lonr = lon_deg * CPOL_DEG;
-    double sl, cl, slon, clon;
-    sincos(latr, &sl, &cl);
-    sincos(lonr, &slon, &clon);
     const double x = clon * cl, y = slon * cl, z = sl;
     const double x_new = m.ctcp * x + m.ctsp * y + m.st * z;
     const double y_new = m.nsp * x + m.cp * y;
