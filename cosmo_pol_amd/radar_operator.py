@@ -13,6 +13,7 @@ callable (hydrometeors, frequency, scheme) -> {h: table}),
 """
 import copy
 import ctypes as C
+import math
 import os
 import threading
 
@@ -29,6 +30,7 @@ from .lut import load_all_lut
 RADAR_FIELDS = ['ZH', 'ZDR', 'ZV', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V']
 DOPPLER_FIELDS = ['RVEL', 'DSPECTRUM']
 _DB_FIELDS = ('ZDR', 'ZV', 'ZH')
+_ITEMSIZE = {np.float32: 4, np.float64: 8}
 
 
 class ModelVar(object):
@@ -637,16 +639,16 @@ class RadarOperator(object):
             # device-to-host copy, queued behind them, moves it.  The block belongs to the arrays: it
             # returns to the pool when the last of them is dropped, whatever happens to the lanes or
             # the operator in between.
-            sizes = [-(-int(np.prod(sh)) * np.dtype(dt).itemsize // 64) * 64 for _, dt, sh in spec]
+            counts = [math.prod(sh) for _, _, sh in spec]
+            sizes = [-(-n_el * _ITEMSIZE[dt] // 64) * 64 for n_el, (_, dt, _) in zip(counts, spec)]
             slab, holder = self._pool.take(sum(sizes), writer=self._lane(lane))
+            base = slab.ctypes.data
             off = 0
-            for (k, dt, sh), nb in zip(spec, sizes):
-                n_el = int(np.prod(sh))
-                res[k] = slab[off:off + n_el * np.dtype(dt).itemsize].view(dt).reshape(sh)
+            for (k, dt, sh), n_el, nb in zip(spec, counts, sizes):
+                res[k] = slab[off:off + n_el * _ITEMSIZE[dt]].view(dt).reshape(sh)
+                setattr(o, k, base + off)           # (= res[k].ctypes.data, without an interface object per array)
                 off += nb
             del slab
-            for k, a in res.items():
-                setattr(o, k, a.ctypes.data)
         ctx = self._lane(lane)
         ctx.run_sweep(p, t, o)
         del keep
