@@ -542,10 +542,16 @@ struct ScanArgs {
     int unit_shift[CPOL_MAX_HYDRO];   // log2(items per work unit): 6, or 7 for the 2-items-per-lane flavour
 };
 
+// log2(items per work unit) of bucket k.  (Constant indices into the by-value argument arrays: a
+// run-time index makes every access a dependent scalar load from the kernarg segment -- with the
+// 32 x 2 unrolled call sites of k_bucket_scan that was 35 us of serialised s_load / s_waitcnt for a
+// 15 k-bucket scan that otherwise takes 4.)
 __device__ __forceinline__ int unit_shift_of(const ScanArgs &a, int k)
 {
     int sh = a.unit_shift[0];
-    for (int q = 1; q < a.n_hydro; ++q) if (k >= a.key_base[q]) sh = a.unit_shift[q];
+#pragma unroll
+    for (int q = 1; q < CPOL_MAX_HYDRO; ++q)
+        if (q < a.n_hydro && k >= a.key_base[q]) sh = a.unit_shift[q];
     return sh;
 }
 

@@ -295,7 +295,10 @@ class RadarOperator(object):
 
     def close(self):
         if self._ctx is not None:
-            self._drop_lanes()
+            try:
+                self._drop_lanes()
+            except IndexError as e:           # a queued sweep left the model domain and nobody waited for it
+                print('RadarOperator.close: %s' % e)
             self._ctx.close()
             self._ctx = None
             self._pool.close()                # (blocks of results still held are freed with their last view)
