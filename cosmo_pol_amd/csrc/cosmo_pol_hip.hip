@@ -1461,9 +1461,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             bool two_d = false;
             for (int j = 0; j < n_hyd; ++j) two_d = two_d || (ctx->its.t[j].tab && ctx->its.t[j].two_d);
             static const int tile_env = getenv("CPOL_LOOKUP_TILE") ? atoi(getenv("CPOL_LOOKUP_TILE")) : 1;
-            la.tile = (two_d && tile_env && n_rays >= 16) ? 1 : 0;
+            constexpr int TILE_GATES = 1 << CPOL_TILE_GATES_LOG2, TILE_RAYS = 64 >> CPOL_TILE_GATES_LOG2;
+            la.tile = (two_d && tile_env && n_rays >= TILE_RAYS) ? 1 : 0;
             la.n_rays = n_rays; la.n_sub = n_sub; la.n_gates = ng;
-            const long n_thr = la.tile ? (long)cdiv(n_rays, 16) * n_sub * cdiv(ng, 4) * 64 : n_sbg;
+            const long n_thr = la.tile ? (long)cdiv(n_rays, TILE_RAYS) * n_sub * cdiv(ng, TILE_GATES) * 64 : n_sbg;
             if (launch)
             hipLaunchKernelGGL(k_psd_lookup, dim3(cdiv(n_thr, CPOL_LOOKUP_THREADS)), dim3(CPOL_LOOKUP_THREADS), 0, st, ctx->hs, ctx->its, la);
         }

@@ -1771,6 +1771,9 @@ __global__ void k_itab_check2(ItabFit2Args f)
 #ifndef CPOL_LOOKUP_THREADS
 #define CPOL_LOOKUP_THREADS 256
 #endif
+#ifndef CPOL_TILE_GATES_LOG2
+#define CPOL_TILE_GATES_LOG2 2       // melting species: a wavefront = 16 neighbouring rays x 4 gates of one sub-beam index
+#endif
 // one thread per sub-beam gate: the items that k_classify placed on an integral table
 struct LookupArgs {
     const int *key;             // [n_hydro][n_sbg] (valid where vmask says so)
@@ -1890,9 +1893,10 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
     bool in = i0 < a.n_sbg;
     if (a.tile) {
         const long W = i0 >> 6;                                         // tile = wavefront
-        const int n_gt = (a.n_gates + 3) >> 2;
+        constexpr int TG = CPOL_TILE_GATES_LOG2, GATES = 1 << TG, RAYS = 64 >> TG;    // tile = RAYS rays x GATES gates
+        const int n_gt = (a.n_gates + GATES - 1) >> TG;
         const int gt = (int)(W % n_gt), sub = (int)((W / n_gt) % a.n_sub);
-        const int ray = (int)(W / ((long)n_gt * a.n_sub)) * 16 + (lane >> 2), gate = gt * 4 + (lane & 3);
+        const int ray = (int)(W / ((long)n_gt * a.n_sub)) * RAYS + (lane >> TG), gate = gt * GATES + (lane & (GATES - 1));
         in = ray < a.n_rays && gate < a.n_gates;
         i0 = ((long)ray * a.n_sub + sub) * a.n_gates + gate;
     }

@@ -216,6 +216,8 @@ class RadarOperator(object):
         self.distributed = bool(distributed)   # shard the rays of every sweep over the ranks
         self.pyart_output = bool(pyart_output) # get_PPI / get_RHI return a pyart.core.Radar (needs Py-ART)
         self.reuse_device_tables = True        # keep per-ray tables in HBM between equal sweeps
+        self.volume_in_one_sequence = True     # get_PPI / get_RHI: all sweeps of a scan in one launch sequence
+                                               # (False: sweep by sweep, spread over the lanes)
         self.lut_dir = lut_dir
         if lut_dir:
             from . import tablecache
@@ -698,6 +700,22 @@ class RadarOperator(object):
         flight together, one host thread per lane (the library calls release the GIL)."""
         if self.distributed:
             return [self._package(r, az, el) for r, (az, el) in zip(self._simulate_volume_sharded(sweeps), sweeps)]
+        if self.volume_in_one_sequence and len(sweeps) > 1:
+            # all sweeps of the scan as ONE launch sequence (rays of different elevations / azimuths in one
+            # cpol_run_sweep call): one submission, 7-12 kernel launches and one device-to-host copy per
+            # volume instead of per sweep; the per-sweep results are row slices of the volume's arrays --
+            # bit-identical to the sweeps run one by one (tests/test_gpu_fullsize.py)
+            az = np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1) for a, _ in sweeps])
+            el = np.concatenate([np.asarray(e, dtype=np.float64).reshape(-1) for _, e in sweeps])
+            res = self.simulate_rays(az, el)
+            out, lo = [], 0
+            for a, e in sweeps:
+                hi = lo + len(np.asarray(a).reshape(-1))
+                part = {k: (v[:, lo:hi] if k in ('model_vars',) else v[lo:hi]) if isinstance(v, np.ndarray) else v
+                        for k, v in res.items()}
+                out.append(self._package(part, a, e))
+                lo = hi
+            return out
         n_par = min(self.lanes, len(sweeps))
         if n_par <= 1:
             return [self._package(self._simulate_sweep(az, el), az, el) for az, el in sweeps]

@@ -284,3 +284,16 @@ def test_one_hip_runtime_whatever_the_import_order():
              'N.load_library()\n'
              'print(len(N.hip_runtimes_mapped()))\n' % ROOT)
     assert subprocess.check_output([sys.executable, '-c', code2]).split() == [b'1']
+
+
+def test_every_product_module_imports():
+    """A syntax / import error in a product module must show up without a GPU."""
+    import importlib
+    import pkgutil
+    import cosmo_pol_amd
+    for m in pkgutil.iter_modules(cosmo_pol_amd.__path__):
+        if m.name == 'pyart_wrapper':
+            continue                        # needs Py-ART (guarded at its call sites)
+        importlib.import_module('cosmo_pol_amd.' + m.name)
+    import bench  # noqa: F401
+    import __graft_entry__  # noqa: F401

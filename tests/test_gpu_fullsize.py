@@ -182,8 +182,9 @@ def test_rhi_and_vprof_api(full):
 
 
 def test_lanes_volume_scan_equals_sequential():
-    """Sweeps spread over forked contexts (cpol_fork, one host thread per lane) give
-    bit-identical fields to the same sweeps run one after the other."""
+    """A volume scan three ways -- its sweeps one after the other, spread over forked contexts
+    (cpol_fork, one host thread per lane), and as ONE launch sequence (the default of get_PPI: rays
+    of all elevations in one cpol_run_sweep call) -- gives bit-identical fields."""
     from cosmo_pol_amd import RadarOperator, synthetic
     import bench
     conf = bench.bench_config(True)
@@ -193,11 +194,12 @@ def test_lanes_volume_scan_equals_sequential():
     luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
     elevs = [0.5, 1.5, 3.0, 5.0, 8.0]
     scans = []
-    for lanes in (1, 3):
+    for lanes, one_sequence in ((1, False), (3, False), (3, True)):
         op = RadarOperator(config=conf, luts=luts, output_variables='all', lanes=lanes)
+        op.volume_in_one_sequence = one_sequence
         op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
         scans.append(op.get_PPI(elevs, az_step=4.0))
-        if lanes == 3:
+        if lanes == 3 and not one_sequence:
             assert len(op._lane_ctx) == 2
             # staging on a context with live lanes is refused by the library; the operator
             # drops its lanes first
@@ -205,13 +207,18 @@ def test_lanes_volume_scan_equals_sequential():
                 op._ctx.set_num_hydro(len(hyds))
             op.set_lut()
             assert op._lane_ctx == []
+        if one_sequence:
+            assert op._lane_ctx == []                    # one call on the root context
         op.close()
-    a, b = scans
-    for i in range(len(elevs)):
-        for name in a.fields:
-            x, y = np.ma.asarray(a.get_field(i, name)), np.ma.asarray(b.get_field(i, name))
-            assert np.array_equal(np.ma.getmaskarray(x), np.ma.getmaskarray(y)), name
-            assert np.array_equal(x.filled(0), y.filled(0)), name
+    a = scans[0]
+    for b in scans[1:]:
+        for i in range(len(elevs)):
+            for name in a.fields:
+                x, y = np.ma.asarray(a.get_field(i, name)), np.ma.asarray(b.get_field(i, name))
+                assert np.array_equal(np.ma.getmaskarray(x), np.ma.getmaskarray(y)), name
+                assert np.array_equal(x.filled(0), y.filled(0)), name
+    # results stay valid after the operators are closed (they live in pooled pinned blocks of their own)
+    assert np.isfinite(scans[2].raw[2]['fields']['ZH']).sum() > 100
 
 
 def test_graph_replay_equals_plain_launches(monkeypatch):
