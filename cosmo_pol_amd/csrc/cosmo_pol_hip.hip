@@ -1596,7 +1596,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sa2.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
         sa2.sz_integ = (float *)ctx->b_szinteg.p;
         sa2.n_rays = n_rays; sa2.n_gates = ng; sa2.n_sub = n_sub; sa2.n_hydro = n_hyd;
-        hipLaunchKernelGGL(k_subbeam_sum, dim3(cdiv(n_rg, CPOL_SUBSUM_THREADS), n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
+        hipLaunchKernelGGL(k_subbeam_sum, dim3(cdiv(n_rg, CPOL_SUBSUM_THREADS), n_hyd * CPOL_SUBSUM_SPLIT), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
     }
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
 

@@ -234,12 +234,25 @@ struct SubsumArgs {
 #else
 #define CPOL_SUBSUM_ATTR
 #endif
+#ifndef CPOL_SUBSUM_SPLIT
+#define CPOL_SUBSUM_SPLIT 1          // threads per (gate, hydrometeor): each accumulates 12 / SPLIT of the columns (1, 2 or 3)
+#endif
+// Column split (experiment knob, blockIdx.y = j * SPLIT + part): two or three threads per (gate,
+// hydrometeor), 6 or 4 columns each, need half / a third of the registers, i.e. more wavefronts in flight
+// over the same gathers (the validity byte, key and record are read once per part).  Measured on the C4
+// volume / the 225-ray share of one of 8 GPUs (k_subbeam_sum alone): SPLIT 1: 3.58 / 0.55 ms; 2: 4.07 / 0.53
+// (3.82 / 0.55 with the allocator held to 78 VGPRs); 3: 4.64 / 0.56 (4.19 / 0.55 at 60 VGPRs).  Occupancy is
+// not what limits the kernel -- neither is it with amdgpu_waves_per_eu alone (5 / 6 / 8 waves: 0.86 -> 1.03 /
+// 1.13 / 1.22 ms of PSD stage on the share, spills) or with more registers (242 VGPRs: no change).
 __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbeam_sum(HydroSet hs, ItabSet its, SubsumArgs a)
 {
-    constexpr int NB = CPOL_ITAB_NC * CPOL_ITAB_NFP;
+    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
+    constexpr int NP = CPOL_N_SZ / 2 / CPOL_SUBSUM_SPLIT;               // double2 column pairs of this thread
+    static_assert(NP * CPOL_SUBSUM_SPLIT * 2 == CPOL_N_SZ, "CPOL_SUBSUM_SPLIT must divide 6");
     const long n_rg = (long)a.n_rays * a.n_gates;
     const long rg = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
+    const int j = blockIdx.y / CPOL_SUBSUM_SPLIT, part = blockIdx.y % CPOL_SUBSUM_SPLIT;
+    const int f0 = part * NP;                                            // first column pair
     if (rg >= n_rg) return;
     const int ray = (int)(rg / a.n_gates), gate = (int)(rg % a.n_gates);
     const long n_sbg = n_rg * a.n_sub;
@@ -248,43 +261,55 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
     const bool tab1 = t.tab && !t.two_d;                                 // uniform
     const int key_base = hs.h[j].key_base;
     const double2 *R = a.rec + (long)j * n_sbg;
-    const bool want_vn = tab1 && a.vn && t.writes_vn;                    // uniform
+    const bool want_vn = tab1 && a.vn && t.writes_vn && part == 0;       // uniform
     double wtot = 0.0;
     if (a.wgate)
         for (int s = 0; s < a.n_sub; ++s) wtot += a.wgate[sbg0 + (long)s * a.n_gates];
-    float acc[CPOL_N_SZ];
+    float acc[2 * NP];
 #pragma unroll
-    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = __builtin_nanf("");
+    for (int c = 0; c < 2 * NP; ++c) acc[c] = __builtin_nanf("");
     for (int s = 0; s < a.n_sub; ++s) {
         const long sbg = sbg0 + (long)s * a.n_gates;
         if (!((a.vmask[sbg] >> j) & 1)) continue;
         const int key = a.key[(long)j * n_sbg + sbg];
         const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
-        double2 v[CPOL_N_SZ / 2];
+        double2 v[NP];
         const double2 rc = tab1 ? R[sbg] : make_double2(-1.0, 0.0);
         if (rc.x >= 0.0) {
             const int pn = min((int)rc.x, t.n_pan - 1);
             const double u = 2.0 * (rc.x - (double)pn) - 1.0;
             const double2 *blk = reinterpret_cast<const double2 *>(t.tab + ((long)(key - key_base) * t.n_pan + pn) * NB);
-            itab1_columns(blk, u, rc.y, v);
+            // this thread's columns of the block (itab1_columns on a part of the row)
+#pragma unroll
+            for (int f = 0; f < NP; ++f) v[f] = blk[(NC - 1) * (NFP / 2) + f0 + f];
+#pragma unroll
+            for (int q = NC - 2; q >= 0; --q) {
+#pragma unroll
+                for (int f = 0; f < NP; ++f) {
+                    const double2 cq = blk[q * (NFP / 2) + f0 + f];
+                    v[f].x = fma(v[f].x, u, cq.x);
+                    v[f].y = fma(v[f].y, u, cq.y);
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < NP; ++f) { v[f].x *= rc.y; v[f].y *= rc.y; }
             if (want_vn) {
-                constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
-                double2 w = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
+                double2 wv = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
 #pragma unroll
                 for (int q = NC - 2; q >= 0; --q) {
                     const double2 cq = blk[q * (NFP / 2) + CPOL_N_SZ / 2];
-                    w.x = fma(w.x, u, cq.x);
-                    w.y = fma(w.y, u, cq.y);
+                    wv.x = fma(wv.x, u, cq.x);
+                    wv.y = fma(wv.y, u, cq.y);
                 }
-                *reinterpret_cast<double2 *>(a.vn + ((long)j * n_sbg + sbg) * 2) = make_double2(w.x * rc.y, w.y * rc.y);
+                *reinterpret_cast<double2 *>(a.vn + ((long)j * n_sbg + sbg) * 2) = make_double2(wv.x * rc.y, wv.y * rc.y);
             }
         } else {
-            const double2 *r = reinterpret_cast<const double2 *>(a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ);
+            const double2 *r = reinterpret_cast<const double2 *>(a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ) + f0;
 #pragma unroll
-            for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = r[c];
+            for (int c = 0; c < NP; ++c) v[c] = r[c];
         }
 #pragma unroll
-        for (int c = 0; c < CPOL_N_SZ; ++c) {
+        for (int c = 0; c < 2 * NP; ++c) {
             // nansum([float32 acc, float64 term]) stored back as float32
             double y = ((c & 1) ? v[c / 2].y : v[c / 2].x) * w;
             double x = (double)acc[c];
@@ -293,10 +318,9 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
             acc[c] = (float)(x + y);
         }
     }
-    float4 *o = reinterpret_cast<float4 *>(a.sz_integ + (rg * a.n_hydro + j) * CPOL_N_SZ);
+    float2 *o = reinterpret_cast<float2 *>(a.sz_integ + (rg * a.n_hydro + j) * CPOL_N_SZ) + f0;
 #pragma unroll
-    for (int c4 = 0; c4 < CPOL_N_SZ / 4; ++c4)
-        o[c4] = make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
+    for (int c2 = 0; c2 < NP; ++c2) o[c2] = make_float2(acc[2 * c2], acc[2 * c2 + 1]);
 }
 
 #ifndef CPOL_SKIP_RVEL
