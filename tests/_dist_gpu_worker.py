@@ -21,7 +21,8 @@ def main():
     over = _cases.gen_golden.radial_case_inputs(name)[0]
     over = {k: dict(v) for k, v in over.items()}
     _, _, _, _, luts, cube = _cases.radial_case(name)
-    azs = np.arange(0., 360., 24.)             # 15 rays: uneven split over 2 ranks
+    n_az = int(sys.argv[1]) if len(sys.argv) > 1 else 15
+    azs = np.arange(n_az) * (360. / n_az)       # 15 rays: uneven split over 2 ranks; 16 over 3: 6 + 6 + 4
     scans = []
     for distributed in (True, False):
         op = RadarOperator(config=over, luts=luts, output_variables='only_radar', device=0,

@@ -275,3 +275,46 @@ def test_operator_first_then_torch_cuda():
             'print("ok", float(z.sum()))\n' % (root, root, root))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'ok 0.0' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_results_live_in_pooled_pinned_blocks_of_their_own():
+    """Host results are views of context-free pinned blocks from the operator's pool: a steady stream
+    of equal sweeps allocates nothing new, dropping a result recycles its block, results survive lane
+    drops (set_lut), re-staging and close(), and non-blocking sweeps on alternating lanes whose results
+    are dropped before anybody waited do not corrupt later ones."""
+    import gc
+    op, over, _, _ = _op('c3_melt_ice', lanes=2)
+    az = np.arange(0., 360., 30.)
+    ref4 = op.simulate_rays(az, np.full(len(az), 4.0))
+    ref7 = op.simulate_rays(az, np.full(len(az), 7.0))
+    keep4 = {k: np.array(v) for k, v in ref4.items() if isinstance(v, np.ndarray)}
+    n0 = op._pool.n_alloc
+    for i in range(12):
+        r = op.simulate_rays(az, np.full(len(az), 4.0 if i % 2 == 0 else 7.0))
+        del r
+    gc.collect()
+    assert op._pool.n_alloc <= n0 + 1, (n0, op._pool.n_alloc)          # dropped blocks were re-used
+    # non-blocking sweeps, results dropped while their copies may still be in flight
+    for i in range(10):
+        op.simulate_rays(az, np.full(len(az), 7.0), pinned=True, lane=i % 2)
+    a = op.simulate_rays(az, np.full(len(az), 4.0), pinned=True, lane=0)
+    b = op.simulate_rays(az, np.full(len(az), 7.0), pinned=True, lane=1)
+    op.wait(0)
+    op.wait(1)
+    for k in FIELDS:
+        assert np.array_equal(a[k], ref4[k], equal_nan=True), k
+        assert np.array_equal(b[k], ref7[k], equal_nan=True), k
+    assert op._pool.n_alloc <= n0 + 4
+    # lanes dropped, tables re-staged, operator closed: the arrays handed out before stay what they were
+    op.set_lut()
+    assert op._lane_ctx == []
+    for k in FIELDS:
+        assert np.array_equal(ref4[k], keep4[k], equal_nan=True), k
+    op.close()
+    gc.collect()
+    for k in FIELDS:
+        assert np.array_equal(ref4[k], keep4[k], equal_nan=True), k
+        assert np.array_equal(a[k], keep4[k], equal_nan=True), k
+    ref4['ZH'][0, 0] = 1.0                                              # still writable memory of its own
+    del ref4, ref7, a, b
+    gc.collect()

@@ -20,6 +20,18 @@ def test_two_ranks_one_gpu_bitwise_equal_to_single_process():
     assert 'DIST_GPU_OK world=2' in out.stdout
 
 
+def test_three_ranks_one_gpu_uneven_volume_split():
+    """Three ranks (15 rays: 5 + 5 + 5 per sweep; gloo) through the same worker: the volume layout with
+    more than two ranks."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3',
+           '--master-addr', '127.0.0.1', '--master-port', '29537',
+           os.path.join(HERE, '_dist_gpu_worker.py'), '16']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert 'DIST_GPU_OK world=3' in out.stdout
+
+
 def test_bench_c4_strong_scaling_mode_two_ranks_one_gpu():
     """bench.py --workload c4 with two ranks (gloo, both on GPU 0): azimuths of every sweep
     sharded, one all-gather per sweep, the gathered volume equals rank 0's own single-GPU

@@ -169,6 +169,11 @@ def test_c4_sector_with_49_subbeams_vs_oracle():
 def test_rhi_and_vprof_api(full):
     op = full['op']
     rhi = op.get_RHI(azimuths=[30.0, 200.0], elevations=np.arange(0.5, 20.0, 2.5))
+    op.volume_in_one_sequence = False                      # sweep by sweep (lanes): the same bits
+    rhi2 = op.get_RHI(azimuths=[30.0, 200.0], elevations=np.arange(0.5, 20.0, 2.5))
+    op.volume_in_one_sequence = True
+    for k in ('ZH', 'ZDR', 'KDP', 'RVEL'):
+        assert np.array_equal(np.ma.getdata(rhi.fields[k]['data']), np.ma.getdata(rhi2.fields[k]['data']), equal_nan=True), k
     assert rhi.nsweeps == 2 and rhi.scan_type == 'rhi'
     assert rhi.fields['ZH']['data'].shape == (16, 500)
     assert np.allclose(rhi.fixed_angle['data'], [30.0, 200.0])

@@ -307,3 +307,48 @@ def test_c5_bench_size_swaths_sampled_rays_vs_oracle():
         assert np.array_equal(zh[:keep.sum()], raw['ZH'][i * M + j, :n][keep][::-1].astype(np.float64), equal_nan=True)
         assert np.all(zh[keep.sum():] == 0)
     op.close()
+
+
+def test_swath_geometry_cache_follows_the_swath(luts_band):
+    """get_GPM_swath keeps the swath-derived geometry (inverse geodesic, ray tables, first-gate pass) of
+    the last few swaths, keyed by the CONTENT of the swath and the band: the same swath again gives the
+    same bits without recomputing, another swath (or the other band) does not see a stale entry."""
+    from cosmo_pol_amd import RadarOperator
+    cube = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G'), two_moment=True,
+                                     **_cases.gen_golden.CUBE_KW)
+    base = {'radar': {'coords': [46.5, 7.5, 1000], 'frequency': 5.6, 'K_squared': 0.93},
+            'microphysics': {'scheme': '2mom', 'with_ice_crystals': 0, 'with_melting': 0},
+            'integration': {'nh_GH': 1, 'nv_GH': 1}}
+    lut_5_6 = {h: synthetic.make_lut(h, 5.6, '2mom', n_e=2, n_t=2) for h in HYD_2MOM}
+
+    def provider(hl, freq, scheme):
+        src = {13.6: luts_band('Ku'), 35.6: luts_band('Ka')}.get(freq, lut_5_6)
+        return {h: src[h] for h in hl}
+    op = RadarOperator(config=base, luts=provider, output_variables='only_radar')
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    sw1 = _swath()
+    sw2 = gpm.synthetic_swath(n_scans=3, n_rays=5, cross_track_deg=3.0, scan_spacing_m=5000.0, heading_deg=75.0)
+    a1 = op.get_GPM_swath(sw1, 'Ku')
+    assert len(op._gpm_cache) == 1
+    a2 = op.get_GPM_swath(dict(sw1), 'Ku')                       # an equal swath in another dict: cache hit
+    assert len(op._gpm_cache) == 1
+    b = op.get_GPM_swath(sw2, 'Ku')
+    c = op.get_GPM_swath(sw1, 'Ka')
+    assert len(op._gpm_cache) == 3
+    for k in ['ZH', 'KDP', 'lats', 'heights', 'mask']:
+        assert np.array_equal(a1.raw[k], a2.raw[k], equal_nan=True), k
+    assert not np.array_equal(a1.azimuths, b.azimuths)
+    assert a1.raw['ZH'].shape != c.raw['ZH'].shape or not np.array_equal(a1.raw['ZH'], c.raw['ZH'], equal_nan=True)
+    # a fresh operator (no cache) agrees with the cached answers
+    op2 = RadarOperator(config=base, luts=provider, output_variables='only_radar')
+    op2.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    b2 = op2.get_GPM_swath(sw2, 'Ku')
+    for k in ['ZH', 'KDP', 'lats', 'heights', 'mask']:
+        assert np.array_equal(b.raw[k], b2.raw[k], equal_nan=True), k
+    # re-staging the model invalidates the entries (the first-gate pass depends on nothing of the cube, but
+    # the key carries the staging serial so that no entry outlives its model)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    op.get_GPM_swath(sw1, 'Ku')
+    assert len(op._gpm_cache) <= 4
+    op.close()
+    op2.close()
