@@ -6,7 +6,7 @@
 
 Workloads (BASELINE.json `configs`):
 
-  c2 (default at N = 1; configs[1], the configuration the metric is quoted on)
+  c2 (default at every N; configs[1], the configuration the metric is quoted on)
       360-azimuth x 500-gate C-band PPI, rain + snow + graupel 1-moment, one sub-beam,
       attenuation on, synthetic COSMO-1-like cube (80 x 774 x 1158) and full-size synthetic
       scattering tables.  A step = one complete sweep through the C ABI as SURVEY 8(d) counts it:
@@ -21,10 +21,16 @@ Workloads (BASELINE.json `configs`):
       the product.  Extras of the same line: `value_cached_geometry` (round 2's headline: one
       fixed elevation, per-ray tables resident, gate coordinates copied once) and
       `value_device_resident` (outputs left in HBM).
+      N > 1 = WEAK scaling of exactly this step, so that the driver's series N = 1, 2, 4, 8
+      compares like with like: every rank runs the N = 1 step unchanged, rank r on elevation
+      (step + r) mod 16 (a scan spread over the GPUs sweep by sweep).  Sweeps are independent, so a
+      step holds no collective; the timed region ends with ONE all-gather (RCCL) of every rank's
+      last sweep, left in HBM for it (`gather_check`: rank 0 recomputes those sweeps and compares
+      the gathered blocks bit for bit).  `value` = N x gates per sweep x K / MAX-over-ranks time.
 
   c3 (configs[2])   5-elevation volume (360 x 500 each), R,S,G,mS,mG,I with melting layer and ice
       crystals, one sub-beam.  A step = one volume: per-sweep tables up, kernels, all outputs down.
-  c4 (default at N > 1; configs[3])   the c3 volume with the 7 x 7 Gauss-Hermite antenna
+  c4 (configs[3]; runs after c2 in the default N > 1 run)   the c3 volume with the 7 x 7 Gauss-Hermite antenna
       quadrature (49 sub-beams).  STRONG scaling: the 360 azimuths of every sweep are split into
       contiguous blocks of ceil(360 / N) rays, one per rank (cosmo_pol_amd/distributed.py); a
       rank runs its rays of ALL five sweeps as one launch sequence and ONE all-gather per volume
@@ -37,7 +43,10 @@ Workloads (BASELINE.json `configs`):
 
 At N = 1 with the default workload the line also carries `c3`, `c4_volume_one_gpu` and `c5`:
 the same script run with --workload c3 / c4 / c5 in child processes after the c2 operator is
-closed (driver-timed like the rest of the run).
+closed (driver-timed like the rest of the run).  At N > 1 with the default workload it carries
+`c4_strong_scaling`: `--workload c4 --gpus N` run by one child process per rank on the same GPUs
+after the c2 part has closed its operator and process group (its `speedup_vs_single_gpu` is the
+strong-scaling figure of north_star's "azimuths sharded, one gather at the end").
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the workload:
 `achieved` = algorithmic bytes per launch over the live HIP-event duration on the
@@ -187,7 +196,8 @@ def main():
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--workload', choices=['auto', 'c2', 'c3', 'c4', 'c5'], default='auto',
-                    help="auto: c2 at N = 1 (the metric's configuration), c4 strong scaling at N > 1")
+                    help="auto: c2 (the metric's configuration; weak scaling at N > 1) followed, at N > 1, by "
+                         "the c4 strong-scaling run as an extra; c4 at N > 1: strong scaling as the main line")
     ap.add_argument('--repeats', type=int, default=5, help='repeats of the timed region (c2)')
     ap.add_argument('--small', action='store_true', help='small cube / tables (debugging, tests)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0,
@@ -206,7 +216,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run for --gpus > 1')
         args.gpus = world
-    workload = args.workload if args.workload != 'auto' else ('c2' if world == 1 else 'c4')
+    workload = args.workload if args.workload != 'auto' else 'c2'
     if args.steps is None:
         args.steps = {'c2': 200, 'c3': 20, 'c4': 10, 'c5': 5}[workload]
     if args.warmup is None:
@@ -280,12 +290,31 @@ def main():
         if cpu_res is not None:
             out['cpu_baseline'] = cpu_res
             out['gpu_over_cpu_core'] = out['value'] / cpu_res['value']
+    extras = args.workload == 'auto' and not os.environ.get('CPOL_BENCH_NO_EXTRAS')
+    port = [None]
     if world > 1:
+        if extras:                                    # a rendezvous port for the c4 run that follows
+            if rank == 0:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(('127.0.0.1', 0))
+                    port[0] = sk.getsockname()[1]
+            dist.broadcast_object_list(port, src=0)
         dist.barrier()
         dist.destroy_process_group()
     op.close()
+    if world > 1 and extras:
+        # BASELINE configs[3] in the same run: the C4 volume strong-scaled over the same N GPUs
+        # (`bench.py --workload c4 --gpus N`, one child per rank, after this rank's operator and
+        # process group are closed)
+        small = ['--small'] if args.small else []
+        res = child_run('c4', ['--gpus', str(world), '--steps', '10', '--warmup', '2'] + small,
+                        env={'MASTER_PORT': str(port[0]), 'TORCHELASTIC_USE_AGENT_STORE': 'False'},
+                        quiet=rank != 0, timeout=240)   # (own store on the new port: the launcher's serves the old one)
+        if rank == 0:
+            out['c4_strong_scaling'] = res
     if rank == 0:
-        if world == 1 and args.workload == 'auto' and not os.environ.get('CPOL_BENCH_NO_EXTRAS'):
+        if world == 1 and extras:
             # the other BASELINE configurations on this GPU, one child process each (after the c2
             # operator is closed): driver-timed like the rest of the run
             small = ['--small'] if args.small else []
@@ -295,21 +324,26 @@ def main():
         print(json.dumps(out))
 
 
-def child_run(workload, flags):
-    """N = 1, default workload only: `bench.py --workload <workload>` on this GPU in a child process, so
-    that the N = 1 line also carries the other BASELINE configurations (c4 = the single-GPU reference
-    of the strong-scaling runs)."""
+def child_run(workload, flags, env=None, quiet=False, timeout=600):
+    """Default workload only: `bench.py --workload <workload>` in a child process of this rank (same
+    GPU, same rank environment), so that the line also carries the other BASELINE configurations:
+    at N = 1 c3, c4 (the single-GPU reference of the strong-scaling runs) and c5; at N > 1 the c4
+    strong-scaling run, every rank starting its own child (`quiet`: a rank whose child prints nothing)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--workload', workload, '--cpu-seconds', '0'] + flags
     t0 = time.time()
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, CPOL_BENCH_NO_EXTRAS='1'))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout,
+                           env=dict(os.environ, CPOL_BENCH_NO_EXTRAS='1', **(env or {})))
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if quiet and r.returncode == 0:
+            return None
         if r.returncode != 0 or not line:
             return {'error': (r.stderr or r.stdout)[-400:]}
         d = json.loads(line[-1])
-        keep = {k: d.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'gather_check',
-                                      'roofline', 'setup_s', 'stages_ms', 'counters', 'api_ms', 'per_band',
+        keep = {k: d.get(k) for k in ('value', 'unit', 'n_gpus', 'ms_per_step', 'steps', 'warmup', 'scaling',
+                                      'gather_check', 'speedup_vs_single_gpu', 'single_gpu_same_workload',
+                                      'per_rank', 'roofline', 'setup_s', 'stages_ms', 'counters', 'api_ms', 'per_band',
                                       'single_sweep_ms', 'host_submit_ms_per_step') if k in d}
         keep['workload'] = d['config']['workload']
         keep['child_wall_s'] = time.time() - t0
@@ -340,25 +374,38 @@ def run_c2(env):
     dev = torch.device('cuda', env['local_rank'])
     counter = [0]
 
-    # N > 1 with this workload = weak scaling (every rank one full sweep per step, one
-    # all-gather of the device slabs per step on a side stream); kept as an option
-    lane_streams = ([torch.cuda.ExternalStream(c.stream_ptr(), device=dev) for c in lanes]
-                    if world > 1 else None)
+    # N > 1 = weak scaling of the SAME step: every rank simulates one full sweep per step exactly as
+    # at N = 1, rank r taking elevation (k + r) mod 16 of step k (a volume scan spread over the
+    # GPUs sweep by sweep).  The sweeps are independent: no collective inside a step.  The timed
+    # region ends with the one gather north_star names: each rank's last sweep, left in HBM,
+    # all-gathered over RCCL on a side stream.
+    weak = world > 1
     n_buf = max(2, n_lanes)
     slabs = [torch.empty((len(RADAR_FIELDS), n_rays, n_gates), dtype=torch.float32, device=dev)
              for _ in range(n_buf)]
-    gathered = ([torch.empty(world * slabs[0].numel(), dtype=torch.float32, device=dev)
-                 for _ in range(n_buf)] if world > 1 else None)
     dev_outs = [{k: sl[i].data_ptr() for i, k in enumerate(RADAR_FIELDS)} for sl in slabs]
-    comm_stream = torch.cuda.Stream() if world > 1 else None
-    slab_free = [None] * n_buf
+    gathered = torch.empty(world * slabs[0].numel(), dtype=torch.float32, device=dev) if weak else None
+    lane0_stream = torch.cuda.ExternalStream(lanes[0].stream_ptr(), device=dev) if weak else None
+    comm_stream = torch.cuda.Stream() if weak else None
+    last_gathered_step = [None]
 
     def step_full():
         """The headline step at N = 1: a NEW elevation, its per-ray tables computed
         on the host and uploaded, all kernels, all 15 output arrays to page-locked host memory."""
         k = counter[0]
         counter[0] += 1
-        return op.simulate_rays(az, els[k % len(els)], pinned=True, lane=k % n_lanes)
+        return op.simulate_rays(az, els[(k + rank) % len(els)], pinned=True, lane=k % n_lanes)
+
+    def end_of_region_gather():
+        """N > 1: the rank's last sweep once more with its outputs left in HBM, then ONE all-gather."""
+        k = counter[0] - 1
+        op.simulate_rays(az, els[(k + rank) % len(els)], device_outputs=dev_outs[0], lane=0)
+        computed = torch.cuda.Event()
+        computed.record(lane0_stream)
+        comm_stream.wait_event(computed)
+        with torch.cuda.stream(comm_stream):
+            dist.all_gather_into_tensor(gathered, slabs[0].view(-1))
+        last_gathered_step[0] = k
 
     def step_cached():                      # round 2's headline: fixed geometry, tables resident
         lane = counter[0] % n_lanes
@@ -369,19 +416,7 @@ def run_c2(env):
         b = counter[0] % n_buf
         lane = counter[0] % n_lanes
         counter[0] += 1
-        if world == 1:
-            op.simulate_rays(az, el, device_outputs=dev_outs[b], lane=lane)
-            return
-        if slab_free[b] is not None:
-            lane_streams[lane].wait_event(slab_free[b])
         op.simulate_rays(az, el, device_outputs=dev_outs[b], lane=lane)
-        computed = torch.cuda.Event()
-        computed.record(lane_streams[lane])
-        comm_stream.wait_event(computed)
-        with torch.cuda.stream(comm_stream):
-            dist.all_gather_into_tensor(gathered[b], slabs[b].view(-1))
-            slab_free[b] = torch.cuda.Event()
-            slab_free[b].record(comm_stream)
 
     def fence():
         for i in range(n_lanes):
@@ -397,20 +432,22 @@ def run_c2(env):
         for _ in range(n):
             step()
         t_submit = time.perf_counter() - t0
+        if weak:
+            end_of_region_gather()
         fence()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if weak:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         return elapsed, t_submit
 
-    step = step_full if world == 1 else step_device
-    if world > 1:
+    step = step_full
+    if weak:
         with torch.cuda.stream(comm_stream):     # communicator set-up belongs to the setup phase
-            dist.all_gather_into_tensor(gathered[0], slabs[0].view(-1))
+            dist.all_gather_into_tensor(gathered, slabs[0].view(-1))
         fence()
-    op.reuse_device_tables = world > 1          # N = 1: nothing of the scan geometry stays on the device
+    op.reuse_device_tables = False              # nothing of the scan geometry stays on the device
     for _ in range(2 * n_lanes):         # set-up: every lane's slabs / work buffers exist
         step()
     fence()
@@ -425,13 +462,18 @@ def run_c2(env):
     value = gates_per_step * args.steps / elapsed
     op.reuse_device_tables = True
 
+    # rank 0 recomputes the last sweep of every rank and compares it with the gathered block, bit for bit
     gather_ok = None
-    if world > 1:
-        b = (counter[0] - 1) % n_buf
-        own = slabs[b].view(-1)
-        blocks = gathered[b].view(world, -1)
-        gather_ok = all(bool(torch.equal(torch.nan_to_num(blocks[r]), torch.nan_to_num(own)))
-                        for r in range(world))
+    if weak:
+        if rank == 0:
+            blocks = gathered.view(world, -1)
+            gather_ok = True
+            for r in range(world):
+                op.simulate_rays(az, els[(last_gathered_step[0] + r) % len(els)], device_outputs=dev_outs[1], lane=0)
+                op.wait(0)
+                gather_ok = gather_ok and bool(torch.equal(torch.nan_to_num(blocks[r]),
+                                                           torch.nan_to_num(slabs[1].view(-1))))
+        fence()
 
     extra = {}
     iso = cnt = None
@@ -527,16 +569,18 @@ def run_c2(env):
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'c2: 360-azimuth x 500-gate C-band PPI, rain+snow+graupel 1-moment, 1 sub-beam, '
-                               'synthetic %s cube; one sweep per GPU per step %s'
+                               'synthetic %s cube; one sweep per GPU per step: a new elevation every step '
+                               '(1.0 + 0.05 k deg, k = (step + rank) mod 16), per-ray tables computed on the host and '
+                               'uploaded, all kernels, all 15 output arrays (9 observables, RVEL, mask, lats, lons, '
+                               'dist, heights) copied to page-locked host memory%s'
                                % ('x'.join(map(str, cube['zlevels'].shape)),
-                                  '(N = 1): a new elevation every step (1.0 + 0.05 k deg, k = step mod 16), per-ray '
-                                  'tables computed on the host and uploaded, all kernels, all 15 output arrays '
-                                  '(9 observables, RVEL, mask, lats, lons, dist, heights) copied to page-locked host memory'
-                                  if world == 1 else '(N > 1: fixed elevation, outputs gathered on the devices)'),
+                                  '' if not weak else '; the timed region ends with one all-gather of every rank\'s '
+                                                      'last sweep (10 float32 fields, device to device)'),
                    'rays_per_gpu': n_rays, 'gates_per_ray': n_gates, 'lanes': n_lanes,
-                   'd2h_bytes_per_step': d2h_full if world == 1 else 0,
-                   'parallelism': ('weak scaling: one sweep per rank per step, 1 all-gather/step on a side '
-                                   'stream') if world > 1 else 'single GPU',
+                   'd2h_bytes_per_step': d2h_full,
+                   'parallelism': ('weak scaling: the sweeps of a scan are independent, rank r simulates elevation '
+                                   '(step + r) mod 16 with the N = 1 step unchanged, no collective inside a step, ONE '
+                                   'all-gather (RCCL) at the end of the timed region') if weak else 'single GPU',
                    'small': bool(args.small)},
         'timed_region_repeats': {'n': len(runs), 'ms_per_step_min': per_step[0],
                                  'ms_per_step_median': statistics.median(per_step),
@@ -555,8 +599,7 @@ def run_c2(env):
         'gather_check': gather_ok,
     }
     out.update(extra)
-    if world == 1:
-        out['d2h_GBs'] = d2h_full * args.steps / elapsed / 1e9
+    out['d2h_GBs'] = world * d2h_full * args.steps / elapsed / 1e9
     return out
 
 

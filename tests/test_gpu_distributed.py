@@ -32,23 +32,48 @@ def test_three_ranks_one_gpu_uneven_volume_split():
     assert 'DIST_GPU_OK world=3' in out.stdout
 
 
-def test_bench_c4_strong_scaling_mode_two_ranks_one_gpu():
-    """bench.py --workload c4 with two ranks (gloo, both on GPU 0): azimuths of every sweep
-    sharded, one all-gather per sweep, the gathered volume equals rank 0's own single-GPU
-    volume bit for bit (`gather_check`)."""
+def _bench_two_ranks(port, *flags):
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1', CPOL_BENCH_BACKEND='gloo',
                CPOL_BENCH_ONE_DEVICE='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29541',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(root, 'bench.py'), '--gpus', '2', '--small', '--steps', '2', '--warmup', '1',
-           '--cpu-seconds', '0']
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           '--cpu-seconds', '0'] + list(flags)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=360)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
-    r = json.loads(line)
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                      # rank 0 alone prints, and one line only
+    return json.loads(lines[0])
+
+
+def _check_c4_strong(r):
     assert r['n_gpus'] == 2 and r['scaling'] == 'strong' and r['gather_check'] is True
-    assert r['config']['workload'].startswith('c4') and len(r['per_rank']) == 2
+    assert len(r['per_rank']) == 2
     assert r['per_rank'][0]['rays_per_sweep'] + r['per_rank'][1]['rays_per_sweep'] == 90
-    assert r['single_gpu_same_workload']['value'] > 0 and r['value'] > 0
+    assert r['single_gpu_same_workload']['value'] > 0 and r['value'] > 0 and r['speedup_vs_single_gpu'] > 0
+
+
+def test_bench_c4_strong_scaling_mode_two_ranks_one_gpu():
+    """bench.py --workload c4 with two ranks (gloo, both on GPU 0): azimuths of every sweep
+    sharded, one all-gather per volume, the gathered volume equals rank 0's own single-GPU
+    volume bit for bit (`gather_check`)."""
+    r = _bench_two_ranks(29541, '--workload', 'c4')
+    assert r['config']['workload'].startswith('c4')
+    _check_c4_strong(r)
+
+
+def test_bench_default_two_ranks_weak_c2_line_with_c4_extra():
+    """The driver's N > 1 command (default workload): the c2 step of N = 1 on every rank (weak scaling,
+    rank r on another elevation), one all-gather at the end of the timed region checked bit for bit,
+    and the c4 strong-scaling run of the same ranks as `c4_strong_scaling`."""
+    r = _bench_two_ranks(29543)
+    assert r['n_gpus'] == 2 and r['scaling'] == 'weak' and r['gather_check'] is True
+    assert r['config']['workload'].startswith('c2') and r['metric'] == 'range-gates/sec'
+    assert r['config']['d2h_bytes_per_step'] > 0 and r['value'] > 0
+    assert r['roofline']['frac'] is None or r['roofline']['frac'] > 0
+    c4 = r['c4_strong_scaling']
+    assert 'error' not in c4, c4
+    assert c4['workload'].startswith('c4')
+    _check_c4_strong(c4)
