@@ -255,6 +255,10 @@ def main():
         cpu_res = cpu_baseline(conf, cube, luts, np.arange(0, 360, 1.0), el_cpu, args.cpu_seconds)
         cpu_res['all_cores'] = cpu_baseline_pool(workload, args.small)
 
+    # this rank's threads onto the cores next to its GPU (after the CPU legs, which use every core);
+    # CPOL_NUMA_BIND=0 leaves the affinity as launched
+    from cosmo_pol_amd import bind_to_device_numa_node
+    numa = bind_to_device_numa_node(local_rank)
     torch.cuda.set_device(local_rank)
     t0 = time.time()
     with contextlib.redirect_stdout(sys.stderr):      # the operator's notices: stdout carries ONE JSON line
@@ -285,6 +289,10 @@ def main():
                args=args, cube=cube, conf=conf, torch=torch, dist=dist, workload=workload, luts=luts)
     out = {'c2': run_c2, 'c3': run_c3, 'c4': run_c4, 'c5': run_c5}[workload](env)
     if rank == 0:
+        out['host_placement'] = {'gpu_pci': numa['pci'], 'numa_node': numa['node'],
+                                 'cores_bound': numa['bound'], 'cores_allowed': len(os.sched_getaffinity(0)),
+                                 'note': 'rank threads restricted to the cores next to the GPU (0 = affinity left as '
+                                         'launched); result blocks are page-locked memory of that node'}
         out['setup_s'] = {'synthetic_inputs': t_gen, 'stage_to_hbm': t_stage,
                           'of_which_scattering_and_integral_tables': t_tables, 'prepare_again': t_rebuild}
         if cpu_res is not None:

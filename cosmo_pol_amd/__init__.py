@@ -12,4 +12,7 @@ def __getattr__(name):
     if name == "RadarOperator":
         from .radar_operator import RadarOperator
         return RadarOperator
+    if name == "bind_to_device_numa_node":      # one process per GPU: run it on the GPU's own socket
+        from ._native import bind_to_device_numa_node
+        return bind_to_device_numa_node
     raise AttributeError(name)

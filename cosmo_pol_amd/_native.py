@@ -100,7 +100,8 @@ EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_fork', 'cpol_last_error', 'cpol_
            'cpol_synchronize', 'cpol_stage_model', 'cpol_stage_hydro', 'cpol_set_num_hydro',
            'cpol_stage_doppler_weights', 'cpol_stage_spectrum_tables', 'cpol_stage_t_function', 'cpol_prepare',
            'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
-           'cpol_spaceborne_first_gate', 'cpol_host_alloc', 'cpol_host_free',
+           'cpol_spaceborne_first_gate', 'cpol_host_alloc', 'cpol_host_free', 'cpol_host_alloc_near',
+           'cpol_device_pci_bus_id',
            'cpol_enable_timing', 'cpol_debug_read', 'cpol_debug_math']
 
 TRAJ_STRIDE, GEO_STRIDE, SITE_STRIDE = 4, 8, 8      # CPOL_*_STRIDE of the header
@@ -231,8 +232,66 @@ def load_library():
     lib.cpol_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]      # (ctx may be NULL: context-free block)
     lib.cpol_host_free.restype = C.c_int
     lib.cpol_host_free.argtypes = [vp, vp]
+    lib.cpol_host_alloc_near.restype = C.c_int
+    lib.cpol_host_alloc_near.argtypes = [C.c_int, C.c_size_t, C.POINTER(vp)]
+    lib.cpol_device_pci_bus_id.restype = C.c_int
+    lib.cpol_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     _lib = lib
     return lib
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist) -> set of ints."""
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def device_numa_info(device=0, sysfs='/sys/bus/pci/devices', pci=None):
+    """{'pci': '0000:75:00.0', 'node': 1, 'cpus': {...}} of GPU `device` (HIP ordinal); node / cpus are
+    None / empty where the kernel does not tell (one-socket hosts report node -1).  `pci`: the bus id
+    when it is known already (tests)."""
+    if pci is None:
+        lib = load_library()
+        buf = C.create_string_buffer(64)
+        if lib.cpol_device_pci_bus_id(int(device), buf, 64) != 0:
+            raise NativeError('cpol_device_pci_bus_id(%d) failed: no such GPU' % device)
+        pci = buf.value.decode()
+    bdf = pci.lower()
+    info = {'pci': bdf, 'node': None, 'cpus': set()}
+    try:
+        with open(os.path.join(sysfs, bdf, 'numa_node')) as f:
+            node = int(f.read().strip())
+        info['node'] = node if node >= 0 else None
+        with open(os.path.join(sysfs, bdf, 'local_cpulist')) as f:
+            info['cpus'] = parse_cpulist(f.read())
+    except (OSError, ValueError):
+        pass
+    return info
+
+
+def bind_to_device_numa_node(device=0, sysfs='/sys/bus/pci/devices', pci=None):
+    """One process per GPU on a multi-socket host: restricts the calling thread (and every thread it
+    starts afterwards) to the cores next to GPU `device`, so that the threads which build ray tables,
+    fill upload buffers and read results run on the socket whose memory the GPU's copies land in
+    (PinnedPool takes its blocks there, cpol_host_alloc_near).  Call it before the operator creates its
+    lane threads.  Never widens the affinity the process was given; does nothing when the GPU's cores
+    and the allowed cores do not intersect or the kernel reports no node.  CPOL_NUMA_BIND=0 switches
+    it off.  -> the info dict of device_numa_info plus 'bound' (number of cores, 0 = unchanged)."""
+    info = device_numa_info(device, sysfs, pci)
+    info['bound'] = 0
+    if os.environ.get('CPOL_NUMA_BIND', '1') == '0' or not info['cpus'] or not hasattr(os, 'sched_setaffinity'):
+        return info
+    allowed = os.sched_getaffinity(0)
+    want = allowed & info['cpus']
+    if want and want != allowed:
+        os.sched_setaffinity(0, want)
+        info['bound'] = len(want)
+    return info
 
 
 def _ptr(a):
@@ -252,9 +311,10 @@ class PinnedPool(object):
     GRANULE = 1 << 20
     MAX_PENDING = 8             # blocks of one size class that may wait for foreign copies before the pool waits
 
-    def __init__(self):
+    def __init__(self, device=None):
         import threading
         self.lib = load_library()
+        self.device = device        # blocks come from the NUMA node next to this GPU (None: the current device's)
         self.free = {}              # size class -> [(address, context or None)]
         self.lock = threading.Lock()
         self.closed = False
@@ -300,7 +360,10 @@ class PinnedPool(object):
             wait_for.synchronize()  # (also surfaces a deferred domain error of that lane, once)
         if addr is None:
             h = C.c_void_p()
-            rc = self.lib.cpol_host_alloc(None, size, C.byref(h))
+            if self.device is None:
+                rc = self.lib.cpol_host_alloc(None, size, C.byref(h))
+            else:
+                rc = self.lib.cpol_host_alloc_near(int(self.device), size, C.byref(h))
             if rc != 0 or not h:
                 raise MemoryError('cpol_host_alloc(%d bytes of page-locked host memory) failed' % size)
             addr = h.value

@@ -110,7 +110,7 @@ struct cpol_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     struct Staging { void *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } stg[4];
     int stg_next = 0;
-    DevBuf b_traj, b_wgate, b_clk;
+    DevBuf b_traj, b_wgate, b_clk, b_rayc;
     DevBuf b_beam, b_spectrum, b_outwin;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
         b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel, b_proj, b_blkranked, b_rec, b_vmask;
@@ -202,6 +202,7 @@ int build_itabs(cpol_ctx *ctx)
     if (ctx->parent) return CPOL_OK;                      // lanes copy the parent's tables
     if (ctx->itab_serial == ctx->lut_serial) return CPOL_OK;
     const bool enabled = !(getenv("CPOL_ITAB") && atoi(getenv("CPOL_ITAB")) == 0);   // read at every (re)build
+    (void)hipGetLastError();            // a stale error of another user of the runtime in this thread is not ours
     ctx->its = ItabSet{};
     ctx->itab_serial = ctx->lut_serial;
     ctx->itab_builds++;
@@ -566,7 +567,7 @@ void cpol_destroy(cpol_ctx *ctx)
         if (sg.ev) (void)hipEventDestroy(sg.ev);
         if (sg.p) (void)hipHostFree(sg.p);
     }
-    DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_tables, &ctx->b_traj, &ctx->b_wgate, &ctx->b_clk,
+    DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_tables, &ctx->b_traj, &ctx->b_wgate, &ctx->b_clk, &ctx->b_rayc,
                      &ctx->b_beam, &ctx->b_spectrum, &ctx->b_outwin, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_units,
@@ -710,6 +711,34 @@ int cpol_host_alloc(cpol_ctx *ctx, size_t bytes, void **out)
     return CPOL_OK;
 }
 
+int cpol_host_alloc_near(int device, size_t bytes, void **out)
+{
+    // a context-free block like cpol_host_alloc(NULL, ...), but placed for `device`: the runtime takes
+    // page-locked memory from the NUMA node next to the CURRENT device of the calling thread, which a
+    // helper thread of a rank on GPU 5 has never set
+    if (!out || bytes == 0 || device < 0) return CPOL_ERR_ARG;
+    *out = nullptr;
+    int prev = -1, n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); return CPOL_ERR_HIP; }
+    if (device >= n_dev) return CPOL_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return CPOL_ERR_ARG; }
+    void *h = nullptr;
+    hipError_t e = hipHostMalloc(&h, bytes, hipHostMallocDefault);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess || !h) { (void)hipGetLastError(); return CPOL_ERR_NOMEM; }
+    *out = h;
+    return CPOL_OK;
+}
+
+int cpol_device_pci_bus_id(int device, char *buf, int len)
+{
+    if (!buf || len < 16 || device < 0) return CPOL_ERR_ARG;
+    buf[0] = 0;
+    if (hipDeviceGetPCIBusId(buf, len, device) == hipSuccess) return CPOL_OK;
+    (void)hipGetLastError();            // (reported through the return code: not left behind as the thread's last error)
+    return CPOL_ERR_HIP;
+}
+
 int cpol_host_free(cpol_ctx *ctx, void *p)
 {
     if (!p) return CPOL_ERR_ARG;
@@ -742,6 +771,7 @@ int cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data, const 
         if (ctx) ctx->err = "cpol_stage_model: bad arguments (need nz >= 3, ny, nx >= 2)";
         return CPOL_ERR_ARG;
     }
+    (void)hipGetLastError();            // a stale error of another user of the runtime in this thread is not ours
     if (ctx->parent || ctx->n_children) {
         ctx->err = "cpol_stage_model: not on a lane, and not while lanes of this context exist (cpol_fork)";
         return CPOL_ERR_ARG;
@@ -749,7 +779,8 @@ int cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data, const 
     HIPCHK(hipSetDevice(ctx->device));
     const long ncell = (long)ny * nx;
     const size_t plane_bytes = (size_t)nz * ncell * sizeof(float);
-    ENSURE(ctx->d_H, plane_bytes);
+    const size_t h_bytes = (plane_bytes + 7) & ~(size_t)7;        // + (top, lowest level) per column behind the levels
+    ENSURE(ctx->d_H, h_bytes + (size_t)ncell * sizeof(float2));
     ENSURE(ctx->d_V, plane_bytes * n_vars);
     DevBuf tmp;
     int rc = ensure(ctx, tmp, plane_bytes);
@@ -757,7 +788,7 @@ int cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data, const 
     const int blk = 256, grd = cdiv(ncell, blk);
     HIPCHK(hipMemcpyAsync(tmp.p, zlevels, plane_bytes, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_stage_heights, dim3(grd), dim3(blk), 0, ctx->stream, (const float *)tmp.p,
-                       (float *)ctx->d_H.p, nz, ncell);
+                       (float *)ctx->d_H.p, (float2 *)((char *)ctx->d_H.p + h_bytes), nz, ncell);
     for (int v = 0; v < n_vars; ++v) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipMemcpyAsync(tmp.p, data[v], plane_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -769,6 +800,7 @@ int cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data, const 
     free_buf(tmp);
     ModelDev &m = ctx->model;
     m.H = (const float *)ctx->d_H.p;
+    m.HT = (const float2 *)((const char *)ctx->d_H.p + h_bytes);
     m.V = (const float *)ctx->d_V.p;
     m.n_vars = n_vars; m.nz = nz; m.ny = ny; m.nx = nx;
     m.llc0 = llc[0]; m.llc1 = llc[1];
@@ -1016,6 +1048,7 @@ int cpol_interp_points(cpol_ctx *ctx, int n, const float *coords, const float *h
         if (ctx) ctx->err = "cpol_interp_points: model not staged or bad arguments";
         return CPOL_ERR_ARG;
     }
+    (void)hipGetLastError();            // a stale error of another user of the runtime in this thread is not ours
     HIPCHK(hipSetDevice(ctx->device));
     DevBuf c, h, o;
     int rc;
@@ -1083,6 +1116,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ctx->err = "cpol_run_sweep: model / hydrometeors not staged or bad arguments";
         return CPOL_ERR_ARG;
     }
+    (void)hipGetLastError();            // a stale error of another user of the runtime in this thread is not ours
     for (int j = 0; j < ctx->hs.n_hydro; ++j)
         if (!ctx->hydro_staged[j]) { ctx->err = "cpol_run_sweep: hydrometeor slot not staged"; return CPOL_ERR_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
@@ -1173,8 +1207,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     }
 
     // ---- work buffers ----
-    if (mode == CPOL_GEOM_HOST_PATHS || ctx->keep_debug)
+    // several sub-beams: the ray paths (shared by the horizontal nodes of a vertical node) and the per-ray
+    // constants of the geodesic come from k_trajectory instead of once per sub-beam gate
+    const bool ray_prep = n_sub >= CPOL_RAY_PREP_MIN_SUB;
+    const bool prep_paths = ray_prep && n_h > 1 && mode != CPOL_GEOM_HOST_PATHS;
+    if (mode == CPOL_GEOM_HOST_PATHS || ctx->keep_debug || prep_paths)
         ENSURE(ctx->b_traj, (size_t)n_rays * n_v * 3 * ng * sizeof(float));
+    if (ray_prep) ENSURE(ctx->b_rayc, ((size_t)n_rays * n_h + n_rays) * 2 * sizeof(double));
     ENSURE(ctx->b_vals, (size_t)n_vars * n_sbg * sizeof(float));
     ENSURE(ctx->b_mask, (size_t)n_sbg);
     ENSURE(ctx->b_elev, (size_t)n_sbg * sizeof(float));
@@ -1315,23 +1354,29 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (mode == CPOL_GEOM_HOST_PATHS) {
         HIPCHK(hipMemcpyAsync(ctx->b_traj.p, t->paths, (size_t)n_rays * n_v * 3 * ng * sizeof(float),
                               hipMemcpyHostToDevice, st));
-    } else if (ctx->keep_debug) {
-        // parity access to the ray paths (cpol_debug_read "traj"): same device function
-        if ((long)n_rays * n_v > 65535) { ctx->err = "cpol_run_sweep: debug ray paths need n_rays * n_vnodes <= 65535"; return CPOL_ERR_ARG; }
+    }
+    if (ray_prep || (ctx->keep_debug && mode != CPOL_GEOM_HOST_PATHS)) {
+        // ray paths + per-ray constants ahead of the sweep kernel (and the parity access to the paths,
+        // cpol_debug_read "traj"): same device functions as the in-place evaluation
+        const bool paths = mode != CPOL_GEOM_HOST_PATHS && (prep_paths || ctx->keep_debug);
         TrajArgs ta{};
         ta.ray_traj = (const double *)ctx->v_traj_in;
         ta.site = t->site ? (const double *)ctx->v_site : nullptr;
-        ta.traj_out = (float *)ctx->b_traj.p;
+        ta.traj_out = paths ? (float *)ctx->b_traj.p : nullptr;
         ta.n_rays = n_rays; ta.n_v = n_v; ta.n_gates = ng; ta.mode = mode;
         ta.range0 = p->range0; ta.range_step = p->range_step;
         ta.ke = p->ke; ta.re = p->re; ta.alt = p->radar_alt;
-        hipLaunchKernelGGL(k_trajectory, dim3(cdiv(ng, 256), n_rays * n_v), dim3(256), 0, st, ta);
+        ta.geo = (const double *)ctx->v_geo;
+        ta.ray_const = ray_prep ? (double *)ctx->b_rayc.p : nullptr;
+        ta.n_h = n_h; ta.lon1 = p->radar_lon;
+        hipLaunchKernelGGL(k_trajectory, dim3((unsigned)(n_rays * n_v), paths ? cdiv(ng, 256) : 1), dim3(256), 0, st, ta);
     }
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_TRAJ], st));
 
     // ---- 2. gate interpolation ----
     InterpArgs ia{};
-    ia.traj = (mode == CPOL_GEOM_HOST_PATHS) ? (const float *)ctx->b_traj.p : nullptr;
+    ia.traj = (mode == CPOL_GEOM_HOST_PATHS || prep_paths) ? (const float *)ctx->b_traj.p : nullptr;
+    ia.ray_const = ray_prep ? (const double *)ctx->b_rayc.p : nullptr;
     ia.rp.ray_traj = (const double *)ctx->v_traj_in;
     ia.rp.site = t->site ? (const double *)ctx->v_site : nullptr;
     ia.rp.n_v = n_v; ia.rp.mode = mode;
@@ -1744,7 +1789,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                          ctx->b_fwmelt.p, ctx->b_key.p, ctx->b_pos.p, ctx->b_par.p, ctx->b_count.p,
                          ctx->b_offset.p, ctx->b_units.p, ctx->b_totals.p, ctx->b_perm.p,
                          ctx->b_res.p, ctx->b_vn.p, ctx->b_icefirst.p, ctx->b_wgate.p, ctx->b_blkranked.p, ctx->b_rec.p,
-                         ctx->b_vmask.p, ctx->v_traj_in, ctx->v_geo, ctx->v_subh,
+                         ctx->b_vmask.p, ctx->b_rayc.p, ctx->v_traj_in, ctx->v_geo, ctx->v_subh,
                          ctx->v_subv, ctx->v_subw, ctx->v_sens, ctx->v_site, ctx->v_nyq,
                          ctx->v_subsmooth, ctx->v_mlfilter, (void *)st};
         mix(arena, sizeof arena);
@@ -1804,6 +1849,7 @@ int cpol_spaceborne_first_gate(cpol_ctx *ctx, const cpol_sweep_params *p, const 
         if (ctx) ctx->err = "cpol_spaceborne_first_gate: bad arguments";
         return CPOL_ERR_ARG;
     }
+    (void)hipGetLastError();            // a stale error of another user of the runtime in this thread is not ours
     HIPCHK(hipSetDevice(ctx->device));
     const int n = p->n_rays * p->n_vnodes;
     DevBuf d_tr, d_site, d_nc, d_out;

@@ -18,6 +18,7 @@
 //  ny*nx*4 B = 3.6 MB; see DESIGN.md "data layout in HBM").
 struct ModelDev {
     const float *H;        // z-levels, column-major per cell, descending with k
+    const float2 *HT;      // per cell (top = H[cell][0], lowest level = H[cell][nz - 1]): one 8-B load for both
     const float *V;        // variables interleaved per (cell, level)
     int n_vars, nz, ny, nx;
     float llc0, llc1;      // Lo1 (lon), La1 (lat)

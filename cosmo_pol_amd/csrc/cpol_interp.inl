@@ -13,13 +13,14 @@
 // the x86-64 SSE build of the reference C.
 
 // ---------------------------------------------------------------- staging
-// [nz][ny][nx] -> H[cell][nz]
+// [nz][ny][nx] -> H[cell][nz], and the pair (model top, lowest level) of every column
 __global__ void k_stage_heights(const float *__restrict__ src, float *__restrict__ dst,
-                                int nz, long ncell)
+                                float2 *__restrict__ top_low, int nz, long ncell)
 {
     long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= ncell) return;
     for (int k = 0; k < nz; ++k) dst[cell * nz + k] = src[(long)k * ncell + cell];
+    top_low[cell] = make_float2(src[cell], src[(long)(nz - 1) * ncell + cell]);
 }
 
 // [nz][ny][nx] of variable v -> V[cell][nz][n_vars]
@@ -41,6 +42,11 @@ struct TrajArgs {
     float *traj_out;
     int n_rays, n_v, n_gates, mode;
     double range0, range_step, ke, re, alt;
+    // constants of a ray that k_interp_sweep would otherwise evaluate once per sub-beam gate (NULL: not wanted)
+    const double *geo;          // [n_rays][n_h][8]
+    double *ray_const;          // [n_rays * n_h][2] sin / cos (2 sigma1), then [n_rays][2] sin / cos (site longitude)
+    int n_h;
+    double lon1;
 };
 
 // height of candidate gate k of a downward-looking (spaceborne) ray
@@ -102,12 +108,33 @@ __device__ __forceinline__ void ray_path(const RayPathArgs &a, int ray, int rv, 
     e32 = (float)e * rad2deg_f;
 }
 
-// debug / parity only (cpol_debug_read "traj"): the sweep kernel evaluates ray_path itself
-__global__ void k_trajectory(TrajArgs a)
+// Ray paths ahead of the sweep kernel: with several horizontal quadrature nodes the sub-beams of one
+// vertical node share their path (7 x 7 nodes: 6 of 7 evaluations of the refraction formulas saved, ~300
+// float64 instructions per sub-beam gate); also the parity access to the paths (cpol_debug_read "traj").
+// Same device function as the in-place evaluation: identical values.  The blocks of the first gate tile
+// also evaluate the per-ray constants of the geodesic (sin / cos of 2 sigma1 per (ray, horizontal node),
+// of the site longitude per ray) with the same OCML calls k_interp_sweep would make per gate.
+// grid = (n_rays * n_v, ceil(n_gates / 256))
+__global__ __launch_bounds__(256) void k_trajectory(TrajArgs a)
 {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    int rv = blockIdx.y;                       // ray * n_v + vnode
-    if (g >= a.n_gates) return;
+    int g = blockIdx.y * blockDim.x + threadIdx.x;
+    int rv = blockIdx.x;                       // ray * n_v + vnode
+    if (a.ray_const && blockIdx.y == 0) {
+        const long n_geo = (long)a.n_rays * a.n_h;
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_geo + a.n_rays;
+             e += (long)gridDim.x * blockDim.x) {
+            double sn, cs;
+            if (e < n_geo) {
+                sincos(2.0 * a.geo[e * 8 + 2], &sn, &cs);
+            } else {
+                const long ray = e - n_geo;
+                sincos((a.site ? a.site[ray * 8 + 2] : a.lon1) * CPOL_DEG, &sn, &cs);
+            }
+            a.ray_const[2 * e] = sn;
+            a.ray_const[2 * e + 1] = cs;
+        }
+    }
+    if (g >= a.n_gates || !a.traj_out) return;
     RayPathArgs rp;
     rp.ray_traj = a.ray_traj; rp.site = a.site; rp.n_v = a.n_v; rp.mode = a.mode;
     rp.range0 = a.range0; rp.range_step = a.range_step; rp.ke = a.ke; rp.re = a.re; rp.alt = a.alt;
@@ -156,6 +183,8 @@ __device__ __forceinline__ int level_search(const float *__restrict__ col, int n
     return i;
 }
 
+struct __attribute__((packed, aligned(4))) F2 { float v[2]; };
+
 struct GateGeom {
     int status;            // 0 ok, +1 above model top, -1 below topography
     float x, y, dx, dy;    // fractional position (x along rows/lat, y along cols/lon)
@@ -185,30 +214,54 @@ __device__ __forceinline__ void gate_geometry(const ModelDev &m, float rlat, flo
     g.cell[2] = (long)i0b * m.nx + i1a;
     g.cell[3] = (long)i0b * m.nx + i1b;
     const int nz = m.nz;
-    float t[4];
+    float t[4], top[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = m.H[g.cell[k] * nz + (nz - 1)];
+    for (int k = 0; k < 4; ++k) { const float2 tl = m.HT[g.cell[k]]; top[k] = tl.x; t[k] = tl.y; }
     // interpolation_c.c:61
     float topo = g.dx * g.dy * t[0] + g.x * t[2] * g.dy + g.dx * t[1] * g.y + g.x * g.y * t[3];
     if (!(topo < h)) { g.status = -1; return; }
     g.status = 0;
-    // the four column searches advance in lockstep: 4 independent loads per step
-    // instead of 4 x 7 dependent ones (same result as interpolation_c.c:108-135)
+    // Level search (interpolation_c.c:108-135: the largest i in [0, nz - 2] with col[i] >= h, 0 if
+    // none; columns descend strictly with the level index).  Column 0 by bisection: 7 dependent
+    // 4-byte gathers at nz = 80.  The three neighbour columns start from its answer -- terrain-following
+    // levels put them within a level or two -- and check the bracket col[i] >= h > col[i + 1] with
+    // ONE 8-byte load, stepping up or down while it fails: the same index, ~3.5 gather instructions
+    // instead of 21, and the bracketing heights (z1, z2) come with it.  (The kernel is bound by the
+    // cache lines its gathers touch, not by arithmetic.)
     const float *col[4];
-    float top[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { col[k] = m.H + g.cell[k] * nz; top[k] = col[k][0]; }
-    int idx[4] = {0, 0, 0, 0};
-    int step = 1;
-    while ((step << 1) <= nz - 2) step <<= 1;                // wave-uniform
+    for (int k = 0; k < 4; ++k) col[k] = m.H + g.cell[k] * nz;
+    int idx[4];
+    float za[4], zb[4];                 // col[idx], col[idx + 1]
+    {
+        int i = 0, step = 1;
+        while ((step << 1) <= nz - 2) step <<= 1;            // wave-uniform
 #pragma unroll 1
-    for (; step >= 1; step >>= 1) {
-        float v[4];
-        int j[4];
+        for (; step >= 1; step >>= 1) {
+            const int j = min(i + step, nz - 2);
+            const float v = col[0][j];
+            if (i + step <= nz - 2 && v >= h) i = j;
+        }
+        idx[0] = i;
+        const F2 p = *(const F2 *)(col[0] + i);
+        za[0] = p.v[0]; zb[0] = p.v[1];
+    }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { j[k] = min(idx[k] + step, nz - 2); v[k] = col[k][j[k]]; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (idx[k] + step <= nz - 2 && v[k] >= h) idx[k] = j[k];
+    for (int k = 1; k < 4; ++k) {
+        int i = idx[0];
+        F2 p = *(const F2 *)(col[k] + i);
+        float a = p.v[0], b = p.v[1];
+#pragma unroll 1
+        for (;;) {
+            if (a >= h) {
+                if (i == nz - 2 || !(b >= h)) break;
+                ++i; a = b; b = col[k][i + 1];
+            } else {
+                if (i == 0) break;
+                --i; b = a; a = col[k][i];
+            }
+        }
+        idx[k] = i; za[k] = a; zb[k] = b;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -218,8 +271,12 @@ __device__ __forceinline__ void gate_geometry(const ModelDev &m, float rlat, flo
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        g.z1[k] = col[k][g.c1[k]];
-        g.z2[k] = col[k][g.c1[k] + 1];
+        if (g.c1[k] == idx[k]) {
+            g.z1[k] = za[k]; g.z2[k] = zb[k];
+        } else {                                             // below the lowest level / at nz - 2: rare
+            g.z1[k] = col[k][g.c1[k]];
+            g.z2[k] = col[k][g.c1[k] + 1];
+        }
     }
 }
 
@@ -284,8 +341,9 @@ __global__ void k_interp_points(ModelDev m, const float *__restrict__ coords,
 // (gate-stride coalesced stores, neighbouring gates share grid columns).
 // grid = (n_rays * n_sub, ceil(n_gates/256)): no 65535 limit on the number of rays
 struct InterpArgs {
-    const float *traj;          // [n_rays][n_v][3][n_gates] host-supplied ray paths
-                                // (CPOL_GEOM_HOST_PATHS) or NULL: ray_path() in place
+    const float *traj;          // [n_rays][n_v][3][n_gates] ray paths: host-supplied (CPOL_GEOM_HOST_PATHS) or
+                                // k_trajectory's (sub-beams sharing a vertical node); NULL: ray_path() in place
+    const double *ray_const;    // k_trajectory's per-ray constants or NULL: evaluated per gate
     RayPathArgs rp;
     int *zero_buf;              // the sweep's bucket counters, cleared here (no fill kernel)
     int zero_n;
@@ -303,10 +361,21 @@ struct InterpArgs {
     const double *site;         // per-ray site or NULL
 };
 
+#ifndef CPOL_RAY_PREP_MIN_SUB
+#define CPOL_RAY_PREP_MIN_SUB 4      // sub-beams per radial from which k_trajectory runs ahead of the sweep kernel
+#endif
 #ifndef CPOL_INTERP_FAST_SUB
 #define CPOL_INTERP_FAST_SUB 1       // 0: every sub-beam through atan2 -> degrees -> sincos like the central one
 #endif
-__global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
+#ifndef CPOL_INTERP_WAVES
+#define CPOL_INTERP_WAVES 0          // > 0: ask for that many wavefronts per SIMD (register budget 512 / waves)
+#endif
+#if CPOL_INTERP_WAVES > 0
+#define CPOL_INTERP_ATTR __attribute__((amdgpu_waves_per_eu(CPOL_INTERP_WAVES, CPOL_INTERP_WAVES)))
+#else
+#define CPOL_INTERP_ATTR
+#endif
+__global__ __launch_bounds__(256) CPOL_INTERP_ATTR void k_interp_sweep(ModelDev m, InterpArgs a)
 {
     const int gate = blockIdx.y * blockDim.x + threadIdx.x;
     const int sub = blockIdx.x % a.n_sub, ray = blockIdx.x / a.n_sub;
@@ -360,7 +429,12 @@ __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
     // sigma = arc / b is a few 1e-2 rad at radar ranges, so sin / cos are short Taylor sums
     // (next terms sigma^13/13!, sigma^12/12! < 1e-19 for |sigma| < 0.1), OCML beyond
     double s2s1, c2s1;
-    sincos(2.0 * sigma1, &s2s1, &c2s1);
+    if (a.ray_const) {                          // (wave-uniform: scalar loads)
+        const double *rc = a.ray_const + 2 * (long)(ray * a.n_h + ih);
+        s2s1 = rc[0]; c2s1 = rc[1];
+    } else {
+        sincos(2.0 * sigma1, &s2s1, &c2s1);
+    }
 #pragma unroll 1
     for (int it = 0; it <= CPOL_VINCENTY_ITERS; ++it) {
         if (fabs(sigma) < 0.1) {
@@ -405,7 +479,12 @@ __global__ __launch_bounds__(256) void k_interp_sweep(ModelDev m, InterpArgs a)
         const double cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
         const double sL = sm * cd - cm * sd, cL = cm * cd + sm * sd;        // lam - dlon
         double s1, c1;
-        sincos(lon1 * CPOL_DEG, &s1, &c1);
+        if (a.ray_const) {
+            const double *rc = a.ray_const + 2 * ((long)a.n_rays * a.n_h + ray);
+            s1 = rc[0]; c1 = rc[1];
+        } else {
+            sincos(lon1 * CPOL_DEG, &s1, &c1);
+        }
         slon = s1 * cL + c1 * sL; clon = c1 * cL - s1 * sL;
     } else
 #endif

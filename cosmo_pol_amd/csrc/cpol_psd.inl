@@ -361,23 +361,30 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
         }
     }
     const float e = in ? a.elev[i] : 0.f;
+    // the loads of the loop below are issued one hydrometeor ahead (the mass density of species j + 1 while
+    // species j is computed) and the temperature once: the kernel waits for memory, not for arithmetic
+    const int var_t0 = hs.h[0].d.var_t;
+    const float T0 = in ? a.vals[var_t0 * n + i] : 0.f;
+    float q_ahead = (in && hs.h[0].d.q_source == CPOL_Q_MODEL) ? a.vals[hs.h[0].d.var_q * n + i] : 0.f;
     for (int j = 0; j < hs.n_hydro; ++j) {
         const HydroDev &h = hs.h[j];
         const cpol_hydro_desc &d = h.d;
         float qm = 0.f;
         double fw = 0.0;
         if (in) {
-            if (d.q_source == CPOL_Q_MODEL) qm = a.vals[d.var_q * n + i];
+            if (d.q_source == CPOL_Q_MODEL) qm = q_ahead;
             else if (d.q_source == CPOL_Q_MELT_SNOW) { qm = qms; fw = fws; }
             else { qm = qmg; fw = fwg; }
         }
+        if (in && j + 1 < hs.n_hydro && hs.h[j + 1].d.q_source == CPOL_Q_MODEL)
+            q_ahead = a.vals[hs.h[j + 1].d.var_q * n + i];
         // NaN -> false (doppler_scatter.py:185); scheme 'ml': only gates where the
         // sub-beam has a non-zero weight (:186-189)
         const bool valid = in && (qm > 0.f) && (!a.wgate || a.wgate[i] > 0.0);
         int key = -1;
         double p0 = 0.0, p1 = 0.0, p2 = 0.0;         // parameter slots 0..2
         if (valid) {
-            const float T = a.vals[d.var_t * n + i];
+            const float T = d.var_t == var_t0 ? T0 : a.vals[d.var_t * n + i];
             // lut.py:336-341: float32 arithmetic for float32 queries
             int eb = clip_bin((e - d.e_lo) / d.e_step, d.n_e);
             int tb = d.second_axis_f64 ? clip_bin64((fw - (double)d.t_lo) / (double)d.t_step, d.n_t)

@@ -206,7 +206,11 @@ class RadarOperator(object):
                                 % (backend,))
         print('Reading options defined in options file')
         self._ctx = N.Context(device)         # raises if the HIP library / GPU is missing
-        self._pool = N.PinnedPool()           # page-locked blocks of the results handed to the user
+        if distributed:
+            # one process per GPU: run this rank's threads next to its GPU (CPOL_NUMA_BIND=0: leave the
+            # affinity alone); the reference's worker pool is not placed at all (radar_operator.py:402)
+            self.numa = N.bind_to_device_numa_node(device)
+        self._pool = N.PinnedPool(device)     # page-locked blocks of the results handed to the user
         # lanes: contexts forked from _ctx (shared cube / tables, own stream + work buffers);
         # the sweeps of a volume scan are spread over them so that they overlap on the GPU
         self.lanes = max(1, int(lanes))

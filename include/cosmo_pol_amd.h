@@ -268,6 +268,14 @@ int  cpol_synchronize(cpol_ctx *ctx);
  * caller makes sure no copy into the block is in flight when it frees or re-uses it */
 int  cpol_host_alloc(cpol_ctx *ctx, size_t bytes, void **out);
 int  cpol_host_free(cpol_ctx *ctx, void *p);
+/* a context-free block as cpol_host_alloc(NULL, ...) gives, taken from the NUMA node next to GPU
+ * `device` whatever the calling thread's current device is (one process per GPU on a two-socket host:
+ * helper threads have never called hipSetDevice); freed by cpol_host_free(NULL, p) */
+int  cpol_host_alloc_near(int device, size_t bytes, void **out);
+/* "0000:75:00.0" of GPU `device` (len >= 16): /sys/bus/pci/devices/<id>/numa_node and local_cpulist
+ * tell a one-process-per-GPU launcher which cores to run the rank on (the reference's pool is not
+ * placed at all, radar_operator.py:402) */
+int  cpol_device_pci_bus_id(int device, char *buf, int len);
 /* the HIP stream (hipStream_t) the context launches on: to order foreign work (copies,
  * collectives) against a sweep with events */
 int  cpol_get_stream(cpol_ctx *ctx, void **hip_stream);

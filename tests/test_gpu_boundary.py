@@ -2,6 +2,7 @@
 error, non-blocking pinned-host outputs, the re-validation in cpol_stage_hydro /
 cpol_run_sweep, and the sensitivity cut of the Doppler spectrum through get_PPI."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -318,3 +319,27 @@ def test_results_live_in_pooled_pinned_blocks_of_their_own():
     ref4['ZH'][0, 0] = 1.0                                              # still writable memory of its own
     del ref4, ref7, a, b
     gc.collect()
+
+
+def test_placement_helpers_on_the_box():
+    """The bus id the library reports names a PCI device of this host; blocks taken next to GPU 0 are
+    ordinary page-locked memory (cpol_host_alloc_near) and the pool uses them."""
+    import ctypes as C
+    from cosmo_pol_amd import _native as N
+    info = N.device_numa_info(0)
+    assert os.path.isdir(os.path.join('/sys/bus/pci/devices', info['pci']))
+    lib = N.load_library()
+    h = C.c_void_p()
+    assert lib.cpol_host_alloc_near(0, 1 << 20, C.byref(h)) == 0 and h.value
+    buf = (C.c_uint8 * (1 << 20)).from_address(h.value)
+    buf[0], buf[-1] = 7, 9
+    assert (buf[0], buf[-1]) == (7, 9)
+    assert lib.cpol_host_free(None, h) == 0
+    assert lib.cpol_host_alloc_near(-1, 1 << 20, C.byref(h)) != 0
+    assert lib.cpol_host_alloc_near(999, 1 << 20, C.byref(h)) != 0
+    pool = N.PinnedPool(0)
+    arr, _ = pool.take(3 << 20)
+    arr[:] = 1
+    assert int(arr.sum()) == arr.size
+    del arr
+    pool.close()

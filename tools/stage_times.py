@@ -19,6 +19,10 @@ def main():
     ap.add_argument('--rays', type=int, default=360, help='azimuths of the sweep (1 deg apart)')
     ap.add_argument('--volume', action='store_true',
                     help='the five elevations of the c3 / c4 volume in ONE launch sequence (rays x 5 rays)')
+    ap.add_argument('--blocks', type=int, default=0,
+                    help='N: the contiguous ray blocks of an N-rank run one after the other (load balance of the ranks)')
+    ap.add_argument('--chunk', type=int, default=0,
+                    help='with --blocks: block-cyclic instead of contiguous (chunks of this many rays dealt round robin)')
     args = ap.parse_args()
     import contextlib
     import numpy as np
@@ -36,12 +40,29 @@ def main():
         op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
         t_tables = time.time() - t0
         op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
-    az = np.arange(0, args.rays, 1.0)
-    el = np.full(args.rays, args.elev)
+    n_gates = len(op.constants.RANGE_RADAR)
+    hyds_n = len(hyds)
+    if args.blocks:
+        per = -(-360 // args.blocks)
+        for b in range(args.blocks):
+            if args.chunk:
+                ids = np.arange(360)
+                rays = ids[(ids // args.chunk) % args.blocks == b].astype(float)
+            else:
+                rays = np.arange(b * per, min(360, (b + 1) * per), 1.0)
+            one_block(op, bench, np, torch, args, rays, n_gates, hyds_n,
+                      wl, t_tables, 'block %d/%d chunk %d' % (b, args.blocks, args.chunk))
+    else:
+        one_block(op, bench, np, torch, args, np.arange(0, args.rays, 1.0), n_gates, hyds_n, wl, t_tables, args.tag)
+    op.close()
+
+
+def one_block(op, bench, np, torch, args, az, n_gates, n_hyd, wl, t_tables, tag):
+    n_rays = len(az)
+    el = np.full(n_rays, args.elev)
     if args.volume:
         az = np.tile(az, len(bench.C4_ELEVATIONS))
-        el = np.repeat(np.asarray(bench.C4_ELEVATIONS, dtype=float), args.rays)
-    n_gates = len(op.constants.RANGE_RADAR)
+        el = np.repeat(np.asarray(bench.C4_ELEVATIONS, dtype=float), n_rays)
     slab = torch.empty((9, len(az), n_gates), dtype=torch.float32, device='cuda')
     ptrs = {k: slab[i].data_ptr() for i, k in enumerate(bench.RADAR_FIELDS)}
     for _ in range(3):
@@ -53,13 +74,12 @@ def main():
     op.wait()
     c = op._ctx.counters()
     chk = op._ctx.itab_report()['check']
-    print(json.dumps(dict(tag=args.tag, config=wl, elev='volume' if args.volume else args.elev, rays=len(az), n_valid=int(c.n_valid_items),
+    print(json.dumps(dict(tag=tag, config=wl, elev='volume' if args.volume else args.elev, rays=len(az), n_valid=int(c.n_valid_items),
                           n_table=int(c.n_table_items), tables_s=round(t_tables, 2),
-                          itab_check=[float('%.2e' % v) for v in chk[:len(hyds)]],
+                          itab_check=[float('%.2e' % v) for v in chk[:n_hyd]],
                           interp=round(c.ms_interp * 1e3, 1), classify=round(c.ms_classify * 1e3, 1),
                           bucket=round(c.ms_bucket * 1e3, 1), psd=round(c.ms_psd * 1e3, 1),
                           final=round(c.ms_final * 1e3, 1), total_us=round(c.ms_total * 1e3, 1))), flush=True)
-    op.close()
 
 
 if __name__ == '__main__':
