@@ -118,6 +118,7 @@ struct cpol_ctx {
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
     int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0, last_n_keys = 0;
+    int subsum_coop = -1;              // CPOL_SUBSUM_COOP: k_subbeam_sum takes its coefficients through the scalar cache: 0 never, 1 always, -1 by launch size
     bool last_subsum = false;          // the 1-D table items of the last sweep never went through res[] (k_subbeam_sum)
     bool keep_debug = false;
     // sticky domain-error word (device): OR-ed by the kernels of every sweep, cleared only
@@ -527,6 +528,9 @@ int cpol_create(int device, cpol_ctx **out)
     // 4x (0.12 -> 0.03 ms) but is no faster on the device (0.232 vs 0.222 ms single lane) and
     // slows three-lane throughput by a quarter when graph launches and plain launches mix
     ctx->use_graph = getenv("CPOL_USE_GRAPH") && atoi(getenv("CPOL_USE_GRAPH")) != 0;
+    // CPOL_SUBSUM_COOP=0 / 1: k_subbeam_sum never / always takes the coefficient rows through the scalar cache
+    // (default: by launch size; the results are identical)
+    if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
     *out = ctx;
     return CPOL_OK;
 }
@@ -623,6 +627,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
         return CPOL_ERR_NOMEM;
     }
     c->use_graph = parent->use_graph;
+    c->subsum_coop = parent->subsum_coop;
     c->parent = parent;
     c->model_staged = parent->model_staged;
     c->model = parent->model;
@@ -1641,7 +1646,19 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sa2.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
         sa2.sz_integ = (float *)ctx->b_szinteg.p;
         sa2.n_rays = n_rays; sa2.n_gates = ng; sa2.n_sub = n_sub; sa2.n_hydro = n_hyd;
-        hipLaunchKernelGGL(k_subbeam_sum, dim3(cdiv(n_rg, CPOL_SUBSUM_THREADS), n_hyd * CPOL_SUBSUM_SPLIT), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
+        // lanes of a wavefront = a tile of neighbouring rays x consecutive gates (16 x 4 from 16 rays on)
+        int tl = CPOL_TILE_GATES_LOG2;
+        while (tl < 6 && (CPOL_WAVE >> tl) > n_rays) ++tl;
+        sa2.tile_log2 = tl;
+        const long tiles = (long)cdiv(n_rays, CPOL_WAVE >> tl) * cdiv(ng, 1 << tl);
+        // the scalar-cache form needs many wavefronts per SIMD to hide its waits (C4 volume, rays per sweep:
+        // 45 / 90 / 180 / 360 -> PSD stage 1.08 / 1.56 / 2.08 / 3.57 ms against 0.85 / 1.48 / 2.35 / 4.71 ms with
+        // the gather): from ~32 wavefronts per SIMD on.  CPOL_SUBSUM_COOP=0 / 1: never / always.
+        const long waves_per_simd = tiles * n_hyd * CPOL_SUBSUM_SPLIT / 1024;
+        const bool coop = ctx->subsum_coop == 1 || (ctx->subsum_coop < 0 && waves_per_simd >= 32);
+        const dim3 sgrid((unsigned)tiles, n_hyd * CPOL_SUBSUM_SPLIT);
+        if (coop) hipLaunchKernelGGL((k_subbeam_sum<true>), sgrid, dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
+        else hipLaunchKernelGGL((k_subbeam_sum<false>), sgrid, dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
     }
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
 

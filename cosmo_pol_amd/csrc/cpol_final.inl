@@ -218,6 +218,7 @@ struct SubsumArgs {
     const double *wgate;        // [n_sbg] or NULL (scheme 'ml')
     float *sz_integ;            // [n_rg][n_hydro][12]
     int n_rays, n_gates, n_sub, n_hydro;
+    int tile_log2;              // lanes of a wavefront = 2^(6 - tile_log2) rays x 2^tile_log2 gates
 };
 
 #ifndef CPOL_SUBSUM_THREADS
@@ -244,45 +245,122 @@ struct SubsumArgs {
 // (3.82 / 0.55 with the allocator held to 78 VGPRs); 3: 4.64 / 0.56 (4.19 / 0.55 at 60 VGPRs).  Occupancy is
 // not what limits the kernel -- neither is it with amdgpu_waves_per_eu alone (5 / 6 / 8 waves: 0.86 -> 1.03 /
 // 1.13 / 1.22 ms of PSD stage on the share, spills) or with more registers (242 VGPRs: no change).
+#ifndef CPOL_SUBSUM_GATHER_UNROLL
+#define CPOL_SUBSUM_GATHER_UNROLL 2  // rows of the per-lane gather requested together (the tail path)
+#endif
+#ifndef CPOL_SUBSUM_ROW_UNROLL
+#define CPOL_SUBSUM_ROW_UNROLL 2     // coefficient rows per scalar-memory wait (3 rows = 72 SGPRs no longer fit: 3.57 -> 4.34 ms)
+#endif
+typedef double __attribute__((address_space(4))) sconst_f64;       // read-only data behind a wave-uniform address
+
+// a * b + c with c in a scalar register pair (a wave-uniform coefficient): written out because the
+// compiler forms v_fmac (addend = destination) and first copies every coefficient into vector registers
+__device__ __forceinline__ double fma_sgpr(double a, double b, double c_uniform)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+    return r;
+}
+
+// Thread -> (ray, gate): the 64 lanes of a wavefront are a TILE of 2^(6 - tile_log2) neighbouring rays x
+// 2^tile_log2 consecutive gates (16 x 4 when the sweep has 16 rays or more), not 64 gates of one ray:
+// neighbouring rays at one range see almost the same PSD slope, so the items of a tile sit on very few
+// distinct (LUT slice, lambda panel) blocks -- measured on the C4 sweep at 3 degrees: 1.7 (snow), 1.8 (ice),
+// 3.2 (graupel) distinct blocks per tile and sub-beam, against 7.5 / 9.2 / 6.2 along 64 gates of a ray.
+// Two forms, bit-identical (same coefficients, same Horner order), chosen per launch by the host:
+//   COOP = false  every lane gathers the rows of its own block: 66 16-byte loads per evaluation through
+//                 the vector L1, which bounds it (~2 500 cycles per wavefront and sub-beam on a CU); the tile
+//                 alone helps (lanes on one block share its lines): C4 volume 3.59 -> 3.2 ms.
+//   COOP = true   the wavefront walks over its distinct blocks: the block address is made wave-uniform
+//                 (readlane), the coefficient rows arrive through the SCALAR cache into SGPRs and the lanes
+//                 on that block run their Horner chains with a scalar operand -- no per-lane gather at all,
+//                 56 VGPRs, 8 wavefronts per SIMD.  2.1 ms on the C4 volume; its wavefronts wait for the
+//                 scalar cache row pair by row pair (s_load returns out of order: nothing to pipeline
+//                 inside a wavefront; three waves per tile with 4 columns each and the whole block in
+//                 one wait: 5.5-6.0 ms of PSD stage, the scalar cache does not keep up), so it needs many
+//                 wavefronts per SIMD to pay: the 225-ray share of one of 8 GPUs takes 1.08 ms this way
+//                 and 0.85 ms with the gather.  The host picks it from ~32 wavefronts per SIMD on.
+template <bool COOP>
 __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbeam_sum(HydroSet hs, ItabSet its, SubsumArgs a)
 {
+    static_assert(CPOL_SUBSUM_THREADS == CPOL_WAVE, "one wavefront per workgroup: the tile walk uses wave-wide ballots");
     constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
     constexpr int NP = CPOL_N_SZ / 2 / CPOL_SUBSUM_SPLIT;               // double2 column pairs of this thread
     static_assert(NP * CPOL_SUBSUM_SPLIT * 2 == CPOL_N_SZ, "CPOL_SUBSUM_SPLIT must divide 6");
     const long n_rg = (long)a.n_rays * a.n_gates;
-    const long rg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y / CPOL_SUBSUM_SPLIT, part = blockIdx.y % CPOL_SUBSUM_SPLIT;
     const int f0 = part * NP;                                            // first column pair
-    if (rg >= n_rg) return;
-    const int ray = (int)(rg / a.n_gates), gate = (int)(rg % a.n_gates);
+    const int tg = a.tile_log2, lane = threadIdx.x;
+    const int gate_tiles = (a.n_gates + (1 << tg) - 1) >> tg;
+    const int ray = (int)(blockIdx.x / gate_tiles) * (CPOL_WAVE >> tg) + (lane >> tg);
+    const int gate = (int)(blockIdx.x % gate_tiles) * (1 << tg) + (lane & ((1 << tg) - 1));
+    const bool in = ray < a.n_rays && gate < a.n_gates;
+    const long rg = in ? (long)ray * a.n_gates + gate : 0;
     const long n_sbg = n_rg * a.n_sub;
-    const long sbg0 = (long)ray * a.n_sub * a.n_gates + gate;
+    const long sbg0 = in ? (long)ray * a.n_sub * a.n_gates + gate : 0;
     const ItabDev &t = its.t[j];
     const bool tab1 = t.tab && !t.two_d;                                 // uniform
     const int key_base = hs.h[j].key_base;
     const double2 *R = a.rec + (long)j * n_sbg;
     const bool want_vn = tab1 && a.vn && t.writes_vn && part == 0;       // uniform
     double wtot = 0.0;
-    if (a.wgate)
+    if (a.wgate && in)
         for (int s = 0; s < a.n_sub; ++s) wtot += a.wgate[sbg0 + (long)s * a.n_gates];
     float acc[2 * NP];
 #pragma unroll
     for (int c = 0; c < 2 * NP; ++c) acc[c] = __builtin_nanf("");
     for (int s = 0; s < a.n_sub; ++s) {
         const long sbg = sbg0 + (long)s * a.n_gates;
-        if (!((a.vmask[sbg] >> j) & 1)) continue;
-        const int key = a.key[(long)j * n_sbg + sbg];
-        const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
+        const bool present = in && ((a.vmask[sbg] >> j) & 1);
+        if (!__builtin_amdgcn_ballot_w64(present)) continue;             // (wave-uniform)
+        const int key = present ? a.key[(long)j * n_sbg + sbg] : 0;
+        const double2 rc = (present && tab1) ? R[sbg] : make_double2(-1.0, 0.0);
+        const bool on_tab = rc.x >= 0.0;
+        const int pn = on_tab ? min((int)rc.x, t.n_pan - 1) : 0;
+        const double u = 2.0 * (rc.x - (double)pn) - 1.0;
+        const int blk_id = on_tab ? (key - key_base) * t.n_pan + pn : -1;
         double2 v[NP];
-        const double2 rc = tab1 ? R[sbg] : make_double2(-1.0, 0.0);
-        if (rc.x >= 0.0) {
-            const int pn = min((int)rc.x, t.n_pan - 1);
-            const double u = 2.0 * (rc.x - (double)pn) - 1.0;
-            const double2 *blk = reinterpret_cast<const double2 *>(t.tab + ((long)(key - key_base) * t.n_pan + pn) * NB);
+        double2 wv = make_double2(0.0, 0.0);
+        // ---- the tile's distinct blocks, one after the other: coefficients through the scalar cache ----
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(on_tab);
+        while (COOP && todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int b = __builtin_amdgcn_readlane(blk_id, leader);
+            const bool mine = blk_id == b;                               // (blk_id = -1 never matches: b >= 0)
+            // (constant address space: a wave-uniform address there is what the backend turns into s_load)
+            const sconst_f64 *B = (const sconst_f64 *)(unsigned long long)(t.tab + (long)b * NB + 2 * f0);
+            if (mine) {
+#pragma unroll
+                for (int f = 0; f < NP; ++f) v[f] = make_double2(B[(NC - 1) * NFP + 2 * f], B[(NC - 1) * NFP + 2 * f + 1]);
+                // (one row per trip: unrolled, the scheduler requests all 11 rows at once and the 264 SGPRs they
+                // would need spill into vector registers)
+#pragma unroll CPOL_SUBSUM_ROW_UNROLL
+                for (int q = NC - 2; q >= 0; --q) {
+#pragma unroll
+                    for (int f = 0; f < NP; ++f) {
+                        v[f].x = fma_sgpr(v[f].x, u, B[q * NFP + 2 * f]);
+                        v[f].y = fma_sgpr(v[f].y, u, B[q * NFP + 2 * f + 1]);
+                    }
+                }
+                if (want_vn) {
+                    const sconst_f64 *W = (const sconst_f64 *)(unsigned long long)(t.tab + (long)b * NB + CPOL_N_SZ);
+                    wv = make_double2(W[(NC - 1) * NFP], W[(NC - 1) * NFP + 1]);
+#pragma unroll CPOL_SUBSUM_ROW_UNROLL
+                    for (int q = NC - 2; q >= 0; --q) {
+                        wv.x = fma_sgpr(wv.x, u, W[q * NFP]);
+                        wv.y = fma_sgpr(wv.y, u, W[q * NFP + 1]);
+                    }
+                }
+            }
+            todo &= ~__builtin_amdgcn_ballot_w64(mine);
+        }
+        // ---- COOP = false: per-lane gather ----
+        if (!COOP && on_tab) {
+            const double2 *blk = reinterpret_cast<const double2 *>(t.tab + (long)blk_id * NB);
             // this thread's columns of the block (itab1_columns on a part of the row)
 #pragma unroll
             for (int f = 0; f < NP; ++f) v[f] = blk[(NC - 1) * (NFP / 2) + f0 + f];
-#pragma unroll
+#pragma unroll CPOL_SUBSUM_GATHER_UNROLL
             for (int q = NC - 2; q >= 0; --q) {
 #pragma unroll
                 for (int f = 0; f < NP; ++f) {
@@ -291,23 +369,28 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
                     v[f].y = fma(v[f].y, u, cq.y);
                 }
             }
-#pragma unroll
-            for (int f = 0; f < NP; ++f) { v[f].x *= rc.y; v[f].y *= rc.y; }
             if (want_vn) {
-                double2 wv = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
+                wv = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
 #pragma unroll
                 for (int q = NC - 2; q >= 0; --q) {
                     const double2 cq = blk[q * (NFP / 2) + CPOL_N_SZ / 2];
                     wv.x = fma(wv.x, u, cq.x);
                     wv.y = fma(wv.y, u, cq.y);
                 }
-                *reinterpret_cast<double2 *>(a.vn + ((long)j * n_sbg + sbg) * 2) = make_double2(wv.x * rc.y, wv.y * rc.y);
             }
+        }
+        if (!present) continue;
+        if (on_tab) {
+#pragma unroll
+            for (int f = 0; f < NP; ++f) { v[f].x *= rc.y; v[f].y *= rc.y; }
+            if (want_vn)
+                *reinterpret_cast<double2 *>(a.vn + ((long)j * n_sbg + sbg) * 2) = make_double2(wv.x * rc.y, wv.y * rc.y);
         } else {
             const double2 *r = reinterpret_cast<const double2 *>(a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ) + f0;
 #pragma unroll
             for (int c = 0; c < NP; ++c) v[c] = r[c];
         }
+        const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
 #pragma unroll
         for (int c = 0; c < 2 * NP; ++c) {
             // nansum([float32 acc, float64 term]) stored back as float32
@@ -318,6 +401,7 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
             acc[c] = (float)(x + y);
         }
     }
+    if (!in) return;
     float2 *o = reinterpret_cast<float2 *>(a.sz_integ + (rg * a.n_hydro + j) * CPOL_N_SZ) + f0;
 #pragma unroll
     for (int c2 = 0; c2 < NP; ++c2) o[c2] = make_float2(acc[2 * c2], acc[2 * c2 + 1]);

@@ -217,6 +217,12 @@ def test_integral_tables_take_the_items_and_the_integrating_kernels_stay_pinned(
                          env=dict(os.environ, CPOL_SUBSUM='0'), capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert '4 passed' in out.stdout, out.stdout[-500:]
+    # ... and k_subbeam_sum with the coefficient rows through the scalar cache (CPOL_SUBSUM_COOP=1: by default
+    # only launches far larger than a test radial take that form)
+    out = subprocess.run(base + ['-k', 'c4_7x7 or c4_subbeams or q_ml_dop2 or c5_2mom_dop2_sub'],
+                         env=dict(os.environ, CPOL_SUBSUM_COOP='1'), capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert '4 passed' in out.stdout, out.stdout[-500:]
 
 
 def test_table_sets_stay_resident_across_configuration_switches():

@@ -121,13 +121,16 @@ def test_c3_full_size_volume_vs_oracle():
     op.close()
 
 
-def test_c4_sector_with_49_subbeams_vs_oracle():
+def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
     """BASELINE configs[3] on a sector: 45 azimuths x 500 gates x 7 x 7 sub-beams at two elevations
     on the bench cube, full 1-moment set with melting.  This is the path of the multi-GPU
     workload -- the melting items grouped by table block over tiles of 16 rays x 4 gates
     (k_psd_lookup), the items on 1-D tables evaluated inside the sub-beam accumulation
     (k_subbeam_sum), the velocity terms in their own kernel (k_rvel_terms) -- against the oracle
-    on sampled rays; the same rays alone (one ray per call: no tiles) must give the same bits."""
+    on sampled rays; the same rays alone (one ray per call: no tiles) must give the same bits, and so
+    must the form of k_subbeam_sum that takes the coefficient rows of a tile's distinct table blocks
+    through the scalar cache (CPOL_SUBSUM_COOP=1; by default only launches of >= 32 wavefronts per SIMD
+    use it) against the per-lane gather (CPOL_SUBSUM_COOP=0)."""
     from cosmo_pol_amd import RadarOperator
     from test_gpu_parity import _pol_tolerances
     over = bench.bench_config(False, 'c4')
