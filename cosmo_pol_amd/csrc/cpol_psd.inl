@@ -313,6 +313,15 @@ __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &ou
 
 #define CPOL_MAX_PAR 6
 
+#ifndef CPOL_X_NO_REC
+#define CPOL_X_NO_REC 0              // timing experiments only (tools/variants.sh): drop a store of k_classify
+#endif
+#ifndef CPOL_X_NO_VN
+#define CPOL_X_NO_VN 0
+#endif
+#ifndef CPOL_X_NO_KEY
+#define CPOL_X_NO_KEY 0
+#endif
 #define CPOL_CLASSIFY_THREADS (CPOL_RANK_WAVES * CPOL_WAVE)
 // (Measured and dropped: finishing the table items inside this kernel -- the lookup fused in, the
 // parameters never leaving the registers, 2 GB less HBM traffic on the C4 sweep -- took 3.35 ms
@@ -383,6 +392,9 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
         const bool valid = in && (qm > 0.f) && (!a.wgate || a.wgate[i] > 0.0);
         int key = -1;
         double p0 = 0.0, p1 = 0.0, p2 = 0.0;         // parameter slots 0..2
+        double loglam = 0.0;                          // log of a slope parameter when the rule formed it as
+        int ll_slot = -1;                             // (slot whose logarithm it is) exp(y log x): the table position and the fall-speed moments
+                                                      // take it from there instead of a logarithm of the result
         if (valid) {
             const float T = d.var_t == var_t0 ? T0 : a.vals[d.var_t * n + i];
             // lut.py:336-341: float32 arithmetic for float32 queries
@@ -392,12 +404,15 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             key = h.key_base + eb * d.n_t + tb;
             const double q = (double)qm;
             double lamf = 0.0, n0v = 0.0, qnv = 0.0;   // final lambda / N0 (get_N units)
+            double ll = 0.0;                           // log(lambda) where the rule has it from its power (has_ll)
             // the item's parameters (slots 0..2 of par[], read by the integrating kernels; slot 1 by
             // the 2-D lookup of the melting species)
             switch (d.rule) {
             case CPOL_RULE_RAIN_1MOM:
             case CPOL_RULE_GRAUPEL_1MOM:
-                lamf = cp_pow(d.lambda_factor / q, d.lam_exponent);
+                ll = d.lam_exponent * cp_log(d.lambda_factor / q);
+                lamf = cp_exp(ll);                            // = cp_pow(lambda_factor / q, lam_exponent)
+                loglam = ll; ll_slot = 0;
                 n0v = d.n0_fixed;
                 p0 = lamf;
                 p1 = 1.0;                                     // N0 folded into pre[]
@@ -408,7 +423,9 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 if (!tfun_lookup(a.tfun_snow, T, n0))
                     n0 = 13.5f * (565000.0f * exp_f32(-0.107f * (T - 273.15f))) / 1000.0f;
                 float an0 = (float)d.a * n0;
-                lamf = cp_pow((double)an0 * d.lambda_factor / q, d.lam_exponent);
+                ll = d.lam_exponent * cp_log((double)an0 * d.lambda_factor / q);
+                lamf = cp_exp(ll);
+                loglam = ll; ll_slot = 0;
                 n0v = (double)n0;
                 p0 = lamf;
                 p1 = n0v;
@@ -452,7 +469,9 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             case CPOL_RULE_MELTING_GRAUPEL: {
                 p0 = q;
                 p1 = fw;
-                p2 = cp_pow(d.r_lambda_factor / q, d.r_lam_exponent);   // rain partner
+                ll = d.r_lam_exponent * cp_log(d.r_lambda_factor / q);
+                p2 = cp_exp(ll);                                         // rain partner
+                loglam = ll; ll_slot = 2;                                // (the melting tables sit on slot 2)
                 // (the dry partner's PSD does not enter get_N, hydrometeors.py:372-390)
                 break; }
             default: break;
@@ -467,7 +486,8 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
             double pf = -1.0;
             if (tj.tab) {
-                pf = (cp_log(tj.par_slot == 2 ? p2 : p0) * 1.4426950408889634 - tj.log2_lo) * (double)tj.ppo;
+                const double lg = ll_slot == tj.par_slot ? loglam : cp_log(tj.par_slot == 2 ? p2 : p0);
+                pf = (lg * 1.4426950408889634 - tj.log2_lo) * (double)tj.ppo;
                 lookup = pf >= (double)tj.pan_lo && pf < (double)tj.pan_hi;   // NaN -> false
                 my_lookup += lookup ? 1 : 0;
             }
@@ -482,7 +502,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             if (tj.tab) {
                 // scale: gamma N0 exp(-lambda d0) (the table holds exp(+lambda d0) x integral); ice and melting: QM
                 const double scale = tj.two_d ? p0 : d.psd_family == CPOL_PSD_ICE_FIELD ? p2 : p1 * cp_exp(-(p0 * tj.d0));
-                a.rec[(long)j * n + i] = make_double2(lookup ? pf : -1.0, scale);
+                if (!CPOL_X_NO_REC || a.n_sbg < 0) a.rec[(long)j * n + i] = make_double2(lookup ? pf : -1.0, scale);
             }
             if (a.doppler && d.psd_family == CPOL_PSD_GAMMA && !d.numeric_intv) {
                 // _Hydrometeor.integrate_V (hydrometeors.py:178-199): analytic moments (a species with
@@ -490,10 +510,11 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 // intercept (rain, graupel) or p1 (few values stay live across the table decision above:
                 // this kernel has 128 VGPRs for its 16-wave ranking workgroups)
                 const double n0v = (d.rule == CPOL_RULE_RAIN_1MOM || d.rule == CPOL_RULE_GRAUPEL_1MOM) ? d.n0_fixed : p1;
-                const double dv = d.vel_factor * n0v * d.alpha / d.nu * cp_pow(p0, -(d.beta + d.mu + 1) / d.nu);
+                const double lp = ll_slot == 0 ? loglam : cp_log(p0);  // one logarithm of lambda for both powers
+                const double dv = d.vel_factor * n0v * d.alpha / d.nu * cp_exp(-(d.beta + d.mu + 1) / d.nu * lp);
                 const double dn = (d.rule == CPOL_RULE_TWO_MOMENT)
-                    ? (double)a.vals[d.var_qn * n + i] : d.ntot_factor * n0v / d.nu * cp_pow(p0, -(d.mu + 1) / d.nu);
-                if (a.vn) *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = make_double2(dv, dn);
+                    ? (double)a.vals[d.var_qn * n + i] : d.ntot_factor * n0v / d.nu * cp_exp(-(d.mu + 1) / d.nu * lp);
+                if (a.vn && (!CPOL_X_NO_VN || a.n_sbg < 0)) *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = make_double2(dv, dn);
                 if (a.keep_par) { P[2 * n] = dv; P[3 * n] = dn; }
             }
             vbits |= 1u << j;
@@ -502,7 +523,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
         const int ticket = rank_insert(sh[j], a.count, key, valid && !lookup);
         // (the LUT slice of a PRESENT hydrometeor; who is present is in vmask[] -- the -1 of the others is
         // only written for the debug reads and the spectrum kernels)
-        if (valid || (in && a.keep_par)) a.key[(long)j * n + i] = key;
+        if ((valid || (in && a.keep_par)) && (!CPOL_X_NO_KEY || a.n_sbg < 0)) a.key[(long)j * n + i] = key;
         if (valid && !lookup) {                       // (rare: pos[] is written only where an item is ranked)
             a.pos[(long)j * n + i] = ticket;
             ranked_mask |= 1u << j;
