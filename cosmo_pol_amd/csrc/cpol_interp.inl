@@ -339,6 +339,11 @@ __global__ void k_interp_points(ModelDev m, const float *__restrict__ coords,
 // ---------------------------------------------------------------- sweep kernel
 // One thread per sub-beam gate; a wave = 64 consecutive gates of ONE sub-beam
 // (gate-stride coalesced stores, neighbouring gates share grid columns).
+// (Measured and dropped: wavefronts of 7 vertical quadrature nodes x 9 gates -- the same model columns at
+// different heights, a quarter of the distinct columns per gather -- 2.18 -> 2.40 ms on the C4 volume: since
+// the hinted level search the kernel is bound by its float64 arithmetic, 1 660 VALU instructions per
+// sub-beam gate = 1.87 ms at full issue rate, and the scattered 36-byte store segments cost more than the
+// gathers save.)
 // grid = (n_rays * n_sub, ceil(n_gates/256)): no 65535 limit on the number of rays
 struct InterpArgs {
     const float *traj;          // [n_rays][n_v][3][n_gates] ray paths: host-supplied (CPOL_GEOM_HOST_PATHS) or

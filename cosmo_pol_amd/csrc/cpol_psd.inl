@@ -313,15 +313,9 @@ __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &ou
 
 #define CPOL_MAX_PAR 6
 
-#ifndef CPOL_X_NO_REC
-#define CPOL_X_NO_REC 0              // timing experiments only (tools/variants.sh): drop a store of k_classify
-#endif
-#ifndef CPOL_X_NO_VN
-#define CPOL_X_NO_VN 0
-#endif
-#ifndef CPOL_X_NO_KEY
-#define CPOL_X_NO_KEY 0
-#endif
+// (Measured with the stores of key / rec / vn dropped one by one: 2.55 ms each time against 2.57 -- the kernel
+// waits for its own dependent float64 chains at 4 wavefronts per SIMD, not for memory; the Doppler moments
+// are 0.27 ms of it.)
 #define CPOL_CLASSIFY_THREADS (CPOL_RANK_WAVES * CPOL_WAVE)
 // (Measured and dropped: finishing the table items inside this kernel -- the lookup fused in, the
 // parameters never leaving the registers, 2 GB less HBM traffic on the C4 sweep -- took 3.35 ms
@@ -502,7 +496,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
             if (tj.tab) {
                 // scale: gamma N0 exp(-lambda d0) (the table holds exp(+lambda d0) x integral); ice and melting: QM
                 const double scale = tj.two_d ? p0 : d.psd_family == CPOL_PSD_ICE_FIELD ? p2 : p1 * cp_exp(-(p0 * tj.d0));
-                if (!CPOL_X_NO_REC || a.n_sbg < 0) a.rec[(long)j * n + i] = make_double2(lookup ? pf : -1.0, scale);
+                a.rec[(long)j * n + i] = make_double2(lookup ? pf : -1.0, scale);
             }
             if (a.doppler && d.psd_family == CPOL_PSD_GAMMA && !d.numeric_intv) {
                 // _Hydrometeor.integrate_V (hydrometeors.py:178-199): analytic moments (a species with
@@ -514,7 +508,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 const double dv = d.vel_factor * n0v * d.alpha / d.nu * cp_exp(-(d.beta + d.mu + 1) / d.nu * lp);
                 const double dn = (d.rule == CPOL_RULE_TWO_MOMENT)
                     ? (double)a.vals[d.var_qn * n + i] : d.ntot_factor * n0v / d.nu * cp_exp(-(d.mu + 1) / d.nu * lp);
-                if (a.vn && (!CPOL_X_NO_VN || a.n_sbg < 0)) *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = make_double2(dv, dn);
+                if (a.vn) *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = make_double2(dv, dn);
                 if (a.keep_par) { P[2 * n] = dv; P[3 * n] = dn; }
             }
             vbits |= 1u << j;
@@ -523,7 +517,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
         const int ticket = rank_insert(sh[j], a.count, key, valid && !lookup);
         // (the LUT slice of a PRESENT hydrometeor; who is present is in vmask[] -- the -1 of the others is
         // only written for the debug reads and the spectrum kernels)
-        if ((valid || (in && a.keep_par)) && (!CPOL_X_NO_KEY || a.n_sbg < 0)) a.key[(long)j * n + i] = key;
+        if (valid || (in && a.keep_par)) a.key[(long)j * n + i] = key;
         if (valid && !lookup) {                       // (rare: pos[] is written only where an item is ranked)
             a.pos[(long)j * n + i] = ticket;
             ranked_mask |= 1u << j;
