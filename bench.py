@@ -121,7 +121,7 @@ def load_profile_summary(workload):
 
 
 # stage of the launch sequence (cpol_counters_t.ms_*) -> its kernels in the rocprofv3 summaries
-STAGE_KERNELS = {'interp': ('k_interp_sweep',), 'classify': ('k_classify', 'k_ml_weights'),
+STAGE_KERNELS = {'interp': ('k_interp_sweep', 'k_trajectory'), 'classify': ('k_classify', 'k_ml_weights'),
                  'bucket': ('k_bucket_scan', 'k_bucket_scatter'),
                  'psd': ('k_psd_lookup', 'k_subbeam_sum'),     # (+ the integrating kernels: empty launches in a sweep)
                  'final': ('k_final', 'k_rvel_terms', 'k_ice_first')}

@@ -81,6 +81,25 @@ __global__ void k_write16(double2 *__restrict__ p, size_t n)
     for (; i < n; i += stride) p[i] = make_double2((double)i, 1.0);
 }
 
+// scalar loads (k_subbeam_sum<true>): every wavefront reads 96 B of each of its 128-B rows through the
+// scalar cache (three s_load_dwordx8), rows at pseudo-random places: n_lines rows, each touched once
+typedef unsigned int __attribute__((address_space(4))) sconst_u32;
+__global__ void k_sread96(const unsigned int *__restrict__ p, size_t n_lines, unsigned int *__restrict__ sink)
+{
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    unsigned int acc = 0;
+    for (size_t i = wave; i < n_lines; i += n_waves) {
+        const size_t line = (i * 2654435761ull) % n_lines;
+        const unsigned long long addr = __builtin_amdgcn_readfirstlane((unsigned int)(line & 0xffffffffu))
+            | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(line >> 32)) << 32);
+        const sconst_u32 *q = (const sconst_u32 *)((unsigned long long)p + addr * 128ull);
+#pragma unroll
+        for (int k = 0; k < 24; ++k) acc ^= q[k];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 int main()
 {
     void *buf = nullptr, *sink = nullptr;
@@ -93,6 +112,7 @@ int main()
         hipLaunchKernelGGL(k_read16, grid, block, 0, 0, (const double2 *)buf, N_BYTES / 16, (double *)sink);
         hipLaunchKernelGGL(k_gather16, grid, block, 0, 0, (const double2 *)buf, N_BYTES / 128, (double *)sink);
         hipLaunchKernelGGL(k_gather4, grid, block, 0, 0, (const float *)buf, N_BYTES / 128, (float *)sink);
+        hipLaunchKernelGGL(k_sread96, grid, block, 0, 0, (const unsigned int *)buf, N_BYTES / 128, (unsigned int *)sink);
         hipLaunchKernelGGL(k_write4, grid, block, 0, 0, (float *)buf, N_BYTES / 4);
         hipLaunchKernelGGL(k_write8, grid, block, 0, 0, (double *)buf, N_BYTES / 8);
         hipLaunchKernelGGL(k_write16, grid, block, 0, 0, (double2 *)buf, N_BYTES / 16);

@@ -22,10 +22,14 @@ def pmc(d):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
+SCALAR_LOAD_KERNELS = ('k_subbeam_sum<true>',)      # coefficient rows through s_load
+
+
 def main():
     stats, dF, dW, dS = sys.argv[1:5]
     out = {'_note': 'means per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE '
-                    'counts 64 B per 128-B request); avg_us from rocprofv3 --kernel-trace --stats'}
+                    'counts 64 B per 128-B request of the vector caches; kernels that read through the scalar cache: '
+                    'FETCH_SIZE + WRITE_SIZE, hbm_bytes_upper = the vector rule); avg_us from rocprofv3 --kernel-trace --stats'}
     with open(stats) as fh:
         for row in csv.DictReader(fh):
             name = row.get('Name') or row.get('KernelName') or ''
@@ -42,6 +46,12 @@ def main():
     for k, e in out.items():
         if isinstance(e, dict) and 'FETCH_SIZE' in e and 'WRITE_SIZE' in e:
             e['hbm_bytes'] = (2 * e['FETCH_SIZE'] + e['WRITE_SIZE']) * 1024
+            if any(tag in k for tag in SCALAR_LOAD_KERNELS):
+                # reads through the scalar cache are counted in full (profiles/r3_fetch_calibration.txt:
+                # k_sread96 1.000 of the 64-B sectors), only the kernel's few vector reads at one half:
+                # FETCH_SIZE + WRITE_SIZE is the lower bound, 2 FETCH_SIZE + WRITE_SIZE the upper one
+                e['hbm_bytes_upper'] = e['hbm_bytes']
+                e['hbm_bytes'] = (e['FETCH_SIZE'] + e['WRITE_SIZE']) * 1024
     print(json.dumps(out, indent=1, sort_keys=True))
 
 
