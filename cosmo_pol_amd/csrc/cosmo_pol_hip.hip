@@ -1654,8 +1654,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // the scalar-cache form needs many wavefronts per SIMD to hide its waits (C4 volume, rays per sweep:
         // 45 / 90 / 180 / 360 -> PSD stage 1.08 / 1.56 / 2.08 / 3.57 ms against 0.85 / 1.48 / 2.35 / 4.71 ms with
         // the gather): from ~32 wavefronts per SIMD on.  CPOL_SUBSUM_COOP=0 / 1: never / always.
+        // With lanes (cpol_fork) other sweeps share the GPU and hide the waits: measured with three lanes in
+        // flight, the share of one of 8 / 4 GPUs (11 / 21 wavefronts per SIMD): 1.30 / 2.24 ms per volume share
+        // against 1.31 / ~2.5 ms with the gather -- from ~12 there.
         const long waves_per_simd = tiles * n_hyd * CPOL_SUBSUM_SPLIT / 1024;
-        const bool coop = ctx->subsum_coop == 1 || (ctx->subsum_coop < 0 && waves_per_simd >= 32);
+        const int lanes_alive = ctx->parent ? ctx->parent->n_children : ctx->n_children;
+        const bool coop = ctx->subsum_coop == 1 || (ctx->subsum_coop < 0 && waves_per_simd >= (lanes_alive >= 2 ? 12 : 32));
         const dim3 sgrid((unsigned)tiles, n_hyd * CPOL_SUBSUM_SPLIT);
         if (coop) hipLaunchKernelGGL((k_subbeam_sum<true>), sgrid, dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
         else hipLaunchKernelGGL((k_subbeam_sum<false>), sgrid, dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
