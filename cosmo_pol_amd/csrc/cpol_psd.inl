@@ -47,7 +47,7 @@ __device__ __forceinline__ int clip_bin64(double q, int n)
 
 // Block-aggregated bucket ranking.  Global atomics are the scarce resource here
 // (measured: ~17k same-sweep atomics cost 54 us, 5x the rest of the kernel), so
-// the 16 wavefronts of a 1024-thread workgroup first merge their per-key counts
+// the wavefronts of a workgroup (CPOL_RANK_WAVES) first merge their per-key counts
 // in a small LDS hash table; ONE returning global atomic per distinct key per
 // workgroup then reserves the key's range and every item derives its final
 // position inside its bucket:  pos = base(block,key) + items of earlier waves
@@ -55,8 +55,12 @@ __device__ __forceinline__ int clip_bin64(double q, int n)
 // writes its own result slot.)
 #define CPOL_RANK_SLOTS 128
 #ifndef CPOL_RANK_WAVES
-#define CPOL_RANK_WAVES 16
-#endif
+#define CPOL_RANK_WAVES 4            // wavefronts per classify workgroup.  16 merged the most atomics (round 1) but left ONE
+#endif                               // workgroup per CU at the kernel's 123 VGPRs: its 16 wavefronts end at different times
+                                     // (gates without hydrometeors) and the CU idles until the last one.  C4 volume, all
+                                     // at 4 wavefronts per SIMD: 16 / 8 / 4 / 2 / 1 -> 2.45 / 2.36 / 2.14 / 3.61 / 6.44 ms
+                                     // (below 4 the per-workgroup reset of the LDS tables dominates); with every item
+                                     // ranked (CPOL_ITAB=0, C4 sweep) 1.26 -> 0.92 ms, on the small C2 sweep 22 -> 30 us.
 struct RankShared {
     int key[CPOL_RANK_SLOTS];
     int base[CPOL_RANK_SLOTS];
@@ -322,7 +326,16 @@ __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &ou
 // against 0.69 ms + 2.21 ms for k_classify + k_psd_lookup: the lookup is bound by the vector-L1
 // gather, not by HBM, and inside the 16-wave ranking workgroups it spills; 4- and 8-wave
 // workgroups 3.6 / 4.5 ms.)
-__global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs, ItabSet its, ClassifyArgs a)
+#ifndef CPOL_CLASSIFY_WPE
+#define CPOL_CLASSIFY_WPE 4          // wavefronts per SIMD asked of the register allocator (128 VGPRs: what 16-wave workgroups
+                                     // imposed; without it the allocator takes more registers and occupancy drops)
+#endif
+#if CPOL_CLASSIFY_WPE
+#define CPOL_CLASSIFY_ATTR __attribute__((amdgpu_waves_per_eu(CPOL_CLASSIFY_WPE, CPOL_CLASSIFY_WPE)))
+#else
+#define CPOL_CLASSIFY_ATTR
+#endif
+__global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) CPOL_CLASSIFY_ATTR void k_classify(HydroSet hs, ItabSet its, ClassifyArgs a)
 {
     // one LDS ranking table per hydrometeor: all global atomics of the workgroup are
     // issued in ONE round (phase B) instead of one dependent round per hydrometeor
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) void k_classify(HydroSet hs,
                 // _Hydrometeor.integrate_V (hydrometeors.py:178-199): analytic moments (a species with
                 // numeric_intv gets its sums from the PSD stage instead); lambda = p0, N0 = the fixed
                 // intercept (rain, graupel) or p1 (few values stay live across the table decision above:
-                // this kernel has 128 VGPRs for its 16-wave ranking workgroups)
+                // this kernel is held to 128 VGPRs, CPOL_CLASSIFY_WPE)
                 const double n0v = (d.rule == CPOL_RULE_RAIN_1MOM || d.rule == CPOL_RULE_GRAUPEL_1MOM) ? d.n0_fixed : p1;
                 const double lp = ll_slot == 0 ? loglam : cp_log(p0);  // one logarithm of lambda for both powers
                 const double dv = d.vel_factor * n0v * d.alpha / d.nu * cp_exp(-(d.beta + d.mu + 1) / d.nu * lp);
