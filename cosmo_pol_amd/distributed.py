@@ -179,8 +179,61 @@ class VolumeLayout(object):
               zip(sweeps, (b[rank] for b in self.bounds))]
         return (np.concatenate(az) if az else np.empty(0)), (np.concatenate(el) if el else np.empty(0))
 
+    # ---- the assembled volume: field-major, inside a field sweep after sweep, rays in scan order ----
+    @property
+    def final(self):
+        """BlockLayout of the assembled volume (sum of all rays rows per field)."""
+        if '_final' not in self.__dict__:
+            self._final = BlockLayout(self.block.fields, max(1, sum(self.n_rays)), self.n_gates)
+        return self._final
+
+    def source_rows(self):
+        """For every row of the assembled volume (sweep after sweep, rays in scan order) the rank that
+        computed it and its row inside that rank's block: two int64 arrays [sum(n_rays)]."""
+        ranks, rows = [], []
+        row = [0] * self.world
+        for b in self.bounds:
+            for r, (lo, hi) in enumerate(b):
+                ranks.append(np.full(hi - lo, r, dtype=np.int64))
+                rows.append(np.arange(row[r], row[r] + hi - lo, dtype=np.int64))
+                row[r] += hi - lo
+        cat = lambda parts: np.concatenate(parts) if parts else np.empty(0, dtype=np.int64)   # noqa: E731
+        return cat(ranks), cat(rows)
+
+    def assemble_on_device(self, gathered, final, index=None):
+        """gathered: [world * nbytes] uint8 tensor (the all-gathered blocks); final: [self.final.nbytes]
+        uint8 tensor on the same device, filled field by field with one row gather each (the rows of a
+        rank's block -> their place in the scan).  The host then needs ONE copy and no concatenation:
+        `views_of_final` slices it.  `index`: (rank, row) index tensors on that device (cached by the caller)."""
+        import torch
+        if index is None:
+            rk, rw = self.source_rows()
+            index = (torch.from_numpy(rk).to(gathered.device), torch.from_numpy(rw).to(gathered.device))
+        total = sum(self.n_rays)
+        if total == 0:
+            return index
+        blocks = gathered.view(self.world, self.block.nbytes)
+        for k, dt in self.block.fields:
+            rb = self.n_gates * dt.itemsize
+            o, of = self.block.offsets[k], self.final.offsets[k]
+            src = blocks[:, o:o + self.per * rb].unflatten(1, (self.per, rb))      # [world, per, row bytes] (a view)
+            final[of:of + total * rb].view(total, rb).copy_(src[index[0], index[1]])
+        return index
+
+    def views_of_final(self, final):
+        """[self.final.nbytes] uint8 (numpy) -> [{field: [n_rays_s, n_gates]} for every sweep s]: views, no copy."""
+        out = [dict() for _ in self.n_rays]
+        for k, dt in self.block.fields:
+            v = self.final.view(final, k)
+            r0 = 0
+            for s, n in enumerate(self.n_rays):
+                out[s][k] = v[r0:r0 + n]
+                r0 += n
+        return out
+
     def assemble(self, gathered):
-        """[world * nbytes] uint8 (numpy) -> [{field: [n_rays_s, n_gates]} for every sweep s]."""
+        """[world * nbytes] uint8 (numpy) -> [{field: [n_rays_s, n_gates]} for every sweep s] (host copy:
+        the gloo / CPU form; the device form is assemble_on_device + views_of_final)."""
         blocks = gathered.reshape(self.world, self.block.nbytes)
         out = [dict() for _ in self.n_rays]
         for k, dt in self.block.fields:
@@ -217,25 +270,29 @@ def simulate_sharded_volume(simulate, sweeps, fields, n_gates, device=None, grou
 
 
 def simulate_sharded_volume_device(run_block, stream_ptr, sweeps, fields, n_gates, device, group=None,
-                                   cache=None):
+                                   cache=None, host_block=None):
     """Device-resident volume sharding (the product path of RadarOperator(distributed=True)):
     `run_block(az, el, {field: device pointer})` queues ONE launch sequence for this rank's rays of
     all sweeps on the library stream; one all_gather_into_tensor of the device blocks (RCCL over
-    xGMI) behind it; one device-to-host copy of the gathered volume.  -> list of per-sweep dicts."""
+    xGMI) behind it; the gathered rows put into scan order on the device; one device-to-host copy.
+    `host_block(nbytes) -> (uint8 array, holder)`: where the result lives (the operator's PinnedPool; the
+    returned arrays are views of it).  -> list of per-sweep dicts."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lay = VolumeLayout(fields, [len(a) for a, _ in sweeps], world, n_gates)
     nb = lay.block.nbytes
     cache = {} if cache is None else cache
-    key = ('blk', nb, world)
+    nf = lay.final.nbytes
+    key = ('blk', nb, nf, world, tuple(lay.n_rays))
     if key not in cache:
         cache.clear()
+        rk, rw = lay.source_rows()
         cache[key] = (torch.zeros(nb, dtype=torch.uint8, device=device),
                       torch.empty(world * nb, dtype=torch.uint8, device=device),
-                      torch.empty(world * nb, dtype=torch.uint8).pin_memory()
-                      if torch.cuda.is_available() else torch.empty(world * nb, dtype=torch.uint8))
-    block, gathered, host = cache[key]
+                      torch.empty(nf, dtype=torch.uint8, device=device),
+                      (torch.from_numpy(rk).to(device), torch.from_numpy(rw).to(device)))
+    block, gathered, final, index = cache[key]
     lib_stream = torch.cuda.ExternalStream(stream_ptr, device=device)
     cur = torch.cuda.current_stream(device)
     lib_stream.wait_stream(cur)                 # the previous gather has consumed the block
@@ -245,6 +302,14 @@ def simulate_sharded_volume_device(run_block, stream_ptr, sweeps, fields, n_gate
         run_block(az, el, {k: base + lay.block.offsets[k] for k, _ in lay.block.fields})
     cur.wait_stream(lib_stream)                 # gather behind the kernels
     dist.all_gather_into_tensor(gathered, block, group=group)
-    host.copy_(gathered, non_blocking=True)
+    # rows -> their place in the scan ON THE DEVICE (one row gather per field), then ONE copy into a
+    # fresh page-locked block that the returned arrays are views of (no host-side concatenation: that was
+    # 70 MB read + written per C4 volume on every rank, ten times the rank's kernel time)
+    lay.assemble_on_device(gathered, final, index)
+    if host_block is not None:
+        arr = host_block(nf)[0][:nf]            # (the block lives as long as a view of it does)
+    else:
+        arr = np.empty(nf, dtype=np.uint8)
+    torch.from_numpy(arr).copy_(final, non_blocking=True)
     cur.synchronize()
-    return lay.assemble(host.numpy())
+    return lay.views_of_final(arr)

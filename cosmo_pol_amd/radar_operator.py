@@ -767,7 +767,7 @@ class RadarOperator(object):
         def run_block(a, e, ptrs):
             self.simulate_rays(a, e, device_outputs=ptrs, lane=lane)
         res = D.simulate_sharded_volume_device(run_block, ctx.stream_ptr(), sweeps, fields, n_gates, dev,
-                                               cache=cache)
+                                               cache=cache, host_block=self._pool.take)
         ctx.synchronize()                                       # deferred domain error, if any
         sub = self._cached('sub', lambda: quadrature.subbeams(self.__config))
         for r in res:

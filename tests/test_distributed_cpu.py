@@ -137,3 +137,38 @@ def test_sharded_volume_one_call_one_gather_equals_single_process(world, rays):
             for k in FIELDS:
                 assert res[s][k].shape == (n, N_GATES) and res[s][k].dtype == ref[k].dtype
                 assert np.array_equal(res[s][k].view(np.uint8), ref[k].view(np.uint8)), (rank, s, k)
+
+
+def test_volume_rows_assembled_by_row_gather_equal_the_host_concatenation():
+    """VolumeLayout.assemble_on_device (what RadarOperator(distributed=True) runs on the GPU behind the
+    all-gather: one row gather per field into the scan-ordered volume, then ONE copy and views) against
+    VolumeLayout.assemble (host concatenation, the gloo form) on CPU tensors: mixed dtypes, uneven and
+    empty sweeps, more ranks than rays."""
+    import torch
+    from cosmo_pol_amd.distributed import VolumeLayout
+    fields = [('ZH', np.float32), ('lats', np.float64), ('mask', np.float64), ('KDP', np.float32)]
+    rng = np.random.default_rng(5)
+    for world in (1, 2, 3, 8):
+        for n_rays in ([7, 5, 9], [1, 1], [16, 0, 3], [45] * 5):
+            ng = 11
+            lay = VolumeLayout(fields, n_rays, world, ng)
+            truth = [{k: rng.standard_normal((n, ng)).astype(dt) for k, dt in fields} for n in n_rays]
+            blocks = np.zeros((world, lay.block.nbytes), dtype=np.uint8)
+            for r in range(world):
+                row = 0
+                for s, b in enumerate(lay.bounds):
+                    lo, hi = b[r]
+                    for k, _ in lay.block.fields:
+                        lay.block.view(blocks[r], k)[row:row + hi - lo] = truth[s][k][lo:hi]
+                    row += hi - lo
+            rk, rw = lay.source_rows()
+            assert len(rk) == len(rw) == sum(n_rays)
+            final = torch.zeros(lay.final.nbytes, dtype=torch.uint8)
+            lay.assemble_on_device(torch.from_numpy(blocks.reshape(-1)), final)
+            got = lay.views_of_final(final.numpy())
+            ref = lay.assemble(blocks.reshape(-1))
+            for s in range(len(n_rays)):
+                for k, dt in fields:
+                    assert got[s][k].dtype == dt and got[s][k].shape == (n_rays[s], ng)
+                    assert np.array_equal(got[s][k], truth[s][k]) and np.array_equal(ref[s][k], truth[s][k])
+                    assert got[s][k].base is not None                  # a view of the one block, not a copy
