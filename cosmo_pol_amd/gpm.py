@@ -150,23 +150,30 @@ class SimulatedGPM(object):
     packed into [N, M, max_len] arrays."""
 
     def __init__(self, fields, mask, lats, lons, n_kept, dim, band):
-        """`data` is a LazyDict and `lats` / `lons` are built on first access: every packed array is a
-        float64 [N, M, max_len] scatter of ~3 M values (8 ms each on the host), eleven of them per swath."""
+        """`data` is a LazyDict and `lats` / `lons` / `bin_surface` are built on first access: every packed array
+        is a float64 [N, M, max_len] scatter of ~3 M values (8 ms each on the host), eleven of them per swath;
+        the boolean passes over the gates behind `bin_surface` alone were a third of a Ku swath call (3.3 of 10 ms)."""
         from .radar_operator import LazyDict
         N, M = dim
         n_rays, n_gates = mask.shape
         self.band = band
         n_kept = np.asarray(n_kept).reshape(-1)
-        inside = np.arange(n_gates)[None, :] < n_kept[:, None]           # gates of the ray
-        above = inside & (mask >= 1)
-        first_above = np.where(above.any(axis=1), above.argmax(axis=1), -1)
-        self.bin_surface = np.where(first_above >= 0, n_kept - first_above, 0).astype(float).reshape(N, M)
-        # kept gates (not below the topography), flipped so that index 0 is the lowest one
-        keep = inside & (mask > -1)
         idx = {}
 
+        def gates_of_ray():
+            if 'inside' not in idx:
+                idx['inside'] = np.arange(n_gates)[None, :] < n_kept[:, None]
+            return idx['inside']
+
+        def bin_surface():
+            above = gates_of_ray() & (mask >= 1)
+            first_above = np.where(above.any(axis=1), above.argmax(axis=1), -1)
+            return np.where(first_above >= 0, n_kept - first_above, 0).astype(float).reshape(N, M)
+
         def indices():
-            if not idx:
+            if 'src' not in idx:
+                # kept gates (not below the topography), flipped so that index 0 is the lowest one
+                keep = gates_of_ray() & (mask > -1)
                 n = keep.sum(axis=1)
                 src_idx = np.flatnonzero(keep)                           # flat source index of every kept gate
                 dest = (n[:, None] - np.cumsum(keep, axis=1, dtype=np.int32)).reshape(-1)[src_idx]
@@ -180,11 +187,16 @@ class SimulatedGPM(object):
             out[dst_idx] = np.asarray(src).reshape(-1)[src_idx]
             return out.reshape(N, M, n_gates)
         self._coords = LazyDict()
+        self._coords.add('bin_surface', bin_surface)
         self._coords.add('lats', lambda: pack(lats, np.nan))
         self._coords.add('lons', lambda: pack(lons, np.nan))
         self.data = LazyDict()
         for k in fields:
             self.data.add(k, (lambda kk: (lambda: pack(fields[kk], 0.0)))(k))
+
+    @property
+    def bin_surface(self):
+        return self._coords['bin_surface']
 
     @property
     def lats(self):
