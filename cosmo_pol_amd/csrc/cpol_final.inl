@@ -280,6 +280,8 @@ __device__ __forceinline__ double fma_sgpr(double a, double b, double c_uniform)
 //                 one wait: 5.5-6.0 ms of PSD stage, the scalar cache does not keep up), so it needs many
 //                 wavefronts per SIMD to pay: the 225-ray share of one of 8 GPUs takes 1.08 ms this way
 //                 and 0.85 ms with the gather.  The host picks it from ~32 wavefronts per SIMD on.
+//                 (Workgroup ids reordered so that the 8 ids of an XCD in every 64 take 8 consecutive ray
+//                 tiles of one range -- blocks shared through that XCD's L2: 2.05 -> 2.23 ms, dropped.)
 template <bool COOP>
 __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbeam_sum(HydroSet hs, ItabSet its, SubsumArgs a)
 {
