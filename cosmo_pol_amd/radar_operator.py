@@ -774,6 +774,41 @@ class RadarOperator(object):
             r['n_sub'] = sub.n_sub
         return res
 
+    def _swath_sharded(self, az, el, coords, n_gates, range0, site, sub, traj, geo_t, dim, lane=0):
+        """A spaceborne swath with its SCAN LINES sharded over the ranks in contiguous blocks:
+        a rank runs the rays of its scan lines as one launch sequence into its block of the gather buffer,
+        ONE all-gather, rows put into swath order on the device, one copy.  Every rank gets the whole
+        swath, bitwise equal to the single-GPU one.  (The swath geometry -- angles, first gates -- is
+        computed by every rank: host work of milliseconds, cached per swath.)"""
+        import torch
+        import torch.distributed as dist
+        from . import distributed as D
+        if self.output_variables != 'only_radar':
+            raise NotImplementedError('distributed swaths return the radar observables only '
+                                      "(use output_variables='only_radar')")
+        n_scans, per_scan = dim
+        fields = ([(k, np.float32) for k in RADAR_FIELDS] + [('dist', np.float32), ('heights', np.float32),
+                  ('mask', np.float64), ('lats', np.float64), ('lons', np.float64)])
+        row = per_scan * n_gates                      # one row of the layout = one scan line
+        lay = D.VolumeLayout(fields, [n_scans], dist.get_world_size(), row)
+        lo, hi = lay.bounds[0][dist.get_rank()]
+        r0, r1 = lo * per_scan, hi * per_scan
+        ctx = self._lane(lane)
+        cache = self.__dict__.setdefault('_dist_cache', {})
+
+        def run_block(_rows, _unused, ptrs):
+            self._run_rays(az[r0:r1], el[r0:r1], coords[r0:r1], n_gates, range0, N.GEOM_SPACEBORNE,
+                           device_outputs=ptrs, site=site[r0:r1], sub=sub, tables=(traj[r0:r1], geo_t[r0:r1]),
+                           lane=lane)
+        lines = [(np.arange(n_scans, dtype=np.float64), np.zeros(n_scans))]
+        res = D.simulate_sharded_volume_device(run_block, ctx.stream_ptr(), lines, fields, row,
+                                               torch.device('cuda', self.device), cache=cache,
+                                               host_block=self._pool.take)[0]
+        ctx.synchronize()                                       # deferred domain error, if any
+        out = {k: v.reshape(n_scans * per_scan, n_gates) for k, v in res.items()}
+        out['n_sub'] = sub.n_sub
+        return out
+
     def _package(self, res, az, el):
         fields = {}
         if self.output_variables in ('all', 'only_radar'):
@@ -900,8 +935,11 @@ class RadarOperator(object):
                         del gcache[k]
                     gcache[gkey] = cached
             az, el, rng, dim, coords, sub, traj, geo_t, site, n_kept, n_gates = cached
-            res = self._run_rays(az, el, coords, n_gates, res_m / 2., N.GEOM_SPACEBORNE,
-                                 site=site, sub=sub, tables=(traj, geo_t))
+            if self.distributed:
+                res = self._swath_sharded(az, el, coords, n_gates, res_m / 2., site, sub, traj, geo_t, dim)
+            else:
+                res = self._run_rays(az, el, coords, n_gates, res_m / 2., N.GEOM_SPACEBORNE,
+                                     site=site, sub=sub, tables=(traj, geo_t))
             fields = {}
             if self.output_variables in ('all', 'only_radar'):
                 for k in RADAR_FIELDS:

@@ -1,6 +1,7 @@
-"""Worker of tests/test_gpu_distributed.py: two ranks on ONE GPU (gloo rendezvous; RCCL
-rejects two ranks on the same device) run RadarOperator(distributed=True).get_PPI and
-compare with the same scan computed locally by each rank."""
+"""Worker of tests/test_gpu_distributed.py: two or three ranks on ONE GPU (gloo rendezvous; RCCL
+rejects two ranks on the same device) run RadarOperator(distributed=True).get_PPI (rays of every
+sweep sharded) and .get_GPM_swath (scan lines sharded) and compare with the same scan / swath
+computed locally by each rank, bit for bit."""
 import os
 import sys
 
@@ -38,9 +39,38 @@ def main():
         assert x.shape == y.shape, k
         assert np.array_equal(np.ma.getmaskarray(x), np.ma.getmaskarray(y)), k
         assert np.array_equal(x.filled(0), y.filled(0)), (k, rank)
+    # a GPM swath (BASELINE configs[4]): scan lines sharded over the ranks, every rank gets the whole swath
+    from cosmo_pol_amd import gpm, synthetic
+    cube2 = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G'), two_moment=True, **_cases.gen_golden.CUBE_KW)
+    base = {'radar': {'coords': [46.5, 7.5, 1000], 'frequency': 5.6, 'K_squared': 0.93},
+            'microphysics': {'scheme': '2mom', 'with_ice_crystals': 0, 'with_melting': 0},
+            'integration': {'nh_GH': 1, 'nv_GH': 3}}
+    tabs = {}
+
+    def provider(hl, freq, scheme):
+        for h in hl:
+            if (h, freq) not in tabs:
+                tabs[(h, freq)] = synthetic.make_lut(h, freq, '2mom', n_e=2, n_t=2)
+        return {h: tabs[(h, freq)] for h in hl}
+    sw = gpm.synthetic_swath(n_scans=7, n_rays=5, cross_track_deg=4.0, scan_spacing_m=6000.0)   # 7 lines: uneven split
+    swaths = []
+    for distributed in (True, False):
+        op = RadarOperator(config=base, luts=provider, output_variables='only_radar', device=0,
+                           distributed=distributed)
+        op.load_model_arrays(cube2['data'], cube2['zlevels'], cube2['proj_info'], cube2['resolution'])
+        swaths.append(op.get_GPM_swath(sw, 'Ku'))
+        op.close()
+    sa, sb = swaths
+    assert np.array_equal(sa.bin_surface, sb.bin_surface)
+    assert np.array_equal(sa.lats, sb.lats, equal_nan=True) and np.array_equal(sa.lons, sb.lons, equal_nan=True)
+    n_fin = 0
+    for k in sb.data:
+        assert np.array_equal(sa.data[k], sb.data[k], equal_nan=True), (k, rank)
+        n_fin += int(np.isfinite(sb.data[k]).sum())
+    assert n_fin > 100
     dist.barrier()
     if rank == 0:
-        print('DIST_GPU_OK world=%d fields=%d' % (world, len(a.fields)))
+        print('DIST_GPU_OK world=%d fields=%d swath_fields=%d' % (world, len(a.fields), len(sb.data)))
     dist.destroy_process_group()
 
 
