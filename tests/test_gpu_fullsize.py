@@ -312,3 +312,40 @@ def test_c4_volume_in_one_launch_sequence_90_azimuths_all_elevations_vs_oracle()
         for k in FIELDS + ['mask', 'lats', 'lons', 'dist', 'heights']:
             assert np.array_equal(one[k], res[k][i * 90:(i + 1) * 90], equal_nan=True), (k, e)
     op.close()
+
+
+def test_c4_full_volume_equals_the_shares_of_eight_ranks_bitwise():
+    """BASELINE configs[3] at its FULL size -- 5 elevations x 360 azimuths x 49 sub-beams x 500 gates,
+    44.1 M sub-beam gates in one launch sequence -- against the same volume computed as the eight
+    contiguous 45-azimuth shares that eight ranks would compute (each share one launch sequence of
+    its rays of all five sweeps): every field bit for bit.  The whole volume is large enough for the
+    scalar-cache form of k_subbeam_sum (32 wavefronts per SIMD and more), the shares take the per-lane
+    gather, so this is also that pair at full size; rays are independent, so nothing else may differ."""
+    from cosmo_pol_amd import RadarOperator
+    over = bench.bench_config(False, 'c4')
+    hyds = list(bench.hydrometeors_of('c4'))
+    cube = synthetic.make_cube(hydrometeors=('R', 'S', 'G', 'I'), **synthetic.BENCH_GRID)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar', lanes=1)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    elevs = np.asarray(bench.C4_ELEVATIONS, dtype=float)
+    az1 = np.arange(0.0, 360.0, 1.0)
+    full = op.simulate_rays(np.tile(az1, len(elevs)), np.repeat(elevs, len(az1)))
+    c = op._ctx.counters()
+    assert full['ZH'].shape == (1800, 500) and c.n_subbeam_gates == 1800 * 49 * 500
+    assert c.n_valid_items > 50e6 and c.n_table_items >= c.n_valid_items - 64
+    names = FIELDS + ['mask', 'lats', 'lons', 'dist', 'heights']
+    full = {k: np.array(full[k], copy=True) for k in names}
+    n_finite = 0
+    for b in range(8):
+        rays = az1[45 * b:45 * (b + 1)]
+        part = op.simulate_rays(np.tile(rays, len(elevs)), np.repeat(elevs, len(rays)))
+        assert op._ctx.counters().n_subbeam_gates == 225 * 49 * 500
+        for s in range(len(elevs)):
+            rows_full = slice(360 * s + 45 * b, 360 * s + 45 * (b + 1))
+            rows_part = slice(45 * s, 45 * (s + 1))
+            for k in names:
+                assert np.array_equal(full[k][rows_full], part[k][rows_part], equal_nan=True), (k, b, s)
+        n_finite += int(np.isfinite(part['ZH']).sum())
+    assert n_finite > 100000
+    op.close()
