@@ -50,3 +50,49 @@ def test_stage_roofline_is_recomputable_from_the_committed_profile(tmp_path, mon
     assert st['interp']['algorithmic_bytes'] == 180000 * (4 * 80 * 4 + 9 * 8 * 4)
     assert st['classify']['traffic'] is None and 'k_itab_fit' not in str(st)
     assert abs(r['whole_sweep']['traffic'] - (29.0e6 + 41.0e6 + 51.0e6)) < 1
+
+
+def test_profile_summary_counts_scalar_cache_reads_in_full(tmp_path):
+    """tools/profile_summary.py: hbm_bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB for kernels that read through
+    the vector caches (rocprofv3 reports half of those bytes on gfx950, profiles/r3_fetch_calibration.txt)
+    but FETCH_SIZE + WRITE_SIZE for k_subbeam_sum<true>, whose coefficient rows come through the scalar
+    cache and are reported in full; the vector rule's figure stays as hbm_bytes_upper."""
+    def counters(d, name, rows):
+        os.makedirs(d)
+        with open(os.path.join(d, 'x_counter_collection.csv'), 'w') as f:
+            f.write('Kernel_Name,Counter_Name,Counter_Value\n')
+            for k, v in rows:
+                f.write('"%s",%s,%g\n' % (k, name, v))
+    coop = 'void k_subbeam_sum<true>(HydroSet, ItabSet, SubsumArgs)'
+    gather = 'void k_subbeam_sum<false>(HydroSet, ItabSet, SubsumArgs)'
+    stats = tmp_path / 'stats.csv'
+    stats.write_text('"Name","Calls","TotalDurationNs","AverageNs"\n"%s",2,4000000,2000000\n"%s",2,1000000,500000\n'
+                     % (coop, gather))
+    counters(str(tmp_path / 'F'), 'FETCH_SIZE', [(coop, 5000.0), (gather, 400.0)])
+    counters(str(tmp_path / 'W'), 'WRITE_SIZE', [(coop, 600.0), (gather, 100.0)])
+    counters(str(tmp_path / 'S'), 'SQ_INSTS_VALU', [(coop, 1e6), (gather, 2e5)])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'profile_summary.py'), str(stats),
+                        str(tmp_path / 'F'), str(tmp_path / 'W'), str(tmp_path / 'S')],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-1000:]
+    d = json.loads(r.stdout)
+    assert d[coop]['hbm_bytes'] == (5000.0 + 600.0) * 1024 and d[coop]['hbm_bytes_upper'] == (2 * 5000.0 + 600.0) * 1024
+    assert d[gather]['hbm_bytes'] == (2 * 400.0 + 100.0) * 1024 and 'hbm_bytes_upper' not in d[gather]
+    assert d[coop]['avg_us'] == 2000.0 and d[coop]['SQ_INSTS_VALU'] == 1e6
+
+
+def test_stage_kernels_cover_every_kernel_of_a_sweep():
+    """Every kernel name of the committed round-3 profiles of a sweep belongs to a stage of bench.py's
+    roofline (or to table building / staging): no kernel's bytes fall out of `roofline.stages`."""
+    import bench
+    known = [k for ks in bench.STAGE_KERNELS.values() for k in ks]
+    integrating = ('k_psd_uniform', 'k_psd<', 'k_psd_ice2', 'k_psd_melting', 'k_spec_', 'k_ml_weights')
+    for name in ('c2_iso', 'c3_el3_iso', 'c4_volume_iso', 'c4_share8_iso'):
+        prof, path = bench.load_profile_summary(name)
+        assert prof is not None and path.endswith('r3_%s_summary.json' % name)
+        for kernel, c in prof.items():
+            if kernel.startswith('_') or not isinstance(c, dict) or kernel.startswith('__amd'):
+                continue
+            if any(t in kernel for t in bench.TABLE_BUILD_KERNELS) or any(t in kernel for t in integrating):
+                continue
+            assert any(k in kernel for k in known), (name, kernel)
