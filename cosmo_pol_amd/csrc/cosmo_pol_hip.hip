@@ -1478,6 +1478,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                             (d.psd_family == CPOL_PSD_MELTING && d.tab_degree == CPOL_MELT_DEGREE) ||
                             (d.psd_family == CPOL_PSD_ICE_FIELD && d.uniform_grid && d.tab_degree == CPOL_ICE_DEGREE)) ? 7 : 6;
     }
+    // (Measured and dropped: this chain -- scan, scatter, the integrating kernels, all idle when every item lies
+    // on a table -- on a sibling stream beside k_psd_lookup, forked and joined with events: the isolated C2 sweep
+    // 122 -> 135 us, the C3 volume 468 -> 476 us, the 225-ray C4 share 1.568 -> 1.553 ms: a cross-stream event
+    // costs the device about as much as the three idle launches it would hide.)
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
     // (a fixed grid: the workgroups stride over the k_classify gate ranges and skip the empty ones)
     const long n_cblk = cdiv(n_sbg, CPOL_CLASSIFY_THREADS);
