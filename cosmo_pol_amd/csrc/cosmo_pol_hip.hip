@@ -118,6 +118,7 @@ struct cpol_ctx {
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
     int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0, last_n_keys = 0;
+    int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
     int subsum_coop = -1;              // CPOL_SUBSUM_COOP: k_subbeam_sum takes its coefficients through the scalar cache: 0 never, 1 always, -1 by launch size
     bool last_subsum = false;          // the 1-D table items of the last sweep never went through res[] (k_subbeam_sum)
     bool keep_debug = false;
@@ -531,6 +532,7 @@ int cpol_create(int device, cpol_ctx **out)
     // CPOL_SUBSUM_COOP=0 / 1: k_subbeam_sum never / always takes the coefficient rows through the scalar cache
     // (default: by launch size; the results are identical)
     if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
+    if (getenv("CPOL_SUBSUM_COOP_ROUNDS")) ctx->subsum_coop_rounds = std::max(0, std::min(64, atoi(getenv("CPOL_SUBSUM_COOP_ROUNDS"))));
     *out = ctx;
     return CPOL_OK;
 }
@@ -628,6 +630,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     }
     c->use_graph = parent->use_graph;
     c->subsum_coop = parent->subsum_coop;
+    c->subsum_coop_rounds = parent->subsum_coop_rounds;
     c->parent = parent;
     c->model_staged = parent->model_staged;
     c->model = parent->model;
@@ -1654,6 +1657,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         int tl = CPOL_TILE_GATES_LOG2;
         while (tl < 6 && (CPOL_WAVE >> tl) > n_rays) ++tl;
         sa2.tile_log2 = tl;
+        sa2.coop_rounds = ctx->subsum_coop_rounds;
         const long tiles = (long)cdiv(n_rays, CPOL_WAVE >> tl) * cdiv(ng, 1 << tl);
         // the scalar-cache form needs many wavefronts per SIMD to hide its waits (C4 volume, rays per sweep:
         // 45 / 90 / 180 / 360 -> PSD stage 1.08 / 1.56 / 2.08 / 3.57 ms against 0.85 / 1.48 / 2.35 / 4.71 ms with

@@ -219,6 +219,9 @@ struct SubsumArgs {
     float *sz_integ;            // [n_rg][n_hydro][12]
     int n_rays, n_gates, n_sub, n_hydro;
     int tile_log2;              // lanes of a wavefront = 2^(6 - tile_log2) rays x 2^tile_log2 gates
+    int coop_rounds;            // COOP: distinct blocks per wavefront and sub-beam through the scalar cache before the
+                                // per-lane gather takes the remaining lanes (6; measured on the C4 volume: every lane
+                                // through that one-row-at-a-time gather 3.2 ms, the normal case 2.04 ms)
 };
 
 #ifndef CPOL_SUBSUM_THREADS
@@ -273,8 +276,10 @@ __device__ __forceinline__ double fma_sgpr(double a, double b, double c_uniform)
 //                 alone helps (lanes on one block share its lines): C4 volume 3.59 -> 3.2 ms.
 //   COOP = true   the wavefront walks over its distinct blocks: the block address is made wave-uniform
 //                 (readlane), the coefficient rows arrive through the SCALAR cache into SGPRs and the lanes
-//                 on that block run their Horner chains with a scalar operand -- no per-lane gather at all,
-//                 56 VGPRs, 8 wavefronts per SIMD.  2.1 ms on the C4 volume; its wavefronts wait for the
+//                 on that block run their Horner chains with a scalar operand -- no per-lane gather for them;
+//                 after `coop_rounds` (6) blocks the lanes still without a value take a one-row-at-a-time
+//                 gather, which bounds a tile of scattered items (91 VGPRs with that tail, 5 wavefronts per
+//                 SIMD; 57 / 7 without it and the same 2.04 ms).  2.0 ms on the C4 volume; its wavefronts wait for the
 //                 scalar cache row pair by row pair (s_load returns out of order: nothing to pipeline
 //                 inside a wavefront; three waves per tile with 4 columns each and the whole block in
 //                 one wait: 5.5-6.0 ms of PSD stage, the scalar cache does not keep up), so it needs many
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
         double2 wv = make_double2(0.0, 0.0);
         // ---- the tile's distinct blocks, one after the other: coefficients through the scalar cache ----
         unsigned long long todo = __builtin_amdgcn_ballot_w64(on_tab);
-        while (COOP && todo) {
+        for (int round = 0; COOP && todo && round < a.coop_rounds; ++round) {
             const int leader = __ffsll((long long)todo) - 1;
             const int b = __builtin_amdgcn_readlane(blk_id, leader);
             const bool mine = blk_id == b;                               // (blk_id = -1 never matches: b >= 0)
@@ -356,13 +361,16 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
             }
             todo &= ~__builtin_amdgcn_ballot_w64(mine);
         }
-        // ---- COOP = false: per-lane gather ----
-        if (!COOP && on_tab) {
+        // ---- per-lane gather: COOP = false; COOP = true: the lanes still without a value after
+        // `coop_rounds` blocks (a tile whose items are scattered over many blocks: noise-like
+        // fields) -- one row at a time there, so that the rare tail costs the common path no registers; it
+        // bounds a wavefront's sub-beam at 6 scalar rounds + one gather instead of up to 64 rounds ----
+        if (on_tab && (!COOP || ((todo >> lane) & 1ull))) {
             const double2 *blk = reinterpret_cast<const double2 *>(t.tab + (long)blk_id * NB);
             // this thread's columns of the block (itab1_columns on a part of the row)
 #pragma unroll
             for (int f = 0; f < NP; ++f) v[f] = blk[(NC - 1) * (NFP / 2) + f0 + f];
-#pragma unroll CPOL_SUBSUM_GATHER_UNROLL
+#pragma unroll (COOP ? 1 : CPOL_SUBSUM_GATHER_UNROLL)
             for (int q = NC - 2; q >= 0; --q) {
 #pragma unroll
                 for (int f = 0; f < NP; ++f) {
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
             }
             if (want_vn) {
                 wv = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
-#pragma unroll
+#pragma unroll (COOP ? 1 : NC - 1)
                 for (int q = NC - 2; q >= 0; --q) {
                     const double2 cq = blk[q * (NFP / 2) + CPOL_N_SZ / 2];
                     wv.x = fma(wv.x, u, cq.x);

@@ -167,6 +167,21 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
                 assert np.array_equal(alone[k][0], res[k][r], equal_nan=True), (k, e, r)
     assert n_valid > 300 and n_melt > 100, (n_valid, n_melt)
     op.close()
+    forms = {}
+    for form in ('gather', 'coop', 'tail'):
+        # 'coop': up to 6 table blocks per wavefront and sub-beam through the scalar cache, the remaining
+        # lanes by the gather tail; 'tail': ONE block that way, every other lane through the tail
+        monkeypatch.setenv('CPOL_SUBSUM_COOP', '0' if form == 'gather' else '1')     # (read when the context is created)
+        monkeypatch.setenv('CPOL_SUBSUM_COOP_ROUNDS', '1' if form == 'tail' else '6')
+        opc = RadarOperator(config=over, luts=luts, output_variables='only_radar', lanes=1)
+        opc.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+        forms[form] = opc.simulate_rays(az, np.full(len(az), 5.0))
+        assert opc._ctx.counters().n_table_items > 100000
+        opc.close()
+    for k in FIELDS:
+        assert np.array_equal(forms['gather'][k], forms['coop'][k], equal_nan=True), k
+        assert np.array_equal(forms['gather'][k], forms['tail'][k], equal_nan=True), k
+        assert np.array_equal(forms['gather'][k], res[k], equal_nan=True), k     # (res: the default choice, last elevation)
 
 
 def test_rhi_and_vprof_api(full):
