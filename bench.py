@@ -278,17 +278,30 @@ def main():
     # sharing).  The process group comes AFTER the lanes for the same reason.
     n_lanes = max(1, int(os.environ.get('CPOL_BENCH_LANES', '3')))
     lanes = [op._lane(i) for i in range(n_lanes)]
-    if world > 1:
+    # (c4 runs the product's distributed path, which needs a process group, at N = 1 as well: a one-rank
+    # group of the same backend -- RCCL executes on every one-GPU run of the workload)
+    # (CPOL_BENCH_FORCE_COLLECTIVES=1: the N > 1 code path of c2 -- process group, all-gather on the side
+    # stream, gather check -- with whatever N is, also 1: how a one-GPU box rehearses the RCCL calls)
+    force = bool(os.environ.get('CPOL_BENCH_FORCE_COLLECTIVES'))
+    grouped = world > 1 or workload == 'c4' or force
+    if grouped:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     env = dict(op=op, lanes=lanes, n_lanes=n_lanes, world=world, rank=rank, local_rank=local_rank,
-               args=args, cube=cube, conf=conf, torch=torch, dist=dist, workload=workload, luts=luts)
+               args=args, cube=cube, conf=conf, torch=torch, dist=dist, workload=workload, luts=luts, force=force)
     out = {'c2': run_c2, 'c3': run_c3, 'c4': run_c4, 'c5': run_c5}[workload](env)
     if rank == 0:
+        out['process_group_backend'] = dist.get_backend() if grouped else None
+        out['n_ranks_seen_by_rccl'] = int(dist.get_world_size()) if grouped and dist.get_backend() == 'nccl' else None
         out['host_placement'] = {'gpu_pci': numa['pci'], 'numa_node': numa['node'],
                                  'cores_bound': numa['bound'], 'cores_allowed': len(os.sched_getaffinity(0)),
                                  'note': 'rank threads restricted to the cores next to the GPU (0 = affinity left as '
@@ -309,8 +322,9 @@ def main():
                     port[0] = sk.getsockname()[1]
             dist.broadcast_object_list(port, src=0)
         dist.barrier()
-        dist.destroy_process_group()
     op.close()
+    if grouped:
+        dist.destroy_process_group()
     if world > 1 and extras:
         # BASELINE configs[3] in the same run: the C4 volume strong-scaled over the same N GPUs
         # (`bench.py --workload c4 --gpus N`, one child per rank, after this rank's operator and
@@ -321,6 +335,10 @@ def main():
                         quiet=rank != 0, timeout=240)   # (own store on the new port: the launcher's serves the old one)
         if rank == 0:
             out['c4_strong_scaling'] = res
+            # the figures that answer north_star's multi-GPU target, at the top level of the line
+            out['c4_speedup_vs_single_gpu'] = (res or {}).get('speedup_vs_single_gpu')
+            out['c4_gather_check'] = (res or {}).get('gather_check')
+            out['c4_collective'] = (res or {}).get('collective')
     if rank == 0:
         if world == 1 and extras:
             # the other BASELINE configurations on this GPU, one child process each (after the c2
@@ -352,7 +370,9 @@ def child_run(workload, flags, env=None, quiet=False, timeout=600):
         keep = {k: d.get(k) for k in ('value', 'unit', 'n_gpus', 'ms_per_step', 'steps', 'warmup', 'scaling',
                                       'gather_check', 'speedup_vs_single_gpu', 'single_gpu_same_workload',
                                       'per_rank', 'roofline', 'setup_s', 'stages_ms', 'counters', 'api_ms', 'per_band',
-                                      'single_sweep_ms', 'host_submit_ms_per_step') if k in d}
+                                      'single_sweep_ms', 'host_submit_ms_per_step', 'collective',
+                                      'collectives_in_timed_region', 'n_ranks_seen_by_backend', 'n_ranks_seen_by_rccl',
+                                      'process_group_backend', 'cpu_baseline') if k in d}
         keep['workload'] = d['config']['workload']
         keep['child_wall_s'] = time.time() - t0
         keep['command'] = 'python bench.py ' + ' '.join(cmd[2:])
@@ -387,7 +407,7 @@ def run_c2(env):
     # GPUs sweep by sweep).  The sweeps are independent: no collective inside a step.  The timed
     # region ends with the one gather north_star names: each rank's last sweep, left in HBM,
     # all-gathered over RCCL on a side stream.
-    weak = world > 1
+    weak = world > 1 or env.get('force', False)
     n_buf = max(2, n_lanes)
     slabs = [torch.empty((len(RADAR_FIELDS), n_rays, n_gates), dtype=torch.float32, device=dev)
              for _ in range(n_buf)]
@@ -485,7 +505,7 @@ def run_c2(env):
 
     extra = {}
     iso = cnt = None
-    if world == 1:
+    if not weak:
         # round 2's headline: fixed elevation, per-ray tables resident, gate coordinates copied once
         for _ in range(2 * n_lanes):
             step_cached()
@@ -543,7 +563,7 @@ def run_c2(env):
         'c2_iso', stage_ms_of(iso), n_sbg, n_valid, n_rays * n_gates, n_vars, nz,
         note='c2 sweep at 1.0 deg elevation: %d valid items, all on integral tables (%d).' % (n_valid, int(iso.n_table_items)))
     roof['psd_stage_ms_with_three_lanes_in_flight'] = cnt.ms_psd
-    if world == 1:
+    if not weak:
         # the integrating kernel itself (it builds the integral tables at staging time and takes the
         # items outside them): a second operator with the tables switched off, one lane
         os.environ['CPOL_ITAB'] = '0'
@@ -810,8 +830,15 @@ def run_c5(env):
 
 # ------------------------------------------------------------------------------------------ c4
 def run_c4(env):
-    """Strong scaling of the C4 volume: the azimuths of every sweep sharded over the ranks; a rank
-    runs its rays of all five sweeps as ONE launch sequence, ONE all-gather per volume."""
+    """Strong scaling of the C4 volume THROUGH THE PRODUCT'S DISTRIBUTED PATH: RadarOperator.submit_volume
+    (what RadarOperator(distributed=True).get_PPI runs) -- the azimuths of every sweep sharded over the
+    ranks, a rank's rays of all five sweeps as ONE launch sequence, ONE collective per volume
+    (cosmo_pol_amd/distributed.py::ShardedVolumeRunner: a gather to rank 0, who alone assembles the volume
+    and copies it to page-locked host memory; CPOL_BENCH_C4_GATHER=all: an all-gather, every rank receives
+    and copies), nothing waits: consecutive volumes alternate over the lanes, so that the collective and
+    the copy of volume k overlap the kernels of volume k + 1.  The nine polarimetric observables travel
+    (36 B per gate); `api_ms.get_PPI_distributed` times the blocking drop-in call with all 15 arrays."""
+    import collections
     from cosmo_pol_amd.distributed import VolumeLayout
     op, lanes, n_lanes, world, rank = env['op'], env['lanes'], env['n_lanes'], env['world'], env['rank']
     args, torch, dist, cube = env['args'], env['torch'], env['dist'], env['cube']
@@ -822,62 +849,25 @@ def run_c4(env):
     sweeps = [(az_all, np.full(n_az, e)) for e in C4_ELEVATIONS]
     fields = [(k, np.float32) for k in RADAR_FIELDS]
     lay = VolumeLayout(fields, [n_az] * n_el, world, n_gates)
-    nb = lay.block.nbytes
     az, el = lay.local_rays(rank, sweeps)
     n_loc = len(az) // n_el
-    # CPOL_BENCH_C4_MODE=sweeps: round 2's form (one launch sequence and one all-gather per sweep, the
-    # sweeps of a volume on alternating lanes) for comparison
-    per_sweep_mode = os.environ.get('CPOL_BENCH_C4_MODE', 'volume') == 'sweeps'
-    n_buf = max(2, n_lanes)
-    blocks = [torch.zeros(nb, dtype=torch.uint8, device=dev) for _ in range(n_buf)]
-    gathered = [torch.empty(world * nb, dtype=torch.uint8, device=dev) for _ in range(n_buf)] if world > 1 else blocks
-    host = torch.empty(world * nb, dtype=torch.uint8).pin_memory() if rank == 0 else None
-    ptrs = [{k: b.data_ptr() + lay.block.offsets[k] for k, _ in fields} for b in blocks]
-    lane_streams = [torch.cuda.ExternalStream(c.stream_ptr(), device=dev) for c in lanes]
-    comm = torch.cuda.Stream(device=dev)
-    block_free = [None] * n_buf
+    op.lanes = n_lanes                                  # (the runner keeps lanes + 1 sets of device buffers)
+    op.gather_to = None if os.environ.get('CPOL_BENCH_C4_GATHER', 'root') == 'all' else 0
+    runner = op._dist_runner()
+    pending = collections.deque()
+    last = [None]
     counter = [0]
-
-    def sweep_ptrs(b, e):
-        row = e * n_loc * n_gates * 4
-        return {k: p + row for k, p in ptrs[b].items()}
 
     def volume():
         k = counter[0]
         counter[0] += 1
-        b = k % n_buf
-        if per_sweep_mode:
-            used = []
-            for e in range(n_el):
-                lane = (k * n_el + e) % n_lanes
-                if block_free[b] is not None:
-                    lane_streams[lane].wait_event(block_free[b])
-                if n_loc > 0:
-                    op.simulate_rays(az[e * n_loc:(e + 1) * n_loc], el[e * n_loc:(e + 1) * n_loc],
-                                     device_outputs=sweep_ptrs(b, e), lane=lane)
-                used.append(lane)
-            for lane in set(used):
-                done = torch.cuda.Event()
-                done.record(lane_streams[lane])
-                comm.wait_event(done)
-        else:
-            lane = k % n_lanes
-            if block_free[b] is not None:
-                lane_streams[lane].wait_event(block_free[b])          # its last gather has read the block
-            if n_loc > 0:
-                op.simulate_rays(az, el, device_outputs=ptrs[b], lane=lane)   # 5 elevations, one launch sequence
-            done = torch.cuda.Event()
-            done.record(lane_streams[lane])
-            comm.wait_event(done)
-        with torch.cuda.stream(comm):
-            if world > 1:
-                dist.all_gather_into_tensor(gathered[b], blocks[b])   # ONE collective per volume
-            if rank == 0:
-                host.copy_(gathered[b], non_blocking=True)
-            block_free[b] = torch.cuda.Event()
-            block_free[b].record(comm)
+        pending.append(op.submit_volume(sweeps, fields=RADAR_FIELDS, lane=k % n_lanes))
+        while len(pending) > n_lanes:                   # results older than the lanes in flight: complete by now
+            last[0] = pending.popleft().wait() or last[0]
 
     def fence():
+        while pending:
+            last[0] = pending.popleft().wait() or last[0]
         for i in range(n_lanes):
             op.wait(i)
         torch.cuda.synchronize()
@@ -885,25 +875,44 @@ def run_c4(env):
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:
-        with torch.cuda.stream(comm):                 # communicator set-up is setup, not a step
-            dist.all_gather_into_tensor(gathered[0], blocks[0])
+    volume()                                            # communicator set-up is setup, not a step
     fence()
-    for _ in range(max(args.warmup, n_lanes)):        # (every lane's work buffers exist)
+    for _ in range(max(args.warmup, n_lanes)):          # (every lane's work buffers exist)
         volume()
     fence()
+    n_coll0 = runner.n_collectives
     t0 = time.perf_counter()
     for _ in range(args.steps):
         volume()
     t_submit = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
+    n_coll = runner.n_collectives - n_coll0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     gates_per_step = n_el * n_az * n_gates
     value = gates_per_step * args.steps / elapsed
+    gathered_volume = last[0]                           # rank 0 (or every rank): the last volume of the timed region
+
+    # the blocking drop-in call on every rank: RadarOperator(distributed=True).get_PPI, all 15 arrays
+    op.distributed = True
+    api = []
+    with contextlib.redirect_stdout(sys.stderr):
+        op.get_PPI(C4_ELEVATIONS, azimuths=az_all)
+        for _ in range(max(3, args.steps // 3)):
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            op.get_PPI(C4_ELEVATIONS, azimuths=az_all)
+            api.append(1e3 * (time.perf_counter() - t0))
+    op.distributed = False
+    fence()
+    ptrs0 = None
+    if n_loc > 0:
+        blk0 = torch.zeros(lay.block.nbytes, dtype=torch.uint8, device=dev)
+        ptrs0 = {k: blk0.data_ptr() + lay.block.offsets[k] for k, _ in fields}
 
     # per-rank work of one volume (untimed pass, one lane, events around every stage)
     mine = {'rank': rank, 'rays_per_sweep': n_loc}
@@ -911,7 +920,7 @@ def run_c4(env):
     if n_loc > 0:
         op._ctx.enable_timing(True)
         for _ in range(3):
-            op.simulate_rays(az, el, device_outputs=ptrs[0], lane=0)
+            op.simulate_rays(az, el, device_outputs=ptrs0, lane=0)
         op.wait(0)
         iso = op._ctx.counters()
         op._ctx.enable_timing(False)
@@ -945,8 +954,9 @@ def run_c4(env):
                   'note': 'rank 0 runs the whole 5 x %d-ray volume alone after the timed region (one launch '
                           'sequence, outputs left in HBM)' % n_az}
         ref = lay1.assemble(full.cpu().numpy())
-        got = lay.assemble(host.numpy())
-        gather_ok = all(np.array_equal(got[s][k], ref[s][k], equal_nan=True) for s in range(n_el) for k, _ in fields)
+        got = gathered_volume
+        gather_ok = bool(got is not None and all(np.array_equal(got[s][k], ref[s][k], equal_nan=True)
+                                                 for s in range(n_el) for k, _ in fields))
     fence()
     if rank != 0:
         return None
@@ -970,11 +980,12 @@ def run_c4(env):
                                % (C4_ELEVATIONS, n_az, n_gates, 'x'.join(map(str, cube['zlevels'].shape))),
                    'rays_per_gpu_per_sweep': lay.bounds[0][0][1] - lay.bounds[0][0][0], 'gates_per_ray': n_gates,
                    'sub_beams': 49, 'lanes': n_lanes,
-                   'parallelism': ('azimuths of every sweep sharded in contiguous blocks of ceil(360/N) rays; a rank runs '
-                                   'its rays of all 5 sweeps as one launch sequence (consecutive volumes on alternating '
-                                   'lanes); ONE all-gather of the device blocks per volume (RCCL), rank 0 copies the '
-                                   'assembled volume to page-locked host memory') if not per_sweep_mode else
-                                  'CPOL_BENCH_C4_MODE=sweeps: one launch sequence and one all-gather per sweep',
+                   'parallelism': 'RadarOperator.submit_volume (the path of RadarOperator(distributed=True).get_PPI): '
+                                  'azimuths of every sweep sharded in contiguous blocks of ceil(360/N) rays; a rank runs '
+                                  'its rays of all 5 sweeps as one launch sequence (consecutive volumes on alternating '
+                                  'lanes); ONE collective of the device blocks per volume (%s); the receiving rank puts '
+                                  'the rows into scan order on the device and copies the volume (9 float32 fields) to '
+                                  'page-locked host memory' % runner.collective,
                    'small': bool(args.small)},
         'roofline': roof,
         'per_rank': per_rank,
@@ -984,6 +995,14 @@ def run_c4(env):
         'speedup_vs_single_gpu': (value / single['value']) if single else None,
         'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
         'gather_check': gather_ok,
+        'collective': runner.collective,
+        'collectives_in_timed_region': n_coll,
+        'n_ranks_seen_by_backend': int(dist.get_world_size()),
+        'api_ms': {'get_PPI_distributed_median': statistics.median(api), 'get_PPI_distributed_min': min(api),
+                   'note': 'RadarOperator(distributed=True%s).get_PPI(5 elevations) on every rank, blocking: the same '
+                           'sharded launch sequence and collective with all 15 arrays of the scan (76 B per gate), '
+                           'RadarScan packaging on the receiving rank(s); wall time on rank 0'
+                           % ('' if op.gather_to is None else ', gather_to=0')},
     }
 
 

@@ -312,21 +312,31 @@ class PinnedPool(object):
     MAX_PENDING = 8             # blocks of one size class that may wait for foreign copies before the pool waits
 
     def __init__(self, device=None):
+        import collections
         import threading
         self.lib = load_library()
         self.device = device        # blocks come from the NUMA node next to this GPU (None: the current device's)
-        self.free = {}              # size class -> [(address, context or None)]
+        self.free = {}              # size class -> [(address, context or None, serial)]
+        self.returned = collections.deque()     # blocks handed back by finalizers, not yet sorted into `free`
         self.lock = threading.Lock()
         self.closed = False
         self.n_alloc = 0
 
     def _release(self, addr, size, holder):
-        with self.lock:
-            if not self.closed:
-                ctx = holder.get('ctx')
-                self.free.setdefault(size, []).append((addr, ctx, holder.get('serial', 0)))
+        # Runs as a weakref finalizer: on ANY thread, possibly inside a garbage collection triggered by an
+        # allocation made while that thread holds self.lock (a result kept alive only by a reference cycle).
+        # So it never takes the lock: deque.append / popleft are atomic, take() sorts the blocks in.
+        self.returned.append((addr, size, holder.get('ctx'), holder.get('serial', 0)))
+        if self.closed:
+            self._free_returned()
+
+    def _free_returned(self):
+        while True:
+            try:
+                addr = self.returned.popleft()[0]
+            except IndexError:
                 return
-        self.lib.cpol_host_free(None, C.c_void_p(addr))
+            self.lib.cpol_host_free(None, C.c_void_p(addr))
 
     @staticmethod
     def _clean(ctx, serial):
@@ -345,6 +355,12 @@ class PinnedPool(object):
         size = max(1, -(-int(nbytes) // self.GRANULE)) * self.GRANULE
         addr = wait_for = None
         with self.lock:
+            while True:                                                   # blocks handed back since the last call
+                try:
+                    a, sz, c, ser = self.returned.popleft()
+                except IndexError:
+                    break
+                self.free.setdefault(sz, []).append((a, c, ser))
             lst = self.free.get(size) or []
             pick = None
             for i, (a, c, ser) in enumerate(lst):                    # oldest first
@@ -382,6 +398,7 @@ class PinnedPool(object):
             self.free = {}
         for a in blocks:
             self.lib.cpol_host_free(None, C.c_void_p(a))
+        self._free_returned()
 
 
 class Context(object):

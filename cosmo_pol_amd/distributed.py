@@ -13,17 +13,20 @@ identical to the single-GPU result.
 Block layout (what one rank contributes, `BlockLayout`): for every output field
 a [per, n_gates] array of the field's dtype, the fields one after the other at
 8-byte aligned offsets; `per` = ceil(n_rays / world) rows, the unused rows of
-the tail ranks stay zero.  The kernels write their outputs straight into the
-block on the device (`simulate_sharded_device`), the all-gather runs on device
-buffers, and ONE device-to-host copy returns the whole sweep.
+the tail ranks stay zero.
 
-A scan of several sweeps (a PPI volume, a set of RHIs) is sharded as a whole
-(`VolumeLayout`, `simulate_sharded_volume_device`): a rank takes its contiguous ray block
-of EVERY sweep, runs them as one launch sequence (rays of different elevations in one
-cpol_run_sweep call), and a single all-gather at the end of the volume assembles all
-sweeps on every rank -- 10 kernel launches and one collective per volume instead of 10
-launches and one collective per sweep.
+A scan of several sweeps (a PPI volume, a set of RHIs; one sweep is the special case) is
+sharded as a whole (`VolumeLayout`, `ShardedVolumeRunner`): a rank takes its contiguous ray
+block of EVERY sweep, runs them as one launch sequence (rays of different elevations in one
+cpol_run_sweep call) whose kernels write straight into the rank's block on the device, and
+ONE collective at the end of the scan collects the blocks -- an all-gather (every rank gets
+the scan) or a gather to one root (`gather_to`: the other ranks receive and copy nothing).
+The receiving rank puts the rows into scan order on the device and copies the scan to
+page-locked host memory once.  `submit` does not wait: the collective and the copy of scan k
+overlap the kernels of scan k + 1.
 """
+import contextlib
+
 import numpy as np
 
 
@@ -112,49 +115,6 @@ def simulate_sharded(simulate, azimuths, elevations, fields, n_gates, device=Non
     if device is not None:
         t = t.to(device)
     return lay.assemble(gather_blocks(t, group).cpu().numpy(), n, world)
-
-
-def simulate_sharded_device(run_block, stream_ptr, azimuths, elevations, fields, n_gates, device,
-                            group=None, cache=None):
-    """Device-resident form (the product path of RadarOperator(distributed=True)):
-
-      run_block(az_block, el_block, {field: device pointer})   queues the sweep of this
-          rank's rays on the library stream `stream_ptr`; the kernels write every output
-          field straight into this rank's block of the gather buffer layout;
-      one all_gather_into_tensor of the device blocks (RCCL over xGMI), ordered behind the
-          kernels with an event;
-      one device-to-host copy of the gathered sweep.
-
-    `cache`: dict owned by the caller that keeps the device block / gather buffers between
-    sweeps of the same shape."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    az = np.asarray(azimuths, dtype=np.float64)
-    el = np.asarray(elevations, dtype=np.float64)
-    n = len(az)
-    lo, hi, per = shard_bounds(n, world, rank)
-    lay = BlockLayout(fields, per, n_gates)
-    cache = {} if cache is None else cache
-    key = ('blk', lay.nbytes, world)
-    if key not in cache:
-        cache.clear()
-        cache[key] = (torch.zeros(lay.nbytes, dtype=torch.uint8, device=device),
-                      torch.empty(world * lay.nbytes, dtype=torch.uint8, device=device),
-                      torch.empty(world * lay.nbytes, dtype=torch.uint8).pin_memory()
-                      if torch.cuda.is_available() else torch.empty(world * lay.nbytes, dtype=torch.uint8))
-    block, gathered, host = cache[key]
-    lib_stream = torch.cuda.ExternalStream(stream_ptr, device=device)
-    cur = torch.cuda.current_stream(device)
-    lib_stream.wait_stream(cur)                 # the previous gather has consumed the block
-    if hi > lo:
-        base = block.data_ptr()
-        run_block(az[lo:hi], el[lo:hi], {k: base + lay.offsets[k] for k, _ in lay.fields})
-    cur.wait_stream(lib_stream)                 # gather behind the kernels
-    dist.all_gather_into_tensor(gathered, block, group=group)
-    host.copy_(gathered, non_blocking=True)
-    cur.synchronize()
-    return lay.assemble(host.numpy(), n, world)
 
 
 class VolumeLayout(object):
@@ -269,47 +229,171 @@ def simulate_sharded_volume(simulate, sweeps, fields, n_gates, device=None, grou
     return lay.assemble(gather_blocks(t, group).cpu().numpy())
 
 
+class PendingVolume(object):
+    """A sharded scan in flight (`ShardedVolumeRunner.submit`).  `wait()` blocks until this rank's part of
+    the collective and, on a receiving rank, the device-to-host copy are complete and returns the per-sweep
+    dicts of [n_rays_s, n_gates] arrays -- views of ONE page-locked block, which lives as long as one of
+    them does -- or None on a rank that is not the root of a rooted gather."""
+
+    def __init__(self, layout, arr, event, keep=None):
+        self._lay, self._arr, self._event, self._keep = layout, arr, event, keep
+
+    def done(self):
+        return self._event is None or bool(self._event.query())
+
+    def wait(self):
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+        self._keep = None
+        return None if self._arr is None else self._lay.views_of_final(self._arr)
+
+    def __del__(self):
+        # a dropped, never awaited result: its block must not return to the pool under a copy in flight
+        try:
+            if self._event is not None:
+                self._event.synchronize()
+        except Exception:
+            pass
+
+
+class ShardedVolumeRunner(object):
+    """Device-resident volume sharding, the product path of RadarOperator(distributed=True) and what
+    `bench.py --workload c4` times.  Per scan (`submit`):
+
+      run_block(az, el, {field: device pointer})   queues ONE launch sequence for this rank's rays of all
+          sweeps on the library stream; the kernels write straight into this rank's block of the gather
+          layout (`VolumeLayout`);
+      ONE collective behind it on the runner's own stream (RCCL over xGMI with backend "nccl"):
+          gather_to = None   all_gather_into_tensor -- every rank receives the whole scan;
+          gather_to = r      gather to rank r -- the other ranks send their block and are done: they
+                             receive nothing, assemble nothing and copy nothing to their hosts;
+      on a receiving rank the gathered rows are put into scan order ON THE DEVICE (one row gather per
+          field) and ONE device-to-host copy lands them in a page-locked block (`host_block`).
+
+    Nothing waits: `submit` returns a `PendingVolume`.  The device buffers of a scan shape exist
+    `slots` times and are used in turn, so that the collective and the copy of scan k (runner stream)
+    overlap the kernels of scan k + 1 (library stream of another lane); a slot is handed to a new scan
+    only behind the event that ends its previous use.  Only the fields named in `fields` travel.
+    On CPU tensors (gloo tests) the same code runs synchronously."""
+
+    def __init__(self, device, group=None, gather_to=None, slots=3):
+        import torch
+        import torch.distributed as dist
+        self.device = torch.device(device)
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if gather_to is not None and not 0 <= int(gather_to) < self.world:
+            raise ValueError('gather_to = %r: not a rank of this group (world size %d)' % (gather_to, self.world))
+        self.root = None if gather_to is None else int(gather_to)
+        self.cuda = self.device.type == 'cuda'
+        self.comm = torch.cuda.Stream(self.device) if self.cuda else None
+        self.n_slots = max(1, int(slots))
+        backend = dist.get_backend(group)
+        # gloo has no rooted gather of device tensors (tests on a one-GPU box): all-gather there, and
+        # still only the root assembles and copies
+        self.rooted = self.root is not None and (backend == 'nccl' or not self.cuda)
+        self.collective = ('gather(dst=%d)' % self.root if self.rooted else 'all_gather_into_tensor') + ' / ' + backend
+        self.receives = self.root is None or self.rank == self.root
+        self._key = None
+        self._slots = []
+        self._turn = 0
+        self._lib = {}
+        self.n_collectives = 0
+
+    def _layout(self, sweeps, fields, n_gates):
+        key = (tuple(len(a) for a, _ in sweeps), tuple((k, str(dt)) for k, dt in fields), int(n_gates))
+        if key != self._key:
+            import torch
+            self.drain()
+            lay = VolumeLayout(fields, key[0], self.world, n_gates)
+            rk, rw = lay.source_rows()
+            self._lay = lay
+            self._index = ((torch.from_numpy(rk).to(self.device), torch.from_numpy(rw).to(self.device))
+                           if self.receives else None)
+            self._slots = []
+            self._key = key
+        return self._lay
+
+    def _slot(self, lay):
+        import torch
+        i = self._turn % self.n_slots
+        self._turn += 1
+        while len(self._slots) <= i:
+            nb = lay.block.nbytes
+            gets_all = self.receives or not self.rooted       # (an all-gather delivers to every rank)
+            self._slots.append({
+                'block': torch.zeros(nb, dtype=torch.uint8, device=self.device),
+                'gathered': torch.empty(self.world * nb, dtype=torch.uint8, device=self.device) if gets_all else None,
+                'final': torch.empty(lay.final.nbytes, dtype=torch.uint8, device=self.device) if self.receives else None,
+                'free': None})
+        return self._slots[i]
+
+    def drain(self):
+        """Waits for everything queued on the runner's stream."""
+        if self.cuda:
+            self.comm.synchronize()
+
+    def submit(self, run_block, stream_ptr, sweeps, fields, n_gates, host_block=None):
+        """-> PendingVolume.  `stream_ptr`: the library stream (hipStream_t) `run_block` queues its kernels
+        on.  `host_block(nbytes) -> (uint8 array, holder)`: where the result lives (the operator's PinnedPool)."""
+        import torch
+        import torch.distributed as dist
+        lay = self._layout(sweeps, fields, n_gates)
+        slot = self._slot(lay)
+        nb, nf = lay.block.nbytes, lay.final.nbytes
+        block = slot['block']
+        lib = None
+        if self.cuda:
+            lib = self._lib.get(stream_ptr)
+            if lib is None:
+                lib = self._lib[stream_ptr] = torch.cuda.ExternalStream(stream_ptr, device=self.device)
+            if slot['free'] is not None:
+                lib.wait_event(slot['free'])           # the slot's last collective / copy have read its buffers
+        az, el = lay.local_rays(self.rank, sweeps)
+        if len(az):
+            base = block.data_ptr()
+            run_block(az, el, {k: base + lay.block.offsets[k] for k, _ in lay.block.fields})
+        arr = None
+        if self.receives:
+            arr = host_block(nf)[0][:nf] if host_block is not None else np.empty(nf, dtype=np.uint8)
+        ctx = contextlib.nullcontext()
+        if self.cuda:
+            computed = torch.cuda.Event()
+            computed.record(lib)
+            self.comm.wait_event(computed)             # the collective behind the kernels
+            ctx = torch.cuda.stream(self.comm)
+        with ctx:
+            if self.rooted:
+                parts = ([slot['gathered'][r * nb:(r + 1) * nb] for r in range(self.world)]
+                         if self.receives else None)
+                dist.gather(block, gather_list=parts, dst=self.root, group=self.group)
+                gathered = slot['gathered']
+            else:
+                dist.all_gather_into_tensor(slot['gathered'], block, group=self.group)
+                gathered = slot['gathered']
+            self.n_collectives += 1
+            if self.receives:
+                # rows -> their place in the scan ON THE DEVICE, then ONE copy into the page-locked block the
+                # returned arrays are views of (no host-side concatenation)
+                lay.assemble_on_device(gathered, slot['final'], self._index)
+                torch.from_numpy(arr).copy_(slot['final'], non_blocking=True)
+            event = None
+            if self.cuda:
+                event = torch.cuda.Event()
+                event.record(self.comm)
+                slot['free'] = event
+        return PendingVolume(lay, arr, event)
+
+
 def simulate_sharded_volume_device(run_block, stream_ptr, sweeps, fields, n_gates, device, group=None,
-                                   cache=None, host_block=None):
-    """Device-resident volume sharding (the product path of RadarOperator(distributed=True)):
-    `run_block(az, el, {field: device pointer})` queues ONE launch sequence for this rank's rays of
-    all sweeps on the library stream; one all_gather_into_tensor of the device blocks (RCCL over
-    xGMI) behind it; the gathered rows put into scan order on the device; one device-to-host copy.
-    `host_block(nbytes) -> (uint8 array, holder)`: where the result lives (the operator's PinnedPool; the
-    returned arrays are views of it).  -> list of per-sweep dicts."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    lay = VolumeLayout(fields, [len(a) for a, _ in sweeps], world, n_gates)
-    nb = lay.block.nbytes
+                                   cache=None, host_block=None, gather_to=None):
+    """Blocking form of `ShardedVolumeRunner.submit` (one scan, then wait).  `cache`: dict of the caller that
+    keeps the runner -- its device buffers and stream -- between scans.  -> list of per-sweep dicts, or None
+    on a rank other than `gather_to`."""
     cache = {} if cache is None else cache
-    nf = lay.final.nbytes
-    key = ('blk', nb, nf, world, tuple(lay.n_rays))
+    key = ('runner', str(device), gather_to, id(group))
     if key not in cache:
         cache.clear()
-        rk, rw = lay.source_rows()
-        cache[key] = (torch.zeros(nb, dtype=torch.uint8, device=device),
-                      torch.empty(world * nb, dtype=torch.uint8, device=device),
-                      torch.empty(nf, dtype=torch.uint8, device=device),
-                      (torch.from_numpy(rk).to(device), torch.from_numpy(rw).to(device)))
-    block, gathered, final, index = cache[key]
-    lib_stream = torch.cuda.ExternalStream(stream_ptr, device=device)
-    cur = torch.cuda.current_stream(device)
-    lib_stream.wait_stream(cur)                 # the previous gather has consumed the block
-    az, el = lay.local_rays(rank, sweeps)
-    if len(az):
-        base = block.data_ptr()
-        run_block(az, el, {k: base + lay.block.offsets[k] for k, _ in lay.block.fields})
-    cur.wait_stream(lib_stream)                 # gather behind the kernels
-    dist.all_gather_into_tensor(gathered, block, group=group)
-    # rows -> their place in the scan ON THE DEVICE (one row gather per field), then ONE copy into a
-    # fresh page-locked block that the returned arrays are views of (no host-side concatenation: that was
-    # 70 MB read + written per C4 volume on every rank, ten times the rank's kernel time)
-    lay.assemble_on_device(gathered, final, index)
-    if host_block is not None:
-        arr = host_block(nf)[0][:nf]            # (the block lives as long as a view of it does)
-    else:
-        arr = np.empty(nf, dtype=np.uint8)
-    torch.from_numpy(arr).copy_(final, non_blocking=True)
-    cur.synchronize()
-    return lay.views_of_final(arr)
+        cache[key] = ShardedVolumeRunner(device, group=group, gather_to=gather_to)
+    return cache[key].submit(run_block, stream_ptr, sweeps, fields, n_gates, host_block).wait()

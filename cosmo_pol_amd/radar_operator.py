@@ -197,7 +197,7 @@ class RadarOperator(object):
     _table_serial = 0          # tags of per-ray table sets handed to the library
 
     def __init__(self, options_file=None, output_variables='all', *, device=0, lut_dir=None,
-                 luts=None, config=None, distributed=False, lanes=2, backend='hip',
+                 luts=None, config=None, distributed=False, gather_to=None, lanes=2, backend='hip',
                  pyart_output=False):
         if backend != 'hip':
             # by design: the product path is the HIP library or nothing (no CPU fallback)
@@ -206,10 +206,15 @@ class RadarOperator(object):
                                 % (backend,))
         print('Reading options defined in options file')
         self._ctx = N.Context(device)         # raises if the HIP library / GPU is missing
+        self._affinity_before = None
         if distributed:
             # one process per GPU: run this rank's threads next to its GPU (CPOL_NUMA_BIND=0: leave the
-            # affinity alone); the reference's worker pool is not placed at all (radar_operator.py:402)
+            # affinity alone; close() restores what the thread had before); the reference's worker pool is
+            # not placed at all (radar_operator.py:402)
+            before = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
             self.numa = N.bind_to_device_numa_node(device)
+            if self.numa.get('bound'):
+                self._affinity_before = before
         self._pool = N.PinnedPool(device)     # page-locked blocks of the results handed to the user
         # lanes: contexts forked from _ctx (shared cube / tables, own stream + work buffers);
         # the sweeps of a volume scan are spread over them so that they overlap on the GPU
@@ -218,6 +223,9 @@ class RadarOperator(object):
         self._lock = threading.RLock()
         self.device = device
         self.distributed = bool(distributed)   # shard the rays of every sweep over the ranks
+        self.gather_to = gather_to             # distributed scans: None = every rank gets the scan (all-gather);
+                                               # r = rank r alone does (gather; get_PPI returns None elsewhere)
+        self._runner = None
         self.pyart_output = bool(pyart_output) # get_PPI / get_RHI return a pyart.core.Radar (needs Py-ART)
         self.reuse_device_tables = True        # keep per-ray tables in HBM between equal sweeps
         self.volume_in_one_sequence = True     # get_PPI / get_RHI: all sweeps of a scan in one launch sequence
@@ -305,9 +313,18 @@ class RadarOperator(object):
                 self._drop_lanes()
             except IndexError as e:           # a queued sweep left the model domain and nobody waited for it
                 print('RadarOperator.close: %s' % e)
+            if self._runner is not None:
+                self._runner.drain()
+                self._runner = None
             self._ctx.close()
             self._ctx = None
             self._pool.close()                # (blocks of results still held are freed with their last view)
+            if self._affinity_before is not None:
+                try:
+                    os.sched_setaffinity(0, self._affinity_before)
+                except OSError:
+                    pass
+                self._affinity_before = None
         self.dic_vars = None
         self.lut_sz = None
         self.__config = None
@@ -703,7 +720,10 @@ class RadarOperator(object):
         after the other (radar_operator.py:429-432); here up to `lanes` of them are in
         flight together, one host thread per lane (the library calls release the GIL)."""
         if self.distributed:
-            return [self._package(r, az, el) for r, (az, el) in zip(self._simulate_volume_sharded(sweeps), sweeps)]
+            res = self._simulate_volume_sharded(sweeps)
+            if res is None:
+                return None                   # gather_to: this rank computed its share, another holds the scan
+            return [self._package(r, az, el) for r, (az, el) in zip(res, sweeps)]
         if self.volume_in_one_sequence and len(sweeps) > 1:
             # all sweeps of the scan as ONE launch sequence (rays of different elevations / azimuths in one
             # cpol_run_sweep call): one submission, 7-12 kernel launches and one device-to-host copy per
@@ -743,32 +763,55 @@ class RadarOperator(object):
         """All rays of a sweep on this GPU."""
         return self.simulate_rays(az, el, lane=lane)
 
-    def _simulate_volume_sharded(self, sweeps, lane=0):
-        """All sweeps of a scan, the rays of every sweep sharded over the ranks of the default
-        torch.distributed group: this rank's rays of ALL sweeps in one launch sequence and ONE
-        all-gather per scan (cosmo_pol_amd/distributed.py).  -> list of per-sweep result dicts."""
-        import torch
-        from . import distributed as D
+    def _dist_runner(self):
+        """The operator's ShardedVolumeRunner (device buffers, the stream of the collectives)."""
+        if self._runner is None:
+            import torch
+            from . import distributed as D
+            self._runner = D.ShardedVolumeRunner(torch.device('cuda', self.device), gather_to=self.gather_to,
+                                                 slots=max(2, self.lanes + 1))
+        return self._runner
+
+    def _scan_fields(self, fields=None):
+        """(name, dtype) of the arrays a distributed scan collects: all of them, or the subset named."""
+        every = ([(k, np.float32) for k in RADAR_FIELDS] + [('dist', np.float32), ('heights', np.float32),
+                 ('mask', np.float64), ('lats', np.float64), ('lons', np.float64)])
+        if self.__config['doppler']['scheme'] in (1, 2, 3) and self.__config['radar'].get('type') != 'GPM':
+            every.append(('RVEL', np.float64))               # (the spectrum itself is not gathered)
+        if fields is None:
+            return every
+        known = dict(every)
+        for k in fields:
+            if k not in known:
+                raise ValueError('distributed scans collect %s; %r is not one of them' % (sorted(known), k))
+        return [(k, known[k]) for k in fields]
+
+    def submit_volume(self, sweeps, fields=None, lane=0):
+        """Queues a scan [(azimuths, elevations), ...] whose rays are sharded over the ranks of the default
+        torch.distributed group and returns at once: this rank's rays of ALL sweeps in one launch sequence
+        on lane `lane`, ONE collective behind it (cosmo_pol_amd/distributed.py: all-gather, or a gather to
+        rank `gather_to`), the device-to-host copy behind that.  -> PendingVolume: `wait()` gives the list of
+        per-sweep result dicts (None on a rank that is not `gather_to`).  `fields`: the arrays to collect
+        (default: all).  Scans submitted on different lanes overlap: the collective and the copy of one run
+        beside the kernels of the next.  Every rank must submit the same scans in the same order."""
         if self.output_variables != 'only_radar':
             raise NotImplementedError('distributed sweeps return the radar observables only '
                                       "(use output_variables='only_radar')")
-        fields = ([(k, np.float32) for k in RADAR_FIELDS] + [('dist', np.float32),
-                  ('heights', np.float32), ('mask', np.float64), ('lats', np.float64),
-                  ('lons', np.float64)])
-        if self.__config['doppler']['scheme'] in (1, 2, 3):     # (the spectrum itself is not gathered)
-            fields.append(('RVEL', np.float64))
         n_gates = len(self.constants.RANGE_RADAR)
-        dev = torch.device('cuda', self.device)
-        # device-resident: the kernels write this rank's rays straight into its block of the
-        # gather buffer, one all-gather of device blocks, one device-to-host copy of the volume
         ctx = self._lane(lane)
-        cache = self.__dict__.setdefault('_dist_cache', {})
 
         def run_block(a, e, ptrs):
             self.simulate_rays(a, e, device_outputs=ptrs, lane=lane)
-        res = D.simulate_sharded_volume_device(run_block, ctx.stream_ptr(), sweeps, fields, n_gates, dev,
-                                               cache=cache, host_block=self._pool.take)
-        ctx.synchronize()                                       # deferred domain error, if any
+        return self._dist_runner().submit(run_block, ctx.stream_ptr(), sweeps, self._scan_fields(fields), n_gates,
+                                          host_block=self._pool.take)
+
+    def _simulate_volume_sharded(self, sweeps, lane=0):
+        """All sweeps of a scan, the rays of every sweep sharded over the ranks (`submit_volume`, then
+        wait).  -> list of per-sweep result dicts, or None on a rank other than `gather_to`."""
+        res = self.submit_volume(sweeps, lane=lane).wait()
+        self._lane(lane).synchronize()                          # deferred domain error, if any
+        if res is None:
+            return None
         sub = self._cached('sub', lambda: quadrature.subbeams(self.__config))
         for r in res:
             r['n_sub'] = sub.n_sub
@@ -777,35 +820,32 @@ class RadarOperator(object):
     def _swath_sharded(self, az, el, coords, n_gates, range0, site, sub, traj, geo_t, dim, lane=0):
         """A spaceborne swath with its SCAN LINES sharded over the ranks in contiguous blocks:
         a rank runs the rays of its scan lines as one launch sequence into its block of the gather buffer,
-        ONE all-gather, rows put into swath order on the device, one copy.  Every rank gets the whole
-        swath, bitwise equal to the single-GPU one.  (The swath geometry -- angles, first gates -- is
+        ONE collective, rows put into swath order on the device, one copy.  Every rank (or rank `gather_to`
+        alone) gets the whole swath, bitwise equal to the single-GPU one.  (The swath geometry -- angles, first gates -- is
         computed by every rank: host work of milliseconds, cached per swath.)"""
-        import torch
         import torch.distributed as dist
         from . import distributed as D
         if self.output_variables != 'only_radar':
             raise NotImplementedError('distributed swaths return the radar observables only '
                                       "(use output_variables='only_radar')")
         n_scans, per_scan = dim
-        fields = ([(k, np.float32) for k in RADAR_FIELDS] + [('dist', np.float32), ('heights', np.float32),
-                  ('mask', np.float64), ('lats', np.float64), ('lons', np.float64)])
+        fields = self._scan_fields()
         row = per_scan * n_gates                      # one row of the layout = one scan line
-        lay = D.VolumeLayout(fields, [n_scans], dist.get_world_size(), row)
-        lo, hi = lay.bounds[0][dist.get_rank()]
+        lo, hi, _ = D.shard_bounds(n_scans, dist.get_world_size(), dist.get_rank())
         r0, r1 = lo * per_scan, hi * per_scan
         ctx = self._lane(lane)
-        cache = self.__dict__.setdefault('_dist_cache', {})
 
         def run_block(_rows, _unused, ptrs):
             self._run_rays(az[r0:r1], el[r0:r1], coords[r0:r1], n_gates, range0, N.GEOM_SPACEBORNE,
                            device_outputs=ptrs, site=site[r0:r1], sub=sub, tables=(traj[r0:r1], geo_t[r0:r1]),
                            lane=lane)
         lines = [(np.arange(n_scans, dtype=np.float64), np.zeros(n_scans))]
-        res = D.simulate_sharded_volume_device(run_block, ctx.stream_ptr(), lines, fields, row,
-                                               torch.device('cuda', self.device), cache=cache,
-                                               host_block=self._pool.take)[0]
+        res = self._dist_runner().submit(run_block, ctx.stream_ptr(), lines, fields, row,
+                                         host_block=self._pool.take).wait()
         ctx.synchronize()                                       # deferred domain error, if any
-        out = {k: v.reshape(n_scans * per_scan, n_gates) for k, v in res.items()}
+        if res is None:
+            return None                                         # (gather_to: another rank holds the swath)
+        out = {k: v.reshape(n_scans * per_scan, n_gates) for k, v in res[0].items()}
         out['n_sub'] = sub.n_sub
         return out
 
@@ -852,6 +892,8 @@ class RadarOperator(object):
         azimuths = np.asarray(azimuths, dtype=float)
         sweeps = self._simulate_sweeps([(azimuths, np.full(len(azimuths), float(e)))
                                         for e in elevations])
+        if sweeps is None:
+            return None                       # distributed with gather_to: rank `gather_to` holds the scan
         return self._finish_scan(RadarScan('ppi', list(elevations), list(azimuths),
                                            self.constants.RANGE_RADAR, self.get_pos_and_time(), sweeps))
 
@@ -868,6 +910,8 @@ class RadarOperator(object):
         elevations = np.asarray(elevations, dtype=float)
         sweeps = self._simulate_sweeps([(np.full(len(elevations), float(a)), elevations)
                                         for a in azimuths])
+        if sweeps is None:
+            return None
         return self._finish_scan(RadarScan('rhi', list(elevations), list(azimuths),
                                            self.constants.RANGE_RADAR, self.get_pos_and_time(), sweeps))
 
@@ -937,6 +981,8 @@ class RadarOperator(object):
             az, el, rng, dim, coords, sub, traj, geo_t, site, n_kept, n_gates = cached
             if self.distributed:
                 res = self._swath_sharded(az, el, coords, n_gates, res_m / 2., site, sub, traj, geo_t, dim)
+                if res is None:
+                    return None               # gather_to: another rank holds the swath
             else:
                 res = self._run_rays(az, el, coords, n_gates, res_m / 2., N.GEOM_SPACEBORNE,
                                      site=site, sub=sub, tables=(traj, geo_t))

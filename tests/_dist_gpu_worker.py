@@ -32,6 +32,33 @@ def main():
         scans.append(op.get_PPI(elevations=[4.0, 6.0], azimuths=azs))
         op.close()
     a, b = scans
+    # the rooted form: rank 1 alone receives, assembles and copies the scan; pipelined submissions on
+    # alternating lanes (collective + copy of scan k beside the kernels of scan k + 1) equal the blocking call
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar', device=0, distributed=True,
+                       gather_to=world - 1, lanes=2)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    rooted = op.get_PPI(elevations=[4.0, 6.0], azimuths=azs)
+    sweeps = [[(azs, np.full(len(azs), e)) for e in els] for els in ([4.0, 6.0], [5.0, 7.0], [4.0, 6.0])]
+    pend = [op.submit_volume(sw, fields=['ZH', 'KDP', 'mask'], lane=i % 2) for i, sw in enumerate(sweeps)]
+    got = [q.wait() for q in pend]
+    op.wait(0)
+    op.wait(1)
+    assert op._dist_runner().collective.startswith('all_gather_into_tensor / gloo')   # (gloo: no rooted device gather)
+    if rank == world - 1:
+        for k in b.fields:
+            if k in rooted.fields:
+                x, y = np.ma.asarray(rooted.fields[k]['data']), np.ma.asarray(b.fields[k]['data'])
+                assert np.array_equal(np.ma.getmaskarray(x), np.ma.getmaskarray(y)) and np.array_equal(x.filled(0), y.filled(0)), k
+        assert all(g is not None and sorted(g[0]) == ['KDP', 'ZH', 'mask'] for g in got)
+        for s in range(2):
+            for k in ('ZH', 'KDP', 'mask'):
+                assert np.array_equal(got[0][s][k], got[2][s][k], equal_nan=True)      # the same scan twice
+                ref = np.asarray(b.raw[s]['fields'][k] if k != 'mask' else b.raw[s]['mask'])
+                assert np.array_equal(got[0][s][k], ref, equal_nan=True), (k, s)
+        assert not np.array_equal(got[0][0]['ZH'], got[1][0]['ZH'], equal_nan=True)    # another elevation
+    else:
+        assert rooted is None and all(g is None for g in got)
+    op.close()
     for k in b.fields:
         if k not in a.fields:
             continue

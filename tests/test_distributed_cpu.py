@@ -172,3 +172,66 @@ def test_volume_rows_assembled_by_row_gather_equal_the_host_concatenation():
                     assert got[s][k].dtype == dt and got[s][k].shape == (n_rays[s], ng)
                     assert np.array_equal(got[s][k], truth[s][k]) and np.array_equal(ref[s][k], truth[s][k])
                     assert got[s][k].base is not None                  # a view of the one block, not a copy
+
+
+def _worker_runner(rank, world, port, rays_per_sweep, gather_to, q):
+    """ShardedVolumeRunner on CPU tensors (gloo): three scans submitted before the first wait."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from cosmo_pol_amd import distributed as D
+    fields = list(zip(FIELDS, DTYPES))
+    runner = D.ShardedVolumeRunner('cpu', gather_to=gather_to, slots=2)
+    calls = []
+
+    def make_run(shift):
+        def run_block(a, e, ptrs):              # the stand-in of the kernels: writes through the block's addresses
+            calls.append(len(a))
+            res = fake_simulate(a, e + shift)
+            for k, dt in fields:
+                n = len(a) * N_GATES
+                buf = (ctypes.c_char * (n * np.dtype(dt).itemsize)).from_address(ptrs[k])
+                np.frombuffer(buf, dtype=dt)[:] = res[k].ravel()
+        return run_block
+    scans = []
+    for shift in (0.0, 1.0, 2.0):               # (2 slots, 3 scans: the first slot is used twice)
+        sweeps = [(np.linspace(0, 359, n), np.full(n, 0.5 + 1.5 * s)) for s, n in enumerate(rays_per_sweep)]
+        scans.append(runner.submit(make_run(shift), 0, sweeps, fields, N_GATES))
+    out = []
+    for pend in scans:
+        res = pend.wait()
+        out.append(None if res is None else [{k: v.copy() for k, v in r.items()} for r in res])
+    q.put((rank, out, calls, runner.n_collectives, runner.collective))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,rays,gather_to', [(2, (9, 4), None), (2, (9, 4), 0), (3, (10, 7, 1), 2), (2, (1,), 1)])
+def test_runner_pending_scans_all_gather_and_rooted_gather(world, rays, gather_to):
+    """The product's distributed path (RadarOperator.submit_volume -> ShardedVolumeRunner.submit) with a CPU
+    stand-in for the kernels: scans queued back to back, one collective each, results bitwise equal to the
+    un-sharded sweeps on the receiving rank(s); with `gather_to` the other ranks get None."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_runner, args=(r, world, port, rays, gather_to, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, calls, n_coll, name in got:
+        assert n_coll == 3 and len(out) == 3
+        assert name.startswith('gather(dst=%d)' % gather_to if gather_to is not None else 'all_gather_into_tensor')
+        for shift, res in zip((0.0, 1.0, 2.0), out):
+            if gather_to is not None and rank != gather_to:
+                assert res is None
+                continue
+            for s, n in enumerate(rays):
+                ref = fake_simulate(np.linspace(0, 359, n), np.full(n, 0.5 + 1.5 * s) + shift)
+                for k in FIELDS:
+                    assert res[s][k].shape == (n, N_GATES) and res[s][k].dtype == ref[k].dtype
+                    assert np.array_equal(res[s][k].view(np.uint8), ref[k].view(np.uint8)), (rank, s, k)

@@ -53,6 +53,8 @@ def _check_c4_strong(r):
     assert len(r['per_rank']) == 2
     assert r['per_rank'][0]['rays_per_sweep'] + r['per_rank'][1]['rays_per_sweep'] == 90
     assert r['single_gpu_same_workload']['value'] > 0 and r['value'] > 0 and r['speedup_vs_single_gpu'] > 0
+    assert r['collectives_in_timed_region'] == r['steps'] and r['n_ranks_seen_by_backend'] == 2
+    assert r['api_ms']['get_PPI_distributed_median'] > 0
 
 
 def test_bench_c4_strong_scaling_mode_two_ranks_one_gpu():
@@ -75,5 +77,44 @@ def test_bench_default_two_ranks_weak_c2_line_with_c4_extra():
     assert r['roofline']['frac'] is None or r['roofline']['frac'] > 0
     c4 = r['c4_strong_scaling']
     assert 'error' not in c4, c4
+    assert r['c4_speedup_vs_single_gpu'] == c4['speedup_vs_single_gpu'] and r['c4_gather_check'] is True
+    assert r['process_group_backend'] == 'gloo' and r['n_ranks_seen_by_rccl'] is None
     assert c4['workload'].startswith('c4')
     _check_c4_strong(c4)
+
+
+def _bench_one_rank(*flags, **env_extra):
+    """bench.py on ONE rank with the real backend (nccl = RCCL): what a one-GPU box can execute of the
+    multi-GPU code -- process group, communicator, collectives on the side stream."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1', CPOL_BENCH_NO_EXTRAS='1', **env_extra)
+    env.pop('CPOL_BENCH_BACKEND', None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--small', '--steps', '3', '--warmup', '1',
+           '--cpu-seconds', '0'] + list(flags)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=360)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_c4_one_rank_through_rccl():
+    """`bench.py --workload c4` at N = 1 runs the product's distributed path (RadarOperator.submit_volume)
+    over a one-rank RCCL group: rooted gather on the runner's stream, device-side assembly, the blocking
+    get_PPI(distributed) call; the gathered volume equals the plain single-GPU volume bit for bit."""
+    r = _bench_one_rank('--workload', 'c4')
+    assert r['process_group_backend'] == 'nccl' and r['n_ranks_seen_by_rccl'] == 1
+    assert r['collective'].startswith('gather(dst=0) / nccl') and r['collectives_in_timed_region'] == 3
+    assert r['gather_check'] is True and r['scaling'] == 'strong' and r['value'] > 0
+    assert r['api_ms']['get_PPI_distributed_median'] > 0
+    r = _bench_one_rank('--workload', 'c4', CPOL_BENCH_C4_GATHER='all')
+    assert r['collective'].startswith('all_gather_into_tensor / nccl') and r['gather_check'] is True
+
+
+def test_bench_c2_weak_path_one_rank_through_rccl():
+    """The N > 1 code path of the default workload (process group after the lanes, all-gather of the last
+    sweep on a side stream, bitwise gather check) with one rank and RCCL (CPOL_BENCH_FORCE_COLLECTIVES)."""
+    r = _bench_one_rank(CPOL_BENCH_FORCE_COLLECTIVES='1')
+    assert r['process_group_backend'] == 'nccl' and r['n_ranks_seen_by_rccl'] == 1
+    assert r['gather_check'] is True and r['scaling'] == 'weak' and r['value'] > 0
