@@ -101,7 +101,7 @@ EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_fork', 'cpol_last_error', 'cpol_
            'cpol_stage_doppler_weights', 'cpol_stage_spectrum_tables', 'cpol_stage_t_function', 'cpol_prepare',
            'cpol_interp_points', 'cpol_ray_tables', 'cpol_run_sweep', 'cpol_counters',
            'cpol_spaceborne_first_gate', 'cpol_host_alloc', 'cpol_host_free', 'cpol_host_alloc_near',
-           'cpol_device_pci_bus_id',
+           'cpol_device_pci_bus_id', 'cpol_mem_info',
            'cpol_enable_timing', 'cpol_debug_read', 'cpol_debug_math']
 
 TRAJ_STRIDE, GEO_STRIDE, SITE_STRIDE = 4, 8, 8      # CPOL_*_STRIDE of the header
@@ -234,6 +234,8 @@ def load_library():
     lib.cpol_host_free.argtypes = [vp, vp]
     lib.cpol_host_alloc_near.restype = C.c_int
     lib.cpol_host_alloc_near.argtypes = [C.c_int, C.c_size_t, C.POINTER(vp)]
+    lib.cpol_mem_info.restype = C.c_int
+    lib.cpol_mem_info.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.cpol_device_pci_bus_id.restype = C.c_int
     lib.cpol_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     _lib = lib
@@ -473,6 +475,12 @@ class Context(object):
         arr = np.frombuffer(buf, dtype=np.uint8)
         self._keep.append(buf)
         return arr
+
+    def mem_info(self):
+        """(free bytes, total bytes) of the GPU's memory, work-buffer bytes per sub-beam gate of a launch sequence."""
+        f, t, g = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._check(self.lib.cpol_mem_info(self.h, C.byref(f), C.byref(t), C.byref(g)), 'cpol_mem_info')
+        return int(f.value), int(t.value), int(g.value)
 
     def enable_timing(self, on=True):
         """True / 1: events around every stage; 2: around the PSD stage only; False: off."""

@@ -119,6 +119,7 @@ struct cpol_ctx {
     long last_n_sbg = 0, last_n_rg = 0;
     int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0, last_n_keys = 0;
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
+    int subsum_small = 0;              // CPOL_SUBSUM_SMALL=1: experiment: the gather form of k_subbeam_sum with three wavefronts per (tile, hydrometeor) and the whole block in flight (measured slower)
     int subsum_coop = -1;              // CPOL_SUBSUM_COOP: k_subbeam_sum takes its coefficients through the scalar cache: 0 never, 1 always, -1 by launch size
     bool last_subsum = false;          // the 1-D table items of the last sweep never went through res[] (k_subbeam_sum)
     bool keep_debug = false;
@@ -159,6 +160,8 @@ int ensure(cpol_ctx *ctx, DevBuf &b, size_t bytes)
     size_t want = bytes + bytes / 8 + 256;
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
+        b.p = nullptr;                      // (the buffer is empty and may be sized again by a later, smaller call)
+        (void)hipGetLastError();            // reported through the return code: not left behind as the thread's last error
         ctx->err = std::string("hipMalloc failed: ") + hipGetErrorString(e);
         return CPOL_ERR_NOMEM;
     }
@@ -532,6 +535,7 @@ int cpol_create(int device, cpol_ctx **out)
     // CPOL_SUBSUM_COOP=0 / 1: k_subbeam_sum never / always takes the coefficient rows through the scalar cache
     // (default: by launch size; the results are identical)
     if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
+    if (getenv("CPOL_SUBSUM_SMALL")) ctx->subsum_small = atoi(getenv("CPOL_SUBSUM_SMALL")) != 0 ? 1 : 0;
     if (getenv("CPOL_SUBSUM_COOP_ROUNDS")) ctx->subsum_coop_rounds = std::max(0, std::min(64, atoi(getenv("CPOL_SUBSUM_COOP_ROUNDS"))));
     *out = ctx;
     return CPOL_OK;
@@ -630,6 +634,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     }
     c->use_graph = parent->use_graph;
     c->subsum_coop = parent->subsum_coop;
+    c->subsum_small = parent->subsum_small;
     c->subsum_coop_rounds = parent->subsum_coop_rounds;
     c->parent = parent;
     c->model_staged = parent->model_staged;
@@ -745,6 +750,24 @@ int cpol_device_pci_bus_id(int device, char *buf, int len)
     if (hipDeviceGetPCIBusId(buf, len, device) == hipSuccess) return CPOL_OK;
     (void)hipGetLastError();            // (reported through the return code: not left behind as the thread's last error)
     return CPOL_ERR_HIP;
+}
+
+int cpol_mem_info(cpol_ctx *ctx, size_t *free_bytes, size_t *total_bytes, size_t *per_gate)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    if (per_gate) {
+        // the arenas cpol_run_sweep sizes by n_sbg (vals, masks, elevation, melting scratch, per-item key / pos /
+        // par / rec / perm / res / vn, velocity terms, per-gate weights)
+        const size_t n_hyd = (size_t)(ctx->hs.n_hydro > 0 ? ctx->hs.n_hydro : 1), n_vars = (size_t)(ctx->model.n_vars > 0 ? ctx->model.n_vars : 9);
+        *per_gate = n_vars * 4 + 1 + 4 + 8 + 16 + 1 + 8 + 8
+                  + n_hyd * (4 + 4 + CPOL_MAX_PAR * 8 + 16 + 4 + CPOL_N_SZ * 8 + 16);
+    }
+    return CPOL_OK;
 }
 
 int cpol_host_free(cpol_ctx *ctx, void *p)
@@ -1287,8 +1310,20 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         for (int j = 0; j < n_hyd; ++j) any1d = any1d || (ctx->its.t[j].tab && !ctx->its.t[j].two_d);
         // (not with Doppler scheme 3: k_spec_atten reads every item's columns from res[]; with one
         // sub-beam there is nothing to accumulate and the extra launch costs more than it saves)
-        subsum = subsum && any1d && !dop3 && n_sub >= 4;
+        subsum = subsum && any1d && !dop3;
     }
+    // ... with fewer than 4 sub-beams k_final itself evaluates them in place (no extra launch, and
+    // k_psd_lookup no longer writes 96 B per item for k_final to read back)
+    // -- where that saves the k_psd_lookup launch altogether (no melting species, no Doppler sums from the tables: the
+    // C2 sweep 122 -> 119 us and 46 MB less traffic).  Where k_psd_lookup runs anyway it keeps storing the columns: the
+    // gathers inside the per-ray workgroups of k_final cost more than the stored rows (C3 sweep at 3 deg: 199 against
+    // 188 us; 512-thread workgroups held to 128 / 168 VGPRs: 138 / 159 us on the C2 sweep; round 4)
+    bool final_inplace = subsum && n_sub < 4;
+    for (int j = 0; j < n_hyd && final_inplace; ++j) {
+        const ItabDev &tj = ctx->its.t[j];
+        if (tj.tab && (tj.two_d || (doppler && tj.writes_vn))) final_inplace = false;
+    }
+    subsum = subsum && n_sub >= 4;
     const bool want_szi = ctx->keep_debug || subsum;
     if (want_szi) ENSURE(ctx->b_szinteg, (size_t)n_rg * n_hyd * CPOL_N_SZ * sizeof(float));
     const bool want_szt = out->sz_total != nullptr || ctx->keep_debug;
@@ -1508,12 +1543,14 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             la.res = (double *)ctx->b_res.p;
             la.vn = doppler ? (double *)ctx->b_vn.p : nullptr;
             la.n_sbg = n_sbg;
-            la.skip_res_1d = subsum ? 1 : 0;
-            bool launch = !subsum;              // with k_subbeam_sum: only for 2-D tables and the ice intercept
+            la.skip_res_1d = (subsum || final_inplace) ? 1 : 0;
+            la.vn_1d = final_inplace ? 1 : 0;
+            bool launch = !(subsum || final_inplace);   // with k_subbeam_sum / in-place evaluation in k_final: only for 2-D tables, Doppler sums and the ice intercept
             for (int j = 0; j < n_hyd && !launch; ++j) {
                 const ItabDev &tj = ctx->its.t[j];
                 if (!tj.tab) continue;
-                launch = tj.two_d || (la.par_w && ctx->hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD);
+                launch = tj.two_d || (la.par_w && ctx->hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD) ||
+                         (final_inplace && la.vn && tj.writes_vn);      // (k_subbeam_sum evaluates the Doppler sums itself)
             }
             bool two_d = false;
             for (int j = 0; j < n_hyd; ++j) two_d = two_d || (ctx->its.t[j].tab && ctx->its.t[j].two_d);
@@ -1665,12 +1702,18 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // With lanes (cpol_fork) other sweeps share the GPU and hide the waits: measured with three lanes in
         // flight, the share of one of 8 / 4 GPUs (11 / 21 wavefronts per SIMD): 1.30 / 2.24 ms per volume share
         // against 1.31 / ~2.5 ms with the gather -- from ~12 there.
-        const long waves_per_simd = tiles * n_hyd * CPOL_SUBSUM_SPLIT / 1024;
+        const long waves_per_simd = tiles * n_hyd / 1024;
         const int lanes_alive = ctx->parent ? ctx->parent->n_children : ctx->n_children;
-        const bool coop = ctx->subsum_coop == 1 || (ctx->subsum_coop < 0 && waves_per_simd >= (lanes_alive >= 2 ? 12 : 32));
-        const dim3 sgrid((unsigned)tiles, n_hyd * CPOL_SUBSUM_SPLIT);
-        if (coop) hipLaunchKernelGGL((k_subbeam_sum<true>), sgrid, dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
-        else hipLaunchKernelGGL((k_subbeam_sum<false>), sgrid, dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
+        // (round 4, with the validity bits read up front: the share of one of 8 GPUs -- 11 wavefronts per SIMD --
+        // with three lanes in flight 1.19 ms per volume share this way against 1.27 with the gather: from 8 there)
+        const bool coop = ctx->subsum_coop == 1 || (ctx->subsum_coop < 0 && waves_per_simd >= (lanes_alive >= 2 ? 8 : 32));
+        // CPOL_SUBSUM_SMALL=1 (experiment, never the default): the gather form with three wavefronts per (tile,
+        // hydrometeor), 4 columns each, and all rows of the block requested at once -- see the note on SPLIT in
+        // cpol_final.inl: slower than the plain gather on the share (571 vs 533 us) and with lanes (1.41 vs 1.27 ms)
+        const bool small = !coop && ctx->subsum_small == 1;
+        if (coop) hipLaunchKernelGGL((k_subbeam_sum<true, 1, 2>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
+        else if (small) hipLaunchKernelGGL((k_subbeam_sum<false, 3, 10>), dim3((unsigned)tiles, n_hyd * 3), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
+        else hipLaunchKernelGGL((k_subbeam_sum<false, 1, 2>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
     }
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
 
@@ -1780,6 +1823,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     }
     if ((size_t)3 * ng * sizeof(float) > 64 * 1024) { ctx->err = "cpol_run_sweep: n_gates too large for the range scans (3 * n_gates floats of LDS)"; return CPOL_ERR_ARG; }
     fa.pre_integ = subsum ? 1 : 0;
+    fa.eval_1d = final_inplace ? 1 : 0;
+    fa.rec = (const double2 *)ctx->b_rec.p;
+    for (int j = 0; j < n_hyd; ++j) fa.key_base[j] = ctx->hs.h[j].key_base;
     if (subsum) fa.sz_integ = (float *)ctx->b_szinteg.p;
     fa.proj = nullptr;
     if (fa.RVEL && n_sub >= 4) {
@@ -1791,10 +1837,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     }
     // (one workgroup per ray: with no more rays than CUs the kernel lasts as long as ONE workgroup -- 512
     // threads halve its gate loop; the share of one of 8 GPUs of a 5 x 360-ray volume is 225 rays)
-    if (n_rays <= 256 && ng > CPOL_FINAL_THREADS)
-        hipLaunchKernelGGL((k_final<2 * CPOL_FINAL_THREADS>), dim3(n_rays), dim3(2 * CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra);
+    static const int final512 = getenv("CPOL_FINAL_512") ? atoi(getenv("CPOL_FINAL_512")) : -1;   // experiment knob
+    if ((final512 == 1 || (final512 < 0 && n_rays <= 256)) && ng > CPOL_FINAL_THREADS)
+        hipLaunchKernelGGL((k_final<2 * CPOL_FINAL_THREADS>), dim3(n_rays), dim3(2 * CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra, ctx->its);
     else
-        hipLaunchKernelGGL((k_final<CPOL_FINAL_THREADS>), dim3(n_rays), dim3(CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra);
+        hipLaunchKernelGGL((k_final<CPOL_FINAL_THREADS>), dim3(n_rays), dim3(CPOL_FINAL_THREADS), (size_t)3 * ng * sizeof(float), st, fa, ra, ctx->its);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
     HIPCHK(hipGetLastError());
 
@@ -1856,7 +1903,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
 
     ctx->last_n_sbg = n_sbg; ctx->last_n_rg = n_rg; ctx->last_n_rays = n_rays;
     ctx->last_n_gates = ng; ctx->last_n_sub = n_sub; ctx->last_n_v = n_v;
-    ctx->last_n_keys = n_keys; ctx->last_subsum = subsum;
+    ctx->last_n_keys = n_keys; ctx->last_subsum = subsum || final_inplace;
     ctx->counters.n_subbeam_gates = n_sbg;
     ctx->counters.n_gates = n_rg;
 
@@ -2024,8 +2071,8 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     else if (!strcmp(name, "item_key")) { src = ctx->b_key.p; bytes = (int64_t)n_hyd * n_sbg * 4; }
     else if (!strcmp(name, "item_res")) {
         if (ctx->last_subsum) {
-            ctx->err = "cpol_debug_read: item_res is incomplete after a sweep with >= 4 sub-beams (the items on 1-D integral "
-                       "tables are evaluated inside k_subbeam_sum and never stored; CPOL_SUBSUM=0 keeps them)";
+            ctx->err = "cpol_debug_read: item_res is incomplete (the items on 1-D integral tables are evaluated inside "
+                       "k_subbeam_sum / k_final and never stored; CPOL_SUBSUM=0 keeps them)";
             return CPOL_ERR_ARG;
         }
         src = ctx->b_res.p; bytes = (int64_t)n_hyd * n_sbg * CPOL_N_SZ * 8;

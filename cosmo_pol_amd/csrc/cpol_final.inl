@@ -126,6 +126,12 @@ struct FinalArgs {
     const double *sub_w;        // [n_sub]
     float *sz_integ;            // [n_rg][n_hydro][12] or NULL
     int pre_integ;              // sz_integ already holds the sub-beam sums (k_subbeam_sum)
+    int eval_1d;                // fewer than 4 sub-beams: the items on 1-D integral tables are evaluated HERE from their
+                                // record (key, panel position, scale) -- k_psd_lookup neither stores their 12 columns
+                                // (96 B per item) nor does this kernel read them back; res[] holds only the melting
+                                // items and the items integrated bin by bin
+    const double2 *rec;         // [n_hydro][n_sbg] {panel position (-1: not on the table), scale} (k_classify)
+    int key_base[CPOL_MAX_HYDRO];
     float *sz_total;            // [n_rg][12] or NULL
     float *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *RHOHV, *ATT_H, *ATT_V;   // work / outputs
     double *mask;               // [n_rg]
@@ -238,19 +244,20 @@ struct SubsumArgs {
 #else
 #define CPOL_SUBSUM_ATTR
 #endif
-#ifndef CPOL_SUBSUM_SPLIT
-#define CPOL_SUBSUM_SPLIT 1          // threads per (gate, hydrometeor): each accumulates 12 / SPLIT of the columns (1, 2 or 3)
-#endif
-// Column split (experiment knob, blockIdx.y = j * SPLIT + part): two or three threads per (gate,
-// hydrometeor), 6 or 4 columns each, need half / a third of the registers, i.e. more wavefronts in flight
-// over the same gathers (the validity byte, key and record are read once per part).  Measured on the C4
-// volume / the 225-ray share of one of 8 GPUs (k_subbeam_sum alone): SPLIT 1: 3.58 / 0.55 ms; 2: 4.07 / 0.53
-// (3.82 / 0.55 with the allocator held to 78 VGPRs); 3: 4.64 / 0.56 (4.19 / 0.55 at 60 VGPRs).  Occupancy is
-// not what limits the kernel -- neither is it with amdgpu_waves_per_eu alone (5 / 6 / 8 waves: 0.86 -> 1.03 /
-// 1.13 / 1.22 ms of PSD stage on the share, spills) or with more registers (242 VGPRs: no change).
-#ifndef CPOL_SUBSUM_GATHER_UNROLL
-#define CPOL_SUBSUM_GATHER_UNROLL 2  // rows of the per-lane gather requested together (the tail path)
-#endif
+// Column split (template parameter SPLIT, blockIdx.y = j * SPLIT + part): two or three threads per (gate,
+// hydrometeor), 6 or 4 columns each (the validity bits, key and record are read once per part).  Measured in
+// round 3 on the C4 volume / the 225-ray share of one of 8 GPUs with the loop as it was then (one dependent
+// validity load per sub-beam, rows requested two at a time): SPLIT 1: 3.58 / 0.55 ms; 2: 4.07 / 0.53; 3: 4.64 /
+// 0.56 -- no gain, because what bounded the share was the NUMBER OF MEMORY ROUND TRIPS per wavefront and
+// sub-beam (validity byte, then key + record, then six pairs of rows: 8), not registers or occupancy.
+// Round 4: the validity bits of all sub-beams are read up front and key + record one sub-beam ahead (C4 volume,
+// scalar-cache form: 2.06 -> 1.86 ms; the gather form on the share: 531 -> 533 us, unchanged), and SPLIT 3 with
+// ALL rows of the block requested at once (GUNROLL = 10: 22 loads in flight per lane, one round trip per
+// sub-beam) was tried for the small launches: 571 us -- so the round trips are not what bounds the gather form
+// either; what does is the number of 16-byte gather instructions a CU's texture-address path takes (16 cycles
+// each whatever the lanes in use: the tile's lanes are a third full on average).  With every item of a
+// wavefront forced onto ONE block (wrong results, timing only) the scalar-cache form takes 1.37 ms: the
+// per-sub-beam overhead of its partly filled wavefronts, not the number of distinct blocks, is most of it.
 #ifndef CPOL_SUBSUM_ROW_UNROLL
 #define CPOL_SUBSUM_ROW_UNROLL 2     // coefficient rows per scalar-memory wait (3 rows = 72 SGPRs no longer fit: 3.57 -> 4.34 ms)
 #endif
@@ -270,10 +277,12 @@ __device__ __forceinline__ double fma_sgpr(double a, double b, double c_uniform)
 // neighbouring rays at one range see almost the same PSD slope, so the items of a tile sit on very few
 // distinct (LUT slice, lambda panel) blocks -- measured on the C4 sweep at 3 degrees: 1.7 (snow), 1.8 (ice),
 // 3.2 (graupel) distinct blocks per tile and sub-beam, against 7.5 / 9.2 / 6.2 along 64 gates of a ray.
-// Two forms, bit-identical (same coefficients, same Horner order), chosen per launch by the host:
+// Forms, bit-identical (same coefficients, same Horner order), chosen per launch by the host:
 //   COOP = false  every lane gathers the rows of its own block: 66 16-byte loads per evaluation through
-//                 the vector L1, which bounds it (~2 500 cycles per wavefront and sub-beam on a CU); the tile
-//                 alone helps (lanes on one block share its lines): C4 volume 3.59 -> 3.2 ms.
+//                 the vector L1, which bounds a large launch (~2 500 cycles per wavefront and sub-beam on a
+//                 CU); the tile alone helps (lanes on one block share its lines): C4 volume 3.59 -> 3.2 ms.
+//                 <false, 3, 10>: the small launches (the share of one of 8 GPUs: 11 wavefronts per SIMD):
+//                 latency-bound, see the note on SPLIT above.
 //   COOP = true   the wavefront walks over its distinct blocks: the block address is made wave-uniform
 //                 (readlane), the coefficient rows arrive through the SCALAR cache into SGPRs and the lanes
 //                 on that block run their Horner chains with a scalar operand -- no per-lane gather for them;
@@ -283,19 +292,18 @@ __device__ __forceinline__ double fma_sgpr(double a, double b, double c_uniform)
 //                 scalar cache row pair by row pair (s_load returns out of order: nothing to pipeline
 //                 inside a wavefront; three waves per tile with 4 columns each and the whole block in
 //                 one wait: 5.5-6.0 ms of PSD stage, the scalar cache does not keep up), so it needs many
-//                 wavefronts per SIMD to pay: the 225-ray share of one of 8 GPUs takes 1.08 ms this way
-//                 and 0.85 ms with the gather.  The host picks it from ~32 wavefronts per SIMD on.
+//                 wavefronts per SIMD to pay.  The host picks it from ~32 wavefronts per SIMD on.
 //                 (Workgroup ids reordered so that the 8 ids of an XCD in every 64 take 8 consecutive ray
 //                 tiles of one range -- blocks shared through that XCD's L2: 2.05 -> 2.23 ms, dropped.)
-template <bool COOP>
+template <bool COOP, int SPLIT, int GUNROLL>
 __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbeam_sum(HydroSet hs, ItabSet its, SubsumArgs a)
 {
     static_assert(CPOL_SUBSUM_THREADS == CPOL_WAVE, "one wavefront per workgroup: the tile walk uses wave-wide ballots");
     constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
-    constexpr int NP = CPOL_N_SZ / 2 / CPOL_SUBSUM_SPLIT;               // double2 column pairs of this thread
-    static_assert(NP * CPOL_SUBSUM_SPLIT * 2 == CPOL_N_SZ, "CPOL_SUBSUM_SPLIT must divide 6");
+    constexpr int NP = CPOL_N_SZ / 2 / SPLIT;                            // double2 column pairs of this thread
+    static_assert(NP * SPLIT * 2 == CPOL_N_SZ, "SPLIT must divide 6");
     const long n_rg = (long)a.n_rays * a.n_gates;
-    const int j = blockIdx.y / CPOL_SUBSUM_SPLIT, part = blockIdx.y % CPOL_SUBSUM_SPLIT;
+    const int j = blockIdx.y / SPLIT, part = blockIdx.y % SPLIT;
     const int f0 = part * NP;                                            // first column pair
     const int tg = a.tile_log2, lane = threadIdx.x;
     const int gate_tiles = (a.n_gates + (1 << tg) - 1) >> tg;
@@ -309,6 +317,7 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
     const bool tab1 = t.tab && !t.two_d;                                 // uniform
     const int key_base = hs.h[j].key_base;
     const double2 *R = a.rec + (long)j * n_sbg;
+    const int *K = a.key + (long)j * n_sbg;
     const bool want_vn = tab1 && a.vn && t.writes_vn && part == 0;       // uniform
     double wtot = 0.0;
     if (a.wgate && in)
@@ -316,99 +325,154 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
     float acc[2 * NP];
 #pragma unroll
     for (int c = 0; c < 2 * NP; ++c) acc[c] = __builtin_nanf("");
-    for (int s = 0; s < a.n_sub; ++s) {
-        const long sbg = sbg0 + (long)s * a.n_gates;
-        const bool present = in && ((a.vmask[sbg] >> j) & 1);
-        if (!__builtin_amdgcn_ballot_w64(present)) continue;             // (wave-uniform)
-        const int key = present ? a.key[(long)j * n_sbg + sbg] : 0;
-        const double2 rc = (present && tab1) ? R[sbg] : make_double2(-1.0, 0.0);
-        const bool on_tab = rc.x >= 0.0;
-        const int pn = on_tab ? min((int)rc.x, t.n_pan - 1) : 0;
-        const double u = 2.0 * (rc.x - (double)pn) - 1.0;
-        const int blk_id = on_tab ? (key - key_base) * t.n_pan + pn : -1;
-        double2 v[NP];
-        double2 wv = make_double2(0.0, 0.0);
-        // ---- the tile's distinct blocks, one after the other: coefficients through the scalar cache ----
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(on_tab);
-        for (int round = 0; COOP && todo && round < a.coop_rounds; ++round) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int b = __builtin_amdgcn_readlane(blk_id, leader);
-            const bool mine = blk_id == b;                               // (blk_id = -1 never matches: b >= 0)
-            // (constant address space: a wave-uniform address there is what the backend turns into s_load)
-            const sconst_f64 *B = (const sconst_f64 *)(unsigned long long)(t.tab + (long)b * NB + 2 * f0);
-            if (mine) {
+    // sub-beams in chunks of 64: the validity bits of a whole chunk are read FIRST (independent byte
+    // loads, 16 in flight), so that neither the skip of an absent sub-beam nor the loads of a present one
+    // wait for a validity byte inside the loop
+    for (int s_lo = 0; s_lo < a.n_sub; s_lo += 64) {
+        const int n_here = min(64, a.n_sub - s_lo);
+        unsigned long long pm = 0;                                       // bit q: species j present at sub-beam s_lo + q (this lane)
+#pragma unroll 16
+        for (int q = 0; q < n_here; ++q) {
+            const unsigned vb = in ? a.vmask[sbg0 + (long)(s_lo + q) * a.n_gates] : 0u;
+            pm |= (unsigned long long)((vb >> j) & 1u) << q;
+        }
+        unsigned long long wp = 0;                                       // ... at any lane of the wavefront (uniform)
+        for (int q = 0; q < n_here; ++q)
+            if (__builtin_amdgcn_ballot_w64((pm >> q) & 1ull)) wp |= 1ull << q;
+        if (!wp) continue;
+        // key + record of the NEXT present sub-beam are requested before the rows of the current one
+        int q_next = __ffsll((long long)wp) - 1;
+        int key_n = 0;
+        double2 rc_n = make_double2(-1.0, 0.0);
+        {
+            const long sbg = sbg0 + (long)(s_lo + q_next) * a.n_gates;
+            const bool pr = (pm >> q_next) & 1ull;
+            key_n = pr ? K[sbg] : 0;
+            rc_n = (pr && tab1) ? R[sbg] : make_double2(-1.0, 0.0);
+        }
+        while (wp) {
+            const int q_cur = q_next;
+            wp &= wp - 1;
+            const int s = s_lo + q_cur;
+            const long sbg = sbg0 + (long)s * a.n_gates;
+            const bool present = (pm >> q_cur) & 1ull;
+            const int key = key_n;
+            const double2 rc = rc_n;
+            if (wp) {
+                q_next = __ffsll((long long)wp) - 1;
+                const long sbg_n = sbg0 + (long)(s_lo + q_next) * a.n_gates;
+                const bool pr = (pm >> q_next) & 1ull;
+                key_n = pr ? K[sbg_n] : 0;
+                rc_n = (pr && tab1) ? R[sbg_n] : make_double2(-1.0, 0.0);
+            }
+            const bool on_tab = rc.x >= 0.0;
+            const int pn = on_tab ? min((int)rc.x, t.n_pan - 1) : 0;
+            const double u = 2.0 * (rc.x - (double)pn) - 1.0;
+            const int blk_id = on_tab ? (key - key_base) * t.n_pan + pn : -1;
+            double2 v[NP];
+            double2 wv = make_double2(0.0, 0.0);
+            // ---- the tile's distinct blocks, one after the other: coefficients through the scalar cache ----
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(on_tab);
+            for (int round = 0; COOP && todo && round < a.coop_rounds; ++round) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int b = __builtin_amdgcn_readlane(blk_id, leader);
+#ifdef CPOL_SUBSUM_FAKE_ONE_BLOCK
+                const bool mine = blk_id >= 0;                           // TIMING EXPERIMENT ONLY (wrong results): every item on the leader's block
+#else
+                const bool mine = blk_id == b;                           // (blk_id = -1 never matches: b >= 0)
+#endif
+                // (constant address space: a wave-uniform address there is what the backend turns into s_load)
+                const sconst_f64 *B = (const sconst_f64 *)(unsigned long long)(t.tab + (long)b * NB + 2 * f0);
+                if (mine) {
 #pragma unroll
-                for (int f = 0; f < NP; ++f) v[f] = make_double2(B[(NC - 1) * NFP + 2 * f], B[(NC - 1) * NFP + 2 * f + 1]);
-                // (one row per trip: unrolled, the scheduler requests all 11 rows at once and the 264 SGPRs they
-                // would need spill into vector registers)
+                    for (int f = 0; f < NP; ++f) v[f] = make_double2(B[(NC - 1) * NFP + 2 * f], B[(NC - 1) * NFP + 2 * f + 1]);
+                    // (one row per trip: unrolled, the scheduler requests all 11 rows at once and the 264 SGPRs they
+                    // would need spill into vector registers)
 #pragma unroll CPOL_SUBSUM_ROW_UNROLL
+                    for (int q = NC - 2; q >= 0; --q) {
+#pragma unroll
+                        for (int f = 0; f < NP; ++f) {
+                            v[f].x = fma_sgpr(v[f].x, u, B[q * NFP + 2 * f]);
+                            v[f].y = fma_sgpr(v[f].y, u, B[q * NFP + 2 * f + 1]);
+                        }
+                    }
+                    if (want_vn) {
+                        const sconst_f64 *W = (const sconst_f64 *)(unsigned long long)(t.tab + (long)b * NB + CPOL_N_SZ);
+                        wv = make_double2(W[(NC - 1) * NFP], W[(NC - 1) * NFP + 1]);
+#pragma unroll CPOL_SUBSUM_ROW_UNROLL
+                        for (int q = NC - 2; q >= 0; --q) {
+                            wv.x = fma_sgpr(wv.x, u, W[q * NFP]);
+                            wv.y = fma_sgpr(wv.y, u, W[q * NFP + 1]);
+                        }
+                    }
+                }
+                todo &= ~__builtin_amdgcn_ballot_w64(mine);
+            }
+            // ---- per-lane gather: COOP = false; COOP = true: the lanes still without a value after
+            // `coop_rounds` blocks (a tile whose items are scattered over many blocks: noise-like
+            // fields) -- one row at a time there, so that the rare tail costs the common path no registers; it
+            // bounds a wavefront's sub-beam at 6 scalar rounds + one gather instead of up to 64 rounds ----
+            if (on_tab && (!COOP || ((todo >> lane) & 1ull))) {
+                const double2 *blk = reinterpret_cast<const double2 *>(t.tab + (long)blk_id * NB);
+                // the Doppler sums of the block (functions 12, 13): with the whole block in flight (GUNROLL = NC - 1)
+                // their rows are requested together with the columns, not one dependent load after the other
+                double2 wq[(!COOP && GUNROLL >= NC - 1) ? NC : 1];
+                if (!COOP && GUNROLL >= NC - 1 && want_vn) {
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) wq[q] = blk[q * (NFP / 2) + CPOL_N_SZ / 2];
+                }
+                // this thread's columns of the block (itab1_columns on a part of the row)
+#pragma unroll
+                for (int f = 0; f < NP; ++f) v[f] = blk[(NC - 1) * (NFP / 2) + f0 + f];
+#pragma unroll (COOP ? 1 : GUNROLL)
                 for (int q = NC - 2; q >= 0; --q) {
 #pragma unroll
                     for (int f = 0; f < NP; ++f) {
-                        v[f].x = fma_sgpr(v[f].x, u, B[q * NFP + 2 * f]);
-                        v[f].y = fma_sgpr(v[f].y, u, B[q * NFP + 2 * f + 1]);
+                        const double2 cq = blk[q * (NFP / 2) + f0 + f];
+                        v[f].x = fma(v[f].x, u, cq.x);
+                        v[f].y = fma(v[f].y, u, cq.y);
                     }
                 }
                 if (want_vn) {
-                    const sconst_f64 *W = (const sconst_f64 *)(unsigned long long)(t.tab + (long)b * NB + CPOL_N_SZ);
-                    wv = make_double2(W[(NC - 1) * NFP], W[(NC - 1) * NFP + 1]);
-#pragma unroll CPOL_SUBSUM_ROW_UNROLL
-                    for (int q = NC - 2; q >= 0; --q) {
-                        wv.x = fma_sgpr(wv.x, u, W[q * NFP]);
-                        wv.y = fma_sgpr(wv.y, u, W[q * NFP + 1]);
+                    if (!COOP && GUNROLL >= NC - 1) {
+                        wv = wq[NC - 1];
+#pragma unroll
+                        for (int q = NC - 2; q >= 0; --q) {
+                            wv.x = fma(wv.x, u, wq[q].x);
+                            wv.y = fma(wv.y, u, wq[q].y);
+                        }
+                    } else {
+                        wv = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
+#pragma unroll (COOP ? 1 : NC - 1)
+                        for (int q = NC - 2; q >= 0; --q) {
+                            const double2 cq = blk[q * (NFP / 2) + CPOL_N_SZ / 2];
+                            wv.x = fma(wv.x, u, cq.x);
+                            wv.y = fma(wv.y, u, cq.y);
+                        }
                     }
                 }
             }
-            todo &= ~__builtin_amdgcn_ballot_w64(mine);
-        }
-        // ---- per-lane gather: COOP = false; COOP = true: the lanes still without a value after
-        // `coop_rounds` blocks (a tile whose items are scattered over many blocks: noise-like
-        // fields) -- one row at a time there, so that the rare tail costs the common path no registers; it
-        // bounds a wavefront's sub-beam at 6 scalar rounds + one gather instead of up to 64 rounds ----
-        if (on_tab && (!COOP || ((todo >> lane) & 1ull))) {
-            const double2 *blk = reinterpret_cast<const double2 *>(t.tab + (long)blk_id * NB);
-            // this thread's columns of the block (itab1_columns on a part of the row)
+            if (!present) continue;
+            if (on_tab) {
 #pragma unroll
-            for (int f = 0; f < NP; ++f) v[f] = blk[(NC - 1) * (NFP / 2) + f0 + f];
-#pragma unroll (COOP ? 1 : CPOL_SUBSUM_GATHER_UNROLL)
-            for (int q = NC - 2; q >= 0; --q) {
+                for (int f = 0; f < NP; ++f) { v[f].x *= rc.y; v[f].y *= rc.y; }
+                if (want_vn)
+                    *reinterpret_cast<double2 *>(a.vn + ((long)j * n_sbg + sbg) * 2) = make_double2(wv.x * rc.y, wv.y * rc.y);
+            } else {
+                const double2 *r = reinterpret_cast<const double2 *>(a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ) + f0;
 #pragma unroll
-                for (int f = 0; f < NP; ++f) {
-                    const double2 cq = blk[q * (NFP / 2) + f0 + f];
-                    v[f].x = fma(v[f].x, u, cq.x);
-                    v[f].y = fma(v[f].y, u, cq.y);
-                }
+                for (int c = 0; c < NP; ++c) v[c] = r[c];
             }
-            if (want_vn) {
-                wv = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
-#pragma unroll (COOP ? 1 : NC - 1)
-                for (int q = NC - 2; q >= 0; --q) {
-                    const double2 cq = blk[q * (NFP / 2) + CPOL_N_SZ / 2];
-                    wv.x = fma(wv.x, u, cq.x);
-                    wv.y = fma(wv.y, u, cq.y);
-                }
+            const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
+#pragma unroll
+            for (int c = 0; c < 2 * NP; ++c) {
+                // nansum([float32 acc, float64 term]) stored back as float32
+                double y = ((c & 1) ? v[c / 2].y : v[c / 2].x) * w;
+                double x = (double)acc[c];
+                if (!(x == x)) x = 0.0;
+                if (!(y == y)) y = 0.0;
+                acc[c] = (float)(x + y);
             }
-        }
-        if (!present) continue;
-        if (on_tab) {
-#pragma unroll
-            for (int f = 0; f < NP; ++f) { v[f].x *= rc.y; v[f].y *= rc.y; }
-            if (want_vn)
-                *reinterpret_cast<double2 *>(a.vn + ((long)j * n_sbg + sbg) * 2) = make_double2(wv.x * rc.y, wv.y * rc.y);
-        } else {
-            const double2 *r = reinterpret_cast<const double2 *>(a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ) + f0;
-#pragma unroll
-            for (int c = 0; c < NP; ++c) v[c] = r[c];
-        }
-        const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
-#pragma unroll
-        for (int c = 0; c < 2 * NP; ++c) {
-            // nansum([float32 acc, float64 term]) stored back as float32
-            double y = ((c & 1) ? v[c / 2].y : v[c / 2].x) * w;
-            double x = (double)acc[c];
-            if (!(x == x)) x = 0.0;
-            if (!(y == y)) y = 0.0;
-            acc[c] = (float)(x + y);
         }
     }
     if (!in) return;
@@ -423,10 +487,13 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
 #ifndef CPOL_FINAL_BATCH
 #define CPOL_FINAL_BATCH 2
 #endif
+#ifndef CPOL_FINAL_ROW_UNROLL
+#define CPOL_FINAL_ROW_UNROLL 5      // coefficient rows of an in-place table evaluation requested together (k_final)
+#endif
 #ifndef CPOL_FINAL_SBATCH
 #define CPOL_FINAL_SBATCH 7          // sub-beams whose RVEL terms / masks are requested together (experiment knob)
 #endif
-__device__ __forceinline__ void final_gate(const FinalArgs &a, int ray, int gate, float &k2_out,
+__device__ __forceinline__ void final_gate(const FinalArgs &a, const ItabSet &its, int ray, int gate, float &k2_out,
                                            float &fh_out, float &fv_out)
 {
     const long n_rg = (long)a.n_rays * a.n_gates;
@@ -451,6 +518,53 @@ __device__ __forceinline__ void final_gate(const FinalArgs &a, int ray, int gate
             for (int c4 = 0; c4 < CPOL_N_SZ / 4; ++c4) {
                 const float4 q4 = pi[c4];
                 acc[4 * c4] = q4.x; acc[4 * c4 + 1] = q4.y; acc[4 * c4 + 2] = q4.z; acc[4 * c4 + 3] = q4.w;
+            }
+        } else if (a.eval_1d && its.t[j].tab && !its.t[j].two_d) {
+            // (uniform per hydrometeor) one to three sub-beams, the table items evaluated in place: the lane
+            // gathers the 11 rows of ITS (slice, panel) block, 12 Horner chains advance together
+            // (itab1_columns: the same coefficients in the same order as k_psd_lookup / k_subbeam_sum)
+            const ItabDev &t = its.t[j];
+            for (int sq = 0; sq < a.n_sub; ++sq) {
+                const long sbg = sbg0 + (long)sq * a.n_gates;
+                if (!((a.vmask[sbg] >> j) & 1)) continue;
+                const double2 rc = a.rec[(long)j * n_sbg + sbg];
+                double2 v[CPOL_N_SZ / 2];
+                if (rc.x >= 0.0) {
+                    const int key = a.key[(long)j * n_sbg + sbg];
+                    const int pn = min((int)rc.x, t.n_pan - 1);
+                    const double u = 2.0 * (rc.x - (double)pn) - 1.0;
+                    // (itab1_columns with the rows requested CPOL_FINAL_ROW_UNROLL at a time: all 66 loads in
+                    // flight at once need 264 VGPRs)
+                    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
+                    const double2 *blk = reinterpret_cast<const double2 *>(
+                        t.tab + ((long)(key - a.key_base[j]) * t.n_pan + pn) * (NC * NFP));
+#pragma unroll
+                    for (int f = 0; f < CPOL_N_SZ / 2; ++f) v[f] = blk[(NC - 1) * (NFP / 2) + f];
+#pragma unroll CPOL_FINAL_ROW_UNROLL
+                    for (int q = NC - 2; q >= 0; --q) {
+#pragma unroll
+                        for (int f = 0; f < CPOL_N_SZ / 2; ++f) {
+                            const double2 cq = blk[q * (NFP / 2) + f];
+                            v[f].x = fma(v[f].x, u, cq.x);
+                            v[f].y = fma(v[f].y, u, cq.y);
+                        }
+                    }
+#pragma unroll
+                    for (int f = 0; f < CPOL_N_SZ / 2; ++f) { v[f].x *= rc.y; v[f].y *= rc.y; }
+                } else {                                       // (an item outside the table: integrated bin by bin)
+                    const double2 *r = reinterpret_cast<const double2 *>(a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ);
+#pragma unroll
+                    for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = r[c];
+                }
+                const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[sq];
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) {
+                    double y = ((c & 1) ? v[c / 2].y : v[c / 2].x) * w;
+                    double x = (double)acc[c];
+                    if (!(x == x)) x = 0.0;
+                    if (!(y == y)) y = 0.0;
+                    acc[c] = (float)(x + y);
+                }
             }
         } else
         // sub-beams in groups of CPOL_FINAL_BATCH: the keys and the result rows of a group are read
@@ -636,8 +750,16 @@ struct ScanRayArgs {
 #endif
 // THREADS: 256 (a gate or two per thread); 512 when the sweep has fewer rays than the GPU has CUs
 // (the share of one of N GPUs: the kernel's duration is that of ONE workgroup then)
+#ifndef CPOL_FINAL_WPE
+#define CPOL_FINAL_WPE 0             // experiment knob: wavefronts per SIMD asked of the register allocator (0: its own choice)
+#endif
+#if CPOL_FINAL_WPE
+#define CPOL_FINAL_ATTR __attribute__((amdgpu_waves_per_eu(CPOL_FINAL_WPE, CPOL_FINAL_WPE)))
+#else
+#define CPOL_FINAL_ATTR
+#endif
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_final(FinalArgs a, ScanRayArgs r)
+__global__ __launch_bounds__(THREADS) CPOL_FINAL_ATTR void k_final(FinalArgs a, ScanRayArgs r, ItabSet its)
 {
     extern __shared__ float lds[];          // [3][n_gates]
     const int ray = blockIdx.x;
@@ -649,7 +771,7 @@ __global__ __launch_bounds__(THREADS) void k_final(FinalArgs a, ScanRayArgs r)
     float *s_k = lds, *s_h = lds + ng, *s_v = lds + 2 * ng;
     for (int g = tid; g < ng; g += THREADS) {
         float k2, fh, fv;
-        final_gate(a, ray, g, k2, fh, fv);
+        final_gate(a, its, ray, g, k2, fh, fv);
         s_k[g] = k2;
         s_h[g] = fh;
         s_v[g] = fv;

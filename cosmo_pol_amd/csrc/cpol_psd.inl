@@ -326,6 +326,10 @@ __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &ou
 // against 0.69 ms + 2.21 ms for k_classify + k_psd_lookup: the lookup is bound by the vector-L1
 // gather, not by HBM, and inside the 16-wave ranking workgroups it spills; 4- and 8-wave
 // workgroups 3.6 / 4.5 ms.)
+#ifndef CPOL_CLASSIFY_TFUN_EARLY
+#define CPOL_CLASSIFY_TFUN_EARLY 0   // (measured, round 4: both float32 functions of T requested right after T, ahead of the
+                                     // hydrometeor loop and whether or not snow / ice are present: C4 volume 2.11 -> 2.20 ms, C2 sweep 19.7 -> 21.5 us)
+#endif
 #ifndef CPOL_CLASSIFY_WPE
 #define CPOL_CLASSIFY_WPE 4          // wavefronts per SIMD asked of the register allocator (128 VGPRs: what 16-wave workgroups
                                      // imposed; without it the allocator takes more registers and occupancy drops)
@@ -382,6 +386,16 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) CPOL_CLASSIFY_ATTR void k_cl
     const int var_t0 = hs.h[0].d.var_t;
     const float T0 = in ? a.vals[var_t0 * n + i] : 0.f;
     float q_ahead = (in && hs.h[0].d.q_source == CPOL_Q_MODEL) ? a.vals[hs.h[0].d.var_q * n + i] : 0.f;
+#if CPOL_CLASSIFY_TFUN_EARLY
+    // both float32 functions of T requested as soon as T is known, ahead of the hydrometeor loop (inside it
+    // the 4-byte gathers sat behind `valid` in the dependent chain of snow and ice)
+    float tf_snow = 0.f, tf_ice = 0.f;
+    const unsigned tf_idx = __float_as_uint(T0) - CPOL_TFUN_FIRST_BITS;
+    const bool tf_ok = in && tf_idx < CPOL_TFUN_COUNT;
+    const bool tf_snow_ok = tf_ok && a.tfun_snow, tf_ice_ok = tf_ok && a.tfun_ice;
+    if (tf_snow_ok) tf_snow = a.tfun_snow[tf_idx];
+    if (tf_ice_ok) tf_ice = a.tfun_ice[tf_idx];
+#endif
     for (int j = 0; j < hs.n_hydro; ++j) {
         const HydroDev &h = hs.h[j];
         const cpol_hydro_desc &d = h.d;
@@ -427,6 +441,10 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) CPOL_CLASSIFY_ATTR void k_cl
             case CPOL_RULE_SNOW_1MOM: {
                 // hydrometeors.py:896-899: float32 chain, then float64 from lambda_factor on
                 float n0;
+#if CPOL_CLASSIFY_TFUN_EARLY
+                if (d.var_t == var_t0 && tf_snow_ok) n0 = tf_snow;
+                else
+#endif
                 if (!tfun_lookup(a.tfun_snow, T, n0))
                     n0 = 13.5f * (565000.0f * exp_f32(-0.107f * (T - 273.15f))) / 1000.0f;
                 float an0 = (float)d.a * n0;
@@ -454,6 +472,10 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) CPOL_CLASSIFY_ATTR void k_cl
                 const float Tc = T - 273.15f;
                 const float n3 = 3.0f;
                 float pa;
+#if CPOL_CLASSIFY_TFUN_EARLY
+                if (d.var_t == var_t0 && tf_ice_ok) pa = tf_ice;
+                else
+#endif
                 if (!tfun_lookup(a.tfun_ice, T, pa)) {
                     pa = 5.065339f - 0.062659f * Tc - (float)(3.032362 * 3) + 0.029469f * Tc * n3
                         - 0.000285f * (Tc * Tc) + (float)(0.312550 * 9) + 0.000204f * (Tc * Tc) * n3
@@ -1821,7 +1843,9 @@ struct LookupArgs {
     long n_sbg;
     int tile;                   // lanes of a wavefront = 16 neighbouring rays x 4 gates of one sub-beam index
     int n_rays, n_sub, n_gates; // (melting species: neighbouring rays share the (slice, panel) block, gates do not)
-    int skip_res_1d;            // the 12 columns of the 1-D species are evaluated by k_subbeam_sum instead
+    int vn_1d;                  // with skip_res_1d: the Doppler sums of the 1-D species are still written here (k_final
+                                // evaluates the columns in place but reads vn[]; k_subbeam_sum writes them itself)
+    int skip_res_1d;            // the 12 columns of the 1-D species are evaluated by k_subbeam_sum / k_final instead
                                 // (nothing of them is stored); only vn / the ice intercept are written here
 };
 
@@ -1948,7 +1972,7 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
         // (k_subbeam_sum evaluates the columns AND the Doppler sums of the 1-D species: nothing to do
         // here for a species that does not need the ice intercept of the spectrum kernels)
         if (a.skip_res_1d && !t.two_d &&
-            !(a.par_w && hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD)) continue;
+            !(a.par_w && hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD) && !(a.vn_1d && a.vn && t.writes_vn)) continue;
         const int key = ((present >> j) & 1u) ? a.key[(long)j * n + i] : -1;
         const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
         const double2 rc = key >= 0 ? a.rec[(long)j * n + i] : make_double2(-1.0, 0.0);
@@ -2003,7 +2027,7 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet 
             t.tab + ((long)(key - hs.h[j].key_base) * t.n_pan + pn) * NB);
         // gamma: N0 x exp(-lambda d0) x G(lambda);  ice: QM x R(lambda)  (the scale comes with the record)
         const double scale = rc.y;
-        const bool want_vn = a.vn && t.writes_vn && !a.skip_res_1d;     // uniform (k_subbeam_sum writes them otherwise)
+        const bool want_vn = a.vn && t.writes_vn && (!a.skip_res_1d || a.vn_1d);     // uniform (k_subbeam_sum writes them otherwise)
         const bool want_n0 = ice && a.par_w;                            // uniform
         if (!a.skip_res_1d) {
             double2 v[CPOL_N_SZ / 2];

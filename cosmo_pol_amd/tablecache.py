@@ -8,7 +8,10 @@ scattering table, so they are kept as `.npz` files under
 
     $CPOL_CACHE_DIR,  else  <lut_dir>/.cpol_cache  (set_default_dir),  else  <tmp>/cosmo_pol_amd_cache_<uid>
 
-named by a digest of EVERYTHING the table depends on (inputs, builder source code, NumPy version);
+(created with mode 0700; a directory that belongs to another user or that group / others may write to is
+not used: the tables are then rebuilt every time) and named by a digest of EVERYTHING the table depends on
+(inputs, builder source code, NumPy version, the machine type and the precision of np.longdouble, in which the
+builders compute);
 the same digest is stored inside the file and checked when it
 is read, a `verify` callback may recompute a sample, and any mismatch, short file or load error
 makes the entry stale: it is rebuilt and replaced.  CPOL_CACHE=0 switches the cache off.
@@ -40,6 +43,32 @@ def enabled():
     return os.environ.get('CPOL_CACHE', '1') != '0'
 
 
+def usable_dir(create=True):
+    """The cache directory if it is safe to use, else None: it must belong to this user and be writable by
+    nobody else (another local user could otherwise plant entries: the stored digest is computable from
+    public inputs).  Created with mode 0700 when missing."""
+    d = cache_dir()
+    try:
+        if create:
+            os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.stat(d)
+    except OSError:
+        return None
+    if hasattr(os, 'getuid') and st.st_uid != os.getuid():
+        return None
+    if st.st_mode & 0o022:
+        return None
+    return d
+
+
+def platform_parts():
+    """What the bits of a host-built table depend on besides its inputs: the machine type and the
+    extended-precision format the builders compute in (x86 80-bit vs aarch64 128-bit long double)."""
+    import platform
+    fi = np.finfo(np.longdouble)
+    return ('platform', platform.machine(), int(fi.bits), float(fi.eps))
+
+
 def digest_of(parts):
     h = hashlib.blake2b(digest_size=20)
     for p in parts:
@@ -65,8 +94,11 @@ def memo(name, parts, compute, verify=None):
     File layout: a float64 header [magic, 20 digest bytes as numbers, is_none] then the array."""
     if not enabled():
         return compute()
-    dg = digest_of(parts)
-    path = os.path.join(cache_dir(), '%s-%s.npz' % (name, dg[:24]))
+    d = usable_dir()
+    if d is None:
+        return compute()
+    dg = digest_of(list(parts) + [platform_parts()])
+    path = os.path.join(d, '%s-%s.npz' % (name, dg[:24]))
     if os.path.exists(path):
         try:
             with np.load(path, allow_pickle=False) as z:
@@ -82,7 +114,6 @@ def memo(name, parts, compute, verify=None):
         stats['miss'] += 1
     value = compute()
     try:
-        os.makedirs(cache_dir(), exist_ok=True)
         tmp = '%s.%d.tmp.npz' % (path, os.getpid())
         np.savez(tmp, digest=np.array(dg), is_none=np.array(value is None),
                  value=np.zeros(0) if value is None else value)

@@ -276,6 +276,12 @@ int  cpol_host_alloc_near(int device, size_t bytes, void **out);
  * tell a one-process-per-GPU launcher which cores to run the rank on (the reference's pool is not
  * placed at all, radar_operator.py:402) */
 int  cpol_device_pci_bus_id(int device, char *buf, int len);
+/* free and total device memory of the context's GPU in bytes (hipMemGetInfo), and an estimate of
+ * the work-buffer bytes ONE sub-beam gate of a launch sequence needs with the hydrometeors staged
+ * now (`per_gate`: about 1.2 KB with six species): what a caller that packs many sweeps into one
+ * cpol_run_sweep call sizes its batches by (the reference processes one radial at a time,
+ * radar_operator.py:431) */
+int  cpol_mem_info(cpol_ctx *ctx, size_t *free_bytes, size_t *total_bytes, size_t *per_gate);
 /* the HIP stream (hipStream_t) the context launches on: to order foreign work (copies,
  * collectives) against a sweep with events */
 int  cpol_get_stream(cpol_ctx *ctx, void **hip_stream);

@@ -168,10 +168,14 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
     assert n_valid > 300 and n_melt > 100, (n_valid, n_melt)
     op.close()
     forms = {}
-    for form in ('gather', 'coop', 'tail'):
+    for form in ('gather', 'gather1', 'coop', 'tail'):
+        # 'gather': the per-lane gather in its small-launch form (three wavefronts per (tile, hydrometeor), the
+        # whole block requested at once: what a 45-ray launch gets by default); 'gather1': one wavefront per
+        # (tile, hydrometeor), rows two at a time (what a large launch gets with CPOL_SUBSUM_COOP=0);
         # 'coop': up to 6 table blocks per wavefront and sub-beam through the scalar cache, the remaining
         # lanes by the gather tail; 'tail': ONE block that way, every other lane through the tail
-        monkeypatch.setenv('CPOL_SUBSUM_COOP', '0' if form == 'gather' else '1')     # (read when the context is created)
+        monkeypatch.setenv('CPOL_SUBSUM_COOP', '0' if form.startswith('gather') else '1')     # (read when the context is created)
+        monkeypatch.setenv('CPOL_SUBSUM_SMALL', '0' if form == 'gather1' else '1')
         monkeypatch.setenv('CPOL_SUBSUM_COOP_ROUNDS', '1' if form == 'tail' else '6')
         opc = RadarOperator(config=over, luts=luts, output_variables='only_radar', lanes=1)
         opc.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
@@ -181,6 +185,7 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
     for k in FIELDS:
         assert np.array_equal(forms['gather'][k], forms['coop'][k], equal_nan=True), k
         assert np.array_equal(forms['gather'][k], forms['tail'][k], equal_nan=True), k
+        assert np.array_equal(forms['gather'][k], forms['gather1'][k], equal_nan=True), k
         assert np.array_equal(forms['gather'][k], res[k], equal_nan=True), k     # (res: the default choice, last elevation)
 
 
@@ -217,10 +222,17 @@ def test_lanes_volume_scan_equals_sequential():
     luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
     elevs = [0.5, 1.5, 3.0, 5.0, 8.0]
     scans = []
-    for lanes, one_sequence in ((1, False), (3, False), (3, True)):
+    for lanes, one_sequence in ((1, False), (3, False), (3, True), (2, 'budget')):
         op = RadarOperator(config=conf, luts=luts, output_variables='all', lanes=lanes)
-        op.volume_in_one_sequence = one_sequence
+        op.volume_in_one_sequence = bool(one_sequence)
         op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+        if one_sequence == 'budget':
+            # a memory budget of two sweeps' work buffers: the scan runs as sequences of 2 + 2 + 1 sweeps
+            free, total, per_gate = op._ctx.mem_info()
+            assert 0 < free <= total and 500 < per_gate < 4000
+            op.sequence_memory_budget = int(2.5 * per_gate * 90 * len(op.constants.RANGE_RADAR))
+            groups = op._sweep_groups([(np.arange(0, 360, 4.0), np.full(90, e)) for e in elevs])
+            assert [len(g) for g in groups] == [2, 2, 1]
         scans.append(op.get_PPI(elevs, az_step=4.0))
         if lanes == 3 and not one_sequence:
             assert len(op._lane_ctx) == 2
@@ -231,7 +243,7 @@ def test_lanes_volume_scan_equals_sequential():
             op.set_lut()
             assert op._lane_ctx == []
         if one_sequence:
-            assert op._lane_ctx == []                    # one call on the root context
+            assert op._lane_ctx == []                    # calls on the root context only
         op.close()
     a = scans[0]
     for b in scans[1:]:

@@ -166,9 +166,9 @@ def test_lazy_fields_equal_the_eager_container():
     assert isinstance(scan.fields, LazyDict)
     assert list(scan.fields.keys()) == ['ZH', 'ZDR', 'ZV', 'KDP', 'Latitude', 'Longitude', 'rangearray']
     assert 'ZH' in scan.fields and len(scan.fields) == 7 and 'pending' in repr(scan.fields)
-    assert not dict.__contains__(scan.fields, 'ZH')                 # nothing built yet
+    assert scan.fields.pending('ZH')                                # nothing built yet
     zh = scan.fields['ZH']['data']
-    assert dict.__contains__(scan.fields, 'ZH') and not dict.__contains__(scan.fields, 'ZV')
+    assert not scan.fields.pending('ZH') and scan.fields.pending('ZV')
     lin = np.concatenate([s['fields']['ZH'] for s in sweeps])
     with np.errstate(divide='ignore'):
         exp = 10 * np.log10(np.where(lin == 0, np.nan, lin))
@@ -187,3 +187,38 @@ def test_lazy_fields_equal_the_eager_container():
     assert list(scan.fields)[-1] == 'extra'
     del scan.fields['ZDR']
     assert 'ZDR' not in scan.fields and len(scan.fields) == 7
+
+
+def test_lazydict_is_a_full_mapping():
+    import pytest
+    """Round-3 advisor finding: the containers' field mapping must behave like the plain dict of the
+    reference for every dict method, pending entries included."""
+    import copy
+    import pickle
+    from cosmo_pol_amd.radar_operator import LazyDict
+    built = []
+
+    def mk(v):
+        def make():
+            built.append(v)
+            return v
+        return make
+    d = LazyDict()
+    d.add('a', mk(1))
+    d.add('b', mk(2))
+    d['c'] = 3
+    assert list(d) == ['a', 'b', 'c'] and len(d) == 3 and 'a' in d and not built
+    assert d.pop('a') == 1 and built == [1] and list(d) == ['b', 'c']          # pop of a pending key builds it
+    d.update({'x': 9, 'b': 20})                                                # update sees and orders every key
+    assert list(d.keys()) == ['b', 'c', 'x'] and d['b'] == 20 and built == [1]  # (the overwritten builder never ran)
+    assert d.setdefault('c', 0) == 3 and d.setdefault('y', 7) == 7
+    d.add('z', mk(5))
+    assert d == {'b': 20, 'c': 3, 'x': 9, 'y': 7, 'z': 5}                      # == builds and compares values
+    c = d.copy()
+    assert type(c) is dict and c == dict(d.items())
+    d.add('p', mk(11))
+    assert pickle.loads(pickle.dumps(d)) == dict(d.items()) and copy.deepcopy(d)['p'] == 11
+    del d['p']
+    with pytest.raises(KeyError):
+        d['p']
+    assert d.get('nope', 4) == 4 and 'pending' not in repr(d)

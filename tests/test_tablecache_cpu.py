@@ -74,3 +74,30 @@ def test_digest_follows_inputs_and_builder_source(cache, monkeypatch):
     before = dict(tablecache.stats)
     hyd.build_hydro('I', '1mom', lut, vi)
     assert tablecache.stats == before
+
+
+def test_a_cache_directory_others_can_write_to_is_not_used(tmp_path, monkeypatch):
+    """Advisor finding of round 3: the default directory name is predictable, so the cache only trusts a
+    directory of this user that nobody else can write to (0700 when it creates it)."""
+    import stat
+    from cosmo_pol_amd import tablecache
+    d = tmp_path / 'shared'
+    monkeypatch.setenv('CPOL_CACHE_DIR', str(d))
+    monkeypatch.setenv('CPOL_CACHE', '1')
+    calls = []
+
+    def compute():
+        calls.append(1)
+        return np.arange(4.0)
+    tablecache.memo('t', ['x'], compute)
+    assert stat.S_IMODE(os.stat(d).st_mode) == 0o700 and len(os.listdir(d)) == 1
+    tablecache.memo('t', ['x'], compute)
+    assert len(calls) == 1                                  # served from the cache
+    os.chmod(d, 0o777)                                      # somebody else may write: not trusted any more
+    assert tablecache.usable_dir() is None
+    tablecache.memo('t', ['x'], compute)
+    assert len(calls) == 2
+    os.chmod(d, 0o700)
+    tablecache.memo('t', ['x'], compute)
+    assert len(calls) == 2
+    assert tablecache.platform_parts()[0] == 'platform' and tablecache.platform_parts()[2] >= 64

@@ -9,6 +9,6 @@ for spec in "$@"; do
   make -s -C cosmo_pol_amd/csrc clean >/dev/null
   if ! make -s -C cosmo_pol_amd/csrc EXTRA="$extra" > gpurun_out/build_$tag.log 2>&1; then echo "$tag BUILD FAILED"; tail -5 gpurun_out/build_$tag.log; continue; fi
   echo "== $tag [$extra] [$envs]"
-  env $envs $cmd --tag "$tag" 2>>gpurun_out/variants.err | grep -E "^\{|^all|^rec|^ice|^melt" | cut -c1-700
+  env $envs $cmd --tag "$tag" 2>>gpurun_out/variants.err | grep -E "^\{|^all|^rec|^ice|^melt|^void |^k_|^== " | cut -c1-700
 done
 make -s -C cosmo_pol_amd/csrc clean >/dev/null; make -s -C cosmo_pol_amd/csrc >/dev/null
