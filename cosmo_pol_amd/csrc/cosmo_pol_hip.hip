@@ -25,6 +25,7 @@
 #include "cpol_interp.inl"
 #include "cpol_psd.inl"
 #include "cpol_final.inl"
+#include "cpol_gate.inl"
 #include "cpol_spectrum.inl"
 
 namespace {
@@ -113,7 +114,7 @@ struct cpol_ctx {
     DevBuf b_traj, b_wgate, b_clk, b_rayc;
     DevBuf b_beam, b_spectrum, b_outwin;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
-        b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel, b_proj, b_blkranked, b_rec, b_vmask;
+        b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel, b_proj, b_blkranked, b_rec, b_vmask, b_gscan, b_defer;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
@@ -582,7 +583,7 @@ void cpol_destroy(cpol_ctx *ctx)
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_units,
                      &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_pos,
-                     &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel, &ctx->b_proj, &ctx->b_blkranked, &ctx->b_rec, &ctx->b_vmask,
+                     &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel, &ctx->b_proj, &ctx->b_blkranked, &ctx->b_rec, &ctx->b_vmask, &ctx->b_gscan, &ctx->b_defer,
                      &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model};
     for (DevBuf *b : all) free_buf(*b);
     for (auto &b : ctx->b_out) free_buf(b);
@@ -1260,8 +1261,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_rec, (size_t)n_hyd * n_sbg * sizeof(double2));
     ENSURE(ctx->b_vmask, (size_t)n_sbg);
     ENSURE(ctx->b_offset, (size_t)2 * n_keys * sizeof(int));        // item and unit offsets
-    const long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
-    ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
+    // (work units: up to 64 / 128 sorted items each; declared here, sized below once the launch mode is known)
+    long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
     ENSURE(ctx->b_totals, 4 * sizeof(long long));
     ENSURE(ctx->b_perm, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_res, (size_t)n_hyd * n_sbg * CPOL_N_SZ * sizeof(double));
@@ -1324,6 +1325,26 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         if (tj.tab && (tj.two_d || (doppler && tj.writes_vn))) final_inplace = false;
     }
     subsum = subsum && n_sub >= 4;
+    // The single-beam fast path (cpol_gate.inl): one sub-beam per radial and every slot on an integral table --
+    // k_gate1 takes a gate from its interpolated model values to its polarimetric variables in one kernel
+    // (k_classify + k_psd_lookup + the per-gate half of k_final), items outside the tables go to the integrating
+    // kernels as one-item work units without the counting sort.  CPOL_GATE1=0 (or CPOL_SUBSUM=0, debug reads, a
+    // slot without a table, Doppler scheme 3) keeps the general launch sequence; the results are bit-identical.
+    // Not with melting species: their 2-D blocks are walked by whole wavefronts, which inside this one fat kernel
+    // (six species in sequence per thread) is no faster than k_classify + k_psd_lookup, and the four idle
+    // launches of the integrating flavours cost more than the two bucket launches they replace (C3 sweep at
+    // 3 deg: 203 us this way against 188; the kernel handles them -- CPOL_GATE1=2 forces it, tests do).
+    static const int gate1_env = getenv("CPOL_GATE1") ? atoi(getenv("CPOL_GATE1")) : 1;
+    bool gate1 = gate1_env != 0 && subsum_enabled && n_sub == 1 && !ctx->keep_debug && !dop3 && !ml;
+    for (int j = 0; j < n_hyd && gate1; ++j)
+        gate1 = ctx->its.t[j].tab != nullptr && (gate1_env == 2 || !ctx->its.t[j].two_d);
+    if (gate1) final_inplace = true;       // (k_final's recomputed gates take the table items from their records)
+    if (gate1) {
+        unit_cap = (long)n_hyd * n_sbg;    // one unit per item outside the tables, worst case every item
+        ENSURE(ctx->b_gscan, (size_t)3 * n_rg * sizeof(float));
+        ENSURE(ctx->b_defer, (size_t)n_rg);
+    }
+    ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
     const bool want_szi = ctx->keep_debug || subsum;
     if (want_szi) ENSURE(ctx->b_szinteg, (size_t)n_rg * n_hyd * CPOL_N_SZ * sizeof(float));
     const bool want_szt = out->sz_total != nullptr || ctx->keep_debug;
@@ -1427,6 +1448,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.rp.ke = p->ke; ia.rp.re = p->re; ia.rp.alt = p->radar_alt;
     ia.zero_buf = (int *)ctx->b_count.p;
     ia.zero_n = n_keys + 3;
+    ia.zero_buf2 = gate1 ? (int *)ctx->b_totals.p : nullptr;     // (4 long long: k_gate1 counts the items outside the tables into them)
+    ia.zero_n2 = 8;
     ia.geo = (const double *)ctx->v_geo;
     ia.sub_h = (const int *)ctx->v_subh;
     ia.sub_v = (const int *)ctx->v_subv;
@@ -1446,6 +1469,72 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     hipLaunchKernelGGL(k_interp_sweep, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256), 0, st,
                        ctx->model, ia);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
+
+    // ---- 2b. the arguments of the final stage (k_gate1, the single-beam fast path, needs them already) ----
+    FinalArgs fa{};
+    fa.res = (const double *)ctx->b_res.p;
+    fa.key = (const int *)ctx->b_key.p;
+    fa.vmask = (const unsigned char *)ctx->b_vmask.p;
+    fa.sub_mask = (const signed char *)ctx->b_mask.p;
+    fa.vals = (const float *)ctx->b_vals.p;
+    fa.sub_w = (const double *)ctx->v_subw;
+    fa.sz_integ = want_szi ? (float *)ctx->b_szinteg.p : nullptr;
+    fa.sz_total = want_szt ? (float *)T[O_SZT] : nullptr;
+    fa.ZH = (float *)T[O_ZH]; fa.ZV = (float *)T[O_ZV];
+    fa.ZDR = (float *)T[O_ZDR]; fa.KDP = (float *)T[O_KDP];
+    fa.DELTA_HV = (float *)T[O_DHV]; fa.RHOHV = (float *)T[O_RHOHV];
+    fa.ATT_H = (float *)T[O_ATTH]; fa.ATT_V = (float *)T[O_ATTV];
+    fa.mask = (double *)T[O_MASK];
+    fa.model_vars = want_model ? (double *)T[O_MODEL] : nullptr;
+    fa.n_rays = n_rays; fa.n_gates = ng; fa.n_sub = n_sub; fa.n_hydro = n_hyd; fa.n_vars = n_vars;
+    fa.c_zh = (float)p->c_zh;
+    fa.c_kdp = (float)(1e-3 * (180.0 / 3.14159265358979323846) * p->wavelength);
+    fa.c_2w = (float)(2 * p->wavelength);
+    double sum_w = 0;
+    for (int s = 0; s < n_sub; ++s) sum_w += t->sub_w[s];
+    fa.sum_w = sum_w;
+    fa.with_attenuation = p->with_attenuation;
+    fa.res_km = (float)(p->radial_res / 1000.);
+    fa.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
+    fa.RVEL = nullptr;
+    if (doppler) {
+        fa.RVEL = (double *)T[O_RVEL];
+        fa.vn = (const double *)ctx->b_vn.p;
+        fa.ice_first = (const IceFirst *)ctx->b_icefirst.p;
+        fa.geo = (const double *)ctx->v_geo;
+        fa.sub_h = (const int *)ctx->v_subh;
+        fa.elev = (const float *)ctx->b_elev.p;
+        fa.n_h = n_h;
+        fa.var_u = p->var_u; fa.var_v = p->var_v; fa.var_w = p->var_w;
+        fa.nyquist = t->nyquist ? (const double *)ctx->v_nyq : nullptr;
+        if (fa.var_u < 0 || fa.var_v < 0 || fa.var_w < 0 || fa.var_u >= n_vars ||
+            fa.var_v >= n_vars || fa.var_w >= n_vars) {
+            ctx->err = "cpol_run_sweep: simulate_doppler needs var_u / var_v / var_w";
+            return CPOL_ERR_ARG;
+        }
+        for (int j = 0; j < n_hyd && !dop3; ++j) {
+            const cpol_hydro_desc &d = ctx->hs.h[j].d;
+            // 1: vn[] per gate -- written by the PSD stage (scheme 2, melting species) or, for the analytic
+            // moments of the gamma species under scheme 1, by k_classify; 2: summed over the ray (1-moment
+            // ice, numeric integrate_V) and credited to the first valid gate
+            fa.vsrc[j] = (dop2 || d.psd_family == CPOL_PSD_MELTING) ? 1
+                       : (d.psd_family == CPOL_PSD_ICE_FIELD || d.numeric_intv) ? 2 : 1;
+        }
+    }
+
+    fa.eval_1d = final_inplace ? 1 : 0;
+    fa.rec = (const double2 *)ctx->b_rec.p;
+    for (int j = 0; j < n_hyd; ++j) fa.key_base[j] = ctx->hs.h[j].key_base;
+    bool any_vsrc2 = false;
+    for (int j = 0; j < n_hyd; ++j) any_vsrc2 = any_vsrc2 || (doppler && !dop3 && fa.vsrc[j] == 2);
+    if (gate1) {
+        fa.pre_gate = 1;
+        fa.ice_redo = any_vsrc2 ? 1 : 0;
+        fa.defer = (const unsigned char *)ctx->b_defer.p;
+        fa.sk = (const float *)ctx->b_gscan.p;
+        fa.sh = fa.sk + n_rg;
+        fa.sv = fa.sk + 2 * n_rg;
+    }
 
     // ---- 3. melting + PSD parameters + bucket histogram ----
     ClassifyArgs ca{};
@@ -1496,6 +1585,22 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         hipLaunchKernelGGL(k_ml_weights, dim3(n_rays * n_sub), dim3(64), 0, st, ma);
         ca.wgate = (const double *)ctx->b_wgate.p;
     }
+    if (gate1) {
+        GateArgs ga{};
+        ga.sk = (float *)ctx->b_gscan.p;
+        ga.sh = ga.sk + n_rg;
+        ga.sv = ga.sk + 2 * n_rg;
+        ga.defer = (unsigned char *)ctx->b_defer.p;
+        ga.units = (WorkUnit *)ctx->b_units.p;
+        ga.perm = (int *)ctx->b_perm.p;
+        ga.totals = (unsigned long long *)ctx->b_totals.p;
+        ga.res = (double *)ctx->b_res.p;
+        ga.store_items = any_vsrc2 ? 1 : 0;
+        ga.analytic_vn = ca.vn ? 1 : 0;
+        if (doppler) ca.vn = (double *)ctx->b_vn.p;        // (also the table-borne sums of a species summed over the ray)
+        hipLaunchKernelGGL(k_gate1, dim3(cdiv(n_rg, CPOL_GATE1_THREADS)), dim3(CPOL_GATE1_THREADS), 0, st,
+                           ctx->hs, ctx->its, ca, fa, ga);
+    } else
     hipLaunchKernelGGL(k_classify, dim3(cdiv(n_sbg, CPOL_CLASSIFY_THREADS)),
                        dim3(CPOL_CLASSIFY_THREADS), 0, st, ctx->hs, ctx->its, ca);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_CLASSIFY], st));
@@ -1520,9 +1625,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // on a table -- on a sibling stream beside k_psd_lookup, forked and joined with events: the isolated C2 sweep
     // 122 -> 135 us, the C3 volume 468 -> 476 us, the 225-ray C4 share 1.568 -> 1.553 ms: a cross-stream event
     // costs the device about as much as the three idle launches it would hide.)
+    if (!gate1)
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
     // (a fixed grid: the workgroups stride over the k_classify gate ranges and skip the empty ones)
     const long n_cblk = cdiv(n_sbg, CPOL_CLASSIFY_THREADS);
+    if (!gate1)
     hipLaunchKernelGGL(k_bucket_scatter, dim3((unsigned)(n_cblk < 2048 ? n_cblk : 2048)), dim3(256), 0, st,
                        (const int *)ctx->b_key.p, (const int *)ctx->b_pos.p,
                        (int *)ctx->b_perm.p, (const int *)ctx->b_blkranked.p,
@@ -1559,7 +1666,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             la.tile = (two_d && tile_env && n_rays >= TILE_RAYS) ? 1 : 0;
             la.n_rays = n_rays; la.n_sub = n_sub; la.n_gates = ng;
             const long n_thr = la.tile ? (long)cdiv(n_rays, TILE_RAYS) * n_sub * cdiv(ng, TILE_GATES) * 64 : n_sbg;
-            if (launch)
+            if (launch && !gate1)
             hipLaunchKernelGGL(k_psd_lookup, dim3(cdiv(n_thr, CPOL_LOOKUP_THREADS)), dim3(CPOL_LOOKUP_THREADS), 0, st, ctx->hs, ctx->its, la);
         }
     }
@@ -1599,8 +1706,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // grids, 512 / 768, measured equal or slower; CPOL_PSD_GRID* are experiment knobs)
         static const long grid_u = getenv("CPOL_PSD_GRID") ? atol(getenv("CPOL_PSD_GRID")) : 1024;
         static const long grid_g = getenv("CPOL_PSD_GRID_GENERIC") ? atol(getenv("CPOL_PSD_GRID_GENERIC")) : 1024;
-        const dim3 grd_u((unsigned)(unit_cap < grid_u ? unit_cap : grid_u));
-        const dim3 grd((unsigned)(unit_cap < grid_g ? unit_cap : grid_g)), blk(CPOL_PSD_THREADS);
+        // (single-beam fast path: the units are single items outside the tables, a handful per volume -- a small
+        // grid costs an idle launch less; a flood of them is still processed, by 128 workgroups)
+        const long cap_u = gate1 ? 128 : grid_u, cap_g = gate1 ? 128 : grid_g;
+        const dim3 grd_u((unsigned)(unit_cap < cap_u ? unit_cap : cap_u));
+        const dim3 grd((unsigned)(unit_cap < cap_g ? unit_cap : cap_g)), blk(CPOL_PSD_THREADS);
         // The flavours touch disjoint items and could run side by side.  Measured (MI355X, one
         // sweep): on sibling streams (fork after the bucket sort, join before the final stage) the
         // PSD stage took 762 vs 734 us on C3 and 29.2 vs 27.1 ms on C4 -- every flavour is a
@@ -1717,62 +1827,14 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     }
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
 
-    // ---- 6. accumulation + polarimetric variables + scans ----
-    FinalArgs fa{};
-    fa.res = (const double *)ctx->b_res.p;
-    fa.key = (const int *)ctx->b_key.p;
-    fa.vmask = (const unsigned char *)ctx->b_vmask.p;
-    fa.sub_mask = (const signed char *)ctx->b_mask.p;
-    fa.vals = (const float *)ctx->b_vals.p;
-    fa.sub_w = (const double *)ctx->v_subw;
-    fa.sz_integ = want_szi ? (float *)ctx->b_szinteg.p : nullptr;
-    fa.sz_total = want_szt ? (float *)T[O_SZT] : nullptr;
-    fa.ZH = (float *)T[O_ZH]; fa.ZV = (float *)T[O_ZV];
-    fa.ZDR = (float *)T[O_ZDR]; fa.KDP = (float *)T[O_KDP];
-    fa.DELTA_HV = (float *)T[O_DHV]; fa.RHOHV = (float *)T[O_RHOHV];
-    fa.ATT_H = (float *)T[O_ATTH]; fa.ATT_V = (float *)T[O_ATTV];
-    fa.mask = (double *)T[O_MASK];
-    fa.model_vars = want_model ? (double *)T[O_MODEL] : nullptr;
-    fa.n_rays = n_rays; fa.n_gates = ng; fa.n_sub = n_sub; fa.n_hydro = n_hyd; fa.n_vars = n_vars;
-    fa.c_zh = (float)p->c_zh;
-    fa.c_kdp = (float)(1e-3 * (180.0 / 3.14159265358979323846) * p->wavelength);
-    fa.c_2w = (float)(2 * p->wavelength);
-    double sum_w = 0;
-    for (int s = 0; s < n_sub; ++s) sum_w += t->sub_w[s];
-    fa.sum_w = sum_w;
-    fa.with_attenuation = p->with_attenuation;
-    fa.res_km = (float)(p->radial_res / 1000.);
-    fa.wgate = ml ? (const double *)ctx->b_wgate.p : nullptr;
-    fa.RVEL = nullptr;
-    if (doppler) {
-        fa.RVEL = (double *)T[O_RVEL];
-        fa.vn = (const double *)ctx->b_vn.p;
-        fa.ice_first = (const IceFirst *)ctx->b_icefirst.p;
-        fa.geo = (const double *)ctx->v_geo;
-        fa.sub_h = (const int *)ctx->v_subh;
-        fa.elev = (const float *)ctx->b_elev.p;
-        fa.n_h = n_h;
-        fa.var_u = p->var_u; fa.var_v = p->var_v; fa.var_w = p->var_w;
-        fa.nyquist = t->nyquist ? (const double *)ctx->v_nyq : nullptr;
-        if (fa.var_u < 0 || fa.var_v < 0 || fa.var_w < 0 || fa.var_u >= n_vars ||
-            fa.var_v >= n_vars || fa.var_w >= n_vars) {
-            ctx->err = "cpol_run_sweep: simulate_doppler needs var_u / var_v / var_w";
-            return CPOL_ERR_ARG;
-        }
-        for (int j = 0; j < n_hyd && !dop3; ++j) {
-            const cpol_hydro_desc &d = ctx->hs.h[j].d;
-            // 1: vn[] per gate -- written by the PSD stage (scheme 2, melting species) or, for the analytic
-            // moments of the gamma species under scheme 1, by k_classify; 2: summed over the ray (1-moment
-            // ice, numeric integrate_V) and credited to the first valid gate
-            fa.vsrc[j] = (dop2 || d.psd_family == CPOL_PSD_MELTING) ? 1
-                       : (d.psd_family == CPOL_PSD_ICE_FIELD || d.numeric_intv) ? 2 : 1;
+    // ---- 6. accumulation + polarimetric variables + scans (the arguments: see 2b above) ----
+    if (doppler)
+        for (int j = 0; j < n_hyd && !dop3; ++j)
             if (fa.vsrc[j] == 2)
                 hipLaunchKernelGGL(k_ice_first, dim3(n_rays * n_sub), dim3(64), 0, st,
                                    (const unsigned char *)ctx->b_vmask.p, j,
                                    (const double *)ctx->b_vn.p + (long)j * n_sbg * 2,
                                    (IceFirst *)ctx->b_icefirst.p, ng);
-        }
-    }
     ScanRayArgs ra{};
     ra.PHIDP = (float *)T[O_PHIDP];
     ra.RVEL = nullptr;
@@ -1823,9 +1885,6 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     }
     if ((size_t)3 * ng * sizeof(float) > 64 * 1024) { ctx->err = "cpol_run_sweep: n_gates too large for the range scans (3 * n_gates floats of LDS)"; return CPOL_ERR_ARG; }
     fa.pre_integ = subsum ? 1 : 0;
-    fa.eval_1d = final_inplace ? 1 : 0;
-    fa.rec = (const double2 *)ctx->b_rec.p;
-    for (int j = 0; j < n_hyd; ++j) fa.key_base[j] = ctx->hs.h[j].key_base;
     if (subsum) fa.sz_integ = (float *)ctx->b_szinteg.p;
     fa.proj = nullptr;
     if (fa.RVEL && n_sub >= 4) {

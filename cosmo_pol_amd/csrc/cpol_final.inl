@@ -132,6 +132,12 @@ struct FinalArgs {
                                 // items and the items integrated bin by bin
     const double2 *rec;         // [n_hydro][n_sbg] {panel position (-1: not on the table), scale} (k_classify)
     int key_base[CPOL_MAX_HYDRO];
+    // single-beam fast path: k_gate1 has finished the gates and left the operands of the range scans; k_final
+    // recomputes (final_gate) only the deferred gates -- an item outside the integral tables -- and, when a
+    // species' fall-speed sums are totals over the ray (`ice_redo`), the gate that receives the total
+    int pre_gate, ice_redo;
+    const unsigned char *defer; // [n_rg]
+    const float *sk, *sh, *sv;  // [n_rg]
     float *sz_total;            // [n_rg][12] or NULL
     float *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *RHOHV, *ATT_H, *ATT_V;   // work / outputs
     double *mask;               // [n_rg]
@@ -159,6 +165,19 @@ struct FinalArgs {
 // the two-way attenuation factors of the gate, NaN -> 1)
 // Radial velocity seen by one sub-beam at one gate (doppler_scatter.py:276-281, 313-333;
 // proj_vel :46-47): mean fall speed of the hydrometeors present, wind projected on the beam.
+// ... the wind projected on the beam minus the mean fall speed v / nn of the species present
+__device__ __forceinline__ double proj_from_moments(const FinalArgs &a, int ray, int s, long sbg, long n_sbg, double v, double nn)
+{
+    const double vh = v / nn;
+    const double *gc = a.geo + ((long)ray * a.n_h + a.sub_h[s]) * 8;
+    const float th = a.elev[sbg] * 0.017453292f;          // np.deg2rad on float32
+    const double ct = (double)(float)cos((double)th), st = (double)(float)sin((double)th);
+    const double U = (double)a.vals[(long)a.var_u * n_sbg + sbg];
+    const double V = (double)a.vals[(long)a.var_v * n_sbg + sbg];
+    const double W = (double)a.vals[(long)a.var_w * n_sbg + sbg];
+    return (U * gc[0] + V * gc[1]) * ct + (W - vh) * st;
+}
+
 __device__ __forceinline__ double subbeam_proj(const FinalArgs &a, int ray, int s, int gate, long sbg, long n_sbg)
 {
     double v = 0.0, nn = 0.0;
@@ -179,14 +198,7 @@ __device__ __forceinline__ double subbeam_proj(const FinalArgs &a, int ray, int 
         if (vj == vj) v += vj;                  // nansum_arr
         if (nj == nj) nn += nj;
     }
-    const double vh = v / nn;
-    const double *gc = a.geo + ((long)ray * a.n_h + a.sub_h[s]) * 8;
-    const float th = a.elev[sbg] * 0.017453292f;          // np.deg2rad on float32
-    const double ct = (double)(float)cos((double)th), st = (double)(float)sin((double)th);
-    const double U = (double)a.vals[(long)a.var_u * n_sbg + sbg];
-    const double V = (double)a.vals[(long)a.var_v * n_sbg + sbg];
-    const double W = (double)a.vals[(long)a.var_w * n_sbg + sbg];
-    return (U * gc[0] + V * gc[1]) * ct + (W - vh) * st;
+    return proj_from_moments(a, ray, s, sbg, n_sbg, v, nn);
 }
 
 // With many sub-beams the terms above are evaluated by one thread per sub-beam gate first (a
@@ -493,6 +505,135 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
 #ifndef CPOL_FINAL_SBATCH
 #define CPOL_FINAL_SBATCH 7          // sub-beams whose RVEL terms / masks are requested together (experiment knob)
 #endif
+// Everything of an output gate behind the hydrometeor sums tot[12]: exact zeros -> NaN, get_pol_from_sz, the
+// operands of the range scans, RVEL, the radial mask, the antenna-averaged model variables.  `have_moments`: the
+// fall-speed sums (mom_v, mom_n) of the ONE sub-beam of a single-beam sweep come from the caller's registers
+// (k_gate1); else they are read from vn[] / ice_first[] (subbeam_proj).
+__device__ __forceinline__ void gate_finish(const FinalArgs &a, int ray, int gate, float (&tot)[CPOL_N_SZ], bool have_moments,
+                                            double mom_v, double mom_n, double wtot, float &k2_out, float &fh_out, float &fv_out)
+{
+    const long n_rg = (long)a.n_rays * a.n_gates;
+    const long rg = (long)ray * a.n_gates + gate;
+    const long n_sbg = n_rg * a.n_sub;
+    const long sbg0 = (long)ray * a.n_sub * a.n_gates + gate;      // + sub * n_gates
+    const float qnan = __builtin_nanf("");
+#pragma unroll
+    for (int c = 0; c < CPOL_N_SZ; ++c) if (tot[c] == 0.0f) tot[c] = qnan;     // Q5
+    if (a.sz_total) {
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) a.sz_total[rg * CPOL_N_SZ + c] = tot[c];
+    }
+
+    // ---- get_pol_from_sz (float32) ----
+    const float two_pi = (float)(2 * 3.14159265358979323846);
+    const float b = tot[0] - tot[1] - tot[2] + tot[3];
+    const float cc = tot[0] + tot[1] + tot[2] + tot[3];
+    const float xs_h = two_pi * b;
+    const float xs_v = two_pi * cc;
+    a.ZH[rg] = a.c_zh * xs_h;
+    a.ZV[rg] = a.c_zh * xs_v;
+    a.ZDR[rg] = xs_h / xs_v;
+    const float kdp = a.c_kdp * (tot[10] - tot[8]);
+    a.KDP[rg] = kdp;
+    const float k2 = 2.0f * kdp;
+    k2_out = (k2 == k2) ? k2 : 0.0f;                           // nan_cumsum
+    const float att_h = 4.343e-3f * (a.c_2w * tot[11]);
+    const float att_v = 4.343e-3f * (a.c_2w * tot[9]);
+    a.ATT_H[rg] = att_h;
+    a.ATT_V[rg] = att_v;
+    fh_out = fv_out = 1.0f;
+    if (a.with_attenuation) {
+        // 10**(-0.1*A*(radial_res/1000.)) in float32 (doppler_scatter.py:413-414); NaN -> 1
+        float fh = (float)exp10((double)(-0.1f * att_h * a.res_km));
+        float fv = (float)exp10((double)(-0.1f * att_v * a.res_km));
+        fh_out = (fh == fh) ? fh : 1.0f;
+        fv_out = (fv == fv) ? fv : 1.0f;
+    }
+    const float t47 = tot[4] + tot[7], t65 = tot[6] - tot[5];
+    const float aa = t47 * t47 + t65 * t65;
+    a.RHOHV[rg] = sqrtf(aa / (b * cc));
+    a.DELTA_HV[rg] = (float)atan2((double)(tot[5] - tot[6]), (double)(-tot[4] - tot[7]));
+
+    // ---- radial velocity, Doppler scheme 1 (doppler_scatter.py:276-281, 313-333, 418-420) ----
+    if (a.RVEL && !CPOL_SKIP_RVEL) {
+        double rv = __builtin_nan(""), tw = 0.0;
+        // with many sub-beams (the terms come from k_rvel_terms): in groups of CPOL_FINAL_SBATCH, the
+        // terms (and per-gate weights) of a group requested together; the float64 accumulation keeps
+        // the reference's order.  (C4 volume: k_final 467 -> 258 us; its 225-ray share 100 -> 70 us.)
+        int s_done = 0;
+        if (a.proj)
+            for (; s_done + CPOL_FINAL_SBATCH <= a.n_sub; s_done += CPOL_FINAL_SBATCH) {
+                double pj[CPOL_FINAL_SBATCH], wj[CPOL_FINAL_SBATCH];
+#pragma unroll
+                for (int q = 0; q < CPOL_FINAL_SBATCH; ++q) {
+                    const long sbg = sbg0 + (long)(s_done + q) * a.n_gates;
+                    pj[q] = a.proj[sbg];
+                    wj[q] = a.wgate ? a.wgate[sbg] : a.sub_w[s_done + q];
+                }
+#pragma unroll
+                for (int q = 0; q < CPOL_FINAL_SBATCH; ++q) {
+                    const double proj = pj[q], w = wj[q];
+                    if (proj == proj) tw += w;
+                    double x = (rv == rv) ? rv : 0.0;
+                    double y = proj * w;
+                    if (!(y == y)) y = 0.0;
+                    rv = x + y;
+                }
+            }
+        for (int s = s_done; s < a.n_sub; ++s) {
+            const long sbg = sbg0 + (long)s * a.n_gates;
+            const double proj = a.proj ? a.proj[sbg] : have_moments ? proj_from_moments(a, ray, s, sbg, n_sbg, mom_v, mom_n)
+                                                       : subbeam_proj(a, ray, s, gate, sbg, n_sbg);
+            const double w = a.wgate ? a.wgate[sbg] : a.sub_w[s];
+            if (proj == proj) tw += w;
+            double x = (rv == rv) ? rv : 0.0;
+            double y = proj * w;
+            if (!(y == y)) y = 0.0;
+            rv = x + y;
+        }
+        rv = rv / tw;
+        if (a.nyquist) {
+            // aliasing (utilities.py:142-156)
+            const double nyq = a.nyquist[ray], pi = 3.14159265358979323846;
+            const double theta = (rv + nyq) / (2 * nyq) * pi - pi / 2.;
+            const double fold = atan(tan(theta));
+            rv = (fold + pi / 2) * (2 * nyq) / pi - nyq;
+        }
+        a.RVEL[rg] = rv;
+    }
+
+    // ---- radial mask (doppler_scatter.py:472-477) ----
+    double msum = 0.0;
+    {
+        int s = 0;
+        for (; s + CPOL_FINAL_SBATCH <= a.n_sub; s += CPOL_FINAL_SBATCH) {
+            signed char mj[CPOL_FINAL_SBATCH];
+#pragma unroll
+            for (int q = 0; q < CPOL_FINAL_SBATCH; ++q) mj[q] = a.sub_mask[sbg0 + (long)(s + q) * a.n_gates];
+#pragma unroll
+            for (int q = 0; q < CPOL_FINAL_SBATCH; ++q) msum += (double)mj[q];
+        }
+        for (; s < a.n_sub; ++s) msum += (double)a.sub_mask[sbg0 + (long)s * a.n_gates];
+    }
+    msum /= (double)a.n_sub;
+    if (msum > -1.0 && msum <= 0.0) msum = 0.0;
+    if (a.mask) a.mask[rg] = msum;
+
+    // ---- integrate_radials: NaN-skipping weighted sum (float64) ----
+    if (a.model_vars) {
+        for (int v = 0; v < a.n_vars; ++v) {
+            double acc = 0.0;
+            for (int s = 0; s < a.n_sub; ++s) {
+                const long sbg = sbg0 + (long)s * a.n_gates;
+                double y = a.wgate ? (double)a.vals[(long)v * n_sbg + sbg] * a.wgate[sbg] / wtot
+                                   : (double)a.vals[(long)v * n_sbg + sbg] * a.sub_w[s] / a.sum_w;
+                if (y == y) acc += y;
+            }
+            a.model_vars[(long)v * n_rg + rg] = acc;
+        }
+    }
+}
+
 __device__ __forceinline__ void final_gate(const FinalArgs &a, const ItabSet &its, int ray, int gate, float &k2_out,
                                            float &fh_out, float &fv_out)
 {
@@ -617,120 +758,7 @@ __device__ __forceinline__ void final_gate(const FinalArgs &a, const ItabSet &it
             tot[c] = (j == 0) ? v : tot[c] + v;
         }
     }
-#pragma unroll
-    for (int c = 0; c < CPOL_N_SZ; ++c) if (tot[c] == 0.0f) tot[c] = qnan;     // Q5
-    if (a.sz_total) {
-#pragma unroll
-        for (int c = 0; c < CPOL_N_SZ; ++c) a.sz_total[rg * CPOL_N_SZ + c] = tot[c];
-    }
-
-    // ---- get_pol_from_sz (float32) ----
-    const float two_pi = (float)(2 * 3.14159265358979323846);
-    const float b = tot[0] - tot[1] - tot[2] + tot[3];
-    const float cc = tot[0] + tot[1] + tot[2] + tot[3];
-    const float xs_h = two_pi * b;
-    const float xs_v = two_pi * cc;
-    a.ZH[rg] = a.c_zh * xs_h;
-    a.ZV[rg] = a.c_zh * xs_v;
-    a.ZDR[rg] = xs_h / xs_v;
-    const float kdp = a.c_kdp * (tot[10] - tot[8]);
-    a.KDP[rg] = kdp;
-    const float k2 = 2.0f * kdp;
-    k2_out = (k2 == k2) ? k2 : 0.0f;                           // nan_cumsum
-    const float att_h = 4.343e-3f * (a.c_2w * tot[11]);
-    const float att_v = 4.343e-3f * (a.c_2w * tot[9]);
-    a.ATT_H[rg] = att_h;
-    a.ATT_V[rg] = att_v;
-    fh_out = fv_out = 1.0f;
-    if (a.with_attenuation) {
-        // 10**(-0.1*A*(radial_res/1000.)) in float32 (doppler_scatter.py:413-414); NaN -> 1
-        float fh = (float)exp10((double)(-0.1f * att_h * a.res_km));
-        float fv = (float)exp10((double)(-0.1f * att_v * a.res_km));
-        fh_out = (fh == fh) ? fh : 1.0f;
-        fv_out = (fv == fv) ? fv : 1.0f;
-    }
-    const float t47 = tot[4] + tot[7], t65 = tot[6] - tot[5];
-    const float aa = t47 * t47 + t65 * t65;
-    a.RHOHV[rg] = sqrtf(aa / (b * cc));
-    a.DELTA_HV[rg] = (float)atan2((double)(tot[5] - tot[6]), (double)(-tot[4] - tot[7]));
-
-    // ---- radial velocity, Doppler scheme 1 (doppler_scatter.py:276-281, 313-333, 418-420) ----
-    if (a.RVEL && !CPOL_SKIP_RVEL) {
-        double rv = __builtin_nan(""), tw = 0.0;
-        // with many sub-beams (the terms come from k_rvel_terms): in groups of CPOL_FINAL_SBATCH, the
-        // terms (and per-gate weights) of a group requested together; the float64 accumulation keeps
-        // the reference's order.  (C4 volume: k_final 467 -> 258 us; its 225-ray share 100 -> 70 us.)
-        int s_done = 0;
-        if (a.proj)
-            for (; s_done + CPOL_FINAL_SBATCH <= a.n_sub; s_done += CPOL_FINAL_SBATCH) {
-                double pj[CPOL_FINAL_SBATCH], wj[CPOL_FINAL_SBATCH];
-#pragma unroll
-                for (int q = 0; q < CPOL_FINAL_SBATCH; ++q) {
-                    const long sbg = sbg0 + (long)(s_done + q) * a.n_gates;
-                    pj[q] = a.proj[sbg];
-                    wj[q] = a.wgate ? a.wgate[sbg] : a.sub_w[s_done + q];
-                }
-#pragma unroll
-                for (int q = 0; q < CPOL_FINAL_SBATCH; ++q) {
-                    const double proj = pj[q], w = wj[q];
-                    if (proj == proj) tw += w;
-                    double x = (rv == rv) ? rv : 0.0;
-                    double y = proj * w;
-                    if (!(y == y)) y = 0.0;
-                    rv = x + y;
-                }
-            }
-        for (int s = s_done; s < a.n_sub; ++s) {
-            const long sbg = sbg0 + (long)s * a.n_gates;
-            const double proj = a.proj ? a.proj[sbg] : subbeam_proj(a, ray, s, gate, sbg, n_sbg);
-            const double w = a.wgate ? a.wgate[sbg] : a.sub_w[s];
-            if (proj == proj) tw += w;
-            double x = (rv == rv) ? rv : 0.0;
-            double y = proj * w;
-            if (!(y == y)) y = 0.0;
-            rv = x + y;
-        }
-        rv = rv / tw;
-        if (a.nyquist) {
-            // aliasing (utilities.py:142-156)
-            const double nyq = a.nyquist[ray], pi = 3.14159265358979323846;
-            const double theta = (rv + nyq) / (2 * nyq) * pi - pi / 2.;
-            const double fold = atan(tan(theta));
-            rv = (fold + pi / 2) * (2 * nyq) / pi - nyq;
-        }
-        a.RVEL[rg] = rv;
-    }
-
-    // ---- radial mask (doppler_scatter.py:472-477) ----
-    double msum = 0.0;
-    {
-        int s = 0;
-        for (; s + CPOL_FINAL_SBATCH <= a.n_sub; s += CPOL_FINAL_SBATCH) {
-            signed char mj[CPOL_FINAL_SBATCH];
-#pragma unroll
-            for (int q = 0; q < CPOL_FINAL_SBATCH; ++q) mj[q] = a.sub_mask[sbg0 + (long)(s + q) * a.n_gates];
-#pragma unroll
-            for (int q = 0; q < CPOL_FINAL_SBATCH; ++q) msum += (double)mj[q];
-        }
-        for (; s < a.n_sub; ++s) msum += (double)a.sub_mask[sbg0 + (long)s * a.n_gates];
-    }
-    msum /= (double)a.n_sub;
-    if (msum > -1.0 && msum <= 0.0) msum = 0.0;
-    if (a.mask) a.mask[rg] = msum;
-
-    // ---- integrate_radials: NaN-skipping weighted sum (float64) ----
-    if (a.model_vars) {
-        for (int v = 0; v < a.n_vars; ++v) {
-            double acc = 0.0;
-            for (int s = 0; s < a.n_sub; ++s) {
-                const long sbg = sbg0 + (long)s * a.n_gates;
-                double y = a.wgate ? (double)a.vals[(long)v * n_sbg + sbg] * a.wgate[sbg] / wtot
-                                   : (double)a.vals[(long)v * n_sbg + sbg] * a.sub_w[s] / a.sum_w;
-                if (y == y) acc += y;
-            }
-            a.model_vars[(long)v * n_rg + rg] = acc;
-        }
-    }
+    gate_finish(a, ray, gate, tot, false, 0.0, 0.0, wtot, k2_out, fh_out, fv_out);
 }
 
 // One workgroup per ray: every thread finishes gates (final_gate), the operands of the three
@@ -771,12 +799,21 @@ __global__ __launch_bounds__(THREADS) CPOL_FINAL_ATTR void k_final(FinalArgs a, 
     float *s_k = lds, *s_h = lds + ng, *s_v = lds + 2 * ng;
     for (int g = tid; g < ng; g += THREADS) {
         float k2, fh, fv;
-        final_gate(a, its, ray, g, k2, fh, fv);
+        bool redo = true;
+        if (a.pre_gate) {
+            redo = a.defer[base + g] != 0;
+            if (a.ice_redo) redo = redo || a.ice_first[ray].first_gate == g;      // (one sub-beam: [ray * n_sub + 0])
+        }
+        if (redo) final_gate(a, its, ray, g, k2, fh, fv);
+        else { k2 = a.sk[base + g]; fh = a.sh[base + g]; fv = a.sv[base + g]; }
         s_k[g] = k2;
         s_h[g] = fh;
         s_v[g] = fv;
     }
     __syncthreads();
+    // (Measured and dropped, round 4: the scanning wavefront loading 64 operands at once, one per lane, and every
+    // step taking its operand with v_readlane while all lanes carry the running value -- no LDS access inside the
+    // dependent chain: k_final 18.4 -> 35.7 us on the C2 sweep, 110 -> 127 us on the 225-ray C4 share.)
     // strictly sequential float32 scans, one wavefront (lane 0) per scan so that the
     // operation is wave-uniform; LDS is read in chunks of 8 so that the read latency is
     // paid once per chunk, not once per dependent step

@@ -355,6 +355,8 @@ struct InterpArgs {
     RayPathArgs rp;
     int *zero_buf;              // the sweep's bucket counters, cleared here (no fill kernel)
     int zero_n;
+    int *zero_buf2;             // ... and the work-unit totals of the single-beam fast path (k_gate1 counts into them) or NULL
+    int zero_n2;
     const double *geo;          // [n_rays][n_h][8]
     const int *sub_h, *sub_v;
     float *vals;                // [n_vars][n_sbg]
@@ -389,9 +391,10 @@ __global__ __launch_bounds__(256) CPOL_INTERP_ATTR void k_interp_sweep(ModelDev 
     const int sub = blockIdx.x % a.n_sub, ray = blockIdx.x / a.n_sub;
     if (a.zero_buf) {
         const long total = (long)gridDim.x * gridDim.y * blockDim.x;
-        for (long i = ((long)blockIdx.x * gridDim.y + blockIdx.y) * blockDim.x + threadIdx.x;
-             i < a.zero_n; i += total)
+        const long first = ((long)blockIdx.x * gridDim.y + blockIdx.y) * blockDim.x + threadIdx.x;
+        for (long i = first; i < a.zero_n; i += total)
             a.zero_buf[i] = 0;
+        if (a.zero_buf2 && first < a.zero_n2) a.zero_buf2[first] = 0;      // (zero_n2 <= one workgroup)
     }
     if (gate >= a.n_gates) return;
     const int ih = a.sub_h[sub], jv = a.sub_v[sub];

@@ -317,6 +317,141 @@ __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &ou
 
 #define CPOL_MAX_PAR 6
 
+// One (gate, hydrometeor): validity, LUT slice, PSD parameters, position on the integral table's panel axis,
+// scale of a table item, analytic fall-speed moments -- everything k_classify hands on per item, computed
+// in registers (k_classify stores it; k_gate1, the fused single-beam kernel, uses it in place).
+struct ClassItem {
+    int key;                 // LUT slice of a present species (-1: absent)
+    double p0, p1, p2;       // parameter slots 0..2 of the integrating kernels
+    double pf;               // position on the panel axis of the slot's integral table (where `lookup`)
+    double scale;            // scale of a table item: gamma N0 exp(-lambda d0), ice and melting QM
+    double dv, dn;           // analytic fall-speed moments (where `has_vn`)
+    bool valid, lookup, has_vn;
+};
+
+__device__ __forceinline__ void classify_item(const HydroDev &h, const ItabDev &tj, const ClassifyArgs &a, long n, long i,
+                                              bool in, float qm, double fw, float T0, int var_t0, float e, ClassItem &o)
+{
+    const cpol_hydro_desc &d = h.d;
+    // NaN -> false (doppler_scatter.py:185); scheme 'ml': only gates where the
+    // sub-beam has a non-zero weight (:186-189)
+    const bool valid = in && (qm > 0.f) && (!a.wgate || a.wgate[i] > 0.0);
+    int key = -1;
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0;         // parameter slots 0..2
+    double loglam = 0.0;                          // log of a slope parameter when the rule formed it as
+    int ll_slot = -1;                             // (slot whose logarithm it is) exp(y log x): the table position and the fall-speed moments
+                                                  // take it from there instead of a logarithm of the result
+    if (valid) {
+        const float T = d.var_t == var_t0 ? T0 : a.vals[d.var_t * n + i];
+        // lut.py:336-341: float32 arithmetic for float32 queries
+        int eb = clip_bin((e - d.e_lo) / d.e_step, d.n_e);
+        int tb = d.second_axis_f64 ? clip_bin64((fw - (double)d.t_lo) / (double)d.t_step, d.n_t)
+                                   : clip_bin((T - d.t_lo) / d.t_step, d.n_t);
+        key = h.key_base + eb * d.n_t + tb;
+        const double q = (double)qm;
+        double lamf = 0.0, n0v = 0.0, qnv = 0.0;   // final lambda / N0 (get_N units)
+        double ll = 0.0;                           // log(lambda) where the rule has it from its power (has_ll)
+        // the item's parameters (slots 0..2 of par[], read by the integrating kernels; slot 1 by
+        // the 2-D lookup of the melting species)
+        switch (d.rule) {
+        case CPOL_RULE_RAIN_1MOM:
+        case CPOL_RULE_GRAUPEL_1MOM:
+            ll = d.lam_exponent * cp_log(d.lambda_factor / q);
+            lamf = cp_exp(ll);                            // = cp_pow(lambda_factor / q, lam_exponent)
+            loglam = ll; ll_slot = 0;
+            n0v = d.n0_fixed;
+            p0 = lamf;
+            p1 = 1.0;                                     // N0 folded into pre[]
+            break;
+        case CPOL_RULE_SNOW_1MOM: {
+            // hydrometeors.py:896-899: float32 chain, then float64 from lambda_factor on
+            float n0;
+            if (!tfun_lookup(a.tfun_snow, T, n0))
+                n0 = 13.5f * (565000.0f * exp_f32(-0.107f * (T - 273.15f))) / 1000.0f;
+            float an0 = (float)d.a * n0;
+            ll = d.lam_exponent * cp_log((double)an0 * d.lambda_factor / q);
+            lamf = cp_exp(ll);
+            loglam = ll; ll_slot = 0;
+            n0v = (double)n0;
+            p0 = lamf;
+            p1 = n0v;
+            break; }
+        case CPOL_RULE_TWO_MOMENT: {
+            // hydrometeors.py:231-246
+            qnv = (double)a.vals[d.var_qn * n + i];
+            double xm = q / (qnv + 2.220446049250313e-16);
+            xm = fmin(fmax(xm, d.x_min), d.x_max);
+            double lam = cp_pow(d.lambda_factor * xm, d.lam_exponent);
+            double n0 = (d.nu / d.ntot_factor) * qnv * cp_pow(lam, d.n0_exponent);
+            lamf = lam * d.c_lam;
+            n0v = n0 * d.c_n0;
+            p0 = lamf;
+            p1 = n0v;
+            break; }
+        case CPOL_RULE_ICE_1MOM: {
+            // hydrometeors.py:1277-1299 (float32 polynomials), :1320-1328
+            const float Tc = T - 273.15f;
+            const float n3 = 3.0f;
+            float pa;
+            if (!tfun_lookup(a.tfun_ice, T, pa)) {
+                pa = 5.065339f - 0.062659f * Tc - (float)(3.032362 * 3) + 0.029469f * Tc * n3
+                    - 0.000285f * (Tc * Tc) + (float)(0.312550 * 9) + 0.000204f * (Tc * Tc) * n3
+                    + 0.003199f * Tc * 9.0f - (float)(0.015952 * 27);
+                pa = pow10_f32(pa);
+            }
+            float pb = 0.476221f - 0.015896f * Tc + (float)(0.165977 * 3) + 0.007468f * Tc * n3
+                - 0.000141f * (Tc * Tc) + (float)(0.060366 * 9) + 0.000079f * (Tc * Tc) * n3
+                + 0.000594f * Tc * 9.0f - (float)(0.003577 * 27);
+            const double qb = q / 3.0;                        // QM / BM_I
+            const double Q2 = cp_pow(qb / (double)pa, (double)(1.0f / pb));
+            const double Q22 = Q2 * Q2;
+            double N0 = (Q22 * Q22) / (q * q * q);            // Q2^4 QM^-3 (b = 3)
+            N0 /= 100000.0;
+            p0 = Q2 / q;                                      // lambda (exponent 1/(b-2) = 1)
+            p1 = N0;
+            p2 = q;
+            break; }
+        case CPOL_RULE_MELTING_SNOW:
+        case CPOL_RULE_MELTING_GRAUPEL: {
+            p0 = q;
+            p1 = fw;
+            ll = d.r_lam_exponent * cp_log(d.r_lambda_factor / q);
+            p2 = cp_exp(ll);                                         // rain partner
+            loglam = ll; ll_slot = 2;                                // (the melting tables sit on slot 2)
+            // (the dry partner's PSD does not enter get_N, hydrometeors.py:372-390)
+            break; }
+        default: break;
+        }
+    }
+    // items whose lambda lies on the slot's integral table are finished from ONE 16-byte record {position on
+    // the panel axis, scale of the item}; only the others are sorted by LUT slice for the integrating kernels
+    bool lookup = false;
+    double pf = -1.0, scale = 0.0;
+    if (valid && tj.tab) {
+        const double lg = ll_slot == tj.par_slot ? loglam : cp_log(tj.par_slot == 2 ? p2 : p0);
+        pf = (lg * 1.4426950408889634 - tj.log2_lo) * (double)tj.ppo;
+        lookup = pf >= (double)tj.pan_lo && pf < (double)tj.pan_hi;   // NaN -> false
+        // scale: gamma N0 exp(-lambda d0) (the table holds exp(+lambda d0) x integral); ice and melting: QM
+        scale = tj.two_d ? p0 : d.psd_family == CPOL_PSD_ICE_FIELD ? p2 : p1 * cp_exp(-(p0 * tj.d0));
+    }
+    double dv = 0.0, dn = 0.0;
+    const bool has_vn = valid && a.doppler && d.psd_family == CPOL_PSD_GAMMA && !d.numeric_intv;
+    if (has_vn) {
+        // _Hydrometeor.integrate_V (hydrometeors.py:178-199): analytic moments (a species with
+        // numeric_intv gets its sums from the PSD stage instead); lambda = p0, N0 = the fixed
+        // intercept (rain, graupel) or p1 (few values stay live across the table decision above:
+        // k_classify is held to 128 VGPRs, CPOL_CLASSIFY_WPE)
+        const double n0v = (d.rule == CPOL_RULE_RAIN_1MOM || d.rule == CPOL_RULE_GRAUPEL_1MOM) ? d.n0_fixed : p1;
+        const double lp = ll_slot == 0 ? loglam : cp_log(p0);  // one logarithm of lambda for both powers
+        dv = d.vel_factor * n0v * d.alpha / d.nu * cp_exp(-(d.beta + d.mu + 1) / d.nu * lp);
+        dn = (d.rule == CPOL_RULE_TWO_MOMENT)
+            ? (double)a.vals[d.var_qn * n + i] : d.ntot_factor * n0v / d.nu * cp_exp(-(d.mu + 1) / d.nu * lp);
+    }
+    o.key = key; o.p0 = p0; o.p1 = p1; o.p2 = p2; o.pf = lookup ? pf : -1.0; o.scale = scale;
+    o.dv = dv; o.dn = dn; o.valid = valid; o.lookup = lookup; o.has_vn = has_vn;
+}
+
+
 // (Measured with the stores of key / rec / vn dropped one by one: 2.55 ms each time against 2.57 -- the kernel
 // waits for its own dependent float64 chains at 4 wavefronts per SIMD, not for memory; the Doppler moments
 // are 0.27 ms of it.)
@@ -326,10 +461,9 @@ __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &ou
 // against 0.69 ms + 2.21 ms for k_classify + k_psd_lookup: the lookup is bound by the vector-L1
 // gather, not by HBM, and inside the 16-wave ranking workgroups it spills; 4- and 8-wave
 // workgroups 3.6 / 4.5 ms.)
-#ifndef CPOL_CLASSIFY_TFUN_EARLY
-#define CPOL_CLASSIFY_TFUN_EARLY 0   // (measured, round 4: both float32 functions of T requested right after T, ahead of the
-                                     // hydrometeor loop and whether or not snow / ice are present: C4 volume 2.11 -> 2.20 ms, C2 sweep 19.7 -> 21.5 us)
-#endif
+// (Measured and dropped, round 4: both float32 functions of T requested right after T is loaded, ahead of the
+// hydrometeor loop and whether or not snow / ice are present at the gate -- they sit behind `valid` in the
+// dependent chain of those species: C4 volume 2.11 -> 2.20 ms, C2 sweep 19.7 -> 21.5 us.)
 #ifndef CPOL_CLASSIFY_WPE
 #define CPOL_CLASSIFY_WPE 4          // wavefronts per SIMD asked of the register allocator (128 VGPRs: what 16-wave workgroups
                                      // imposed; without it the allocator takes more registers and occupancy drops)
@@ -386,16 +520,6 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) CPOL_CLASSIFY_ATTR void k_cl
     const int var_t0 = hs.h[0].d.var_t;
     const float T0 = in ? a.vals[var_t0 * n + i] : 0.f;
     float q_ahead = (in && hs.h[0].d.q_source == CPOL_Q_MODEL) ? a.vals[hs.h[0].d.var_q * n + i] : 0.f;
-#if CPOL_CLASSIFY_TFUN_EARLY
-    // both float32 functions of T requested as soon as T is known, ahead of the hydrometeor loop (inside it
-    // the 4-byte gathers sat behind `valid` in the dependent chain of snow and ice)
-    float tf_snow = 0.f, tf_ice = 0.f;
-    const unsigned tf_idx = __float_as_uint(T0) - CPOL_TFUN_FIRST_BITS;
-    const bool tf_ok = in && tf_idx < CPOL_TFUN_COUNT;
-    const bool tf_snow_ok = tf_ok && a.tfun_snow, tf_ice_ok = tf_ok && a.tfun_ice;
-    if (tf_snow_ok) tf_snow = a.tfun_snow[tf_idx];
-    if (tf_ice_ok) tf_ice = a.tfun_ice[tf_idx];
-#endif
     for (int j = 0; j < hs.n_hydro; ++j) {
         const HydroDev &h = hs.h[j];
         const cpol_hydro_desc &d = h.d;
@@ -408,143 +532,26 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) CPOL_CLASSIFY_ATTR void k_cl
         }
         if (in && j + 1 < hs.n_hydro && hs.h[j + 1].d.q_source == CPOL_Q_MODEL)
             q_ahead = a.vals[hs.h[j + 1].d.var_q * n + i];
-        // NaN -> false (doppler_scatter.py:185); scheme 'ml': only gates where the
-        // sub-beam has a non-zero weight (:186-189)
-        const bool valid = in && (qm > 0.f) && (!a.wgate || a.wgate[i] > 0.0);
-        int key = -1;
-        double p0 = 0.0, p1 = 0.0, p2 = 0.0;         // parameter slots 0..2
-        double loglam = 0.0;                          // log of a slope parameter when the rule formed it as
-        int ll_slot = -1;                             // (slot whose logarithm it is) exp(y log x): the table position and the fall-speed moments
-                                                      // take it from there instead of a logarithm of the result
-        if (valid) {
-            const float T = d.var_t == var_t0 ? T0 : a.vals[d.var_t * n + i];
-            // lut.py:336-341: float32 arithmetic for float32 queries
-            int eb = clip_bin((e - d.e_lo) / d.e_step, d.n_e);
-            int tb = d.second_axis_f64 ? clip_bin64((fw - (double)d.t_lo) / (double)d.t_step, d.n_t)
-                                       : clip_bin((T - d.t_lo) / d.t_step, d.n_t);
-            key = h.key_base + eb * d.n_t + tb;
-            const double q = (double)qm;
-            double lamf = 0.0, n0v = 0.0, qnv = 0.0;   // final lambda / N0 (get_N units)
-            double ll = 0.0;                           // log(lambda) where the rule has it from its power (has_ll)
-            // the item's parameters (slots 0..2 of par[], read by the integrating kernels; slot 1 by
-            // the 2-D lookup of the melting species)
-            switch (d.rule) {
-            case CPOL_RULE_RAIN_1MOM:
-            case CPOL_RULE_GRAUPEL_1MOM:
-                ll = d.lam_exponent * cp_log(d.lambda_factor / q);
-                lamf = cp_exp(ll);                            // = cp_pow(lambda_factor / q, lam_exponent)
-                loglam = ll; ll_slot = 0;
-                n0v = d.n0_fixed;
-                p0 = lamf;
-                p1 = 1.0;                                     // N0 folded into pre[]
-                break;
-            case CPOL_RULE_SNOW_1MOM: {
-                // hydrometeors.py:896-899: float32 chain, then float64 from lambda_factor on
-                float n0;
-#if CPOL_CLASSIFY_TFUN_EARLY
-                if (d.var_t == var_t0 && tf_snow_ok) n0 = tf_snow;
-                else
-#endif
-                if (!tfun_lookup(a.tfun_snow, T, n0))
-                    n0 = 13.5f * (565000.0f * exp_f32(-0.107f * (T - 273.15f))) / 1000.0f;
-                float an0 = (float)d.a * n0;
-                ll = d.lam_exponent * cp_log((double)an0 * d.lambda_factor / q);
-                lamf = cp_exp(ll);
-                loglam = ll; ll_slot = 0;
-                n0v = (double)n0;
-                p0 = lamf;
-                p1 = n0v;
-                break; }
-            case CPOL_RULE_TWO_MOMENT: {
-                // hydrometeors.py:231-246
-                qnv = (double)a.vals[d.var_qn * n + i];
-                double xm = q / (qnv + 2.220446049250313e-16);
-                xm = fmin(fmax(xm, d.x_min), d.x_max);
-                double lam = cp_pow(d.lambda_factor * xm, d.lam_exponent);
-                double n0 = (d.nu / d.ntot_factor) * qnv * cp_pow(lam, d.n0_exponent);
-                lamf = lam * d.c_lam;
-                n0v = n0 * d.c_n0;
-                p0 = lamf;
-                p1 = n0v;
-                break; }
-            case CPOL_RULE_ICE_1MOM: {
-                // hydrometeors.py:1277-1299 (float32 polynomials), :1320-1328
-                const float Tc = T - 273.15f;
-                const float n3 = 3.0f;
-                float pa;
-#if CPOL_CLASSIFY_TFUN_EARLY
-                if (d.var_t == var_t0 && tf_ice_ok) pa = tf_ice;
-                else
-#endif
-                if (!tfun_lookup(a.tfun_ice, T, pa)) {
-                    pa = 5.065339f - 0.062659f * Tc - (float)(3.032362 * 3) + 0.029469f * Tc * n3
-                        - 0.000285f * (Tc * Tc) + (float)(0.312550 * 9) + 0.000204f * (Tc * Tc) * n3
-                        + 0.003199f * Tc * 9.0f - (float)(0.015952 * 27);
-                    pa = pow10_f32(pa);
-                }
-                float pb = 0.476221f - 0.015896f * Tc + (float)(0.165977 * 3) + 0.007468f * Tc * n3
-                    - 0.000141f * (Tc * Tc) + (float)(0.060366 * 9) + 0.000079f * (Tc * Tc) * n3
-                    + 0.000594f * Tc * 9.0f - (float)(0.003577 * 27);
-                const double qb = q / 3.0;                        // QM / BM_I
-                const double Q2 = cp_pow(qb / (double)pa, (double)(1.0f / pb));
-                const double Q22 = Q2 * Q2;
-                double N0 = (Q22 * Q22) / (q * q * q);            // Q2^4 QM^-3 (b = 3)
-                N0 /= 100000.0;
-                p0 = Q2 / q;                                      // lambda (exponent 1/(b-2) = 1)
-                p1 = N0;
-                p2 = q;
-                break; }
-            case CPOL_RULE_MELTING_SNOW:
-            case CPOL_RULE_MELTING_GRAUPEL: {
-                p0 = q;
-                p1 = fw;
-                ll = d.r_lam_exponent * cp_log(d.r_lambda_factor / q);
-                p2 = cp_exp(ll);                                         // rain partner
-                loglam = ll; ll_slot = 2;                                // (the melting tables sit on slot 2)
-                // (the dry partner's PSD does not enter get_N, hydrometeors.py:372-390)
-                break; }
-            default: break;
-            }
-        }
-        // items whose lambda lies on the slot's integral table are finished by k_psd_lookup /
-        // k_subbeam_sum from ONE 16-byte record {position on the panel axis, scale of the item}; only
-        // the others are sorted by LUT slice for the integrating kernels
-        bool lookup = false;
         const ItabDev &tj = its.t[j];
+        ClassItem it;
+        classify_item(h, tj, a, n, i, in, qm, fw, T0, var_t0, e, it);
+        const bool valid = it.valid, lookup = it.lookup;
+        const int key = it.key;
         if (valid) {
             double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
-            double pf = -1.0;
-            if (tj.tab) {
-                const double lg = ll_slot == tj.par_slot ? loglam : cp_log(tj.par_slot == 2 ? p2 : p0);
-                pf = (lg * 1.4426950408889634 - tj.log2_lo) * (double)tj.ppo;
-                lookup = pf >= (double)tj.pan_lo && pf < (double)tj.pan_hi;   // NaN -> false
-                my_lookup += lookup ? 1 : 0;
-            }
+            my_lookup += lookup ? 1 : 0;
             if (!lookup || a.keep_par) {                     // read by the integrating kernels / the spectrum kernels
-                P[0] = p0;
-                P[n] = p1;
-                if (h.n_par >= 3) P[2 * n] = p2;
-                if (tj.tab) P[4 * n] = lookup ? pf : -1.0;    // (debug reads)
+                P[0] = it.p0;
+                P[n] = it.p1;
+                if (h.n_par >= 3) P[2 * n] = it.p2;
+                if (tj.tab) P[4 * n] = it.pf;                 // (debug reads; -1: not on the table)
             } else if (tj.two_d) {
-                P[n] = p1;                                    // wet fraction: position inside the 2-D block
+                P[n] = it.p1;                                 // wet fraction: position inside the 2-D block
             }
-            if (tj.tab) {
-                // scale: gamma N0 exp(-lambda d0) (the table holds exp(+lambda d0) x integral); ice and melting: QM
-                const double scale = tj.two_d ? p0 : d.psd_family == CPOL_PSD_ICE_FIELD ? p2 : p1 * cp_exp(-(p0 * tj.d0));
-                a.rec[(long)j * n + i] = make_double2(lookup ? pf : -1.0, scale);
-            }
-            if (a.doppler && d.psd_family == CPOL_PSD_GAMMA && !d.numeric_intv) {
-                // _Hydrometeor.integrate_V (hydrometeors.py:178-199): analytic moments (a species with
-                // numeric_intv gets its sums from the PSD stage instead); lambda = p0, N0 = the fixed
-                // intercept (rain, graupel) or p1 (few values stay live across the table decision above:
-                // this kernel is held to 128 VGPRs, CPOL_CLASSIFY_WPE)
-                const double n0v = (d.rule == CPOL_RULE_RAIN_1MOM || d.rule == CPOL_RULE_GRAUPEL_1MOM) ? d.n0_fixed : p1;
-                const double lp = ll_slot == 0 ? loglam : cp_log(p0);  // one logarithm of lambda for both powers
-                const double dv = d.vel_factor * n0v * d.alpha / d.nu * cp_exp(-(d.beta + d.mu + 1) / d.nu * lp);
-                const double dn = (d.rule == CPOL_RULE_TWO_MOMENT)
-                    ? (double)a.vals[d.var_qn * n + i] : d.ntot_factor * n0v / d.nu * cp_exp(-(d.mu + 1) / d.nu * lp);
-                if (a.vn) *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = make_double2(dv, dn);
-                if (a.keep_par) { P[2 * n] = dv; P[3 * n] = dn; }
+            if (tj.tab) a.rec[(long)j * n + i] = make_double2(it.pf, it.scale);
+            if (it.has_vn) {
+                if (a.vn) *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = make_double2(it.dv, it.dn);
+                if (a.keep_par) { P[2 * n] = it.dv; P[3 * n] = it.dn; }
             }
             vbits |= 1u << j;
         }

@@ -225,6 +225,13 @@ def test_radial_vs_reference_golden_and_oracle(golden, name):
         gk = g['cutll_' + k]
         assert np.array_equal(np.isnan(cut[k][0]), np.isnan(gk)), 'cut pattern: ' + k
         assert np.array_equal(cut[k][0][~np.isnan(gk)], res[k][0][~np.isnan(gk)]), k
+    # ---- the same radial without the debug reads: single-beam cases then take the fast path (k_gate1: PSD
+    # parameters, table evaluation and get_pol_from_sz in one kernel), the others the general sequence without
+    # its debug stores -- every output must carry the same bits as the run above ----
+    plain = op.simulate_rays([az], [el], apply_sensitivity=False)
+    for k, v in res.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(plain[k], v, equal_nan=True), 'fast path / no debug: ' + k
     op.close()
 
 
