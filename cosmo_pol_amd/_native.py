@@ -580,16 +580,18 @@ class Context(object):
         """Accuracy gate of the integral tables of the staged slots (cpol_prepare): per slot the worst
         deviation of a block's polynomial from the integrating kernel at the block's check point
         (`check`: negative = table rejected, the slot is integrated bin by bin; 0 = no table), where it
-        was found (`at`), the number of (block, function) pairs above the limit (`n_bad`, 1-D tables)
-        and the device time of the build and of the check alone (`build_ms`, `check_ms`)."""
-        a = self.debug_read('itab_check', (3, CPOL_MAX_HYDRO), np.float64)
+        was found (`at`), the number of (block, function) pairs above the limit (`n_bad`, 1-D tables),
+        the worst deviation at the second check point alone -- u = 0.96, between the last two nodes of a
+        lambda panel (`check_edge`, 1-D tables; `check` is the maximum over both points) -- and the device
+        time of the build and of the check alone (`build_ms`, `check_ms`)."""
+        a = self.debug_read('itab_check', (4, CPOL_MAX_HYDRO), np.float64)
         t = self.debug_read('itab_times', (CPOL_MAX_HYDRO, 2), np.float64)
-        return {'check': a[0], 'at': a[1], 'n_bad': a[2], 'build_ms': t[:, 0], 'check_ms': t[:, 1]}
+        return {'check': a[0], 'at': a[1], 'n_bad': a[2], 'check_edge': a[3], 'build_ms': t[:, 0], 'check_ms': t[:, 1]}
 
     def itab_detail(self, slot):
         """1-D integral table of `slot`: {'log2_lo', 'ppo', 'd0', 'n_pan', 'by_fn' [15], 'by_pan'
-        [n_pan], 'accepted_panels'} -- the worst deviation at the check points per function and per
-        lambda panel (panel p covers lambda in 2^(log2_lo + [p, p + 1] / ppo)) and the run of panels
+        [n_pan], 'by_pan_edge' [n_pan], 'accepted_panels'} -- the worst deviation at the check points per function and per
+        lambda panel (`by_pan_edge`: at the point near the panel edge alone) (panel p covers lambda in 2^(log2_lo + [p, p + 1] / ppo)) and the run of panels
         [lo, hi) that passed the gate (None: table rejected); None for a slot without such a table."""
         n = self.lib.cpol_debug_read(self.h, ('itab_detail%d' % slot).encode(), None, 0)
         if n == 0:
@@ -599,9 +601,9 @@ class Context(object):
             self._check(int(n), 'cpol_debug_read(itab_detail)')
         v = self.debug_read('itab_detail%d' % slot, (nb // 8,), np.float64)
         n_pan = int(v[3])
-        acc = v[19 + n_pan:19 + n_pan + 2]
+        acc = v[19 + 2 * n_pan:19 + 2 * n_pan + 2]
         return {'log2_lo': v[0], 'ppo': int(v[1]), 'd0': v[2], 'n_pan': n_pan, 'by_fn': v[4:19],
-                'by_pan': v[19:19 + n_pan],
+                'by_pan': v[19:19 + n_pan], 'by_pan_edge': v[19 + n_pan:19 + 2 * n_pan],
                 'accepted_panels': (int(acc[0]), int(acc[1])) if len(acc) == 2 else None}
 
     def debug_math(self, op, x):

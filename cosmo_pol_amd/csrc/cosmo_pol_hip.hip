@@ -51,7 +51,7 @@ struct ItabCacheEntry {
     int dop2 = 0;
     DevBuf tab, head;
     ItabDev t{};
-    double check = 0.0, check_at = 0.0;
+    double check = 0.0, check_at = 0.0, check_edge = 0.0;
     uint64_t used = 0;          // build serial of the last use (LRU; entries of the current build are pinned)
 };
 
@@ -91,6 +91,7 @@ struct cpol_ctx {
     double itab_check[CPOL_MAX_HYDRO] = {};     // worst deviation at the blocks' check points (negative: table rejected)
     std::vector<double> itab_detail[CPOL_MAX_HYDRO];   // 1-D tables: [log2_lo, ppo, d0, n_pan, worst per function (NF), worst per panel (n_pan)]
     double itab_ms[CPOL_MAX_HYDRO][2] = {};     // device time of the last build of the slot's table: all of it, the check alone
+    double itab_check_edge[CPOL_MAX_HYDRO] = {};   // 1-D tables: worst deviation at the second check point (near the panel edge) alone
     double itab_bad[CPOL_MAX_HYDRO] = {};       // 1-D tables: (block, function) pairs at or above the accepted deviation
     ItabSet its{};
     uint64_t lut_serial = 0;           // bumped by the staging calls the integral tables depend on (not the model cube)
@@ -213,7 +214,7 @@ int build_itabs(cpol_ctx *ctx)
     ctx->itab_serial = ctx->lut_serial;
     ctx->itab_builds++;
     for (int j = 0; j < CPOL_MAX_HYDRO; ++j) {
-        ctx->itab_check[j] = ctx->itab_check_at[j] = ctx->itab_bad[j] = 0.0;
+        ctx->itab_check[j] = ctx->itab_check_at[j] = ctx->itab_bad[j] = ctx->itab_check_edge[j] = 0.0;
         ctx->itab_ms[j][0] = ctx->itab_ms[j][1] = 0.0;
     }
     if (!enabled) return CPOL_OK;
@@ -262,6 +263,7 @@ int build_itabs(cpol_ctx *ctx)
                 if (e.id == d.table_id && e.dop2 == (int)dop2) {
                     ctx->its.t[j] = e.t;
                     ctx->itab_check[j] = e.check;
+                    ctx->itab_check_edge[j] = e.check_edge;
                     ctx->itab_check_at[j] = e.check_at;
                     e.used = ctx->itab_builds;
                     hit = true;
@@ -339,10 +341,10 @@ int build_itabs(cpol_ctx *ctx)
         if ((rc = ensure(ctx, b_par, (size_t)CPOL_MAX_PAR * n_items * sizeof(double))) ||
             (rc = ensure(ctx, b_perm, (size_t)n_items * sizeof(int))) ||
             (rc = ensure(ctx, b_units, (size_t)n_units * sizeof(WorkUnit))) ||
-            (rc = ensure(ctx, b_tot, 6 * sizeof(long long))) ||
+            (rc = ensure(ctx, b_tot, 8 * sizeof(long long))) ||
             (rc = ensure(ctx, b_res, (size_t)n_items * CPOL_N_SZ * sizeof(double))) ||
             (rc = ensure(ctx, b_vn, (size_t)n_items * 2 * sizeof(double))) ||
-            (rc = ensure(ctx, b_det, (size_t)(n_pan + CPOL_ITAB_NF) * sizeof(unsigned long long))) ||
+            (rc = ensure(ctx, b_det, (size_t)(2 * n_pan + CPOL_ITAB_NF) * sizeof(unsigned long long))) ||
             (rc = ensure(ctx, dst_tab, tab_bytes))) {
             free_buf(b_par); free_buf(b_perm); free_buf(b_units); free_buf(b_tot); free_buf(b_res); free_buf(b_vn); free_buf(b_det);
             drop_entry();
@@ -393,7 +395,7 @@ int build_itabs(cpol_ctx *ctx)
             else hipLaunchKernelGGL((k_psd<PSD_MODE_GAMMA_EXP, false>), grd, blk, 0, st, ctx->hs, pa);
         }
         double worst = 0.0;
-        unsigned long long worst_bits = 0;
+        unsigned long long worst_bits = 0, edge_bits = 0;
         unsigned int n_bad = 0;
         if (melt) {
             ItabFit2Args fa{};
@@ -415,18 +417,19 @@ int build_itabs(cpol_ctx *ctx)
             fa.worst = (unsigned long long *)b_tot.p + 3;
             fa.n_bad = (unsigned int *)((unsigned long long *)b_tot.p + 4);
             fa.max_dev = max_dev;
-            HIPCHK(hipMemsetAsync(b_det.p, 0, (size_t)(n_pan + CPOL_ITAB_NF) * sizeof(unsigned long long), st));
+            HIPCHK(hipMemsetAsync(b_det.p, 0, (size_t)(2 * n_pan + CPOL_ITAB_NF) * sizeof(unsigned long long), st));
             fa.by_fn = (unsigned long long *)b_det.p;
-            fa.by_pan = fa.by_fn + CPOL_ITAB_NF;
-            det_bits.resize((size_t)n_pan + CPOL_ITAB_NF);
-            HIPCHK(hipMemsetAsync(fa.worst, 0, 2 * sizeof(unsigned long long), st));
+            fa.by_pan = fa.by_fn + CPOL_ITAB_NF;            // [n_pan] both check points, then [n_pan] the edge point alone
+            det_bits.resize((size_t)2 * n_pan + CPOL_ITAB_NF);
+            HIPCHK(hipMemsetAsync(fa.worst, 0, 3 * sizeof(unsigned long long), st));      // worst, n_bad, worst at the edge point
             const dim3 fgrid(cdiv((long)n_slices * n_pan * CPOL_ITAB_NF, 256));
-            // (the check is part of the fit kernel: its share of the build = the 12th item of every block)
+            // (the check is part of the fit kernel: its share of the build = the two check items of every block)
             (void)hipEventRecord(evb[1], st);
             (void)hipEventRecord(evb[2], st);
             hipLaunchKernelGGL(k_itab_fit, fgrid, dim3(256), 0, st, fa);
             HIPCHK(hipMemcpyAsync(&worst_bits, fa.worst, sizeof worst_bits, hipMemcpyDeviceToHost, st));
             HIPCHK(hipMemcpyAsync(&n_bad, fa.n_bad, sizeof n_bad, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&edge_bits, fa.worst + 2, sizeof edge_bits, hipMemcpyDeviceToHost, st));
             HIPCHK(hipMemcpyAsync(det_bits.data(), b_det.p, det_bits.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         }
         (void)hipEventRecord(evb[3], st);
@@ -459,6 +462,7 @@ int build_itabs(cpol_ctx *ctx)
         }
         ctx->itab_check[j] = worst;
         ctx->itab_bad[j] = (double)n_bad;
+        { double ev = 0.0; memcpy(&ev, &edge_bits, sizeof ev); ctx->itab_check_edge[j] = ev; }   // (all panels; the accepted run: below)
         int pan_lo = 0, pan_hi = n_pan;
         if (!melt && !(worst < max_dev)) {
             // 1-D table: keep the longest run of lambda panels whose blocks all pass (in practice everything
@@ -494,13 +498,20 @@ int build_itabs(cpol_ctx *ctx)
         t.d0 = gamma ? d0 : 0.0;
         t.n_pan = n_pan;
         t.pan_lo = pan_lo; t.pan_hi = pan_hi;
-        if (!ctx->itab_detail[j].empty()) { ctx->itab_detail[j].push_back(pan_lo); ctx->itab_detail[j].push_back(pan_hi); }
+        if (!ctx->itab_detail[j].empty()) {
+            // (the edge point's worst over the accepted run of panels, like `check`)
+            const std::vector<double> &dv = ctx->itab_detail[j];
+            double we = 0.0;
+            for (int p = pan_lo; p < pan_hi; ++p) we = fmax(we, dv[4 + CPOL_ITAB_NF + n_pan + p]);
+            ctx->itab_check_edge[j] = we;
+            ctx->itab_detail[j].push_back(pan_lo); ctx->itab_detail[j].push_back(pan_hi);
+        }
         t.writes_vn = ice || dop2 || d.numeric_intv || melt;
         t.ppo = ppo;
         t.two_d = melt ? 1 : 0;
         t.par_slot = melt ? 2 : 0;
         t.n_t = d.n_t;
-        if (ce) { ce->t = t; ce->check = ctx->itab_check[j]; ce->check_at = ctx->itab_check_at[j]; }
+        if (ce) { ce->t = t; ce->check = ctx->itab_check[j]; ce->check_at = ctx->itab_check_at[j]; ce->check_edge = ctx->itab_check_edge[j]; }
     }
     return CPOL_OK;
 }
@@ -2085,7 +2096,8 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     }
     if (!strncmp(name, "itab_detail", 11) && name[11] >= '0' && name[11] < '0' + CPOL_MAX_HYDRO && !name[12]) {
         // slot j ("itab_detail<j>"): log2_lo, panels per octave, d0, n_pan, then the worst deviation at the
-        // check points per function (CPOL_ITAB_NF values) and per lambda panel (n_pan values); 1-D tables only
+        // check points per function (CPOL_ITAB_NF values), per lambda panel (n_pan values: both check points;
+        // n_pan values: the point near the panel edge alone), the accepted run of panels [lo, hi); 1-D tables only
         const cpol_ctx *own = ctx->parent ? ctx->parent : ctx;
         const std::vector<double> &v = own->itab_detail[name[11] - '0'];
         const int64_t nb = (int64_t)(v.size() * sizeof(double));
@@ -2107,6 +2119,12 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
         const cpol_ctx *own = ctx->parent ? ctx->parent : ctx;
         if (!dst || max_bytes < (int64_t)sizeof own->itab_check) return CPOL_ERR_ARG;
         memcpy(dst, own->itab_check, sizeof own->itab_check);
+        if (max_bytes >= 4 * (int64_t)sizeof own->itab_check) {
+            memcpy((char *)dst + sizeof own->itab_check, own->itab_check_at, sizeof own->itab_check_at);
+            memcpy((char *)dst + 2 * sizeof own->itab_check, own->itab_bad, sizeof own->itab_bad);
+            memcpy((char *)dst + 3 * sizeof own->itab_check, own->itab_check_edge, sizeof own->itab_check_edge);
+            return 4 * (int64_t)sizeof own->itab_check;
+        }
         if (max_bytes >= 3 * (int64_t)sizeof own->itab_check) {
             memcpy((char *)dst + sizeof own->itab_check, own->itab_check_at, sizeof own->itab_check_at);
             memcpy((char *)dst + 2 * sizeof own->itab_check, own->itab_bad, sizeof own->itab_bad);

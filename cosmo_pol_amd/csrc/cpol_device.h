@@ -72,12 +72,16 @@ struct SpecSet {
 #define CPOL_ITAB_NF     15      // 12 columns, 2 Doppler sums (v, n), ice: normalised N0 (Doppler spectrum)
 #define CPOL_ITAB_NFP    16      // functions per coefficient row (padded: one row = 128 B)
 #define CPOL_ITAB_PPO    8       // panels per octave of lambda
-// Every 1-D block is verified when it is built: a 12th item per (slice, panel), at the off-node
-// position CPOL_ITAB1_CHECK_U, is integrated by the same kernel and compared with the polynomial,
-// function by function, on the scale of the function over the block (end of k_itab_fit).  A slot whose
-// worst deviation reaches CPOL_ITAB_MAX_DEVIATION keeps its items on the integrating kernels.
-#define CPOL_ITAB1_NODES (CPOL_ITAB_NC + 1)
+// Every 1-D block is verified when it is built: two more items per (slice, panel), at the off-node
+// positions CPOL_ITAB1_CHECK_U (mid-panel: T_11(0.37) = 0.86 of the nodal polynomial's maximum) and
+// CPOL_ITAB1_CHECK_U2 (between the last two Chebyshev nodes, where the interpolation error of a function
+// with a nearby singularity peaks -- and where the panel borders on the next one; round 4), are
+// integrated by the same kernel and compared with the polynomial, function by function, on the scale of
+// the function over the block (end of k_itab_fit).  A slot whose worst deviation reaches
+// CPOL_ITAB_MAX_DEVIATION keeps its items on the integrating kernels.
+#define CPOL_ITAB1_NODES (CPOL_ITAB_NC + 2)
 #define CPOL_ITAB1_CHECK_U 0.37
+#define CPOL_ITAB1_CHECK_U2 0.96      // ~cos(pi / 11): the extremum of T_11 between the last two nodes
 #define CPOL_ITAB_MAX_DEVIATION 1e-10
 // Melting species: N(D) has TWO per-item parameters, the wet fraction fw (which also selects the
 // LUT slice, floor bin of the table's second axis) and the slope lambda_r of the rain partner, and

@@ -1651,9 +1651,10 @@ __global__ void k_itab_nodes(ItabBuildArgs b)
         return;
     }
     {
-        const int p = r / CPOL_ITAB1_NODES, q = r % CPOL_ITAB1_NODES;      // q == NC: the block's check point
+        const int p = r / CPOL_ITAB1_NODES, q = r % CPOL_ITAB1_NODES;      // q >= NC: the block's two check points
+        const double uc = q == CPOL_ITAB_NC ? CPOL_ITAB1_CHECK_U : CPOL_ITAB1_CHECK_U2;
         b.par[i] = q < CPOL_ITAB_NC ? itab_node_lambda(b.log2_lo, p, q)
-                                    : exp2(b.log2_lo + ((double)p + (CPOL_ITAB1_CHECK_U + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
+                                    : exp2(b.log2_lo + ((double)p + (uc + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
     }
     b.par[b.n_items + i] = 1.0;             // N0
     b.par[2 * b.n_items + i] = 1.0;         // QM (ice)
@@ -1672,9 +1673,10 @@ struct ItabFitArgs {
     int n_slices, n_pan;
     double log2_lo, d0;
     unsigned long long *worst; // check kernel: bits of the worst deviation | (block x NF + function) mod 2^24
+                               // ([2]: bits of the worst deviation at the SECOND check point alone, near the panel edge)
     unsigned int *n_bad;       // check kernel: (block, function) pairs at or above max_dev
     double max_dev;
-    unsigned long long *by_pan;   // check kernel: [n_pan] bits of the worst deviation per lambda panel
+    unsigned long long *by_pan;   // check kernel: [n_pan] bits of the worst deviation per lambda panel, then [n_pan] at the edge point alone
     unsigned long long *by_fn;    // check kernel: [CPOL_ITAB_NF] ... per function
 };
 
@@ -1719,12 +1721,19 @@ __global__ void k_itab_fit(ItabFitArgs f)
     // at the nodes and the check point -- so that a column that changes sign inside a panel raises no
     // false alarm, while node values that are rounding noise of a cancelling sum do ----
     const double lam_c = exp2(f.log2_lo + ((double)p + (CPOL_ITAB1_CHECK_U + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
-    const double ref = value(CPOL_ITAB_NC, lam_c);
-    scale = fmax(scale, fabs(ref));
-    double got = c[CPOL_ITAB_NC - 1];
+    const double lam_e = exp2(f.log2_lo + ((double)p + (CPOL_ITAB1_CHECK_U2 + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
+    const double ref = value(CPOL_ITAB_NC, lam_c), ref_e = value(CPOL_ITAB_NC + 1, lam_e);
+    scale = fmax(scale, fmax(fabs(ref), fabs(ref_e)));
+    double got = c[CPOL_ITAB_NC - 1], got_e = c[CPOL_ITAB_NC - 1];
 #pragma unroll
-    for (int q = CPOL_ITAB_NC - 2; q >= 0; --q) got = fma(got, CPOL_ITAB1_CHECK_U, c[q]);
+    for (int q = CPOL_ITAB_NC - 2; q >= 0; --q) {
+        got = fma(got, CPOL_ITAB1_CHECK_U, c[q]);
+        got_e = fma(got_e, CPOL_ITAB1_CHECK_U2, c[q]);
+    }
+    double err_e = scale > 0.0 ? fabs(got_e - ref_e) / scale : 0.0;
+    if (nan || !(err_e == err_e) || !(ref_e == ref_e) || isinf(scale)) err_e = 1.0;
     double err = scale > 0.0 ? fabs(got - ref) / scale : 0.0;
+    err = fmax(err, err_e);
     if (nan || !(err == err) || !(ref == ref) || isinf(scale)) err = 1.0;
     if (err >= f.max_dev) atomicAdd(f.n_bad, 1u);
     if (err > 0.0) {
@@ -1733,6 +1742,9 @@ __global__ void k_itab_fit(ItabFitArgs f)
         const unsigned long long eb = (unsigned long long)__double_as_longlong(err);   // (positive doubles order like their bits)
         const unsigned long long tagged = (eb & ~0xFFFFFFull) | ((unsigned long long)t & 0xFFFFFFull);
         if (tagged > __builtin_nontemporal_load(f.worst)) atomicMax(f.worst, tagged);
+        const unsigned long long ee = (unsigned long long)__double_as_longlong(err_e);
+        if (ee > __builtin_nontemporal_load(f.worst + 2)) atomicMax(f.worst + 2, ee);
+        if (ee > __builtin_nontemporal_load(f.by_pan + f.n_pan + p)) atomicMax(f.by_pan + f.n_pan + p, ee);
         if (eb > __builtin_nontemporal_load(f.by_pan + p)) atomicMax(f.by_pan + p, eb);
         if (eb > __builtin_nontemporal_load(f.by_fn + fn)) atomicMax(f.by_fn + fn, eb);
     }

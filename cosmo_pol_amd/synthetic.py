@@ -94,20 +94,12 @@ def _mass_params(h, scheme):
 _RHO_CORR = {'R': 0.992, 'S': 0.93, 'G': 0.96, 'H': 0.95, 'I': 0.97, 'mS': 0.95, 'mG': 0.97}
 
 
-def _fill_table(h, D, eps, ar, k0, rng_mod):
-    """D, eps, ar broadcastable to [ne, nt, nd] (e axis added here)."""
-    Sa, Sz = _spheroid_amplitudes(D, ar, eps, k0)          # [1|., nt, nd]
-    e = np.deg2rad(ELEVATIONS.astype(np.float64))[:, None, None]
-    x = k0 * D / 2.0
-    res = (1 - 0.08 * x * x) * np.exp(1j * 0.35 * x * x)    # mild resonance + phase
-    Shh_b = Sa * res
-    Svv_b = (Sa * np.sin(e) ** 2 + Sz * np.cos(e) ** 2) * res * (1 + 0.02j * x)
-    Shh_f = Sa + 0j * e
-    Svv_f = Sa * np.sin(e) ** 2 + Sz * np.cos(e) ** 2
-    ext = lambda S: S.real + 1j * (S.imag + 2.0 / 3.0 * k0 * np.abs(S) ** 2)
-    Shh_f, Svv_f = ext(Shh_f), ext(Svv_f)
+def table_columns(h, Shh_b, Svv_b, Shh_f, Svv_f):
+    """The 12 table columns (compute_lut_sz.py:265-297: Z11, Z12, Z21, Z22, Z33, Z34, Z43, Z44 of the
+    back-scattering Mueller matrix, Re / Im S11, Re / Im S22 forward) from the co-polar amplitudes
+    [n_e, n_t, n_d] (mm) of a particle without cross-polar scattering."""
     S11 = -Svv_b                                            # FSA sign in backscatter
-    S22 = Shh_b + 0 * e
+    S22 = Shh_b + 0 * Svv_b
     rho0 = _RHO_CORR[h]
     shape = np.broadcast(S11, S22).shape
     tab = np.zeros(shape + (12,), dtype=np.float64)
@@ -125,6 +117,23 @@ def _fill_table(h, D, eps, ar, k0, rng_mod):
     tab[..., 9] = np.broadcast_to(Svv_f.imag, shape)
     tab[..., 10] = np.broadcast_to(Shh_f.real, shape)
     tab[..., 11] = np.broadcast_to(Shh_f.imag, shape)
+    return tab
+
+
+def _fill_table(h, D, eps, ar, k0, rng_mod):
+    """D, eps, ar broadcastable to [ne, nt, nd] (e axis added here)."""
+    Sa, Sz = _spheroid_amplitudes(D, ar, eps, k0)          # [1|., nt, nd]
+    e = np.deg2rad(ELEVATIONS.astype(np.float64))[:, None, None]
+    x = k0 * D / 2.0
+    res = (1 - 0.08 * x * x) * np.exp(1j * 0.35 * x * x)    # mild resonance + phase
+    Shh_b = Sa * res
+    Svv_b = (Sa * np.sin(e) ** 2 + Sz * np.cos(e) ** 2) * res * (1 + 0.02j * x)
+    Shh_f = Sa + 0j * e
+    Svv_f = Sa * np.sin(e) ** 2 + Sz * np.cos(e) ** 2
+    ext = lambda S: S.real + 1j * (S.imag + 2.0 / 3.0 * k0 * np.abs(S) ** 2)
+    Shh_f, Svv_f = ext(Shh_f), ext(Svv_f)
+    tab = table_columns(h, Shh_b, Svv_b, Shh_f, Svv_f)
+    shape = tab.shape[:-1]
     mod = _modulation(rng_mod, shape[:2], shape[2])
     # the same factor on all 12 columns keeps the matrix physically consistent
     tab *= mod[..., None]

@@ -10,7 +10,7 @@ import copy
 
 import numpy as np
 
-KINDS = ('random_sign', 'resonance', 'cancelling', 'alternating')
+KINDS = ('random_sign', 'resonance', 'cancelling', 'alternating', 'mie')
 
 
 def roughen(lut, kind, seed):
@@ -49,5 +49,11 @@ def roughen(lut, kind, seed):
     return out
 
 
-def roughen_all(luts, kind, seed=20261004):
+def roughen_all(luts, kind, seed=20261004, frequency=None, scheme='1mom'):
+    """`kind` 'mie': the non-melting species get closed-form Mie tables (cosmo_pol_amd/mie.py: real resonances
+    along D at the case's frequency -- rain and hail at Ku / Ka band oscillate and change sign) on the axes of
+    their smooth tables; the melting species keep theirs."""
+    if kind == 'mie':
+        from cosmo_pol_amd import mie
+        return {h: (l if h in ('mS', 'mG') else mie.mie_table_like(l, h, frequency, scheme)) for h, l in luts.items()}
     return {h: roughen(l, kind, seed + 97 * j) for j, (h, l) in enumerate(sorted(luts.items()))}

@@ -98,7 +98,7 @@ def _amplification(szi, szt):
 def test_rough_tables_itab_vs_direct_vs_oracle(name, kind):
     conf, az, el, ocube, luts, cube = _cases.radial_case(name)
     over = _cases.gen_golden.radial_case_inputs(name)[0]
-    rl = _rough.roughen_all(luts, kind)
+    rl = _rough.roughen_all(luts, kind, frequency=conf['radar']['frequency'], scheme=conf['microphysics']['scheme'])
     on = _run_hip(over, rl, cube, az, el, itab=True)
     off = _run_hip(over, rl, cube, az, el, itab=False)
     subs = beam.interpolate_radial(ocube, conf, az, el)
@@ -120,7 +120,10 @@ def test_rough_tables_itab_vs_direct_vs_oracle(name, kind):
                 assert np.all(d['by_pan'][lo:hi] < 1e-10) and 2 * (hi - lo) >= d['n_pan'], (h, lo, hi)
                 # all but the last panels -- except for 'alternating', where node values that are
                 # rounding noise of a 1e10-fold cancellation must make the gate cut the range
-                assert kind == 'alternating' or (lo == 0 and hi >= d['n_pan'] - 2), (h, lo, hi)
+                # (and for 'mie': a Mie table is accepted where it passes, the rest of its lambda range falls back)
+                # ('random_sign': since the second check point exists -- u = 0.96, round 4 -- the white-noise rain
+                # table loses its first panels too: 2.3e-10 in panel 8, which the mid-panel point had passed)
+                assert kind in ('alternating', 'mie', 'random_sign') or (lo == 0 and hi >= d['n_pan'] - 2), (h, lo, hi)
                 ranges[h] = (lo, hi, d['n_pan'])
             accepted.append(h)
     assert off['n_table_items'] == 0 and off['n_valid_items'] == on['n_valid_items']
@@ -172,6 +175,7 @@ def test_rough_tables_itab_vs_direct_vs_oracle(name, kind):
         worst['RHOHV'] = _worst_rel(on['RHOHV'][well], o.values['RHOHV'][well])
     _record({'case': name, 'kind': kind, 'hydro': hl,
              'itab_check': [float(x) for x in rep['check'][:len(hl)]],
+             'itab_check_edge': [float(x) for x in rep['check_edge'][:len(hl)]],
              'accepted': accepted, 'accepted_panels': ranges, 'n_table_items': on['n_table_items'], 'n_valid_items': on['n_valid_items'],
              'sz_integ_worst_rel_on': _worst_rel(on['sz_integ'], o.sz_integ),
              'sz_integ_worst_rel_off': _worst_rel(off['sz_integ'], o.sz_integ),
@@ -205,8 +209,9 @@ def test_rejected_table_falls_back_to_the_integrating_kernels(monkeypatch):
 
 
 def test_check_costs_little_on_full_size_tables():
-    """Full-size R, S, G tables (46 x 27|39 slices): the accuracy gate (the 12th item of every block +
-    k_itab_check1) takes < 5 % of cpol_prepare, and the smooth bench tables pass far below 1e-10."""
+    """Full-size R, S, G tables (46 x 27|39 slices): the accuracy gate (the two check items of every block of
+    11 nodes, compared inside k_itab_fit) takes < 8 % of cpol_prepare, and the smooth bench tables pass far
+    below 1e-10 at both check points (mid-panel and between the last two nodes)."""
     import time
     import bench
     from cosmo_pol_amd import RadarOperator, synthetic
@@ -226,11 +231,14 @@ def test_check_costs_little_on_full_size_tables():
         assert np.all(d['by_pan'][lo:hi] < 1e-10)
     chk, ms_chk, ms_all = rep['check'][:3], rep['check_ms'][:3], rep['build_ms'][:3]
     _record({'case': 'bench R,S,G full-size tables', 'itab_check': [float(x) for x in chk],
+             'itab_check_edge': [float(x) for x in rep['check_edge'][:3]],
              'build_ms': [float(x) for x in ms_all], 'check_ms': [float(x) for x in ms_chk],
              'accepted_panels': [d['accepted_panels'] + (d['n_pan'],) for d in det],
              'worst_by_function': [[float(x) for x in d['by_fn']] for d in det],
              'set_lut_wall_ms': t_prepare})
     assert np.all(chk > 0) and np.all(chk < 1e-10), chk
-    # the gate = one more item per block of 11 nodes (the comparison itself rides in the fit kernel)
-    assert ms_chk.sum() < 0.05 * t_prepare, (ms_chk, t_prepare)
-    assert ms_chk.sum() < 0.10 * ms_all.sum(), (ms_chk, ms_all)
+    edge = rep['check_edge'][:3]
+    assert np.all(edge > 0) and np.all(edge <= chk), (edge, chk)        # (`check` = the maximum over both points)
+    # the gate = two more items per block of 11 nodes (the comparison itself rides in the fit kernel)
+    assert ms_chk.sum() < 0.08 * t_prepare, (ms_chk, t_prepare)
+    assert ms_chk.sum() < 0.17 * ms_all.sum(), (ms_chk, ms_all)

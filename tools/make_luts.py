@@ -12,7 +12,8 @@ layout `load_all_lut` expects:
   python tools/make_luts.py info   FILE.lut [...]
 
 `write` produces the SYNTHETIC tables of cosmo_pol_amd/synthetic.py (Rayleigh-
-spheroid model in the exact reference layout; pytmatrix is not available, so
+spheroid model in the exact reference layout) or, with --model mie, closed-form Mie
+tables (cosmo_pol_amd/mie.py: resonant in D; pytmatrix is not available, so
 the table VALUES are not the reference's -- real cosmo_pol .lut files drop into
 the same directory and are read by the same loader).  `RadarOperator(...,
 lut_dir=DIR)` then stages them exactly as it would stage real tables.
@@ -36,12 +37,17 @@ DEFAULT_HYDROMETEORS = {'1mom': ['R', 'S', 'G', 'I', 'mS', 'mG'],
 
 
 def write(lut_dir, frequency, scheme, hydrometeors, scattering, n_e=None, n_t=None,
-          seed=20260301, quiet=False):
+          seed=20260301, quiet=False, model='spheroid'):
     folder = os.path.join(lut_dir, FOLDERS[scattering])
     os.makedirs(folder, exist_ok=True)
     written = []
     for h in hydrometeors:
         table = synthetic.make_lut(h, frequency, scheme, seed, n_e, n_t)
+        if model == 'mie' and h not in ('mS', 'mG'):
+            # closed-form Mie series of the equal-volume sphere (resonances along D), the two polarisations
+            # split by the Rayleigh spheroid ratio (cosmo_pol_amd/mie.py); the melting species keep the spheroid model
+            from cosmo_pol_amd import mie
+            table = mie.mie_table_like(table, h, frequency, scheme)
         path = os.path.join(folder, lutmod.lut_filename(h, frequency, scheme))
         lutmod.save_lut(table, path)
         written.append(path)
@@ -73,12 +79,15 @@ def main(argv=None):
     w.add_argument('--n-e', type=int, default=None, help='truncate the elevation axis (small tables)')
     w.add_argument('--n-t', type=int, default=None, help='truncate the temperature / wet-fraction axis')
     w.add_argument('--seed', type=int, default=20260301)
+    w.add_argument('--model', choices=['spheroid', 'mie'], default='spheroid',
+                   help="spheroid: smooth Rayleigh-spheroid tables (default); mie: Lorenz-Mie series of the "
+                        "equal-volume sphere for the non-melting species (resonant in D at Ku / Ka band)")
     i = sub.add_parser('info')
     i.add_argument('files', nargs='+')
     a = ap.parse_args(argv)
     if a.cmd == 'write':
         write(a.lut_dir, a.frequency, a.scheme, a.hydrometeors or DEFAULT_HYDROMETEORS[a.scheme],
-              a.scattering, a.n_e, a.n_t, a.seed)
+              a.scattering, a.n_e, a.n_t, a.seed, model=a.model)
     else:
         for f in a.files:
             info(f)
