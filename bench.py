@@ -106,11 +106,11 @@ def hydrometeors_of(workload):
 
 
 def load_profile_summary(workload):
-    """profiles/r3_<workload>_summary.json (tools/profile_summary.py; r2_* if this round's file is
+    """profiles/r4_<workload>_summary.json (tools/profile_summary.py; r3_* / r2_* if this round's file is
     missing): per kernel the mean FETCH_SIZE / WRITE_SIZE / SQ counters per dispatch, `hbm_bytes`
     (FETCH_SIZE weighted per kernel as profiles/README.md states, + WRITE_SIZE) and the
     kernel-trace duration."""
-    for tag in ('r3', 'r2'):
+    for tag in ('r4', 'r3', 'r2'):
         path = os.path.join(ROOT, 'profiles', '%s_%s_summary.json' % (tag, workload))
         try:
             with open(path) as f:
@@ -121,7 +121,7 @@ def load_profile_summary(workload):
 
 
 # stage of the launch sequence (cpol_counters_t.ms_*) -> its kernels in the rocprofv3 summaries
-STAGE_KERNELS = {'interp': ('k_interp_sweep', 'k_trajectory'), 'classify': ('k_classify', 'k_ml_weights'),
+STAGE_KERNELS = {'interp': ('k_interp_sweep', 'k_trajectory'), 'classify': ('k_classify', 'k_ml_weights', 'k_gate1'),
                  'bucket': ('k_bucket_scan', 'k_bucket_scatter'),
                  'psd': ('k_psd_lookup', 'k_subbeam_sum'),     # (+ the integrating kernels: empty launches in a sweep)
                  'final': ('k_final', 'k_rvel_terms', 'k_ice_first')}
@@ -237,7 +237,13 @@ def main():
     if workload == 'c5':
         cube = (synthetic.small_test_cube(hydrometeors=cube_h, two_moment=True) if args.small
                 else synthetic.make_cube(hydrometeors=cube_h, two_moment=True, **synthetic.BENCH_GRID))
-        luts = lambda hl, freq, scheme: synthetic.make_all_luts(hl, freq, scheme, n_e=n_e)   # noqa: E731 (Ku / Ka / C sets)
+        _sets = {}
+
+        def luts(hl, freq, scheme):                   # (Ku / Ka / C sets, each built once)
+            key = (tuple(hl), freq, scheme)
+            if key not in _sets:
+                _sets[key] = synthetic.make_all_luts(hl, freq, scheme, n_e=n_e)
+            return _sets[key]
     elif args.small:
         cube = synthetic.small_test_cube(hydrometeors=cube_h)
         luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
@@ -249,11 +255,17 @@ def main():
     # CPU baselines first: the all-core leg forks workers, which must happen before this
     # process initialises the GPU (HIP state does not survive a fork)
     cpu_res = None
-    if world == 1 and args.cpu_seconds > 0 and workload != 'c5':
-        el_cpu = 1.0 if workload == 'c2' else C4_ELEVATIONS[2]
+    if world == 1 and args.cpu_seconds > 0:
         print('[bench] CPU baseline: one pinned core ...', file=sys.stderr, flush=True)
-        cpu_res = cpu_baseline(conf, cube, luts, np.arange(0, 360, 1.0), el_cpu, args.cpu_seconds)
-        cpu_res['all_cores'] = cpu_baseline_pool(workload, args.small)
+        if workload == 'c5':
+            cpu_res = cpu_baseline_c5(conf, cube, luts, args.cpu_seconds, args.small)
+        else:
+            el_cpu = 1.0 if workload == 'c2' else C4_ELEVATIONS[2]
+            # (c4: a radial of 49 sub-beams takes the oracle about a second: one radial per sample at least)
+            cpu_res = cpu_baseline(conf, cube, luts, np.arange(0, 360, 1.0), el_cpu, args.cpu_seconds,
+                                   n_samples=5 if workload == 'c2' else 2 if workload == 'c4' else 3)
+        if workload == 'c2' and not os.environ.get('CPOL_BENCH_NO_EXTRAS'):
+            cpu_res['all_cores'] = cpu_baseline_pool(workload, args.small)
 
     # this rank's threads onto the cores next to its GPU (after the CPU legs, which use every core);
     # CPOL_NUMA_BIND=0 leaves the affinity as launched
@@ -344,9 +356,11 @@ def main():
             # the other BASELINE configurations on this GPU, one child process each (after the c2
             # operator is closed): driver-timed like the rest of the run
             small = ['--small'] if args.small else []
-            out['c3'] = child_run('c3', ['--steps', '20', '--warmup', '3'] + small)
-            out['c4_volume_one_gpu'] = child_run('c4', ['--steps', '6', '--warmup', '2'] + small)
-            out['c5'] = child_run('c5', ['--steps', '3', '--warmup', '1'] + small)
+            # (each with its own bounded one-core CPU baseline: SURVEY 8(d) for every BASELINE configuration)
+            cpu = ['--cpu-seconds', '0' if args.cpu_seconds <= 0 else '8']
+            out['c3'] = child_run('c3', ['--steps', '20', '--warmup', '3'] + small + cpu)
+            out['c4_volume_one_gpu'] = child_run('c4', ['--steps', '6', '--warmup', '2'] + small + cpu)
+            out['c5'] = child_run('c5', ['--steps', '3', '--warmup', '1'] + small + cpu)
         print(json.dumps(out))
 
 
@@ -356,7 +370,7 @@ def child_run(workload, flags, env=None, quiet=False, timeout=600):
     at N = 1 c3, c4 (the single-GPU reference of the strong-scaling runs) and c5; at N > 1 the c4
     strong-scaling run, every rank starting its own child (`quiet`: a rank whose child prints nothing)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--workload', workload, '--cpu-seconds', '0'] + flags
+    cmd = [sys.executable, os.path.abspath(__file__), '--workload', workload] + (flags if '--cpu-seconds' in flags else flags + ['--cpu-seconds', '0'])
     t0 = time.time()
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout,
@@ -541,6 +555,27 @@ def run_c2(env):
                 t0 = time.perf_counter()
                 op.get_PPI(elevations=[1.0], az_step=1.0)
                 lat_ppi.append(1e3 * (time.perf_counter() - t0))
+        # refraction scheme 2 at scan scale (host side): the ray paths of a 90-elevation RHI with 3 vertical
+        # quadrature nodes = 270 LSODA solves (cosmo_pol_amd/refraction.py), on an exponential refractivity column
+        from cosmo_pol_amd import refraction
+        zc = np.ascontiguousarray(cube['zlevels'][::-1, cube['zlevels'].shape[1] // 2, cube['zlevels'].shape[2] // 2])
+        n_col = (1.0 + 315e-6 * np.exp(-zc.astype(np.float64) / 7350.0)).astype(np.float32)
+        rr = np.asarray(op.constants.RANGE_RADAR, dtype=np.float64)
+        coords = env['conf']['radar']['coords']
+        ode = {}
+        for tag, w in (('solved_in_this_process', 0), ('helper_processes_first_call', None), ('helper_processes', None)):
+            refraction._SOLVED.clear()
+            t0 = time.perf_counter()
+            refraction.ode_paths(rr, np.arange(0.5, 90.5, 1.0), np.array([-0.3, 0.0, 0.3]), coords, zc, n_col, workers=w)
+            ode[tag] = 1e3 * (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        refraction.ode_paths(rr, np.arange(0.5, 90.5, 1.0), np.array([-0.3, 0.0, 0.3]), coords, zc, n_col)
+        ode['same_model_state_again'] = 1e3 * (time.perf_counter() - t0)
+        ode['helpers'] = len(refraction._POOL)
+        refraction._pool_close()
+        ode['note'] = ('ms of host time for the 270 ray paths (500 gates each) of a 90-elevation RHI with 3 vertical nodes, '
+                       'refraction scheme 2; round 3: 2.1 s (interp1d inside the right-hand side)')
+        extra['refraction2_rhi_90x3_ms'] = ode
         extra['single_sweep_latency_ms'] = {
             'simulate_rays_blocking_host_outputs': statistics.median(lat_rays),
             'get_PPI_one_elevation_with_packaging': statistics.median(lat_ppi),
@@ -618,9 +653,10 @@ def run_c2(env):
         'roofline': roof,
         'stages_ms': {'interp': iso.ms_interp, 'classify': iso.ms_classify,
                       'bucket': iso.ms_bucket, 'psd': iso.ms_psd, 'final': iso.ms_final,
-                      'device_total': iso.ms_total, 'launches_per_sweep': 7,
-                      'note': 'one sweep at a time on one lane, HIP events around every stage (the pass after '
-                              'the timed region)'},
+                      'device_total': iso.ms_total, 'launches_per_sweep': 4,
+                      'note': 'one sweep at a time on one lane, HIP events around every stage (the pass after the timed '
+                              'region); single-beam fast path: k_interp_sweep, k_gate1 (`classify`), one idle '
+                              'integrating kernel (`psd`), k_final (range scans); `bucket` holds no kernel'},
         'counters': {'n_subbeam_gates': n_sbg, 'n_valid_items': n_valid,
                      'n_work_units': int(iso.n_work_units), 'n_table_items': int(iso.n_table_items)},
         'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
@@ -810,6 +846,16 @@ def run_c5(env):
                 t_band[band] += time.perf_counter() - t1
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+    # one Ku swath at a time, HIP events around every stage of its launch sequence (what profiles/r4_c5_ku_iso_* profiles:
+    # tools/stage_times.py --config c5)
+    iso = None
+    with contextlib.redirect_stdout(sys.stderr):
+        op.get_GPM_swath(swaths['Ku'], 'Ku')
+        op._ctx.enable_timing(True)
+        for _ in range(3):
+            op.get_GPM_swath(swaths['Ku'], 'Ku')
+        iso = op._ctx.counters()
+        op._ctx.enable_timing(False)
     for b in swaths:
         per_band[b]['swath_ms'] = 1e3 * t_band[b] / args.steps
         per_band[b]['gates_per_s'] = per_band[b]['kept_gates'] * args.steps / t_band[b]
@@ -822,8 +868,13 @@ def run_c5(env):
                                'cube (R,S,G,H,I) through RadarOperator.get_GPM_swath (blocking host outputs, SimulatedGPM '
                                'packaging included); one step = both swaths; gates = gates kept below 35 km'
                                % (n_scans, n_scans), 'small': bool(args.small)},
-        'roofline': {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
-                     'note': 'an API-level figure (host packaging included); the kernels are those of c2 / c3'},
+        'roofline': roofline_of_dominant_stage(
+            'c5_ku_iso', stage_ms_of(iso), int(iso.n_subbeam_gates), int(iso.n_valid_items), int(iso.n_subbeam_gates),
+            len(op._staged_vars), env['cube']['zlevels'].shape[0],
+            note='c5: the launch sequence of ONE Ku swath (%d rays x %d gates, one sub-beam, 2-moment R,S,G,H,I: the '
+                 'single-beam fast path), events around every stage; `value` itself is an API-level figure (blocking '
+                 'host outputs, SimulatedGPM packaging).' % (per_band['Ku']['rays'], int(iso.n_subbeam_gates) // max(1, per_band['Ku']['rays']))),
+        'stages_ms': dict(stage_ms_of(iso), device_total=iso.ms_total, swath='Ku'),
         'per_band': per_band,
     }
 
@@ -1038,39 +1089,87 @@ def _pool_radial(a):
     return _one_radial(_POOL_STATE['inputs'], a, _POOL_STATE['el'])
 
 
-def cpu_baseline(conf, cube, luts, az, el, budget_s, n_samples=5):
-    """SURVEY 8(d)(i): the CPU oracle (restatement of the reference algorithm: per radial,
-    per-variable C gate kernel, float64 LUT gather + einsum) on ONE core: the process is pinned
-    to one CPU (sched_setaffinity, what `taskset` does), 1 warm-up radial, then `n_samples`
-    samples of budget/n_samples seconds each over consecutive azimuths; median gates/s."""
-    inputs = _oracle_inputs(conf, cube, luts)
+def _sample_one_core(one, n_units, budget_s, n_samples, what):
+    """`one(k) -> gates` of unit k on ONE pinned core (sched_setaffinity, what `taskset` does): one warm-up
+    unit, then `n_samples` samples of budget/n_samples seconds each (at least one unit per sample) over
+    consecutive units; median gates/s."""
     old = os.sched_getaffinity(0)
     os.sched_setaffinity(0, {sorted(old)[len(old) // 2]})
     try:
-        _one_radial(inputs, az[0], el)
+        one(0)
         rates, n_done, k = [], 0, 0
         for _ in range(n_samples):
             t0 = time.perf_counter()
-            gates = rad = 0
+            gates = units = 0
             while True:
-                gates += _one_radial(inputs, az[k % len(az)], el)
+                gates += one(k % n_units)
                 k += 1
-                rad += 1
+                units += 1
                 if time.perf_counter() - t0 > budget_s / n_samples:
                     break
             dt = time.perf_counter() - t0
-            rates.append((gates / dt, rad / dt))
-            n_done += rad
+            rates.append((gates / dt, units / dt))
+            n_done += units
     finally:
         os.sched_setaffinity(0, old)
     rates.sort()
     med = rates[len(rates) // 2]
     return {'value': med[0], 'unit': 'gates/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d radials in azimuth order (el %.1f deg) in %d samples of %.1f s, median; '
-                      'oracle/cosmo_pol_oracle pinned to one host core (sched_setaffinity)'
-                      % (n_done, el, n_samples, budget_s / n_samples),
+            'sample': '%d %s in %d samples of %.1f s, median; oracle/cosmo_pol_oracle pinned to one host core '
+                      '(sched_setaffinity)' % (n_done, what, n_samples, budget_s / n_samples),
             'samples_gates_per_s': [r[0] for r in rates], 'radials_per_s': med[1],
             'host_cpus': os.cpu_count()}
+
+
+def cpu_baseline(conf, cube, luts, az, el, budget_s, n_samples=5):
+    """SURVEY 8(d)(i): the CPU oracle (restatement of the reference algorithm: per radial,
+    per-variable C gate kernel, float64 LUT gather + einsum) on ONE core, radials in azimuth order."""
+    inputs = _oracle_inputs(conf, cube, luts)
+    n_sub = conf['integration']['nh_GH'] * conf['integration']['nv_GH']
+    return _sample_one_core(lambda k: _one_radial(inputs, az[k], el), len(az), budget_s, n_samples,
+                            'radials in azimuth order (el %.1f deg, %d sub-beam%s each; output gates counted)'
+                            % (el, n_sub, '' if n_sub == 1 else 's'))
+
+
+def cpu_baseline_c5(conf, cube, luts_of, budget_s, small, n_samples=3):
+    """The CPU oracle on Ku-band swath rays of the c5 workload (oracle/cosmo_pol_oracle/gpm.py: the intended
+    behaviour of compute_trajectory_GPM, atm_refraction.py:222-272; 2-moment R,S,G,H,I): rays of the swath
+    centre line in scan order, gates = gates kept below 35 km."""
+    from cosmo_pol_amd import gpm
+    from cosmo_pol_oracle import beam, scatter
+    from cosmo_pol_oracle import config as ocfg
+    from cosmo_pol_oracle import gpm as ogpm
+    from cosmo_pol_oracle import lut as olut
+    freq, res_m = gpm.band_settings('Ku')
+    hyds = hydrometeors_of('c5')
+    over = {k: dict(v) for k, v in conf.items()}
+    over['radar'].update(frequency=freq, radial_resolution=res_m, sensitivity=12.0, type='GPM')
+    over['radar']['3dB_beamwidth'] = 0.5
+    oconf = ocfg.make_config(over)
+    order = ['U', 'V', 'W', 'QR_v', 'QS_v', 'QG_v', 'QI_v', 'RHO', 'T', 'QH_v', 'QNH_v', 'QNR_v', 'QNS_v', 'QNG_v', 'QNI_v']
+    oc = beam.ModelCube({n: cube['data'][n] for n in order}, cube['zlevels'], cube['proj_info'], cube['resolution'], order)
+    ol = {}
+    for h, s in luts_of(hyds, freq, '2mom').items():
+        L = olut.LookupTable()
+        L.axes, L.axes_names, L.axes_limits, L.axes_step = s.axes, s.axes_names, s.axes_limits, s.axes_step
+        L.value_table = s.value_table
+        ol[h] = L
+    n_scans = 24 if not small else 6
+    sw = gpm.synthetic_swath(n_scans=n_scans, n_rays=5, centre=(46.5, 7.5), cross_track_deg=4.0,
+                             scan_spacing_m=25000.0 if not small else 1500.0)
+    if small:
+        for k in ('Latitude', 'Longitude'):
+            c0 = 46.5 if k == 'Latitude' else 7.5
+            sw[k] = c0 + (sw[k] - c0) * 0.12
+    az, el, rng, sat = ogpm.swath_angles(sw)
+
+    def one(k):
+        i = k % n_scans
+        subs, _, n = ogpm.interpolate_swath_ray(oc, oconf, az[i, 2], el[i, 2], rng[i, 2], sat[i])
+        scatter.radar_observables(subs, ol, oconf, doppler=False)
+        return n
+    return _sample_one_core(one, n_scans, budget_s, n_samples,
+                            'Ku rays (centre line of a %d-scan swath across the domain, 125-m gates kept below 35 km)' % n_scans)
 
 
 def _pool_leg(ctx, procs, az, budget_s, chunk, first_result_timeout=45.0, **pool_kw):

@@ -8,6 +8,8 @@ read at [round(p0), round(p0)] (the row index is used for both axes, :113-117)
 and the earth radius is evaluated with the radar LATITUDE in degrees fed to
 cos/sin (:120, utilities.py:126-139).
 """
+import os
+
 import numpy as np
 from scipy.integrate import odeint
 
@@ -34,12 +36,25 @@ class _PiecewiseLinear(object):
     """Linear interpolation with linear extrapolation beyond both ends
     (atm_refraction.py:151-179): scipy's interp1d inside the table, as the reference builds it --
     LSODA's step control amplifies a last-bit difference of the right-hand side into float32-ulp
-    differences of the path, so the interpolant is the reference's own, not a re-derivation."""
+    differences of the path, so the interpolant is the reference's own, not a re-derivation.
+    Inside the table the value is interp1d's, evaluated without its per-call overhead (20 us of
+    argument checking per scalar, two calls per right-hand side, ~1 500 right-hand sides per ray):
+    the same statements on the same dtypes -- slope = (y_hi - y_lo) / (x_hi - x_lo) in the dtype of the
+    column (float32 for model fields), then slope * (v - x_lo) + y_lo in float64, segment chosen by
+    searchsorted(side='left') clipped to [1, n - 1] -- checked bit for bit against interp1d
+    (tests/test_refraction_cpu.py)."""
 
     def __init__(self, x, y):
         from scipy.interpolate import interp1d
         self.f = interp1d(x, y)                 # (dtypes as given: a float32 column interpolates with float32 slopes)
         self.x, self.y = self.f.x, self.f.y
+        x_, y_ = np.asarray(self.x), np.asarray(self.y)
+        slope = (y_[1:] - y_[:-1]) / (x_[1:] - x_[:-1])          # dtype of the column, as interp1d forms it per call
+        self._xs = [float(v) for v in x_]
+        self._x_lo = self._xs[:-1]
+        self._y_lo = [float(v) for v in y_[:-1]]
+        self._slope = [float(v) for v in slope]
+        self._n = len(self._xs)
 
     def __call__(self, v):
         x, y = self.x, self.y
@@ -47,7 +62,9 @@ class _PiecewiseLinear(object):
             return y[0] + (v - x[0]) * (y[1] - y[0]) / (x[1] - x[0])
         if v > x[-1]:
             return y[-1] + (v - x[-1]) * (y[-1] - y[-2]) / (x[-1] - x[-2])
-        return float(self.f(v))
+        import bisect
+        i = min(max(bisect.bisect_left(self._xs, v), 1), self._n - 1) - 1
+        return self._slope[i] * (v - self._x_lo[i]) + self._y_lo[i]
 
 
 def refractivity_column(N_data, zlevels, proj_info, resolution, coords_radar, radar_type='ground'):
@@ -89,16 +106,125 @@ def ode_path(range_vec, elevation_deg, coords_radar, h_col, n_col):
     return s.astype('float32'), h.astype('float32'), np.rad2deg(e.astype('float32'))
 
 
-def ode_paths(range_vec, elevations, pts_ver, coords_radar, h_col, n_col):
-    """float32 [n_rays, n_vnodes, 3, n_gates]; solves are shared between rays with
-    equal elevation (a PPI needs n_vnodes solves)."""
+_SOLVED = {}            # (digest of column + range grid + site, elevation) -> [3, n_gates] float32; the last few scans
+_SOLVED_MAX = 4096
+
+
+def _digest(range_vec, coords_radar, h_col, n_col):
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    for a in (range_vec, coords_radar, h_col, n_col):
+        a = np.ascontiguousarray(a)
+        h.update(str((a.dtype.str, a.shape)).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def ode_paths(range_vec, elevations, pts_ver, coords_radar, h_col, n_col, workers=None):
+    """float32 [n_rays, n_vnodes, 3, n_gates]; solves are shared between rays with equal elevation (a PPI
+    needs n_vnodes solves) and kept across calls for the same refractivity column, range grid and site (a
+    volume scanned again over the same model state costs nothing).  One solve takes 4 - 8 ms of host time
+    (LSODA with a Python right-hand side, as in the reference), an RHI of 90 elevations with 3 vertical
+    nodes 270 of them: from 16 missing solves on they are spread over `workers` helper processes
+    (`python -m cosmo_pol_amd.refraction --worker`, started once and kept; default min(16, cores),
+    CPOL_REFRACTION_WORKERS, 0 = solve here) -- the same function on the same inputs: the same bits."""
     el = np.asarray(elevations, dtype=np.float64)
     out = np.zeros((len(el), len(pts_ver), 3, len(range_vec)), dtype=np.float32)
-    cache = {}
+    dg = _digest(range_vec, coords_radar, h_col, n_col)
+    keys = sorted({float(pt + e) for e in el for pt in pts_ver})
+    missing = [k for k in keys if (dg, k) not in _SOLVED]
+    if workers is None:
+        workers = int(os.environ.get('CPOL_REFRACTION_WORKERS', min(16, os.cpu_count() or 1)))
+    solved = None
+    if len(missing) >= 16 and workers > 1:
+        solved = _pool_solve(range_vec, coords_radar, h_col, n_col, missing, workers)
+    if solved is None:
+        solved = [np.stack(ode_path(range_vec, k, coords_radar, h_col, n_col)) for k in missing]
+    if len(_SOLVED) + len(missing) > _SOLVED_MAX:
+        _SOLVED.clear()
+    for k, v in zip(missing, solved):
+        _SOLVED[(dg, k)] = v
     for r in range(len(el)):
         for j, pt in enumerate(pts_ver):
-            key = float(pt + el[r])
-            if key not in cache:
-                cache[key] = np.stack(ode_path(range_vec, key, coords_radar, h_col, n_col))
-            out[r, j] = cache[key]
+            out[r, j] = _SOLVED[(dg, float(pt + el[r]))]
     return out
+
+
+# ---------------------------------------------------------------- helper processes
+_POOL = []
+
+
+def _pool_solve(range_vec, coords_radar, h_col, n_col, keys, workers):
+    """Solves `keys` (elevations) in helper processes; None if they cannot be started (the caller solves here).
+    Plain subprocesses speaking length-prefixed pickles over their pipes: no fork of a process that holds a GPU
+    context, no re-import of the caller's __main__ (multiprocessing's spawn / forkserver would do that)."""
+    import pickle
+    import struct
+    import subprocess
+    import sys
+    try:
+        while len(_POOL) < workers:
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''),
+                       OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+            _POOL.append(subprocess.Popen([sys.executable, '-m', 'cosmo_pol_amd.refraction', '--worker'],
+                                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env))
+        if not _POOL_ATEXIT:
+            import atexit
+            atexit.register(_pool_close)
+            _POOL_ATEXIT.append(1)
+        parts = [keys[i::workers] for i in range(workers)]
+        used = []
+        for proc, part in zip(_POOL, parts):
+            if not part:
+                continue
+            msg = pickle.dumps((np.asarray(range_vec), list(coords_radar), np.asarray(h_col), np.asarray(n_col), part), protocol=4)
+            proc.stdin.write(struct.pack('<Q', len(msg)) + msg)
+            proc.stdin.flush()
+            used.append((proc, part))
+        got = {}
+        for proc, part in used:
+            head = proc.stdout.read(8)
+            if len(head) != 8:
+                raise IOError('refraction helper process ended')
+            n = struct.unpack('<Q', head)[0]
+            for k, v in zip(part, pickle.loads(proc.stdout.read(n))):
+                got[k] = v
+        return [got[k] for k in keys]
+    except (OSError, IOError, ValueError, pickle.PickleError):
+        _pool_close()
+        return None
+
+
+_POOL_ATEXIT = []
+
+
+def _pool_close():
+    while _POOL:
+        p = _POOL.pop()
+        try:
+            p.stdin.close()
+            p.wait(timeout=2)
+        except Exception:
+            p.kill()
+
+
+def _worker_main():
+    import pickle
+    import struct
+    import sys
+    inp, out = sys.stdin.buffer, sys.stdout.buffer
+    while True:
+        head = inp.read(8)
+        if len(head) != 8:
+            return
+        rv, coords, h_col, n_col, keys = pickle.loads(inp.read(struct.unpack('<Q', head)[0]))
+        res = pickle.dumps([np.stack(ode_path(rv, k, coords, h_col, n_col)) for k in keys], protocol=4)
+        out.write(struct.pack('<Q', len(res)) + res)
+        out.flush()
+
+
+if __name__ == '__main__':
+    import sys
+    if '--worker' in sys.argv:
+        _worker_main()

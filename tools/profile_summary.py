@@ -22,7 +22,7 @@ def pmc(d):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
-SCALAR_LOAD_KERNELS = ('k_subbeam_sum<true>',)      # coefficient rows through s_load
+SCALAR_LOAD_KERNELS = ('k_subbeam_sum<true',)       # coefficient rows through s_load (k_subbeam_sum<true, 1, 2>)
 
 
 def main():

@@ -30,6 +30,8 @@ def main():
     import bench
     from cosmo_pol_amd import RadarOperator, synthetic
     wl = args.config
+    if wl == 'c5':
+        return c5_swath(args, bench, np)
     conf = bench.bench_config(False, wl)
     hyds = list(bench.hydrometeors_of(wl))
     cube = synthetic.make_cube(hydrometeors=tuple(h for h in hyds if h in 'RSGI'), **synthetic.BENCH_GRID)
@@ -54,6 +56,36 @@ def main():
                       wl, t_tables, 'block %d/%d chunk %d' % (b, args.blocks, args.chunk))
     else:
         one_block(op, bench, np, torch, args, np.arange(0, args.rays, 1.0), n_gates, hyds_n, wl, t_tables, args.tag)
+    op.close()
+
+
+def c5_swath(args, bench, np):
+    """ONE Ku swath of the c5 workload (200 scans x 49 rays, 2-moment R,S,G,H,I) through get_GPM_swath."""
+    import contextlib
+    from cosmo_pol_amd import RadarOperator, gpm, synthetic
+    hyds = bench.hydrometeors_of('c5')
+    cube = synthetic.make_cube(hydrometeors=hyds, two_moment=True, **synthetic.BENCH_GRID)
+    sets = {}
+
+    def luts(hl, freq, scheme):
+        if (tuple(hl), freq) not in sets:
+            sets[(tuple(hl), freq)] = synthetic.make_all_luts(hl, freq, scheme)
+        return sets[(tuple(hl), freq)]
+    sw = gpm.synthetic_swath(n_scans=200, n_rays=49, centre=(46.5, 7.5), cross_track_deg=17.0, scan_spacing_m=3000.0)
+    with contextlib.redirect_stdout(sys.stderr):
+        op = RadarOperator(config=bench.bench_config(False, 'c5'), luts=luts, output_variables='only_radar', lanes=1)
+        op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+        for _ in range(2):
+            out = op.get_GPM_swath(sw, 'Ku')
+        op._ctx.enable_timing(True)
+        for _ in range(max(3, args.steps // 5)):
+            op.get_GPM_swath(sw, 'Ku')
+        c = op._ctx.counters()
+    print(json.dumps(dict(tag=args.tag, config='c5', band='Ku', rays=int(out.azimuths.size), n_valid=int(c.n_valid_items),
+                          n_table=int(c.n_table_items), n_sbg=int(c.n_subbeam_gates),
+                          interp=round(c.ms_interp * 1e3, 1), classify=round(c.ms_classify * 1e3, 1),
+                          bucket=round(c.ms_bucket * 1e3, 1), psd=round(c.ms_psd * 1e3, 1),
+                          final=round(c.ms_final * 1e3, 1), total_us=round(c.ms_total * 1e3, 1))), flush=True)
     op.close()
 
 
