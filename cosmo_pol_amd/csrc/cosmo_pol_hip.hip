@@ -121,6 +121,8 @@ struct cpol_ctx {
     long last_n_sbg = 0, last_n_rg = 0;
     int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0, last_n_keys = 0;
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
+    int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
+    int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
     int subsum_small = 0;              // CPOL_SUBSUM_SMALL=1: experiment: the gather form of k_subbeam_sum with three wavefronts per (tile, hydrometeor) and the whole block in flight (measured slower)
     int subsum_coop = -1;              // CPOL_SUBSUM_COOP: k_subbeam_sum takes its coefficients through the scalar cache: 0 never, 1 always, -1 by launch size
     bool last_subsum = false;          // the 1-D table items of the last sweep never went through res[] (k_subbeam_sum)
@@ -547,6 +549,8 @@ int cpol_create(int device, cpol_ctx **out)
     // CPOL_SUBSUM_COOP=0 / 1: k_subbeam_sum never / always takes the coefficient rows through the scalar cache
     // (default: by launch size; the results are identical)
     if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
+    if (getenv("CPOL_RARE_DIRECT")) ctx->rare_direct = atoi(getenv("CPOL_RARE_DIRECT")) != 0 ? 1 : 0;
+    if (getenv("CPOL_GATE1")) ctx->gate1 = atoi(getenv("CPOL_GATE1"));
     if (getenv("CPOL_SUBSUM_SMALL")) ctx->subsum_small = atoi(getenv("CPOL_SUBSUM_SMALL")) != 0 ? 1 : 0;
     if (getenv("CPOL_SUBSUM_COOP_ROUNDS")) ctx->subsum_coop_rounds = std::max(0, std::min(64, atoi(getenv("CPOL_SUBSUM_COOP_ROUNDS"))));
     *out = ctx;
@@ -647,6 +651,8 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->use_graph = parent->use_graph;
     c->subsum_coop = parent->subsum_coop;
     c->subsum_small = parent->subsum_small;
+    c->rare_direct = parent->rare_direct;
+    c->gate1 = parent->gate1;
     c->subsum_coop_rounds = parent->subsum_coop_rounds;
     c->parent = parent;
     c->model_staged = parent->model_staged;
@@ -1345,17 +1351,24 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // (six species in sequence per thread) is no faster than k_classify + k_psd_lookup, and the four idle
     // launches of the integrating flavours cost more than the two bucket launches they replace (C3 sweep at
     // 3 deg: 203 us this way against 188; the kernel handles them -- CPOL_GATE1=2 forces it, tests do).
-    static const int gate1_env = getenv("CPOL_GATE1") ? atoi(getenv("CPOL_GATE1")) : 1;
+    const int gate1_env = ctx->gate1;
     bool gate1 = gate1_env != 0 && subsum_enabled && n_sub == 1 && !ctx->keep_debug && !dop3 && !ml;
     for (int j = 0; j < n_hyd && gate1; ++j)
         gate1 = ctx->its.t[j].tab != nullptr && (gate1_env == 2 || !ctx->its.t[j].two_d);
     if (gate1) final_inplace = true;       // (k_final's recomputed gates take the table items from their records)
     if (gate1) {
-        unit_cap = (long)n_hyd * n_sbg;    // one unit per item outside the tables, worst case every item
         ENSURE(ctx->b_gscan, (size_t)3 * n_rg * sizeof(float));
         ENSURE(ctx->b_defer, (size_t)n_rg);
     }
-    ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
+    // Every slot on an integral table: the items outside the tables (a handful per volume) are listed directly as
+    // one-item work units by k_classify / k_gate1 -- key in b_pos, gate in b_perm, count in b_totals -- and the
+    // counting sort (LDS ranking in k_classify, k_bucket_scan, k_bucket_scatter) is not run at all.  CPOL_RARE_DIRECT=0,
+    // debug reads (bucket counts) or a slot without a table keep the sort: with EVERY item integrated one item per
+    // work unit would waste 63 of 64 lanes.
+    bool rare_direct = gate1 || (ctx->rare_direct != 0 && !ctx->keep_debug);
+    for (int j = 0; j < n_hyd && rare_direct; ++j) rare_direct = ctx->its.t[j].tab != nullptr;
+    if (rare_direct) unit_cap = (long)n_hyd * n_sbg;           // (virtual units: no b_units entries are written)
+    else ENSURE(ctx->b_units, (size_t)unit_cap * sizeof(WorkUnit));
     const bool want_szi = ctx->keep_debug || subsum;
     if (want_szi) ENSURE(ctx->b_szinteg, (size_t)n_rg * n_hyd * CPOL_N_SZ * sizeof(float));
     const bool want_szt = out->sz_total != nullptr || ctx->keep_debug;
@@ -1459,7 +1472,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.rp.ke = p->ke; ia.rp.re = p->re; ia.rp.alt = p->radar_alt;
     ia.zero_buf = (int *)ctx->b_count.p;
     ia.zero_n = n_keys + 3;
-    ia.zero_buf2 = gate1 ? (int *)ctx->b_totals.p : nullptr;     // (4 long long: k_gate1 counts the items outside the tables into them)
+    ia.zero_buf2 = rare_direct ? (int *)ctx->b_totals.p : nullptr;     // (4 long long: k_classify / k_gate1 count the items outside the tables into them)
     ia.zero_n2 = 8;
     ia.geo = (const double *)ctx->v_geo;
     ia.sub_h = (const int *)ctx->v_subh;
@@ -1572,6 +1585,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ca.vmask = (unsigned char *)ctx->b_vmask.p;
     ca.vn = (doppler && !dop2 && !dop3) ? (double *)ctx->b_vn.p : nullptr;     // analytic moments (Doppler scheme 1)
     ca.keep_par = (ctx->keep_debug || dop3) ? 1 : 0;
+    if (rare_direct) {
+        ca.rare_key = (int *)ctx->b_pos.p;
+        ca.rare_perm = (int *)ctx->b_perm.p;
+        ca.rare_totals = (unsigned long long *)ctx->b_totals.p;
+    }
     for (int j = 0; j < n_hyd; ++j) {
         const cpol_hydro_desc &d = ctx->hs.h[j].d;
         if (d.q_source != CPOL_Q_MODEL) continue;
@@ -1602,7 +1620,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ga.sh = ga.sk + n_rg;
         ga.sv = ga.sk + 2 * n_rg;
         ga.defer = (unsigned char *)ctx->b_defer.p;
-        ga.units = (WorkUnit *)ctx->b_units.p;
+        ga.unit_key = (int *)ctx->b_pos.p;
         ga.perm = (int *)ctx->b_perm.p;
         ga.totals = (unsigned long long *)ctx->b_totals.p;
         ga.res = (double *)ctx->b_res.p;
@@ -1636,11 +1654,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // on a table -- on a sibling stream beside k_psd_lookup, forked and joined with events: the isolated C2 sweep
     // 122 -> 135 us, the C3 volume 468 -> 476 us, the 225-ray C4 share 1.568 -> 1.553 ms: a cross-stream event
     // costs the device about as much as the three idle launches it would hide.)
-    if (!gate1)
+    if (!rare_direct)
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, sa);
     // (a fixed grid: the workgroups stride over the k_classify gate ranges and skip the empty ones)
     const long n_cblk = cdiv(n_sbg, CPOL_CLASSIFY_THREADS);
-    if (!gate1)
+    if (!rare_direct)
     hipLaunchKernelGGL(k_bucket_scatter, dim3((unsigned)(n_cblk < 2048 ? n_cblk : 2048)), dim3(256), 0, st,
                        (const int *)ctx->b_key.p, (const int *)ctx->b_pos.p,
                        (int *)ctx->b_perm.p, (const int *)ctx->b_blkranked.p,
@@ -1686,6 +1704,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // ---- 5. PSD x scattering table: one launch per kernel flavour present ----
     {
         PsdArgs pa{};
+        pa.unit_key = rare_direct ? (const int *)ctx->b_pos.p : nullptr;
         pa.units = (const WorkUnit *)ctx->b_units.p;
         pa.totals = (const long long *)ctx->b_totals.p;
         pa.perm = (const int *)ctx->b_perm.p;
@@ -1717,9 +1736,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // grids, 512 / 768, measured equal or slower; CPOL_PSD_GRID* are experiment knobs)
         static const long grid_u = getenv("CPOL_PSD_GRID") ? atol(getenv("CPOL_PSD_GRID")) : 1024;
         static const long grid_g = getenv("CPOL_PSD_GRID_GENERIC") ? atol(getenv("CPOL_PSD_GRID_GENERIC")) : 1024;
-        // (single-beam fast path: the units are single items outside the tables, a handful per volume -- a small
+        // (items listed directly: the units are single items outside the tables, a handful per volume -- a small
         // grid costs an idle launch less; a flood of them is still processed, by 128 workgroups)
-        const long cap_u = gate1 ? 128 : grid_u, cap_g = gate1 ? 128 : grid_g;
+        const long cap_u = rare_direct ? 128 : grid_u, cap_g = rare_direct ? 128 : grid_g;
         const dim3 grd_u((unsigned)(unit_cap < cap_u ? unit_cap : cap_u));
         const dim3 grd((unsigned)(unit_cap < cap_g ? unit_cap : cap_g)), blk(CPOL_PSD_THREADS);
         // The flavours touch disjoint items and could run side by side.  Measured (MI355X, one
@@ -2105,6 +2124,16 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
         if (nb) memcpy(dst, v.data(), (size_t)nb);
         return nb;
     }
+#ifdef CPOL_SUBSUM_STATS
+    if (!strcmp(name, "subsum_stats")) {
+        if (!dst || max_bytes < 32) return CPOL_ERR_ARG;
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_subsum_stats), 32));
+        unsigned long long z[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_subsum_stats), z, 32));
+        return 32;
+    }
+#endif
     if (!strcmp(name, "itab_times")) {
         // per hydrometeor slot: device ms of the last integral-table build, and of its accuracy check
         const cpol_ctx *own = ctx->parent ? ctx->parent : ctx;

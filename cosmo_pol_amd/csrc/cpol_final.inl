@@ -307,6 +307,11 @@ __device__ __forceinline__ double fma_sgpr(double a, double b, double c_uniform)
 //                 wavefronts per SIMD to pay.  The host picks it from ~32 wavefronts per SIMD on.
 //                 (Workgroup ids reordered so that the 8 ids of an XCD in every 64 take 8 consecutive ray
 //                 tiles of one range -- blocks shared through that XCD's L2: 2.05 -> 2.23 ms, dropped.)
+#ifdef CPOL_SUBSUM_STATS
+// measurement build (tools/variants.sh "-DCPOL_SUBSUM_STATS"): [0] wavefront iterations that did work, [1] lanes
+// with an item in them, [2] scalar-cache rounds, [3] wavefront iterations skipped (species absent in the whole tile)
+__device__ unsigned long long g_subsum_stats[4];
+#endif
 template <bool COOP, int SPLIT, int GUNROLL>
 __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbeam_sum(HydroSet hs, ItabSet its, SubsumArgs a)
 {
@@ -351,6 +356,9 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
         unsigned long long wp = 0;                                       // ... at any lane of the wavefront (uniform)
         for (int q = 0; q < n_here; ++q)
             if (__builtin_amdgcn_ballot_w64((pm >> q) & 1ull)) wp |= 1ull << q;
+#ifdef CPOL_SUBSUM_STATS
+        if (lane == 0 && part == 0) atomicAdd(&g_subsum_stats[3], (unsigned long long)(n_here - __popcll(wp)));
+#endif
         if (!wp) continue;
         // key + record of the NEXT present sub-beam are requested before the rows of the current one
         int q_next = __ffsll((long long)wp) - 1;
@@ -385,7 +393,13 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
             double2 wv = make_double2(0.0, 0.0);
             // ---- the tile's distinct blocks, one after the other: coefficients through the scalar cache ----
             unsigned long long todo = __builtin_amdgcn_ballot_w64(on_tab);
+#ifdef CPOL_SUBSUM_STATS
+            if (lane == 0 && part == 0) { atomicAdd(&g_subsum_stats[0], 1ull); atomicAdd(&g_subsum_stats[1], (unsigned long long)__popcll(todo)); }
+#endif
             for (int round = 0; COOP && todo && round < a.coop_rounds; ++round) {
+#ifdef CPOL_SUBSUM_STATS
+                if (lane == 0) atomicAdd(&g_subsum_stats[2], 1ull);
+#endif
                 const int leader = __ffsll((long long)todo) - 1;
                 const int b = __builtin_amdgcn_readlane(blk_id, leader);
 #ifdef CPOL_SUBSUM_FAKE_ONE_BLOCK

@@ -27,8 +27,8 @@
 struct GateArgs {
     float *sk, *sh, *sv;          // [n_rg] operands of the three range scans (2 KDP; two-way attenuation factors)
     unsigned char *defer;         // [n_rg] 1: the gate holds an item outside the integral tables (k_final recomputes it)
-    WorkUnit *units;              // [n_hydro * n_rg] one unit per item outside the tables
-    int *perm;                    // [n_hydro * n_rg]
+    int *unit_key;                // [n_hydro * n_rg] LUT slice of every item outside the tables (one work unit each)
+    int *perm;                    // [n_hydro * n_rg] its gate
     unsigned long long *totals;   // [0] items, [1] units handed to the integrating kernels (cleared by k_interp_sweep)
     double *res;                  // [n_hydro][n_rg][12] melting items (read again only for recomputed gates)
     int store_items;              // some species' fall-speed sums are per ray: vmask / key / rec / vn of EVERY gate are
@@ -210,9 +210,7 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(Hy
             deferred = true;
             const unsigned long long idx = atomicAdd(g.totals + 1, 1ull);
             atomicAdd(g.totals, 1ull);
-            WorkUnit wu;
-            wu.key = it.key; wu.start = (int)idx; wu.count = 1; wu.pad = 0;
-            g.units[idx] = wu;
+            g.unit_key[idx] = it.key;
             g.perm[idx] = (int)i;
             double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
             P[0] = it.p0;

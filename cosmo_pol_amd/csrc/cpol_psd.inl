@@ -302,6 +302,11 @@ struct ClassifyArgs {
     unsigned char *vmask;        // [n_sbg] bit j: hydrometeor j present (what the kernels that only ask
                                  // "key >= 0 ?" read instead of n_hydro keys)
     int keep_par;                // also write par[] of the table items (debug reads, Doppler scheme 3)
+    // every slot has an integral table: the items outside the tables are a handful per volume, and the kernel lists
+    // them directly as one-item work units -- no ranking tables, no counting sort, no scan / scatter launches
+    int *rare_key;               // [n_hydro * n_sbg] LUT slice of listed item u (non-NULL: this mode)
+    int *rare_perm;              // [n_hydro * n_sbg] its sub-beam gate
+    unsigned long long *rare_totals;   // [0] items, [1] units (= items) listed; cleared by k_interp_sweep
     int *blk_ranked;             // [gridDim.x] items of this workgroup's gates ranked for the integrating kernels
                                  // (k_bucket_scatter skips the gates of a workgroup without any; pos[] is only
                                  // written where there are some)
@@ -479,7 +484,9 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) CPOL_CLASSIFY_ATTR void k_cl
     // issued in ONE round (phase B) instead of one dependent round per hydrometeor
     __shared__ RankShared sh[CPOL_MAX_HYDRO];
     __shared__ int s_lookup, s_ranked;
-    for (int j = 0; j < hs.n_hydro; ++j) rank_reset(sh[j]);
+    const bool direct = a.rare_key != nullptr;                 // (uniform)
+    if (!direct)
+        for (int j = 0; j < hs.n_hydro; ++j) rank_reset(sh[j]);
     if (threadIdx.x == 0) { s_lookup = 0; s_ranked = 0; }
     __syncthreads();
     int my_lookup = 0, my_ranked = 0;
@@ -556,6 +563,16 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) CPOL_CLASSIFY_ATTR void k_cl
             vbits |= 1u << j;
         }
         my_ranked += (valid && !lookup) ? 1 : 0;
+        if (direct) {
+            if (valid && !lookup) {
+                const unsigned long long idx = atomicAdd(a.rare_totals + 1, 1ull);
+                atomicAdd(a.rare_totals, 1ull);
+                a.rare_key[idx] = key;
+                a.rare_perm[idx] = (int)i;
+            }
+            if (valid || (in && a.keep_par)) a.key[(long)j * n + i] = key;
+            continue;
+        }
         const int ticket = rank_insert(sh[j], a.count, key, valid && !lookup);
         // (the LUT slice of a PRESENT hydrometeor; who is present is in vmask[] -- the -1 of the others is
         // only written for the debug reads and the spectrum kernels)
@@ -578,6 +595,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) CPOL_CLASSIFY_ATTR void k_cl
     __syncthreads();
     if (threadIdx.x == 0 && s_lookup) atomicAdd(a.n_lookup, s_lookup);
     if (threadIdx.x == 0 && s_ranked) atomicAdd(a.n_lookup + 1, s_ranked);
+    if (direct) return;
     if (threadIdx.x == 0) a.blk_ranked[blockIdx.x] = s_ranked;
     if (s_ranked == 0) return;                        // workgroup-uniform: every ticket is -1; pos[] stays unwritten
     for (int idx = threadIdx.x; idx < hs.n_hydro * CPOL_RANK_SLOTS; idx += blockDim.x)
@@ -750,6 +768,8 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const int *__restrict__ 
 enum { PSD_MODE_GAMMA_EXP = 0, PSD_MODE_GAMMA_UNIFORM = 1, PSD_MODE_ICE = 2, PSD_MODE_MELTING = 3 };
 
 struct PsdArgs {
+    const int *unit_key;        // non-NULL: the work units are single items outside the integral tables, listed directly by
+                                // k_classify / k_gate1 (unit u = {unit_key[u], start u, count 1}; `units` unused)
     const WorkUnit *units;
     const long long *totals;    // [1] = number of work units of this sweep; [2] != 0: k_psd_ice2 left
                                 // units (lambda outside the tables) for k_psd<ICE>
@@ -765,6 +785,21 @@ struct PsdArgs {
     int ice_force_sum;          // test hook (CPOL_ICE_FORCE_SUM=1): treat every lambda as outside the
                                 // tabulated range, i.e. sum the ice normalisation integrals directly
 };
+
+// work unit u: from the sorted list of k_bucket_scatter, or one directly listed item
+__device__ __forceinline__ void load_unit(const PsdArgs &a, int u, int &key, int &start, int &count)
+{
+    if (a.unit_key) {
+        key = __builtin_amdgcn_readfirstlane(a.unit_key[u]);
+        start = u;
+        count = 1;
+    } else {
+        const WorkUnit *up = a.units + u;
+        key = __builtin_amdgcn_readfirstlane(up->key);
+        start = __builtin_amdgcn_readfirstlane(up->start);
+        count = __builtin_amdgcn_readfirstlane(up->count);
+    }
+}
 
 __device__ __forceinline__ int psd_mode_of(const cpol_hydro_desc &d)
 {
@@ -867,10 +902,8 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
     // lambda outside the tabulated range is summed here, as two 64-item halves: uu = 2 u + half)
     constexpr int SUB = (MODE == PSD_MODE_ICE) ? 2 : 1;
     for (int uu = blockIdx.x; uu < SUB * n_units; uu += gridDim.x) {
-    const WorkUnit *up = a.units + uu / SUB;
-    const int key = __builtin_amdgcn_readfirstlane(up->key);
-    int start = __builtin_amdgcn_readfirstlane(up->start);
-    int count = __builtin_amdgcn_readfirstlane(up->count);
+    int key, start, count;
+    load_unit(a, uu / SUB, key, start, count);
     int j = 0;
     for (int q = 1; q < hs.n_hydro; ++q) if (key >= hs.h[q].key_base) j = q;
     const HydroDev &h = hs.h[j];
@@ -1344,10 +1377,8 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting_tab(HydroSet h
     __shared__ double s_part[4][NV][CPOL_WAVE];
     const int n_units = (int)a.totals[1];
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const WorkUnit *up = a.units + u;
-        const int key = __builtin_amdgcn_readfirstlane(up->key);
-        const int start = __builtin_amdgcn_readfirstlane(up->start);
-        const int count = __builtin_amdgcn_readfirstlane(up->count);
+        int key, start, count;
+        load_unit(a, u, key, start, count);
         int j = 0;
         for (int q = 1; q < hs.n_hydro; ++q) if (key >= hs.h[q].key_base) j = q;
         const HydroDev &h = hs.h[j];
@@ -1460,10 +1491,8 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS, 4) void k_psd_ice2(HydroSet hs, P
     __shared__ double s_part[4][NV][CPOL_WAVE];
     const int n_units = (int)a.totals[1];
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const WorkUnit *up = a.units + u;
-        const int key = __builtin_amdgcn_readfirstlane(up->key);
-        const int start = __builtin_amdgcn_readfirstlane(up->start);
-        const int count = __builtin_amdgcn_readfirstlane(up->count);
+        int key, start, count;
+        load_unit(a, u, key, start, count);
         int j = 0;
         for (int q = 1; q < hs.n_hydro; ++q) if (key >= hs.h[q].key_base) j = q;
         const HydroDev &h = hs.h[j];

@@ -105,3 +105,50 @@ def test_bad_arguments_are_value_errors():
     with pytest.raises(ValueError):
         op.simulate_rays([0.], [1.], paths=np.zeros((1, 1, 3, 7), dtype=np.float32))
     op.close()
+
+
+def test_items_outside_the_integral_tables_three_ways(monkeypatch):
+    """Mass densities so small that the PSD slope leaves the tabulated range (lambda beyond the last accepted
+    panel): such items go to the integrating kernels.  Three launch sequences must give the same bits:
+    the general one with the counting sort (CPOL_RARE_DIRECT=0, CPOL_GATE1=0), the general one with the items
+    listed directly as one-item work units (CPOL_GATE1=0) and the single-beam fused kernel, which defers the
+    gates that hold such an item to k_final -- with one and with nine sub-beams, hundreds of items each."""
+    import bench
+    from cosmo_pol_amd import RadarOperator, synthetic
+    hyds = ('R', 'S', 'G')
+    cube = synthetic.small_test_cube(hydrometeors=hyds)
+    data = {k: v.copy() for k, v in cube['data'].items()}
+    # a wedge of the domain with rain / snow of 1e-15 .. 1e-19 kg m-3 (lambda far beyond the tables), the rest as it is
+    ny, nx = data['QR_v'].shape[1:]
+    yy, xx = np.meshgrid(np.arange(ny), np.arange(nx), indexing='ij')
+    wedge = (xx > nx // 2) & (yy > ny // 2)
+    for k, tiny in (('QR_v', 1e-16), ('QS_v', 3e-18)):
+        f = data[k]
+        f[:, wedge] = np.where(f[:, wedge] > 0, np.float32(tiny) * (1 + (np.arange(f.shape[0]) % 5))[:, None], 0).astype(np.float32)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
+    az = np.arange(20.0, 70.0, 2.5)
+    results = {}
+    for n_gh in (1, 3):
+        conf = bench.bench_config(True)
+        conf['integration'].update(nh_GH=n_gh, nv_GH=n_gh)
+        for mode, env in (('sorted', {'CPOL_RARE_DIRECT': '0', 'CPOL_GATE1': '0'}), ('direct', {'CPOL_GATE1': '0'}), ('default', {})):
+            for k in ('CPOL_RARE_DIRECT', 'CPOL_GATE1'):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)                    # (read when the context is created)
+            op = RadarOperator(config=conf, luts=luts, output_variables='only_radar')
+            op.load_model_arrays(data, cube['zlevels'], cube['proj_info'], cube['resolution'])
+            res = op.simulate_rays(az, np.full(len(az), 2.0))
+            c = op._ctx.counters()
+            n_off = int(c.n_valid_items - c.n_table_items)
+            assert n_off > 200, (mode, n_off)
+            assert int(c.n_work_units) == (n_off if mode != 'sorted' else int(c.n_work_units)) and c.n_work_units > 0
+            results[(n_gh, mode)] = (res, n_off)
+            op.close()
+        ref, n_ref = results[(n_gh, 'sorted')]
+        for mode in ('direct', 'default'):
+            got, n_got = results[(n_gh, mode)]
+            assert n_got == n_ref
+            for k in ('ZH', 'ZV', 'ZDR', 'KDP', 'RHOHV', 'PHIDP', 'DELTA_HV', 'ATT_H', 'ATT_V', 'RVEL', 'mask'):
+                assert np.array_equal(got[k], ref[k], equal_nan=True), (n_gh, mode, k)
+        assert np.isfinite(ref['ZH']).sum() > 500

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes of an arbitrary python command (run on the GPU box), merged into one summary:
-#   tools/profile_cmd.sh <name> <script.py> [args...]
+#   [PC_ENV="A=1 B=2"] tools/profile_cmd.sh <name> <script.py> [args...]
 #   -> gpurun_out/profiles_<name>/<name>_kernel_stats.csv and <name>_summary.json
 # kernel-trace + stats, then separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ counters), as
 # MI355X_MICROARCH.md prescribes; the program itself follows `--` (no env / bash hop).
@@ -15,6 +15,7 @@ out=$root/gpurun_out/profiles_$name
 mkdir -p "$out"
 script=$root/$1; shift
 [ -f "$script" ] || { echo "profile_cmd: no such script: $script" >&2; exit 2; }
+for kv in ${PC_ENV:-}; do export "$kv"; done     # (exported here: never an `env` hop behind `--`)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt /tmp/pmcF /tmp/pmcW /tmp/pmcS
 
