@@ -125,7 +125,8 @@ STAGE_KERNELS = {'interp': ('k_interp_sweep', 'k_trajectory'), 'classify': ('k_c
                  'bucket': ('k_bucket_scan', 'k_bucket_scatter'),
                  'psd': ('k_psd_lookup', 'k_subbeam_sum'),     # (+ the integrating kernels: empty launches in a sweep)
                  'final': ('k_final', 'k_rvel_terms', 'k_ice_first')}
-TABLE_BUILD_KERNELS = ('k_itab_', 'k_stage_')      # cpol_prepare / cpol_stage_model: not part of a sweep
+TABLE_BUILD_KERNELS = ('k_itab_', 'k_stage_', 'k_spaceborne_first_gate')      # cpol_prepare / cpol_stage_model / the swath's
+                                                                              # gate windows (once per swath geometry): not part of a sweep
 
 
 def stage_rooflines(prof_name, stage_ms, n_sbg, n_valid, n_gates, n_vars, nz, launches_per_run=1):

@@ -63,8 +63,8 @@ def test_profile_summary_counts_scalar_cache_reads_in_full(tmp_path):
             f.write('Kernel_Name,Counter_Name,Counter_Value\n')
             for k, v in rows:
                 f.write('"%s",%s,%g\n' % (k, name, v))
-    coop = 'void k_subbeam_sum<true>(HydroSet, ItabSet, SubsumArgs)'
-    gather = 'void k_subbeam_sum<false>(HydroSet, ItabSet, SubsumArgs)'
+    coop = 'void k_subbeam_sum<true, 1, 2>(HydroSet, ItabSet, SubsumArgs)'
+    gather = 'void k_subbeam_sum<false, 1, 2>(HydroSet, ItabSet, SubsumArgs)'
     stats = tmp_path / 'stats.csv'
     stats.write_text('"Name","Calls","TotalDurationNs","AverageNs"\n"%s",2,4000000,2000000\n"%s",2,1000000,500000\n'
                      % (coop, gather))
@@ -82,14 +82,16 @@ def test_profile_summary_counts_scalar_cache_reads_in_full(tmp_path):
 
 
 def test_stage_kernels_cover_every_kernel_of_a_sweep():
-    """Every kernel name of the committed round-3 profiles of a sweep belongs to a stage of bench.py's
+    """Every kernel name of the committed profiles of a sweep (this round's) belongs to a stage of bench.py's
     roofline (or to table building / staging): no kernel's bytes fall out of `roofline.stages`."""
     import bench
     known = [k for ks in bench.STAGE_KERNELS.values() for k in ks]
     integrating = ('k_psd_uniform', 'k_psd<', 'k_psd_ice2', 'k_psd_melting', 'k_spec_', 'k_ml_weights')
-    for name in ('c2_iso', 'c3_el3_iso', 'c4_volume_iso', 'c4_share8_iso'):
+    for name in ('c2_iso', 'c3_el3_iso', 'c4_volume_iso', 'c4_share8_iso', 'c5_ku_iso'):
         prof, path = bench.load_profile_summary(name)
-        assert prof is not None and path.endswith('r3_%s_summary.json' % name)
+        assert prof is not None and path.endswith('r4_%s_summary.json' % name)
+        if name in ('c2_iso', 'c5_ku_iso'):                  # single-beam sweeps run the fused kernel
+            assert any('k_gate1' in k for k in prof) and not any('k_classify' in k for k in prof)
         for kernel, c in prof.items():
             if kernel.startswith('_') or not isinstance(c, dict) or kernel.startswith('__amd'):
                 continue
