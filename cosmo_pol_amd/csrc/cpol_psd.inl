@@ -1995,7 +1995,10 @@ __device__ __forceinline__ void itab1_columns(const double2 *c, double u, double
 // (Measured on the C4 volume, 6.4 M melting items, this form 1.35 ms: every block replaced by ONE cached
 // block 1.32 ms -- the rows are not the cost; 2 / 3 / 4 items of a block in flight per trip 1.33 / 1.39 /
 // 1.40 ms -- nor is the latency of an item's chain; four items per pass with lane = (item slot, function)
-// and every lane running the whole 66-term polynomial from its own row loads, no cross-lane sums: 3.04 ms.)
+// and every lane running the whole 66-term polynomial from its own row loads, no cross-lane sums: 3.04 ms.
+// Round 4: the rows of the NEXT distinct block requested before the items of the current one (two row sets in
+// registers, 180 VGPRs, 2 wavefronts per SIMD): C3 sweep 66.6 -> 73.8 us, the 225-ray C4 share 245 -> 394 us,
+// the C4 volume 1.36 -> 2.38 ms -- the walk does not wait for its rows at any of these sizes.)
 __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet hs, ItabSet its, LookupArgs a)
 {
     constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
