@@ -1999,7 +1999,10 @@ __device__ __forceinline__ void itab1_columns(const double2 *c, double u, double
 // Round 4: the rows of the NEXT distinct block requested before the items of the current one (two row sets in
 // registers, 180 VGPRs, 2 wavefronts per SIMD): C3 sweep 66.6 -> 73.8 us, the 225-ray C4 share 245 -> 394 us,
 // the C4 volume 1.36 -> 2.38 ms -- the walk does not wait for its rows at any of these sizes.)
-__global__ __launch_bounds__(CPOL_LOOKUP_THREADS, 4) void k_psd_lookup(HydroSet hs, ItabSet its, LookupArgs a)
+#ifndef CPOL_LOOKUP_WPE
+#define CPOL_LOOKUP_WPE 5             // wavefronts per SIMD asked of the register allocator (102 VGPRs: 5 fit since round 4; C4 volume 4 / 5 / 6 / 8: 1.36 / 1.22 / 1.51 / 2.24 ms, share 245 / 227 / 278 us, C3 sweep 66.6 / 67.1 us)
+#endif
+__global__ __launch_bounds__(CPOL_LOOKUP_THREADS, CPOL_LOOKUP_WPE) void k_psd_lookup(HydroSet hs, ItabSet its, LookupArgs a)
 {
     constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
     long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
