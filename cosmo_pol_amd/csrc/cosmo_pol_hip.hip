@@ -1627,8 +1627,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ga.store_items = any_vsrc2 ? 1 : 0;
         ga.analytic_vn = ca.vn ? 1 : 0;
         if (doppler) ca.vn = (double *)ctx->b_vn.p;        // (also the table-borne sums of a species summed over the ray)
-        hipLaunchKernelGGL(k_gate1, dim3(cdiv(n_rg, CPOL_GATE1_THREADS)), dim3(CPOL_GATE1_THREADS), 0, st,
-                           ctx->hs, ctx->its, ca, fa, ga);
+        bool melt_tab = false;
+        for (int j = 0; j < n_hyd; ++j) melt_tab = melt_tab || ctx->its.t[j].two_d;
+        if (melt_tab) hipLaunchKernelGGL((k_gate1<true>), dim3(cdiv(n_rg, CPOL_GATE1_THREADS)), dim3(CPOL_GATE1_THREADS), 0, st,
+                                         ctx->hs, ctx->its, ca, fa, ga);
+        else hipLaunchKernelGGL((k_gate1<false>), dim3(cdiv(n_rg, CPOL_GATE1_THREADS)), dim3(CPOL_GATE1_THREADS), 0, st,
+                                ctx->hs, ctx->its, ca, fa, ga);
     } else
     hipLaunchKernelGGL(k_classify, dim3(cdiv(n_sbg, CPOL_CLASSIFY_THREADS)),
                        dim3(CPOL_CLASSIFY_THREADS), 0, st, ctx->hs, ctx->its, ca);

@@ -62,10 +62,13 @@ __device__ __forceinline__ void gate1_store_item(const ClassifyArgs &a, const It
 #else
 #define CPOL_GATE1_ATTR
 #endif
+// TWO_D: a melting species is present (CPOL_GATE1=2): the 2-D walk, its 21 row registers per lane and the 28 KB of LDS that
+// bring its results to their lanes are compiled into that instantiation only
+template <bool TWO_D>
 __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(HydroSet hs, ItabSet its, ClassifyArgs a, FinalArgs f, GateArgs g)
 {
     constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
-    __shared__ double s_walk[CPOL_GATE1_THREADS / CPOL_WAVE][CPOL_WAVE][CPOL_N_SZ + 2];   // 2-D walk: item -> its lane
+    __shared__ double s_walk[TWO_D ? CPOL_GATE1_THREADS / CPOL_WAVE : 1][TWO_D ? CPOL_WAVE : 1][CPOL_N_SZ + 2];   // 2-D walk: item -> its lane
     __shared__ int s_lookup;
     if (threadIdx.x == 0) s_lookup = 0;
     __syncthreads();
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(Hy
         for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = make_double2(0.0, 0.0);
         double2 wv = make_double2(0.0, 0.0);
         bool have = false;
-        if (t.two_d) {
+        if (TWO_D && t.two_d) {
             // ---- melting species: the wavefront walks over the distinct 2-D blocks of its items (k_psd_lookup) ----
             int blk = 0;
             double u = 0.0, w = 0.0, q = 0.0;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(Hy
         // ---- fall-speed moments of the species (subbeam_proj) ----
         if (want_rvel && it.valid && f.vsrc[j] == 1) {
             double vj, nj;
-            if (want_vn || t.two_d) { vj = wv.x; nj = wv.y; }
+            if (want_vn || (TWO_D && t.two_d)) { vj = wv.x; nj = wv.y; }
             else { vj = it.dv; nj = it.dn; }
             if (vj == vj) mom_v += vj;
             if (nj == nj) mom_n += nj;

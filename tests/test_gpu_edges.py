@@ -152,3 +152,29 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
             for k in ('ZH', 'ZV', 'ZDR', 'KDP', 'RHOHV', 'PHIDP', 'DELTA_HV', 'ATT_H', 'ATT_V', 'RVEL', 'mask'):
                 assert np.array_equal(got[k], ref[k], equal_nan=True), (n_gh, mode, k)
         assert np.isfinite(ref['ZH']).sum() > 500
+
+
+def test_fused_kernel_with_melting_species_equals_the_general_sequence(monkeypatch):
+    """CPOL_GATE1=2 takes the single-beam fused kernel also when melting species are present (k_gate1<true>: the
+    2-D walk inside, results to their lanes through LDS; not the default: slower there).  Same bits as the
+    general sequence, RVEL with the ice total credited to one gate per ray included."""
+    import bench
+    from cosmo_pol_amd import RadarOperator, synthetic
+    hyds = ['R', 'S', 'G', 'mS', 'mG', 'I']
+    conf = bench.bench_config(True, 'c3')
+    cube = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G', 'I'))
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
+    az = np.arange(0.0, 360.0, 7.5)
+    out = {}
+    for mode in ('0', '2'):
+        monkeypatch.setenv('CPOL_GATE1', mode)                  # (read when the context is created)
+        op = RadarOperator(config=conf, luts=luts, output_variables='all')
+        op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+        out[mode] = op.simulate_rays(az, np.full(len(az), 3.0))
+        c = op._ctx.counters()
+        assert c.n_table_items == c.n_valid_items > 5000
+        op.close()
+    for k, v in out['0'].items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(out['2'][k], v, equal_nan=True), k
+    assert np.isfinite(out['0']['RVEL']).sum() > 1000 and np.isfinite(out['0']['ZH']).sum() > 1000
