@@ -123,6 +123,7 @@ struct cpol_ctx {
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
     int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
+    int subsum_scalar = 0;             // CPOL_SUBSUM_FORM=scalar: the cooperative form of k_subbeam_sum takes its rows through the scalar cache instead of LDS
     int subsum_small = 0;              // CPOL_SUBSUM_SMALL=1: experiment: the gather form of k_subbeam_sum with three wavefronts per (tile, hydrometeor) and the whole block in flight (measured slower)
     int subsum_coop = -1;              // CPOL_SUBSUM_COOP: k_subbeam_sum takes its coefficients through the scalar cache: 0 never, 1 always, -1 by launch size
     bool last_subsum = false;          // the 1-D table items of the last sweep never went through res[] (k_subbeam_sum)
@@ -551,6 +552,7 @@ int cpol_create(int device, cpol_ctx **out)
     if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
     if (getenv("CPOL_RARE_DIRECT")) ctx->rare_direct = atoi(getenv("CPOL_RARE_DIRECT")) != 0 ? 1 : 0;
     if (getenv("CPOL_GATE1")) ctx->gate1 = atoi(getenv("CPOL_GATE1"));
+    if (getenv("CPOL_SUBSUM_FORM")) ctx->subsum_scalar = !strcmp(getenv("CPOL_SUBSUM_FORM"), "scalar") ? 1 : 0;
     if (getenv("CPOL_SUBSUM_SMALL")) ctx->subsum_small = atoi(getenv("CPOL_SUBSUM_SMALL")) != 0 ? 1 : 0;
     if (getenv("CPOL_SUBSUM_COOP_ROUNDS")) ctx->subsum_coop_rounds = std::max(0, std::min(64, atoi(getenv("CPOL_SUBSUM_COOP_ROUNDS"))));
     *out = ctx;
@@ -651,6 +653,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->use_graph = parent->use_graph;
     c->subsum_coop = parent->subsum_coop;
     c->subsum_small = parent->subsum_small;
+    c->subsum_scalar = parent->subsum_scalar;
     c->rare_direct = parent->rare_direct;
     c->gate1 = parent->gate1;
     c->subsum_coop_rounds = parent->subsum_coop_rounds;
@@ -1855,9 +1858,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // hydrometeor), 4 columns each, and all rows of the block requested at once -- see the note on SPLIT in
         // cpol_final.inl: slower than the plain gather on the share (571 vs 533 us) and with lanes (1.41 vs 1.27 ms)
         const bool small = !coop && ctx->subsum_small == 1;
-        if (coop) hipLaunchKernelGGL((k_subbeam_sum<true, 1, 2>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
-        else if (small) hipLaunchKernelGGL((k_subbeam_sum<false, 3, 10>), dim3((unsigned)tiles, n_hyd * 3), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
-        else hipLaunchKernelGGL((k_subbeam_sum<false, 1, 2>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
+        // the cooperative form: coefficient rows through LDS (default since round 4) or through the scalar cache
+        // (CPOL_SUBSUM_FORM=scalar, read when the context is created)
+        if (coop && ctx->subsum_scalar) hipLaunchKernelGGL(k_subbeam_sum_scalar, dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
+        else if (coop) hipLaunchKernelGGL(k_subbeam_sum_lds, dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
+        else if (small) hipLaunchKernelGGL((k_subbeam_sum_gather<3, 10>), dim3((unsigned)tiles, n_hyd * 3), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
+        else hipLaunchKernelGGL((k_subbeam_sum_gather<1, 2>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
     }
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st));
 

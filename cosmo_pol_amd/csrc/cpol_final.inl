@@ -270,6 +270,9 @@ struct SubsumArgs {
 // each whatever the lanes in use: the tile's lanes are a third full on average).  With every item of a
 // wavefront forced onto ONE block (wrong results, timing only) the scalar-cache form takes 1.37 ms: the
 // per-sub-beam overhead of its partly filled wavefronts, not the number of distinct blocks, is most of it.
+#ifndef CPOL_SUBSUM_LDS_UNROLL
+#define CPOL_SUBSUM_LDS_UNROLL 2
+#endif
 #ifndef CPOL_SUBSUM_ROW_UNROLL
 #define CPOL_SUBSUM_ROW_UNROLL 2     // coefficient rows per scalar-memory wait (3 rows = 72 SGPRs no longer fit: 3.57 -> 4.34 ms)
 #endif
@@ -312,9 +315,11 @@ __device__ __forceinline__ double fma_sgpr(double a, double b, double c_uniform)
 // with an item in them, [2] scalar-cache rounds, [3] wavefront iterations skipped (species absent in the whole tile)
 __device__ unsigned long long g_subsum_stats[4];
 #endif
-template <bool COOP, int SPLIT, int GUNROLL>
-__global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbeam_sum(HydroSet hs, ItabSet its, SubsumArgs a)
+enum { SUBSUM_GATHER = 0, SUBSUM_SCALAR = 1, SUBSUM_LDS = 2 };
+template <int FORM, int SPLIT, int GUNROLL>
+__device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabSet &its, const SubsumArgs &a)
 {
+    constexpr bool COOP = FORM != SUBSUM_GATHER;
     static_assert(CPOL_SUBSUM_THREADS == CPOL_WAVE, "one wavefront per workgroup: the tile walk uses wave-wide ballots");
     constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
     constexpr int NP = CPOL_N_SZ / 2 / SPLIT;                            // double2 column pairs of this thread
@@ -342,6 +347,8 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
     float acc[2 * NP];
 #pragma unroll
     for (int c = 0; c < 2 * NP; ++c) acc[c] = __builtin_nanf("");
+    int pre_b = -1;                                     // SUBSUM_LDS: block whose pieces are already on their way into s_blk[cur]
+    int cur = 0;
     // sub-beams in chunks of 64: the validity bits of a whole chunk are read FIRST (independent byte
     // loads, 16 in flight), so that neither the skip of an absent sub-beam nor the loads of a present one
     // wait for a validity byte inside the loop
@@ -396,7 +403,77 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
 #ifdef CPOL_SUBSUM_STATS
             if (lane == 0 && part == 0) { atomicAdd(&g_subsum_stats[0], 1ull); atomicAdd(&g_subsum_stats[1], (unsigned long long)__popcll(todo)); }
 #endif
-            for (int round = 0; COOP && todo && round < a.coop_rounds; ++round) {
+            // ---- SUBSUM_LDS: the block's 88 16-byte pieces go straight from global memory into LDS (two
+            // global_load_lds_dwordx4 of the wavefront: no vector registers in between), every coefficient pair is
+            // then read back by ALL lanes from ONE address (ds_read_b128 broadcast) and used as a vector operand.  Two
+            // buffers: the pieces of the NEXT block -- of this sub-beam, or the first one of the next sub-beam with
+            // work -- are requested before the Horner chains / the accumulation of the current one start. ----
+            if constexpr (FORM == SUBSUM_LDS) {
+            __shared__ double2 s_blk[2][NC * NFP / 2];
+            constexpr int REST = NC * NFP / 2 - CPOL_WAVE;
+            // the 88 pieces of block `blk` straight from global memory into s_blk[bufi] (global_load_lds_dwordx4:
+            // no vector registers in between); their arrival is awaited with s_waitcnt vmcnt(0) before the first read
+            auto request = [&](int blk, int bufi) {
+                const double2 *src = reinterpret_cast<const double2 *>(t.tab + (long)blk * NB);
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + lane),
+                                                 (void __attribute__((address_space(3))) *)s_blk[bufi], 16, 0, 0);
+                if (lane < REST)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + CPOL_WAVE + lane),
+                                                     (void __attribute__((address_space(3))) *)(s_blk[bufi] + CPOL_WAVE), 16, 0, 0);
+            };
+            if (todo) {
+                int b = __builtin_amdgcn_readlane(blk_id, __ffsll((long long)todo) - 1);
+                if (b != pre_b) request(b, cur);
+                pre_b = -1;
+                for (int round = 0; todo && round < a.coop_rounds; ++round) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    const bool mine = blk_id == b;
+                    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+                    const bool more = todo && round + 1 < a.coop_rounds;
+                    if (more) {
+                        b = __builtin_amdgcn_readlane(blk_id, __ffsll((long long)todo) - 1);
+                        request(b, cur ^ 1);               // in flight during the Horner chains below
+                    }
+                    const double2 *sb = s_blk[cur];
+                    if (mine) {
+#pragma unroll
+                        for (int f = 0; f < NP; ++f) v[f] = sb[(NC - 1) * (NFP / 2) + f0 + f];
+#pragma unroll CPOL_SUBSUM_LDS_UNROLL
+                        for (int q = NC - 2; q >= 0; --q) {
+#pragma unroll
+                            for (int f = 0; f < NP; ++f) {
+                                const double2 cq = sb[q * (NFP / 2) + f0 + f];
+                                v[f].x = fma(v[f].x, u, cq.x);
+                                v[f].y = fma(v[f].y, u, cq.y);
+                            }
+                        }
+                        if (want_vn) {
+                            wv = sb[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
+                            for (int q = NC - 2; q >= 0; --q) {
+                                const double2 cq = sb[q * (NFP / 2) + CPOL_N_SZ / 2];
+                                wv.x = fma(wv.x, u, cq.x);
+                                wv.y = fma(wv.y, u, cq.y);
+                            }
+                        }
+                    }
+                    if (more) cur ^= 1;
+                }
+            }
+            if (wp) {
+                // the first block of the NEXT sub-beam with work (its key / record were requested at the top of this one)
+                const bool on_n = rc_n.x >= 0.0;
+                const unsigned long long mn = __builtin_amdgcn_ballot_w64(on_n);
+                if (mn) {
+                    const int pn_n = on_n ? min((int)rc_n.x, t.n_pan - 1) : 0;
+                    const int blk_n = on_n ? (key_n - key_base) * t.n_pan + pn_n : -1;
+                    pre_b = __builtin_amdgcn_readlane(blk_n, __ffsll((long long)mn) - 1);
+                    cur ^= 1;                              // (the buffer the last Horner chains did not read)
+                    request(pre_b, cur);
+                }
+            }
+            }
+            for (int round = 0; FORM == SUBSUM_SCALAR && todo && round < a.coop_rounds; ++round) {
 #ifdef CPOL_SUBSUM_STATS
                 if (lane == 0) atomicAdd(&g_subsum_stats[2], 1ull);
 #endif
@@ -506,6 +583,16 @@ __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR void k_subbea
 #pragma unroll
     for (int c2 = 0; c2 < NP; ++c2) o[c2] = make_float2(acc[2 * c2], acc[2 * c2 + 1]);
 }
+
+// the three forms as kernels: the LDS form asks the register allocator for 5 wavefronts per SIMD (96 VGPRs; its own choice
+// of 98 gives 4: C4 volume 1.77 against 1.68 ms), the others keep the allocator's choice (scalar: 96 / 5, gather: 104 / 4)
+__global__ __launch_bounds__(CPOL_SUBSUM_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
+void k_subbeam_sum_lds(HydroSet hs, ItabSet its, SubsumArgs a) { subbeam_sum_body<SUBSUM_LDS, 1, 2>(hs, its, a); }
+__global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR
+void k_subbeam_sum_scalar(HydroSet hs, ItabSet its, SubsumArgs a) { subbeam_sum_body<SUBSUM_SCALAR, 1, 2>(hs, its, a); }
+template <int SPLIT, int GUNROLL>
+__global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR
+void k_subbeam_sum_gather(HydroSet hs, ItabSet its, SubsumArgs a) { subbeam_sum_body<SUBSUM_GATHER, SPLIT, GUNROLL>(hs, its, a); }
 
 #ifndef CPOL_SKIP_RVEL
 #define CPOL_SKIP_RVEL 0      // experiment knob (tools/variants.sh): time of the RVEL loop

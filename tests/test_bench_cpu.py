@@ -63,8 +63,8 @@ def test_profile_summary_counts_scalar_cache_reads_in_full(tmp_path):
             f.write('Kernel_Name,Counter_Name,Counter_Value\n')
             for k, v in rows:
                 f.write('"%s",%s,%g\n' % (k, name, v))
-    coop = 'void k_subbeam_sum<true, 1, 2>(HydroSet, ItabSet, SubsumArgs)'
-    gather = 'void k_subbeam_sum<false, 1, 2>(HydroSet, ItabSet, SubsumArgs)'
+    coop = 'k_subbeam_sum_scalar(HydroSet, ItabSet, SubsumArgs)'
+    gather = 'void k_subbeam_sum_gather<1, 2>(HydroSet, ItabSet, SubsumArgs)'
     stats = tmp_path / 'stats.csv'
     stats.write_text('"Name","Calls","TotalDurationNs","AverageNs"\n"%s",2,4000000,2000000\n"%s",2,1000000,500000\n'
                      % (coop, gather))

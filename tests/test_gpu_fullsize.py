@@ -168,15 +168,17 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
     assert n_valid > 300 and n_melt > 100, (n_valid, n_melt)
     op.close()
     forms = {}
-    for form in ('gather', 'gather1', 'coop', 'tail'):
+    for form in ('gather', 'gather1', 'coop', 'scalar', 'tail'):
         # 'gather': the per-lane gather in its small-launch form (three wavefronts per (tile, hydrometeor), the
         # whole block requested at once: what a 45-ray launch gets by default); 'gather1': one wavefront per
         # (tile, hydrometeor), rows two at a time (what a large launch gets with CPOL_SUBSUM_COOP=0);
-        # 'coop': up to 6 table blocks per wavefront and sub-beam through the scalar cache, the remaining
-        # lanes by the gather tail; 'tail': ONE block that way, every other lane through the tail
+        # 'coop': up to 6 table blocks per wavefront and sub-beam staged in LDS (global_load_lds, round 4), the
+        # remaining lanes by the gather tail; 'scalar': the same walk with the rows through the scalar cache
+        # (round 3's form, CPOL_SUBSUM_FORM=scalar); 'tail': ONE block that way, every other lane through the tail
         monkeypatch.setenv('CPOL_SUBSUM_COOP', '0' if form.startswith('gather') else '1')     # (read when the context is created)
         monkeypatch.setenv('CPOL_SUBSUM_SMALL', '0' if form == 'gather1' else '1')
         monkeypatch.setenv('CPOL_SUBSUM_COOP_ROUNDS', '1' if form == 'tail' else '6')
+        monkeypatch.setenv('CPOL_SUBSUM_FORM', 'scalar' if form == 'scalar' else 'lds')
         opc = RadarOperator(config=over, luts=luts, output_variables='only_radar', lanes=1)
         opc.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
         forms[form] = opc.simulate_rays(az, np.full(len(az), 5.0))
@@ -186,6 +188,7 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
         assert np.array_equal(forms['gather'][k], forms['coop'][k], equal_nan=True), k
         assert np.array_equal(forms['gather'][k], forms['tail'][k], equal_nan=True), k
         assert np.array_equal(forms['gather'][k], forms['gather1'][k], equal_nan=True), k
+        assert np.array_equal(forms['gather'][k], forms['scalar'][k], equal_nan=True), k
         assert np.array_equal(forms['gather'][k], res[k], equal_nan=True), k     # (res: the default choice, last elevation)
 
 

@@ -22,7 +22,8 @@ def pmc(d):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
-SCALAR_LOAD_KERNELS = ('k_subbeam_sum<true',)       # coefficient rows through s_load (k_subbeam_sum<true, 1, 2>)
+SCALAR_LOAD_KERNELS = ('k_subbeam_sum<true', 'k_subbeam_sum_scalar')       # coefficient rows through s_load (round 4's default form,
+                                                                           # k_subbeam_sum_lds, reads through the vector path: the common rule)
 
 
 def main():
