@@ -24,6 +24,7 @@
 #include "cpol_device.h"
 #include "cpol_interp.inl"
 #include "cpol_psd.inl"
+#include "cpol_fused.inl"
 #include "cpol_final.inl"
 #include "cpol_gate.inl"
 #include "cpol_spectrum.inl"
@@ -122,6 +123,7 @@ struct cpol_ctx {
     int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0, last_n_keys = 0;
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
+    int fuse_classify = 1;             // CPOL_FUSE_CLASSIFY=0: k_interp_sweep + k_classify instead of k_interp_classify (read when the context is created)
     int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
     int subsum_scalar = 0;             // CPOL_SUBSUM_FORM=scalar: the cooperative form of k_subbeam_sum takes its rows through the scalar cache instead of LDS
     int subsum_small = 0;              // CPOL_SUBSUM_SMALL=1: experiment: the gather form of k_subbeam_sum with three wavefronts per (tile, hydrometeor) and the whole block in flight (measured slower)
@@ -550,6 +552,7 @@ int cpol_create(int device, cpol_ctx **out)
     // CPOL_SUBSUM_COOP=0 / 1: k_subbeam_sum never / always takes the coefficient rows through the scalar cache
     // (default: by launch size; the results are identical)
     if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
+    if (getenv("CPOL_FUSE_CLASSIFY")) ctx->fuse_classify = atoi(getenv("CPOL_FUSE_CLASSIFY")) != 0 ? 1 : 0;
     if (getenv("CPOL_RARE_DIRECT")) ctx->rare_direct = atoi(getenv("CPOL_RARE_DIRECT")) != 0 ? 1 : 0;
     if (getenv("CPOL_GATE1")) ctx->gate1 = atoi(getenv("CPOL_GATE1"));
     if (getenv("CPOL_SUBSUM_FORM")) ctx->subsum_scalar = !strcmp(getenv("CPOL_SUBSUM_FORM"), "scalar") ? 1 : 0;
@@ -655,6 +658,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->subsum_small = parent->subsum_small;
     c->subsum_scalar = parent->subsum_scalar;
     c->rare_direct = parent->rare_direct;
+    c->fuse_classify = parent->fuse_classify;
     c->gate1 = parent->gate1;
     c->subsum_coop_rounds = parent->subsum_coop_rounds;
     c->parent = parent;
@@ -1276,7 +1280,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_key, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_pos, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_par, (size_t)n_hyd * CPOL_MAX_PAR * n_sbg * sizeof(double));
-    ENSURE(ctx->b_count, (size_t)(n_keys + 3) * sizeof(int));       // + [n_keys + 1]: items on integral tables, [+ 2]: items ranked
+    ENSURE(ctx->b_count, (size_t)(n_keys + 3 + CPOL_COUNT_SLOTS) * sizeof(int));   // + [n_keys + 2]: items ranked, [n_keys + 3 ...): items on integral tables (count_table_items)
     ENSURE(ctx->b_blkranked, (size_t)cdiv(n_sbg, CPOL_CLASSIFY_THREADS) * sizeof(int));
     ENSURE(ctx->b_rec, (size_t)n_hyd * n_sbg * sizeof(double2));
     ENSURE(ctx->b_vmask, (size_t)n_sbg);
@@ -1376,6 +1380,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (want_szi) ENSURE(ctx->b_szinteg, (size_t)n_rg * n_hyd * CPOL_N_SZ * sizeof(float));
     const bool want_szt = out->sz_total != nullptr || ctx->keep_debug;
     const bool want_model = p->integrate_model && out->model_vars;
+    // >= 4 sub-beams, every slot on a table, no debug reads: the gate kernel classifies its gates itself
+    // (k_interp_classify, cpol_fused.inl); k_trajectory, which runs ahead of it, clears the counters
+    const bool fused = ctx->fuse_classify != 0 && rare_direct && !gate1 && ray_prep && !ml && !dop3 && !ctx->keep_debug;
     void *const user_out[O_N] = {out->ZH, out->ZV, out->ZDR, out->KDP, out->DELTA_HV, out->PHIDP,
                                  out->RHOHV, out->ATT_H, out->ATT_V, out->mask, out->lats, out->lons,
                                  out->dist, out->heights, out->RVEL, out->model_vars, out->sz_total,
@@ -1460,6 +1467,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ta.geo = (const double *)ctx->v_geo;
         ta.ray_const = ray_prep ? (double *)ctx->b_rayc.p : nullptr;
         ta.n_h = n_h; ta.lon1 = p->radar_lon;
+        if (fused) {
+            ta.zero_buf = (int *)ctx->b_count.p; ta.zero_n = n_keys + 3 + CPOL_COUNT_SLOTS;
+            ta.zero_buf2 = (int *)ctx->b_totals.p; ta.zero_n2 = 8;
+        }
         hipLaunchKernelGGL(k_trajectory, dim3((unsigned)(n_rays * n_v), paths ? cdiv(ng, 256) : 1), dim3(256), 0, st, ta);
     }
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_TRAJ], st));
@@ -1474,7 +1485,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.rp.range0 = p->range0; ia.rp.range_step = p->range_step;
     ia.rp.ke = p->ke; ia.rp.re = p->re; ia.rp.alt = p->radar_alt;
     ia.zero_buf = (int *)ctx->b_count.p;
-    ia.zero_n = n_keys + 3;
+    ia.zero_n = n_keys + 3 + CPOL_COUNT_SLOTS;
     ia.zero_buf2 = rare_direct ? (int *)ctx->b_totals.p : nullptr;     // (4 long long: k_classify / k_gate1 count the items outside the tables into them)
     ia.zero_n2 = 8;
     ia.geo = (const double *)ctx->v_geo;
@@ -1493,9 +1504,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.central_sub = n_sub / 2;
     ia.sin_u1 = p->sin_u1; ia.cos_u1 = p->cos_u1; ia.lon1 = p->radar_lon;
     ia.site = t->site ? (const double *)ctx->v_site : nullptr;
+    if (!fused)
     hipLaunchKernelGGL(k_interp_sweep, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256), 0, st,
                        ctx->model, ia);
-    if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
+    if (tm && !fused) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
 
     // ---- 2b. the arguments of the final stage (k_gate1, the single-beam fast path, needs them already) ----
     FinalArgs fa{};
@@ -1617,7 +1629,15 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         hipLaunchKernelGGL(k_ml_weights, dim3(n_rays * n_sub), dim3(64), 0, st, ma);
         ca.wgate = (const double *)ctx->b_wgate.p;
     }
-    if (gate1) {
+    if (fused) {
+        // the variables later kernels read: U, V, W (k_rvel_terms); all of them for the integrated model variables
+        ia.zero_buf = nullptr; ia.zero_buf2 = nullptr;
+        ia.store_mask = want_model ? 0xffffffffu : 0u;
+        if (doppler) ia.store_mask |= (1u << p->var_u) | (1u << p->var_v) | (1u << p->var_w);
+        hipLaunchKernelGGL(k_interp_classify, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256),
+                           (size_t)n_vars * 256 * sizeof(float), st, ctx->model, ia, ctx->hs, ctx->its, ca);
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
+    } else if (gate1) {
         GateArgs ga{};
         ga.sk = (float *)ctx->b_gscan.p;
         ga.sh = ga.sk + n_rg;
@@ -2052,8 +2072,12 @@ int cpol_counters(cpol_ctx *ctx, cpol_counters_t *out)
         HIPCHK(hipStreamSynchronize(ctx->stream));
         long long totals[2] = {0, 0};
         HIPCHK(hipMemcpy(totals, ctx->b_totals.p, sizeof totals, hipMemcpyDeviceToHost));
-        int n_lookup = 0;
-        HIPCHK(hipMemcpy(&n_lookup, (const int *)ctx->b_count.p + ctx->last_n_keys + 1, sizeof n_lookup, hipMemcpyDeviceToHost));
+        long long n_lookup = 0;
+        {
+            std::vector<int> slots(CPOL_COUNT_SLOTS);       // the kernels count into one of many words (count_table_items)
+            HIPCHK(hipMemcpy(slots.data(), (const int *)ctx->b_count.p + ctx->last_n_keys + 3, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+            for (int v : slots) n_lookup += v;
+        }
         ctx->counters.n_table_items = n_lookup;
         totals[0] += n_lookup;                              // valid items = integrated + looked up
         ctx->counters.n_valid_items = totals[0];

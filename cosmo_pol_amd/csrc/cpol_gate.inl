@@ -126,7 +126,7 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(Hy
             q_ahead = a.vals[hs.h[j + 1].d.var_q * n + i];
         const ItabDev &t = its.t[j];
         ClassItem it;
-        classify_item(h, t, a, n, i, in, qm, fw, T0, var_t0, e, it);
+        classify_item(h, t, a, a.vals, n, i, i, in, qm, fw, T0, var_t0, e, it);
         const bool want_vn = want_rvel && t.writes_vn;                      // uniform: the table carries the Doppler sums
         double2 v[CPOL_N_SZ / 2];
 #pragma unroll
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(Hy
             if (in && j + 1 < hs.n_hydro && hs.h[j + 1].d.q_source == CPOL_Q_MODEL)
                 q2 = a.vals[hs.h[j + 1].d.var_q * n + i];
             ClassItem it;
-            classify_item(h, its.t[j], a, n, i, in && deferred, qm, fw, T0, var_t0, e, it);
+            classify_item(h, its.t[j], a, a.vals, n, i, i, in && deferred, qm, fw, T0, var_t0, e, it);
             if (deferred) {
                 gate1_store_item(a, its.t[j], j, n, i, it, g.analytic_vn != 0);
                 // (the Doppler sums of a table item of this gate: evaluated once more from its block)
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(Hy
     for (int off = 32; off >= 1; off >>= 1) my_lookup += __shfl_xor(my_lookup, off);
     if (lane == 0 && my_lookup) atomicAdd(&s_lookup, my_lookup);
     __syncthreads();
-    if (threadIdx.x == 0 && s_lookup) atomicAdd(a.n_lookup, s_lookup);
+    if (threadIdx.x == 0) count_table_items(a.n_lookup, s_lookup);
 
     // ---- get_pol_from_sz, RVEL, mask, model variables; the operands of the range scans ----
     if (!in || deferred) return;

@@ -47,6 +47,10 @@ struct TrajArgs {
     double *ray_const;          // [n_rays * n_h][2] sin / cos (2 sigma1), then [n_rays][2] sin / cos (site longitude)
     int n_h;
     double lon1;
+    int *zero_buf;              // the sweep's counters when the sweep kernel itself counts into them (k_interp_classify) or NULL
+    int zero_n;
+    int *zero_buf2;
+    int zero_n2;
 };
 
 // height of candidate gate k of a downward-looking (spaceborne) ray
@@ -108,6 +112,17 @@ __device__ __forceinline__ void ray_path(const RayPathArgs &a, int ray, int rv, 
     e32 = (float)e * rad2deg_f;
 }
 
+// the counters of a sweep start at zero: cleared by the first kernel of the launch sequence
+__device__ __forceinline__ void clear_counters(int *zero_buf, int zero_n, int *zero_buf2, int zero_n2)
+{
+    if (!zero_buf) return;
+    const long total = (long)gridDim.x * gridDim.y * blockDim.x;
+    const long first = ((long)blockIdx.x * gridDim.y + blockIdx.y) * blockDim.x + threadIdx.x;
+    for (long i = first; i < zero_n; i += total)
+        zero_buf[i] = 0;
+    if (zero_buf2 && first < zero_n2) zero_buf2[first] = 0;      // (zero_n2 <= one workgroup)
+}
+
 // Ray paths ahead of the sweep kernel: with several horizontal quadrature nodes the sub-beams of one
 // vertical node share their path (7 x 7 nodes: 6 of 7 evaluations of the refraction formulas saved, ~300
 // float64 instructions per sub-beam gate); also the parity access to the paths (cpol_debug_read "traj").
@@ -119,6 +134,7 @@ __global__ __launch_bounds__(256) void k_trajectory(TrajArgs a)
 {
     int g = blockIdx.y * blockDim.x + threadIdx.x;
     int rv = blockIdx.x;                       // ray * n_v + vnode
+    clear_counters(a.zero_buf, a.zero_n, a.zero_buf2, a.zero_n2);
     if (a.ray_const && blockIdx.y == 0) {
         const long n_geo = (long)a.n_rays * a.n_h;
         for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_geo + a.n_rays;
@@ -366,6 +382,7 @@ struct InterpArgs {
     double *lats, *lons;        // [n_rays*n_gates] central sub-beam
     float *dist, *heights;      // [n_rays*n_gates] central sub-beam
     int *error_flag;
+    unsigned store_mask;        // k_interp_classify: bit v = variable v is read by a later kernel and goes to vals[]
     int n_rays, n_gates, n_sub, n_h, n_v, central_sub;
     double sin_u1, cos_u1, lon1;
     const double *site;         // per-ray site or NULL
@@ -385,21 +402,23 @@ struct InterpArgs {
 #else
 #define CPOL_INTERP_ATTR
 #endif
-__global__ __launch_bounds__(256) CPOL_INTERP_ATTR void k_interp_sweep(ModelDev m, InterpArgs a)
+// One sub-beam gate: ray path, geodesic, rotated-pole coordinates, level search, the variables.  Returns the
+// gate's status (0: inside the model, values valid; 1 / -1 / 2: above / below / outside, values NaN; 3: no such
+// gate in this launch) and its index.  KEEP = false: every variable goes to a.vals[] (k_interp_sweep).
+// KEEP = true (k_interp_classify): the values of a status-0 gate stay with the thread -- sv[v * blockDim.x],
+// its column of the workgroup's LDS array -- and the caller stores what later kernels read; of the NaN of the
+// other gates only the variables in a.store_mask are written.
+template <bool KEEP>
+__device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &a, float *sv, long &sbg_out, float &elev_out)
 {
     const int gate = blockIdx.y * blockDim.x + threadIdx.x;
     const int sub = blockIdx.x % a.n_sub, ray = blockIdx.x / a.n_sub;
-    if (a.zero_buf) {
-        const long total = (long)gridDim.x * gridDim.y * blockDim.x;
-        const long first = ((long)blockIdx.x * gridDim.y + blockIdx.y) * blockDim.x + threadIdx.x;
-        for (long i = first; i < a.zero_n; i += total)
-            a.zero_buf[i] = 0;
-        if (a.zero_buf2 && first < a.zero_n2) a.zero_buf2[first] = 0;      // (zero_n2 <= one workgroup)
-    }
-    if (gate >= a.n_gates) return;
+    if (gate >= a.n_gates) return 3;
     const int ih = a.sub_h[sub], jv = a.sub_v[sub];
     const long sbg = ((long)ray * a.n_sub + sub) * a.n_gates + gate;
     const long n_sbg = (long)a.n_rays * a.n_sub * a.n_gates;
+    sbg_out = sbg;
+    elev_out = 0.0f;
 
     float s32, h32, e32;
     if (a.traj) {
@@ -413,7 +432,8 @@ __global__ __launch_bounds__(256) CPOL_INTERP_ATTR void k_interp_sweep(ModelDev 
         // no gate here (ray shorter than the batch: spaceborne / host paths): counts
         // as "above the model", produces no item
         a.mask[sbg] = 1;
-        for (int v = 0; v < m.n_vars; ++v) a.vals[(long)v * n_sbg + sbg] = qnan;
+        for (int v = 0; v < m.n_vars; ++v)
+            if (!KEEP || ((a.store_mask >> v) & 1u)) a.vals[(long)v * n_sbg + sbg] = qnan;
         a.elev[sbg] = 0.0f;
         if (a.coords) { a.coords[2 * sbg] = qnan; a.coords[2 * sbg + 1] = qnan; }
         if (sub == a.central_sub) {
@@ -423,7 +443,7 @@ __global__ __launch_bounds__(256) CPOL_INTERP_ATTR void k_interp_sweep(ModelDev 
             if (a.dist) a.dist[rg] = qnan;
             if (a.heights) a.heights[rg] = qnan;
         }
-        return;
+        return 1;
     }
     const double sin_u1 = a.site ? a.site[(long)ray * 8 + 0] : a.sin_u1;
     const double cos_u1 = a.site ? a.site[(long)ray * 8 + 1] : a.cos_u1;
@@ -523,8 +543,10 @@ __global__ __launch_bounds__(256) CPOL_INTERP_ATTR void k_interp_sweep(ModelDev 
         !(rlon == rlon) || !(rlat == rlat)) {
         atomicOr(a.error_flag, 1);          // sticky until reported (cpol_synchronize / cpol_counters)
         a.mask[sbg] = 2;
-        for (int v = 0; v < m.n_vars; ++v) a.vals[(long)v * n_sbg + sbg] = __builtin_nanf("");
+        for (int v = 0; v < m.n_vars; ++v)
+            if (!KEEP || ((a.store_mask >> v) & 1u)) a.vals[(long)v * n_sbg + sbg] = __builtin_nanf("");
         a.elev[sbg] = e32;
+        elev_out = e32;
         if (a.coords) { a.coords[2 * sbg] = rlat; a.coords[2 * sbg + 1] = rlon; }
         if (sub == a.central_sub) {         // no stale data in the caller's buffers
             const long rg = (long)ray * a.n_gates + gate;
@@ -533,7 +555,7 @@ __global__ __launch_bounds__(256) CPOL_INTERP_ATTR void k_interp_sweep(ModelDev 
             if (a.dist) a.dist[rg] = qnan;
             if (a.heights) a.heights[rg] = qnan;
         }
-        return;
+        return 2;
     }
 
     GateGeom g;
@@ -544,11 +566,19 @@ __global__ __launch_bounds__(256) CPOL_INTERP_ATTR void k_interp_sweep(ModelDev 
             float o[4];
             gate_value4(m, g, h32, v, o);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a.vals[(long)(v + j) * n_sbg + sbg] = o[j];
+            for (int j = 0; j < 4; ++j) {
+                if (KEEP) sv[(v + j) * blockDim.x] = o[j];
+                else a.vals[(long)(v + j) * n_sbg + sbg] = o[j];
+            }
         }
-        for (; v < m.n_vars; ++v) a.vals[(long)v * n_sbg + sbg] = gate_value(m, g, h32, v);
+        for (; v < m.n_vars; ++v) {
+            const float o = gate_value(m, g, h32, v);
+            if (KEEP) sv[v * blockDim.x] = o;
+            else a.vals[(long)v * n_sbg + sbg] = o;
+        }
     } else {
-        for (int v = 0; v < m.n_vars; ++v) a.vals[(long)v * n_sbg + sbg] = qnan;
+        for (int v = 0; v < m.n_vars; ++v)
+            if (!KEEP || ((a.store_mask >> v) & 1u)) a.vals[(long)v * n_sbg + sbg] = qnan;
     }
     a.mask[sbg] = (signed char)g.status;
 
@@ -556,6 +586,7 @@ __global__ __launch_bounds__(256) CPOL_INTERP_ATTR void k_interp_sweep(ModelDev 
     if (e32 > 90.0f) e32 = 180.0f - e32;
     if (e32 < 0.0f) e32 = -e32;
     a.elev[sbg] = e32;
+    elev_out = e32;
     if (a.coords) { a.coords[2 * sbg] = rlat; a.coords[2 * sbg + 1] = rlon; }
 
     if (sub == a.central_sub) {
@@ -565,4 +596,13 @@ __global__ __launch_bounds__(256) CPOL_INTERP_ATTR void k_interp_sweep(ModelDev 
         if (a.dist) a.dist[rg] = s32;
         if (a.heights) a.heights[rg] = h32;
     }
+    return g.status;
+}
+
+__global__ __launch_bounds__(256) CPOL_INTERP_ATTR void k_interp_sweep(ModelDev m, InterpArgs a)
+{
+    clear_counters(a.zero_buf, a.zero_n, a.zero_buf2, a.zero_n2);
+    long sbg;
+    float e;
+    interp_gate<false>(m, a, nullptr, sbg, e);
 }

@@ -294,7 +294,8 @@ struct ClassifyArgs {
     // correctly rounded value in 20-40 % of the arguments, and K_DP shows it
     const float *tfun_snow;      // snow intercept N0(T)  (hydrometeors.py:896) or NULL
     const float *tfun_ice;       // 10**a(T) of the Field (2005) moment relation (:1287) or NULL
-    int *n_lookup;               // [0] items taken by the integral tables (k_psd_lookup), [1] items ranked
+    int *n_lookup;               // [1] items ranked for the integrating kernels; [2 .. 2 + CPOL_COUNT_SLOTS): items taken by the
+                                 // integral tables, counted into one of many words (count_table_items); [0] unused
     double2 *rec;                // [n_hydro][n_sbg] items of a slot with an integral table: {panel position (-1: not
                                  // on the table), scale}
     double *vn;                  // [n_hydro][n_sbg][2] analytic fall-speed moments of the gamma species (Doppler
@@ -312,6 +313,17 @@ struct ClassifyArgs {
                                  // written where there are some)
 };
 
+// The count of the items on integral tables (reported by cpol_counters, nothing on the device reads it): ONE word
+// took an atomic per workgroup of k_classify -- 172 000 on the C4 volume, each waiting for the one before it
+// at the same L2 address, ~11 ns apiece: 0.12 ms of the kernel's 2.0, and 3.2 ms of k_interp_classify's 6.6 when that
+// kernel added per wavefront.  The words are spread over CPOL_COUNT_SLOTS; the host adds them up.
+#define CPOL_COUNT_SLOTS 1024
+__device__ __forceinline__ void count_table_items(int *n_lookup, int items)
+{
+    const unsigned slot = (blockIdx.x * 4u + (threadIdx.x >> 6)) & (CPOL_COUNT_SLOTS - 1);
+    if (items) atomicAdd(n_lookup + 2 + slot, items);
+}
+
 __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &out)
 {
     const unsigned idx = __float_as_uint(T) - CPOL_TFUN_FIRST_BITS;
@@ -324,7 +336,9 @@ __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &ou
 
 // One (gate, hydrometeor): validity, LUT slice, PSD parameters, position on the integral table's panel axis,
 // scale of a table item, analytic fall-speed moments -- everything k_classify hands on per item, computed
-// in registers (k_classify stores it; k_gate1, the fused single-beam kernel, uses it in place).
+// in registers (k_classify stores it; k_gate1, the fused single-beam kernel, uses it in place).  The model variables
+// of the gate are vals[var * n + i] (the sweep's array, or the workgroup's LDS copy in k_interp_classify); gi = the
+// gate's index in the sweep.
 struct ClassItem {
     int key;                 // LUT slice of a present species (-1: absent)
     double p0, p1, p2;       // parameter slots 0..2 of the integrating kernels
@@ -334,20 +348,20 @@ struct ClassItem {
     bool valid, lookup, has_vn;
 };
 
-__device__ __forceinline__ void classify_item(const HydroDev &h, const ItabDev &tj, const ClassifyArgs &a, long n, long i,
+__device__ __forceinline__ void classify_item(const HydroDev &h, const ItabDev &tj, const ClassifyArgs &a, const float *vals, long n, long i, long gi,
                                               bool in, float qm, double fw, float T0, int var_t0, float e, ClassItem &o)
 {
     const cpol_hydro_desc &d = h.d;
     // NaN -> false (doppler_scatter.py:185); scheme 'ml': only gates where the
     // sub-beam has a non-zero weight (:186-189)
-    const bool valid = in && (qm > 0.f) && (!a.wgate || a.wgate[i] > 0.0);
+    const bool valid = in && (qm > 0.f) && (!a.wgate || a.wgate[gi] > 0.0);
     int key = -1;
     double p0 = 0.0, p1 = 0.0, p2 = 0.0;         // parameter slots 0..2
     double loglam = 0.0;                          // log of a slope parameter when the rule formed it as
     int ll_slot = -1;                             // (slot whose logarithm it is) exp(y log x): the table position and the fall-speed moments
                                                   // take it from there instead of a logarithm of the result
     if (valid) {
-        const float T = d.var_t == var_t0 ? T0 : a.vals[d.var_t * n + i];
+        const float T = d.var_t == var_t0 ? T0 : vals[d.var_t * n + i];
         // lut.py:336-341: float32 arithmetic for float32 queries
         int eb = clip_bin((e - d.e_lo) / d.e_step, d.n_e);
         int tb = d.second_axis_f64 ? clip_bin64((fw - (double)d.t_lo) / (double)d.t_step, d.n_t)
@@ -383,7 +397,7 @@ __device__ __forceinline__ void classify_item(const HydroDev &h, const ItabDev &
             break; }
         case CPOL_RULE_TWO_MOMENT: {
             // hydrometeors.py:231-246
-            qnv = (double)a.vals[d.var_qn * n + i];
+            qnv = (double)vals[d.var_qn * n + i];
             double xm = q / (qnv + 2.220446049250313e-16);
             xm = fmin(fmax(xm, d.x_min), d.x_max);
             double lam = cp_pow(d.lambda_factor * xm, d.lam_exponent);
@@ -450,7 +464,7 @@ __device__ __forceinline__ void classify_item(const HydroDev &h, const ItabDev &
         const double lp = ll_slot == 0 ? loglam : cp_log(p0);  // one logarithm of lambda for both powers
         dv = d.vel_factor * n0v * d.alpha / d.nu * cp_exp(-(d.beta + d.mu + 1) / d.nu * lp);
         dn = (d.rule == CPOL_RULE_TWO_MOMENT)
-            ? (double)a.vals[d.var_qn * n + i] : d.ntot_factor * n0v / d.nu * cp_exp(-(d.mu + 1) / d.nu * lp);
+            ? (double)vals[d.var_qn * n + i] : d.ntot_factor * n0v / d.nu * cp_exp(-(d.mu + 1) / d.nu * lp);
     }
     o.key = key; o.p0 = p0; o.p1 = p1; o.p2 = p2; o.pf = lookup ? pf : -1.0; o.scale = scale;
     o.dv = dv; o.dn = dn; o.valid = valid; o.lookup = lookup; o.has_vn = has_vn;
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) CPOL_CLASSIFY_ATTR void k_cl
             q_ahead = a.vals[hs.h[j + 1].d.var_q * n + i];
         const ItabDev &tj = its.t[j];
         ClassItem it;
-        classify_item(h, tj, a, n, i, in, qm, fw, T0, var_t0, e, it);
+        classify_item(h, tj, a, a.vals, n, i, i, in, qm, fw, T0, var_t0, e, it);
         const bool valid = it.valid, lookup = it.lookup;
         const int key = it.key;
         if (valid) {
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(CPOL_CLASSIFY_THREADS) CPOL_CLASSIFY_ATTR void k_cl
     if (lane_id() == 0 && my_lookup) atomicAdd(&s_lookup, my_lookup);
     if (lane_id() == 0 && my_ranked) atomicAdd(&s_ranked, my_ranked);
     __syncthreads();
-    if (threadIdx.x == 0 && s_lookup) atomicAdd(a.n_lookup, s_lookup);
+    if (threadIdx.x == 0) count_table_items(a.n_lookup, s_lookup);
     if (threadIdx.x == 0 && s_ranked) atomicAdd(a.n_lookup + 1, s_ranked);
     if (direct) return;
     if (threadIdx.x == 0) a.blk_ranked[blockIdx.x] = s_ranked;
