@@ -13,7 +13,7 @@
 // cannot clear what its own workgroups count into).  Not with the debug reads, integration scheme 'ml'
 // (k_ml_weights runs between the two kernels) or Doppler scheme 3 (the spectrum kernels read vals[]).
 #ifndef CPOL_FUSED_WPE
-#define CPOL_FUSED_WPE 0
+#define CPOL_FUSED_WPE 5          // measured on the C4 volume: 3 / 4 (the allocator's choice) / 5 / 6 wavefronts per SIMD: 4.31 / 3.51 / 3.34 / 4.34 ms
 #endif
 #if CPOL_FUSED_WPE
 #define CPOL_FUSED_ATTR __attribute__((amdgpu_waves_per_eu(CPOL_FUSED_WPE, CPOL_FUSED_WPE)))

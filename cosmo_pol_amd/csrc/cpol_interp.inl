@@ -217,8 +217,10 @@ __device__ __forceinline__ void gate_geometry(const ModelDev &m, float rlat, flo
     float p1 = (rlon - m.llc0) / m.res0;
     int i0 = (int)floor((double)p0);
     int i1 = (int)floor((double)p1);
-    g.x = fmodf(p0, 1.0f);
-    g.y = fmodf(p1, 1.0f);
+    // fmodf(p, 1.0f) = p - trunc(p) with the sign of p: exact (the difference of a float and its integer part
+    // is representable), so the same bits as the C library's loop (OCML: ~25 instructions each, these: 3)
+    g.x = copysignf(p0 - truncf(p0), p0);
+    g.y = copysignf(p1 - truncf(p1), p1);
     g.dx = 1.0f - g.x;
     g.dy = 1.0f - g.y;
     // the reference does not range-check; callers pass the domain check first.
@@ -402,6 +404,16 @@ struct InterpArgs {
 #else
 #define CPOL_INTERP_ATTR
 #endif
+// 1 / sqrt(x) for x of order 1: v_rsq_f64 (~27 bits) and two Newton steps y <- y (3/2 - x/2 y^2); within 2 ulp
+__device__ __forceinline__ double rsqrt_newton(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
 // One sub-beam gate: ray path, geodesic, rotated-pole coordinates, level search, the variables.  Returns the
 // gate's status (0: inside the model, values valid; 1 / -1 / 2: above / below / outside, values NaN; 3: no such
 // gate in this launch) and its index.  KEEP = false: every variable goes to a.vals[] (k_interp_sweep).
@@ -466,8 +478,16 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     } else {
         sincos(2.0 * sigma1, &s2s1, &c2s1);
     }
+    // (the correction converges by a factor B ~ 1.7e-3 per pass: after 4 passes sigma is within 4e-16 rad -- 1e-14
+    // relative -- of the fixed point, after 5 within rounding.  The central sub-beam, whose float64 coordinates
+    // are outputs, takes 5; the others, of which only the float32 grid coordinates are used, 4.)
+#if CPOL_INTERP_FAST_SUB
+    const int n_iter = sub != a.central_sub ? CPOL_VINCENTY_ITERS - 1 : CPOL_VINCENTY_ITERS;
+#else
+    const int n_iter = CPOL_VINCENTY_ITERS;
+#endif
 #pragma unroll 1
-    for (int it = 0; it <= CPOL_VINCENTY_ITERS; ++it) {
+    for (int it = 0; it <= n_iter; ++it) {
         if (fabs(sigma) < 0.1) {
             const double z = sigma * sigma;
             sin_s = sigma * fma(z, fma(z, fma(z, fma(z, fma(z, -1.0 / 39916800.0, 1.0 / 362880.0),
@@ -478,7 +498,7 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
             sincos(sigma, &sin_s, &cos_s);
         }
         cos2sm = c2s1 * cos_s - s2s1 * sin_s;
-        if (it == CPOL_VINCENTY_ITERS) break;           // values of the converged sigma
+        if (it == n_iter) break;                        // values of the converged sigma
         double dsig = B * sin_s * (cos2sm + B / 4.0 * (cos_s * (-1.0 + 2.0 * cos2sm * cos2sm)
                       - B / 6.0 * cos2sm * (-3.0 + 4.0 * sin_s * sin_s)
                       * (-3.0 + 4.0 * cos2sm * cos2sm)));
@@ -501,9 +521,11 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
         // atan2 -> degrees -> radians -> sincos.  Same values to a few ulp (float64) before the float32 cast
         // of the rotated coordinates, i.e. the same float32 coordinate in all but ~1e-8 of the cases, like
         // the device's Taylor sums above; 4 OCML calls of ~100 instructions fewer per sub-beam gate.
-        const double hl = 1.0 / sqrt(lat_num * lat_num + lat_den * lat_den);
+        // (1 / sqrt as the hardware's reciprocal square root + two Newton steps -- the arguments are ~1 -- instead
+        // of a correctly rounded square root and a correctly rounded division: ~10 instructions instead of ~45)
+        const double hl = rsqrt_newton(lat_num * lat_num + lat_den * lat_den);
         sl = lat_num * hl; cl = lat_den * hl;
-        const double hm = 1.0 / sqrt(lam_y * lam_y + lam_x * lam_x);
+        const double hm = rsqrt_newton(lam_y * lam_y + lam_x * lam_x);
         const double sm = lam_y * hm, cm = lam_x * hm;                      // sin / cos of lam
         const double d2 = dlon * dlon;
         const double sd = dlon * fma(d2, -1.0 / 6.0, 1.0);                   // |dlon| < 2e-4: next terms < 1e-21
@@ -535,8 +557,19 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     const double x_new = m.ctcp * x + m.ctsp * y + m.st * z;
     const double y_new = m.nsp * x + m.cp * y;
     const double z_new = m.nstcp * x - m.stsp * y + m.ct * z;
-    const float rlon = (float)(atan2(y_new, x_new) / CPOL_DEG);
-    const float rlat = (float)(asin(z_new) / CPOL_DEG);
+    float rlon, rlat;
+#if CPOL_INTERP_FAST_SUB
+    if (sub != a.central_sub) {
+        // (radians -> degrees as a product with 180 / pi: a float64 division by a constant is ~25 instructions;
+        // the last float64 bit may differ from the quotient's, the float32 cast hides it but for ~1e-8 of the gates)
+        rlon = (float)(atan2(y_new, x_new) * (1.0 / CPOL_DEG));
+        rlat = (float)(asin(z_new) * (1.0 / CPOL_DEG));
+    } else
+#endif
+    {
+        rlon = (float)(atan2(y_new, x_new) / CPOL_DEG);
+        rlat = (float)(asin(z_new) / CPOL_DEG);
+    }
 
     // interpolation.py:572-575 (IndexError in the reference)
     if (rlon < m.llc0 || rlat < m.llc1 || rlon > m.urc0 || rlat > m.urc1 ||
