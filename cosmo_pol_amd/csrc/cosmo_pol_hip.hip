@@ -101,8 +101,20 @@ struct cpol_ctx {
     const float *tfun[CPOL_N_TFUN] = {};
     // per-sweep work buffers (grow only)
     // per-sweep host tables: packed into ONE pinned staging buffer (ring of 4, an event each) and
-    // moved by ONE host-to-device copy into b_tables; v_* = views into that arena
-    DevBuf b_tables;
+    // moved by ONE host-to-device copy into the arena of a table set (tsets[]); v_* = views into the set in use
+    // The per-ray tables of the last CPOL_TABLE_SETS scan geometries stay on the device, found again by the
+    // caller's version tag: a scan that cycles through its elevations uploads each set once (a 35 KB copy in
+    // front of a 0.09 ms sweep costs the stream 25-45 us: measured with tools/submit_cost.py, one lane,
+    // 8 elevations in turn: 115 us per sweep against 70 with one resident set).
+    struct TableSet {
+        uint64_t version = 0, last_use = 0;
+        long shape[6] = {0, 0, 0, 0, 0, 0};
+        DevBuf buf;
+        void *views[11] = {nullptr};
+    };
+    static constexpr int N_TABLE_SETS = 8;
+    TableSet tsets[N_TABLE_SETS];
+    uint64_t tset_clock = 0;
     void *v_traj_in = nullptr, *v_geo = nullptr, *v_subh = nullptr, *v_subv = nullptr, *v_subw = nullptr,
          *v_sens = nullptr, *v_site = nullptr, *v_nyq = nullptr, *v_subsmooth = nullptr,
          *v_mlfilter = nullptr, *v_varray = nullptr;
@@ -134,8 +146,6 @@ struct cpol_ctx {
     // when it has been read AND reported (host-output sweeps, cpol_synchronize, cpol_counters)
     int *d_errword = nullptr;
     std::vector<void *> host_allocs;   // pinned host memory handed out by cpol_host_alloc
-    uint64_t tables_version = 0;       // tag of the per-ray tables resident on the device
-    long tables_shape[6] = {0, 0, 0, 0, 0, 0};
     // timing: one event set per sweep since cpol_enable_timing(ctx, 1); elapsed
     // times are collected (averaged) by cpol_counters after the stream drained,
     // so recording does not serialise the timed loop.
@@ -598,7 +608,8 @@ void cpol_destroy(cpol_ctx *ctx)
         if (sg.ev) (void)hipEventDestroy(sg.ev);
         if (sg.p) (void)hipHostFree(sg.p);
     }
-    DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_tables, &ctx->b_traj, &ctx->b_wgate, &ctx->b_clk, &ctx->b_rayc,
+    for (auto &ts : ctx->tsets) free_buf(ts.buf);
+    DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj, &ctx->b_wgate, &ctx->b_clk, &ctx->b_rayc,
                      &ctx->b_beam, &ctx->b_spectrum, &ctx->b_outwin, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_units,
@@ -1218,27 +1229,38 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     }
     const long shape[6] = {n_rays, ng, n_sub, n_h, n_v, (ml ? 64 + t->ml_radius * 128L : 0) + (long)mode * 8 + (t->nyquist ? 4 : 0) + (t->site ? 2 : 0) + (cut ? 1 : 0)
                            + (t->varray ? 16 + p->n_vbins * 65536L : 0)};
-    const bool reuse = t->version != 0 && t->version == ctx->tables_version &&
-                       memcmp(shape, ctx->tables_shape, sizeof shape) == 0;
-    if (!reuse) {
+    void **const views[11] = {&ctx->v_traj_in, &ctx->v_site, &ctx->v_geo, &ctx->v_subh, &ctx->v_subv, &ctx->v_subw,
+                              &ctx->v_sens, &ctx->v_nyq, &ctx->v_subsmooth, &ctx->v_mlfilter, &ctx->v_varray};
+    cpol_ctx::TableSet *set = nullptr, *lru = &ctx->tsets[0];
+    for (auto &ts : ctx->tsets) {
+        if (t->version != 0 && ts.version == t->version && memcmp(shape, ts.shape, sizeof shape) == 0) set = &ts;
+        if (ts.last_use < lru->last_use) lru = &ts;
+    }
+    const bool reuse = set != nullptr;
+    if (!set) set = lru;
+    set->last_use = ++ctx->tset_clock;
+    if (reuse) {
+        for (int k = 0; k < 11; ++k) *views[k] = set->views[k];
+    } else {
         // pack every table of this sweep into one pinned staging slot, one H2D copy
-        struct Item { const void *src; size_t bytes; void **view; };
-        const Item items[] = {
-            {t->traj, (size_t)n_rays * n_v * CPOL_TRAJ_STRIDE * sizeof(double), &ctx->v_traj_in},
-            {t->site, t->site ? (size_t)n_rays * CPOL_SITE_STRIDE * sizeof(double) : 0, &ctx->v_site},
-            {t->geo, (size_t)n_rays * n_h * CPOL_GEO_STRIDE * sizeof(double), &ctx->v_geo},
-            {t->sub_h, (size_t)n_sub * sizeof(int), &ctx->v_subh},
-            {t->sub_v, (size_t)n_sub * sizeof(int), &ctx->v_subv},
-            {t->sub_w, (size_t)n_sub * sizeof(double), &ctx->v_subw},
-            {cut ? t->sens_thr : nullptr, cut ? (size_t)ng * sizeof(double) : 0, &ctx->v_sens},
-            {t->nyquist, t->nyquist ? (size_t)n_rays * sizeof(double) : 0, &ctx->v_nyq},
-            {ml ? t->sub_smooth : nullptr, ml ? (size_t)n_sub * sizeof(int) : 0, &ctx->v_subsmooth},
-            {ml ? t->ml_filter : nullptr, ml ? (size_t)(2 * t->ml_radius + 1) * sizeof(double) : 0, &ctx->v_mlfilter},
-            {t->varray, t->varray ? (size_t)p->n_vbins * sizeof(double) : 0, &ctx->v_varray},
+        struct Item { const void *src; size_t bytes; };
+        const Item items[11] = {
+            {t->traj, (size_t)n_rays * n_v * CPOL_TRAJ_STRIDE * sizeof(double)},
+            {t->site, t->site ? (size_t)n_rays * CPOL_SITE_STRIDE * sizeof(double) : 0},
+            {t->geo, (size_t)n_rays * n_h * CPOL_GEO_STRIDE * sizeof(double)},
+            {t->sub_h, (size_t)n_sub * sizeof(int)},
+            {t->sub_v, (size_t)n_sub * sizeof(int)},
+            {t->sub_w, (size_t)n_sub * sizeof(double)},
+            {cut ? t->sens_thr : nullptr, cut ? (size_t)ng * sizeof(double) : 0},
+            {t->nyquist, t->nyquist ? (size_t)n_rays * sizeof(double) : 0},
+            {ml ? t->sub_smooth : nullptr, ml ? (size_t)n_sub * sizeof(int) : 0},
+            {ml ? t->ml_filter : nullptr, ml ? (size_t)(2 * t->ml_radius + 1) * sizeof(double) : 0},
+            {t->varray, t->varray ? (size_t)p->n_vbins * sizeof(double) : 0},
         };
         size_t total = 0;
         for (const Item &it : items) total += (it.bytes + 63) & ~(size_t)63;
-        ENSURE(ctx->b_tables, total);
+        set->version = 0;                                        // (not valid until the copy is queued)
+        ENSURE(set->buf, total);
         cpol_ctx::Staging &sg = ctx->stg[ctx->stg_next];
         ctx->stg_next = (ctx->stg_next + 1) % 4;
         if (sg.used) HIPCHK(hipEventSynchronize(sg.ev));        // its last copy has left the buffer
@@ -1250,18 +1272,19 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         }
         if (!sg.ev) HIPCHK(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
         size_t off = 0;
-        for (const Item &it : items) {
-            *it.view = it.bytes ? (void *)((char *)ctx->b_tables.p + off) : nullptr;
+        for (int k = 0; k < 11; ++k) {
+            const Item &it = items[k];
+            set->views[k] = it.bytes ? (void *)((char *)set->buf.p + off) : nullptr;
+            *views[k] = set->views[k];
             if (it.bytes) memcpy((char *)sg.p + off, it.src, it.bytes);
             off += (it.bytes + 63) & ~(size_t)63;
         }
-        HIPCHK(hipMemcpyAsync(ctx->b_tables.p, sg.p, total, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(set->buf.p, sg.p, total, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipEventRecord(sg.ev, ctx->stream));
         sg.used = true;
-        ctx->tables_version = t->version;
-        memcpy(ctx->tables_shape, shape, sizeof shape);
+        set->version = t->version;
+        memcpy(set->shape, shape, sizeof shape);
     }
-
     // ---- work buffers ----
     // several sub-beams: the ray paths (shared by the horizontal nodes of a vertical node) and the per-ray
     // constants of the geodesic come from k_trajectory instead of once per sub-beam gate

@@ -575,84 +575,97 @@ class RadarOperator(object):
             if paths is not None or site is not None or not self.reuse_device_tables:
                 version = 0
 
-        p = N.SweepParams()
-        p.n_rays, p.n_gates, p.n_sub = n_rays, n_gates, sub.n_sub
-        p.n_hnodes, p.n_vnodes = len(sub.pts_hor), len(sub.pts_ver)
-        p.with_melting = int(conf['microphysics']['with_melting'])
-        p.with_attenuation = int(conf['microphysics']['with_attenuation'])
         want_model = self.output_variables in ('all', 'only_model')
-        p.integrate_model = int(want_model)
-        p.outputs_on_device = 1 if device_outputs is not None else 2     # host outputs: page-locked, one copy
-        # Doppler schemes 1 (analytic mean fall speed) and 2 (rcs-weighted); none for GPM
-        # (doppler_scatter.py:83-87); scheme 3 (full spectrum) is out of scope
-        doppler = (conf['doppler']['scheme'] in (1, 2, 3) and conf['radar'].get('type') != 'GPM'
-                   and mode != N.GEOM_SPACEBORNE)
-        spectrum = doppler and conf['doppler']['scheme'] == 3
-        if spectrum and (conf['doppler']['turbulence_correction'] or conf['doppler']['motion_correction']):
-            # both corrections are dead upstream: spectral_width_turb / _motion read a module-level
-            # CONFIG that is still None (doppler_scatter.py:24, 737, 771), EDR is never loaded
-            raise NotImplementedError('doppler/turbulence_correction and doppler/motion_correction '
-                                      'raise in the reference as well; not reproduced')
-        p.simulate_doppler = int(conf['doppler']['scheme']) if doppler else 0
-        vi = {v: i for i, v in enumerate(self._staged_vars)}
-        p.var_u, p.var_v, p.var_w = vi['U'], vi['V'], vi['W']
-        p.var_rho = vi.get('RHO', -1)
-        varray = None
-        if spectrum:
-            varray = np.ascontiguousarray(self.constants.VARRAY, dtype=np.float64)
-            p.n_vbins = len(varray)
-            p.c_spectrum = float(self.constants.WAVELENGTH ** 4
-                                 / (np.pi ** 5 * conf['radar']['K_squared'] ** 2))
-        p.geometry_mode = mode
-        if site is None:
-            re, ke = geo.earth_radius_for_refraction(coords)
-            sin_u1, cos_u1, _ = geo.radar_site_constants(coords)
-            p.radar_lat, p.radar_lon, p.radar_alt = (float(coords[0]), float(coords[1]),
-                                                     float(coords[2]))
-            p.ke, p.re = ke, re
-            p.sin_u1, p.cos_u1 = sin_u1, cos_u1
-        else:
-            p.ke, p.re = 1.0, 0.0
-        p.range0 = range0
-        p.range_step = float(conf['radar']['radial_resolution'])
-        p.wavelength = float(self.constants.WAVELENGTH)
-        p.k_squared = float(conf['radar']['K_squared'])
-        p.radial_res = float(conf['radar']['radial_resolution'])
-        p.c_zh = float(self.constants.WAVELENGTH ** 4 / (np.pi ** 5 * conf['radar']['K_squared']))
 
-        thr = (self._cached(('sens', n_gates),
-                            lambda: geo.sensitivity_threshold(conf, self.constants, n_gates))
-               if apply_sensitivity else None)
-        p.apply_sensitivity = int(thr is not None)
-        t = N.RayTables()
-        if paths is not None:
-            paths = np.ascontiguousarray(paths, dtype=np.float32)
-            if paths.shape != (n_rays, p.n_vnodes, 3, n_gates):
-                raise ValueError('paths must have shape [n_rays, n_vnodes, 3, n_gates] = %s'
-                                 % ((n_rays, p.n_vnodes, 3, n_gates),))
-        if site is not None:
-            site = np.ascontiguousarray(site, dtype=np.float64)
-        keep = [traj, geo_t, sub.sub_h, sub.sub_v, sub.sub_w, thr, paths, site]
-        t.traj, t.geo = traj.ctypes.data, geo_t.ctypes.data
-        t.sub_h, t.sub_v, t.sub_w = sub.sub_h.ctypes.data, sub.sub_v.ctypes.data, sub.sub_w.ctypes.data
-        t.sens_thr = thr.ctypes.data if thr is not None else None
-        t.site = site.ctypes.data if site is not None else None
-        t.paths = paths.ctypes.data if paths is not None else None
-        nyq = None
-        if doppler and conf['radar']['nyquist_velocity'] is not None:
-            # Nyquist velocity of every ray from its nominal elevation / azimuth
-            # (doppler_scatter.py:431-437: the central sub-beam's angles)
-            nyq = np.ascontiguousarray(conf['radar']['nyquist_velocity'](el, az), dtype=np.float64)
-            keep.append(nyq)
-        t.nyquist = nyq.ctypes.data if nyq is not None else None
-        if varray is not None:
-            keep.append(varray)
-            t.varray = varray.ctypes.data
-        if sub.sub_smooth is not None:        # integration scheme 'ml': per-gate weights
-            t.sub_smooth = sub.sub_smooth.ctypes.data
-            t.ml_filter = sub.ml_filter.ctypes.data
-            t.ml_radius = int(sub.ml_radius)
-        t.version = version
+        def prepare(paths=paths, site=site):
+            """The argument structs of cpol_run_sweep for this set of rays (and the arrays they point into)."""
+            p = N.SweepParams()
+            p.n_rays, p.n_gates, p.n_sub = n_rays, n_gates, sub.n_sub
+            p.n_hnodes, p.n_vnodes = len(sub.pts_hor), len(sub.pts_ver)
+            p.with_melting = int(conf['microphysics']['with_melting'])
+            p.with_attenuation = int(conf['microphysics']['with_attenuation'])
+            p.integrate_model = int(want_model)
+            p.outputs_on_device = 1 if device_outputs is not None else 2     # host outputs: page-locked, one copy
+            # Doppler schemes 1 (analytic mean fall speed) and 2 (rcs-weighted); none for GPM
+            # (doppler_scatter.py:83-87); scheme 3 (full spectrum) is out of scope
+            doppler = (conf['doppler']['scheme'] in (1, 2, 3) and conf['radar'].get('type') != 'GPM'
+                       and mode != N.GEOM_SPACEBORNE)
+            spectrum = doppler and conf['doppler']['scheme'] == 3
+            if spectrum and (conf['doppler']['turbulence_correction'] or conf['doppler']['motion_correction']):
+                # both corrections are dead upstream: spectral_width_turb / _motion read a module-level
+                # CONFIG that is still None (doppler_scatter.py:24, 737, 771), EDR is never loaded
+                raise NotImplementedError('doppler/turbulence_correction and doppler/motion_correction '
+                                          'raise in the reference as well; not reproduced')
+            p.simulate_doppler = int(conf['doppler']['scheme']) if doppler else 0
+            vi = {v: i for i, v in enumerate(self._staged_vars)}
+            p.var_u, p.var_v, p.var_w = vi['U'], vi['V'], vi['W']
+            p.var_rho = vi.get('RHO', -1)
+            varray = None
+            if spectrum:
+                varray = np.ascontiguousarray(self.constants.VARRAY, dtype=np.float64)
+                p.n_vbins = len(varray)
+                p.c_spectrum = float(self.constants.WAVELENGTH ** 4
+                                     / (np.pi ** 5 * conf['radar']['K_squared'] ** 2))
+            p.geometry_mode = mode
+            if site is None:
+                re, ke = geo.earth_radius_for_refraction(coords)
+                sin_u1, cos_u1, _ = geo.radar_site_constants(coords)
+                p.radar_lat, p.radar_lon, p.radar_alt = (float(coords[0]), float(coords[1]),
+                                                         float(coords[2]))
+                p.ke, p.re = ke, re
+                p.sin_u1, p.cos_u1 = sin_u1, cos_u1
+            else:
+                p.ke, p.re = 1.0, 0.0
+            p.range0 = range0
+            p.range_step = float(conf['radar']['radial_resolution'])
+            p.wavelength = float(self.constants.WAVELENGTH)
+            p.k_squared = float(conf['radar']['K_squared'])
+            p.radial_res = float(conf['radar']['radial_resolution'])
+            p.c_zh = float(self.constants.WAVELENGTH ** 4 / (np.pi ** 5 * conf['radar']['K_squared']))
+
+            thr = (self._cached(('sens', n_gates),
+                                lambda: geo.sensitivity_threshold(conf, self.constants, n_gates))
+                   if apply_sensitivity else None)
+            p.apply_sensitivity = int(thr is not None)
+            t = N.RayTables()
+            if paths is not None:
+                paths = np.ascontiguousarray(paths, dtype=np.float32)
+                if paths.shape != (n_rays, p.n_vnodes, 3, n_gates):
+                    raise ValueError('paths must have shape [n_rays, n_vnodes, 3, n_gates] = %s'
+                                     % ((n_rays, p.n_vnodes, 3, n_gates),))
+            if site is not None:
+                site = np.ascontiguousarray(site, dtype=np.float64)
+            keep = [traj, geo_t, sub.sub_h, sub.sub_v, sub.sub_w, thr, paths, site]
+            t.traj, t.geo = traj.ctypes.data, geo_t.ctypes.data
+            t.sub_h, t.sub_v, t.sub_w = sub.sub_h.ctypes.data, sub.sub_v.ctypes.data, sub.sub_w.ctypes.data
+            t.sens_thr = thr.ctypes.data if thr is not None else None
+            t.site = site.ctypes.data if site is not None else None
+            t.paths = paths.ctypes.data if paths is not None else None
+            nyq = None
+            if doppler and conf['radar']['nyquist_velocity'] is not None:
+                # Nyquist velocity of every ray from its nominal elevation / azimuth
+                # (doppler_scatter.py:431-437: the central sub-beam's angles)
+                nyq = np.ascontiguousarray(conf['radar']['nyquist_velocity'](el, az), dtype=np.float64)
+                keep.append(nyq)
+            t.nyquist = nyq.ctypes.data if nyq is not None else None
+            if varray is not None:
+                keep.append(varray)
+                t.varray = varray.ctypes.data
+            if sub.sub_smooth is not None:        # integration scheme 'ml': per-gate weights
+                t.sub_smooth = sub.sub_smooth.ctypes.data
+                t.ml_filter = sub.ml_filter.ctypes.data
+                t.ml_radius = int(sub.ml_radius)
+            t.version = version
+            return p, t, keep, doppler, spectrum, varray
+
+        # the structs of an unchanged set of rays are built once (a sweep repeated, the sweeps of a volume scanned
+        # again): ~25 us of attribute traffic per call otherwise, half of what a c2 sweep takes on the device
+        if version and paths is None and site is None:
+            p, t, keep, doppler, spectrum, varray = self._cached(
+                ('prepared', version, n_gates, range0, mode, bool(apply_sensitivity), want_model, device_outputs is not None),
+                prepare, lru=16)
+        else:
+            p, t, keep, doppler, spectrum, varray = prepare()
 
         o = N.Outputs()
         res = {}
