@@ -133,6 +133,12 @@ struct cpol_ctx {
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
     int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0, last_n_keys = 0;
+    // Two sets of sweep counters (b_count, b_totals), used in turn: the first kernel of a launch sequence clears
+    // the set of the NEXT sweep, so that a kernel which counts can also be the first of its sequence (a kernel cannot
+    // clear what its own workgroups add to), and no sequence needs a fill kernel.  Both sets are zero when (re)allocated.
+    uint64_t sweep_serial = 0;
+    long count_stride = 0;             // ints per set of b_count
+    int last_par = 0;                  // the set the last sweep used
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
     int fuse_classify = 1;             // CPOL_FUSE_CLASSIFY=0: k_interp_sweep + k_classify instead of k_interp_classify (read when the context is created)
@@ -1303,14 +1309,27 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_key, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_pos, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_par, (size_t)n_hyd * CPOL_MAX_PAR * n_sbg * sizeof(double));
-    ENSURE(ctx->b_count, (size_t)(n_keys + 3 + CPOL_COUNT_SLOTS) * sizeof(int));   // + [n_keys + 2]: items ranked, [n_keys + 3 ...): items on integral tables (count_table_items)
+    // per set: [n_keys] bucket counts, [n_keys + 2]: items ranked, [n_keys + 3 ...): items on integral tables (count_table_items)
+    const long cnt_stride = n_keys + 3 + CPOL_COUNT_SLOTS;
+    {
+        void *const was = ctx->b_count.p, *const was_t = ctx->b_totals.p;
+        ENSURE(ctx->b_count, (size_t)2 * cnt_stride * sizeof(int));
+        ENSURE(ctx->b_totals, 2 * 4 * sizeof(long long));
+        if (ctx->b_count.p != was || ctx->b_totals.p != was_t || ctx->count_stride != cnt_stride) {
+            HIPCHK(hipMemsetAsync(ctx->b_count.p, 0, (size_t)2 * cnt_stride * sizeof(int), ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->b_totals.p, 0, 2 * 4 * sizeof(long long), ctx->stream));
+            ctx->count_stride = cnt_stride;
+        }
+    }
+    const int par = (int)(ctx->sweep_serial & 1);        // (the serial advances once the sequence is queued)
+    int *const cnt_p = (int *)ctx->b_count.p + par * cnt_stride, *const cnt_next = (int *)ctx->b_count.p + (par ^ 1) * cnt_stride;
+    long long *const tot_p = (long long *)ctx->b_totals.p + par * 4, *const tot_next = (long long *)ctx->b_totals.p + (par ^ 1) * 4;
     ENSURE(ctx->b_blkranked, (size_t)cdiv(n_sbg, CPOL_CLASSIFY_THREADS) * sizeof(int));
     ENSURE(ctx->b_rec, (size_t)n_hyd * n_sbg * sizeof(double2));
     ENSURE(ctx->b_vmask, (size_t)n_sbg);
     ENSURE(ctx->b_offset, (size_t)2 * n_keys * sizeof(int));        // item and unit offsets
     // (work units: up to 64 / 128 sorted items each; declared here, sized below once the launch mode is known)
     long unit_cap = (long)n_hyd * n_sbg / 64 + n_keys + 64;
-    ENSURE(ctx->b_totals, 4 * sizeof(long long));
     ENSURE(ctx->b_perm, (size_t)n_hyd * n_sbg * sizeof(int));
     ENSURE(ctx->b_res, (size_t)n_hyd * n_sbg * CPOL_N_SZ * sizeof(double));
     const bool doppler = p->simulate_doppler != 0;
@@ -1403,9 +1422,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (want_szi) ENSURE(ctx->b_szinteg, (size_t)n_rg * n_hyd * CPOL_N_SZ * sizeof(float));
     const bool want_szt = out->sz_total != nullptr || ctx->keep_debug;
     const bool want_model = p->integrate_model && out->model_vars;
-    // >= 4 sub-beams, every slot on a table, no debug reads: the gate kernel classifies its gates itself
-    // (k_interp_classify, cpol_fused.inl); k_trajectory, which runs ahead of it, clears the counters
-    const bool fused = ctx->fuse_classify != 0 && rare_direct && !gate1 && ray_prep && !ml && !dop3 && !ctx->keep_debug;
+    // every slot on a table, no debug reads: the gate kernel classifies its gates itself (k_interp_classify,
+    // cpol_fused.inl)
+    const bool fused = ctx->fuse_classify != 0 && rare_direct && !gate1 && !ml && !dop3 && !ctx->keep_debug;
     void *const user_out[O_N] = {out->ZH, out->ZV, out->ZDR, out->KDP, out->DELTA_HV, out->PHIDP,
                                  out->RHOHV, out->ATT_H, out->ATT_V, out->mask, out->lats, out->lons,
                                  out->dist, out->heights, out->RVEL, out->model_vars, out->sz_total,
@@ -1490,10 +1509,6 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ta.geo = (const double *)ctx->v_geo;
         ta.ray_const = ray_prep ? (double *)ctx->b_rayc.p : nullptr;
         ta.n_h = n_h; ta.lon1 = p->radar_lon;
-        if (fused) {
-            ta.zero_buf = (int *)ctx->b_count.p; ta.zero_n = n_keys + 3 + CPOL_COUNT_SLOTS;
-            ta.zero_buf2 = (int *)ctx->b_totals.p; ta.zero_n2 = 8;
-        }
         hipLaunchKernelGGL(k_trajectory, dim3((unsigned)(n_rays * n_v), paths ? cdiv(ng, 256) : 1), dim3(256), 0, st, ta);
     }
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_TRAJ], st));
@@ -1507,9 +1522,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.rp.n_v = n_v; ia.rp.mode = mode;
     ia.rp.range0 = p->range0; ia.rp.range_step = p->range_step;
     ia.rp.ke = p->ke; ia.rp.re = p->re; ia.rp.alt = p->radar_alt;
-    ia.zero_buf = (int *)ctx->b_count.p;
-    ia.zero_n = n_keys + 3 + CPOL_COUNT_SLOTS;
-    ia.zero_buf2 = rare_direct ? (int *)ctx->b_totals.p : nullptr;     // (4 long long: k_classify / k_gate1 count the items outside the tables into them)
+    ia.zero_buf = cnt_next;
+    ia.zero_n = (int)cnt_stride;
+    ia.zero_buf2 = (int *)tot_next;     // (4 long long: k_classify / k_gate1 count the items outside the tables into them)
     ia.zero_n2 = 8;
     ia.geo = (const double *)ctx->v_geo;
     ia.sub_h = (const int *)ctx->v_subh;
@@ -1608,7 +1623,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ca.key = (int *)ctx->b_key.p;
     ca.pos = (int *)ctx->b_pos.p;
     ca.par = (double *)ctx->b_par.p;
-    ca.count = (int *)ctx->b_count.p;
+    ca.count = cnt_p;
     ca.n_sbg = n_sbg;
     ca.with_melting = p->with_melting;
     ca.var_qr = ca.var_qs = ca.var_qg = -1;
@@ -1617,7 +1632,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ca.tfun_ice = ctx->tfun[CPOL_TFUN_ICE_MOM2_A];
     // integral tables: not with Doppler scheme 3 + ice (k_spec_gate needs every item's parameters as
     // the integrating kernels leave them; the lookup writes the same slots, so it is fine) -- always on
-    ca.n_lookup = (int *)ctx->b_count.p + n_keys + 1;
+    ca.n_lookup = cnt_p + n_keys + 1;
     ca.blk_ranked = (int *)ctx->b_blkranked.p;
     ca.rec = (double2 *)ctx->b_rec.p;
     ca.vmask = (unsigned char *)ctx->b_vmask.p;
@@ -1626,7 +1641,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (rare_direct) {
         ca.rare_key = (int *)ctx->b_pos.p;
         ca.rare_perm = (int *)ctx->b_perm.p;
-        ca.rare_totals = (unsigned long long *)ctx->b_totals.p;
+        ca.rare_totals = (unsigned long long *)tot_p;
     }
     for (int j = 0; j < n_hyd; ++j) {
         const cpol_hydro_desc &d = ctx->hs.h[j].d;
@@ -1654,7 +1669,6 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     }
     if (fused) {
         // the variables later kernels read: U, V, W (k_rvel_terms); all of them for the integrated model variables
-        ia.zero_buf = nullptr; ia.zero_buf2 = nullptr;
         ia.store_mask = want_model ? 0xffffffffu : 0u;
         if (doppler) ia.store_mask |= (1u << p->var_u) | (1u << p->var_v) | (1u << p->var_w);
         hipLaunchKernelGGL(k_interp_classify, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256),
@@ -1668,7 +1682,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ga.defer = (unsigned char *)ctx->b_defer.p;
         ga.unit_key = (int *)ctx->b_pos.p;
         ga.perm = (int *)ctx->b_perm.p;
-        ga.totals = (unsigned long long *)ctx->b_totals.p;
+        ga.totals = (unsigned long long *)tot_p;
         ga.res = (double *)ctx->b_res.p;
         ga.store_items = any_vsrc2 ? 1 : 0;
         ga.analytic_vn = ca.vn ? 1 : 0;
@@ -1686,11 +1700,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
 
     // ---- 4. counting sort by LUT slice ----
     ScanArgs sa{};
-    sa.count = (const int *)ctx->b_count.p;
+    sa.count = cnt_p;
     sa.offset = (int *)ctx->b_offset.p;
     sa.uoffset = (int *)ctx->b_offset.p + n_keys;
     sa.units = (WorkUnit *)ctx->b_units.p;
-    sa.totals = (long long *)ctx->b_totals.p;
+    sa.totals = tot_p;
     sa.n_keys = n_keys;
     sa.n_hydro = n_hyd;
     for (int j = 0; j < n_hyd; ++j) {
@@ -1756,7 +1770,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         PsdArgs pa{};
         pa.unit_key = rare_direct ? (const int *)ctx->b_pos.p : nullptr;
         pa.units = (const WorkUnit *)ctx->b_units.p;
-        pa.totals = (const long long *)ctx->b_totals.p;
+        pa.totals = tot_p;
         pa.perm = (const int *)ctx->b_perm.p;
         pa.par = (const double *)ctx->b_par.p;
         pa.res = (double *)ctx->b_res.p;
@@ -2004,8 +2018,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         mix(T, sizeof T);
         mix(&ctx->stage_serial, sizeof ctx->stage_serial);
         void *arena[] = {ctx->b_traj.p, ctx->b_vals.p, ctx->b_mask.p, ctx->b_elev.p, ctx->b_qmelt.p,
-                         ctx->b_fwmelt.p, ctx->b_key.p, ctx->b_pos.p, ctx->b_par.p, ctx->b_count.p,
-                         ctx->b_offset.p, ctx->b_units.p, ctx->b_totals.p, ctx->b_perm.p,
+                         ctx->b_fwmelt.p, ctx->b_key.p, ctx->b_pos.p, ctx->b_par.p, (void *)cnt_p,
+                         ctx->b_offset.p, ctx->b_units.p, (void *)tot_p, ctx->b_perm.p,
                          ctx->b_res.p, ctx->b_vn.p, ctx->b_icefirst.p, ctx->b_wgate.p, ctx->b_blkranked.p, ctx->b_rec.p,
                          ctx->b_vmask.p, ctx->b_rayc.p, ctx->v_traj_in, ctx->v_geo, ctx->v_subh,
                          ctx->v_subv, ctx->v_subw, ctx->v_sens, ctx->v_site, ctx->v_nyq,
@@ -2045,6 +2059,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
 
     ctx->last_n_sbg = n_sbg; ctx->last_n_rg = n_rg; ctx->last_n_rays = n_rays;
     ctx->last_n_gates = ng; ctx->last_n_sub = n_sub; ctx->last_n_v = n_v;
+    ctx->last_par = par;
+    ++ctx->sweep_serial;
     ctx->last_n_keys = n_keys; ctx->last_subsum = subsum || final_inplace;
     ctx->counters.n_subbeam_gates = n_sbg;
     ctx->counters.n_gates = n_rg;
@@ -2094,11 +2110,11 @@ int cpol_counters(cpol_ctx *ctx, cpol_counters_t *out)
         // device-side totals of the LAST sweep (valid once the stream drained)
         HIPCHK(hipStreamSynchronize(ctx->stream));
         long long totals[2] = {0, 0};
-        HIPCHK(hipMemcpy(totals, ctx->b_totals.p, sizeof totals, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(totals, (const long long *)ctx->b_totals.p + ctx->last_par * 4, sizeof totals, hipMemcpyDeviceToHost));
         long long n_lookup = 0;
         {
             std::vector<int> slots(CPOL_COUNT_SLOTS);       // the kernels count into one of many words (count_table_items)
-            HIPCHK(hipMemcpy(slots.data(), (const int *)ctx->b_count.p + ctx->last_n_keys + 3, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(slots.data(), (const int *)ctx->b_count.p + ctx->last_par * ctx->count_stride + ctx->last_n_keys + 3, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
             for (int v : slots) n_lookup += v;
         }
         ctx->counters.n_table_items = n_lookup;
@@ -2248,7 +2264,7 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     else if (!strcmp(name, "sz_total")) { src = ctx->b_sztotal.p; bytes = (int64_t)n_rg * CPOL_N_SZ * 4; }
     else if (!strcmp(name, "traj")) { src = ctx->b_traj.p; bytes = (int64_t)ctx->last_n_rays * ctx->last_n_v * 3 * ctx->last_n_gates * 4; }
     else if (!strcmp(name, "psd_clock")) { src = ctx->b_clk.p; bytes = 2048 * 4 * 8; }
-    else if (!strcmp(name, "bucket_count")) { src = ctx->b_count.p; bytes = (int64_t)ctx->last_n_keys * 4; }
+    else if (!strcmp(name, "bucket_count")) { src = (const int *)ctx->b_count.p + ctx->last_par * ctx->count_stride; bytes = (int64_t)ctx->last_n_keys * 4; }
     else { ctx->err = std::string("cpol_debug_read: unknown buffer ") + name; return CPOL_ERR_ARG; }
     if (!src) { ctx->err = "cpol_debug_read: buffer not kept (call with name \"enable\" first)"; return CPOL_ERR_ARG; }
     if (bytes > max_bytes) { ctx->err = "cpol_debug_read: destination too small"; return CPOL_ERR_ARG; }

@@ -1,5 +1,6 @@
 // k_interp_classify: the gate kernel and the classification of the gate's hydrometeors in ONE pass -- the
-// launch sequences with >= 4 sub-beams per radial whose slots all have integral tables (the C4 volume).
+// launch sequences whose slots all have integral tables (the C3 and C4 volumes; the single-beam sequence without melting
+// species has its own fused kernel, k_gate1).
 //
 // k_interp_sweep leaves n_vars float32 per sub-beam gate in vals[] and k_classify reads temperature, mass
 // densities and elevation back: 4.8 + 7.1 GB on the C4 volume, and two kernels that each wait -- the first for its
@@ -9,8 +10,8 @@
 // there, and only what later kernels read goes to vals[] (a.store_mask: U, V, W for the Doppler terms; everything
 // when the integrated model variables are asked for).  Same device functions as the two kernels -- interp_gate<>,
 // classify_item -- on the same values: identical results (tests/test_gpu_fullsize.py compares the sequences).
-// The counters the classification adds to are cleared by k_trajectory, the kernel before this one (a kernel
-// cannot clear what its own workgroups count into).  Not with the debug reads, integration scheme 'ml'
+// The counters the classification adds to were cleared by the sweep before this one (two sets used in turn: a
+// kernel cannot clear what its own workgroups count into).  Not with the debug reads, integration scheme 'ml'
 // (k_ml_weights runs between the two kernels) or Doppler scheme 3 (the spectrum kernels read vals[]).
 #ifndef CPOL_FUSED_WPE
 #define CPOL_FUSED_WPE 5          // measured on the C4 volume: 3 / 4 (the allocator's choice) / 5 / 6 wavefronts per SIMD: 4.31 / 3.51 / 3.34 / 4.34 ms
@@ -24,6 +25,7 @@ __global__ __launch_bounds__(256) CPOL_FUSED_ATTR void k_interp_classify(ModelDe
                                                                         ClassifyArgs a)
 {
     extern __shared__ float s_vals[];                 // [n_vars][blockDim.x]
+    clear_counters(ia.zero_buf, ia.zero_n, ia.zero_buf2, ia.zero_n2);      // (the NEXT sweep's set)
     float *sv = s_vals + threadIdx.x;
     const long ls = blockDim.x;
     long sbg = 0;

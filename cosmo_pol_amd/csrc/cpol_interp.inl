@@ -47,10 +47,6 @@ struct TrajArgs {
     double *ray_const;          // [n_rays * n_h][2] sin / cos (2 sigma1), then [n_rays][2] sin / cos (site longitude)
     int n_h;
     double lon1;
-    int *zero_buf;              // the sweep's counters when the sweep kernel itself counts into them (k_interp_classify) or NULL
-    int zero_n;
-    int *zero_buf2;
-    int zero_n2;
 };
 
 // height of candidate gate k of a downward-looking (spaceborne) ray
@@ -112,7 +108,7 @@ __device__ __forceinline__ void ray_path(const RayPathArgs &a, int ray, int rv, 
     e32 = (float)e * rad2deg_f;
 }
 
-// the counters of a sweep start at zero: cleared by the first kernel of the launch sequence
+// the counters of a sweep start at zero: the gate kernel of the sweep BEFORE it cleared them (two sets used in turn)
 __device__ __forceinline__ void clear_counters(int *zero_buf, int zero_n, int *zero_buf2, int zero_n2)
 {
     if (!zero_buf) return;
@@ -134,7 +130,6 @@ __global__ __launch_bounds__(256) void k_trajectory(TrajArgs a)
 {
     int g = blockIdx.y * blockDim.x + threadIdx.x;
     int rv = blockIdx.x;                       // ray * n_v + vnode
-    clear_counters(a.zero_buf, a.zero_n, a.zero_buf2, a.zero_n2);
     if (a.ray_const && blockIdx.y == 0) {
         const long n_geo = (long)a.n_rays * a.n_h;
         for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_geo + a.n_rays;
@@ -371,7 +366,7 @@ struct InterpArgs {
                                 // k_trajectory's (sub-beams sharing a vertical node); NULL: ray_path() in place
     const double *ray_const;    // k_trajectory's per-ray constants or NULL: evaluated per gate
     RayPathArgs rp;
-    int *zero_buf;              // the sweep's bucket counters, cleared here (no fill kernel)
+    int *zero_buf;              // the NEXT sweep's bucket counters, cleared here (no fill kernel)
     int zero_n;
     int *zero_buf2;             // ... and the work-unit totals of the single-beam fast path (k_gate1 counts into them) or NULL
     int zero_n2;
