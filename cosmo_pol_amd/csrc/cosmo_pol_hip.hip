@@ -141,6 +141,7 @@ struct cpol_ctx {
     int last_par = 0;                  // the set the last sweep used
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
+    int fuse_gate1 = 0;                // CPOL_FUSE_GATE1=1: k_interp_gate1 instead of k_interp_sweep + k_gate1 (measured slower where it matters)
     int fuse_classify = 1;             // CPOL_FUSE_CLASSIFY=0: k_interp_sweep + k_classify instead of k_interp_classify (read when the context is created)
     int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
     int subsum_scalar = 0;             // CPOL_SUBSUM_FORM=scalar: the cooperative form of k_subbeam_sum takes its rows through the scalar cache instead of LDS
@@ -568,6 +569,7 @@ int cpol_create(int device, cpol_ctx **out)
     // CPOL_SUBSUM_COOP=0 / 1: k_subbeam_sum never / always takes the coefficient rows through the scalar cache
     // (default: by launch size; the results are identical)
     if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
+    if (getenv("CPOL_FUSE_GATE1")) ctx->fuse_gate1 = atoi(getenv("CPOL_FUSE_GATE1")) != 0 ? 1 : 0;
     if (getenv("CPOL_FUSE_CLASSIFY")) ctx->fuse_classify = atoi(getenv("CPOL_FUSE_CLASSIFY")) != 0 ? 1 : 0;
     if (getenv("CPOL_RARE_DIRECT")) ctx->rare_direct = atoi(getenv("CPOL_RARE_DIRECT")) != 0 ? 1 : 0;
     if (getenv("CPOL_GATE1")) ctx->gate1 = atoi(getenv("CPOL_GATE1"));
@@ -676,6 +678,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->subsum_scalar = parent->subsum_scalar;
     c->rare_direct = parent->rare_direct;
     c->fuse_classify = parent->fuse_classify;
+    c->fuse_gate1 = parent->fuse_gate1;
     c->gate1 = parent->gate1;
     c->subsum_coop_rounds = parent->subsum_coop_rounds;
     c->parent = parent;
@@ -1425,6 +1428,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // every slot on a table, no debug reads: the gate kernel classifies its gates itself (k_interp_classify,
     // cpol_fused.inl)
     const bool fused = ctx->fuse_classify != 0 && rare_direct && !gate1 && !ml && !dop3 && !ctx->keep_debug;
+    // k_interp_gate1 (CPOL_FUSE_GATE1=1, not the default): the single-beam kernel interpolates its gates too.  Measured: the
+    // isolated C2 sweep 95.4 -> 88.6 us (one lane back to back: 70 -> 62 us per sweep), but with three lanes in flight 42.2 ->
+    // 44.8 us per sweep, and the Ku swath of config 5 (9 800 rays) 0.93 -> 1.18 ms: at the 3 wavefronts per SIMD k_gate1 needs,
+    // the interpolation -- VALU-bound at 5 -- loses more than the saved launch and the 14 MB of vals[] give back.
+    const bool fused_gate1 = ctx->fuse_gate1 != 0 && gate1;
     void *const user_out[O_N] = {out->ZH, out->ZV, out->ZDR, out->KDP, out->DELTA_HV, out->PHIDP,
                                  out->RHOHV, out->ATT_H, out->ATT_V, out->mask, out->lats, out->lons,
                                  out->dist, out->heights, out->RVEL, out->model_vars, out->sz_total,
@@ -1542,10 +1550,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.central_sub = n_sub / 2;
     ia.sin_u1 = p->sin_u1; ia.cos_u1 = p->cos_u1; ia.lon1 = p->radar_lon;
     ia.site = t->site ? (const double *)ctx->v_site : nullptr;
-    if (!fused)
+    if (!fused && !fused_gate1)
     hipLaunchKernelGGL(k_interp_sweep, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256), 0, st,
                        ctx->model, ia);
-    if (tm && !fused) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
+    if (tm && !fused && !fused_gate1) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
 
     // ---- 2b. the arguments of the final stage (k_gate1, the single-beam fast path, needs them already) ----
     FinalArgs fa{};
@@ -1667,10 +1675,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         hipLaunchKernelGGL(k_ml_weights, dim3(n_rays * n_sub), dim3(64), 0, st, ma);
         ca.wgate = (const double *)ctx->b_wgate.p;
     }
+    // the variables later kernels read: U, V, W (the Doppler terms); all of them for the integrated model variables
+    ia.store_mask = want_model ? 0xffffffffu : 0u;
+    if (doppler) ia.store_mask |= (1u << p->var_u) | (1u << p->var_v) | (1u << p->var_w);
     if (fused) {
-        // the variables later kernels read: U, V, W (k_rvel_terms); all of them for the integrated model variables
-        ia.store_mask = want_model ? 0xffffffffu : 0u;
-        if (doppler) ia.store_mask |= (1u << p->var_u) | (1u << p->var_v) | (1u << p->var_w);
         hipLaunchKernelGGL(k_interp_classify, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256),
                            (size_t)n_vars * 256 * sizeof(float), st, ctx->model, ia, ctx->hs, ctx->its, ca);
         if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
@@ -1689,10 +1697,17 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         if (doppler) ca.vn = (double *)ctx->b_vn.p;        // (also the table-borne sums of a species summed over the ray)
         bool melt_tab = false;
         for (int j = 0; j < n_hyd; ++j) melt_tab = melt_tab || ctx->its.t[j].two_d;
-        if (melt_tab) hipLaunchKernelGGL((k_gate1<true>), dim3(cdiv(n_rg, CPOL_GATE1_THREADS)), dim3(CPOL_GATE1_THREADS), 0, st,
+        const dim3 ggrid((unsigned)n_rays, cdiv(ng, CPOL_GATE1_THREADS));
+        const size_t glds = (size_t)n_vars * CPOL_GATE1_THREADS * sizeof(float);
+        if (fused_gate1 && melt_tab) hipLaunchKernelGGL((k_interp_gate1<true>), ggrid, dim3(CPOL_GATE1_THREADS), glds, st,
+                                                        ctx->model, ia, ctx->hs, ctx->its, ca, fa, ga);
+        else if (fused_gate1) hipLaunchKernelGGL((k_interp_gate1<false>), ggrid, dim3(CPOL_GATE1_THREADS), glds, st,
+                                                 ctx->model, ia, ctx->hs, ctx->its, ca, fa, ga);
+        else if (melt_tab) hipLaunchKernelGGL((k_gate1<true>), dim3(cdiv(n_rg, CPOL_GATE1_THREADS)), dim3(CPOL_GATE1_THREADS), 0, st,
                                          ctx->hs, ctx->its, ca, fa, ga);
         else hipLaunchKernelGGL((k_gate1<false>), dim3(cdiv(n_rg, CPOL_GATE1_THREADS)), dim3(CPOL_GATE1_THREADS), 0, st,
                                 ctx->hs, ctx->its, ca, fa, ga);
+        if (tm && fused_gate1) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
     } else
     hipLaunchKernelGGL(k_classify, dim3(cdiv(n_sbg, CPOL_CLASSIFY_THREADS)),
                        dim3(CPOL_CLASSIFY_THREADS), 0, st, ctx->hs, ctx->its, ca);

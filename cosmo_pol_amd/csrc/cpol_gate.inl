@@ -64,18 +64,34 @@ __device__ __forceinline__ void gate1_store_item(const ClassifyArgs &a, const It
 #endif
 // TWO_D: a melting species is present (CPOL_GATE1=2): the 2-D walk, its 21 row registers per lane and the 28 KB of LDS that
 // bring its results to their lanes are compiled into that instantiation only
-template <bool TWO_D>
-__global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(HydroSet hs, ItabSet its, ClassifyArgs a, FinalArgs f, GateArgs g)
+// INTERP (k_interp_gate1): the gate is interpolated here as well -- grid and thread mapping of k_interp_sweep, the
+// variables of the gate in the thread's column of the workgroup's LDS array instead of vals[] (as in
+// k_interp_classify, cpol_fused.inl): the whole sweep is this kernel and the range scans of k_final.
+template <bool TWO_D, bool INTERP>
+__device__ __forceinline__ void gate1_body(const ModelDev &m, const InterpArgs &ia, float *sv, const HydroSet &hs, const ItabSet &its,
+                                           const ClassifyArgs &a, const FinalArgs &f, const GateArgs &g)
 {
     constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
     __shared__ double s_walk[TWO_D ? CPOL_GATE1_THREADS / CPOL_WAVE : 1][TWO_D ? CPOL_WAVE : 1][CPOL_N_SZ + 2];   // 2-D walk: item -> its lane
     __shared__ int s_lookup;
     if (threadIdx.x == 0) s_lookup = 0;
     __syncthreads();
-    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i0 < a.n_sbg;
+    long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool in = i0 < a.n_sbg;
+    float e_interp = 0.f;
+    if (INTERP) {
+        long sbg = 0;
+        const int status = interp_gate<true>(m, ia, sv, sbg, e_interp);
+        in = status != 3;
+        i0 = sbg;
+        if (in && status != 0)                       // (no model values here: NaN, as k_interp_sweep leaves them in vals[])
+            for (int v = 0; v < m.n_vars; ++v) sv[v * blockDim.x] = __builtin_nanf("");
+    }
     const long n = a.n_sbg;
     const long i = in ? i0 : 0;
+    // the model variables of the gate: vals[var * vn + vi]
+    float *const vals = INTERP ? sv : a.vals;
+    const long vn = INTERP ? (long)blockDim.x : n, vi = INTERP ? 0 : i;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int ray = (int)(i / f.n_gates), gate = (int)(i % f.n_gates);
     int my_lookup = 0;
@@ -84,24 +100,27 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(Hy
     float qms = 0.f, qmg = 0.f;
     double fws = 0.0, fwg = 0.0;
     if (a.with_melting && in) {
-        float qr = a.vals[a.var_qr * n + i], qs = a.vals[a.var_qs * n + i], qg = a.vals[a.var_qg * n + i];
+        float qr = vals[a.var_qr * vn + vi], qs = vals[a.var_qs * vn + vi], qg = vals[a.var_qg * vn + vi];
         float qsg = qs + qg;
         if (qr > 0.f && qsg > 0.f) {
             qms = qs + qr * (qs / qsg);
             qmg = qg + qr * (qg / qsg);
             if (qms > 0.f || qmg > 0.f) {
-                a.vals[a.var_qr * n + i] = 0.f;
-                a.vals[a.var_qs * n + i] = 0.f;
-                a.vals[a.var_qg * n + i] = 0.f;
+                vals[a.var_qr * vn + vi] = 0.f;
+                vals[a.var_qs * vn + vi] = 0.f;
+                vals[a.var_qg * vn + vi] = 0.f;
             }
             fws = (double)(qr * qs / qsg) / (double)qms;
             fwg = (double)(qr * qg / qsg) / (double)qmg;
         }
     }
-    const float e = in ? a.elev[i] : 0.f;
+    if (INTERP && in)                                // what later kernels (and gate_finish below) read of the gate
+        for (int v = 0; v < m.n_vars; ++v)
+            if ((ia.store_mask >> v) & 1u) ia.vals[(long)v * n + i] = sv[v * blockDim.x];
+    const float e = !in ? 0.f : INTERP ? e_interp : a.elev[i];
     const int var_t0 = hs.h[0].d.var_t;
-    const float T0 = in ? a.vals[var_t0 * n + i] : 0.f;
-    float q_ahead = (in && hs.h[0].d.q_source == CPOL_Q_MODEL) ? a.vals[hs.h[0].d.var_q * n + i] : 0.f;
+    const float T0 = in ? vals[var_t0 * vn + vi] : 0.f;
+    float q_ahead = (in && hs.h[0].d.q_source == CPOL_Q_MODEL) ? vals[hs.h[0].d.var_q * vn + vi] : 0.f;
 
     float tot[CPOL_N_SZ];
 #pragma unroll
@@ -123,10 +142,10 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(Hy
             else { qm = qmg; fw = fwg; }
         }
         if (in && j + 1 < hs.n_hydro && hs.h[j + 1].d.q_source == CPOL_Q_MODEL)
-            q_ahead = a.vals[hs.h[j + 1].d.var_q * n + i];
+            q_ahead = vals[hs.h[j + 1].d.var_q * vn + vi];
         const ItabDev &t = its.t[j];
         ClassItem it;
-        classify_item(h, t, a, a.vals, n, i, i, in, qm, fw, T0, var_t0, e, it);
+        classify_item(h, t, a, vals, vn, vi, i, in, qm, fw, T0, var_t0, e, it);
         const bool want_vn = want_rvel && t.writes_vn;                      // uniform: the table carries the Doppler sums
         double2 v[CPOL_N_SZ / 2];
 #pragma unroll
@@ -244,7 +263,7 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(Hy
 
     // ---- items of a deferred gate, stored for final_gate (rare: second pass over the species) ----
     if (__ballot(deferred && !g.store_items)) {
-        float q2 = (in && hs.h[0].d.q_source == CPOL_Q_MODEL) ? a.vals[hs.h[0].d.var_q * n + i] : 0.f;
+        float q2 = (in && hs.h[0].d.q_source == CPOL_Q_MODEL) ? vals[hs.h[0].d.var_q * vn + vi] : 0.f;
         for (int j = 0; j < hs.n_hydro; ++j) {
             const HydroDev &h = hs.h[j];
             const cpol_hydro_desc &d = h.d;
@@ -256,9 +275,9 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(Hy
                 else { qm = qmg; fw = fwg; }
             }
             if (in && j + 1 < hs.n_hydro && hs.h[j + 1].d.q_source == CPOL_Q_MODEL)
-                q2 = a.vals[hs.h[j + 1].d.var_q * n + i];
+                q2 = vals[hs.h[j + 1].d.var_q * vn + vi];
             ClassItem it;
-            classify_item(h, its.t[j], a, a.vals, n, i, i, in && deferred, qm, fw, T0, var_t0, e, it);
+            classify_item(h, its.t[j], a, vals, vn, vi, i, in && deferred, qm, fw, T0, var_t0, e, it);
             if (deferred) {
                 gate1_store_item(a, its.t[j], j, n, i, it, g.analytic_vn != 0);
                 // (the Doppler sums of a table item of this gate: evaluated once more from its block)
@@ -295,4 +314,20 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(Hy
     g.sk[i] = k2;
     g.sh[i] = fh;
     g.sv[i] = fv;
+}
+
+template <bool TWO_D>
+__global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_gate1(HydroSet hs, ItabSet its, ClassifyArgs a, FinalArgs f, GateArgs g)
+{
+    gate1_body<TWO_D, false>(ModelDev{}, InterpArgs{}, nullptr, hs, its, a, f, g);
+}
+
+// grid = (n_rays, ceil(n_gates / 256)), dynamic LDS = n_vars * 256 floats (the mapping of k_interp_sweep with one sub-beam)
+template <bool TWO_D>
+__global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_interp_gate1(ModelDev m, InterpArgs ia, HydroSet hs, ItabSet its,
+                                                                                    ClassifyArgs a, FinalArgs f, GateArgs g)
+{
+    extern __shared__ float s_vals[];                 // [n_vars][blockDim.x]
+    clear_counters(ia.zero_buf, ia.zero_n, ia.zero_buf2, ia.zero_n2);      // (the NEXT sweep's set)
+    gate1_body<TWO_D, true>(m, ia, s_vals + threadIdx.x, hs, its, a, f, g);
 }

@@ -112,7 +112,8 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
     panel): such items go to the integrating kernels.  Three launch sequences must give the same bits:
     the general one with the counting sort (CPOL_RARE_DIRECT=0, CPOL_GATE1=0), the general one with the items
     listed directly as one-item work units (CPOL_GATE1=0) and the single-beam fused kernel, which defers the
-    gates that hold such an item to k_final -- with one and with nine sub-beams, hundreds of items each."""
+    gates that hold such an item to k_final -- with one and with nine sub-beams, hundreds of items each.  Also the
+    two-kernel form of the direct listing (CPOL_FUSE_CLASSIFY=0) and the opt-in k_interp_gate1 (CPOL_FUSE_GATE1=1)."""
     import bench
     from cosmo_pol_amd import RadarOperator, synthetic
     hyds = ('R', 'S', 'G')
@@ -131,8 +132,10 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
     for n_gh in (1, 3):
         conf = bench.bench_config(True)
         conf['integration'].update(nh_GH=n_gh, nv_GH=n_gh)
-        for mode, env in (('sorted', {'CPOL_RARE_DIRECT': '0', 'CPOL_GATE1': '0'}), ('direct', {'CPOL_GATE1': '0'}), ('default', {})):
-            for k in ('CPOL_RARE_DIRECT', 'CPOL_GATE1'):
+        for mode, env in (('sorted', {'CPOL_RARE_DIRECT': '0', 'CPOL_GATE1': '0'}), ('direct', {'CPOL_GATE1': '0'}), ('default', {}),
+                          ('direct_two_kernels', {'CPOL_GATE1': '0', 'CPOL_FUSE_CLASSIFY': '0'}),     # k_interp_sweep + k_classify
+                          ('interp_gate1', {'CPOL_FUSE_GATE1': '1'})):                                 # k_interp_gate1 (opt-in)
+            for k in ('CPOL_RARE_DIRECT', 'CPOL_GATE1', 'CPOL_FUSE_CLASSIFY', 'CPOL_FUSE_GATE1'):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)                    # (read when the context is created)
@@ -146,7 +149,7 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
             results[(n_gh, mode)] = (res, n_off)
             op.close()
         ref, n_ref = results[(n_gh, 'sorted')]
-        for mode in ('direct', 'default'):
+        for mode in ('direct', 'default', 'direct_two_kernels', 'interp_gate1'):
             got, n_got = results[(n_gh, mode)]
             assert n_got == n_ref
             for k in ('ZH', 'ZV', 'ZDR', 'KDP', 'RHOHV', 'PHIDP', 'DELTA_HV', 'ATT_H', 'ATT_V', 'RVEL', 'mask'):
@@ -166,8 +169,9 @@ def test_fused_kernel_with_melting_species_equals_the_general_sequence(monkeypat
     luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
     az = np.arange(0.0, 360.0, 7.5)
     out = {}
-    for mode in ('0', '2'):
-        monkeypatch.setenv('CPOL_GATE1', mode)                  # (read when the context is created)
+    for mode in ('0', '2', '2+interp'):
+        monkeypatch.setenv('CPOL_GATE1', mode[0])               # (read when the context is created)
+        monkeypatch.setenv('CPOL_FUSE_GATE1', '1' if mode == '2+interp' else '0')      # k_interp_gate1<true>
         op = RadarOperator(config=conf, luts=luts, output_variables='all')
         op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
         out[mode] = op.simulate_rays(az, np.full(len(az), 3.0))
@@ -177,4 +181,5 @@ def test_fused_kernel_with_melting_species_equals_the_general_sequence(monkeypat
     for k, v in out['0'].items():
         if isinstance(v, np.ndarray):
             assert np.array_equal(out['2'][k], v, equal_nan=True), k
+            assert np.array_equal(out['2+interp'][k], v, equal_nan=True), k
     assert np.isfinite(out['0']['RVEL']).sum() > 1000 and np.isfinite(out['0']['ZH']).sum() > 1000
