@@ -124,7 +124,8 @@ def load_profile_summary(workload):
 
 
 # stage of the launch sequence (cpol_counters_t.ms_*) -> its kernels in the rocprofv3 summaries
-STAGE_KERNELS = {'interp': ('k_interp_sweep', 'k_trajectory'), 'classify': ('k_classify', 'k_ml_weights', 'k_gate1'),
+STAGE_KERNELS = {'interp': ('k_interp_sweep', 'k_interp_classify', 'k_interp_gate1', 'k_trajectory'),   # (k_interp_classify: the gate kernel that also classifies)
+                 'classify': ('k_classify', 'k_ml_weights', 'k_gate1'),
                  'bucket': ('k_bucket_scan', 'k_bucket_scatter'),
                  'psd': ('k_psd_lookup', 'k_subbeam_sum'),     # (+ the integrating kernels: empty launches in a sweep)
                  'final': ('k_final', 'k_rvel_terms', 'k_ice_first')}
