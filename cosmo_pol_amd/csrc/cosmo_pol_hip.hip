@@ -141,6 +141,7 @@ struct cpol_ctx {
     int last_par = 0;                  // the set the last sweep used
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
+    int lookup_split = 0;              // CPOL_LOOKUP_SPLIT=<n>: wavefronts per tile of k_psd_lookup (0: by launch size)
     int fuse_gate1 = 0;                // CPOL_FUSE_GATE1=1: k_interp_gate1 instead of k_interp_sweep + k_gate1 (measured slower where it matters)
     int fuse_classify = 1;             // CPOL_FUSE_CLASSIFY=0: k_interp_sweep + k_classify instead of k_interp_classify (read when the context is created)
     int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
@@ -569,6 +570,7 @@ int cpol_create(int device, cpol_ctx **out)
     // CPOL_SUBSUM_COOP=0 / 1: k_subbeam_sum never / always takes the coefficient rows through the scalar cache
     // (default: by launch size; the results are identical)
     if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
+    if (getenv("CPOL_LOOKUP_SPLIT")) ctx->lookup_split = std::max(0, std::min(16, atoi(getenv("CPOL_LOOKUP_SPLIT"))));
     if (getenv("CPOL_FUSE_GATE1")) ctx->fuse_gate1 = atoi(getenv("CPOL_FUSE_GATE1")) != 0 ? 1 : 0;
     if (getenv("CPOL_FUSE_CLASSIFY")) ctx->fuse_classify = atoi(getenv("CPOL_FUSE_CLASSIFY")) != 0 ? 1 : 0;
     if (getenv("CPOL_RARE_DIRECT")) ctx->rare_direct = atoi(getenv("CPOL_RARE_DIRECT")) != 0 ? 1 : 0;
@@ -679,6 +681,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->rare_direct = parent->rare_direct;
     c->fuse_classify = parent->fuse_classify;
     c->fuse_gate1 = parent->fuse_gate1;
+    c->lookup_split = parent->lookup_split;
     c->gate1 = parent->gate1;
     c->subsum_coop_rounds = parent->subsum_coop_rounds;
     c->parent = parent;
@@ -1774,8 +1777,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             la.tile = (two_d && tile_env && n_rays >= TILE_RAYS) ? 1 : 0;
             la.n_rays = n_rays; la.n_sub = n_sub; la.n_gates = ng;
             const long n_thr = la.tile ? (long)cdiv(n_rays, TILE_RAYS) * n_sub * cdiv(ng, TILE_GATES) * 64 : n_sbg;
+            // few wavefronts (a single sweep with one sub-beam): the walk of the busiest tile is the kernel's duration;
+            // its distinct blocks and species are dealt to `split` wavefronts (CPOL_LOOKUP_SPLIT=<n>; default by launch size)
+            const long lookup_waves_per_simd = n_thr / 64 / 1024;
+            la.split = ctx->lookup_split > 0 ? ctx->lookup_split : (la.tile && lookup_waves_per_simd < 16) ? 4 : 1;
             if (launch && !gate1)
-            hipLaunchKernelGGL(k_psd_lookup, dim3(cdiv(n_thr, CPOL_LOOKUP_THREADS)), dim3(CPOL_LOOKUP_THREADS), 0, st, ctx->hs, ctx->its, la);
+            hipLaunchKernelGGL(k_psd_lookup, dim3(cdiv(n_thr, CPOL_LOOKUP_THREADS), la.split), dim3(CPOL_LOOKUP_THREADS), 0, st, ctx->hs, ctx->its, la);
         }
     }
 

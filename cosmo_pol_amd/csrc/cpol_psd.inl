@@ -1904,6 +1904,7 @@ struct LookupArgs {
     double *vn;                 // [n_hydro][n_sbg][2] or NULL
     long n_sbg;
     int tile;                   // lanes of a wavefront = 16 neighbouring rays x 4 gates of one sub-beam index
+    int split;                  // wavefronts per tile (gridDim.y) sharing the distinct 2-D blocks and the 1-D species of the tile (1: large launches)
     int n_rays, n_sub, n_gates; // (melting species: neighbouring rays share the (slice, panel) block, gates do not)
     int vn_1d;                  // with skip_res_1d: the Doppler sums of the 1-D species are still written here (k_final
                                 // evaluates the columns in place but reads vn[]; k_subbeam_sum writes them itself)
@@ -2062,13 +2063,24 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, CPOL_LOOKUP_WPE) void k_psd_lo
             // the wavefront walks over the DISTINCT blocks of its items (16 neighbouring rays x 4
             // gates: ~6): the rows of a block are fetched once (21 values per lane) and serve
             // every item of the wavefront that lies on it
+            // a.split > 1 (small launches): `split` wavefronts per tile (blockIdx.y), each takes every split-th distinct
+            // block (and every split-th 1-D species below) -- with few wavefronts per SIMD the kernel lasts as long as
+            // its busiest wavefront, a tile inside the melting layer with 64 items of both melting species evaluated one
+            // after the other.  C3 sweep at 3 deg, 1 / 2 / 4 / 8 wavefronts per tile: 66.5 / 53 / 50.5 / 52 us; the 225-ray
+            // C4 share 846 / 861 / 937 us of PSD stage and the C4 volume with 2: 3.03 -> 3.41 ms: only for small launches.
+            // (Measured and dropped: key, record and wet fraction of EVERY species requested right after the validity
+            // byte, 150 VGPRs: 50.5 -> 59.9 us, although the skeleton alone -- both table parts compiled out -- takes 23 us.)
             unsigned long long todo = __ballot(item);
             const int f = lane & (NFP - 1), r = lane >> 4;
+            int turn = 0;
             while (todo) {
                 const int lead = (int)__ffsll((long long)todo) - 1;
                 const int cur = __builtin_amdgcn_readlane(blk, lead);
                 unsigned long long grp = __ballot(item && blk == cur);
                 todo &= ~grp;
+                const bool mine = turn == (int)blockIdx.y;
+                turn = turn + 1 == a.split ? 0 : turn + 1;
+                if (!mine) continue;
                 double rows[CPOL_ITAB2_QROWS];
                 itab2_quarter_rows(t.tab + (long)cur * (CPOL_ITAB2_NB * NFP) + f, r, rows);
                 while (grp) {
@@ -2086,7 +2098,7 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, CPOL_LOOKUP_WPE) void k_psd_lo
             }
             continue;
         }
-        if (!item) continue;
+        if (!item || (j % a.split) != (int)blockIdx.y) continue;        // (the 1-D items: one lane each; the species dealt to the tile's wavefronts)
         const cpol_hydro_desc &d = hs.h[j].d;
         const bool ice = d.psd_family == CPOL_PSD_ICE_FIELD;
         const int pn = min((int)pf, t.n_pan - 1);
