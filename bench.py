@@ -142,6 +142,12 @@ def stage_rooflines(prof_name, stage_ms, n_sbg, n_valid, n_gates, n_vars, nz, la
     prof, prof_path = load_profile_summary(prof_name)
     alg = {'interp': n_sbg * (4 * nz * 4 + n_vars * 8 * 4), 'psd': n_valid * LUT_SLICE_BYTES,
            'final': n_gates * 48, 'classify': 0, 'bucket': 0}
+    if prof and any('k_gate1' in name for name in prof):
+        # the single-beam fused kernel does the PSD stage's work from the integral tables: what its lanes ask for is the
+        # model values of the gate (4 n_vars + 5 B), 66 16-byte coefficient pieces per item (1056 B instead of the
+        # 49152-B table slice of SURVEY 8(d)) and the gate's outputs (10 float32 fields, RVEL, mask, 3 scan operands: 68 B)
+        alg['classify'] = n_gates * (4 * n_vars + 5 + 68) + n_valid * 1056
+        alg['psd'] = 0
     out = {}
     for st, kernels in STAGE_KERNELS.items():
         ms = stage_ms.get(st)
@@ -192,7 +198,8 @@ def roofline_of_dominant_stage(prof_name, stage_ms, n_sbg, n_valid, n_gates, n_v
                      'stage (one isolated sweep, one lane) / 8 TB/s; achieved = the same in GB/s.  hbm_alg_frac = '
                      'SURVEY 8(d) algorithmic bytes over the same duration: > 1 for the PSD stage, because the '
                      'integral tables replace the gather of a 49152-B table slice per item by 1056 B of polynomial '
-                     'coefficients (the slices are read once, at staging).  ' + note)}
+                     'coefficients (the slices are read once, at staging); for the single-beam fused kernel (k_gate1) the '
+                     'algorithmic bytes are what its lanes ask for with the tables: N_gates x (4 n_vars + 5 + 68) B + N_valid x 1056 B.  ' + note)}
 
 
 def main():
