@@ -1924,7 +1924,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         const long tiles = (long)cdiv(n_rays, CPOL_WAVE >> tl) * cdiv(ng, 1 << tl);
         // the scalar-cache form needs many wavefronts per SIMD to hide its waits (C4 volume, rays per sweep:
         // 45 / 90 / 180 / 360 -> PSD stage 1.08 / 1.56 / 2.08 / 3.57 ms against 0.85 / 1.48 / 2.35 / 4.71 ms with
-        // the gather): from ~32 wavefronts per SIMD on.  CPOL_SUBSUM_COOP=0 / 1: never / always.
+        // the gather): from ~32 wavefronts per SIMD on (the scalar-cache form; see below for the LDS form).  CPOL_SUBSUM_COOP=0 / 1: never / always.
         // With lanes (cpol_fork) other sweeps share the GPU and hide the waits: measured with three lanes in
         // flight, the share of one of 8 / 4 GPUs (11 / 21 wavefronts per SIMD): 1.30 / 2.24 ms per volume share
         // against 1.31 / ~2.5 ms with the gather -- from ~12 there.
@@ -1932,7 +1932,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         const int lanes_alive = ctx->parent ? ctx->parent->n_children : ctx->n_children;
         // (round 4, with the validity bits read up front: the share of one of 8 GPUs -- 11 wavefronts per SIMD --
         // with three lanes in flight 1.19 ms per volume share this way against 1.27 with the gather: from 8 there)
-        const bool coop = ctx->subsum_coop == 1 || (ctx->subsum_coop < 0 && waves_per_simd >= (lanes_alive >= 2 ? 8 : 32));
+        // (the LDS form, round 4: the share of one of 8 / 4 / 2 GPUs alone -- 11 / 21 / 43 wavefronts per SIMD -- PSD stage 905 / 1281 /
+        // 1748 us against 846 / 1413 / 2312 with the gather: from 16 there)
+        const bool coop = ctx->subsum_coop == 1 || (ctx->subsum_coop < 0 && waves_per_simd >= (lanes_alive >= 2 ? 8 : 16));
         // CPOL_SUBSUM_SMALL=1 (experiment, never the default): the gather form with three wavefronts per (tile,
         // hydrometeor), 4 columns each, and all rows of the block requested at once -- see the note on SPLIT in
         // cpol_final.inl: slower than the plain gather on the share (571 vs 533 us) and with lanes (1.41 vs 1.27 ms)

@@ -129,7 +129,7 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
     (k_subbeam_sum), the velocity terms in their own kernel (k_rvel_terms) -- against the oracle
     on sampled rays; the same rays alone (one ray per call: no tiles) must give the same bits, and so
     must the form of k_subbeam_sum that takes the coefficient rows of a tile's distinct table blocks
-    through the scalar cache (CPOL_SUBSUM_COOP=1; by default only launches of >= 32 wavefronts per SIMD
+    through the scalar cache (CPOL_SUBSUM_COOP=1; by default only launches of >= 16 wavefronts per SIMD
     use it) against the per-lane gather (CPOL_SUBSUM_COOP=0)."""
     from cosmo_pol_amd import RadarOperator
     from test_gpu_parity import _pol_tolerances
@@ -355,7 +355,7 @@ def test_c4_full_volume_equals_the_shares_of_eight_ranks_bitwise():
     44.1 M sub-beam gates in one launch sequence -- against the same volume computed as the eight
     contiguous 45-azimuth shares that eight ranks would compute (each share one launch sequence of
     its rays of all five sweeps): every field bit for bit.  The whole volume is large enough for the
-    scalar-cache form of k_subbeam_sum (32 wavefronts per SIMD and more), the shares take the per-lane
+    cooperative (LDS) form of k_subbeam_sum (16 wavefronts per SIMD and more), the shares take the per-lane
     gather, so this is also that pair at full size; rays are independent, so nothing else may differ."""
     from cosmo_pol_amd import RadarOperator
     over = bench.bench_config(False, 'c4')

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--profile', action='store_true')
+    ap.add_argument('--tag', default='')
     ap.add_argument('--lanes', default='1,3', help='lane counts to measure')
     args = ap.parse_args()
     import numpy as np
@@ -56,7 +57,7 @@ def main():
         t1 = time.perf_counter()
         fence()
         t2 = time.perf_counter()
-        return {'lanes': n_lanes, 'elevations': n_el, 'submit_us': 1e6 * (t1 - t0) / n, 'total_us': 1e6 * (t2 - t0) / n}
+        return {'tag': args.tag, 'lanes': n_lanes, 'elevations': n_el, 'submit_us': 1e6 * (t1 - t0) / n, 'total_us': 1e6 * (t2 - t0) / n}
     res = [run(n, e, args.steps) for e in (1, 8) for n in lane_counts]
     for r in res:
         print(json.dumps(r))
