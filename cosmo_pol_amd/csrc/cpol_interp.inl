@@ -409,6 +409,55 @@ __device__ __forceinline__ double rsqrt_newton(double x)
     return y;
 }
 
+// a * b + c with a wave-uniform (literal) addend from a scalar register pair: left to itself the compiler forms
+// v_fmac_f64 and first moves every coefficient into vector registers (two v_mov_b32 per Horner step)
+__device__ __forceinline__ double fma_kc(double a, double b, double c_uniform)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+    return r;
+}
+
+// atan(t) and asin(z) for |t|, |z| <= 0.2 (the rotated coordinates of a limited-area domain: +-11 degrees) as their
+// Maclaurin series, 13 / 12 terms (next term < 7e-19 / 5e-18 relative): within 2 ulp of the C library's value, in ~15
+// instructions instead of the ~90 / ~60 of the general atan2 / asin.
+__device__ __forceinline__ double atan_small(double t)
+{
+    const double z = t * t;
+    double p = 1.0 / 25.0;
+    p = fma_kc(p, z, -1.0 / 23.0);
+    p = fma_kc(p, z, 1.0 / 21.0);
+    p = fma_kc(p, z, -1.0 / 19.0);
+    p = fma_kc(p, z, 1.0 / 17.0);
+    p = fma_kc(p, z, -1.0 / 15.0);
+    p = fma_kc(p, z, 1.0 / 13.0);
+    p = fma_kc(p, z, -1.0 / 11.0);
+    p = fma_kc(p, z, 1.0 / 9.0);
+    p = fma_kc(p, z, -1.0 / 7.0);
+    p = fma_kc(p, z, 1.0 / 5.0);
+    p = fma_kc(p, z, -1.0 / 3.0);
+    p = fma(p, z, 1.0);
+    return t * p;
+}
+
+__device__ __forceinline__ double asin_small(double x)
+{
+    const double z = x * x;
+    double p = 88179.0 / 12058624.0;
+    p = fma_kc(p, z, 46189.0 / 5505024.0);
+    p = fma_kc(p, z, 12155.0 / 1245184.0);
+    p = fma_kc(p, z, 6435.0 / 557056.0);
+    p = fma_kc(p, z, 143.0 / 10240.0);
+    p = fma_kc(p, z, 231.0 / 13312.0);
+    p = fma_kc(p, z, 63.0 / 2816.0);
+    p = fma_kc(p, z, 35.0 / 1152.0);
+    p = fma_kc(p, z, 5.0 / 112.0);
+    p = fma_kc(p, z, 3.0 / 40.0);
+    p = fma_kc(p, z, 1.0 / 6.0);
+    p = fma(p, z, 1.0);
+    return x * p;
+}
+
 // One sub-beam gate: ray path, geodesic, rotated-pole coordinates, level search, the variables.  Returns the
 // gate's status (0: inside the model, values valid; 1 / -1 / 2: above / below / outside, values NaN; 3: no such
 // gate in this launch) and its index.  KEEP = false: every variable goes to a.vals[] (k_interp_sweep).
@@ -557,8 +606,19 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     if (sub != a.central_sub) {
         // (radians -> degrees as a product with 180 / pi: a float64 division by a constant is ~25 instructions;
         // the last float64 bit may differ from the quotient's, the float32 cast hides it but for ~1e-8 of the gates)
-        rlon = (float)(atan2(y_new, x_new) * (1.0 / CPOL_DEG));
-        rlat = (float)(asin(z_new) * (1.0 / CPOL_DEG));
+        // (and the two angles from their short series where the rotated coordinates are small -- every limited-area
+        // domain -- with 1 / x_new by Newton from v_rcp_f64: ~115 instructions fewer per sub-beam gate)
+        double rx = __builtin_amdgcn_rcp(x_new);
+        rx = rx * fma(-x_new, rx, 2.0);
+        rx = rx * fma(-x_new, rx, 2.0);
+        const double tq = y_new * rx;
+        if (x_new > 0.5 && fabs(tq) <= 0.2 && fabs(z_new) <= 0.2) {
+            rlon = (float)(atan_small(tq) * (1.0 / CPOL_DEG));
+            rlat = (float)(asin_small(z_new) * (1.0 / CPOL_DEG));
+        } else {
+            rlon = (float)(atan2(y_new, x_new) * (1.0 / CPOL_DEG));
+            rlat = (float)(asin(z_new) * (1.0 / CPOL_DEG));
+        }
     } else
 #endif
     {
