@@ -877,6 +877,10 @@ struct ScanRayArgs {
 #ifndef CPOL_FINAL_THREADS
 #define CPOL_FINAL_THREADS 256
 #endif
+// (Measured and dropped, round 4: a second instantiation for sweeps whose gates k_gate1 has finished -- scans, cut and the
+// rare recomputed gates -- held to 64 VGPRs so that a CU holds eight workgroups instead of two (the allocator's 243
+// registers are for the per-gate function, which almost never runs there): 840 B of scratch per lane, and the C2 sweep's
+// k_final 18.5 -> 27.9 us, the C5 Ku swath's 183 -> 319 us; at 128 / 168 VGPRs the swath takes 948 / 921 us against 945.)
 // THREADS: 256 (a gate or two per thread); 512 when the sweep has fewer rays than the GPU has CUs
 // (the share of one of N GPUs: the kernel's duration is that of ONE workgroup then)
 #ifndef CPOL_FINAL_WPE
