@@ -142,6 +142,7 @@ struct cpol_ctx {
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
     int lookup_split = 0;              // CPOL_LOOKUP_SPLIT=<n>: wavefronts per tile of k_psd_lookup (0: by launch size)
+    int gate1_species = 1;             // CPOL_GATE1_SPECIES=0 / 2: never / always k_gate1_species (one wavefront per species; default: small launches)
     int fuse_gate1 = 0;                // CPOL_FUSE_GATE1=1: k_interp_gate1 instead of k_interp_sweep + k_gate1 (measured slower where it matters)
     int fuse_classify = 1;             // CPOL_FUSE_CLASSIFY=0: k_interp_sweep + k_classify instead of k_interp_classify (read when the context is created)
     int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
@@ -571,6 +572,7 @@ int cpol_create(int device, cpol_ctx **out)
     // (default: by launch size; the results are identical)
     if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
     if (getenv("CPOL_LOOKUP_SPLIT")) ctx->lookup_split = std::max(0, std::min(16, atoi(getenv("CPOL_LOOKUP_SPLIT"))));
+    if (getenv("CPOL_GATE1_SPECIES")) ctx->gate1_species = std::max(0, std::min(2, atoi(getenv("CPOL_GATE1_SPECIES"))));
     if (getenv("CPOL_FUSE_GATE1")) ctx->fuse_gate1 = atoi(getenv("CPOL_FUSE_GATE1")) != 0 ? 1 : 0;
     if (getenv("CPOL_FUSE_CLASSIFY")) ctx->fuse_classify = atoi(getenv("CPOL_FUSE_CLASSIFY")) != 0 ? 1 : 0;
     if (getenv("CPOL_RARE_DIRECT")) ctx->rare_direct = atoi(getenv("CPOL_RARE_DIRECT")) != 0 ? 1 : 0;
@@ -681,6 +683,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->rare_direct = parent->rare_direct;
     c->fuse_classify = parent->fuse_classify;
     c->fuse_gate1 = parent->fuse_gate1;
+    c->gate1_species = parent->gate1_species;
     c->lookup_split = parent->lookup_split;
     c->gate1 = parent->gate1;
     c->subsum_coop_rounds = parent->subsum_coop_rounds;
@@ -1702,7 +1705,16 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         for (int j = 0; j < n_hyd; ++j) melt_tab = melt_tab || ctx->its.t[j].two_d;
         const dim3 ggrid((unsigned)n_rays, cdiv(ng, CPOL_GATE1_THREADS));
         const size_t glds = (size_t)n_vars * CPOL_GATE1_THREADS * sizeof(float);
-        if (fused_gate1 && melt_tab) hipLaunchKernelGGL((k_interp_gate1<true>), ggrid, dim3(CPOL_GATE1_THREADS), glds, st,
+        // one wavefront per species (k_gate1_species) where no melting species and no per-ray fall-speed sums are involved
+        // -- for small launches: the C2 sweep (8 wavefronts per SIMD) 33.6 -> 30.7 us and 42.9 -> 39.2 us per sweep with three
+        // lanes in flight; the C5 Ku swath (235 per SIMD, five species) 429 -> 674 us: every species' wavefront repeats the
+        // gate's loads and wavefronts 1.. idle while wavefront 0 finishes the gates (CPOL_GATE1_SPECIES=0 / 2: never / always)
+        const long g1_waves_per_simd = n_rg * n_hyd / 64 / 1024;
+        const bool by_species = (ctx->gate1_species == 2 || (ctx->gate1_species == 1 && g1_waves_per_simd < 32)) &&
+                                !fused_gate1 && !melt_tab && !ga.store_items && !p->with_melting;
+        if (by_species) hipLaunchKernelGGL(k_gate1_species, dim3((unsigned)cdiv(n_rg, 64)), dim3(64 * n_hyd),
+                                           (size_t)n_hyd * 64 * GATE1S_BYTES, st, ctx->hs, ctx->its, ca, fa, ga);
+        else if (fused_gate1 && melt_tab) hipLaunchKernelGGL((k_interp_gate1<true>), ggrid, dim3(CPOL_GATE1_THREADS), glds, st,
                                                         ctx->model, ia, ctx->hs, ctx->its, ca, fa, ga);
         else if (fused_gate1) hipLaunchKernelGGL((k_interp_gate1<false>), ggrid, dim3(CPOL_GATE1_THREADS), glds, st,
                                                  ctx->model, ia, ctx->hs, ctx->its, ca, fa, ga);

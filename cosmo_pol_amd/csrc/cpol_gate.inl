@@ -331,3 +331,158 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_interp_g
     clear_counters(ia.zero_buf, ia.zero_n, ia.zero_buf2, ia.zero_n2);      // (the NEXT sweep's set)
     gate1_body<TWO_D, true>(m, ia, s_vals + threadIdx.x, hs, its, a, f, g);
 }
+
+
+// k_gate1_species: the same work with ONE WAVEFRONT PER SPECIES -- a workgroup takes 64 consecutive gates, its wavefront j
+// the hydrometeor j of those gates (classification, block gather, Horner chains); the per-species columns and fall-speed
+// sums meet in LDS and wavefront 0 adds them in species order (the float32 sums of k_gate1, term by term) and finishes
+// the gates.  k_gate1 is bound by the latency of ONE thread's chain through all species at 3 wavefronts per SIMD; here a
+// thread's chain is one species long, the species is wave-uniform (no divergent rule switch) and the registers of a
+// thread hold one block instead of the bookkeeping of a loop over species.  Not for melting species (k_gate1<true>) nor
+// when a species' fall-speed sums are per ray (store_items): those keep k_gate1.
+// grid = ceil(n_rg / 64), block = 64 * n_hydro, dynamic LDS = n_hydro * 64 * GATE1S_BYTES
+#define GATE1S_BYTES (CPOL_N_SZ * 4 + 8 + 8 + 4)
+#ifndef CPOL_GATE1S_WPE
+#define CPOL_GATE1S_WPE 0
+#endif
+#if CPOL_GATE1S_WPE
+#define CPOL_GATE1S_ATTR __attribute__((amdgpu_waves_per_eu(CPOL_GATE1S_WPE, CPOL_GATE1S_WPE)))
+#else
+#define CPOL_GATE1S_ATTR
+#endif
+__global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_species(HydroSet hs, ItabSet its, ClassifyArgs a, FinalArgs f, GateArgs g)
+{
+    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
+    extern __shared__ unsigned char s_raw[];
+    const int n_h = hs.n_hydro;
+    float *s_acc = reinterpret_cast<float *>(s_raw);                                   // [n_h][12][64]
+    double *s_mv = reinterpret_cast<double *>(s_raw + (size_t)n_h * CPOL_N_SZ * 64 * 4);   // [n_h][64]
+    double *s_mn = s_mv + n_h * 64;                                                    // [n_h][64]
+    unsigned *s_flag = reinterpret_cast<unsigned *>(s_mn + n_h * 64);                  // [n_h][64]: 1 valid, 2 off the tables, 4 moments
+    __shared__ int s_lookup;
+    if (threadIdx.x == 0) s_lookup = 0;
+    const int lane = lane_id();
+    const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                    // the wavefront's hydrometeor
+    const long i0 = (long)blockIdx.x * 64 + lane;
+    const bool in = i0 < a.n_sbg;
+    const long n = a.n_sbg;
+    const long i = in ? i0 : 0;
+    const HydroDev &h = hs.h[j];
+    const cpol_hydro_desc &d = h.d;
+    const ItabDev &t = its.t[j];
+    const bool want_rvel = f.RVEL != nullptr;
+    const bool want_vn = want_rvel && t.writes_vn;                                     // uniform: the table carries the Doppler sums
+    const double w0 = f.sub_w[0];
+
+    const float e = in ? a.elev[i] : 0.f;
+    const float T = in ? a.vals[d.var_t * n + i] : 0.f;
+    const float qm = in ? a.vals[d.var_q * n + i] : 0.f;                               // (q_source == CPOL_Q_MODEL: no melting species here)
+    ClassItem it;
+    classify_item(h, t, a, a.vals, n, i, i, in, qm, 0.0, T, d.var_t, e, it);
+    double2 v[CPOL_N_SZ / 2];
+#pragma unroll
+    for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = make_double2(0.0, 0.0);
+    double2 wv = make_double2(0.0, 0.0);
+    bool have = false;
+    if (t.tab && it.lookup) {
+        // ---- 1-D block: the lane gathers the rows of its (slice, panel) block (as k_gate1) ----
+        const int pn = min((int)it.pf, t.n_pan - 1);
+        const double u = 2.0 * (it.pf - (double)pn) - 1.0;
+        const double2 *blk = reinterpret_cast<const double2 *>(t.tab + ((long)(it.key - h.key_base) * t.n_pan + pn) * NB);
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = blk[(NC - 1) * (NFP / 2) + c];
+        if (want_vn) wv = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
+#pragma unroll CPOL_GATE1_ROW_UNROLL
+        for (int q = NC - 2; q >= 0; --q) {
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ / 2; ++c) {
+                const double2 cq = blk[q * (NFP / 2) + c];
+                v[c].x = fma(v[c].x, u, cq.x);
+                v[c].y = fma(v[c].y, u, cq.y);
+            }
+            if (want_vn) {
+                const double2 cq = blk[q * (NFP / 2) + CPOL_N_SZ / 2];
+                wv.x = fma(wv.x, u, cq.x);
+                wv.y = fma(wv.y, u, cq.y);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ / 2; ++c) { v[c].x *= it.scale; v[c].y *= it.scale; }
+        wv.x *= it.scale; wv.y *= it.scale;
+        have = true;
+    }
+    int my_lookup = it.lookup ? 1 : 0;
+    const bool off_table = it.valid && !it.lookup;
+    if (off_table) {
+        // ---- an item outside the integral table: a work unit of its own for the integrating kernels (as k_gate1) ----
+        const unsigned long long idx = atomicAdd(g.totals + 1, 1ull);
+        atomicAdd(g.totals, 1ull);
+        g.unit_key[idx] = it.key;
+        g.perm[idx] = (int)i;
+        double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + i;
+        P[0] = it.p0;
+        P[n] = it.p1;
+        if (h.n_par >= 3) P[2 * n] = it.p2;
+    }
+    // ---- this species' term of the ONE sub-beam (nansum([NaN, y]) stored as float32) and its fall-speed moments ----
+#pragma unroll
+    for (int c = 0; c < CPOL_N_SZ; ++c) {
+        double y = ((c & 1) ? v[c / 2].y : v[c / 2].x) * w0;
+        if (!(y == y)) y = 0.0;
+        s_acc[(j * CPOL_N_SZ + c) * 64 + lane] = have ? (float)(0.0 + y) : 0.f;
+    }
+    const bool moments = want_rvel && it.valid && f.vsrc[j] == 1;
+    double vj = 0.0, nj = 0.0;
+    if (moments) {
+        if (want_vn) { vj = wv.x; nj = wv.y; }
+        else { vj = it.dv; nj = it.dn; }
+    }
+    s_mv[j * 64 + lane] = vj;
+    s_mn[j * 64 + lane] = nj;
+    s_flag[j * 64 + lane] = (it.valid ? 1u : 0u) | (off_table ? 2u : 0u) | (moments ? 4u : 0u);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) my_lookup += __shfl_xor(my_lookup, off);
+    __syncthreads();                                  // (s_lookup = 0 is visible; the species' terms are in LDS)
+    if (lane == 0 && my_lookup) atomicAdd(&s_lookup, my_lookup);
+
+    // ---- the gate: deferred if any species is off its table; the items of a deferred gate are stored for final_gate ----
+    unsigned vbits = 0;
+    bool deferred = false;
+    for (int q = 0; q < n_h; ++q) {
+        const unsigned fl = s_flag[q * 64 + lane];
+        vbits |= (fl & 1u) << q;
+        deferred = deferred || (fl & 2u);
+    }
+    if (deferred) {
+        gate1_store_item(a, t, j, n, i, it, g.analytic_vn != 0);
+        if (want_vn && t.tab && !t.two_d && it.lookup && a.vn)
+            *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = wv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) count_table_items(a.n_lookup, s_lookup);
+    if (j != 0) return;
+    // ---- wavefront 0: sum over the species in order, get_pol_from_sz, RVEL, mask; the operands of the range scans ----
+    if (in && deferred) a.vmask[i] = (unsigned char)vbits;
+    if (in) g.defer[i] = deferred ? 1 : 0;
+    if (!in || deferred) return;
+    float tot[CPOL_N_SZ];
+    double mom_v = 0.0, mom_n = 0.0;
+    for (int q = 0; q < n_h; ++q) {
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) {
+            const float acc = s_acc[(q * CPOL_N_SZ + c) * 64 + lane];
+            tot[c] = (q == 0) ? acc : tot[c] + acc;
+        }
+        if (s_flag[q * 64 + lane] & 4u) {
+            const double vq = s_mv[q * 64 + lane], nq = s_mn[q * 64 + lane];
+            if (vq == vq) mom_v += vq;
+            if (nq == nq) mom_n += nq;
+        }
+    }
+    const int ray = (int)(i / f.n_gates), gate = (int)(i % f.n_gates);
+    float k2, fh, fv;
+    gate_finish(f, ray, gate, tot, want_rvel, mom_v, mom_n, 0.0, k2, fh, fv);
+    g.sk[i] = k2;
+    g.sh[i] = fh;
+    g.sv[i] = fv;
+}

@@ -113,7 +113,8 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
     the general one with the counting sort (CPOL_RARE_DIRECT=0, CPOL_GATE1=0), the general one with the items
     listed directly as one-item work units (CPOL_GATE1=0) and the single-beam fused kernel, which defers the
     gates that hold such an item to k_final -- with one and with nine sub-beams, hundreds of items each.  Also the
-    two-kernel form of the direct listing (CPOL_FUSE_CLASSIFY=0) and the opt-in k_interp_gate1 (CPOL_FUSE_GATE1=1)."""
+    two-kernel form of the direct listing (CPOL_FUSE_CLASSIFY=0), the opt-in k_interp_gate1 (CPOL_FUSE_GATE1=1) and both forms of the
+    single-beam kernel: one wavefront per species (k_gate1_species, the default of small sweeps) / one thread per gate (k_gate1)."""
     import bench
     from cosmo_pol_amd import RadarOperator, synthetic
     hyds = ('R', 'S', 'G')
@@ -134,8 +135,9 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
         conf['integration'].update(nh_GH=n_gh, nv_GH=n_gh)
         for mode, env in (('sorted', {'CPOL_RARE_DIRECT': '0', 'CPOL_GATE1': '0'}), ('direct', {'CPOL_GATE1': '0'}), ('default', {}),
                           ('direct_two_kernels', {'CPOL_GATE1': '0', 'CPOL_FUSE_CLASSIFY': '0'}),     # k_interp_sweep + k_classify
-                          ('interp_gate1', {'CPOL_FUSE_GATE1': '1'})):                                 # k_interp_gate1 (opt-in)
-            for k in ('CPOL_RARE_DIRECT', 'CPOL_GATE1', 'CPOL_FUSE_CLASSIFY', 'CPOL_FUSE_GATE1'):
+                          ('interp_gate1', {'CPOL_FUSE_GATE1': '1'}),                                  # k_interp_gate1 (opt-in)
+                          ('gate1_one_thread', {'CPOL_GATE1_SPECIES': '0'})):      # k_gate1 instead of k_gate1_species (what large swaths get)
+            for k in ('CPOL_RARE_DIRECT', 'CPOL_GATE1', 'CPOL_FUSE_CLASSIFY', 'CPOL_FUSE_GATE1', 'CPOL_GATE1_SPECIES'):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)                    # (read when the context is created)
@@ -149,7 +151,7 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
             results[(n_gh, mode)] = (res, n_off)
             op.close()
         ref, n_ref = results[(n_gh, 'sorted')]
-        for mode in ('direct', 'default', 'direct_two_kernels', 'interp_gate1'):
+        for mode in ('direct', 'default', 'direct_two_kernels', 'interp_gate1', 'gate1_one_thread'):
             got, n_got = results[(n_gh, mode)]
             assert n_got == n_ref
             for k in ('ZH', 'ZV', 'ZDR', 'KDP', 'RHOHV', 'PHIDP', 'DELTA_HV', 'ATT_H', 'ATT_V', 'RVEL', 'mask'):
