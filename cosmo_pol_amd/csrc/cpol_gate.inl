@@ -342,6 +342,9 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_interp_g
 // when a species' fall-speed sums are per ray (store_items): those keep k_gate1.
 // grid = ceil(n_rg / 64), block = 64 * n_hydro, dynamic LDS = n_hydro * 64 * GATE1S_BYTES
 #define GATE1S_BYTES (CPOL_N_SZ * 4 + 8 + 8 + 4)
+#ifndef CPOL_GATE1S_ROW_UNROLL
+#define CPOL_GATE1S_ROW_UNROLL 2     // coefficient rows of the block requested together
+#endif
 #ifndef CPOL_GATE1S_WPE
 #define CPOL_GATE1S_WPE 0
 #endif
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_
 #pragma unroll
         for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = blk[(NC - 1) * (NFP / 2) + c];
         if (want_vn) wv = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
-#pragma unroll CPOL_GATE1_ROW_UNROLL
+#pragma unroll CPOL_GATE1S_ROW_UNROLL
         for (int q = NC - 2; q >= 0; --q) {
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ / 2; ++c) {
