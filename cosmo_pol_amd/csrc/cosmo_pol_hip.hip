@@ -1708,9 +1708,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // one wavefront per species (k_gate1_species) where no melting species and no per-ray fall-speed sums are involved
         // -- for small launches: the C2 sweep (8 wavefronts per SIMD) 33.6 -> 30.7 us and 42.9 -> 39.2 us per sweep with three
         // lanes in flight; the C5 Ku swath (235 per SIMD, five species) 429 -> 674 us: every species' wavefront repeats the
-        // gate's loads and wavefronts 1.. idle while wavefront 0 finishes the gates (CPOL_GATE1_SPECIES=0 / 2: never / always)
+        // gate's loads and wavefronts 1.. idle while wavefront 0 finishes the gates; five C2 sweeps as one sequence (44 per
+        // SIMD) 112 -> 100 us (CPOL_GATE1_SPECIES=0 / 2: never / always)
         const long g1_waves_per_simd = n_rg * n_hyd / 64 / 1024;
-        const bool by_species = (ctx->gate1_species == 2 || (ctx->gate1_species == 1 && g1_waves_per_simd < 32)) &&
+        const bool by_species = (ctx->gate1_species == 2 || (ctx->gate1_species == 1 && g1_waves_per_simd < 48)) &&
                                 !fused_gate1 && !melt_tab && !ga.store_items && !p->with_melting;
         if (by_species) hipLaunchKernelGGL(k_gate1_species, dim3((unsigned)cdiv(n_rg, 64)), dim3(64 * n_hyd),
                                            (size_t)n_hyd * 64 * GATE1S_BYTES, st, ctx->hs, ctx->its, ca, fa, ga);
