@@ -204,9 +204,10 @@ typedef struct {
     const double *nyquist;      /* [n_rays] Nyquist velocity per ray [m/s] for the RVEL
                                    aliasing (utilities.py:142-156) or NULL (no folding) */
     uint64_t version;           /* 0: tables are uploaded on every call; otherwise the
-                                   caller's tag of this table set -- an unchanged tag
-                                   means the device copies of the previous call are
-                                   reused (repeated scans of the same geometry)      */
+                                   caller's tag of this table set -- a context keeps the
+                                   device copies of the last 8 tags it has seen (same tag
+                                   and same shapes: nothing is uploaded), so a scan that
+                                   cycles through its elevations uploads each set once  */
     /* integration scheme 'ml' (interpolation.py:168-193, 423-436; per-gate weights as in
        doppler_scatter.py:124-129, 186-189, 259-264): NULL / 0 for scalar weights */
     const double *varray;       /* [n_vbins] velocity bins of the Doppler spectrum

@@ -349,3 +349,27 @@ def test_placement_helpers_on_the_box():
     assert int(arr.sum()) == arr.size
     del arr
     pool.close()
+
+
+def test_ray_table_sets_of_the_last_scan_geometries_stay_on_the_device():
+    """The library keeps the per-ray tables of the last 8 tagged scan geometries of a context on the device
+    (cpol_ray_tables_t.version): 11 elevations in turn, three times round -- more geometries than sets, so sets
+    are evicted and uploaded again; then the first few once more (found resident).  Every result must equal the
+    result of an operator that uploads its tables on every call (version 0), bit for bit, on both lanes."""
+    op, _, _, _ = _op('c4_subbeams', lanes=2)
+    ref, _, _, _ = _op('c4_subbeams')
+    ref.reuse_device_tables = False
+    az = np.arange(0.0, 360.0, 30.0)
+    elevations = [1.0 + 0.7 * k for k in range(11)]
+    want = {}
+    for e in elevations:
+        want[e] = ref.simulate_rays(az, np.full(len(az), e))
+    k = 0
+    for e in elevations * 3 + elevations[:4] + elevations[:4]:
+        got = op.simulate_rays(az, np.full(len(az), e), lane=k % 2)
+        k += 1
+        for f in ('ZH', 'ZDR', 'KDP', 'PHIDP', 'RVEL', 'mask', 'lats', 'heights'):
+            assert np.array_equal(got[f], want[e][f], equal_nan=True), (f, e, k)
+    assert np.isfinite(want[elevations[2]]['ZH']).sum() > 50
+    op.close()
+    ref.close()
