@@ -2013,7 +2013,12 @@ __device__ __forceinline__ void itab1_columns(const double2 *c, double u, double
 // and every lane running the whole 66-term polynomial from its own row loads, no cross-lane sums: 3.04 ms.
 // Round 4: the rows of the NEXT distinct block requested before the items of the current one (two row sets in
 // registers, 180 VGPRs, 2 wavefronts per SIMD): C3 sweep 66.6 -> 73.8 us, the 225-ray C4 share 245 -> 394 us,
-// the C4 volume 1.36 -> 2.38 ms -- the walk does not wait for its rows at any of these sizes.)
+// the C4 volume 1.36 -> 2.38 ms -- the walk does not wait for its rows at any of these sizes.
+// The block staged in LDS (8.25 KB per wavefront, 4 wavefronts per SIMD) and its items four at a time, lane = (item slot,
+// function) running the whole polynomial from the LDS copy -- the four quarter sums formed and joined exactly as here, the
+// item's operands brought to its 16 lanes by ds_bpermute, no cross-lane sums: PSD stage of the C4 volume 3.05 -> 3.21 ms,
+// of the 225-ray share 850 -> 877 us, of the C3 sweep 62.5 -> 59.8 us: ~10 items share a block, staging it costs what the
+// 66 LDS reads per pass save.)
 #ifndef CPOL_LOOKUP_WPE
 #define CPOL_LOOKUP_WPE 5             // wavefronts per SIMD asked of the register allocator (102 VGPRs: 5 fit since round 4; C4 volume 4 / 5 / 6 / 8: 1.36 / 1.22 / 1.51 / 2.24 ms, share 245 / 227 / 278 us, C3 sweep 66.6 / 67.1 us)
 #endif
