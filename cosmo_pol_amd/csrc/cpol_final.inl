@@ -571,8 +571,8 @@ __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabS
             for (int c = 0; c < 2 * NP; ++c) {
                 // nansum([float32 acc, float64 term]) stored back as float32
                 double y = ((c & 1) ? v[c / 2].y : v[c / 2].x) * w;
-                double x = (double)acc[c];
-                if (!(x == x)) x = 0.0;
+                const float xa = (acc[c] == acc[c]) ? acc[c] : 0.f;      // (NaN -> 0 before the conversion: one select instead of two)
+                const double x = (double)xa;
                 if (!(y == y)) y = 0.0;
                 acc[c] = (float)(x + y);
             }
