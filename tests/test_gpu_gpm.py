@@ -352,3 +352,32 @@ def test_swath_geometry_cache_follows_the_swath(luts_band):
     assert len(op._gpm_cache) <= 4
     op.close()
     op2.close()
+
+
+def test_single_beam_kernel_by_species_equals_by_gate_on_a_two_moment_swath(luts_band, monkeypatch):
+    """k_gate1_species (one wavefront per species: the default of small sweeps) against k_gate1 (one thread per gate
+    through all species: what a bench-size swath gets) on a 2-moment Ku swath with four species: every field bit for bit."""
+    from cosmo_pol_amd import RadarOperator
+    cube = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G'), two_moment=True, **_cases.gen_golden.CUBE_KW)
+    base = {'radar': {'coords': [46.5, 7.5, 1000], 'frequency': 5.6, 'K_squared': 0.93},
+            'microphysics': {'scheme': '2mom', 'with_ice_crystals': 0, 'with_melting': 0},
+            'integration': {'nh_GH': 1, 'nv_GH': 1}}
+    lut_5_6 = {h: synthetic.make_lut(h, 5.6, '2mom', n_e=2, n_t=2) for h in HYD_2MOM}
+
+    def provider(hl, freq, scheme):
+        src = {13.6: luts_band('Ku'), 35.6: luts_band('Ka')}.get(freq, lut_5_6)
+        return {h: src[h] for h in hl}
+    sw = gpm.synthetic_swath(n_scans=6, n_rays=9, cross_track_deg=6.0, scan_spacing_m=5000.0)
+    out = {}
+    for mode in ('0', '2'):
+        monkeypatch.setenv('CPOL_GATE1_SPECIES', mode)           # (read when the context is created)
+        op = RadarOperator(config=base, luts=provider, output_variables='only_radar')
+        op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+        out[mode] = op.get_GPM_swath(sw, 'Ku').raw
+        c = op._ctx.counters()
+        assert c.n_table_items > 500
+        op.close()
+    for k, v in out['0'].items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(out['2'][k], v, equal_nan=True), k
+    assert np.isfinite(out['0']['ZH']).sum() > 200
