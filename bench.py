@@ -51,13 +51,23 @@ closed (driver-timed like the rest of the run).  At N > 1 with the default workl
 after the c2 part has closed its operator and process group (its `speedup_vs_single_gpu` is the
 strong-scaling figure of north_star's "azimuths sharded, one gather at the end").
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the workload:
-`achieved` = algorithmic bytes per launch over the live HIP-event duration on the
-library's stream (cpol_enable_timing / cpol_counters), `traffic` = HBM bytes per launch of the
-rocprofv3 PMC passes committed under profiles/ (read at run time, never hard-coded), `frac` =
-traffic over the live duration against the 8 TB/s HBM peak.  `cpu_baseline` times the CPU oracle
-(the restatement of the reference algorithm, per radial, un-batched) on this host: one pinned core
-(median of 5 samples) and a fork pool over os.cpu_count() cores as radar_operator.py:402,431 does.
+OUTPUT (rank 0).  The LAST stdout line is ONE compact JSON object (< 4 KB: `compact_line`, guarded by
+tests/test_bench_cpu.py): metric, value, unit, n_gpus, steps, warmup, ms_per_step, dtype, data,
+config{workload, ...}, roofline{...}, cpu_baseline{...}, value_host_outputs (+ its five repeats),
+c4_speedup_vs_single_gpu, n_ranks_seen_by_rccl.  Everything else -- per-stage tables, notes, the c3 / c4 /
+c5 child runs, repeats, latencies -- goes to `bench_detail.json` beside this script and to EARLIER stdout
+lines that start with `#detail ` (one section per line), never to the last line.
+
+`roofline` describes the dominant kernel of the workload: `traffic` = HBM-side bytes per launch of the
+rocprofv3 PMC passes committed under profiles/ (read at run time, never hard-coded), `avg_launch_ms` = its
+live HIP-event duration on the library's stream (cpol_enable_timing / cpol_counters), `achieved` = traffic /
+avg_launch_ms, `frac` = achieved / 8 TB/s; `timed_region` = the bytes of one whole sweep over ms_per_sweep of
+the timed region itself; `valu_f64` = the resource that binds (VALU issue: wave instructions x 4 cycles over
+the SIMD cycles of the same duration); `alg_8d` = SURVEY 8(d)'s algorithmic bytes, kept with the note that
+the integral tables void it (a sweep gathers 1056 B of coefficients per item, not a 49152-B table slice).
+`cpu_baseline` times the CPU oracle (the restatement of the reference algorithm, per radial, un-batched) on
+this host: one pinned core (median of 5 samples); the fork-pool legs (radar_operator.py:402,431) run AFTER
+the GPU measurements, time-boxed, and are reported in the detail file.
 """
 import argparse
 import contextlib
@@ -134,24 +144,25 @@ TABLE_BUILD_KERNELS = ('k_itab_', 'k_stage_', 'k_spaceborne_first_gate')      # 
 
 
 def stage_rooflines(prof_name, stage_ms, n_sbg, n_valid, n_gates, n_vars, nz, launches_per_run=1):
-    """Every stage of ONE sweep against the HBM roofline.  Per stage: live HIP-event duration
-    (cpol_counters_t, one isolated sweep on one lane), HBM bytes per sweep of its kernels from the
-    committed rocprofv3 PMC passes of the SAME isolated sweep (profiles/<prof_name>_summary.json),
-    `frac` = those bytes / live duration / 8 TB/s, and the ALGORITHMIC bytes of SURVEY 8(d):
-    interp N_sbg x (4 nz 4 + n_vars 8 4) B, psd N_valid x 49152 B, final N_gates x 48 B."""
+    """Every stage of ONE sweep against the HBM roofline and against VALU issue.  Per stage: live HIP-event
+    duration (cpol_counters_t, one isolated sweep on one lane), HBM-side bytes and VALU wave instructions per
+    sweep of its kernels from the committed rocprofv3 PMC passes of the SAME isolated sweep
+    (profiles/<prof_name>_summary.json), `frac` = those bytes / live duration / 8 TB/s, `valu_frac` = VALU issue,
+    and the ALGORITHMIC bytes of SURVEY 8(d) (`algorithmic_bytes_8d`: interp N_sbg x (4 nz 4 + n_vars 8 4) B,
+    psd N_valid x 49152 B, final N_gates x 48 B)."""
     prof, prof_path = load_profile_summary(prof_name)
     alg = {'interp': n_sbg * (4 * nz * 4 + n_vars * 8 * 4), 'psd': n_valid * LUT_SLICE_BYTES,
            'final': n_gates * 48, 'classify': 0, 'bucket': 0}
     if prof and any('k_gate1' in name for name in prof):
-        # the single-beam fused kernel does the PSD stage's work from the integral tables: what its lanes ask for is the
-        # model values of the gate (4 n_vars + 5 B), 66 16-byte coefficient pieces per item (1056 B instead of the
-        # 49152-B table slice of SURVEY 8(d)) and the gate's outputs (10 float32 fields, RVEL, mask, 3 scan operands: 68 B)
-        alg['classify'] = n_gates * (4 * n_vars + 5 + 68) + n_valid * 1056
+        # the single-beam fused kernel (stage `classify`) does the PSD stage's work: SURVEY 8(d)'s bytes of the PSD stage
+        # are booked there.  (They are VOID as a roofline: the integral tables replace the 49152-B slice per item by
+        # 1056 B of polynomial coefficients, so B_alg / t exceeds the HBM peak many times over; kept for the record.)
+        alg['classify'] = alg['psd']
         alg['psd'] = 0
     out = {}
     for st, kernels in STAGE_KERNELS.items():
         ms = stage_ms.get(st)
-        traffic = prof_us = None
+        traffic = prof_us = valu = None
         used = []
         if prof:
             for name, c in prof.items():
@@ -162,18 +173,32 @@ def stage_rooflines(prof_name, stage_ms, n_sbg, n_valid, n_gates, n_vars, nz, la
                 per_sweep = c.get('per_sweep', 1.0)          # dispatches of this kernel per sweep
                 traffic = (traffic or 0.0) + c['hbm_bytes'] * per_sweep
                 prof_us = (prof_us or 0.0) + (c.get('avg_us') or 0.0) * per_sweep
+                if c.get('SQ_INSTS_VALU') is not None:
+                    valu = (valu or 0.0) + c['SQ_INSTS_VALU'] * per_sweep
                 used.append(name.split('(')[0])
         t = ms * 1e-3 if ms and ms > 0 else None
         out[st] = {'kernels': used, 'live_ms': ms, 'profile_us': prof_us, 'traffic': traffic,
                    'achieved': traffic / t / 1e9 if (t and traffic) else None,
                    'frac': traffic / t / 1e9 / HBM_PEAK_GBS if (t and traffic) else None,
-                   'algorithmic_bytes': alg[st],
-                   'hbm_alg_frac': alg[st] / t / 1e9 / HBM_PEAK_GBS if (t and alg[st]) else None}
+                   'valu_wave_instructions': valu,
+                   'valu_frac': valu_issue_frac(valu, t),
+                   'algorithmic_bytes_8d': alg[st],
+                   'alg_8d_frac': alg[st] / t / 1e9 / HBM_PEAK_GBS if (t and alg[st]) else None}
     return out, prof_path
 
 
+def valu_issue_frac(wave_instructions, seconds):
+    """VALU issue: a wave64 vector instruction occupies its SIMD for 4 cycles (f32, f64 and integer alike on
+    CDNA4; transcendentals and f64 division longer: a lower bound) -> instructions x 4 over the cycles of
+    1024 SIMDs at 2.4 GHz during `seconds`."""
+    if not wave_instructions or not seconds:
+        return None
+    return wave_instructions * VALU_F64_CYCLES / (N_SIMD * PEAK_CLOCK * seconds)
+
+
 def roofline_of_dominant_stage(prof_name, stage_ms, n_sbg, n_valid, n_gates, n_vars, nz, note=''):
-    """The bench line's `roofline`: the stage with the longest live duration."""
+    """The bench line's `roofline`: the stage with the longest live duration, against HBM (bytes of the committed
+    PMC passes over the live duration) and against the resource that binds (`valu_f64`: VALU issue)."""
     stages, prof_path = stage_rooflines(prof_name, stage_ms, n_sbg, n_valid, n_gates, n_vars, nz)
     live = {k: v['live_ms'] for k, v in stages.items() if v['live_ms']}
     if not live:
@@ -183,23 +208,143 @@ def roofline_of_dominant_stage(prof_name, stage_ms, n_sbg, n_valid, n_gates, n_v
     d = stages[dom]
     total_ms = sum(live.values())
     total_traffic = sum(v['traffic'] or 0.0 for v in stages.values())
-    total_alg = sum(v['algorithmic_bytes'] for v in stages.values())
+    total_alg = sum(v['algorithmic_bytes_8d'] for v in stages.values())
+    total_valu = sum(v['valu_wave_instructions'] or 0.0 for v in stages.values())
     return {'kernel': ' + '.join(d['kernels']) or dom, 'stage': dom, 'bound': 'hbm',
             'achieved': d['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': d['frac'],
             'traffic': d['traffic'], 'traffic_source': prof_path,
             'avg_launch_ms': d['live_ms'], 'profile_avg_us': d['profile_us'],
-            'algorithmic_bytes_per_launch': d['algorithmic_bytes'], 'hbm_alg_frac': d['hbm_alg_frac'],
+            'valu_f64': {'bound': 'valu_f64', 'frac': d['valu_frac'],
+                         'wave_instructions_per_launch': d['valu_wave_instructions'],
+                         'peak_G_wave_instructions_per_s': N_SIMD * PEAK_CLOCK / VALU_F64_CYCLES / 1e9,
+                         'whole_sweep_frac': valu_issue_frac(total_valu, total_ms * 1e-3)},
+            'alg_8d': {'bytes_per_launch': d['algorithmic_bytes_8d'], 'frac': d['alg_8d_frac'],
+                       'whole_sweep_bytes': total_alg,
+                       'whole_sweep_frac': total_alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       'note': 'SURVEY 8(d) B_alg; void as a roofline where > 1: the integral tables replace the '
+                               '49152-B slice per item by 1056 B of coefficients'},
             'whole_sweep': {'live_ms': total_ms, 'traffic': total_traffic,
                             'frac': total_traffic / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if total_traffic else None,
-                            'algorithmic_bytes': total_alg,
-                            'hbm_alg_frac': total_alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                            'valu_wave_instructions': total_valu,
+                            'valu_frac': valu_issue_frac(total_valu, total_ms * 1e-3)},
             'stages': stages,
-            'note': ('frac = HBM bytes per launch of the PMC passes (profiles/) / live HIP-event duration of the '
-                     'stage (one isolated sweep, one lane) / 8 TB/s; achieved = the same in GB/s.  hbm_alg_frac = '
-                     'SURVEY 8(d) algorithmic bytes over the same duration: > 1 for the PSD stage, because the '
-                     'integral tables replace the gather of a 49152-B table slice per item by 1056 B of polynomial '
-                     'coefficients (the slices are read once, at staging); for the single-beam fused kernel (k_gate1) the '
-                     'algorithmic bytes are what its lanes ask for with the tables: N_gates x (4 n_vars + 5 + 68) B + N_valid x 1056 B.  ' + note)}
+            'note': ('frac = HBM-side bytes per launch of the PMC passes (profiles/; FETCH_SIZE counts fabric reads, so '
+                     'Infinity-Cache hits are included: an upper bound of DRAM traffic) / live HIP-event duration of '
+                     'the stage (one isolated sweep, one lane) / 8 TB/s; valu_f64.frac = VALU wave instructions x 4 '
+                     'cycles / (1024 SIMDs x 2.4 GHz x the same duration).  ' + note)}
+
+
+# ------------------------------------------------------------------------ the line the driver parses
+COMPACT_LIMIT = 4096
+
+
+def _r(x, sig=6):
+    """Numbers of the compact line: 6 significant digits; NaN / Infinity never reach the line."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, int):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float('inf'), float('-inf')):
+            return None
+        return float('%.*g' % (sig, x))
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact_line(d):
+    """The final stdout line from the full result dict `d` of a workload: the contract's keys at the top level,
+    the roofline of the dominant kernel (HBM + the VALU bound + the timed region), the one-core CPU baseline,
+    the SURVEY 8(d) step (`value_host_outputs`), the multi-GPU answers; < COMPACT_LIMIT bytes whatever `d`
+    holds (notes and tables stay in bench_detail.json)."""
+    cfg = d.get('config') or {}
+    roof = d.get('roofline') or {}
+    cpu = d.get('cpu_baseline') or None
+    ho = d.get('host_outputs') or {}
+    out = {k: d.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
+                                 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')}
+    out['config'] = {'workload': str(cfg.get('workload', ''))[:300]}
+    for k in ('rays_per_gpu', 'rays_per_gpu_per_sweep', 'gates_per_ray', 'sub_beams', 'lanes', 'sweeps_per_step', 'small'):
+        if k in cfg:
+            out['config'][k] = cfg[k]
+    if isinstance(cfg.get('parallelism'), str):
+        out['config']['parallelism'] = cfg['parallelism'][:160]
+    r = {k: roof.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source',
+                                  'avg_launch_ms')}
+    if isinstance(r.get('kernel'), str):
+        r['kernel'] = r['kernel'][:80]
+    tr = roof.get('timed_region') or {}
+    if tr:
+        r['timed_region'] = {k: tr.get(k) for k in ('ms_per_sweep', 'traffic_per_sweep', 'achieved', 'frac', 'valu_frac')}
+    vf = roof.get('valu_f64') or {}
+    if vf:
+        r['valu_f64'] = {k: vf.get(k) for k in ('bound', 'frac', 'wave_instructions_per_launch', 'whole_sweep_frac')}
+    a8 = roof.get('alg_8d') or {}
+    if a8:
+        r['alg_8d'] = {'bytes_per_launch': a8.get('bytes_per_launch'), 'frac': a8.get('frac'),
+                       'void': bool((a8.get('frac') or 0) > 1.0)}
+    out['roofline'] = r
+    if cpu:
+        out['cpu_baseline'] = {k: cpu.get(k) for k in ('value', 'unit', 'cores', 'kind', 'host_cpus')}
+        out['cpu_baseline']['sample'] = str(cpu.get('sample', ''))[:200]
+        if d.get('value') and cpu.get('value'):
+            out['gpu_over_cpu_core'] = d['value'] / cpu['value']
+    if ho:
+        out['value_host_outputs'] = ho.get('value')
+        out['host_outputs_ms_per_sweep'] = ho.get('ms_per_sweep')
+        out['host_outputs_ms_per_sweep_repeats'] = ho.get('ms_per_sweep_repeats')
+        if ho.get('value') and cpu and cpu.get('value'):
+            out['host_outputs_over_cpu_core'] = ho['value'] / cpu['value']
+    for k in ('ms_per_sweep', 'value_definition', 'c4_speedup_vs_single_gpu', 'c4_speedup_single_volume', 'c4_gather_check',
+              'speedup_vs_single_gpu', 'speedup_single_volume', 'gather_check', 'n_ranks_seen_by_rccl', 'collective'):
+        if d.get(k) is not None:
+            out[k] = d[k][:200] if isinstance(d[k], str) else d[k]
+    others = {}
+    for k in ('c3', 'c4_volume_one_gpu', 'c5', 'c4_strong_scaling'):
+        c = d.get(k)
+        if isinstance(c, dict):
+            others[k] = ({'value': c.get('value'), 'ms_per_step': c.get('ms_per_step'),
+                          'roofline_frac': (c.get('roofline') or {}).get('frac'),
+                          'cpu_baseline': (c.get('cpu_baseline') or {}).get('value')}
+                         if 'error' not in c else {'error': str(c['error'])[:80]})
+    if others:
+        out['other_configs'] = others
+    out['detail'] = d.get('detail_file', 'bench_detail.json')
+    out = _r(out)
+    # whatever a caller put into `d`: the line stays below the limit (drop the optional parts first)
+    for victim in ('other_configs', 'host_outputs_ms_per_sweep_repeats'):
+        if len(json.dumps(out)) < COMPACT_LIMIT:
+            break
+        out.pop(victim, None)
+    if len(json.dumps(out)) >= COMPACT_LIMIT:
+        out['config'] = {'workload': out['config']['workload'][:120]}
+        out['roofline'] = {k: out['roofline'].get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
+    return out
+
+
+def emit(d, detail_path=None):
+    """Rank 0: the full result to `bench_detail.json` (beside this script; CPOL_BENCH_DETAIL: another path) and to
+    stdout lines that start with '#detail ' (one top-level section per line), THEN the compact line -- the last
+    line of stdout, the one the driver parses."""
+    path = detail_path or os.environ.get('CPOL_BENCH_DETAIL') or os.path.join(ROOT, 'bench_detail.json')
+    d['detail_file'] = os.path.basename(path)
+    try:
+        with open(path, 'w') as f:
+            json.dump(_r(d, 9), f, indent=1)
+    except OSError as e:                              # (a read-only checkout: the '#detail' lines still carry everything)
+        print('[bench] could not write %s: %s' % (path, e), file=sys.stderr)
+    scalars = {k: v for k, v in d.items() if not isinstance(v, (dict, list))}
+    print('#detail scalars ' + json.dumps(_r(scalars, 9)))
+    for k, v in d.items():
+        if isinstance(v, (dict, list)):
+            print('#detail %s %s' % (k, json.dumps(_r(v, 9))))
+    line = json.dumps(compact_line(d))
+    assert len(line) < COMPACT_LIMIT and not line.startswith('#')
+    sys.stdout.flush()
+    print(line, flush=True)
 
 
 def main():
@@ -264,8 +409,10 @@ def main():
         luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
     t_gen = time.time() - t0
 
-    # CPU baselines first: the all-core leg forks workers, which must happen before this
-    # process initialises the GPU (HIP state does not survive a fork)
+    # The one-core CPU baseline first (a bounded sample: --cpu-seconds of oracle work on one pinned core).  The
+    # fork-pool legs run in a child interpreter AFTER every GPU measurement of this run: up to
+    # 256 NumPy workers leave the host in a state (clocks, page cache, run queues) that the host-bound
+    # `host_outputs` step of round 4 was measured in by accident.
     cpu_res = None
     if world == 1 and args.cpu_seconds > 0:
         print('[bench] CPU baseline: one pinned core ...', file=sys.stderr, flush=True)
@@ -276,8 +423,6 @@ def main():
             # (c4: a radial of 49 sub-beams takes the oracle about a second: one radial per sample at least)
             cpu_res = cpu_baseline(conf, cube, luts, np.arange(0, 360, 1.0), el_cpu, args.cpu_seconds,
                                    n_samples=5 if workload == 'c2' else 2 if workload == 'c4' else 3)
-        if workload == 'c2' and not os.environ.get('CPOL_BENCH_NO_EXTRAS'):
-            cpu_res['all_cores'] = cpu_baseline_pool(workload, args.small)
 
     # this rank's threads onto the cores next to its GPU (after the CPU legs, which use every core);
     # CPOL_NUMA_BIND=0 leaves the affinity as launched
@@ -361,6 +506,7 @@ def main():
             out['c4_strong_scaling'] = res
             # the figures that answer north_star's multi-GPU target, at the top level of the line
             out['c4_speedup_vs_single_gpu'] = (res or {}).get('speedup_vs_single_gpu')
+            out['c4_speedup_single_volume'] = (res or {}).get('speedup_single_volume')
             out['c4_gather_check'] = (res or {}).get('gather_check')
             out['c4_collective'] = (res or {}).get('collective')
     if rank == 0:
@@ -373,7 +519,15 @@ def main():
             out['c3'] = child_run('c3', ['--steps', '20', '--warmup', '3'] + small + cpu)
             out['c4_volume_one_gpu'] = child_run('c4', ['--steps', '6', '--warmup', '2'] + small + cpu)
             out['c5'] = child_run('c5', ['--steps', '3', '--warmup', '1'] + small + cpu)
-        print(json.dumps(out))
+            c4 = out['c4_volume_one_gpu'] or {}
+            out['c4_speedup_vs_single_gpu'] = c4.get('speedup_vs_single_gpu')         # (N = 1: the path's own overhead)
+            out['c4_speedup_single_volume'] = c4.get('speedup_single_volume')
+            if out.get('n_ranks_seen_by_rccl') is None:
+                out['n_ranks_seen_by_rccl'] = c4.get('n_ranks_seen_by_rccl')
+            if args.cpu_seconds > 0 and cpu_res is not None and workload == 'c2':
+                # the fork-pool legs, last of all (time-boxed; the line never waits longer than the limit)
+                out['cpu_baseline']['all_cores'] = cpu_baseline_pool(workload, args.small)
+        emit(out)
 
 
 def child_run(workload, flags, env=None, quiet=False, timeout=600):
@@ -382,29 +536,42 @@ def child_run(workload, flags, env=None, quiet=False, timeout=600):
     at N = 1 c3, c4 (the single-GPU reference of the strong-scaling runs) and c5; at N > 1 the c4
     strong-scaling run, every rank starting its own child (`quiet`: a rank whose child prints nothing)."""
     import subprocess
+    import tempfile
     cmd = [sys.executable, os.path.abspath(__file__), '--workload', workload] + (flags if '--cpu-seconds' in flags else flags + ['--cpu-seconds', '0'])
     t0 = time.time()
+    fd, detail = tempfile.mkstemp(prefix='cpol_bench_%s_' % workload, suffix='.json')
+    os.close(fd)
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout,
-                           env=dict(os.environ, CPOL_BENCH_NO_EXTRAS='1', **(env or {})))
+                           env=dict(os.environ, CPOL_BENCH_NO_EXTRAS='1', CPOL_BENCH_DETAIL=detail, **(env or {})))
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
         if quiet and r.returncode == 0:
             return None
         if r.returncode != 0 or not line:
             return {'error': (r.stderr or r.stdout)[-400:]}
-        d = json.loads(line[-1])
+        try:
+            with open(detail) as f:                           # the full result (the child's last line is compact)
+                d = json.load(f)
+        except (OSError, ValueError):
+            d = json.loads(line[-1])
         keep = {k: d.get(k) for k in ('value', 'unit', 'n_gpus', 'ms_per_step', 'steps', 'warmup', 'scaling',
                                       'gather_check', 'speedup_vs_single_gpu', 'single_gpu_same_workload',
                                       'per_rank', 'roofline', 'setup_s', 'stages_ms', 'counters', 'api_ms', 'per_band',
-                                      'single_sweep_ms', 'host_submit_ms_per_step', 'collective',
+                                      'single_sweep_ms', 'host_submit_ms_per_step', 'submit_loop_ms_per_step', 'speedup_device_only', 'collective',
                                       'collectives_in_timed_region', 'n_ranks_seen_by_backend', 'n_ranks_seen_by_rccl',
-                                      'process_group_backend', 'cpu_baseline') if k in d}
+                                      'process_group_backend', 'cpu_baseline', 'speedup_single_volume',
+                                      'single_volume_blocking') if k in d}
         keep['workload'] = d['config']['workload']
         keep['child_wall_s'] = time.time() - t0
         keep['command'] = 'python bench.py ' + ' '.join(cmd[2:])
         return keep
     except Exception as e:                                   # the headline line must not depend on an extra
         return {'error': repr(e)[:400]}
+    finally:
+        try:
+            os.unlink(detail)
+        except OSError:
+            pass
 
 
 # ------------------------------------------------------------------------------------------ c2
@@ -644,8 +811,9 @@ def run_c2(env):
             'ms_per_sweep': ms_sweep, 'traffic_per_sweep': ws['traffic'],
             'achieved': ws['traffic'] / (ms_sweep * 1e-3) / 1e9, 'unit': 'GB/s',
             'frac': ws['traffic'] / (ms_sweep * 1e-3) / (HBM_PEAK_GBS * 1e9),
-            'note': 'HBM bytes of one sweep (the committed PMC passes of the isolated sweep) over the time per sweep of the '
-                    'timed region itself (sweeps of three lanes in flight)'}
+            'valu_frac': valu_issue_frac(ws.get('valu_wave_instructions'), ms_sweep * 1e-3),
+            'note': 'HBM-side bytes / VALU wave instructions of one sweep (the committed PMC passes of the isolated sweep) '
+                    'over the time per sweep of the timed region itself (sweeps of three lanes in flight)'}
     if not weak:
         # the integrating kernel itself (it builds the integral tables at staging time and takes the
         # items outside them): a second operator with the tables switched off, one lane
@@ -679,16 +847,17 @@ def run_c2(env):
         'ms_per_step': 1e3 * elapsed / args.steps, 'ms_per_sweep': 1e3 * elapsed / args.steps / n_cycle,
         'sweeps_per_step': n_cycle, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': 'c2: 360-azimuth x 500-gate C-band PPI, rain+snow+graupel 1-moment, 1 sub-beam, '
-                               'synthetic %s cube; a step = 8 sweeps per GPU through cpol_run_sweep, one at each of 8 elevations '
-                               '(1.0 + 0.05 k deg, k = (sweep + rank) mod 8; their per-ray constants are on the host and their '
-                               'table sets on the device before the timed region), every kernel of the launch sequence, the 10 '
-                               'radar fields of every sweep left in HBM (inputs and outputs resident; one sweep with host '
-                               'outputs: `host_outputs`)%s'
+        'value_definition': 'v2 (round 4 on): 8 sweeps per step, inputs and outputs resident in HBM; '
+                            'value_host_outputs = the SURVEY 8(d) step (v1, rounds 1-3: one sweep, H2D of its tables, D2H of 15 arrays)',
+        'config': {'workload': 'c2: step = 8 sweeps per GPU of the 360-az x 500-gate C-band PPI (R+S+G 1-mom, 1 sub-beam), '
+                               'inputs and outputs resident in HBM; synthetic %s cube; each sweep = one cpol_run_sweep at one of '
+                               '8 elevations (1.0 + 0.05 k deg, k = (sweep + rank) mod 8; per-ray constants on the host and '
+                               'table sets on the device before the timed region), every kernel of the launch sequence, the '
+                               '10 radar fields left in HBM; the SURVEY 8(d) step with host outputs: value_host_outputs%s'
                                % ('x'.join(map(str, cube['zlevels'].shape)),
                                   '' if not weak else '; the timed region ends with one all-gather of every rank\'s '
                                                       'last sweep (10 float32 fields, device to device)'),
-                   'rays_per_gpu': n_rays, 'gates_per_ray': n_gates, 'lanes': n_lanes,
+                   'rays_per_gpu': n_rays, 'gates_per_ray': n_gates, 'lanes': n_lanes, 'sweeps_per_step': n_cycle,
                    'parallelism': ('weak scaling: the sweeps of a scan are independent, rank r simulates elevation '
                                    '(sweep + r) mod 8 with the N = 1 step unchanged, no collective inside a step, ONE '
                                    'all-gather (RCCL) at the end of the timed region') if weak else 'single GPU',
@@ -995,6 +1164,61 @@ def run_c4(env):
     value = gates_per_step * args.steps / elapsed
     gathered_volume = last[0]                           # rank 0 (or every rank): the last volume of the timed region
 
+    # ONE VOLUME AT A TIME through the same path (what a single get_PPI(distributed=True) sees): submit, wait, next
+    def blocking_region(group, n):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            op.submit_volume(sweeps, fields=RADAR_FIELDS, lane=0, group=group).wait()
+        op.wait(0)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    op.submit_volume(sweeps, fields=RADAR_FIELDS, lane=0).wait()
+    t_block = blocking_region(None, args.steps)
+    if world > 1:
+        tt = torch.tensor([t_block], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_block = float(tt.item())
+
+    # THE SAME TWO REGIMES ON ONE GPU: rank 0 alone, through the same code path on a one-rank group (the other ranks
+    # wait at the fence).  Numerator and denominator of both speedups are then like for like: distributed path,
+    # 9 fields gathered, assembled on the device and copied to page-locked host memory; pipelined over the lanes
+    # (`speedup_vs_single_gpu`), or one volume at a time (`speedup_single_volume`).
+    one = None
+    solo = dist.new_group([0]) if world > 1 else None    # (every rank makes the call; N = 1: the default group is it)
+    if rank == 0:
+        n_it = max(3, args.steps // 2)
+        pend = collections.deque()
+        for k in range(n_lanes + 1):                     # buffers of the one-rank layout, every lane
+            pend.append(op.submit_volume(sweeps, fields=RADAR_FIELDS, lane=k % n_lanes, group=solo))
+        while pend:
+            pend.popleft().wait()
+        for i in range(n_lanes):
+            op.wait(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_it):
+            pend.append(op.submit_volume(sweeps, fields=RADAR_FIELDS, lane=k % n_lanes, group=solo))
+            while len(pend) > n_lanes:
+                pend.popleft().wait()
+        while pend:
+            pend.popleft().wait()
+        for i in range(n_lanes):
+            op.wait(i)
+        torch.cuda.synchronize()
+        t1_pipe = (time.perf_counter() - t0) / n_it
+        t0 = time.perf_counter()
+        for _ in range(n_it):
+            op.submit_volume(sweeps, fields=RADAR_FIELDS, lane=0, group=solo).wait()
+        op.wait(0)
+        torch.cuda.synchronize()
+        t1_block = (time.perf_counter() - t0) / n_it
+        one = {'pipelined_ms_per_volume': 1e3 * t1_pipe, 'single_volume_ms': 1e3 * t1_block, 'volumes_timed': n_it,
+               'note': 'rank 0 alone runs the whole volume through the same distributed path on a one-rank group: '
+                       '%d lanes alternating (pipelined) and submit().wait() per volume (single volume)' % n_lanes}
+    fence()
+
     # the blocking drop-in call on every rank: RadarOperator(distributed=True).get_PPI, all 15 arrays
     op.distributed = True
     api = []
@@ -1050,8 +1274,10 @@ def run_c4(env):
         op.wait(0)
         t1 = (time.perf_counter() - t0) / n_it
         single = {'ms_per_volume': 1e3 * t1, 'value': gates_per_step / t1,
-                  'note': 'rank 0 runs the whole 5 x %d-ray volume alone after the timed region (one launch '
-                          'sequence, outputs left in HBM)' % n_az}
+                  'through_the_distributed_path': one,
+                  'note': 'rank 0 runs the whole 5 x %d-ray volume alone after the timed region: ms_per_volume / value = '
+                          'one launch sequence at a time with the outputs left in HBM (device work only; NOT the '
+                          'denominator of the speedups); through_the_distributed_path = the regimes of the speedups' % n_az}
         ref = lay1.assemble(full.cpu().numpy())
         got = gathered_volume
         gather_ok = bool(got is not None and all(np.array_equal(got[s][k], ref[s][k], equal_nan=True)
@@ -1067,7 +1293,7 @@ def run_c4(env):
         busiest['n_valid_items'], n_el * busiest['rays_per_sweep'] * n_gates, n_vars, nz,
         note='c4: the five-elevation launch sequence of the busiest rank (%d rays per sweep), one lane, the pass '
              'after the timed region; traffic from the profile of the same launch sequence when committed '
-             '(N = 1: profiles/r3_c4_volume_iso_*).' % busiest['rays_per_sweep'])
+             '(N = 1: profiles/*_c4_volume_iso_*; N = 8: *_c4_share8_iso_*).' % busiest['rays_per_sweep'])
     return {
         'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -1091,8 +1317,13 @@ def run_c4(env):
         'counters': {'n_valid_items_per_volume': sum(q.get('n_valid_items', 0) for q in per_rank),
                      'n_subbeam_gates_per_volume': n_el * n_az * n_gates * 49},
         'single_gpu_same_workload': single,
-        'speedup_vs_single_gpu': (value / single['value']) if single else None,
-        'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
+        # both speedups compare like with like: the distributed path on N ranks against the same path on one rank
+        'speedup_vs_single_gpu': (one['pipelined_ms_per_volume'] / (1e3 * elapsed / args.steps)) if one else None,
+        'speedup_single_volume': (one['single_volume_ms'] / (1e3 * t_block)) if one else None,
+        'single_volume_blocking': {'ms_per_volume': 1e3 * t_block, 'value': gates_per_step / t_block,
+                                   'note': 'submit_volume().wait() per step, nothing else in flight (max over ranks)'},
+        'speedup_device_only': (value / single['value']) if single else None,
+        'submit_loop_ms_per_step': 1e3 * t_submit / args.steps,
         'gather_check': gather_ok,
         'collective': runner.collective,
         'collectives_in_timed_region': n_coll,
@@ -1281,7 +1512,7 @@ def cpu_pool_child(args):
         cube = synthetic.make_cube(hydrometeors=cube_h, **synthetic.BENCH_GRID)
         luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
     az = np.arange(0, 360, 1.0)
-    budget_s = 6.0
+    budget_s = 4.0
     n_cpu = max(1, os.cpu_count() or 1)
     _POOL_STATE['inputs'] = _oracle_inputs(conf, cube, luts)     # inherited by fork, not pickled
     _POOL_STATE['el'] = 1.0 if workload == 'c2' else C4_ELEVATIONS[2]
@@ -1289,10 +1520,11 @@ def cpu_pool_child(args):
     legs = {}
     for procs in sorted({n_cpu, min(n_cpu, 64), min(n_cpu, 16)}):       # small pools first
         print('[bench] CPU pool leg: %d worker processes ...' % procs, file=sys.stderr, flush=True)
-        legs[procs] = _pool_leg(ctx, procs, az, budget_s, chunk=4)
+        legs[procs] = _pool_leg(ctx, procs, az, budget_s, chunk=4, first_result_timeout=25.0)
         print(json.dumps({'partial': {str(k): (v or {}).get('gates_per_s') for k, v in legs.items()}}), flush=True)
     print('[bench] CPU pool leg: reference style (a fork per radial) ...', file=sys.stderr, flush=True)
-    ref = _pool_leg(ctx, n_cpu, az, min(budget_s, 4.0), chunk=1, maxtasksperchild=1)
+    n_ref = min(n_cpu, 64)                     # (a fork per radial from 256 parents-of-2.9-GB stalls the host: bounded)
+    ref = _pool_leg(ctx, n_ref, az, 3.0, chunk=1, first_result_timeout=20.0, maxtasksperchild=1)
     full = legs.get(n_cpu)
     done = {k: v for k, v in legs.items() if v}
     best_p = max(done, key=lambda k: done[k]['gates_per_s']) if done else None
@@ -1307,11 +1539,11 @@ def cpu_pool_child(args):
            'reference_style': {'value': ref['gates_per_s'],
                                'sample': '%d radials in %.1f s, Pool(%d, maxtasksperchild=1) as '
                                          'radar_operator.py:402,431 (a fork per radial)'
-                                         % (ref['radials'], ref['seconds'], n_cpu)} if ref else None}
+                                         % (ref['radials'], ref['seconds'], n_ref)} if ref else None}
     print(json.dumps(out), flush=True)
 
 
-def cpu_baseline_pool(workload, small, limit_s=150.0):
+def cpu_baseline_pool(workload, small, limit_s=100.0):
     """Runs cpu_pool_child in a child interpreter of its own session with a hard time limit; the
     bench line never waits longer than `limit_s` for the all-core legs."""
     import signal

@@ -21,6 +21,7 @@ PSD_GAMMA, PSD_ICE_FIELD, PSD_MELTING = 0, 1, 2
  RULE_MELTING_SNOW, RULE_MELTING_GRAUPEL) = range(7)
 Q_MODEL, Q_MELT_SNOW, Q_MELT_GRAUPEL = 0, 1, 2
 GEOM_GROUND_43, GEOM_SPACEBORNE, GEOM_HOST_PATHS = 0, 1, 2
+DEBUG_EXACT_SUBBEAMS = 1
 
 ERR_HIP, ERR_ARG, ERR_DOMAIN, ERR_NOMEM = -1, -2, -3, -4
 
@@ -65,7 +66,7 @@ class SweepParams(C.Structure):
         ('wavelength', C.c_double), ('k_squared', C.c_double), ('radial_res', C.c_double),
         ('c_zh', C.c_double),
         ('var_u', C.c_int32), ('var_v', C.c_int32), ('var_w', C.c_int32), ('var_rho', C.c_int32),
-        ('n_vbins', C.c_int32), ('pad2_', C.c_int32), ('c_spectrum', C.c_double),
+        ('n_vbins', C.c_int32), ('debug_flags', C.c_int32), ('c_spectrum', C.c_double),
     ]
 
 

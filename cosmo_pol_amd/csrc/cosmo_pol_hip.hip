@@ -68,8 +68,8 @@ struct cpol_ctx {
     int n_children = 0;
     // HIP graph of the sweep's launch sequence (device outputs, unchanged arguments)
     bool use_graph = false;
-    hipGraphExec_t graph_exec = nullptr;
-    uint64_t graph_key = 0;
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};     // one per counter set (the sets alternate sweep by sweep)
+    uint64_t graph_key[2] = {0, 0};
     uint64_t stage_serial = 0;         // bumped by every staging call (kernel arguments change)
     std::string err;
     // model
@@ -138,6 +138,8 @@ struct cpol_ctx {
     // clear what its own workgroups add to), and no sequence needs a fill kernel.  Both sets are zero when (re)allocated.
     uint64_t sweep_serial = 0;
     long count_stride = 0;             // ints per set of b_count
+    bool counters_dirty = false;       // a launch sequence began and did not end in sweep_serial advancing (an error return after
+                                       // its first launch): both counter sets are cleared before the next sequence uses one
     int last_par = 0;                  // the set the last sweep used
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
@@ -151,6 +153,8 @@ struct cpol_ctx {
     int subsum_coop = -1;              // CPOL_SUBSUM_COOP: k_subbeam_sum takes its coefficients through the scalar cache: 0 never, 1 always, -1 by launch size
     bool last_subsum = false;          // the 1-D table items of the last sweep never went through res[] (k_subbeam_sum)
     bool keep_debug = false;
+    bool fail_next = false;            // test hook (cpol_debug_read "fail_next_sweep"): the next launch sequence returns an error
+                                       // after its kernels are queued, as a failed copy or capture would
     // sticky domain-error word (device): OR-ed by the kernels of every sweep, cleared only
     // when it has been read AND reported (host-output sweeps, cpol_synchronize, cpol_counters)
     int *d_errword = nullptr;
@@ -643,7 +647,7 @@ void cpol_destroy(cpol_ctx *ctx)
         for (int k = 0; k < EV_N; ++k) (void)hipEventDestroy(set[k]);
         delete[] set;
     }
-    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    for (hipGraphExec_t g : ctx->graph_exec) if (g) (void)hipGraphExecDestroy(g);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->d_errword) (void)hipFree(ctx->d_errword);
     for (void *h : ctx->host_allocs) (void)hipHostFree(h);
@@ -809,6 +813,17 @@ int cpol_mem_info(cpol_ctx *ctx, size_t *free_bytes, size_t *total_bytes, size_t
     HIPCHK(hipSetDevice(ctx->device));
     size_t f = 0, t = 0;
     HIPCHK(hipMemGetInfo(&f, &t));
+    // "free" for a launch sequence of THIS context = what the device has free + what the context's grow-only work
+    // buffers hold already (a scan that fitted as one sequence the first time fits again: a caller that sizes its
+    // batches by this figure groups the same scan the same way on every call)
+    {
+        const DevBuf *work[] = {&ctx->b_traj, &ctx->b_wgate, &ctx->b_rayc, &ctx->b_beam, &ctx->b_vals, &ctx->b_mask, &ctx->b_elev,
+                                &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key, &ctx->b_par, &ctx->b_units,
+                                &ctx->b_perm, &ctx->b_res, &ctx->b_pos, &ctx->b_vn, &ctx->b_proj, &ctx->b_rec, &ctx->b_vmask,
+                                &ctx->b_gscan, &ctx->b_defer, &ctx->b_szinteg};
+        for (const DevBuf *b : work) if (b->p) f += b->cap;
+        if (f > t) f = t;
+    }
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
     if (per_gate) {
@@ -1324,10 +1339,14 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         void *const was = ctx->b_count.p, *const was_t = ctx->b_totals.p;
         ENSURE(ctx->b_count, (size_t)2 * cnt_stride * sizeof(int));
         ENSURE(ctx->b_totals, 2 * 4 * sizeof(long long));
-        if (ctx->b_count.p != was || ctx->b_totals.p != was_t || ctx->count_stride != cnt_stride) {
+        // (counters_dirty: the previous call returned an error after its counting kernel was queued -- an ENSURE that
+        // found no memory, a failed copy or capture: its set holds counts and the serial did not advance, so the set
+        // would be used again as it is; the memsets are queued behind whatever that call left on the stream)
+        if (ctx->b_count.p != was || ctx->b_totals.p != was_t || ctx->count_stride != cnt_stride || ctx->counters_dirty) {
             HIPCHK(hipMemsetAsync(ctx->b_count.p, 0, (size_t)2 * cnt_stride * sizeof(int), ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->b_totals.p, 0, 2 * 4 * sizeof(long long), ctx->stream));
             ctx->count_stride = cnt_stride;
+            ctx->counters_dirty = false;
         }
     }
     const int par = (int)(ctx->sweep_serial & 1);        // (the serial advances once the sequence is queued)
@@ -1368,7 +1387,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (doppler) {
         ENSURE(ctx->b_vn, (size_t)n_hyd * n_sbg * 2 * sizeof(double));
         ENSURE(ctx->b_icefirst, (size_t)n_rays * n_sub * sizeof(IceFirst));
+        if (!dop3 && n_sub >= 4) ENSURE(ctx->b_proj, (size_t)n_sbg * sizeof(double));     // k_rvel_terms
     }
+    // (every argument check and every allocation of the sequence happens before its first launch: an error return
+    // further down would leave the sweep's counter set half used; see counters_dirty)
+    if ((size_t)3 * ng * sizeof(float) > 64 * 1024) { ctx->err = "cpol_run_sweep: n_gates too large for the range scans (3 * n_gates floats of LDS)"; return CPOL_ERR_ARG; }
     if (dop3) {
         ENSURE(ctx->b_beam, (size_t)n_sbg * n_vb * sizeof(float));
     }
@@ -1556,6 +1579,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.central_sub = n_sub / 2;
     ia.sin_u1 = p->sin_u1; ia.cos_u1 = p->cos_u1; ia.lon1 = p->radar_lon;
     ia.site = t->site ? (const double *)ctx->v_site : nullptr;
+    ia.exact_sub = (p->debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS) ? 1 : 0;
     if (!fused && !fused_gate1)
     hipLaunchKernelGGL(k_interp_sweep, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256), 0, st,
                        ctx->model, ia);
@@ -2017,13 +2041,11 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         hipLaunchKernelGGL(k_spec_final, dim3((unsigned)n_rg), dim3(64), 0, st, sf);
         ra.RVEL = (double *)T[O_RVEL];       // censored with the other observables in k_final
     }
-    if ((size_t)3 * ng * sizeof(float) > 64 * 1024) { ctx->err = "cpol_run_sweep: n_gates too large for the range scans (3 * n_gates floats of LDS)"; return CPOL_ERR_ARG; }
     fa.pre_integ = subsum ? 1 : 0;
     if (subsum) fa.sz_integ = (float *)ctx->b_szinteg.p;
     fa.proj = nullptr;
     if (fa.RVEL && n_sub >= 4) {
         // the per-sub-beam velocity terms by one thread per sub-beam gate (k_final adds them in order)
-        ENSURE(ctx->b_proj, (size_t)n_sbg * sizeof(double));
         hipLaunchKernelGGL(k_rvel_terms, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256), 0, st,
                            fa, (double *)ctx->b_proj.p);
         fa.proj = (const double *)ctx->b_proj.p;
@@ -2041,6 +2063,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     return CPOL_OK;
     };
 
+    ctx->counters_dirty = true;         // until the sequence is queued completely (cleared where sweep_serial advances)
     // graph key: every value that ends up in a kernel argument
     const bool graphable = ctx->use_graph && dev && !tm_psd && !ctx->keep_debug && mode != CPOL_GEOM_HOST_PATHS &&
                            !dop3 && reuse && !want_szt && !want_model;
@@ -2062,8 +2085,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                          ctx->v_subv, ctx->v_subw, ctx->v_sens, ctx->v_site, ctx->v_nyq,
                          ctx->v_subsmooth, ctx->v_mlfilter, (void *)st};
         mix(arena, sizeof arena);
-        if (!ctx->graph_exec || ctx->graph_key != key) {
-            if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+        hipGraphExec_t &gexec = ctx->graph_exec[par];
+        if (!gexec || ctx->graph_key[par] != key) {
+            if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             const int lrc = launch_all();
@@ -2074,16 +2098,21 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                 ctx->err = "cpol_run_sweep: stream capture failed";
                 return CPOL_ERR_HIP;
             }
-            const hipError_t ie = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
+            const hipError_t ie = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
-            if (ie != hipSuccess) { ctx->graph_exec = nullptr; ctx->err = "cpol_run_sweep: hipGraphInstantiate failed"; return CPOL_ERR_HIP; }
-            ctx->graph_key = key;
+            if (ie != hipSuccess) { gexec = nullptr; ctx->err = "cpol_run_sweep: hipGraphInstantiate failed"; return CPOL_ERR_HIP; }
+            ctx->graph_key[par] = key;
         }
-        HIPCHK(hipGraphLaunch(ctx->graph_exec, st));
+        HIPCHK(hipGraphLaunch(gexec, st));
     } else {
         if ((rc = launch_all()) != CPOL_OK) return rc;
     }
 
+    if (ctx->fail_next) {
+        ctx->fail_next = false;
+        ctx->err = "cpol_run_sweep: failure requested by the test hook (fail_next_sweep)";
+        return CPOL_ERR_HIP;
+    }
     // ---- outputs that the kernels did not write in place ----
     if (window) {
         HIPCHK(hipMemcpyAsync(win_lo, (const char *)ctx->b_outwin.p + win_skew, (size_t)(win_hi - win_lo), hipMemcpyDeviceToHost, st));
@@ -2098,6 +2127,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ctx->last_n_gates = ng; ctx->last_n_sub = n_sub; ctx->last_n_v = n_v;
     ctx->last_par = par;
     ++ctx->sweep_serial;
+    ctx->counters_dirty = false;
     ctx->last_n_keys = n_keys; ctx->last_subsum = subsum || final_inplace;
     ctx->counters.n_subbeam_gates = n_sbg;
     ctx->counters.n_gates = n_rg;
@@ -2215,6 +2245,7 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     if (!ctx || !name) return CPOL_ERR_ARG;
     if (!strcmp(name, "enable")) { ctx->keep_debug = true; return 0; }
     if (!strcmp(name, "disable")) { ctx->keep_debug = false; return 0; }
+    if (!strcmp(name, "fail_next_sweep")) { ctx->fail_next = true; return 0; }
     if (!strcmp(name, "cache")) {
         // [integral-table cache entries, scattering-table cache entries, integral-table builds] (table_id)
         const cpol_ctx *own = ctx->parent ? ctx->parent : ctx;

@@ -383,6 +383,7 @@ struct InterpArgs {
     int n_rays, n_gates, n_sub, n_h, n_v, central_sub;
     double sin_u1, cos_u1, lon1;
     const double *site;         // per-ray site or NULL
+    int exact_sub;              // debug (cpol_sweep_params.debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS): every sub-beam takes the central one's long form
 };
 
 #ifndef CPOL_RAY_PREP_MIN_SUB
@@ -526,7 +527,9 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     // relative -- of the fixed point, after 5 within rounding.  The central sub-beam, whose float64 coordinates
     // are outputs, takes 5; the others, of which only the float32 grid coordinates are used, 4.)
 #if CPOL_INTERP_FAST_SUB
-    const int n_iter = sub != a.central_sub ? CPOL_VINCENTY_ITERS - 1 : CPOL_VINCENTY_ITERS;
+    // (wave-uniform: a wavefront walks ONE sub-beam; exact_sub is a kernel argument)
+    const bool short_form = sub != a.central_sub && !a.exact_sub;
+    const int n_iter = short_form ? CPOL_VINCENTY_ITERS - 1 : CPOL_VINCENTY_ITERS;
 #else
     const int n_iter = CPOL_VINCENTY_ITERS;
 #endif
@@ -558,7 +561,7 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     double lat_deg = 0.0, lon_deg = 0.0;
     double sl, cl, slon, clon;                    // sin / cos of the geographic latitude and longitude
 #if CPOL_INTERP_FAST_SUB
-    if (sub != a.central_sub) {
+    if (short_form) {
         // Sub-beams other than the central one (wave-uniform: a wavefront walks ONE sub-beam) need the
         // geographic coordinates only as sin / cos for the rotated-pole transform: taken straight from the
         // arguments of the two atan2 (sin = y / hypot, cos = x / hypot) and the addition theorem, instead of
@@ -603,7 +606,7 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     const double z_new = m.nstcp * x - m.stsp * y + m.ct * z;
     float rlon, rlat;
 #if CPOL_INTERP_FAST_SUB
-    if (sub != a.central_sub) {
+    if (short_form) {
         // (radians -> degrees as a product with 180 / pi: a float64 division by a constant is ~25 instructions;
         // the last float64 bit may differ from the quotient's, the float32 cast hides it but for ~1e-8 of the gates)
         // (and the two angles from their short series where the rotated coordinates are small -- every limited-area

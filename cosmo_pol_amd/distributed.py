@@ -327,6 +327,13 @@ class ShardedVolumeRunner(object):
                 'gathered': torch.empty(self.world * nb, dtype=torch.uint8, device=self.device) if gets_all else None,
                 'final': torch.empty(lay.final.nbytes, dtype=torch.uint8, device=self.device) if self.receives else None,
                 'free': None})
+            if self.cuda:
+                # the zero fill runs on torch's current stream; the library stream (non-blocking: not ordered
+                # against it by anything) writes the block next.  The first user of the slot waits for this event
+                # exactly as it waits for the slot's previous scan.
+                filled = torch.cuda.Event()
+                filled.record(torch.cuda.current_stream(self.device))
+                self._slots[-1]['free'] = filled
         return self._slots[i]
 
     def drain(self):

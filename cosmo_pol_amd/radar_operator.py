@@ -56,6 +56,7 @@ class LazyDict(MutableMapping):
     def __init__(self):
         self._make = {}
         self._data = {}             # key -> value, or the sentinel while pending (keeps the insertion order)
+        self._build = threading.Lock()      # two threads reading one pending key: built once, by the first
 
     _PENDING = object()
 
@@ -66,7 +67,10 @@ class LazyDict(MutableMapping):
     def __getitem__(self, key):
         v = self._data[key]
         if v is LazyDict._PENDING:
-            v = self._data[key] = self._make.pop(key)()
+            with self._build:
+                v = self._data[key]
+                if v is LazyDict._PENDING:
+                    v = self._data[key] = self._make.pop(key)()
         return v
 
     def __setitem__(self, key, value):
@@ -239,6 +243,7 @@ class RadarOperator(object):
         self.sequence_memory_budget = None     # bytes of device work buffers ONE launch sequence may need (about 1.2 KB per
                                                # sub-beam gate with six species): a scan beyond it is run as several
                                                # sequences of whole sweeps.  None: a third of the memory free at the time
+        self.debug_flags = 0                   # cpol_sweep_params.debug_flags (tests / tools only: N.DEBUG_EXACT_SUBBEAMS)
         self.lut_dir = lut_dir
         if lut_dir:
             from . import tablecache
@@ -325,6 +330,8 @@ class RadarOperator(object):
             if self._runner is not None:
                 self._runner.drain()
                 self._runner = None
+            for _, r in self.__dict__.pop('_group_runners', {}).values():
+                r.drain()
             self._ctx.close()
             self._ctx = None
             self._pool.close()                # (blocks of results still held are freed with their last view)
@@ -607,6 +614,7 @@ class RadarOperator(object):
                 p.c_spectrum = float(self.constants.WAVELENGTH ** 4
                                      / (np.pi ** 5 * conf['radar']['K_squared'] ** 2))
             p.geometry_mode = mode
+            p.debug_flags = int(self.debug_flags)
             if site is None:
                 re, ke = geo.earth_radius_for_refraction(coords)
                 sin_u1, cos_u1, _ = geo.radar_site_constants(coords)
@@ -662,7 +670,8 @@ class RadarOperator(object):
         # again): ~25 us of attribute traffic per call otherwise, half of what a c2 sweep takes on the device
         if version and paths is None and site is None:
             p, t, keep, doppler, spectrum, varray = self._cached(
-                ('prepared', version, n_gates, range0, mode, bool(apply_sensitivity), want_model, device_outputs is not None),
+                ('prepared', version, n_gates, range0, mode, bool(apply_sensitivity), want_model, device_outputs is not None,
+                 int(self.debug_flags)),
                 prepare, lru=16)
         else:
             p, t, keep, doppler, spectrum, varray = prepare()
@@ -791,7 +800,8 @@ class RadarOperator(object):
             return list(pool.map(one, sweeps))
 
     def _sweep_groups(self, sweeps):
-        """Consecutive sweeps whose launch sequence fits the memory budget (at least one sweep per group)."""
+        """Consecutive sweeps whose launch sequence fits the memory budget (at least one sweep per group).  (`free` counts
+        the work buffers the context holds already, cpol_mem_info: the same scan is grouped the same way on every call.)"""
         free, _, per_gate = self._ctx.mem_info()
         budget = self.sequence_memory_budget if self.sequence_memory_budget is not None else free // 3
         sub = self._cached('sub', lambda: quadrature.subbeams(self.__config))
@@ -826,14 +836,25 @@ class RadarOperator(object):
         """All rays of a sweep on this GPU."""
         return self.simulate_rays(az, el, lane=lane)
 
-    def _dist_runner(self):
-        """The operator's ShardedVolumeRunner (device buffers, the stream of the collectives)."""
-        if self._runner is None:
-            import torch
-            from . import distributed as D
-            self._runner = D.ShardedVolumeRunner(torch.device('cuda', self.device), gather_to=self.gather_to,
-                                                 slots=max(2, self.lanes + 1))
-        return self._runner
+    def _dist_runner(self, group=None):
+        """The operator's ShardedVolumeRunner (device buffers, the stream of the collectives) for the default
+        process group, or one of its own for another `group` (kept until close())."""
+        import torch
+        from . import distributed as D
+        if group is None:
+            if self._runner is None:
+                self._runner = D.ShardedVolumeRunner(torch.device('cuda', self.device), gather_to=self.gather_to,
+                                                     slots=max(2, self.lanes + 1))
+            return self._runner
+        runners = self.__dict__.setdefault('_group_runners', {})
+        if id(group) not in runners:
+            import torch.distributed as dist
+            root = self.gather_to
+            if root is not None:                  # (gather_to names a rank of the default group)
+                root = dist.get_group_rank(group, root) if root in dist.get_process_group_ranks(group) else 0
+            runners[id(group)] = (group, D.ShardedVolumeRunner(torch.device('cuda', self.device), group=group,
+                                                               gather_to=root, slots=max(2, self.lanes + 1)))
+        return runners[id(group)][1]
 
     def _scan_fields(self, fields=None):
         """(name, dtype) of the arrays a distributed scan collects: all of them, or the subset named."""
@@ -849,9 +870,9 @@ class RadarOperator(object):
                 raise ValueError('distributed scans collect %s; %r is not one of them' % (sorted(known), k))
         return [(k, known[k]) for k in fields]
 
-    def submit_volume(self, sweeps, fields=None, lane=0):
+    def submit_volume(self, sweeps, fields=None, lane=0, group=None):
         """Queues a scan [(azimuths, elevations), ...] whose rays are sharded over the ranks of the default
-        torch.distributed group and returns at once: this rank's rays of ALL sweeps in one launch sequence
+        torch.distributed group (or of `group`) and returns at once: this rank's rays of ALL sweeps in one launch sequence
         on lane `lane`, ONE collective behind it (cosmo_pol_amd/distributed.py: all-gather, or a gather to
         rank `gather_to`), the device-to-host copy behind that.  -> PendingVolume: `wait()` gives the list of
         per-sweep result dicts (None on a rank that is not `gather_to`).  `fields`: the arrays to collect
@@ -865,8 +886,8 @@ class RadarOperator(object):
 
         def run_block(a, e, ptrs):
             self.simulate_rays(a, e, device_outputs=ptrs, lane=lane)
-        return self._dist_runner().submit(run_block, ctx.stream_ptr(), sweeps, self._scan_fields(fields), n_gates,
-                                          host_block=self._pool.take)
+        return self._dist_runner(group).submit(run_block, ctx.stream_ptr(), sweeps, self._scan_fields(fields), n_gates,
+                                               host_block=self._pool.take)
 
     def _simulate_volume_sharded(self, sweeps, lane=0):
         """All sweeps of a scan, the rays of every sweep sharded over the ranks (`submit_volume`, then

@@ -39,6 +39,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the cpol_* functions below are its only exported symbols. */
+#if defined(__GNUC__)
+#define CPOL_API __attribute__((visibility("default")))
+#else
+#define CPOL_API
+#endif
+
 typedef struct cpol_ctx cpol_ctx;
 
 enum {
@@ -172,9 +179,15 @@ typedef struct {
     int32_t var_rho;            /* ... of the air density (Doppler scheme 3) or -1 */
     /* Doppler scheme 3 */
     int32_t n_vbins;            /* len(VARRAY) = FFT_length + 1 (global_constants.py:171) */
-    int32_t pad2_;
+    int32_t debug_flags;        /* 0 in production.  CPOL_DEBUG_EXACT_SUBBEAMS (bit 0): the non-central sub-beams take
+                                   the long form of the geodesy the central one takes (5 Vincenty passes, atan2 ->
+                                   degrees -> sincos, correctly rounded division / square root) instead of the short
+                                   form (4 passes, reciprocal roots + Newton, short series): what
+                                   tests/test_gpu_fullsize.py and tools/fast_sub_check.py compare the short form with */
     double  c_spectrum;         /* wavelength^4 / (pi^5 K^2 K^2)  (doppler_scatter.py:709) */
 } cpol_sweep_params;
+
+#define CPOL_DEBUG_EXACT_SUBBEAMS 1
 
 /* ray-path models */
 enum {
@@ -243,54 +256,55 @@ typedef struct {
     int32_t pad_;
 } cpol_counters_t;
 
-int  cpol_create(int device, cpol_ctx **out);
-void cpol_destroy(cpol_ctx *ctx);
+CPOL_API int  cpol_create(int device, cpol_ctx **out);
+CPOL_API void cpol_destroy(cpol_ctx *ctx);
 /* A LANE of `parent`: a context that shares the parent's staged model cube and
  * scattering tables (read-only, no copy) and owns its own HIP stream, work buffers and
  * counters, so that independent sweeps (the elevations of a volume scan, consecutive
  * scans) are in flight together -- the reference runs them one after the other
  * (radar_operator.py:429-432).  Fork after staging; stage calls fail on a lane and on a
  * parent with live lanes; destroy lanes before their parent.  One host thread per lane. */
-int  cpol_fork(cpol_ctx *parent, cpol_ctx **out);
-const char *cpol_last_error(cpol_ctx *ctx);
+CPOL_API int  cpol_fork(cpol_ctx *parent, cpol_ctx **out);
+CPOL_API const char *cpol_last_error(cpol_ctx *ctx);
 /* use an externally created hipStream_t (e.g. torch's current stream); NULL = own stream */
-int  cpol_set_stream(cpol_ctx *ctx, void *hip_stream);
+CPOL_API int  cpol_set_stream(cpol_ctx *ctx, void *hip_stream);
 /* waits for the context's stream.  Also the point where a DEFERRED domain error surfaces:
  * sweeps with outputs_on_device = 1 / 2 return before their kernels ran, so a gate outside
  * the model domain (reference: IndexError, interpolation.py:572-580) sets a sticky error word
  * on the device that stays set over later sweeps until cpol_synchronize or cpol_counters has
  * reported it ONCE as CPOL_ERR_DOMAIN (then it is cleared). */
-int  cpol_synchronize(cpol_ctx *ctx);
+CPOL_API int  cpol_synchronize(cpol_ctx *ctx);
 /* page-locked host memory owned by the context (freed by cpol_host_free / cpol_destroy): the
  * target of outputs_on_device = 2, so that the device-to-host copy of one sweep overlaps the
  * kernels of the next (other lanes) instead of being staged through pageable memory.
  * ctx = NULL: a context-free block owned by the caller until cpol_host_free(NULL, p) -- for host-side
  * pools whose blocks (results handed to the user) must outlive the contexts that filled them; the
  * caller makes sure no copy into the block is in flight when it frees or re-uses it */
-int  cpol_host_alloc(cpol_ctx *ctx, size_t bytes, void **out);
-int  cpol_host_free(cpol_ctx *ctx, void *p);
+CPOL_API int  cpol_host_alloc(cpol_ctx *ctx, size_t bytes, void **out);
+CPOL_API int  cpol_host_free(cpol_ctx *ctx, void *p);
 /* a context-free block as cpol_host_alloc(NULL, ...) gives, taken from the NUMA node next to GPU
  * `device` whatever the calling thread's current device is (one process per GPU on a two-socket host:
  * helper threads have never called hipSetDevice); freed by cpol_host_free(NULL, p) */
-int  cpol_host_alloc_near(int device, size_t bytes, void **out);
+CPOL_API int  cpol_host_alloc_near(int device, size_t bytes, void **out);
 /* "0000:75:00.0" of GPU `device` (len >= 16): /sys/bus/pci/devices/<id>/numa_node and local_cpulist
  * tell a one-process-per-GPU launcher which cores to run the rank on (the reference's pool is not
  * placed at all, radar_operator.py:402) */
-int  cpol_device_pci_bus_id(int device, char *buf, int len);
-/* free and total device memory of the context's GPU in bytes (hipMemGetInfo), and an estimate of
+CPOL_API int  cpol_device_pci_bus_id(int device, char *buf, int len);
+/* free and total device memory of the context's GPU in bytes (hipMemGetInfo; `free_bytes` also counts what the
+ * context's own grow-only work buffers hold already: the room a launch sequence of THIS context has), and an estimate of
  * the work-buffer bytes ONE sub-beam gate of a launch sequence needs with the hydrometeors staged
  * now (`per_gate`: about 1.2 KB with six species): what a caller that packs many sweeps into one
  * cpol_run_sweep call sizes its batches by (the reference processes one radial at a time,
  * radar_operator.py:431) */
-int  cpol_mem_info(cpol_ctx *ctx, size_t *free_bytes, size_t *total_bytes, size_t *per_gate);
+CPOL_API int  cpol_mem_info(cpol_ctx *ctx, size_t *free_bytes, size_t *total_bytes, size_t *per_gate);
 /* the HIP stream (hipStream_t) the context launches on: to order foreign work (copies,
  * collectives) against a sweep with events */
-int  cpol_get_stream(cpol_ctx *ctx, void **hip_stream);
+CPOL_API int  cpol_get_stream(cpol_ctx *ctx, void **hip_stream);
 
 /* data[v] and zlevels: [nz][ny][nx] float32, C order (x = rotated longitude
  * fastest), level 0 = model top; llc = (Lo1, La1), urc = (Lo2, La2), res =
  * (dlon, dlat) as float32; south_pole = (lat, lon) of the rotated south pole. */
-int  cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data,
+CPOL_API int  cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data,
                       const float *zlevels, int nz, int ny, int nx,
                       const float llc[2], const float urc[2], const float res[2],
                       const double south_pole[2]);
@@ -313,10 +327,10 @@ int  cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data,
  * u in [-1, 1] across a panel of log2(lambda): the renormalisation sums of IceParticle.set_psd /
  * integrate_V (hydrometeors.py:1331-1339, 1256-1275) are 1024-term sums that depend on the
  * item's lambda only, not on its LUT slice. */
-int  cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc,
+CPOL_API int  cpol_stage_hydro(cpol_ctx *ctx, int slot, const cpol_hydro_desc *desc,
                       const double *table, const double *pre, const double *dnu,
                       const double *aux, int n_aux);
-int  cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro);
+CPOL_API int  cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro);
 /* Finishes staging: builds the INTEGRAL TABLES now instead of at the first sweep / cpol_fork.
  * For every species whose N(D) has one per-item shape parameter lambda (all gamma-family species,
  * 1-moment ice) the 12 PSD-integrated entries of an item -- what get_N + lookup_line + einsum
@@ -347,7 +361,7 @@ int  cpol_set_num_hydro(cpol_ctx *ctx, int n_hydro);
  * size; RESIDENT tables 0.3 - 0.5 GB per 1-D slot, 1.5 GB per melting slot.
  * Depends on every staged table: call after the last cpol_stage_* (any later staging call
  * invalidates the tables; they are rebuilt on demand). */
-int  cpol_prepare(cpol_ctx *ctx);
+CPOL_API int  cpol_prepare(cpol_ctx *ctx);
 
 /* float32 functions of the gate temperature, TABULATED BY THE HOST over every float32 value
  * in [128 K, 512 K) (2^24 consecutive bit patterns from CPOL_TFUN_FIRST_BITS).  The reference
@@ -362,49 +376,49 @@ int  cpol_prepare(cpol_ctx *ctx);
 enum { CPOL_TFUN_SNOW_N0 = 0, CPOL_TFUN_ICE_MOM2_A = 1, CPOL_N_TFUN = 2 };
 #define CPOL_TFUN_FIRST_BITS 0x43000000u      /* 128.0f */
 #define CPOL_TFUN_COUNT      (1u << 24)       /* every float32 in [128, 512) */
-int  cpol_stage_t_function(cpol_ctx *ctx, int which, const float *table /* [CPOL_TFUN_COUNT] */);
+CPOL_API int  cpol_stage_t_function(cpol_ctx *ctx, int which, const float *table /* [CPOL_TFUN_COUNT] */);
 
 /* Doppler scheme 2 (doppler_scatter.py:283-296): per table slice and diameter bin the
  * trapezoid weight w_k (1/2 at both ends) times the horizontal radar cross-section
  * 2 pi (Z11 - Z12 - Z21 + Z22), and the same times the fall speed V(D_k):
  * weights [n_e][n_t][n_d][2] = (w rcs V, w rcs) float64.  Needed only when
  * cpol_sweep_params.simulate_doppler == 2. */
-int  cpol_stage_doppler_weights(cpol_ctx *ctx, int slot, const double *weights);
+CPOL_API int  cpol_stage_doppler_weights(cpol_ctx *ctx, int slot, const double *weights);
 
 /* Doppler scheme 3: per table slice and diameter bin the float32 horizontal radar cross
  * section 2 pi (Z11 - Z12 - Z21 + Z22) (doppler_scatter.py:686-695), and the float32
  * diameter grid np.linspace(d_min, d_max, n_d) of get_doppler_spectrum with D^mu, D^nu
  * evaluated in float32 (:676-681): dgrid = [3][n_d].  Power-law species only. */
-int  cpol_stage_spectrum_tables(cpol_ctx *ctx, int slot, const float *rcs32, const float *dgrid);
+CPOL_API int  cpol_stage_spectrum_tables(cpol_ctx *ctx, int slot, const float *rcs32, const float *dgrid);
 
 /* gate kernel on explicit points: coords [n][2] (rotated lat, lon) float32,
  * heights [n] float32 -> out [n_vars][n] float32 with the reference's
  * sentinels (-9999 above the model top, NaN below topography). */
-int  cpol_interp_points(cpol_ctx *ctx, int n, const float *coords, const float *heights,
+CPOL_API int  cpol_interp_points(cpol_ctx *ctx, int n, const float *coords, const float *heights,
                         float *out);
 
 /* fills per-ray tables with libm (C callers); Python callers use numpy.
  * traj_out: [n_rays][n_vnodes][CPOL_TRAJ_STRIDE] doubles (el_rad, sin el, cos el, el_deg);
  * geo_out:  [n_rays][n_hnodes][CPOL_GEO_STRIDE] doubles. */
-int  cpol_ray_tables(const cpol_sweep_params *p, const double *az_deg, const double *el_deg,
+CPOL_API int  cpol_ray_tables(const cpol_sweep_params *p, const double *az_deg, const double *el_deg,
                      const double *pts_h_deg, const double *pts_v_deg,
                      double *traj_out, double *geo_out);
 
-int  cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tables_t *tables,
+CPOL_API int  cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tables_t *tables,
                     cpol_outputs *out);
 
 /* CPOL_GEOM_SPACEBORNE helper: index of the first candidate gate below the
  * model-top ceiling for each (ray, vertical node): first_gate [n_rays*n_vnodes]
  * (host buffer).  `traj` [n_rays][n_vnodes][CPOL_TRAJ_STRIDE] and `site`
  * [n_rays][CPOL_SITE_STRIDE] as in cpol_ray_tables_t, n_cand[n_rays] candidate gates. */
-int  cpol_spaceborne_first_gate(cpol_ctx *ctx, const cpol_sweep_params *p, const double *traj,
+CPOL_API int  cpol_spaceborne_first_gate(cpol_ctx *ctx, const cpol_sweep_params *p, const double *traj,
                                 const double *site, const int32_t *n_cand, double ceiling_m,
                                 int32_t *first_gate);
 
-int  cpol_counters(cpol_ctx *ctx, cpol_counters_t *out);
+CPOL_API int  cpol_counters(cpol_ctx *ctx, cpol_counters_t *out);
 /* on = 1: HIP events around every stage of every sweep (7 per sweep); on = 2: only around the
  * PSD x table stage (2 per sweep; ms_psd alone is filled in); on = 0: off */
-int  cpol_enable_timing(cpol_ctx *ctx, int on);
+CPOL_API int  cpol_enable_timing(cpol_ctx *ctx, int on);
 
 /* debug / parity access to intermediate device buffers of the last sweep:
  * "sub_values" float32 [n_vars][n_sbg], "sub_mask" int8 [n_sbg], "sub_elev"
@@ -412,11 +426,11 @@ int  cpol_enable_timing(cpol_ctx *ctx, int on);
  * [n_hydro][n_sbg], "sz_integ" float32 [n_rays*n_gates][n_hydro][12],
  * "traj" float32 [n_rays][n_vnodes][3][n_gates], "item_res" float64
  * [n_hydro][n_sbg][12].  Returns bytes copied or < 0. */
-int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_bytes);
+CPOL_API int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_bytes);
 
 /* test hook: evaluates one of the device math helpers of the melting-species kernel on
  * host arrays (op 0 exp, 1 log, 2 cbrt, 3 cbrt via x^(-1/6), 4 x^(1/6), 5 x^(1/4), 6 1/x) */
-int  cpol_debug_math(cpol_ctx *ctx, int op, const double *x, double *y, int n);
+CPOL_API int  cpol_debug_math(cpol_ctx *ctx, int op, const double *x, double *y, int n);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ def test_cpu_pool_child_reports_every_leg():
 
 def test_stage_roofline_is_recomputable_from_the_committed_profile(tmp_path, monkeypatch):
     """roofline.frac of the bench line = HBM bytes per launch of the committed PMC summary / live
-    duration / 8 TB/s for the dominant stage; hbm_alg_frac = SURVEY 8(d) bytes over the same time."""
+    duration / 8 TB/s for the dominant stage; alg_8d = SURVEY 8(d) bytes over the same time."""
     import bench
     prof = {'_note': 'x',
             'k_psd_lookup(HydroSet, ItabSet, LookupArgs)': {'avg_us': 25.0, 'hbm_bytes': 29.0e6},
@@ -44,12 +44,107 @@ def test_stage_roofline_is_recomputable_from_the_committed_profile(tmp_path, mon
     assert r['stage'] == 'final' and r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert abs(r['traffic'] - 41.0e6) < 1 and abs(r['achieved'] - 41.0e6 / 0.031e-3 / 1e9) < 1e-6
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0 < r['frac'] < 1
-    assert r['algorithmic_bytes_per_launch'] == 180000 * 48
+    assert r['alg_8d']['bytes_per_launch'] == 180000 * 48
     st = r['stages']
-    assert st['psd']['algorithmic_bytes'] == 195751 * bench.LUT_SLICE_BYTES and st['psd']['hbm_alg_frac'] > 1
-    assert st['interp']['algorithmic_bytes'] == 180000 * (4 * 80 * 4 + 9 * 8 * 4)
+    assert st['psd']['algorithmic_bytes_8d'] == 195751 * bench.LUT_SLICE_BYTES and st['psd']['alg_8d_frac'] > 1
+    assert st['interp']['algorithmic_bytes_8d'] == 180000 * (4 * 80 * 4 + 9 * 8 * 4)
     assert st['classify']['traffic'] is None and 'k_itab_fit' not in str(st)
     assert abs(r['whole_sweep']['traffic'] - (29.0e6 + 41.0e6 + 51.0e6)) < 1
+    # the bound that binds: VALU issue = wave instructions x 4 cycles over 1024 SIMDs x 2.4 GHz x the live duration
+    assert r['valu_f64']['bound'] == 'valu_f64' and r['valu_f64']['frac'] is None      # (this canned profile has no SQ counters)
+
+
+def test_valu_issue_fraction():
+    import bench
+    f = bench.valu_issue_frac(5437184.0, 27.56e-6)          # k_gate1_species of profiles/r4_c2_iso_summary.json
+    assert abs(f - 5437184.0 * 4 / (1024 * 2.4e9 * 27.56e-6)) < 1e-12 and 0.3 < f < 0.35
+    assert bench.valu_issue_frac(None, 1.0) is None and bench.valu_issue_frac(1.0, None) is None
+
+
+def _canned_detail():
+    """A full result dict of the default N = 1 run as bench.py builds it (the shape of round 4's 22.6-KB line: nested
+    child runs, per-stage tables, long notes), with a NaN and an Infinity planted."""
+    note = 'x' * 700
+    stages = {st: {'kernels': ['k_' + st], 'live_ms': 0.02, 'profile_us': 21.7, 'traffic': 4.1e7, 'achieved': 1900.0,
+                   'frac': 0.24, 'valu_wave_instructions': 5.4e6, 'valu_frac': 0.33, 'algorithmic_bytes_8d': 9.6e9,
+                   'alg_8d_frac': 43.0} for st in ('interp', 'classify', 'bucket', 'psd', 'final')}
+    roof = {'kernel': 'k_gate1_species', 'stage': 'classify', 'bound': 'hbm', 'achieved': 1013.5684417848793, 'peak': 8000.0,
+            'unit': 'GB/s', 'frac': 0.12669605522310992, 'traffic': 30293837.88679245,
+            'traffic_source': 'profiles/r5_c2_iso_summary.json', 'avg_launch_ms': 0.029888300225138664,
+            'profile_avg_us': 27.56, 'valu_f64': {'bound': 'valu_f64', 'frac': 0.3211, 'wave_instructions_per_launch': 5437184.0,
+                                                  'peak_G_wave_instructions_per_s': 614.4, 'whole_sweep_frac': 0.27},
+            'alg_8d': {'bytes_per_launch': 9621553152, 'frac': 40.2, 'whole_sweep_bytes': 9.9e9, 'whole_sweep_frac': 14.6,
+                       'note': note},
+            'whole_sweep': {'live_ms': 0.0848, 'traffic': 79237393.5, 'frac': 0.1167, 'valu_wave_instructions': 1.25e7,
+                            'valu_frac': 0.24},
+            'timed_region': {'ms_per_sweep': 0.04097689379705116, 'traffic_per_sweep': 79237393.50943395,
+                             'achieved': 1933.709126462293, 'unit': 'GB/s', 'frac': 0.2417, 'valu_frac': 0.497, 'note': note},
+            'stages': stages, 'note': note, 'integrating_kernel': {'note': note, 'frac': float('nan')}}
+    cpu = {'value': 62779.57020777228, 'unit': 'gates/s', 'cores': 1, 'kind': 'port', 'sample': 'y' * 400,
+           'samples_gates_per_s': [60151.5, 62126.8, 62779.5, 63310.1, 70145.7], 'radials_per_s': 125.5, 'host_cpus': 256,
+           'all_cores': {'value': None, 'error': 'z' * 300, 'by_workers': {'16': 1.0e6, '64': None, '256': None}}}
+    child = {'value': 4.8e8, 'unit': 'gates/s', 'n_gpus': 1, 'ms_per_step': 1.865, 'steps': 20, 'warmup': 3, 'scaling': 'weak',
+             'roofline': dict(roof), 'setup_s': {'a': 1.0}, 'stages_ms': {'interp': 0.03}, 'api_ms': {'note': note},
+             'single_sweep_ms': [{'elevation': e, 'device_ms': 0.13} for e in range(5)], 'cpu_baseline': dict(cpu),
+             'workload': 'w' * 300, 'child_wall_s': 18.7, 'command': 'python bench.py --workload c3'}
+    return {
+        'metric': 'range-gates/sec', 'value': 4392719489.463923, 'unit': 'gates/s', 'n_gpus': 1, 'steps': 20, 'warmup': 5,
+        'ms_per_step': 0.3278151503764093, 'ms_per_sweep': 0.04097689379705116, 'sweeps_per_step': 8,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'value_definition': 'v2 ' + 'd' * 150,
+        'config': {'workload': 'c2: step = 8 sweeps per GPU of the 360-az x 500-gate C-band PPI ' + 'w' * 600,
+                   'rays_per_gpu': 360, 'gates_per_ray': 500, 'lanes': 3, 'sweeps_per_step': 8, 'parallelism': 'single GPU',
+                   'small': False},
+        'timed_region_repeats': {'n': 5, 'note': note}, 'roofline': roof,
+        'stages_ms': {'interp': 0.024, 'note': note}, 'counters': {'n_valid_items': 195751},
+        'host_outputs': {'value': 6.9e8, 'unit': 'gates/s', 'ms_per_sweep': 0.26, 'sweeps_timed': 20,
+                         'ms_per_sweep_repeats': [0.64, 0.61, 0.257, 0.258, float('inf')], 'note': note},
+        'value_cached_geometry': 9.6e8, 'refraction2_rhi_90x3_ms': {'note': note},
+        'single_sweep_latency_ms': {'note': note}, 'process_group_backend': None, 'n_ranks_seen_by_rccl': 1,
+        'host_placement': {'note': note}, 'setup_s': {'synthetic_inputs': 2.9}, 'cpu_baseline': cpu,
+        'gpu_over_cpu_core': 69970.5, 'c3': dict(child), 'c4_volume_one_gpu': dict(child, speedup_vs_single_gpu=0.99),
+        'c5': {'error': 'e' * 400}, 'c4_speedup_vs_single_gpu': 0.99, 'c4_speedup_single_volume': 1.0, 'gather_check': None}
+
+
+def test_final_line_is_small_and_complete(tmp_path, capsys):
+    """The line the driver parses (round 4: a 22.6-KB line left BENCH_r04.parsed = null): < 4 KB, strict JSON (no NaN /
+    Infinity), the contract's keys at the top level with `roofline` and `cpu_baseline`, the SURVEY 8(d) step beside
+    `value`; everything else in the side file and on '#detail ' lines BEFORE it."""
+    import bench
+    d = _canned_detail()
+    line = bench.compact_line(d)
+    text = json.dumps(line, allow_nan=False)                 # (raises on NaN / Infinity)
+    assert len(text) < 4096, len(text)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'value_host_outputs',
+              'host_outputs_ms_per_sweep_repeats', 'c4_speedup_vs_single_gpu', 'n_ranks_seen_by_rccl'):
+        assert k in line, k
+    assert line['value'] == 4392720000.0 and line['steps'] == 20 and line['n_gpus'] == 1
+    assert line['config']['workload'].startswith('c2: step = 8 sweeps') and line['config']['lanes'] == 3
+    for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'avg_launch_ms'):
+        assert line['roofline'][k] is not None, k
+    assert line['roofline']['bound'] == 'hbm' and line['roofline']['valu_f64']['bound'] == 'valu_f64'
+    assert abs(line['roofline']['frac'] - line['roofline']['achieved'] / line['roofline']['peak']) < 1e-5
+    assert line['roofline']['timed_region']['frac'] == 0.2417 and line['roofline']['alg_8d']['void'] is True
+    assert set(line['cpu_baseline']) == {'value', 'unit', 'cores', 'kind', 'host_cpus', 'sample'}
+    assert line['cpu_baseline']['cores'] == 1 and line['cpu_baseline']['kind'] == 'port'
+    assert line['host_outputs_ms_per_sweep_repeats'][-1] is None          # the planted Infinity
+    assert line['other_configs']['c5'] == {'error': 'e' * 80} and line['other_configs']['c3']['value'] == 4.8e8
+    # emit(): the side file, the prefixed detail lines, then the compact line LAST
+    path = tmp_path / 'bench_detail.json'
+    bench.emit(d, str(path))
+    out = capsys.readouterr().out.splitlines()
+    assert json.loads(out[-1]) == json.loads(json.dumps(bench.compact_line(d))) and len(out[-1]) < 4096
+    assert all(ln.startswith('#detail ') for ln in out[:-1]) and len(out) > 5
+    assert [ln for ln in out if ln.startswith('{')] == [out[-1]]
+    full = json.loads(path.read_text())
+    assert full['roofline']['stages']['psd']['alg_8d_frac'] == 43.0 and full['c3']['api_ms']['note'] == 'x' * 700
+    assert full['roofline']['integrating_kernel']['frac'] is None          # the planted NaN
+    # a result with absurdly long strings everywhere still fits
+    d['config']['parallelism'] = 'p' * 5000
+    d['roofline']['kernel'] = 'k' * 5000
+    d['cpu_baseline']['sample'] = 's' * 5000
+    assert len(json.dumps(bench.compact_line(d))) < 4096
 
 
 def test_profile_summary_counts_scalar_cache_reads_in_full(tmp_path):

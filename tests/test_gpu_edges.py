@@ -185,3 +185,53 @@ def test_fused_kernel_with_melting_species_equals_the_general_sequence(monkeypat
             assert np.array_equal(out['2'][k], v, equal_nan=True), k
             assert np.array_equal(out['2+interp'][k], v, equal_nan=True), k
     assert np.isfinite(out['0']['RVEL']).sum() > 1000 and np.isfinite(out['0']['ZH']).sum() > 1000
+
+
+def test_sweep_after_a_failed_sweep_equals_a_fresh_context(monkeypatch):
+    """A launch sequence that returns an error AFTER its counting kernel was queued (a failed copy or capture; here:
+    the test hook `fail_next_sweep`) must not leave its counter set half used: the sweep's two counter sets are used
+    in turn and the serial advances only when a sequence is queued completely, so the next sweep would count on top
+    of the stale bucket counts / rare-item totals (round-4 advisor finding; RadarOperator._simulate_sweeps retries on
+    the same context after a MemoryError).  With the counting sort (the counts index the permutation) and with the
+    default direct listing, one and nine sub-beams: the sweep after the failure has the bits and the counters of a
+    sweep on a fresh context."""
+    import bench
+    from cosmo_pol_amd import RadarOperator, synthetic
+    from cosmo_pol_amd._native import NativeError
+    hyds = ('R', 'S', 'G')
+    cube = synthetic.small_test_cube(hydrometeors=hyds)
+    data = {k: v.copy() for k, v in cube['data'].items()}
+    ny, nx = data['QR_v'].shape[1:]
+    yy, xx = np.meshgrid(np.arange(ny), np.arange(nx), indexing='ij')
+    wedge = (xx > nx // 2) & (yy > ny // 2)                     # items outside the tables: the rare-item totals matter too
+    f = data['QR_v']
+    f[:, wedge] = np.where(f[:, wedge] > 0, np.float32(1e-16), 0).astype(np.float32)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
+    az = np.arange(20.0, 70.0, 2.5)
+    el = np.full(len(az), 2.0)
+    keys = ('ZH', 'ZV', 'ZDR', 'KDP', 'RHOHV', 'PHIDP', 'DELTA_HV', 'ATT_H', 'ATT_V', 'RVEL', 'mask')
+    for n_gh in (1, 3):
+        conf = bench.bench_config(True)
+        conf['integration'].update(nh_GH=n_gh, nv_GH=n_gh)
+        for env in ({'CPOL_RARE_DIRECT': '0', 'CPOL_GATE1': '0'}, {}):
+            for k in ('CPOL_RARE_DIRECT', 'CPOL_GATE1'):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
+            op.load_model_arrays(data, cube['zlevels'], cube['proj_info'], cube['resolution'])
+            ref = {k: v.copy() for k, v in op.simulate_rays(az, el).items() if k in keys}
+            c0 = op._ctx.counters()
+            want = (int(c0.n_valid_items), int(c0.n_table_items), int(c0.n_work_units))
+            assert want[0] > want[1] > 0
+            for failures in (1, 2):                             # (an odd and an even number of failed sequences)
+                for _ in range(failures):
+                    assert op._ctx.lib.cpol_debug_read(op._ctx.h, b'fail_next_sweep', None, 0) == 0
+                    with pytest.raises(NativeError, match='fail_next_sweep'):
+                        op.simulate_rays(az, el)
+                got = op.simulate_rays(az, el)
+                c = op._ctx.counters()
+                assert (int(c.n_valid_items), int(c.n_table_items), int(c.n_work_units)) == want, (n_gh, env, failures)
+                for k in keys:
+                    assert np.array_equal(got[k], ref[k], equal_nan=True), (n_gh, env, failures, k)
+            op.close()

@@ -385,3 +385,38 @@ def test_c4_full_volume_equals_the_shares_of_eight_ranks_bitwise():
         n_finite += int(np.isfinite(part['ZH']).sum())
     assert n_finite > 100000
     op.close()
+
+
+def test_short_form_of_the_subbeam_geodesy_keeps_every_cell_index():
+    """The non-central sub-beams take a SHORT form of the geodesy (4 Vincenty passes, Newton reciprocal roots, short
+    atan / asin series: cpol_interp.inl, CPOL_INTERP_FAST_SUB); cpol_sweep_params.debug_flags =
+    CPOL_DEBUG_EXACT_SUBBEAMS sends them through the central sub-beam's long form.  On the C4 sector (45 rays x 49
+    sub-beams x 500 gates, two elevations: 2.2 M sub-beam gates, 4.4 M float32 coordinates) the two forms must agree
+    on every model cell (i0, i1) and every mask -- north_star's "bit-exact for gate/bin indexing" -- and a float32
+    coordinate may differ by one ulp at most; the record of the full volume (44.1 M sub-beam gates) is
+    profiles/r5_fast_sub_check.json (tools/fast_sub_check.py)."""
+    import importlib.util
+    import os
+    from cosmo_pol_amd import RadarOperator
+    spec = importlib.util.spec_from_file_location(
+        'fast_sub_check', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fast_sub_check.py'))
+    fsc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fsc)
+    over = bench.bench_config(False, 'c4')
+    hyds = list(bench.hydrometeors_of('c4'))
+    cube = synthetic.make_cube(hydrometeors=('R', 'S', 'G', 'I'), **synthetic.BENCH_GRID)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar', lanes=1)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    az = np.arange(100.0, 145.0, 1.0)
+    n = 0
+    for e in (1.5, 5.0):
+        r = fsc.compare_sweep(op, az, np.full(len(az), e))
+        assert r['n_subbeam_gates'] == 45 * 49 * 500
+        assert r['b_cells_that_differ'] == 0 and r['b_masks_that_differ'] == 0 and r['c_nan_pattern_differs'] == 0, r
+        assert r['a_max_ulp'] <= 1 and r['a_coordinates_that_differ'] <= 1e-5 * r['n_coordinates'], r
+        assert r['radial_mask_equal']
+        assert max(r['c_worst_relative_change_of_an_output'].values()) < 1e-5, r
+        n += r['n_coordinates']
+    assert n > 4.0e6
+    op.close()

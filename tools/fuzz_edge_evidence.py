@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""Evidence for ONE gate of a fuzz case (tools/fuzz_parity.py) whose Doppler-scheme-3 RVEL differs from the oracle by
+more than the tolerance: is it the 1-ulp flip of a velocity-bin edge that DESIGN.md section 4 describes, or something else?
+
+  python tools/fuzz_edge_evidence.py <n_cases> <seed> <case> [> profiles/r5_fuzz_489.txt]
+
+The case is replayed WITHOUT the sensitivity cut on both sides (a fully censored spectrum hides the bins), the gate
+with the largest RVEL deviation is taken, and for it the record names:
+  * the velocity bins whose power differs between the device and the oracle, and by how much;
+  * for every sub-beam and hydrometeor of the oracle the bin edges next to those velocity bins: the inverted diameter
+    D = (w / alpha)^(1 / beta) as float32 (hex), the float32 quotient q = (D - D_min) / step whose truncation is the
+    table bin (doppler_c.c:11-32), and the distance of q from the nearest integer in float32 ulp of q;
+  * the power ONE table bin at that edge carries (N x rcs x step x radar constant x sub-beam weight), to be compared
+    with the power that moved.
+An edge flip shows as: power moved between two NEIGHBOURING velocity bins, total power of the gate unchanged to
+rounding, |q - integer| of one (sub-beam, hydrometeor) edge within a few ulp, and that bin's power = the power moved."""
+import copy
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tools')):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+
+def f32hex(x):
+    return '0x%08x' % int(np.float32(x).view(np.uint32))
+
+
+def main():
+    n_cases, seed, want = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    import _cases
+    import fuzz_parity
+    from cosmo_pol_amd import RadarOperator, synthetic
+    from cosmo_pol_oracle import beam, scatter
+    from cosmo_pol_oracle import config as ocfg
+    from cosmo_pol_oracle import spectrum as SP
+    from cosmo_pol_oracle import constants as OK
+    for case, over, two, azs, els, cut, nyq in fuzz_parity.draws(n_cases, seed):
+        if case == want:
+            break
+    else:
+        raise SystemExit('no such case')
+    print('case %d of seed %d: doppler scheme %d, microphysics %s, integration %s, az %s, el %s, cut %s, nyquist %s'
+          % (case, seed, over['doppler']['scheme'], over['microphysics'],
+             {k: v for k, v in over['integration'].items() if k != 'antenna_diagram'}, azs, els, cut, nyq))
+    if over['doppler']['scheme'] != 3:
+        raise SystemExit('not a Doppler-spectrum case')
+    conf = ocfg.make_config(over)
+    hl = ocfg.hydrometeor_list(conf)
+    cube = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G', 'I'), two_moment=two, **_cases.gen_golden.CUBE_KW)
+    order = _cases.ORDER_2MOM if two else _cases.ORDER
+    ocube = beam.ModelCube({n: cube['data'][n].copy() for n in order}, cube['zlevels'], cube['proj_info'],
+                           cube['resolution'], order)
+    luts = {h: _cases.synthetic_lut(h, conf['radar']['frequency'], conf['microphysics']['scheme']) for h in hl}
+    olut = {h: _cases.as_oracle_lut(l) for h, l in luts.items()}
+    op = RadarOperator(config=copy.deepcopy(over), luts=luts, output_variables='all', lanes=1)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    res = op.simulate_rays(azs, els, apply_sensitivity=False)
+    varray = SP.velocity_array(conf)
+
+    # record what the oracle's bin sums see, call by call
+    calls = []
+    orig_d, orig_b = SP.diameters_from_radial_velocity, SP.bin_reflectivities
+
+    def rec_d(hyds, limits, varray_, phi, theta, U, V, W, rho):
+        out = orig_d(hyds, limits, varray_, phi, theta, U, V, W, rho)
+        calls.append({'Da': out[0].copy(), 'Db': out[1].copy(), 'idx': out[2].copy(),
+                      'args': (float(phi), float(theta), float(U), float(V), float(W), float(rho)),
+                      'alpha_beta': [(float(h.alpha), float(h.beta)) for h in hyds]})
+        return out
+
+    def rec_b(Da, Db, rcs, N, step_D, D_min):
+        calls[-1].update(rcs=rcs.copy(), N=N.copy(), step=step_D.copy(), dmin=D_min.copy())
+        return orig_b(Da, Db, rcs, N, step_D, D_min)
+    worst = None
+    for r in range(2):
+        subs = beam.interpolate_radial(ocube, conf, azs[r], els[r])
+        del calls[:]
+        SP.diameters_from_radial_velocity, SP.bin_reflectivities = rec_d, rec_b
+        try:
+            o = scatter.radar_observables(subs, olut, conf, return_sz=True, nyquist=nyq)
+        finally:
+            SP.diameters_from_radial_velocity, SP.bin_reflectivities = orig_d, orig_b
+        with np.errstate(invalid='ignore'):
+            d = np.abs(res['RVEL'][r] - o.values['RVEL'])
+        if not np.isfinite(d).any():
+            continue
+        g = int(np.nanargmax(d))
+        if worst is None or d[g] > worst[0]:
+            # calls are made sub-beam by sub-beam over the gates that sub-beam processes
+            per_sub, k = [], 0
+            for sb in subs:
+                gates = [i for i in range(len(sb.dist_profile)) if sb.mask[i] == 0
+                         and (np.isscalar(sb.quad_weight) or sb.quad_weight[i] != 0)]
+                per_sub.append({gi: calls[k + n] for n, gi in enumerate(gates)})
+                k += len(gates)
+            assert k == len(calls), (k, len(calls))
+            worst = (float(d[g]), r, g, o, subs, per_sub)
+    dev, r, g, o, subs, per_sub = worst
+    got_s, ref_s = res['DSPECTRUM'][r][g].astype(np.float64), o.values['DSPECTRUM'][g].astype(np.float64)
+    print('ray %d gate %d: RVEL device %.9g oracle %.9g (deviation %.3g m/s, relative %.3g)'
+          % (r, g, res['RVEL'][r][g], o.values['RVEL'][g], dev, dev / max(abs(o.values['RVEL'][g]), 1e-30)))
+    print('spectrum power of the gate: device %.12g oracle %.12g (relative difference %.3g)'
+          % (np.nansum(got_s), np.nansum(ref_s), abs(np.nansum(got_s) - np.nansum(ref_s)) / max(np.nansum(ref_s), 1e-300)))
+    diff = got_s - ref_s
+    tol = 1e-6 * np.nanmax(ref_s) + 2e-5 * np.abs(ref_s)
+    bins = np.where(np.abs(diff) > tol)[0]
+    print('velocity bins whose power differs (of %d): %s' % (len(varray), bins.tolist()))
+    for b in bins:
+        print('   bin %d  v = %.6f m/s  device %.9g  oracle %.9g  device - oracle %+.9g' % (b, varray[b], got_s[b], ref_s[b], diff[b]))
+    if len(bins) == 2 and abs(bins[0] - bins[1]) == 1:
+        print('   -> power moved between two NEIGHBOURING bins: %+.9g and %+.9g (sum %.3g)' % (diff[bins[0]], diff[bins[1]], diff[bins].sum()))
+    if len(bins) == 0:
+        print('   (no bin above the tolerance: the deviation of RVEL is not an edge flip)')
+        return
+    const = OK.Derived(conf).WAVELENGTH ** 4 / (np.pi ** 5 * conf['radar']['K_squared'] ** 2)
+    moved = float(np.max(np.abs(diff[bins])))
+    print('edges next to those bins, per sub-beam and hydrometeor (oracle side); the power that moved: %.9g' % moved)
+    cands = []
+    for s, (sb, by_gate) in enumerate(zip(subs, per_sub)):
+        c = by_gate.get(g)
+        if c is None:
+            continue
+        w = sb.quad_weight if np.isscalar(sb.quad_weight) else sb.quad_weight[g]
+        idx = c['idx']
+        for row in range(len(idx)):
+            if not (idx[row] in bins or idx[row] + 1 in bins):
+                continue
+            for j in range(c['Da'].shape[1]):
+                for name, D in (('Da', c['Da'][row, j]), ('Db', c['Db'][row, j])):
+                    q = np.float32((np.float32(D) - c['dmin'][j]) / c['step'][j])
+                    ulp = float(np.spacing(np.float32(abs(q)))) if q != 0 else 1e-45
+                    dist = abs(float(q) - round(float(q))) / ulp
+                    b = int(q)
+                    if 0 <= b < c['N'].shape[0]:
+                        p_bin = float(np.float32(c['N'][b, j]) * np.float32(c['rcs'][b, j]) * c['step'][j]) * const * float(w)
+                    else:
+                        p_bin = float('nan')
+                    cands.append((dist, s, row, j, name, D, q, b, p_bin, float(w)))
+    cands.sort(key=lambda t: t[0])
+    for dist, s, row, j, name, D, q, b, p_bin, w in cands[:6]:
+        print('   sub-beam %2d (weight %.6g) hydrometeor %d velocity row %d %s: D = %.9g (%s)  q = (D - D_min) / step = %.9g (%s)'
+              '  -> table bin %d;  |q - integer| = %.2f ulp of q;  power of that table bin in this sub-beam (unattenuated): %.9g'
+              % (s, w, j, row, name, D, f32hex(D), q, f32hex(q), b, dist, p_bin))
+    if cands:
+        best = cands[0]
+        verdict = ('EDGE FLIP: the quotient of one (sub-beam, hydrometeor) edge lies within %.2f float32 ulp of an integer and its '
+                   'table bin carries %.3g of the %.3g that moved' % (best[0], best[8], moved)) if best[0] <= 4.0 else \
+                  'NOT explained by an edge within 4 ulp of an integer: nearest is %.1f ulp away' % best[0]
+        print(verdict)
+    op.close()
+
+
+if __name__ == '__main__':
+    main()

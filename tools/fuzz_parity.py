@@ -47,6 +47,18 @@ def draw(rng):
     return over, two
 
 
+def draws(n_cases, seed):
+    """The random draws of every case in order (what `only_case` and tools/fuzz_edge_evidence.py replay)."""
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        over, two = draw(rng)
+        azs = rng.uniform(0, 360, 2)
+        els = rng.uniform(0.5, 30, 2)
+        cut = bool(rng.random() < 0.5)
+        nyq = float(rng.uniform(0.5, 6.0)) if rng.random() < 0.3 else None
+        yield case, over, two, azs, els, cut, nyq
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -55,10 +67,8 @@ def main():
     from cosmo_pol_amd import RadarOperator, synthetic
     from cosmo_pol_oracle import beam, scatter
     from cosmo_pol_oracle import config as ocfg
-    rng = np.random.default_rng(seed)
     cubes = {}
-    for case in range(n_cases):
-        over, two = draw(rng)
+    for case, over, two, azs, els, cut, nyq in draws(n_cases, seed):
         conf = ocfg.make_config(over)
         hl = ocfg.hydrometeor_list(conf)
         if two not in cubes:
@@ -72,10 +82,6 @@ def main():
         luts = {h: _cases.synthetic_lut(h, conf['radar']['frequency'], conf['microphysics']['scheme'])
                 for h in hl}
         olut = {h: _cases.as_oracle_lut(l) for h, l in luts.items()}
-        azs = rng.uniform(0, 360, 2)
-        els = rng.uniform(0.5, 30, 2)
-        cut = bool(rng.random() < 0.5)
-        nyq = float(rng.uniform(0.5, 6.0)) if rng.random() < 0.3 else None
         if only is not None and case != only:
             continue
         if nyq is not None:
