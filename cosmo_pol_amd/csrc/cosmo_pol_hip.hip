@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <time.h>
 #include <string.h>
 #include <string>
 #include <type_traits>
@@ -83,7 +84,7 @@ struct cpol_ctx {
         d_aux[CPOL_MAX_HYDRO], d_rcsw[CPOL_MAX_HYDRO], d_rcs32[CPOL_MAX_HYDRO], d_dgrid[CPOL_MAX_HYDRO];
     bool hydro_staged[CPOL_MAX_HYDRO] = {};
     // integral tables (built on the device by build_itabs after staging; lanes share the parent's)
-    DevBuf d_itab[CPOL_MAX_HYDRO], d_itab_head[CPOL_MAX_HYDRO], d_itab_M;
+    DevBuf d_itab[CPOL_MAX_HYDRO], d_itab_head[CPOL_MAX_HYDRO], d_itab_M, d_itab_M1;
     std::vector<ItabCacheEntry> itab_cache;
     std::vector<TableCacheEntry> table_cache;  // staged scattering tables with a table_id
     uint64_t table_clock = 0;
@@ -153,6 +154,10 @@ struct cpol_ctx {
     int subsum_coop = -1;              // CPOL_SUBSUM_COOP: k_subbeam_sum takes its coefficients through the scalar cache: 0 never, 1 always, -1 by launch size
     bool last_subsum = false;          // the 1-D table items of the last sweep never went through res[] (k_subbeam_sum)
     bool keep_debug = false;
+    // host time of cpol_run_sweep by section (ns, summed; cpol_debug_read "host_times"): [0] calls, [1] per-ray tables
+    // (staging memcpy + the H2D copy call), [2] work-buffer checks / allocations, [3] kernel launches, [4] the
+    // device-to-host copy call(s), [5] everything
+    double host_ns[6] = {0, 0, 0, 0, 0, 0};
     bool fail_next = false;            // test hook (cpol_debug_read "fail_next_sweep"): the next launch sequence returns an error
                                        // after its kernels are queued, as a failed copy or capture would
     // sticky domain-error word (device): OR-ed by the kernels of every sweep, cleared only
@@ -249,27 +254,35 @@ int build_itabs(cpol_ctx *ctx)
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int n_hyd = ctx->hs.n_hydro;
-    constexpr int NC = CPOL_ITAB_NC;
-    // M[pw][q] = sum_n c2m[n][pw] w_n T_n(x_q): node values -> monomial coefficients
-    {
-        long double T[NC][NC] = {};                       // T[n][pw]: monomial coefficients of T_n
-        T[0][0] = 1.0L;
-        if (NC > 1) T[1][1] = 1.0L;
-        for (int n = 2; n < NC; ++n)
-            for (int pw = 0; pw < NC; ++pw)
-                T[n][pw] = (pw > 0 ? 2.0L * T[n - 1][pw - 1] : 0.0L) - T[n - 2][pw];
+    constexpr int NC = CPOL_ITAB_NC, NC1 = CPOL_ITAB1_NC;
+    // M[pw][q] = sum_n c2m[n][pw] w_n T_n(x_q): node values -> monomial coefficients, for n nodes:
+    // out = [M | Tm (nodes -> Chebyshev) | C2M (T_n -> monomials)], each [n][n]
+    auto basis_matrices = [](int n, std::vector<double> &out) {
+        std::vector<long double> T((size_t)n * n, 0.0L);          // T[k][pw]: monomial coefficients of T_k
+        T[0] = 1.0L;
+        if (n > 1) T[(size_t)n + 1] = 1.0L;
+        for (int k = 2; k < n; ++k)
+            for (int pw = 0; pw < n; ++pw)
+                T[(size_t)k * n + pw] = (pw > 0 ? 2.0L * T[(size_t)(k - 1) * n + pw - 1] : 0.0L) - T[(size_t)(k - 2) * n + pw];
         const long double pi = 3.141592653589793238462643383279502884L;
-        double M[3 * NC * NC];                             // M | Tm (nodes -> Chebyshev) | C2M (T_n -> monomials)
-        for (int pw = 0; pw < NC; ++pw)
-            for (int q = 0; q < NC; ++q) {
+        out.assign((size_t)3 * n * n, 0.0);
+        for (int pw = 0; pw < n; ++pw)
+            for (int q = 0; q < n; ++q) {
                 long double acc = 0.0L;
-                for (int n = 0; n < NC; ++n)
-                    acc += T[n][pw] * (n == 0 ? 1.0L : 2.0L) / NC * cosl(pi * n * (q + 0.5L) / NC);
-                M[pw * NC + q] = (double)acc;
-                M[NC * NC + pw * NC + q] = (double)((pw == 0 ? 1.0L : 2.0L) / NC * cosl(pi * pw * (q + 0.5L) / NC));
-                M[2 * NC * NC + pw * NC + q] = (double)T[pw][q];
+                for (int k = 0; k < n; ++k)
+                    acc += T[(size_t)k * n + pw] * (k == 0 ? 1.0L : 2.0L) / n * cosl(pi * k * (q + 0.5L) / n);
+                out[(size_t)pw * n + q] = (double)acc;
+                out[(size_t)n * n + pw * n + q] = (double)((pw == 0 ? 1.0L : 2.0L) / n * cosl(pi * pw * (q + 0.5L) / n));
+                out[(size_t)2 * n * n + pw * n + q] = (double)T[(size_t)pw * n + q];
             }
-        int rc = upload(ctx, ctx->d_itab_M, M, sizeof M);
+    };
+    {
+        std::vector<double> M2, M1;
+        basis_matrices(NC, M2);                                    // 2-D blocks (k_itab_fit2: Tm, C2M)
+        basis_matrices(NC1, M1);                                   // 1-D blocks (k_itab_fit: M)
+        int rc = upload(ctx, ctx->d_itab_M, M2.data(), M2.size() * sizeof(double));
+        if (rc != CPOL_OK) return rc;
+        rc = upload(ctx, ctx->d_itab_M1, M1.data(), M1.size() * sizeof(double));
         if (rc != CPOL_OK) return rc;
         HIPCHK(hipStreamSynchronize(st));
     }
@@ -325,7 +338,7 @@ int build_itabs(cpol_ctx *ctx)
         const int upers = (n_pan * per_block + unit_items - 1) / unit_items;
         const long n_units = (long)n_slices * upers;
         if (n_items >= (1L << 31)) continue;
-        const size_t tab_bytes = (size_t)n_slices * n_pan * (melt ? CPOL_ITAB2_NB : NC) * CPOL_ITAB_NFP * sizeof(double);
+        const size_t tab_bytes = (size_t)n_slices * n_pan * (melt ? CPOL_ITAB2_NB : NC1) * CPOL_ITAB_NFP * sizeof(double);
         DevBuf b_par, b_perm, b_units, b_tot, b_res, b_vn, b_det;
         std::vector<unsigned long long> det_bits;
         int rc;
@@ -440,7 +453,7 @@ int build_itabs(cpol_ctx *ctx)
         } else {
             ItabFitArgs fa{};
             fa.res = (const double *)b_res.p; fa.vn = (const double *)b_vn.p; fa.par = (const double *)b_par.p;
-            fa.M = (const double *)ctx->d_itab_M.p; fa.tab = (double *)dst_tab.p;
+            fa.M = (const double *)ctx->d_itab_M1.p; fa.tab = (double *)dst_tab.p;
             fa.n_items = n_items; fa.n_slices = n_slices; fa.n_pan = n_pan; fa.log2_lo = lo; fa.d0 = gamma ? d0 : 0.0;
             fa.worst = (unsigned long long *)b_tot.p + 3;
             fa.n_bad = (unsigned int *)((unsigned long long *)b_tot.p + 4);
@@ -604,7 +617,7 @@ void cpol_destroy(cpol_ctx *ctx)
         for (auto &b : ctx->d_tfun) b = DevBuf();
         for (auto &b : ctx->d_itab) b = DevBuf();
         for (auto &b : ctx->d_itab_head) b = DevBuf();
-        ctx->d_itab_M = DevBuf();
+        ctx->d_itab_M = DevBuf(); ctx->d_itab_M1 = DevBuf();
         ctx->parent->n_children -= 1;
     }
     for (auto &b : ctx->d_tfun) free_buf(b);
@@ -615,6 +628,7 @@ void cpol_destroy(cpol_ctx *ctx)
     for (auto &e : ctx->table_cache) free_buf(e.buf);
     ctx->table_cache.clear();
     free_buf(ctx->d_itab_M);
+    free_buf(ctx->d_itab_M1);
     for (int i = 0; i < 3; ++i) {
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
         if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
@@ -1194,6 +1208,13 @@ int cpol_ray_tables(const cpol_sweep_params *p, const double *az_deg, const doub
     return CPOL_OK;
 }
 
+static inline double now_ns()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e9 + (double)ts.tv_nsec;
+}
+
 static int copy_out(cpol_ctx *ctx, void *dst, const void *src, size_t bytes, bool dst_on_device)
 {
     if (!dst) return CPOL_OK;
@@ -1213,6 +1234,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ctx->err = "cpol_run_sweep: model / hydrometeors not staged or bad arguments";
         return CPOL_ERR_ARG;
     }
+    const double t_enter = now_ns();
     (void)hipGetLastError();            // a stale error of another user of the runtime in this thread is not ours
     for (int j = 0; j < ctx->hs.n_hydro; ++j)
         if (!ctx->hydro_staged[j]) { ctx->err = "cpol_run_sweep: hydrometeor slot not staged"; return CPOL_ERR_ARG; }
@@ -1315,6 +1337,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         set->version = t->version;
         memcpy(set->shape, shape, sizeof shape);
     }
+    const double t_tables = now_ns();
     // ---- work buffers ----
     // several sub-beams: the ray paths (shared by the horizontal nodes of a vertical node) and the per-ray
     // constants of the geodesic come from k_trajectory instead of once per sub-beam gate
@@ -2063,6 +2086,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     return CPOL_OK;
     };
 
+    const double t_buffers = now_ns();
     ctx->counters_dirty = true;         // until the sequence is queued completely (cleared where sweep_serial advances)
     // graph key: every value that ends up in a kernel argument
     const bool graphable = ctx->use_graph && dev && !tm_psd && !ctx->keep_debug && mode != CPOL_GEOM_HOST_PATHS &&
@@ -2108,6 +2132,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         if ((rc = launch_all()) != CPOL_OK) return rc;
     }
 
+    const double t_launched = now_ns();
     if (ctx->fail_next) {
         ctx->fail_next = false;
         ctx->err = "cpol_run_sweep: failure requested by the test hook (fail_next_sweep)";
@@ -2123,6 +2148,15 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         }
     }
 
+    {
+        const double t_done = now_ns();
+        ctx->host_ns[0] += 1.0;
+        ctx->host_ns[1] += t_tables - t_enter;
+        ctx->host_ns[2] += t_buffers - t_tables;
+        ctx->host_ns[3] += t_launched - t_buffers;
+        ctx->host_ns[4] += t_done - t_launched;
+        ctx->host_ns[5] += t_done - t_enter;
+    }
     ctx->last_n_sbg = n_sbg; ctx->last_n_rg = n_rg; ctx->last_n_rays = n_rays;
     ctx->last_n_gates = ng; ctx->last_n_sub = n_sub; ctx->last_n_v = n_v;
     ctx->last_par = par;
@@ -2246,6 +2280,13 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     if (!strcmp(name, "enable")) { ctx->keep_debug = true; return 0; }
     if (!strcmp(name, "disable")) { ctx->keep_debug = false; return 0; }
     if (!strcmp(name, "fail_next_sweep")) { ctx->fail_next = true; return 0; }
+    if (!strcmp(name, "host_times")) {
+        // host time of cpol_run_sweep by section since the last read (see cpol_ctx::host_ns); reading resets
+        if (!dst || max_bytes < (int64_t)sizeof ctx->host_ns) return CPOL_ERR_ARG;
+        memcpy(dst, ctx->host_ns, sizeof ctx->host_ns);
+        for (double &v : ctx->host_ns) v = 0.0;
+        return (int64_t)sizeof ctx->host_ns;
+    }
     if (!strcmp(name, "cache")) {
         // [integral-table cache entries, scattering-table cache entries, integral-table builds] (table_id)
         const cpol_ctx *own = ctx->parent ? ctx->parent : ctx;

@@ -67,11 +67,21 @@ struct SpecSet {
 // lambda): F_c is evaluated ONCE per (LUT slice, 1/8-octave panel of lambda, Chebyshev node) by
 // the PSD kernels themselves and stored as degree-10 polynomials in the position inside the panel;
 // a sweep then gathers 15 x 11 coefficients per item instead of integrating 1024 diameter bins.
-#define CPOL_ITAB_DEGREE 10
+#define CPOL_ITAB_DEGREE 10      // 2-D blocks (melting species): total degree of the polynomial in (u, w)
 #define CPOL_ITAB_NC     (CPOL_ITAB_DEGREE + 1)
+// 1-D blocks: degree of the polynomial in the panel position and panels per octave of lambda.  What a sweep pays per item
+// is (degree + 1) rows of 128 B gathered and `degree` Horner steps of 12 (14) chains; what the table costs is
+// panels x (degree + 1) rows.  Measured pairs that pass the 1e-10 gate on every table of the bench, the goldens and
+// the Mie sets: see DESIGN.md 3.4 / profiles/r5_itab1_degree.txt (make EXTRA="-DCPOL_ITAB1_DEGREE=.. -DCPOL_ITAB_PPO=..").
+#ifndef CPOL_ITAB1_DEGREE
+#define CPOL_ITAB1_DEGREE 10
+#endif
+#define CPOL_ITAB1_NC    (CPOL_ITAB1_DEGREE + 1)
 #define CPOL_ITAB_NF     15      // 12 columns, 2 Doppler sums (v, n), ice: normalised N0 (Doppler spectrum)
 #define CPOL_ITAB_NFP    16      // functions per coefficient row (padded: one row = 128 B)
-#define CPOL_ITAB_PPO    8       // panels per octave of lambda
+#ifndef CPOL_ITAB_PPO
+#define CPOL_ITAB_PPO    8       // panels per octave of lambda (1-D blocks)
+#endif
 // Every 1-D block is verified when it is built: two more items per (slice, panel), at the off-node
 // positions CPOL_ITAB1_CHECK_U (mid-panel: T_11(0.37) = 0.86 of the nodal polynomial's maximum) and
 // CPOL_ITAB1_CHECK_U2 (between the last two Chebyshev nodes, where the interpolation error of a function
@@ -79,7 +89,7 @@ struct SpecSet {
 // integrated by the same kernel and compared with the polynomial, function by function, on the scale of
 // the function over the block (end of k_itab_fit).  A slot whose worst deviation reaches
 // CPOL_ITAB_MAX_DEVIATION keeps its items on the integrating kernels.
-#define CPOL_ITAB1_NODES (CPOL_ITAB_NC + 2)
+#define CPOL_ITAB1_NODES (CPOL_ITAB1_NC + 2)
 #define CPOL_ITAB1_CHECK_U 0.37
 #define CPOL_ITAB1_CHECK_U2 0.96      // ~cos(pi / 11): the extremum of T_11 between the last two nodes
 #define CPOL_ITAB_MAX_DEVIATION 1e-10
@@ -92,7 +102,9 @@ struct SpecSet {
 // Chebyshev interpolant with the terms T_a(u) T_b(w), a + b > 10, dropped (their coefficients are of
 // the size of the 1-D tails), converted to monomials u^a w^b, a + b <= 10: 66 rows of 128 B, the
 // rows of w^b (a = 0 .. 10 - b) at row CPOL_ITAB2_ROW(b).
+#ifndef CPOL_ITAB2_PPO
 #define CPOL_ITAB2_PPO   4
+#endif
 #define CPOL_ITAB2_NB    (CPOL_ITAB_NC * (CPOL_ITAB_NC + 1) / 2)       // coefficient rows per block
 #define CPOL_ITAB2_ROW(b) ((b) * CPOL_ITAB_NC - (b) * ((b) - 1) / 2)
 #define CPOL_ITAB2_NODES (CPOL_ITAB_NC * CPOL_ITAB_NC + 1)              // build items per block: the nodes + 1 check point
@@ -101,7 +113,7 @@ struct SpecSet {
 #define CPOL_ITAB2_MAX_DEVIATION CPOL_ITAB_MAX_DEVIATION   // accepted |polynomial - integrating kernel| / |value| at the check points (measured on
                                          // the full-size tables: 1.7e-12, in a column that nearly cancels at 88 deg elevation)
 struct ItabDev {
-    const double *tab;     // 1-D: [n_slices][n_pan][CPOL_ITAB_NC][CPOL_ITAB_NFP] monomial coefficients (power-major:
+    const double *tab;     // 1-D: [n_slices][n_pan][CPOL_ITAB1_NC][CPOL_ITAB_NFP] monomial coefficients (power-major:
                            //   one 128-B row holds the coefficient of u^q of all functions), or NULL
                            // 2-D: [n_slices][n_pan][CPOL_ITAB2_NB rows (w^b u^a, a + b <= 10)][CPOL_ITAB_NFP]
     const double *head;    // 2-D: [n_t][2] centre and 1 / half-width of the wet-fraction bins

@@ -321,7 +321,7 @@ __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabS
 {
     constexpr bool COOP = FORM != SUBSUM_GATHER;
     static_assert(CPOL_SUBSUM_THREADS == CPOL_WAVE, "one wavefront per workgroup: the tile walk uses wave-wide ballots");
-    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
+    constexpr int NC = CPOL_ITAB1_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
     constexpr int NP = CPOL_N_SZ / 2 / SPLIT;                            // double2 column pairs of this thread
     static_assert(NP * SPLIT * 2 == CPOL_N_SZ, "SPLIT must divide 6");
     const long n_rg = (long)a.n_rays * a.n_gates;
@@ -409,13 +409,16 @@ __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabS
             // buffers: the pieces of the NEXT block -- of this sub-beam, or the first one of the next sub-beam with
             // work -- are requested before the Horner chains / the accumulation of the current one start. ----
             if constexpr (FORM == SUBSUM_LDS) {
-            __shared__ double2 s_blk[2][NC * NFP / 2];
-            constexpr int REST = NC * NFP / 2 - CPOL_WAVE;
+            constexpr int PIECES = NC * NFP / 2;          // 16-byte pieces of a block (88 at degree 10, 56 at degree 6)
+            __shared__ double2 s_blk[2][PIECES > CPOL_WAVE ? PIECES : CPOL_WAVE];
+            constexpr int REST = PIECES - CPOL_WAVE;
             // the 88 pieces of block `blk` straight from global memory into s_blk[bufi] (global_load_lds_dwordx4:
             // no vector registers in between); their arrival is awaited with s_waitcnt vmcnt(0) before the first read
             auto request = [&](int blk, int bufi) {
                 const double2 *src = reinterpret_cast<const double2 *>(t.tab + (long)blk * NB);
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + lane),
+                // (a block shorter than a wavefront: the lanes beyond it fetch its last piece again, into the buffer's
+                // tail, which nobody reads -- every lane of the instruction writes its own 16-byte slot of LDS)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + (PIECES >= CPOL_WAVE ? lane : min(lane, PIECES - 1))),
                                                  (void __attribute__((address_space(3))) *)s_blk[bufi], 16, 0, 0);
                 if (lane < REST)
                     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + CPOL_WAVE + lane),
@@ -777,7 +780,7 @@ __device__ __forceinline__ void final_gate(const FinalArgs &a, const ItabSet &it
                     const double u = 2.0 * (rc.x - (double)pn) - 1.0;
                     // (itab1_columns with the rows requested CPOL_FINAL_ROW_UNROLL at a time: all 66 loads in
                     // flight at once need 264 VGPRs)
-                    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
+                    constexpr int NC = CPOL_ITAB1_NC, NFP = CPOL_ITAB_NFP;
                     const double2 *blk = reinterpret_cast<const double2 *>(
                         t.tab + ((long)(key - a.key_base[j]) * t.n_pan + pn) * (NC * NFP));
 #pragma unroll

@@ -71,7 +71,7 @@ template <bool TWO_D, bool INTERP>
 __device__ __forceinline__ void gate1_body(const ModelDev &m, const InterpArgs &ia, float *sv, const HydroSet &hs, const ItabSet &its,
                                            const ClassifyArgs &a, const FinalArgs &f, const GateArgs &g)
 {
-    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
+    constexpr int NC = CPOL_ITAB1_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;      // (1-D blocks)
     __shared__ double s_walk[TWO_D ? CPOL_GATE1_THREADS / CPOL_WAVE : 1][TWO_D ? CPOL_WAVE : 1][CPOL_N_SZ + 2];   // 2-D walk: item -> its lane
     __shared__ int s_lookup;
     if (threadIdx.x == 0) s_lookup = 0;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_interp_g
 #endif
 __global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_species(HydroSet hs, ItabSet its, ClassifyArgs a, FinalArgs f, GateArgs g)
 {
-    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
+    constexpr int NC = CPOL_ITAB1_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
     extern __shared__ unsigned char s_raw[];
     const int n_h = hs.n_hydro;
     float *s_acc = reinterpret_cast<float *>(s_raw);                                   // [n_h][12][64]

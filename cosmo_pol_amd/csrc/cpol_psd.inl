@@ -1638,7 +1638,7 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS, 4) void k_psd_ice2(HydroSet hs, P
 // [2^(lo + p/PPO), 2^(lo + (p+1)/PPO)] on the log2(lambda) axis.
 __device__ __forceinline__ double itab_node_lambda(double log2_lo, int p, int q)
 {
-    const double x = cos(3.14159265358979323846 * ((double)q + 0.5) / (double)CPOL_ITAB_NC);
+    const double x = cos(3.14159265358979323846 * ((double)q + 0.5) / (double)CPOL_ITAB1_NC);
     return exp2(log2_lo + ((double)p + (x + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
 }
 
@@ -1695,8 +1695,8 @@ __global__ void k_itab_nodes(ItabBuildArgs b)
     }
     {
         const int p = r / CPOL_ITAB1_NODES, q = r % CPOL_ITAB1_NODES;      // q >= NC: the block's two check points
-        const double uc = q == CPOL_ITAB_NC ? CPOL_ITAB1_CHECK_U : CPOL_ITAB1_CHECK_U2;
-        b.par[i] = q < CPOL_ITAB_NC ? itab_node_lambda(b.log2_lo, p, q)
+        const double uc = q == CPOL_ITAB1_NC ? CPOL_ITAB1_CHECK_U : CPOL_ITAB1_CHECK_U2;
+        b.par[i] = q < CPOL_ITAB1_NC ? itab_node_lambda(b.log2_lo, p, q)
                                     : exp2(b.log2_lo + ((double)p + (uc + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
     }
     b.par[b.n_items + i] = 1.0;             // N0
@@ -1710,8 +1710,8 @@ struct ItabFitArgs {
     const double *res;         // [n_items][12]
     const double *vn;          // [n_items][2]
     const double *par;         // [CPOL_MAX_PAR][n_items] (slot 3: ice normalised N0)
-    const double *M;           // [NC][NC]
-    double *tab;               // [n_slices][n_pan][NF][NC]
+    const double *M;           // [NC1][NC1] (NC1 = CPOL_ITAB1_NC)
+    double *tab;               // [n_slices][n_pan][NC1][NFP]
     long n_items;
     int n_slices, n_pan;
     double log2_lo, d0;
@@ -1739,22 +1739,22 @@ __global__ void k_itab_fit(ItabFitArgs f)
         if (f.d0 != 0.0) x *= exp(lambda * f.d0);
         return x;
     };
-    double v[CPOL_ITAB_NC];
+    double v[CPOL_ITAB1_NC];
     double scale = 0.0;
     bool nan = false;
 #pragma unroll
-    for (int q = 0; q < CPOL_ITAB_NC; ++q) {
+    for (int q = 0; q < CPOL_ITAB1_NC; ++q) {
         v[q] = value(q, itab_node_lambda(f.log2_lo, p, q));
         nan = nan || !(v[q] == v[q]);
         scale = fmax(scale, fabs(v[q]));
     }
-    double *o = f.tab + blk * (CPOL_ITAB_NC * CPOL_ITAB_NFP) + fn;
-    double c[CPOL_ITAB_NC];
+    double *o = f.tab + blk * (CPOL_ITAB1_NC * CPOL_ITAB_NFP) + fn;
+    double c[CPOL_ITAB1_NC];
 #pragma unroll
-    for (int pw = 0; pw < CPOL_ITAB_NC; ++pw) {
+    for (int pw = 0; pw < CPOL_ITAB1_NC; ++pw) {
         double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < CPOL_ITAB_NC; ++q) acc = fma(f.M[pw * CPOL_ITAB_NC + q], v[q], acc);
+        for (int q = 0; q < CPOL_ITAB1_NC; ++q) acc = fma(f.M[pw * CPOL_ITAB1_NC + q], v[q], acc);
         c[pw] = acc;
         o[pw * CPOL_ITAB_NFP] = acc;
         if (fn == CPOL_ITAB_NF - 1) o[pw * CPOL_ITAB_NFP + 1] = 0.0;     // padding column
@@ -1765,11 +1765,11 @@ __global__ void k_itab_fit(ItabFitArgs f)
     // false alarm, while node values that are rounding noise of a cancelling sum do ----
     const double lam_c = exp2(f.log2_lo + ((double)p + (CPOL_ITAB1_CHECK_U + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
     const double lam_e = exp2(f.log2_lo + ((double)p + (CPOL_ITAB1_CHECK_U2 + 1.0) * 0.5) / (double)CPOL_ITAB_PPO);
-    const double ref = value(CPOL_ITAB_NC, lam_c), ref_e = value(CPOL_ITAB_NC + 1, lam_e);
+    const double ref = value(CPOL_ITAB1_NC, lam_c), ref_e = value(CPOL_ITAB1_NC + 1, lam_e);
     scale = fmax(scale, fmax(fabs(ref), fabs(ref_e)));
-    double got = c[CPOL_ITAB_NC - 1], got_e = c[CPOL_ITAB_NC - 1];
+    double got = c[CPOL_ITAB1_NC - 1], got_e = c[CPOL_ITAB1_NC - 1];
 #pragma unroll
-    for (int q = CPOL_ITAB_NC - 2; q >= 0; --q) {
+    for (int q = CPOL_ITAB1_NC - 2; q >= 0; --q) {
         got = fma(got, CPOL_ITAB1_CHECK_U, c[q]);
         got_e = fma(got_e, CPOL_ITAB1_CHECK_U2, c[q]);
     }
@@ -1963,7 +1963,7 @@ __device__ __forceinline__ double itab2_quarter_sum(const double (&rows)[CPOL_IT
 // the 12 integrated columns of an item from its 1-D block (c) at panel position u, times its scale
 __device__ __forceinline__ void itab1_columns(const double2 *c, double u, double scale, double2 (&v)[CPOL_N_SZ / 2])
 {
-    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
+    constexpr int NC = CPOL_ITAB1_NC, NFP = CPOL_ITAB_NFP;
 #pragma unroll
     for (int f = 0; f < CPOL_N_SZ / 2; ++f) v[f] = c[(NC - 1) * (NFP / 2) + f];
 #pragma unroll
@@ -2024,7 +2024,7 @@ __device__ __forceinline__ void itab1_columns(const double2 *c, double u, double
 #endif
 __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, CPOL_LOOKUP_WPE) void k_psd_lookup(HydroSet hs, ItabSet its, LookupArgs a)
 {
-    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
+    constexpr int NC = CPOL_ITAB1_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;      // (1-D blocks; the 2-D walk has its own constants)
     long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = lane_id();
     bool in = i0 < a.n_sbg;

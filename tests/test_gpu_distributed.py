@@ -41,11 +41,32 @@ def _bench_two_ranks(port, *flags):
            '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(root, 'bench.py'), '--gpus', '2', '--small', '--steps', '2', '--warmup', '1',
            '--cpu-seconds', '0'] + list(flags)
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=360)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1                      # rank 0 alone prints, and one line only
-    return json.loads(lines[0])
+    return _run_and_read(cmd, env)
+
+
+def _run_and_read(cmd, env):
+    """Runs bench.py; checks that stdout ends with ONE compact JSON line (< 4 KB, the contract's keys) preceded only by
+    '#detail ' lines, and returns the FULL result (bench_detail.json, written where CPOL_BENCH_DETAIL says)."""
+    import json
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, 'detail.json')
+        out = subprocess.run(cmd, env=dict(env, CPOL_BENCH_DETAIL=detail), capture_output=True, text=True, timeout=420)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        rows = out.stdout.splitlines()
+        lines = [l for l in rows if l.startswith('{')]
+        assert len(lines) == 1 and rows[-1] == lines[0]          # rank 0 alone prints; the compact line is the last one
+        assert len(lines[0]) < 4096
+        assert all(l.startswith('#detail ') for l in rows[:-1] if l.strip())
+        line = json.loads(lines[0])
+        with open(detail) as f:
+            full = json.load(f)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'dtype', 'data', 'config', 'roofline'):
+        assert k in line, k
+        if k not in ('config', 'roofline', 'value', 'ms_per_step'):
+            assert line[k] == full[k], k
+    assert abs(line['value'] - full['value']) <= 1e-5 * full['value']
+    return full
 
 
 def _check_c4_strong(r):
@@ -53,6 +74,11 @@ def _check_c4_strong(r):
     assert len(r['per_rank']) == 2
     assert r['per_rank'][0]['rays_per_sweep'] + r['per_rank'][1]['rays_per_sweep'] == 90
     assert r['single_gpu_same_workload']['value'] > 0 and r['value'] > 0 and r['speedup_vs_single_gpu'] > 0
+    # both speedups compare the distributed path on N ranks with the SAME path on a one-rank group (rank 0 alone)
+    one = r['single_gpu_same_workload']['through_the_distributed_path']
+    assert one['pipelined_ms_per_volume'] > 0 and one['single_volume_ms'] > 0 and r['speedup_single_volume'] > 0
+    assert abs(r['speedup_vs_single_gpu'] - one['pipelined_ms_per_volume'] / r['ms_per_step']) < 1e-6 * r['speedup_vs_single_gpu']
+    assert r['single_volume_blocking']['ms_per_volume'] > 0
     assert r['collectives_in_timed_region'] == r['steps'] and r['n_ranks_seen_by_backend'] == 2
     assert r['api_ms']['get_PPI_distributed_median'] > 0
 
@@ -92,11 +118,7 @@ def _bench_one_rank(*flags, **env_extra):
     env.pop('CPOL_BENCH_BACKEND', None)
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--small', '--steps', '3', '--warmup', '1',
            '--cpu-seconds', '0'] + list(flags)
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=360)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1
-    return json.loads(lines[0])
+    return _run_and_read(cmd, env)
 
 
 def test_bench_c4_one_rank_through_rccl():

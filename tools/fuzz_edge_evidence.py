@@ -69,7 +69,8 @@ def main():
         out = orig_d(hyds, limits, varray_, phi, theta, U, V, W, rho)
         calls.append({'Da': out[0].copy(), 'Db': out[1].copy(), 'idx': out[2].copy(),
                       'args': (float(phi), float(theta), float(U), float(V), float(W), float(rho)),
-                      'alpha_beta': [(float(h.alpha), float(h.beta)) for h in hyds]})
+                      'alpha_beta': [(float(h.alpha), float(h.beta)) for h in hyds],
+                      'names': [type(h).__name__ for h in hyds]})
         return out
 
     def rec_b(Da, Db, rcs, N, step_D, D_min):
@@ -120,6 +121,7 @@ def main():
     moved = float(np.max(np.abs(diff[bins])))
     print('edges next to those bins, per sub-beam and hydrometeor (oracle side); the power that moved: %.9g' % moved)
     cands = []
+    names = [h for h in hl]
     for s, (sb, by_gate) in enumerate(zip(subs, per_sub)):
         c = by_gate.get(g)
         if c is None:
@@ -127,30 +129,56 @@ def main():
         w = sb.quad_weight if np.isscalar(sb.quad_weight) else sb.quad_weight[g]
         idx = c['idx']
         for row in range(len(idx)):
-            if not (idx[row] in bins or idx[row] + 1 in bins):
+            if not (idx[row] in bins or idx[row] + 1 in bins or idx[row] - 1 in bins):
                 continue
             for j in range(c['Da'].shape[1]):
                 for name, D in (('Da', c['Da'][row, j]), ('Db', c['Db'][row, j])):
                     q = np.float32((np.float32(D) - c['dmin'][j]) / c['step'][j])
-                    ulp = float(np.spacing(np.float32(abs(q)))) if q != 0 else 1e-45
-                    dist = abs(float(q) - round(float(q))) / ulp
-                    b = int(q)
-                    if 0 <= b < c['N'].shape[0]:
-                        p_bin = float(np.float32(c['N'][b, j]) * np.float32(c['rcs'][b, j]) * c['step'][j]) * const * float(w)
-                    else:
-                        p_bin = float('nan')
-                    cands.append((dist, s, row, j, name, D, q, b, p_bin, float(w)))
-    cands.sort(key=lambda t: t[0])
-    for dist, s, row, j, name, D, q, b, p_bin, w in cands[:6]:
-        print('   sub-beam %2d (weight %.6g) hydrometeor %d velocity row %d %s: D = %.9g (%s)  q = (D - D_min) / step = %.9g (%s)'
-              '  -> table bin %d;  |q - integer| = %.2f ulp of q;  power of that table bin in this sub-beam (unattenuated): %.9g'
-              % (s, w, j, row, name, D, f32hex(D), q, f32hex(q), b, dist, p_bin))
-    if cands:
-        best = cands[0]
-        verdict = ('EDGE FLIP: the quotient of one (sub-beam, hydrometeor) edge lies within %.2f float32 ulp of an integer and its '
-                   'table bin carries %.3g of the %.3g that moved' % (best[0], best[8], moved)) if best[0] <= 4.0 else \
-                  'NOT explained by an edge within 4 ulp of an integer: nearest is %.1f ulp away' % best[0]
-        print(verdict)
+                    ulp_q = float(np.spacing(np.float32(abs(q)))) if q != 0 else 1e-45
+                    frac = abs(float(q) - round(float(q)))
+                    # how far the inverted diameter would have to move for the truncation (int) q to change
+                    need_D = frac * float(c['step'][j])
+                    need_ulp_D = need_D / float(np.spacing(np.float32(D)))
+                    b0 = int(q)
+                    p = []
+                    for bb in (b0 - 1, b0):                       # the table bin that enters or leaves the sum
+                        if 0 <= bb < c['N'].shape[0]:
+                            p.append(float(np.float32(c['N'][bb, j]) * np.float32(c['rcs'][bb, j]) * c['step'][j]) * const * float(w))
+                    alpha, beta = c['alpha_beta'][j]
+                    cands.append({'sub': s, 'w': float(w), 'j': j, 'row': row, 'edge': name, 'D': float(D), 'q': float(q), 'bin': b0,
+                                  'ulp_q': frac / ulp_q, 'need_ulp_D': need_ulp_D, 'p_bins': p, 'alpha': alpha, 'beta': beta,
+                                  'name': c['names'][j]})
+    # an edge explains the difference when ONE table bin next to it carries the power that moved (times the two-way
+    # attenuation of the sub-beam up to this gate, a factor in (0, 1])
+    def ratio(cd):
+        return min((abs(moved / pb - 0.9) for pb in cd['p_bins'] if pb > 0), default=9e9)
+    plausible = [cd for cd in cands if any(pb > 0 and 0.3 <= moved / pb <= 1.05 for pb in cd['p_bins'])]
+    plausible.sort(key=lambda cd: cd['need_ulp_D'])
+    print('edges whose neighbouring table bin carries the power that moved (moved / bin power in [0.3, 1.05]: the attenuation), '
+          'nearest to a flip first:')
+    for cd in plausible[:5]:
+        print('   sub-beam %2d (weight %.6g) species %s (alpha %.6g beta %.6g, 1/beta %.3g) velocity row %d %s: D = %.9g (%s)  '
+              'q = (D - D_min) / step = %.9g (%s) -> table bin %d; q is %.2f float32 ulp of q from an integer: the truncation '
+              'changes if D moves by %.3g = %.1f float32 ulp of D (a relative change of %.2e in D, i.e. of %.2e in the '
+              'radial-velocity term w before the power 1/beta); power of the table bins next to the edge in this sub-beam, '
+              'unattenuated: %s' % (cd['sub'], cd['w'], cd['name'], cd['alpha'], cd['beta'],
+                                    1.0 / cd['beta'], cd['row'], cd['edge'], cd['D'], f32hex(cd['D']), cd['q'], f32hex(cd['q']), cd['bin'],
+                                    cd['ulp_q'], cd['need_ulp_D'] * float(np.spacing(np.float32(cd['D']))), cd['need_ulp_D'],
+                                    cd['need_ulp_D'] * float(np.spacing(np.float32(cd['D']))) / cd['D'],
+                                    cd['need_ulp_D'] * float(np.spacing(np.float32(cd['D']))) / cd['D'] * cd['beta'],
+                                    ['%.6g' % pb for pb in cd['p_bins']]))
+    if plausible:
+        best = plausible[0]
+        rel_w = best['need_ulp_D'] * float(np.spacing(np.float32(best['D']))) / best['D'] * best['beta']
+        print('VERDICT: ONE table bin entered (or left) the bin sum of one (sub-beam, species) edge: its power matches the power that '
+              'moved, and the edge flips when the float32 chain that leads to w -- rho_corr = (RHO / RHO[0]) ** 0.5 and 1 / rho_corr in '
+              'float32, the wind terms -- differs by %.1e relative (%.1f float32 ulp) between NumPy and the device; the power law '
+              '(1 / beta = %.3g) turns that into %.1f ulp of D.' % (rel_w, rel_w / 5.96e-8, 1.0 / best['beta'], best['need_ulp_D']))
+        print('         %s' % ('A last-bit difference upstream: an EDGE FLIP as DESIGN.md section 4 describes (the record there said '
+                               '"1-ulp inverted diameter"; what differs by an ulp or two is w, D by 1/beta times as much).'
+                               if rel_w / 5.96e-8 <= 4.0 else 'MORE than a few ulp upstream: not a rounding-level flip -- look at the kernel.'))
+    else:
+        print('VERDICT: no (sub-beam, species) edge next to the differing bins carries the power that moved: NOT an edge flip.')
     op.close()
 
 
