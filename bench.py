@@ -135,9 +135,9 @@ def load_profile_summary(workload):
 
 # stage of the launch sequence (cpol_counters_t.ms_*) -> its kernels in the rocprofv3 summaries
 STAGE_KERNELS = {'interp': ('k_interp_sweep', 'k_interp_classify', 'k_interp_gate1', 'k_trajectory'),   # (k_interp_classify: the gate kernel that also classifies)
-                 'classify': ('k_classify', 'k_ml_weights', 'k_gate1'),
+                 'classify': ('k_classify', 'k_ml_weights', 'k_gate1'),          # (k_gate1_ray: the whole rest of a single-beam sweep)
                  'bucket': ('k_bucket_scan', 'k_bucket_scatter'),
-                 'psd': ('k_psd_lookup', 'k_subbeam_sum'),     # (+ the integrating kernels: empty launches in a sweep)
+                 'psd': ('k_psd_lookup', 'k_subbeam_sum', 'k_psd_rare'),     # (k_psd_rare: the integrating flavours, one launch, idle in a sweep)
                  'final': ('k_final', 'k_rvel_terms', 'k_ice_first')}
 TABLE_BUILD_KERNELS = ('k_itab_', 'k_stage_', 'k_spaceborne_first_gate')      # cpol_prepare / cpol_stage_model / the swath's
                                                                               # gate windows (once per swath geometry): not part of a sweep

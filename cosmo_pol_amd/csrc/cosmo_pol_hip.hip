@@ -130,7 +130,7 @@ struct cpol_ctx {
     DevBuf b_beam, b_spectrum, b_outwin;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
         b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel, b_proj, b_blkranked, b_rec, b_vmask, b_gscan, b_defer;
-    DevBuf b_out[16], b_szinteg, b_sztotal, b_model;
+    DevBuf b_out[16], b_szinteg, b_sztotal, b_model, b_ticket;
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
     int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0, last_n_keys = 0;
@@ -145,11 +145,14 @@ struct cpol_ctx {
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
     int lookup_split = 0;              // CPOL_LOOKUP_SPLIT=<n>: wavefronts per tile of k_psd_lookup (0: by launch size)
+    int gate1_ray = 1;                 // CPOL_GATE1_RAY=0: never k_gate1_ray (the range scans inside the gate kernel, items off the tables integrated in place: a sweep of two launches)
     int gate1_species = 1;             // CPOL_GATE1_SPECIES=0 / 2: never / always k_gate1_species (one wavefront per species; default: small launches)
     int fuse_gate1 = 0;                // CPOL_FUSE_GATE1=1: k_interp_gate1 instead of k_interp_sweep + k_gate1 (measured slower where it matters)
     int fuse_classify = 1;             // CPOL_FUSE_CLASSIFY=0: k_interp_sweep + k_classify instead of k_interp_classify (read when the context is created)
     int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
     int subsum_scalar = 0;             // CPOL_SUBSUM_FORM=scalar: the cooperative form of k_subbeam_sum takes its rows through the scalar cache instead of LDS
+    int psd_rare = 1;                  // CPOL_PSD_RARE=0: one launch per integrating flavour also when the units are directly listed items (read when the context is created)
+    int subsum_lanes = 1;              // CPOL_SUBSUM_WALK=wave: the gather form of k_subbeam_sum walks the union of the wavefront's sub-beams (round 4) instead of every lane its own
     int subsum_small = 0;              // CPOL_SUBSUM_SMALL=1: experiment: the gather form of k_subbeam_sum with three wavefronts per (tile, hydrometeor) and the whole block in flight (measured slower)
     int subsum_coop = -1;              // CPOL_SUBSUM_COOP: k_subbeam_sum takes its coefficients through the scalar cache: 0 never, 1 always, -1 by launch size
     bool last_subsum = false;          // the 1-D table items of the last sweep never went through res[] (k_subbeam_sum)
@@ -157,7 +160,9 @@ struct cpol_ctx {
     // host time of cpol_run_sweep by section (ns, summed; cpol_debug_read "host_times"): [0] calls, [1] per-ray tables
     // (staging memcpy + the H2D copy call), [2] work-buffer checks / allocations, [3] kernel launches, [4] the
     // device-to-host copy call(s), [5] everything
-    double host_ns[6] = {0, 0, 0, 0, 0, 0};
+    // [6..9]: section [1] split: waiting for the staging slot's previous copy (hipEventSynchronize), filling the slot,
+    // the hipMemcpyAsync call, hipEventRecord
+    double host_ns[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool fail_next = false;            // test hook (cpol_debug_read "fail_next_sweep"): the next launch sequence returns an error
                                        // after its kernels are queued, as a failed copy or capture would
     // sticky domain-error word (device): OR-ed by the kernels of every sweep, cleared only
@@ -505,6 +510,13 @@ int build_itabs(cpol_ctx *ctx)
         ctx->itab_bad[j] = (double)n_bad;
         { double ev = 0.0; memcpy(&ev, &edge_bits, sizeof ev); ctx->itab_check_edge[j] = ev; }   // (all panels; the accepted run: below)
         int pan_lo = 0, pan_hi = n_pan;
+        // CPOL_ITAB_KEEP_PANELS=<lo>:<hi> (test knob, 1-D tables): only the panels [lo, hi) stay on the table -- the items
+        // beyond go to the integrating kernels, as with a table that lost panels to the accuracy gate
+        int keep_lo = 0, keep_hi = n_pan;
+        if (!melt && getenv("CPOL_ITAB_KEEP_PANELS") && sscanf(getenv("CPOL_ITAB_KEEP_PANELS"), "%d:%d", &keep_lo, &keep_hi) == 2) {
+            keep_lo = std::max(0, std::min(keep_lo, n_pan));
+            keep_hi = std::max(keep_lo, std::min(keep_hi, n_pan));
+        } else { keep_lo = 0; keep_hi = n_pan; }
         if (!melt && !(worst < max_dev)) {
             // 1-D table: keep the longest run of lambda panels whose blocks all pass (in practice everything
             // but the last panel, where exp(-lambda D^nu) of the bins behind the first one goes subnormal);
@@ -538,6 +550,7 @@ int build_itabs(cpol_ctx *ctx)
         t.log2_lo = lo;
         t.d0 = gamma ? d0 : 0.0;
         t.n_pan = n_pan;
+        if (!melt) { pan_lo = std::max(pan_lo, keep_lo); pan_hi = std::max(pan_lo, std::min(pan_hi, keep_hi)); }
         t.pan_lo = pan_lo; t.pan_hi = pan_hi;
         if (!ctx->itab_detail[j].empty()) {
             // (the edge point's worst over the accepted run of panels, like `check`)
@@ -590,12 +603,15 @@ int cpol_create(int device, cpol_ctx **out)
     if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
     if (getenv("CPOL_LOOKUP_SPLIT")) ctx->lookup_split = std::max(0, std::min(16, atoi(getenv("CPOL_LOOKUP_SPLIT"))));
     if (getenv("CPOL_GATE1_SPECIES")) ctx->gate1_species = std::max(0, std::min(2, atoi(getenv("CPOL_GATE1_SPECIES"))));
+    if (getenv("CPOL_GATE1_RAY")) ctx->gate1_ray = std::max(0, std::min(2, atoi(getenv("CPOL_GATE1_RAY"))));   // (2: also with tables that lost panels)
     if (getenv("CPOL_FUSE_GATE1")) ctx->fuse_gate1 = atoi(getenv("CPOL_FUSE_GATE1")) != 0 ? 1 : 0;
     if (getenv("CPOL_FUSE_CLASSIFY")) ctx->fuse_classify = atoi(getenv("CPOL_FUSE_CLASSIFY")) != 0 ? 1 : 0;
     if (getenv("CPOL_RARE_DIRECT")) ctx->rare_direct = atoi(getenv("CPOL_RARE_DIRECT")) != 0 ? 1 : 0;
     if (getenv("CPOL_GATE1")) ctx->gate1 = atoi(getenv("CPOL_GATE1"));
     if (getenv("CPOL_SUBSUM_FORM")) ctx->subsum_scalar = !strcmp(getenv("CPOL_SUBSUM_FORM"), "scalar") ? 1 : 0;
     if (getenv("CPOL_SUBSUM_SMALL")) ctx->subsum_small = atoi(getenv("CPOL_SUBSUM_SMALL")) != 0 ? 1 : 0;
+    if (getenv("CPOL_PSD_RARE")) ctx->psd_rare = atoi(getenv("CPOL_PSD_RARE")) != 0 ? 1 : 0;
+    if (getenv("CPOL_SUBSUM_WALK")) ctx->subsum_lanes = strcmp(getenv("CPOL_SUBSUM_WALK"), "wave") != 0 ? 1 : 0;
     if (getenv("CPOL_SUBSUM_COOP_ROUNDS")) ctx->subsum_coop_rounds = std::max(0, std::min(64, atoi(getenv("CPOL_SUBSUM_COOP_ROUNDS"))));
     *out = ctx;
     return CPOL_OK;
@@ -697,11 +713,14 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->use_graph = parent->use_graph;
     c->subsum_coop = parent->subsum_coop;
     c->subsum_small = parent->subsum_small;
+    c->subsum_lanes = parent->subsum_lanes;
+    c->psd_rare = parent->psd_rare;
     c->subsum_scalar = parent->subsum_scalar;
     c->rare_direct = parent->rare_direct;
     c->fuse_classify = parent->fuse_classify;
     c->fuse_gate1 = parent->fuse_gate1;
     c->gate1_species = parent->gate1_species;
+    c->gate1_ray = parent->gate1_ray;
     c->lookup_split = parent->lookup_split;
     c->gate1 = parent->gate1;
     c->subsum_coop_rounds = parent->subsum_coop_rounds;
@@ -1315,7 +1334,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ENSURE(set->buf, total);
         cpol_ctx::Staging &sg = ctx->stg[ctx->stg_next];
         ctx->stg_next = (ctx->stg_next + 1) % 4;
+        const double t_s0 = now_ns();
         if (sg.used) HIPCHK(hipEventSynchronize(sg.ev));        // its last copy has left the buffer
+        const double t_s1 = now_ns();
         if (sg.cap < total) {
             if (sg.p) (void)hipHostFree(sg.p);
             sg.p = nullptr; sg.cap = 0;
@@ -1331,8 +1352,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             if (it.bytes) memcpy((char *)sg.p + off, it.src, it.bytes);
             off += (it.bytes + 63) & ~(size_t)63;
         }
+        const double t_s2 = now_ns();
         HIPCHK(hipMemcpyAsync(set->buf.p, sg.p, total, hipMemcpyHostToDevice, ctx->stream));
+        const double t_s3 = now_ns();
         HIPCHK(hipEventRecord(sg.ev, ctx->stream));
+        const double t_s4 = now_ns();
+        ctx->host_ns[6] += t_s1 - t_s0; ctx->host_ns[7] += t_s2 - t_s1; ctx->host_ns[8] += t_s3 - t_s2; ctx->host_ns[9] += t_s4 - t_s3;
         sg.used = true;
         set->version = t->version;
         memcpy(set->shape, shape, sizeof shape);
@@ -1358,6 +1383,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ENSURE(ctx->b_par, (size_t)n_hyd * CPOL_MAX_PAR * n_sbg * sizeof(double));
     // per set: [n_keys] bucket counts, [n_keys + 2]: items ranked, [n_keys + 3 ...): items on integral tables (count_table_items)
     const long cnt_stride = n_keys + 3 + CPOL_COUNT_SLOTS;
+    const bool was_dirty = ctx->counters_dirty;          // (the previous sequence was cut short: its rays' tickets may be half taken too)
     {
         void *const was = ctx->b_count.p, *const was_t = ctx->b_totals.p;
         ENSURE(ctx->b_count, (size_t)2 * cnt_stride * sizeof(int));
@@ -1463,6 +1489,29 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (gate1) {
         ENSURE(ctx->b_gscan, (size_t)3 * n_rg * sizeof(float));
         ENSURE(ctx->b_defer, (size_t)n_rg);
+    }
+    // k_gate1_ray (cpol_gate.inl): the single-beam kernel with one wavefront per species, the ray's range scans by the
+    // workgroup that finishes the ray last and the items outside the tables integrated in place -- the sweep is
+    // k_interp_sweep + that kernel, no integrating launch, no k_final.  Only where the in-place integration mirrors the
+    // integrating kernels: gamma-family species without Doppler-scheme-2 sums and without per-ray fall-speed totals
+    // (numeric_intv), whose tables kept all panels but the tail (an item off the table costs a wavefront ~10 000 cycles:
+    // fine for the handful a volume has, not for a table that lost half of its panels to the accuracy gate).
+    bool gate1_ray = gate1 && ctx->gate1_ray && !ctx->fuse_gate1 && !p->with_melting && !dop2 && n_rays <= 65535;
+    for (int j = 0; j < n_hyd && gate1_ray; ++j) {
+        const cpol_hydro_desc &d = ctx->hs.h[j].d;
+        const ItabDev &tj = ctx->its.t[j];
+        gate1_ray = d.psd_family == CPOL_PSD_GAMMA && !d.numeric_intv && d.q_source == CPOL_Q_MODEL && tj.tab && !tj.two_d &&
+                    ((tj.pan_lo == 0 && tj.pan_hi >= tj.n_pan - 2) || ctx->gate1_ray == 2) && ctx->hs.h[j].pre && ctx->hs.h[j].dnu;
+    }
+    {
+        const long g1_waves = n_rg * n_hyd / 64 / 1024;
+        gate1_ray = gate1_ray && (ctx->gate1_species == 2 || (ctx->gate1_species == 1 && g1_waves < 48));
+    }
+    if (gate1_ray) {
+        void *const was = ctx->b_ticket.p;
+        ENSURE(ctx->b_ticket, (size_t)n_rays * sizeof(int));
+        if (ctx->b_ticket.p != was || was_dirty)                 // (the kernel leaves every ticket at 0 behind it)
+            HIPCHK(hipMemsetAsync(ctx->b_ticket.p, 0, ctx->b_ticket.cap, ctx->stream));
     }
     // Every slot on an integral table: the items outside the tables (a handful per volume) are listed directly as
     // one-item work units by k_classify / k_gate1 -- key in b_pos, gate in b_perm, count in b_totals -- and the
@@ -1760,6 +1809,23 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         const long g1_waves_per_simd = n_rg * n_hyd / 64 / 1024;
         const bool by_species = (ctx->gate1_species == 2 || (ctx->gate1_species == 1 && g1_waves_per_simd < 48)) &&
                                 !fused_gate1 && !melt_tab && !ga.store_items && !p->with_melting;
+        if (gate1_ray && by_species) {
+            // the whole rest of the sweep in this launch: no integrating kernels, no k_final
+            ga.ticket = (int *)ctx->b_ticket.p;
+            ScanRayArgs rr{};
+            rr.PHIDP = (float *)T[O_PHIDP];
+            rr.RVEL = nullptr;
+            rr.sens_thr = cut ? (const double *)ctx->v_sens : nullptr;
+            rr.radial_res = (float)p->radial_res;
+            const size_t lds_terms = (size_t)n_hyd * 64 * GATE1S_BYTES, lds_scan = (size_t)3 * ng * sizeof(float);
+            hipLaunchKernelGGL(k_gate1_ray, dim3((unsigned)cdiv(ng, 64), (unsigned)n_rays), dim3(64 * n_hyd),
+                               lds_terms > lds_scan ? lds_terms : lds_scan, st, ctx->hs, ctx->its, ca, fa, ga, rr);
+            if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_CLASSIFY], st));
+            if (tm_psd) { HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st)); HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st)); }
+            if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
+            HIPCHK(hipGetLastError());
+            return CPOL_OK;
+        }
         if (by_species) hipLaunchKernelGGL(k_gate1_species, dim3((unsigned)cdiv(n_rg, 64)), dim3(64 * n_hyd),
                                            (size_t)n_hyd * 64 * GATE1S_BYTES, st, ctx->hs, ctx->its, ca, fa, ga);
         else if (fused_gate1 && melt_tab) hipLaunchKernelGGL((k_interp_gate1<true>), ggrid, dim3(CPOL_GATE1_THREADS), glds, st,
@@ -1894,6 +1960,20 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // traffic.  Back to back on the sweep's stream is the default; CPOL_PSD_SIBLINGS=1 forks.
         static const bool siblings = getenv("CPOL_PSD_SIBLINGS") && atoi(getenv("CPOL_PSD_SIBLINGS")) != 0;
         const int order[4] = {PSD_MODE_MELTING, PSD_MODE_ICE, PSD_MODE_GAMMA_UNIFORM, PSD_MODE_GAMMA_EXP};
+        // items listed directly (every slot on a table): ONE launch runs every flavour (k_psd_rare); CPOL_PSD_RARE=0: a launch
+        // per flavour as before (same bits: tests/test_gpu_edges.py)
+        if (rare_direct && ctx->psd_rare && only == 15 && !siblings && !ctx->keep_debug) {
+            int modes = 0;
+            for (int m = 0; m < 4; ++m) if (need[m]) modes |= 1 << m;
+            for (int jj = 0; jj < n_hyd; ++jj) {
+                const cpol_hydro_desc &dd = ctx->hs.h[jj].d;
+                if (dd.psd_family == CPOL_PSD_MELTING && dd.tab_degree != CPOL_MELT_DEGREE) modes |= 16;
+            }
+            pa.ice_same_launch = 1;
+            if (dop2) hipLaunchKernelGGL((k_psd_rare<true>), grd, blk, 0, st, ctx->hs, pa, modes);
+            else hipLaunchKernelGGL((k_psd_rare<false>), grd, blk, 0, st, ctx->hs, pa, modes);
+            for (int m = 0; m < 4; ++m) need[m] = false;
+        }
         int n_need = 0;
         for (int m = 0; m < 4; ++m) n_need += need[m] ? 1 : 0;
         const bool fork = siblings && n_need > 1;
@@ -2003,6 +2083,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // (CPOL_SUBSUM_FORM=scalar, read when the context is created)
         if (coop && ctx->subsum_scalar) hipLaunchKernelGGL(k_subbeam_sum_scalar, dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
         else if (coop) hipLaunchKernelGGL(k_subbeam_sum_lds, dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
+        else if (!small && ctx->subsum_lanes) hipLaunchKernelGGL(k_subbeam_sum_lanes, dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
         else if (small) hipLaunchKernelGGL((k_subbeam_sum_gather<3, 10>), dim3((unsigned)tiles, n_hyd * 3), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
         else hipLaunchKernelGGL((k_subbeam_sum_gather<1, 2>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
     }

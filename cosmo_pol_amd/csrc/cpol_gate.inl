@@ -34,6 +34,7 @@ struct GateArgs {
     int store_items;              // some species' fall-speed sums are per ray: vmask / key / rec / vn of EVERY gate are
                                   // stored (k_ice_first and the recomputed first-ice gate read them), not only of deferred gates
     int analytic_vn;              // Doppler scheme 1: the gamma species take their analytic fall-speed moments
+    int *ticket;                  // [n_rays] k_gate1_ray: workgroups of the ray that have finished (0 between sweeps)
 };
 
 #define CPOL_GATE1_THREADS 256
@@ -353,7 +354,86 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_interp_g
 #else
 #define CPOL_GATE1S_ATTR
 #endif
-__global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_species(HydroSet hs, ItabSet its, ClassifyArgs a, FinalArgs f, GateArgs g)
+// ---- an item outside its integral table, integrated by the wavefront that meets it (k_gate1_ray) ----
+// Lanes 0..7 of the wavefront play the eight wavefronts of the integrating kernels' workgroup (psd_body): lane w sums the
+// diameter bins [w * chunk, (w + 1) * chunk) of the item with the same statements in the same order -- GAMMA_UNIFORM:
+// exp(-lambda D_k) by the geometric recurrence from one exp at the chunk start, the partial sums joined by the tree
+// ((w0+w4)+(w2+w6)) + ((w1+w5)+(w3+w7)); GAMMA_EXP: one exp per bin, the partial sums added in wave order -- so that the
+// 12 columns are the bits k_psd_uniform / k_psd<GAMMA_EXP> leave in res[] (tests/test_gpu_edges.py compares the launch
+// sequences bit for bit).  Items outside the tables are a handful per volume (lambda beyond the last panel: a mass
+// density of 1e-17 kg m-3), ~10 000 cycles of one wavefront each; the host takes this path only when every slot is a
+// gamma-family species without Doppler-scheme-2 sums whose table kept (all but the tail of) its panels.
+// `lam`, `n0`, `slice_index`: wave-uniform.  Lane 0 leaves the 12 columns (x dD) in out[] (LDS).
+// (not inlined: the rare path must not cost the common one its registers -- inlined, the kernel needs 131 VGPRs and
+// 3 wavefronts per SIMD instead of 105 / 4)
+__device__ __attribute__((noinline)) void integrate_gamma_item_wave(const double *table, const double *pre, const double *dnu, const double *aux,
+                                                                    int n_d, int uniform_grid, double dD, int slice_index,
+                                                                    double lam, double n0, double *out /* LDS, [CPOL_N_SZ] */)
+{
+    const int lane = lane_id();
+    constexpr int NW = 8;                                  // CPOL_PSD_WAVES = CPOL_PSD_WAVES_U = 8 chunks
+    static_assert(CPOL_PSD_WAVES == 8 && CPOL_PSD_WAVES_U == 8, "integrate_gamma_item_wave mirrors the 8-wave split of psd_body");
+    const int chunk = (n_d + NW - 1) / NW;
+    const int w = lane < NW ? lane : NW - 1;
+    const int k0 = w * chunk, k1 = lane < NW ? min(k0 + chunk, n_d) : k0;      // (lanes 8..63: empty range)
+    const double *slice = table + (long)slice_index * n_d * CPOL_N_SZ;
+    double acc[CPOL_N_SZ];
+#pragma unroll
+    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = 0.0;
+    if (uniform_grid) {
+        // (psd_body, PSD_MODE_GAMMA_UNIFORM, item 0 of the lane)
+        const double hstep = aux[0];
+        const double d0 = dnu[k0 < n_d ? k0 : 0];
+        double A0 = n0 * exp(-(lam * d0));
+        const double r0 = exp(-(lam * hstep));
+        const double *pq = aux + 1 + n_d;                   // [k][4] = (pre, q1, q2, .)
+#pragma unroll 1
+        for (int k = k0; k < k1; ++k) {
+            const double pk = pq[4 * k], q1 = pq[4 * k + 1], q2 = pq[4 * k + 2];
+            const double nk = A0 * fma(lam, fma(lam, q2, -q1), pk);
+            A0 *= r0;
+            const double *row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
+        }
+        // the tree of the kernel: (w += w + 4), (w += w + 2), (w0 += w1)
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) {
+            double x = acc[c];
+            x += shfl_f64(x, (lane + 4) & 63);
+            x += shfl_f64(x, (lane + 2) & 63);
+            x += shfl_f64(x, (lane + 1) & 63);
+            if (lane == 0) out[c] = x * dD;
+        }
+    } else {
+        // (psd_body, PSD_MODE_GAMMA_EXP)
+#pragma unroll 1
+        for (int k = k0; k < k1; ++k) {
+            const double nk = (n0 * pre[k]) * exp(-(lam * dnu[k]));
+            const double *row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ; ++c) {
+            double sum = 0.0;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) sum += readlane_f64(acc[c], q);
+            if (lane == 0) out[c] = sum * dD;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// RAY = false: k_gate1_species as described above (grid = ceil(n_rg / 64)).
+// RAY = true (k_gate1_ray): the workgroup's 64 gates are gates [64 bx, 64 bx + 64) of ray `by` (grid = (ceil(n_gates / 64),
+// n_rays)), an item outside its table is integrated on the spot (integrate_gamma_item_wave: no deferred gates, no
+// integrating launch behind this kernel), and the workgroup that finishes LAST of its ray -- a ticket per ray, taken behind
+// a device-scope fence -- runs the ray's three sequential float32 range scans, PHIDP, the attenuated ZDR and the
+// sensitivity cut (the second half of k_final): the whole sweep is k_interp_sweep + this kernel.
+template <bool RAY>
+__device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const ItabSet &its, const ClassifyArgs &a, const FinalArgs &f,
+                                                   const GateArgs &g, const ScanRayArgs &r)
 {
     constexpr int NC = CPOL_ITAB1_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
     extern __shared__ unsigned char s_raw[];
@@ -363,11 +443,14 @@ __global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_
     double *s_mn = s_mv + n_h * 64;                                                    // [n_h][64]
     unsigned *s_flag = reinterpret_cast<unsigned *>(s_mn + n_h * 64);                  // [n_h][64]: 1 valid, 2 off the tables, 4 moments
     __shared__ int s_lookup;
+    __shared__ int s_last;
     if (threadIdx.x == 0) s_lookup = 0;
     const int lane = lane_id();
     const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                    // the wavefront's hydrometeor
-    const long i0 = (long)blockIdx.x * 64 + lane;
-    const bool in = i0 < a.n_sbg;
+    const int ray_b = RAY ? (int)blockIdx.y : 0;
+    const int gate_b = (int)blockIdx.x * 64 + lane;
+    const long i0 = RAY ? (long)ray_b * f.n_gates + gate_b : (long)blockIdx.x * 64 + lane;
+    const bool in = RAY ? gate_b < f.n_gates : i0 < a.n_sbg;
     const long n = a.n_sbg;
     const long i = in ? i0 : 0;
     const HydroDev &h = hs.h[j];
@@ -415,8 +498,29 @@ __global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_
         have = true;
     }
     int my_lookup = it.lookup ? 1 : 0;
-    const bool off_table = it.valid && !it.lookup;
-    if (off_table) {
+    bool off_table = it.valid && !it.lookup;
+    if (RAY) {
+        // ---- items outside the integral table: integrated here, one after the other (rare) ----
+        unsigned long long todo = __ballot(off_table);
+        if (todo && lane == 0) {                                  // (cpol_counters: items integrated bin by bin, one "unit" each)
+            atomicAdd(g.totals, (unsigned long long)__popcll(todo));
+            atomicAdd(g.totals + 1, (unsigned long long)__popcll(todo));
+        }
+        while (todo) {
+            const int l = (int)__ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            double *col = s_mv + j * 64;                          // (this wavefront's own piece of LDS, written for good further down)
+            integrate_gamma_item_wave(h.table, h.pre, h.dnu, h.aux, d.n_d, d.uniform_grid, d.dD,
+                                      __builtin_amdgcn_readlane(it.key, l) - h.key_base, readlane_f64(it.p0, l), readlane_f64(it.p1, l), col);
+            if (lane == l) {
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = make_double2(col[2 * c], col[2 * c + 1]);
+                have = true;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        off_table = false;                                        // (nothing is deferred)
+    } else if (off_table) {
         // ---- an item outside the integral table: a work unit of its own for the integrating kernels (as k_gate1) ----
         const unsigned long long idx = atomicAdd(g.totals + 1, 1ull);
         atomicAdd(g.totals, 1ull);
@@ -462,30 +566,128 @@ __global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_
             *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = wv;
     }
     __syncthreads();
-    if (threadIdx.x == 0) count_table_items(a.n_lookup, s_lookup);
-    if (j != 0) return;
-    // ---- wavefront 0: sum over the species in order, get_pol_from_sz, RVEL, mask; the operands of the range scans ----
-    if (in && deferred) a.vmask[i] = (unsigned char)vbits;
-    if (in) g.defer[i] = deferred ? 1 : 0;
-    if (!in || deferred) return;
-    float tot[CPOL_N_SZ];
-    double mom_v = 0.0, mom_n = 0.0;
-    for (int q = 0; q < n_h; ++q) {
+    if (threadIdx.x == 0) {
+        const unsigned slot = ((blockIdx.x + blockIdx.y * gridDim.x) * 4u) & (CPOL_COUNT_SLOTS - 1);
+        if (s_lookup) atomicAdd(a.n_lookup + 2 + slot, s_lookup);
+    }
+    if (j == 0) {
+        // ---- wavefront 0: sum over the species in order, get_pol_from_sz, RVEL, mask; the operands of the range scans ----
+        if (in && deferred) a.vmask[i] = (unsigned char)vbits;
+        if (in && !RAY) g.defer[i] = deferred ? 1 : 0;
+        if (in && !deferred) {
+            float tot[CPOL_N_SZ];
+            double mom_v = 0.0, mom_n = 0.0;
+            for (int q = 0; q < n_h; ++q) {
 #pragma unroll
-        for (int c = 0; c < CPOL_N_SZ; ++c) {
-            const float acc = s_acc[(q * CPOL_N_SZ + c) * 64 + lane];
-            tot[c] = (q == 0) ? acc : tot[c] + acc;
-        }
-        if (s_flag[q * 64 + lane] & 4u) {
-            const double vq = s_mv[q * 64 + lane], nq = s_mn[q * 64 + lane];
-            if (vq == vq) mom_v += vq;
-            if (nq == nq) mom_n += nq;
+                for (int c = 0; c < CPOL_N_SZ; ++c) {
+                    const float acc = s_acc[(q * CPOL_N_SZ + c) * 64 + lane];
+                    tot[c] = (q == 0) ? acc : tot[c] + acc;
+                }
+                if (s_flag[q * 64 + lane] & 4u) {
+                    const double vq = s_mv[q * 64 + lane], nq = s_mn[q * 64 + lane];
+                    if (vq == vq) mom_v += vq;
+                    if (nq == nq) mom_n += nq;
+                }
+            }
+            const int ray = (int)(i / f.n_gates), gate = (int)(i % f.n_gates);
+            float k2, fh, fv;
+            gate_finish(f, ray, gate, tot, want_rvel, mom_v, mom_n, 0.0, k2, fh, fv);
+            g.sk[i] = k2;
+            g.sh[i] = fh;
+            g.sv[i] = fv;
         }
     }
-    const int ray = (int)(i / f.n_gates), gate = (int)(i % f.n_gates);
-    float k2, fh, fv;
-    gate_finish(f, ray, gate, tot, want_rvel, mom_v, mom_n, 0.0, k2, fh, fv);
-    g.sk[i] = k2;
-    g.sh[i] = fh;
-    g.sv[i] = fv;
+    if (!RAY) return;
+
+    // ---- the ray's ticket: the workgroup that finishes LAST of the ray scans it ----
+    __threadfence();                                  // (release: this workgroup's gates -- outputs and scan operands -- are visible device-wide)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = atomicAdd(g.ticket + ray_b, 1);
+        s_last = old == (int)gridDim.x - 1;
+        if (s_last) g.ticket[ray_b] = 0;              // (ready for the next sweep: nobody else touches the ray's ticket any more)
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                  // (acquire: the other workgroups' gates of this ray)
+    const int ng = f.n_gates, tid = threadIdx.x, nthr = blockDim.x;
+    const int wave = j, n_waves = n_h;
+    const long base = (long)ray_b * ng;
+    float *lds = reinterpret_cast<float *>(s_raw);    // [3][n_gates] (the species' terms above are consumed)
+    float *s_k = lds, *s_h = lds + ng, *s_v = lds + 2 * ng;
+    for (int gg = tid; gg < ng; gg += nthr) {
+        s_k[gg] = g.sk[base + gg];
+        s_h[gg] = g.sh[base + gg];
+        s_v[gg] = g.sv[base + gg];
+    }
+    __syncthreads();
+    // strictly sequential float32 scans (np.cumsum / np.cumprod order is part of the numerical contract), lane 0 of
+    // a wavefront per scan (with fewer than three species a wavefront takes several), LDS read in chunks of 8 (k_final)
+    if (lane == 0) {
+        const int n_scan = f.with_attenuation ? 3 : 1;
+        for (int sc = wave; sc < n_scan; sc += n_waves) {
+            float *sv = (sc == 0) ? s_k : (sc == 1 ? s_h : s_v);
+            float c = 0.0f;
+            int gg = 0;
+            if (sc == 0) {
+                for (; gg + 8 <= ng; gg += 8) {
+                    float q8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) q8[q] = sv[gg + q];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { c = (gg + q == 0) ? q8[0] : c + q8[q]; q8[q] = c; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sv[gg + q] = q8[q];
+                }
+                for (; gg < ng; ++gg) { c = (gg == 0) ? sv[gg] : c + sv[gg]; sv[gg] = c; }
+            } else {
+                for (; gg + 8 <= ng; gg += 8) {
+                    float q8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) q8[q] = sv[gg + q];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { c = (gg + q == 0) ? q8[0] : c * q8[q]; q8[q] = c; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sv[gg + q] = q8[q];
+                }
+                for (; gg < ng; ++gg) { c = (gg == 0) ? sv[gg] : c * sv[gg]; sv[gg] = c; }
+            }
+        }
+    }
+    __syncthreads();
+    double *rvel = f.RVEL ? f.RVEL : r.RVEL;
+    for (int gg = tid; gg < ng; gg += nthr) {
+        const long ii = base + gg;
+        // (written by other workgroups of this kernel: read behind the acquire fence)
+        const float zh = f.ZH[ii], zv = f.ZV[ii];
+        float phidp = s_k[gg] * r.radial_res / 1000.0f + f.DELTA_HV[ii];
+        float zdr = f.ZDR[ii];
+        if (f.with_attenuation) zdr = (zh * s_h[gg]) / (zv * s_v[gg]);
+        bool cut = false;
+        if (r.sens_thr) {
+            // 10*np.log10(ZH) (float32) < threshold(r) (float64)
+            const float dbz = 10.0f * (float)log10((double)zh);
+            cut = (double)dbz < r.sens_thr[gg];
+        }
+        if (cut) {
+            const float qnan = __builtin_nanf("");
+            f.ZH[ii] = qnan; f.ZV[ii] = qnan; f.KDP[ii] = qnan; f.RHOHV[ii] = qnan;
+            zdr = qnan; phidp = qnan;
+            if (rvel) rvel[ii] = __builtin_nan("");
+        }
+        r.PHIDP[ii] = phidp;
+        f.ZDR[ii] = zdr;
+    }
+}
+
+__global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_species(HydroSet hs, ItabSet its, ClassifyArgs a, FinalArgs f, GateArgs g)
+{
+    gate1_species_body<false>(hs, its, a, f, g, ScanRayArgs{});
+}
+
+// grid = (ceil(n_gates / 64), n_rays), block = 64 * n_hydro, dynamic LDS = max(n_hydro * 64 * GATE1S_BYTES, 3 * n_gates * 4)
+__global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_ray(HydroSet hs, ItabSet its, ClassifyArgs a, FinalArgs f, GateArgs g,
+                                                                                  ScanRayArgs r)
+{
+    gate1_species_body<true>(hs, its, a, f, g, r);
 }

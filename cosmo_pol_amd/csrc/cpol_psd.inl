@@ -798,6 +798,8 @@ struct PsdArgs {
                                 // end of every workgroup (effective shader clock), or NULL
     int ice_force_sum;          // test hook (CPOL_ICE_FORCE_SUM=1): treat every lambda as outside the
                                 // tabulated range, i.e. sum the ice normalisation integrals directly
+    int ice_same_launch;        // k_psd_rare: the ice flavours run in ONE launch, so totals[2] (units k_psd_ice2 left to
+                                // k_psd<ICE>, set by another workgroup) cannot be waited for: every unit is tested instead
 };
 
 // work unit u: from the sorted list of k_bucket_scatter, or one directly listed item
@@ -885,8 +887,11 @@ __device__ __forceinline__ bool ice_unit_in_table(const HydroDev &h, const PsdAr
     return __syncthreads_and(ok) != 0;
 }
 
+// LDS of the integrating kernels: one raw buffer per kernel, sized for the largest flavour, handed to the bodies (so
+// that k_psd_rare can run every flavour from ONE launch)
+#define CPOL_PSD_LDS_DOUBLES (8 * (CPOL_N_SZ + 3) * CPOL_WAVE)            /* 61 440 B: the generic flavours, 8 wave slots */
 template <int MODE, bool DOP2>
-__device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
+__device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a, double *lds_raw)
 {
     // [wave][value][lane]; value 12 = normalisation sum (ice, melting)
     // the recurrence flavour needs no extra sums and combines its 8 partials with a
@@ -896,7 +901,8 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
     // two items per fetched row halve that traffic
     constexpr int NV = (MODE == PSD_MODE_GAMMA_UNIFORM) ? 2 * CPOL_N_SZ + (DOP2 ? 4 : 0) : CPOL_N_SZ + 3;
     constexpr int NSLOT = (MODE == PSD_MODE_GAMMA_UNIFORM) ? 4 : CPOL_PSD_WAVES;
-    __shared__ double s_part[NSLOT][NV][CPOL_WAVE];
+    static_assert(NSLOT * NV * CPOL_WAVE <= CPOL_PSD_LDS_DOUBLES, "LDS buffer of the integrating kernels too small");
+    double (*const s_part)[NV][CPOL_WAVE] = reinterpret_cast<double (*)[NV][CPOL_WAVE]>(lds_raw);
 #ifdef CPOL_CLOCK_PROBE
     // debug build only (make PROBE=1): the stores below cost the production kernel its
     // scalar loads of the unit list (the compiler can no longer prove them unclobbered)
@@ -926,7 +932,7 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
     if (MODE == PSD_MODE_MELTING && d.tab_degree == CPOL_MELT_DEGREE) continue;   // k_psd_melting_tab
     if (MODE == PSD_MODE_ICE) {
         if (d.tab_degree == CPOL_ICE_DEGREE) {
-            if (a.totals[2] == 0) continue;                  // k_psd_ice2 took every unit (the rule)
+            if (!a.ice_same_launch && a.totals[2] == 0) continue;   // k_psd_ice2 took every unit (the rule)
             if (ice_unit_in_table(h, a, j, start, count)) continue;               // k_psd_ice2
             start += (uu % SUB) * CPOL_WAVE;
             count = min(CPOL_WAVE, count - (uu % SUB) * CPOL_WAVE);
@@ -1306,7 +1312,9 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a)
 template <int MODE, bool DOP2>
 __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a)
 {
-    psd_body<MODE, DOP2>(hs, a);
+    constexpr int NVK = CPOL_N_SZ + 3;
+    __shared__ double lds_raw[CPOL_PSD_WAVES * NVK * CPOL_WAVE];
+    psd_body<MODE, DOP2>(hs, a, lds_raw);
 }
 
 // The recurrence flavour (the dominant kernel of a sweep).  The compiler's own allocation
@@ -1317,7 +1325,9 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd(HydroSet hs, PsdArgs a
 template <bool DOP2>
 __global__ __launch_bounds__(CPOL_PSD_THREADS_U) void k_psd_uniform(HydroSet hs, PsdArgs a)
 {
-    psd_body<PSD_MODE_GAMMA_UNIFORM, DOP2>(hs, a);
+    constexpr int NVU = 2 * CPOL_N_SZ + (DOP2 ? 4 : 0);
+    __shared__ double lds_raw[4 * NVU * CPOL_WAVE];
+    psd_body<PSD_MODE_GAMMA_UNIFORM, DOP2>(hs, a, lds_raw);
 }
 
 // The melting flavour (own kernel symbol so that its register allocation is reported and can be
@@ -1325,7 +1335,9 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS_U) void k_psd_uniform(HydroSet hs,
 template <bool DOP2>
 __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting(HydroSet hs, PsdArgs a)
 {
-    psd_body<PSD_MODE_MELTING, DOP2>(hs, a);
+    constexpr int NVK = CPOL_N_SZ + 3;
+    __shared__ double lds_raw[CPOL_PSD_WAVES * NVK * CPOL_WAVE];
+    psd_body<PSD_MODE_MELTING, DOP2>(hs, a, lds_raw);
 }
 
 
@@ -1384,11 +1396,12 @@ __device__ __forceinline__ void melt_store(const cpol_hydro_desc &d, const PsdAr
 }
 
 template <bool DOP2>
-__global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting_tab(HydroSet hs, PsdArgs a)
+__device__ __forceinline__ void psd_melting_tab_body(const HydroSet &hs, const PsdArgs &a, double *lds_raw)
 {
     constexpr int NC = CPOL_MELT_DEGREE + 1;
     constexpr int NV = CPOL_MELT_NV;
-    __shared__ double s_part[4][NV][CPOL_WAVE];
+    static_assert(4 * NV * CPOL_WAVE <= CPOL_PSD_LDS_DOUBLES, "LDS buffer of the integrating kernels too small");
+    double (*const s_part)[NV][CPOL_WAVE] = reinterpret_cast<double (*)[NV][CPOL_WAVE]>(lds_raw);
     const int n_units = (int)a.totals[1];
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
         int key, start, count;
@@ -1498,11 +1511,12 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting_tab(HydroSet h
 // units, bins split over 8 waves, fixed-order tree combine.
 #define CPOL_ICE_NV (2 * (CPOL_N_SZ + 2))
 template <bool DOP2>
-__global__ __launch_bounds__(CPOL_PSD_THREADS, 4) void k_psd_ice2(HydroSet hs, PsdArgs a)
+__device__ __forceinline__ void psd_ice2_body(const HydroSet &hs, const PsdArgs &a, double *lds_raw)
 {
     constexpr int NC = CPOL_ICE_DEGREE + 1;
     constexpr int NV = CPOL_ICE_NV;                       // 2 x (12 columns + Doppler-2 v, n)
-    __shared__ double s_part[4][NV][CPOL_WAVE];
+    static_assert(4 * NV * CPOL_WAVE <= CPOL_PSD_LDS_DOUBLES, "LDS buffer of the integrating kernels too small");
+    double (*const s_part)[NV][CPOL_WAVE] = reinterpret_cast<double (*)[NV][CPOL_WAVE]>(lds_raw);
     const int n_units = (int)a.totals[1];
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
         int key, start, count;
@@ -1631,6 +1645,46 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS, 4) void k_psd_ice2(HydroSet hs, P
             }
         }
     }
+}
+
+template <bool DOP2>
+__global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_melting_tab(HydroSet hs, PsdArgs a)
+{
+    __shared__ double lds_raw[4 * CPOL_MELT_NV * CPOL_WAVE];
+    psd_melting_tab_body<DOP2>(hs, a, lds_raw);
+}
+
+template <bool DOP2>
+__global__ __launch_bounds__(CPOL_PSD_THREADS, 4) void k_psd_ice2(HydroSet hs, PsdArgs a)
+{
+    __shared__ double lds_raw[4 * CPOL_ICE_NV * CPOL_WAVE];
+    psd_ice2_body<DOP2>(hs, a, lds_raw);
+}
+
+// Every integrating flavour from ONE launch, for the sweeps whose work units are single items listed directly (every slot on
+// an integral table: the units are the handful of items outside the tables, usually none).  The flavours used to be up to
+// five launches that found nothing to do (5-6 us apiece on the stream: 20 of the 157 us of a C3 sweep); the bodies are the
+// kernels' own, run one after the other by every workgroup (each skips the units of the other flavours), so the results
+// are the same bits.  `modes`: bit m = flavour m (PSD_MODE_*) is staged; bit 4: a melting slot without polynomial tables.
+template <bool DOP2>
+__global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_rare(HydroSet hs, PsdArgs a, int modes)
+{
+    static_assert(CPOL_PSD_THREADS_U == CPOL_PSD_THREADS, "k_psd_rare runs the recurrence flavour with the workgroup of the others");
+    if (a.totals[1] == 0) return;                         // nothing outside the tables (the rule)
+    __shared__ double lds_raw[CPOL_PSD_LDS_DOUBLES];
+    if (modes & (1 << PSD_MODE_MELTING)) {
+        psd_melting_tab_body<DOP2>(hs, a, lds_raw);
+        __syncthreads();
+        if (modes & 16) { psd_body<PSD_MODE_MELTING, DOP2>(hs, a, lds_raw); __syncthreads(); }
+    }
+    if (modes & (1 << PSD_MODE_ICE)) {
+        psd_ice2_body<DOP2>(hs, a, lds_raw);
+        __syncthreads();
+        psd_body<PSD_MODE_ICE, DOP2>(hs, a, lds_raw);      // (a.ice_same_launch: tests every unit itself)
+        __syncthreads();
+    }
+    if (modes & (1 << PSD_MODE_GAMMA_UNIFORM)) { psd_body<PSD_MODE_GAMMA_UNIFORM, DOP2>(hs, a, lds_raw); __syncthreads(); }
+    if (modes & (1 << PSD_MODE_GAMMA_EXP)) psd_body<PSD_MODE_GAMMA_EXP, DOP2>(hs, a, lds_raw);
 }
 
 // ---------------------------------------------------------------- integral tables (itab)

@@ -181,7 +181,7 @@ def test_stage_kernels_cover_every_kernel_of_a_sweep():
     roofline (or to table building / staging): no kernel's bytes fall out of `roofline.stages`."""
     import bench
     known = [k for ks in bench.STAGE_KERNELS.values() for k in ks]
-    integrating = ('k_psd_uniform', 'k_psd<', 'k_psd_ice2', 'k_psd_melting', 'k_spec_', 'k_ml_weights')
+    integrating = ('k_psd_uniform', 'k_psd<', 'k_psd_ice2', 'k_psd_melting', 'k_psd_rare', 'k_spec_', 'k_ml_weights')
     for name in ('c2_iso', 'c3_el3_iso', 'c4_volume_iso', 'c4_share8_iso', 'c5_ku_iso'):
         prof, path = bench.load_profile_summary(name)
         assert prof is not None and path.endswith('r4_%s_summary.json' % name)

@@ -134,10 +134,13 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
         conf = bench.bench_config(True)
         conf['integration'].update(nh_GH=n_gh, nv_GH=n_gh)
         for mode, env in (('sorted', {'CPOL_RARE_DIRECT': '0', 'CPOL_GATE1': '0'}), ('direct', {'CPOL_GATE1': '0'}), ('default', {}),
+                          ('direct_launch_per_flavour', {'CPOL_GATE1': '0', 'CPOL_PSD_RARE': '0'}),   # (round 4: k_psd_uniform alone instead of k_psd_rare)
                           ('direct_two_kernels', {'CPOL_GATE1': '0', 'CPOL_FUSE_CLASSIFY': '0'}),     # k_interp_sweep + k_classify
                           ('interp_gate1', {'CPOL_FUSE_GATE1': '1'}),                                  # k_interp_gate1 (opt-in)
-                          ('gate1_one_thread', {'CPOL_GATE1_SPECIES': '0'})):      # k_gate1 instead of k_gate1_species (what large swaths get)
-            for k in ('CPOL_RARE_DIRECT', 'CPOL_GATE1', 'CPOL_FUSE_CLASSIFY', 'CPOL_FUSE_GATE1', 'CPOL_GATE1_SPECIES'):
+                          ('gate1_one_thread', {'CPOL_GATE1_SPECIES': '0'}),       # k_gate1 instead of k_gate1_species (what large swaths get)
+                          ('gate1_species_then_final', {'CPOL_GATE1_RAY': '0'})):  # k_gate1_species + integrating launch + k_final (round 4's default;
+                                                                                   # the default now: k_gate1_ray, off-table items integrated in place)
+            for k in ('CPOL_RARE_DIRECT', 'CPOL_GATE1', 'CPOL_FUSE_CLASSIFY', 'CPOL_FUSE_GATE1', 'CPOL_GATE1_SPECIES', 'CPOL_GATE1_RAY', 'CPOL_PSD_RARE'):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)                    # (read when the context is created)
@@ -151,7 +154,7 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
             results[(n_gh, mode)] = (res, n_off)
             op.close()
         ref, n_ref = results[(n_gh, 'sorted')]
-        for mode in ('direct', 'default', 'direct_two_kernels', 'interp_gate1', 'gate1_one_thread'):
+        for mode in ('direct', 'default', 'direct_launch_per_flavour', 'direct_two_kernels', 'interp_gate1', 'gate1_one_thread', 'gate1_species_then_final'):
             got, n_got = results[(n_gh, mode)]
             assert n_got == n_ref
             for k in ('ZH', 'ZV', 'ZDR', 'KDP', 'RHOHV', 'PHIDP', 'DELTA_HV', 'ATT_H', 'ATT_V', 'RVEL', 'mask'):
@@ -235,3 +238,90 @@ def test_sweep_after_a_failed_sweep_equals_a_fresh_context(monkeypatch):
                 for k in keys:
                     assert np.array_equal(got[k], ref[k], equal_nan=True), (n_gh, env, failures, k)
             op.close()
+
+
+def test_two_moment_items_outside_the_tables_in_place_integration(monkeypatch):
+    """The two-launch single-beam sweep (k_interp_sweep + k_gate1_ray) integrates an item outside its integral table in
+    place, lanes 0..7 of the wavefront standing in for the eight wavefronts of the integrating kernels.  Here for the
+    2-moment gamma species (nu != 1: one exp per bin, k_psd<GAMMA_EXP>; rain, snow, graupel, hail without ice
+    crystals), whose slope is bounded by the clip of the mean mass, so that nothing leaves a complete table: the test
+    keeps only the lower panels of every table (CPOL_ITAB_KEEP_PANELS, as a table that lost panels to the accuracy gate)
+    and forces the path (CPOL_GATE1_RAY=2).  Same bits as the sequence with the integrating launch and k_final
+    (CPOL_GATE1_RAY=0) and as the general sequence with the counting sort; range scans and sensitivity cut included."""
+    import bench
+    from cosmo_pol_amd import RadarOperator, synthetic
+    hyds = ('R', 'S', 'G', 'H')
+    cube = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G'), two_moment=True)
+    conf = bench.bench_config(True)
+    conf['microphysics'].update(scheme='2mom', with_ice_crystals=0)
+    luts = synthetic.make_all_luts(hyds, 5.6, '2mom', n_e=8)
+    az = np.arange(20.0, 70.0, 2.5)
+    el = np.full(len(az), 2.0)
+    # where do the items lie?  (all on the table by default)
+    op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    op.simulate_rays(az, el)
+    c = op._ctx.counters()
+    assert c.n_table_items == c.n_valid_items > 1000
+    n_pan = [op._ctx.itab_detail(j)['n_pan'] for j in range(len(hyds))]
+    op.close()
+    out = {}
+    monkeypatch.setenv('CPOL_ITAB_KEEP_PANELS', '0:%d' % (min(n_pan) * 5 // 8))
+    for mode, env in (('sorted', {'CPOL_RARE_DIRECT': '0', 'CPOL_GATE1': '0'}), ('final', {'CPOL_GATE1_RAY': '0'}), ('ray', {'CPOL_GATE1_RAY': '2'})):
+        for k in ('CPOL_RARE_DIRECT', 'CPOL_GATE1', 'CPOL_GATE1_RAY'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
+        op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+        res = op.simulate_rays(az, el)
+        c = op._ctx.counters()
+        out[mode] = (res, int(c.n_valid_items), int(c.n_table_items))
+        op.close()
+    assert out['sorted'][1] == out['ray'][1] == out['final'][1] and out['sorted'][2] == out['ray'][2] == out['final'][2]
+    assert out['ray'][1] - out['ray'][2] > 50 and out['ray'][2] > 50, out['ray'][1:]      # items integrated bin by bin, and items on the tables
+    for k in ('ZH', 'ZV', 'ZDR', 'KDP', 'RHOHV', 'PHIDP', 'DELTA_HV', 'ATT_H', 'ATT_V', 'RVEL', 'mask'):
+        assert np.array_equal(out['ray'][0][k], out['sorted'][0][k], equal_nan=True), k
+        assert np.array_equal(out['final'][0][k], out['sorted'][0][k], equal_nan=True), k
+    assert np.isfinite(out['ray'][0]['ZH']).sum() > 300
+
+
+def test_rare_items_of_every_flavour_in_one_launch(monkeypatch):
+    """k_psd_rare runs every integrating flavour -- melting (polynomial tables), 1-moment ice (lambda tables and the direct
+    sums), the gamma recurrence -- from ONE launch when the work units are directly listed items.  A C3-like sweep (R, S, G,
+    mS, mG, I; nine sub-beams) with a wedge of mass densities so small that items of every species leave their tables:
+    same bits as one launch per flavour (CPOL_PSD_RARE=0) and as the counting sort (CPOL_RARE_DIRECT=0)."""
+    import bench
+    from cosmo_pol_amd import RadarOperator, synthetic
+    hyds = ['R', 'S', 'G', 'mS', 'mG', 'I']
+    conf = bench.bench_config(True, 'c3')
+    conf['integration'].update(nh_GH=3, nv_GH=3)
+    cube = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G', 'I'))
+    data = {k: v.copy() for k, v in cube['data'].items()}
+    ny, nx = data['QR_v'].shape[1:]
+    yy, xx = np.meshgrid(np.arange(ny), np.arange(nx), indexing='ij')
+    wedge = (xx > nx // 2) & (yy > ny // 2)
+    for k, tiny in (('QR_v', 1e-16), ('QS_v', 3e-18), ('QG_v', 1e-17), ('QI_v', 1e-19)):
+        f = data[k]
+        f[:, wedge] = np.where(f[:, wedge] > 0, np.float32(tiny), 0).astype(np.float32)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
+    az = np.arange(20.0, 70.0, 2.5)
+    el = np.full(len(az), 3.0)
+    out = {}
+    for mode, env in (('sorted', {'CPOL_RARE_DIRECT': '0'}), ('per_flavour', {'CPOL_PSD_RARE': '0'}), ('one_launch', {})):
+        for k in ('CPOL_RARE_DIRECT', 'CPOL_PSD_RARE'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
+        op.load_model_arrays(data, cube['zlevels'], cube['proj_info'], cube['resolution'])
+        res = op.simulate_rays(az, el)
+        c = op._ctx.counters()
+        out[mode] = (res, int(c.n_valid_items), int(c.n_table_items))
+        op.close()
+    assert out['sorted'][1:] == out['one_launch'][1:] == out['per_flavour'][1:]
+    assert out['one_launch'][1] - out['one_launch'][2] > 200, out['one_launch'][1:]
+    for k in ('ZH', 'ZV', 'ZDR', 'KDP', 'RHOHV', 'PHIDP', 'DELTA_HV', 'ATT_H', 'ATT_V', 'RVEL', 'mask'):
+        assert np.array_equal(out['one_launch'][0][k], out['sorted'][0][k], equal_nan=True), k
+        assert np.array_equal(out['per_flavour'][0][k], out['sorted'][0][k], equal_nan=True), k
+    assert np.isfinite(out['one_launch'][0]['ZH']).sum() > 300

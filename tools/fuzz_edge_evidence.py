@@ -147,7 +147,7 @@ def main():
                     alpha, beta = c['alpha_beta'][j]
                     cands.append({'sub': s, 'w': float(w), 'j': j, 'row': row, 'edge': name, 'D': float(D), 'q': float(q), 'bin': b0,
                                   'ulp_q': frac / ulp_q, 'need_ulp_D': need_ulp_D, 'p_bins': p, 'alpha': alpha, 'beta': beta,
-                                  'name': c['names'][j]})
+                                  'name': c['names'][j], 'args': c['args'], 'vidx': int(idx[row]), 'dmin': float(c['dmin'][j]), 'step': float(c['step'][j])})
     # an edge explains the difference when ONE table bin next to it carries the power that moved (times the two-way
     # attenuation of the sub-beam up to this gate, a factor in (0, 1])
     def ratio(cd):
@@ -170,13 +170,36 @@ def main():
     if plausible:
         best = plausible[0]
         rel_w = best['need_ulp_D'] * float(np.spacing(np.float32(best['D']))) / best['D'] * best['beta']
-        print('VERDICT: ONE table bin entered (or left) the bin sum of one (sub-beam, species) edge: its power matches the power that '
-              'moved, and the edge flips when the float32 chain that leads to w -- rho_corr = (RHO / RHO[0]) ** 0.5 and 1 / rho_corr in '
-              'float32, the wind terms -- differs by %.1e relative (%.1f float32 ulp) between NumPy and the device; the power law '
+        print('An edge flips here when w differs by %.1e relative (%.1f float32 ulp of w) between NumPy and the device; the power law '
               '(1 / beta = %.3g) turns that into %.1f ulp of D.' % (rel_w, rel_w / 5.96e-8, 1.0 / best['beta'], best['need_ulp_D']))
-        print('         %s' % ('A last-bit difference upstream: an EDGE FLIP as DESIGN.md section 4 describes (the record there said '
-                               '"1-ulp inverted diameter"; what differs by an ulp or two is w, D by 1/beta times as much).'
-                               if rel_w / 5.96e-8 <= 4.0 else 'MORE than a few ulp upstream: not a rounding-level flip -- look at the kernel.'))
+        # Where can such a difference come from?  w = 1 / rho_corr * (W + (U sin(phi) + V cos(phi)) / tan(theta) - v / sin(theta))
+        # with theta = np.deg2rad(elevation) a FLOAT32 (the elevation profile is float32): NumPy evaluates sin / tan of a float32
+        # with its SIMD float32 routines (within 1 ulp, not correctly rounded); the device rounds the float64 value once
+        # ((float)sin((double)th), cpol_spectrum.inl).  Both ways for this edge:
+        phi_deg, theta_deg, U, V, W, rho = best['args']
+        theta = np.deg2rad(np.float32(theta_deg))
+        phi = np.deg2rad(phi_deg)
+        v_edges = [varray[best['vidx']], varray[min(best['vidx'] + 1, len(varray) - 1)]]
+        forms = {'NumPy float32 sin / tan': (np.sin(theta), np.tan(theta)),
+                 'correctly rounded float32 (device)': (np.float32(np.sin(np.float64(theta))), np.float32(np.tan(np.float64(theta))))}
+        print('   theta = %.9g rad (float32 %s)' % (float(theta), f32hex(theta)))
+        for tag, (s32, t32) in forms.items():
+            with np.errstate(invalid='ignore', divide='ignore'):
+                wh = (1. / np.float32(rho) * (np.float32(W) + (np.float32(U) * np.sin(phi) + np.float32(V) * np.cos(phi)) / t32
+                                              - np.asarray(v_edges) / s32))
+                Dv = ((wh / best['alpha']) ** (1. / best['beta'])).astype(np.float32)
+            qv = ((Dv - np.float32(best['dmin'])) / np.float32(best['step'])).astype(np.float32)
+            print('   %-36s sin %s tan %s -> w %s  D %s (%s)  q %s -> bins %s'
+                  % (tag, f32hex(s32), f32hex(t32), ['%.9g' % x for x in wh], ['%.9g' % x for x in Dv], [f32hex(x) for x in Dv],
+                     ['%.9g' % x for x in qv], [int(x) for x in qv]))
+        s_np, t_np = forms['NumPy float32 sin / tan']
+        s_cr, t_cr = forms['correctly rounded float32 (device)']
+        differ = (s_np != s_cr) or (t_np != t_cr)
+        print('VERDICT: %s' % ('the float32 sin / tan of the elevation differ in the last bit between NumPy and a correctly rounded evaluation; '
+                               'v / sin(theta) and the wind term are ~10 x w here (they cancel), so that one float32 ulp in them is ~1e-6 of '
+                               'w: an EDGE FLIP from a last-bit difference upstream (DESIGN.md section 4 said "1-ulp inverted diameter": the ulp '
+                               'is in sin / tan of the float32 elevation, D moves by several).' if differ else
+                               'sin / tan agree: the difference must come from elsewhere in the chain (rho_corr, the power).'))
     else:
         print('VERDICT: no (sub-beam, species) edge next to the differing bins carries the power that moved: NOT an edge flip.')
     op.close()

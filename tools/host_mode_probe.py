@@ -135,15 +135,17 @@ def main():
         s = sec.take()
         known = sum(s.values())
         # the library's own split of cpol_run_sweep (host ns by section, summed over the lanes)
-        lib = np.zeros(6)
+        lib = np.zeros(10)
         for i in range(n_lanes):
-            lib += op._lane(i).debug_read('host_times', (6,), np.float64)
+            lib += op._lane(i).debug_read('host_times', (10,), np.float64)
         calls = max(lib[0], 1.0)
         return {'ms_per_sweep': 1e3 * el / n, 'submit_ms_per_sweep': 1e3 * t_submit / n,
                 'sections_us_per_sweep': dict({k: 1e6 * v / n for k, v in s.items()}, rest=1e6 * (t_submit - known) / n),
                 'inside_cpol_run_sweep_us': {'tables_staging_and_h2d_call': 1e-3 * lib[1] / calls, 'work_buffers': 1e-3 * lib[2] / calls,
                                              'kernel_launches': 1e-3 * lib[3] / calls, 'd2h_copy_call': 1e-3 * lib[4] / calls,
-                                             'all': 1e-3 * lib[5] / calls},
+                                             'all': 1e-3 * lib[5] / calls,
+                                             'of_tables: wait_for_staging_slot': 1e-3 * lib[6] / calls, 'of_tables: fill_slot': 1e-3 * lib[7] / calls,
+                                             'of_tables: hipMemcpyAsync_h2d': 1e-3 * lib[8] / calls, 'of_tables: hipEventRecord': 1e-3 * lib[9] / calls},
                 'cpu': [c0, c1], 'cpu_mhz_before': m0, 'cpu_mhz_after': cpu_mhz(c1) if c1 >= 0 else None,
                 'ctx_switches': [ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw],
                 'minor_faults': ru1.ru_minflt - ru0.ru_minflt, 'pinned_blocks_allocated': op._pool.n_alloc}
@@ -151,10 +153,11 @@ def main():
     def show(tag, r):
         s = r['sections_us_per_sweep']
         li = r['inside_cpol_run_sweep_us']
-        print('%-15s %.3f ms/sweep  submit %.3f  [ray_tables %5.0f  take %4.0f  run_sweep %5.0f (tables+h2d %4.0f  buffers %4.0f  '
-              'launches %4.0f  d2h call %4.0f)  rest %5.0f us]  csw %s  faults %d  blocks %d'
+        print('%-15s %.3f ms/sweep  submit %.3f  [ray_tables %5.0f  take %4.0f  run_sweep %5.0f (tables+h2d %4.0f = wait %3.0f fill %3.0f '
+              'h2d %3.0f record %3.0f;  buffers %4.0f  launches %4.0f  d2h call %4.0f)  rest %5.0f us]  csw %s  faults %d  blocks %d'
               % (tag, r['ms_per_sweep'], r['submit_ms_per_sweep'], s.get('ray_tables', 0), s.get('pool_take', 0),
-                 s.get('cpol_run_sweep', 0), li['tables_staging_and_h2d_call'], li['work_buffers'], li['kernel_launches'],
+                 s.get('cpol_run_sweep', 0), li['tables_staging_and_h2d_call'], li['of_tables: wait_for_staging_slot'], li['of_tables: fill_slot'],
+                 li['of_tables: hipMemcpyAsync_h2d'], li['of_tables: hipEventRecord'], li['work_buffers'], li['kernel_launches'],
                  li['d2h_copy_call'], s['rest'], r['ctx_switches'], r['minor_faults'], r['pinned_blocks_allocated']),
               file=sys.stderr, flush=True)
 
