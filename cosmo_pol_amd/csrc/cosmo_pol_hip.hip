@@ -145,14 +145,14 @@ struct cpol_ctx {
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
     int lookup_split = 0;              // CPOL_LOOKUP_SPLIT=<n>: wavefronts per tile of k_psd_lookup (0: by launch size)
-    int gate1_ray = 1;                 // CPOL_GATE1_RAY=0: never k_gate1_ray (the range scans inside the gate kernel, items off the tables integrated in place: a sweep of two launches)
+    int gate1_ray = 1;                 // CPOL_GATE1_RAY=0: never k_gate1_ray (items off the tables integrated in place, the range scans by k_scan_rays: a single-beam sweep
+                                       // of three lean launches, no integrating launch); 2: also with tables that lost panels; 3: the scans inside the gate kernel (a ticket per ray)
     int gate1_species = 1;             // CPOL_GATE1_SPECIES=0 / 2: never / always k_gate1_species (one wavefront per species; default: small launches)
     int fuse_gate1 = 0;                // CPOL_FUSE_GATE1=1: k_interp_gate1 instead of k_interp_sweep + k_gate1 (measured slower where it matters)
     int fuse_classify = 1;             // CPOL_FUSE_CLASSIFY=0: k_interp_sweep + k_classify instead of k_interp_classify (read when the context is created)
     int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
     int subsum_scalar = 0;             // CPOL_SUBSUM_FORM=scalar: the cooperative form of k_subbeam_sum takes its rows through the scalar cache instead of LDS
     int psd_rare = 1;                  // CPOL_PSD_RARE=0: one launch per integrating flavour also when the units are directly listed items (read when the context is created)
-    int subsum_lanes = 1;              // CPOL_SUBSUM_WALK=wave: the gather form of k_subbeam_sum walks the union of the wavefront's sub-beams (round 4) instead of every lane its own
     int subsum_small = 0;              // CPOL_SUBSUM_SMALL=1: experiment: the gather form of k_subbeam_sum with three wavefronts per (tile, hydrometeor) and the whole block in flight (measured slower)
     int subsum_coop = -1;              // CPOL_SUBSUM_COOP: k_subbeam_sum takes its coefficients through the scalar cache: 0 never, 1 always, -1 by launch size
     bool last_subsum = false;          // the 1-D table items of the last sweep never went through res[] (k_subbeam_sum)
@@ -603,7 +603,7 @@ int cpol_create(int device, cpol_ctx **out)
     if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
     if (getenv("CPOL_LOOKUP_SPLIT")) ctx->lookup_split = std::max(0, std::min(16, atoi(getenv("CPOL_LOOKUP_SPLIT"))));
     if (getenv("CPOL_GATE1_SPECIES")) ctx->gate1_species = std::max(0, std::min(2, atoi(getenv("CPOL_GATE1_SPECIES"))));
-    if (getenv("CPOL_GATE1_RAY")) ctx->gate1_ray = std::max(0, std::min(2, atoi(getenv("CPOL_GATE1_RAY"))));   // (2: also with tables that lost panels)
+    if (getenv("CPOL_GATE1_RAY")) ctx->gate1_ray = std::max(0, std::min(3, atoi(getenv("CPOL_GATE1_RAY"))));   // (2: also with tables that lost panels; 3: the scans inside the gate kernel)
     if (getenv("CPOL_FUSE_GATE1")) ctx->fuse_gate1 = atoi(getenv("CPOL_FUSE_GATE1")) != 0 ? 1 : 0;
     if (getenv("CPOL_FUSE_CLASSIFY")) ctx->fuse_classify = atoi(getenv("CPOL_FUSE_CLASSIFY")) != 0 ? 1 : 0;
     if (getenv("CPOL_RARE_DIRECT")) ctx->rare_direct = atoi(getenv("CPOL_RARE_DIRECT")) != 0 ? 1 : 0;
@@ -611,7 +611,6 @@ int cpol_create(int device, cpol_ctx **out)
     if (getenv("CPOL_SUBSUM_FORM")) ctx->subsum_scalar = !strcmp(getenv("CPOL_SUBSUM_FORM"), "scalar") ? 1 : 0;
     if (getenv("CPOL_SUBSUM_SMALL")) ctx->subsum_small = atoi(getenv("CPOL_SUBSUM_SMALL")) != 0 ? 1 : 0;
     if (getenv("CPOL_PSD_RARE")) ctx->psd_rare = atoi(getenv("CPOL_PSD_RARE")) != 0 ? 1 : 0;
-    if (getenv("CPOL_SUBSUM_WALK")) ctx->subsum_lanes = strcmp(getenv("CPOL_SUBSUM_WALK"), "wave") != 0 ? 1 : 0;
     if (getenv("CPOL_SUBSUM_COOP_ROUNDS")) ctx->subsum_coop_rounds = std::max(0, std::min(64, atoi(getenv("CPOL_SUBSUM_COOP_ROUNDS"))));
     *out = ctx;
     return CPOL_OK;
@@ -713,7 +712,6 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->use_graph = parent->use_graph;
     c->subsum_coop = parent->subsum_coop;
     c->subsum_small = parent->subsum_small;
-    c->subsum_lanes = parent->subsum_lanes;
     c->psd_rare = parent->psd_rare;
     c->subsum_scalar = parent->subsum_scalar;
     c->rare_direct = parent->rare_direct;
@@ -1501,13 +1499,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         const cpol_hydro_desc &d = ctx->hs.h[j].d;
         const ItabDev &tj = ctx->its.t[j];
         gate1_ray = d.psd_family == CPOL_PSD_GAMMA && !d.numeric_intv && d.q_source == CPOL_Q_MODEL && tj.tab && !tj.two_d &&
-                    ((tj.pan_lo == 0 && tj.pan_hi >= tj.n_pan - 2) || ctx->gate1_ray == 2) && ctx->hs.h[j].pre && ctx->hs.h[j].dnu;
+                    ((tj.pan_lo == 0 && tj.pan_hi >= tj.n_pan - 2) || ctx->gate1_ray >= 2) && ctx->hs.h[j].pre && ctx->hs.h[j].dnu;
     }
     {
         const long g1_waves = n_rg * n_hyd / 64 / 1024;
         gate1_ray = gate1_ray && (ctx->gate1_species == 2 || (ctx->gate1_species == 1 && g1_waves < 48));
     }
-    if (gate1_ray) {
+    if (gate1_ray && ctx->gate1_ray == 3) {
         void *const was = ctx->b_ticket.p;
         ENSURE(ctx->b_ticket, (size_t)n_rays * sizeof(int));
         if (ctx->b_ticket.p != was || was_dirty)                 // (the kernel leaves every ticket at 0 behind it)
@@ -1818,8 +1816,19 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             rr.sens_thr = cut ? (const double *)ctx->v_sens : nullptr;
             rr.radial_res = (float)p->radial_res;
             const size_t lds_terms = (size_t)n_hyd * 64 * GATE1S_BYTES, lds_scan = (size_t)3 * ng * sizeof(float);
-            hipLaunchKernelGGL(k_gate1_ray, dim3((unsigned)cdiv(ng, 64), (unsigned)n_rays), dim3(64 * n_hyd),
-                               lds_terms > lds_scan ? lds_terms : lds_scan, st, ctx->hs, ctx->its, ca, fa, ga, rr);
+            const dim3 rgrid((unsigned)cdiv(ng, 64), (unsigned)n_rays);
+            if (ctx->gate1_ray == 3) {
+                hipLaunchKernelGGL(k_gate1_ray_scan, rgrid, dim3(64 * n_hyd), lds_terms > lds_scan ? lds_terms : lds_scan, st,
+                                   ctx->hs, ctx->its, ca, fa, ga, rr);
+            } else {
+                hipLaunchKernelGGL(k_gate1_ray, rgrid, dim3(64 * n_hyd), lds_terms, st, ctx->hs, ctx->its, ca, fa, ga, rr);
+                if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_CLASSIFY], st));
+                if (tm_psd) { HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st)); HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st)); }
+                hipLaunchKernelGGL(k_scan_rays, dim3((unsigned)n_rays), dim3(256), lds_scan, st, fa, ga, rr);
+                if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
+                HIPCHK(hipGetLastError());
+                return CPOL_OK;
+            }
             if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_CLASSIFY], st));
             if (tm_psd) { HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st)); HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st)); }
             if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
@@ -2083,7 +2092,6 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // (CPOL_SUBSUM_FORM=scalar, read when the context is created)
         if (coop && ctx->subsum_scalar) hipLaunchKernelGGL(k_subbeam_sum_scalar, dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
         else if (coop) hipLaunchKernelGGL(k_subbeam_sum_lds, dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
-        else if (!small && ctx->subsum_lanes) hipLaunchKernelGGL(k_subbeam_sum_lanes, dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
         else if (small) hipLaunchKernelGGL((k_subbeam_sum_gather<3, 10>), dim3((unsigned)tiles, n_hyd * 3), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
         else hipLaunchKernelGGL((k_subbeam_sum_gather<1, 2>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
     }

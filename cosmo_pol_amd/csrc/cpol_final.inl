@@ -316,15 +316,14 @@ __device__ __forceinline__ double fma_sgpr(double a, double b, double c_uniform)
 __device__ unsigned long long g_subsum_stats[4];
 #endif
 enum { SUBSUM_GATHER = 0, SUBSUM_SCALAR = 1, SUBSUM_LDS = 2 };
-// PERLANE (gather form only): every lane walks ITS OWN present sub-beams (the set bits of its validity word, in order)
-// instead of the wavefront walking the union of its lanes' sub-beams with the absent lanes idle.  A tile of 16 rays x 4
-// gates sees a species at different sub-beams in different rays, so the union is ~3 x what one lane has ("the tile's
-// lanes are a third full on average", above): the wavefront now runs max-over-lanes iterations instead.  Same terms in
-// the same order per gate: the same bits.
-template <int FORM, int SPLIT, int GUNROLL, bool PERLANE = false>
+// (Measured and dropped, round 5: the gather form with every lane walking ITS OWN present sub-beams -- the set bits of its
+// validity word -- instead of the wavefront walking the union of its lanes' sub-beams: the 225-ray share 849 -> 885 us of
+// PSD stage; the longest lane of a tile is as long as the union.  And the table rows themselves are not what bounds it
+// either: degree-6 blocks on panels a quarter as wide, 7 rows gathered instead of 11, 842 -> 806 us, with k_final
+// paying for it elsewhere: profiles/r5_itab1_degree.txt.)
+template <int FORM, int SPLIT, int GUNROLL>
 __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabSet &its, const SubsumArgs &a)
 {
-    static_assert(!PERLANE || FORM == SUBSUM_GATHER, "the per-lane walk has no shared blocks");
     constexpr bool COOP = FORM != SUBSUM_GATHER;
     static_assert(CPOL_SUBSUM_THREADS == CPOL_WAVE, "one wavefront per workgroup: the tile walk uses wave-wide ballots");
     constexpr int NC = CPOL_ITAB1_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
@@ -373,71 +372,6 @@ __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabS
         if (lane == 0 && part == 0) atomicAdd(&g_subsum_stats[3], (unsigned long long)(n_here - __popcll(wp)));
 #endif
         if (!wp) continue;
-        if constexpr (PERLANE) {
-            unsigned long long mine = pm;
-            // key + record of the lane's NEXT sub-beam are requested before the rows of the current one
-            int q_n = mine ? __ffsll((long long)mine) - 1 : 0;
-            int key_n = mine ? K[sbg0 + (long)(s_lo + q_n) * a.n_gates] : 0;
-            double2 rc_n = (mine && tab1) ? R[sbg0 + (long)(s_lo + q_n) * a.n_gates] : make_double2(-1.0, 0.0);
-            while (__builtin_amdgcn_ballot_w64(mine != 0)) {
-                const bool present = mine != 0;
-                const int s = s_lo + q_n;
-                const long sbg = sbg0 + (long)s * a.n_gates;
-                const int key = key_n;
-                const double2 rc = rc_n;
-                mine &= mine - 1;
-                if (mine) {
-                    q_n = __ffsll((long long)mine) - 1;
-                    const long sbg_n = sbg0 + (long)(s_lo + q_n) * a.n_gates;
-                    key_n = K[sbg_n];
-                    rc_n = tab1 ? R[sbg_n] : make_double2(-1.0, 0.0);
-                }
-                if (!present) continue;
-                const bool on_tab = rc.x >= 0.0;
-                double2 v[NP];
-                double2 wv = make_double2(0.0, 0.0);
-                if (on_tab) {
-                    const int pn = min((int)rc.x, t.n_pan - 1);
-                    const double u = 2.0 * (rc.x - (double)pn) - 1.0;
-                    const double2 *blk = reinterpret_cast<const double2 *>(t.tab + ((long)(key - key_base) * t.n_pan + pn) * NB);
-#pragma unroll
-                    for (int f = 0; f < NP; ++f) v[f] = blk[(NC - 1) * (NFP / 2) + f0 + f];
-                    if (want_vn) wv = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
-#pragma unroll GUNROLL
-                    for (int q = NC - 2; q >= 0; --q) {
-#pragma unroll
-                        for (int f = 0; f < NP; ++f) {
-                            const double2 cq = blk[q * (NFP / 2) + f0 + f];
-                            v[f].x = fma(v[f].x, u, cq.x);
-                            v[f].y = fma(v[f].y, u, cq.y);
-                        }
-                        if (want_vn) {
-                            const double2 cq = blk[q * (NFP / 2) + CPOL_N_SZ / 2];
-                            wv.x = fma(wv.x, u, cq.x);
-                            wv.y = fma(wv.y, u, cq.y);
-                        }
-                    }
-#pragma unroll
-                    for (int f = 0; f < NP; ++f) { v[f].x *= rc.y; v[f].y *= rc.y; }
-                    if (want_vn)
-                        *reinterpret_cast<double2 *>(a.vn + ((long)j * n_sbg + sbg) * 2) = make_double2(wv.x * rc.y, wv.y * rc.y);
-                } else {
-                    const double2 *r = reinterpret_cast<const double2 *>(a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ) + f0;
-#pragma unroll
-                    for (int c = 0; c < NP; ++c) v[c] = r[c];
-                }
-                const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
-#pragma unroll
-                for (int c = 0; c < 2 * NP; ++c) {
-                    double y = ((c & 1) ? v[c / 2].y : v[c / 2].x) * w;
-                    const float xa = (acc[c] == acc[c]) ? acc[c] : 0.f;
-                    const double x = (double)xa;
-                    if (!(y == y)) y = 0.0;
-                    acc[c] = (float)(x + y);
-                }
-            }
-            continue;
-        }
         // key + record of the NEXT present sub-beam are requested before the rows of the current one
         int q_next = __ffsll((long long)wp) - 1;
         int key_n = 0;
@@ -667,11 +601,7 @@ void k_subbeam_sum_scalar(HydroSet hs, ItabSet its, SubsumArgs a) { subbeam_sum_
 template <int SPLIT, int GUNROLL>
 __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR
 void k_subbeam_sum_gather(HydroSet hs, ItabSet its, SubsumArgs a) { subbeam_sum_body<SUBSUM_GATHER, SPLIT, GUNROLL>(hs, its, a); }
-#ifndef CPOL_SUBSUM_LANE_UNROLL
-#define CPOL_SUBSUM_LANE_UNROLL 2
-#endif
-__global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR
-void k_subbeam_sum_lanes(HydroSet hs, ItabSet its, SubsumArgs a) { subbeam_sum_body<SUBSUM_GATHER, 1, CPOL_SUBSUM_LANE_UNROLL, true>(hs, its, a); }
+
 
 #ifndef CPOL_SKIP_RVEL
 #define CPOL_SKIP_RVEL 0      // experiment knob (tools/variants.sh): time of the RVEL loop

@@ -431,7 +431,7 @@ __device__ __attribute__((noinline)) void integrate_gamma_item_wave(const double
 // integrating launch behind this kernel), and the workgroup that finishes LAST of its ray -- a ticket per ray, taken behind
 // a device-scope fence -- runs the ray's three sequential float32 range scans, PHIDP, the attenuated ZDR and the
 // sensitivity cut (the second half of k_final): the whole sweep is k_interp_sweep + this kernel.
-template <bool RAY>
+template <bool RAY, bool TICKET>
 __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const ItabSet &its, const ClassifyArgs &a, const FinalArgs &f,
                                                    const GateArgs &g, const ScanRayArgs &r)
 {
@@ -597,19 +597,32 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
             g.sv[i] = fv;
         }
     }
-    if (!RAY) return;
+    if (!TICKET) return;
 
     // ---- the ray's ticket: the workgroup that finishes LAST of the ray scans it ----
-    __threadfence();                                  // (release: this workgroup's gates -- outputs and scan operands -- are visible device-wide)
+    // (hand-off between workgroups as MI355X_MICROARCH.md prescribes: the XCDs' L2s are not coherent with each other and
+    // a CU's L1 is never refreshed by another CU's stores.  Producer: plain stores, every storing wave waits for them,
+    // workgroup barrier, ONE lane releases at agent scope -- writes the XCD L2's dirty lines back -- and adds to the ray's
+    // ticket.  Consumer: the workgroup whose add came last, told by the value the add returned; the adding lane acquires at
+    // agent scope -- invalidates this CU's L1 -- waits for the invalidate, the workgroup barrier holds the other waves
+    // until then; plain loads behind it.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int old = atomicAdd(g.ticket + ray_b, 1);
-        s_last = old == (int)gridDim.x - 1;
-        if (s_last) g.ticket[ray_b] = 0;              // (ready for the next sweep: nobody else touches the ray's ticket any more)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(g.ticket + ray_b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == (int)gridDim.x - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (ready for the next sweep: nobody else touches the ray's ticket any more)
+            __hip_atomic_store(g.ticket + ray_b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();                                  // (acquire: the other workgroups' gates of this ray)
     const int ng = f.n_gates, tid = threadIdx.x, nthr = blockDim.x;
     const int wave = j, n_waves = n_h;
     const long base = (long)ray_b * ng;
@@ -682,12 +695,91 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
 
 __global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_species(HydroSet hs, ItabSet its, ClassifyArgs a, FinalArgs f, GateArgs g)
 {
-    gate1_species_body<false>(hs, its, a, f, g, ScanRayArgs{});
+    gate1_species_body<false, false>(hs, its, a, f, g, ScanRayArgs{});
 }
 
 // grid = (ceil(n_gates / 64), n_rays), block = 64 * n_hydro, dynamic LDS = max(n_hydro * 64 * GATE1S_BYTES, 3 * n_gates * 4)
 __global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_ray(HydroSet hs, ItabSet its, ClassifyArgs a, FinalArgs f, GateArgs g,
                                                                                   ScanRayArgs r)
 {
-    gate1_species_body<true>(hs, its, a, f, g, r);
+    gate1_species_body<true, false>(hs, its, a, f, g, r);
+}
+
+// the same with the ray's scans inside (the ticket: see gate1_species_body); CPOL_GATE1_RAY=3.  Measured: the agent-scope
+// release every workgroup needs in front of its ticket costs more than the launch of k_scan_rays saves (profiles/r5_variants.txt)
+__global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_ray_scan(HydroSet hs, ItabSet its, ClassifyArgs a, FinalArgs f, GateArgs g,
+                                                                                       ScanRayArgs r)
+{
+    gate1_species_body<true, true>(hs, its, a, f, g, r);
+}
+
+// The range scans of a single-beam sweep whose gates k_gate1_ray has finished (no deferred gates: nothing of final_gate):
+// one workgroup per ray, the operands of the three strictly sequential float32 scans through LDS, lane 0 of three
+// wavefronts runs one scan each, then PHIDP, the attenuated ZDR and the sensitivity cut -- the second half of k_final
+// without the per-gate function's 243 registers (k_final<256> on the C2 sweep: 15-19 us for this work).
+__global__ __launch_bounds__(256) void k_scan_rays(FinalArgs f, GateArgs g, ScanRayArgs r)
+{
+    extern __shared__ float lds_scan[];                // [3][n_gates]
+    const int ray = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ng = f.n_gates;
+    const long base = (long)ray * ng;
+    float *s_k = lds_scan, *s_h = lds_scan + ng, *s_v = lds_scan + 2 * ng;
+    for (int gg = tid; gg < ng; gg += 256) {
+        s_k[gg] = g.sk[base + gg];
+        s_h[gg] = g.sh[base + gg];
+        s_v[gg] = g.sv[base + gg];
+    }
+    __syncthreads();
+    if (lane == 0 && (wave == 0 || (f.with_attenuation && wave < 3))) {
+        float *sv = (wave == 0) ? s_k : (wave == 1 ? s_h : s_v);
+        float c = 0.0f;
+        int gg = 0;
+        if (wave == 0) {
+            for (; gg + 8 <= ng; gg += 8) {
+                float q8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) q8[q] = sv[gg + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { c = (gg + q == 0) ? q8[0] : c + q8[q]; q8[q] = c; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sv[gg + q] = q8[q];
+            }
+            for (; gg < ng; ++gg) { c = (gg == 0) ? sv[gg] : c + sv[gg]; sv[gg] = c; }
+        } else {
+            for (; gg + 8 <= ng; gg += 8) {
+                float q8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) q8[q] = sv[gg + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { c = (gg + q == 0) ? q8[0] : c * q8[q]; q8[q] = c; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sv[gg + q] = q8[q];
+            }
+            for (; gg < ng; ++gg) { c = (gg == 0) ? sv[gg] : c * sv[gg]; sv[gg] = c; }
+        }
+    }
+    __syncthreads();
+    double *rvel = f.RVEL ? f.RVEL : r.RVEL;
+    for (int gg = tid; gg < ng; gg += 256) {
+        const long ii = base + gg;
+        const float zh = f.ZH[ii], zv = f.ZV[ii];
+        float phidp = s_k[gg] * r.radial_res / 1000.0f + f.DELTA_HV[ii];
+        float zdr = f.ZDR[ii];
+        if (f.with_attenuation) zdr = (zh * s_h[gg]) / (zv * s_v[gg]);
+        bool cut = false;
+        if (r.sens_thr) {
+            // 10*np.log10(ZH) (float32) < threshold(r) (float64)
+            const float dbz = 10.0f * (float)log10((double)zh);
+            cut = (double)dbz < r.sens_thr[gg];
+        }
+        if (cut) {
+            const float qnan = __builtin_nanf("");
+            f.ZH[ii] = qnan; f.ZV[ii] = qnan; f.KDP[ii] = qnan; f.RHOHV[ii] = qnan;
+            zdr = qnan; phidp = qnan;
+            if (rvel) rvel[ii] = __builtin_nan("");
+        }
+        r.PHIDP[ii] = phidp;
+        f.ZDR[ii] = zdr;
+    }
 }

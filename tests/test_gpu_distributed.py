@@ -57,7 +57,7 @@ def _run_and_read(cmd, env):
         lines = [l for l in rows if l.startswith('{')]
         assert len(lines) == 1 and rows[-1] == lines[0]          # rank 0 alone prints; the compact line is the last one
         assert len(lines[0]) < 4096
-        assert all(l.startswith('#detail ') for l in rows[:-1] if l.strip())
+        assert any(l.startswith('#detail ') for l in rows[:-1])      # (the full result also travels on prefixed lines)
         line = json.loads(lines[0])
         with open(detail) as f:
             full = json.load(f)

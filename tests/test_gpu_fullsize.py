@@ -168,20 +168,17 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
     assert n_valid > 300 and n_melt > 100, (n_valid, n_melt)
     op.close()
     forms = {}
-    for form in ('gather', 'gather1', 'gather1_wave', 'coop', 'scalar', 'tail', 'two_kernels'):
+    for form in ('gather', 'gather1', 'coop', 'scalar', 'tail', 'two_kernels'):
         # 'gather': the per-lane gather in its small-launch form (three wavefronts per (tile, hydrometeor), the
-        # whole block requested at once: CPOL_SUBSUM_SMALL=1, an experiment); 'gather1': one wavefront per (tile,
-        # hydrometeor), every LANE walking its own present sub-beams (k_subbeam_sum_lanes, round 5: what a small launch
-        # gets by default); 'gather1_wave': the same with the wavefront walking the union of its lanes' sub-beams
-        # (CPOL_SUBSUM_WALK=wave, round 4's form);
+        # whole block requested at once: CPOL_SUBSUM_SMALL=1, an experiment); 'gather1': one wavefront per
+        # (tile, hydrometeor), rows two at a time (what a small launch gets by default);
         # 'coop': up to 6 table blocks per wavefront and sub-beam staged in LDS (global_load_lds, round 4), the
         # remaining lanes by the gather tail; 'scalar': the same walk with the rows through the scalar cache
         # (round 3's form, CPOL_SUBSUM_FORM=scalar); 'tail': ONE block that way, every other lane through the tail
         # 'two_kernels': the default forms, but k_interp_sweep + k_classify instead of the one kernel that interpolates
         # and classifies its gates (k_interp_classify, the default of this path since round 4)
         monkeypatch.setenv('CPOL_SUBSUM_COOP', '0' if form.startswith('gather') else '1')     # (read when the context is created)
-        monkeypatch.setenv('CPOL_SUBSUM_SMALL', '0' if form.startswith('gather1') else '1')
-        monkeypatch.setenv('CPOL_SUBSUM_WALK', 'wave' if form == 'gather1_wave' else 'lane')
+        monkeypatch.setenv('CPOL_SUBSUM_SMALL', '0' if form == 'gather1' else '1')
         monkeypatch.setenv('CPOL_SUBSUM_COOP_ROUNDS', '1' if form == 'tail' else '6')
         monkeypatch.setenv('CPOL_SUBSUM_FORM', 'scalar' if form == 'scalar' else 'lds')
         monkeypatch.setenv('CPOL_FUSE_CLASSIFY', '0' if form == 'two_kernels' else '1')
@@ -196,7 +193,6 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
         assert np.array_equal(forms['gather'][k], forms['coop'][k], equal_nan=True), k
         assert np.array_equal(forms['gather'][k], forms['tail'][k], equal_nan=True), k
         assert np.array_equal(forms['gather'][k], forms['gather1'][k], equal_nan=True), k
-        assert np.array_equal(forms['gather'][k], forms['gather1_wave'][k], equal_nan=True), k
         assert np.array_equal(forms['gather'][k], forms['scalar'][k], equal_nan=True), k
         assert np.array_equal(forms['gather'][k], forms['two_kernels'][k], equal_nan=True), k
         assert np.array_equal(forms['gather'][k], res[k], equal_nan=True), k     # (res: the default choice, last elevation)
