@@ -126,7 +126,7 @@ struct cpol_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     struct Staging { void *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } stg[4];
     int stg_next = 0;
-    DevBuf b_traj, b_wgate, b_clk, b_rayc;
+    DevBuf b_traj, b_wgate, b_clk, b_rayc, b_poly, d_geoM;
     DevBuf b_beam, b_spectrum, b_outwin;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
         b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel, b_proj, b_blkranked, b_rec, b_vmask, b_gscan, b_defer;
@@ -152,6 +152,8 @@ struct cpol_ctx {
     int fuse_classify = 1;             // CPOL_FUSE_CLASSIFY=0: k_interp_sweep + k_classify instead of k_interp_classify (read when the context is created)
     int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
     int subsum_scalar = 0;             // CPOL_SUBSUM_FORM=scalar: the cooperative form of k_subbeam_sum takes its rows through the scalar cache instead of LDS
+    int upload_kernel = 1;             // CPOL_TABLE_UPLOAD=memcpy: the per-ray tables by hipMemcpyAsync instead of k_upload_tables
+    int geo_poly = 1;                  // CPOL_GEO_POLY=0: the non-central sub-beams take the short closed form of the geodesy instead of the per-ray polynomials
     int psd_rare = 1;                  // CPOL_PSD_RARE=0: one launch per integrating flavour also when the units are directly listed items (read when the context is created)
     int subsum_small = 0;              // CPOL_SUBSUM_SMALL=1: experiment: the gather form of k_subbeam_sum with three wavefronts per (tile, hydrometeor) and the whole block in flight (measured slower)
     int subsum_coop = -1;              // CPOL_SUBSUM_COOP: k_subbeam_sum takes its coefficients through the scalar cache: 0 never, 1 always, -1 by launch size
@@ -610,6 +612,8 @@ int cpol_create(int device, cpol_ctx **out)
     if (getenv("CPOL_GATE1")) ctx->gate1 = atoi(getenv("CPOL_GATE1"));
     if (getenv("CPOL_SUBSUM_FORM")) ctx->subsum_scalar = !strcmp(getenv("CPOL_SUBSUM_FORM"), "scalar") ? 1 : 0;
     if (getenv("CPOL_SUBSUM_SMALL")) ctx->subsum_small = atoi(getenv("CPOL_SUBSUM_SMALL")) != 0 ? 1 : 0;
+    if (getenv("CPOL_TABLE_UPLOAD")) ctx->upload_kernel = strcmp(getenv("CPOL_TABLE_UPLOAD"), "memcpy") != 0 ? 1 : 0;
+    if (getenv("CPOL_GEO_POLY")) ctx->geo_poly = atoi(getenv("CPOL_GEO_POLY")) != 0 ? 1 : 0;
     if (getenv("CPOL_PSD_RARE")) ctx->psd_rare = atoi(getenv("CPOL_PSD_RARE")) != 0 ? 1 : 0;
     if (getenv("CPOL_SUBSUM_COOP_ROUNDS")) ctx->subsum_coop_rounds = std::max(0, std::min(64, atoi(getenv("CPOL_SUBSUM_COOP_ROUNDS"))));
     *out = ctx;
@@ -660,7 +664,7 @@ void cpol_destroy(cpol_ctx *ctx)
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_units,
                      &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_pos,
                      &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel, &ctx->b_proj, &ctx->b_blkranked, &ctx->b_rec, &ctx->b_vmask, &ctx->b_gscan, &ctx->b_defer,
-                     &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model};
+                     &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model, &ctx->b_ticket, &ctx->b_poly, &ctx->d_geoM};
     for (DevBuf *b : all) free_buf(*b);
     for (auto &b : ctx->b_out) free_buf(b);
     for (int j = 0; j < CPOL_MAX_HYDRO; ++j) {
@@ -713,6 +717,8 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->subsum_coop = parent->subsum_coop;
     c->subsum_small = parent->subsum_small;
     c->psd_rare = parent->psd_rare;
+    c->geo_poly = parent->geo_poly;
+    c->upload_kernel = parent->upload_kernel;
     c->subsum_scalar = parent->subsum_scalar;
     c->rare_direct = parent->rare_direct;
     c->fuse_classify = parent->fuse_classify;
@@ -1225,6 +1231,17 @@ int cpol_ray_tables(const cpol_sweep_params *p, const double *az_deg, const doub
     return CPOL_OK;
 }
 
+// The per-ray tables of a sweep, from the page-locked staging slot (host memory the device can address) into the table
+// set's device buffer, by a kernel instead of hipMemcpyAsync: measured (tools/host_mode_probe.py, profiles/
+// r5_host_mode_probe.txt) the runtime's small host-to-device copy call takes ~2 us most of the time and ~340 us, with ~200
+// page faults per call, in the two timed regions that follow the first synchronisation of a process -- the "slow mode"
+// of round 4's host_outputs figure.  A launch costs the host the same 3-5 us every time.
+__global__ __launch_bounds__(256) void k_upload_tables(uint4 *__restrict__ dst, const uint4 *__restrict__ src, long n16)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
 static inline double now_ns()
 {
     timespec ts;
@@ -1351,7 +1368,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             off += (it.bytes + 63) & ~(size_t)63;
         }
         const double t_s2 = now_ns();
-        HIPCHK(hipMemcpyAsync(set->buf.p, sg.p, total, hipMemcpyHostToDevice, ctx->stream));
+        if (ctx->upload_kernel) {
+            const long n16 = (long)(total / 16);          // (every table is padded to 64 bytes)
+            hipLaunchKernelGGL(k_upload_tables, dim3((unsigned)std::min<long>(cdiv(n16, 256), 256)), dim3(256), 0, ctx->stream,
+                               (uint4 *)set->buf.p, (const uint4 *)sg.p, n16);
+        } else {
+            HIPCHK(hipMemcpyAsync(set->buf.p, sg.p, total, hipMemcpyHostToDevice, ctx->stream));
+        }
         const double t_s3 = now_ns();
         HIPCHK(hipEventRecord(sg.ev, ctx->stream));
         const double t_s4 = now_ns();
@@ -1369,6 +1392,32 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (mode == CPOL_GEOM_HOST_PATHS || ctx->keep_debug || prep_paths)
         ENSURE(ctx->b_traj, (size_t)n_rays * n_v * 3 * ng * sizeof(float));
     if (ray_prep) ENSURE(ctx->b_rayc, ((size_t)n_rays * n_h + n_rays) * 2 * sizeof(double));
+    // the rotated coordinates of the non-central sub-beams as polynomials of the arc distance (cpol_interp.inl: geo_poly_fit):
+    // ground radars on the 4/3-earth ray paths, one site (CPOL_GEO_POLY=0: the short closed form of round 4)
+    const bool geo_poly = ray_prep && ctx->geo_poly && mode == CPOL_GEOM_GROUND_43 && !t->site;
+    if (geo_poly) {
+        ENSURE(ctx->b_poly, (size_t)n_rays * n_h * 2 * CPOL_GEO_NP * sizeof(double));
+        if (!ctx->d_geoM.p) {
+            // Chebyshev-node values -> monomial coefficients (as build_itabs' M), extended precision on the host
+            constexpr int NP = CPOL_GEO_NP;
+            long double T[NP][NP] = {};
+            T[0][0] = 1.0L;
+            if (NP > 1) T[1][1] = 1.0L;
+            for (int k = 2; k < NP; ++k)
+                for (int pw = 0; pw < NP; ++pw) T[k][pw] = (pw > 0 ? 2.0L * T[k - 1][pw - 1] : 0.0L) - T[k - 2][pw];
+            const long double pi = 3.141592653589793238462643383279502884L;
+            double M[NP * NP];
+            for (int pw = 0; pw < NP; ++pw)
+                for (int q = 0; q < NP; ++q) {
+                    long double acc = 0.0L;
+                    for (int k = 0; k < NP; ++k) acc += T[k][pw] * (k == 0 ? 1.0L : 2.0L) / NP * cosl(pi * k * (q + 0.5L) / NP);
+                    M[pw * NP + q] = (double)acc;
+                }
+            rc = upload(ctx, ctx->d_geoM, M, sizeof M);
+            if (rc != CPOL_OK) return rc;
+            HIPCHK(hipStreamSynchronize(ctx->stream));           // (M is a stack array)
+        }
+    }
     ENSURE(ctx->b_vals, (size_t)n_vars * n_sbg * sizeof(float));
     ENSURE(ctx->b_mask, (size_t)n_sbg);
     ENSURE(ctx->b_elev, (size_t)n_sbg * sizeof(float));
@@ -1616,7 +1665,14 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ta.geo = (const double *)ctx->v_geo;
         ta.ray_const = ray_prep ? (double *)ctx->b_rayc.p : nullptr;
         ta.n_h = n_h; ta.lon1 = p->radar_lon;
-        hipLaunchKernelGGL(k_trajectory, dim3((unsigned)(n_rays * n_v), paths ? cdiv(ng, 256) : 1), dim3(256), 0, st, ta);
+        if (geo_poly) {
+            ta.poly = (double *)ctx->b_poly.p;
+            ta.poly_M = (const double *)ctx->d_geoM.p;
+            // arc distance <= slant range; a margin of 1e-3 for the asin of the 4/3-earth formula
+            ta.poly_scale = 2.0 / ((p->range0 + (double)(ng - 1) * p->range_step) * 1.001);
+            ta.sin_u1 = p->sin_u1; ta.cos_u1 = p->cos_u1;
+        }
+        hipLaunchKernelGGL(k_trajectory, dim3((unsigned)(n_rays * n_v), paths ? cdiv(ng, 256) : 1), dim3(256), 0, st, ctx->model, ta);
     }
     if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_TRAJ], st));
 
@@ -1650,6 +1706,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.sin_u1 = p->sin_u1; ia.cos_u1 = p->cos_u1; ia.lon1 = p->radar_lon;
     ia.site = t->site ? (const double *)ctx->v_site : nullptr;
     ia.exact_sub = (p->debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS) ? 1 : 0;
+    ia.poly = geo_poly ? (const double *)ctx->b_poly.p : nullptr;
+    ia.poly_scale = geo_poly ? 2.0 / ((p->range0 + (double)(ng - 1) * p->range_step) * 1.001) : 0.0;
     if (!fused && !fused_gate1)
     hipLaunchKernelGGL(k_interp_sweep, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256), 0, st,
                        ctx->model, ia);

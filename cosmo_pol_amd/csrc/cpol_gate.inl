@@ -173,6 +173,16 @@ __device__ __forceinline__ void gate1_body(const ModelDev &m, const InterpArgs &
                 const int cur = __builtin_amdgcn_readlane(blk, lead);
                 unsigned long long grp = __ballot(it.lookup && blk == cur);
                 todo &= ~grp;
+#if CPOL_ITAB2_PAIR
+                itab2_walk_pairs(t.tab + (long)cur * (CPOL_ITAB2_NB * NFP) + fn, grp, u, w, q, [&](int l, double acc, bool live) {
+                    const long il = ((long)__shfl((int)(i >> 32), l) << 32) | (unsigned)__shfl((int)i, l);
+                    const long o = (long)j * n + il;
+                    if (!live || (lane & 16)) return;
+                    if (fn < CPOL_N_SZ + 2) s_walk[wave][l][fn] = acc;
+                    if (fn < CPOL_N_SZ) g.res[o * CPOL_N_SZ + fn] = acc;          // (for a recomputed gate)
+                    else if (fn < CPOL_N_SZ + 2 && a.vn) a.vn[o * 2 + (fn - CPOL_N_SZ)] = acc;   // (k_ice_first, a recomputed gate)
+                });
+#else
                 double rows[CPOL_ITAB2_QROWS];
                 itab2_quarter_rows(t.tab + (long)cur * (CPOL_ITAB2_NB * NFP) + fn, r, rows);
                 while (grp) {
@@ -188,6 +198,7 @@ __device__ __forceinline__ void gate1_body(const ModelDev &m, const InterpArgs &
                     if (lane < CPOL_N_SZ) g.res[o * CPOL_N_SZ + lane] = acc;      // (for a recomputed gate)
                     else if (lane < CPOL_N_SZ + 2 && a.vn) a.vn[o * 2 + (lane - CPOL_N_SZ)] = acc;        // (k_ice_first, a recomputed gate)
                 }
+#endif
             }
             __builtin_amdgcn_wave_barrier();
             if (it.lookup) {
@@ -366,7 +377,15 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_interp_g
 // `lam`, `n0`, `slice_index`: wave-uniform.  Lane 0 leaves the 12 columns (x dD) in out[] (LDS).
 // (not inlined: the rare path must not cost the common one its registers -- inlined, the kernel needs 131 VGPRs and
 // 3 wavefronts per SIMD instead of 105 / 4)
-__device__ __attribute__((noinline)) void integrate_gamma_item_wave(const double *table, const double *pre, const double *dnu, const double *aux,
+#ifndef CPOL_RARE_INLINE
+#define CPOL_RARE_INLINE 0
+#endif
+#if CPOL_RARE_INLINE
+#define CPOL_RARE_ATTR __forceinline__
+#else
+#define CPOL_RARE_ATTR __attribute__((noinline))
+#endif
+__device__ CPOL_RARE_ATTR void integrate_gamma_item_wave(const double *table, const double *pre, const double *dnu, const double *aux,
                                                                     int n_d, int uniform_grid, double dD, int slice_index,
                                                                     double lam, double n0, double *out /* LDS, [CPOL_N_SZ] */)
 {
@@ -717,6 +736,34 @@ __global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_
 // one workgroup per ray, the operands of the three strictly sequential float32 scans through LDS, lane 0 of three
 // wavefronts runs one scan each, then PHIDP, the attenuated ZDR and the sensitivity cut -- the second half of k_final
 // without the per-gate function's 243 registers (k_final<256> on the C2 sweep: 15-19 us for this work).
+// one strictly sequential float32 scan over sv[0 .. ng) in LDS by ONE lane (MUL: running product, else running sum), the
+// operands of the next 8 steps requested before the 8 dependent operations of the current ones
+template <bool MUL>
+__device__ __forceinline__ void scan_lds_sequential(float *sv, int ng)
+{
+    float c = 0.0f;
+    int gg = 0;
+    float nx[8];
+    if (ng >= 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nx[q] = sv[q];
+    }
+    for (; gg + 8 <= ng; gg += 8) {
+        float q8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) q8[q] = nx[q];
+        if (gg + 16 <= ng) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nx[q] = sv[gg + 8 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { c = (gg + q == 0) ? q8[0] : (MUL ? c * q8[q] : c + q8[q]); q8[q] = c; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sv[gg + q] = q8[q];
+    }
+    for (; gg < ng; ++gg) { c = (gg == 0) ? sv[gg] : (MUL ? c * sv[gg] : c + sv[gg]); sv[gg] = c; }
+}
+
 __global__ __launch_bounds__(256) void k_scan_rays(FinalArgs f, GateArgs g, ScanRayArgs r)
 {
     extern __shared__ float lds_scan[];                // [3][n_gates]
@@ -730,48 +777,39 @@ __global__ __launch_bounds__(256) void k_scan_rays(FinalArgs f, GateArgs g, Scan
         s_h[gg] = g.sh[base + gg];
         s_v[gg] = g.sv[base + gg];
     }
+    // what the last loop needs of the gates, requested before the scans so that it arrives behind them (two gates per
+    // thread at 500 gates; a ray of more than 512 gates reads the rest in the loop itself)
+    constexpr int PRE = 2;
+    float p_zh[PRE], p_zv[PRE], p_dhv[PRE], p_zdr[PRE];
+    double p_thr[PRE];
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+        const int gg = tid + q * 256;
+        const bool ok = gg < ng;
+        const long ii = base + (ok ? gg : 0);
+        p_zh[q] = f.ZH[ii]; p_zv[q] = f.ZV[ii]; p_dhv[q] = f.DELTA_HV[ii]; p_zdr[q] = f.ZDR[ii];
+        p_thr[q] = r.sens_thr ? r.sens_thr[ok ? gg : 0] : 0.0;
+    }
     __syncthreads();
     if (lane == 0 && (wave == 0 || (f.with_attenuation && wave < 3))) {
-        float *sv = (wave == 0) ? s_k : (wave == 1 ? s_h : s_v);
-        float c = 0.0f;
-        int gg = 0;
-        if (wave == 0) {
-            for (; gg + 8 <= ng; gg += 8) {
-                float q8[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) q8[q] = sv[gg + q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { c = (gg + q == 0) ? q8[0] : c + q8[q]; q8[q] = c; }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) sv[gg + q] = q8[q];
-            }
-            for (; gg < ng; ++gg) { c = (gg == 0) ? sv[gg] : c + sv[gg]; sv[gg] = c; }
-        } else {
-            for (; gg + 8 <= ng; gg += 8) {
-                float q8[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) q8[q] = sv[gg + q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { c = (gg + q == 0) ? q8[0] : c * q8[q]; q8[q] = c; }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) sv[gg + q] = q8[q];
-            }
-            for (; gg < ng; ++gg) { c = (gg == 0) ? sv[gg] : c * sv[gg]; sv[gg] = c; }
-        }
+        if (wave == 0) scan_lds_sequential<false>(s_k, ng);
+        else scan_lds_sequential<true>(wave == 1 ? s_h : s_v, ng);
     }
     __syncthreads();
     double *rvel = f.RVEL ? f.RVEL : r.RVEL;
-    for (int gg = tid; gg < ng; gg += 256) {
+    for (int gg = tid, q = 0; gg < ng; gg += 256, ++q) {
         const long ii = base + gg;
-        const float zh = f.ZH[ii], zv = f.ZV[ii];
-        float phidp = s_k[gg] * r.radial_res / 1000.0f + f.DELTA_HV[ii];
-        float zdr = f.ZDR[ii];
+        float zh, zv, dhv, zdr;
+        double thr;
+        if (q < PRE) { zh = p_zh[q < PRE ? q : 0]; zv = p_zv[q < PRE ? q : 0]; dhv = p_dhv[q < PRE ? q : 0]; zdr = p_zdr[q < PRE ? q : 0]; thr = p_thr[q < PRE ? q : 0]; }
+        else { zh = f.ZH[ii]; zv = f.ZV[ii]; dhv = f.DELTA_HV[ii]; zdr = f.ZDR[ii]; thr = r.sens_thr ? r.sens_thr[gg] : 0.0; }
+        float phidp = s_k[gg] * r.radial_res / 1000.0f + dhv;
         if (f.with_attenuation) zdr = (zh * s_h[gg]) / (zv * s_v[gg]);
         bool cut = false;
         if (r.sens_thr) {
             // 10*np.log10(ZH) (float32) < threshold(r) (float64)
             const float dbz = 10.0f * (float)log10((double)zh);
-            cut = (double)dbz < r.sens_thr[gg];
+            cut = (double)dbz < thr;
         }
         if (cut) {
             const float qnan = __builtin_nanf("");

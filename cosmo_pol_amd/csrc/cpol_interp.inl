@@ -47,6 +47,11 @@ struct TrajArgs {
     double *ray_const;          // [n_rays * n_h][2] sin / cos (2 sigma1), then [n_rays][2] sin / cos (site longitude)
     int n_h;
     double lon1;
+    // rotated coordinates along a ray as polynomials of the arc distance (see geo_poly_fit): NULL: not wanted
+    double *poly;               // [n_rays * n_h][2][CPOL_GEO_NP] monomial coefficients of rlat(x), rlon(x) [deg], x = s * poly_scale - 1
+    const double *poly_M;       // [CPOL_GEO_NP][CPOL_GEO_NP] Chebyshev-node values -> monomial coefficients
+    double poly_scale;          // 2 / s_max
+    double sin_u1, cos_u1;      // reduced latitude of the (one) radar site
 };
 
 // height of candidate gate k of a downward-looking (spaceborne) ray
@@ -119,6 +124,81 @@ __device__ __forceinline__ void clear_counters(int *zero_buf, int zero_n, int *z
     if (zero_buf2 && first < zero_n2) zero_buf2[first] = 0;      // (zero_n2 <= one workgroup)
 }
 
+// ---- rotated coordinates of the NON-CENTRAL sub-beams as polynomials of the arc distance (round 5) ----
+// The gates of one (ray, horizontal quadrature node) lie on ONE geodesic from the radar: their rotated coordinates are
+// two smooth functions of the arc distance s alone, evaluated ~3 500 times per volume ray (7 vertical nodes x 500
+// gates) with ~300 float64 instructions each (Vincenty passes, two inverse trigonometric functions, the rotation).  Over
+// the 150 km of a radar ray -- 0.024 rad of arc -- a degree-8 polynomial through 9 Chebyshev nodes reproduces them to
+// rounding (next coefficient ~ (0.024 / 4)^9 / 9! of the function), so k_trajectory evaluates the LONG form (the central
+// sub-beam's: 5 Vincenty passes, atan2 / asin, a true division) at the 9 nodes once per (ray, node) and the gate kernel
+// runs two Horner chains: 17 FMAs per sub-beam gate.  The central sub-beam, whose float64 latitude / longitude are
+// outputs, keeps the long form.  Measured against the long form on the C4 volume (tools/fast_sub_check.py,
+// profiles/r5_fast_sub_check.json): see DESIGN.md section 4.  Ground radars with the 4/3-earth ray paths only.
+#ifndef CPOL_GEO_NP
+#define CPOL_GEO_NP 9
+#endif
+__device__ __forceinline__ void exact_rotated_coords(const ModelDev &m, const double *gc, double sin_u1, double cos_u1, double lon1,
+                                                     double s2s1, double c2s1, double s, double &rlat_deg, double &rlon_deg)
+{
+    // (the statements of interp_gate's long form)
+    const double sin_a1 = gc[0], cos_a1 = gc[1], sin_alpha = gc[3];
+    const double bA = gc[4], B = gc[5], C = gc[6];
+    const double f = CPOL_WGS84_F;
+    const double sigma0 = s / bA;
+    double sigma = sigma0, cos2sm = 0.0, sin_s = 0.0, cos_s = 1.0;
+#pragma unroll 1
+    for (int it = 0; it <= CPOL_VINCENTY_ITERS; ++it) {
+        sincos(sigma, &sin_s, &cos_s);
+        cos2sm = c2s1 * cos_s - s2s1 * sin_s;
+        if (it == CPOL_VINCENTY_ITERS) break;
+        const double dsig = B * sin_s * (cos2sm + B / 4.0 * (cos_s * (-1.0 + 2.0 * cos2sm * cos2sm)
+                            - B / 6.0 * cos2sm * (-3.0 + 4.0 * sin_s * sin_s) * (-3.0 + 4.0 * cos2sm * cos2sm)));
+        sigma = sigma0 + dsig;
+    }
+    const double tmp = sin_u1 * sin_s - cos_u1 * cos_s * cos_a1;
+    const double lat_num = sin_u1 * cos_s + cos_u1 * sin_s * cos_a1;
+    const double lat_den = (1.0 - f) * sqrt(sin_alpha * sin_alpha + tmp * tmp);
+    const double lam_y = sin_s * sin_a1, lam_x = cos_u1 * cos_s - sin_u1 * sin_s * cos_a1;
+    const double dlon = (1.0 - C) * f * sin_alpha * (sigma + C * sin_s * (cos2sm + C * cos_s * (-1.0 + 2.0 * cos2sm * cos2sm)));
+    const double lat2 = atan2(lat_num, lat_den);
+    const double L = atan2(lam_y, lam_x) - dlon;
+    const double lat_deg = lat2 / CPOL_DEG, lon_deg = lon1 + L / CPOL_DEG;
+    double sl, cl, slon, clon;
+    sincos(lat_deg * CPOL_DEG, &sl, &cl);
+    sincos(lon_deg * CPOL_DEG, &slon, &clon);
+    const double x = clon * cl, y = slon * cl, z = sl;
+    const double x_new = m.ctcp * x + m.ctsp * y + m.st * z;
+    const double y_new = m.nsp * x + m.cp * y;
+    const double z_new = m.nstcp * x - m.stsp * y + m.ct * z;
+    rlon_deg = atan2(y_new, x_new) / CPOL_DEG;
+    rlat_deg = asin(z_new) / CPOL_DEG;
+}
+
+// one thread per (ray, horizontal node): node values -> monomial coefficients of rlat(x), rlon(x)
+__device__ __forceinline__ void geo_poly_fit(const ModelDev &m, const TrajArgs &a, long e)
+{
+    constexpr int NP = CPOL_GEO_NP;
+    const double *gc = a.geo + e * 8;
+    double s2s1, c2s1;
+    sincos(2.0 * gc[2], &s2s1, &c2s1);
+    double vlat[NP], vlon[NP];
+#pragma unroll 1
+    for (int q = 0; q < NP; ++q) {
+        const double xq = cos(3.14159265358979323846 * ((double)q + 0.5) / (double)NP);
+        exact_rotated_coords(m, gc, a.sin_u1, a.cos_u1, a.lon1, s2s1, c2s1, (xq + 1.0) / a.poly_scale, vlat[q], vlon[q]);
+    }
+    double *o = a.poly + e * (2 * NP);
+    for (int pw = 0; pw < NP; ++pw) {
+        double c0 = 0.0, c1 = 0.0;
+        for (int q = 0; q < NP; ++q) {
+            c0 = fma(a.poly_M[pw * NP + q], vlat[q], c0);
+            c1 = fma(a.poly_M[pw * NP + q], vlon[q], c1);
+        }
+        o[pw] = c0;
+        o[NP + pw] = c1;
+    }
+}
+
 // Ray paths ahead of the sweep kernel: with several horizontal quadrature nodes the sub-beams of one
 // vertical node share their path (7 x 7 nodes: 6 of 7 evaluations of the refraction formulas saved, ~300
 // float64 instructions per sub-beam gate); also the parity access to the paths (cpol_debug_read "traj").
@@ -126,10 +206,15 @@ __device__ __forceinline__ void clear_counters(int *zero_buf, int zero_n, int *z
 // also evaluate the per-ray constants of the geodesic (sin / cos of 2 sigma1 per (ray, horizontal node),
 // of the site longitude per ray) with the same OCML calls k_interp_sweep would make per gate.
 // grid = (n_rays * n_v, ceil(n_gates / 256))
-__global__ __launch_bounds__(256) void k_trajectory(TrajArgs a)
+__global__ __launch_bounds__(256) void k_trajectory(ModelDev m, TrajArgs a)
 {
     int g = blockIdx.y * blockDim.x + threadIdx.x;
     int rv = blockIdx.x;                       // ray * n_v + vnode
+    if (a.poly && blockIdx.y == 0) {
+        const long n_geo = (long)a.n_rays * a.n_h;
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_geo; e += (long)gridDim.x * blockDim.x)
+            geo_poly_fit(m, a, e);
+    }
     if (a.ray_const && blockIdx.y == 0) {
         const long n_geo = (long)a.n_rays * a.n_h;
         for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_geo + a.n_rays;
@@ -384,6 +469,8 @@ struct InterpArgs {
     double sin_u1, cos_u1, lon1;
     const double *site;         // per-ray site or NULL
     int exact_sub;              // debug (cpol_sweep_params.debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS): every sub-beam takes the central one's long form
+    const double *poly;         // k_trajectory's coordinate polynomials [n_rays * n_h][2][CPOL_GEO_NP] or NULL (geo_poly_fit)
+    double poly_scale;          // x = s * poly_scale - 1
 };
 
 #ifndef CPOL_RAY_PREP_MIN_SUB
@@ -502,6 +589,24 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
         }
         return 1;
     }
+    float rlon, rlat;
+    double lat_deg = 0.0, lon_deg = 0.0;
+    // (wave-uniform: a wavefront walks ONE sub-beam; exact_sub is a kernel argument)
+    const bool short_form = sub != a.central_sub && !a.exact_sub;
+    if (short_form && a.poly) {
+        // ---- non-central sub-beam: the rotated coordinates from the (ray, horizontal node)'s polynomials (geo_poly_fit) ----
+        constexpr int NP = CPOL_GEO_NP;
+        const double *pc = a.poly + (long)(ray * a.n_h + ih) * (2 * NP);          // (wave-uniform: scalar loads)
+        const double x = fma((double)s32, a.poly_scale, -1.0);
+        double la = pc[NP - 1], lo = pc[2 * NP - 1];
+#pragma unroll
+        for (int q = NP - 2; q >= 0; --q) {
+            la = fma(la, x, pc[q]);
+            lo = fma(lo, x, pc[NP + q]);
+        }
+        rlat = (float)la;
+        rlon = (float)lo;
+    } else {
     const double sin_u1 = a.site ? a.site[(long)ray * 8 + 0] : a.sin_u1;
     const double cos_u1 = a.site ? a.site[(long)ray * 8 + 1] : a.cos_u1;
     const double lon1 = a.site ? a.site[(long)ray * 8 + 2] : a.lon1;
@@ -527,8 +632,6 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     // relative -- of the fixed point, after 5 within rounding.  The central sub-beam, whose float64 coordinates
     // are outputs, takes 5; the others, of which only the float32 grid coordinates are used, 4.)
 #if CPOL_INTERP_FAST_SUB
-    // (wave-uniform: a wavefront walks ONE sub-beam; exact_sub is a kernel argument)
-    const bool short_form = sub != a.central_sub && !a.exact_sub;
     const int n_iter = short_form ? CPOL_VINCENTY_ITERS - 1 : CPOL_VINCENTY_ITERS;
 #else
     const int n_iter = CPOL_VINCENTY_ITERS;
@@ -558,7 +661,6 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     // L = lam - dlon: the ellipsoidal correction of the longitude difference (|dlon| < f sigma ~ 1e-4 rad)
     const double dlon = (1.0 - C) * f * sin_alpha *
         (sigma + C * sin_s * (cos2sm + C * cos_s * (-1.0 + 2.0 * cos2sm * cos2sm)));
-    double lat_deg = 0.0, lon_deg = 0.0;
     double sl, cl, slon, clon;                    // sin / cos of the geographic latitude and longitude
 #if CPOL_INTERP_FAST_SUB
     if (short_form) {
@@ -604,7 +706,6 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     const double x_new = m.ctcp * x + m.ctsp * y + m.st * z;
     const double y_new = m.nsp * x + m.cp * y;
     const double z_new = m.nstcp * x - m.stsp * y + m.ct * z;
-    float rlon, rlat;
 #if CPOL_INTERP_FAST_SUB
     if (short_form) {
         // (radians -> degrees as a product with 180 / pi: a float64 division by a constant is ~25 instructions;
@@ -627,6 +728,8 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     {
         rlon = (float)(atan2(y_new, x_new) / CPOL_DEG);
         rlat = (float)(asin(z_new) / CPOL_DEG);
+    }
+
     }
 
     // interpolation.py:572-575 (IndexError in the reference)

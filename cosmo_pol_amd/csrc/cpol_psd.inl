@@ -2014,6 +2014,72 @@ __device__ __forceinline__ double itab2_quarter_sum(const double (&rows)[CPOL_IT
     return acc * ((r & 1 ? wi : 1.0) * (r & 2 ? w2 : 1.0));
 }
 
+// TWO items of a 2-D block per pass (CPOL_ITAB2_PAIR, round 5): lane = (item slot, half h, function f); half h owns the
+// rows of the powers w^b with b = h (mod 2) -- 36 row values per lane in registers (h = 1: 30, padded with zeros) -- and
+// sums  w^h sum_k (w^2)^k sum_a rows u^a  for ITS slot's item; one cross-lane add joins the halves.  The per-item work
+// that is not arithmetic (operands brought to the lanes, the address, the store) is paid once per pair: ~40 wave
+// instructions per item instead of ~70 with four quarters on one item.
+#ifndef CPOL_ITAB2_PAIR
+#define CPOL_ITAB2_PAIR 1
+#endif
+#define CPOL_ITAB2_HROWS 36
+__device__ __forceinline__ void itab2_half_rows(const double *c, int h, double (&rows)[CPOL_ITAB2_HROWS])
+{
+    constexpr int NC = CPOL_ITAB_NC, NFP = CPOL_ITAB_NFP;
+    static_assert(NC == 11, "the half split is written for total degree 10");
+    int idx = 0;
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+        const int b = h + 2 * k;                                        // power of w of this half's row set
+        const int bb = min(b, NC - 1);
+        const double *cb = c + (long)CPOL_ITAB2_ROW(bb) * NFP;
+#pragma unroll
+        for (int pa = NC - 1 - 2 * k; pa >= 0; --pa) rows[idx++] = pa <= NC - 1 - b ? cb[pa * NFP] : 0.0;
+    }
+}
+
+__device__ __forceinline__ double itab2_half_sum(const double (&rows)[CPOL_ITAB2_HROWS], int h, double ui, double wi)
+{
+    constexpr int NC = CPOL_ITAB_NC;
+    const double w2 = wi * wi;
+    double acc = 0.0;
+    int idx = 0;
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+        double inner = 0.0;
+#pragma unroll
+        for (int pa = NC - 1 - 2 * k; pa >= 0; --pa) inner = fma(inner, ui, rows[idx++]);
+        acc = fma(acc, w2, inner);
+    }
+    return acc * (h ? wi : 1.0);
+}
+
+// The items of one block (`grp`: their lanes), two per pass; `emit(l, acc, live)` is called by EVERY lane with its slot's item l and
+// the lane's function value (the two halves already joined, times the item's scale); `live` = the slot holds an item: lanes with
+// h == 0 of a live slot store.
+template <typename Emit>
+__device__ __forceinline__ void itab2_walk_pairs(const double *blk_f, unsigned long long grp, double u, double w, double q, Emit emit)
+{
+    const int lane = lane_id();
+    const int h = (lane >> 4) & 1, slot = lane >> 5;
+    double rows[CPOL_ITAB2_HROWS];
+    itab2_half_rows(blk_f, h, rows);
+    while (grp) {
+        const int la = (int)__ffsll((long long)grp) - 1;
+        grp &= grp - 1;
+        const bool two = grp != 0;
+        const int lb = two ? (int)__ffsll((long long)grp) - 1 : la;
+        if (two) grp &= grp - 1;
+        const double ua = readlane_f64(u, la), ub = readlane_f64(u, lb);
+        const double wa = readlane_f64(w, la), wb = readlane_f64(w, lb);
+        const double qa = readlane_f64(q, la), qb = readlane_f64(q, lb);
+        double acc = itab2_half_sum(rows, h, slot ? ub : ua, slot ? wb : wa);
+        acc += shfl_xor_f64(acc, 16);
+        acc *= slot ? qb : qa;
+        emit(slot ? lb : la, acc, slot == 0 || two);                    // (every lane calls: the lambda may shuffle)
+    }
+}
+
 // the 12 integrated columns of an item from its 1-D block (c) at panel position u, times its scale
 __device__ __forceinline__ void itab1_columns(const double2 *c, double u, double scale, double2 (&v)[CPOL_N_SZ / 2])
 {
@@ -2140,6 +2206,16 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, CPOL_LOOKUP_WPE) void k_psd_lo
                 const bool mine = turn == (int)blockIdx.y;
                 turn = turn + 1 == a.split ? 0 : turn + 1;
                 if (!mine) continue;
+#if CPOL_ITAB2_PAIR
+                itab2_walk_pairs(t.tab + (long)cur * (CPOL_ITAB2_NB * NFP) + f, grp, u, w, q, [&](int l, double acc, bool live) {
+                    // (l: lane-varying between the two slots -- the item's sub-beam gate by bpermute, not readlane)
+                    const long il = ((long)__shfl((int)(i >> 32), l) << 32) | (unsigned)__shfl((int)i, l);
+                    const long o = (long)j * n + il;
+                    if (!live || (lane & 16)) return;                       // (half 1 holds the same sum)
+                    if (f < CPOL_N_SZ) a.res[o * CPOL_N_SZ + f] = acc;
+                    else if (f < CPOL_N_SZ + 2 && a.vn) a.vn[o * 2 + (f - CPOL_N_SZ)] = acc;
+                });
+#else
                 double rows[CPOL_ITAB2_QROWS];
                 itab2_quarter_rows(t.tab + (long)cur * (CPOL_ITAB2_NB * NFP) + f, r, rows);
                 while (grp) {
@@ -2154,6 +2230,7 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, CPOL_LOOKUP_WPE) void k_psd_lo
                     if (lane < CPOL_N_SZ) a.res[o * CPOL_N_SZ + lane] = acc;
                     else if (lane < CPOL_N_SZ + 2 && a.vn) a.vn[o * 2 + (lane - CPOL_N_SZ)] = acc;
                 }
+#endif
             }
             continue;
         }

@@ -207,8 +207,9 @@ def test_sweep_after_a_failed_sweep_equals_a_fresh_context(monkeypatch):
     ny, nx = data['QR_v'].shape[1:]
     yy, xx = np.meshgrid(np.arange(ny), np.arange(nx), indexing='ij')
     wedge = (xx > nx // 2) & (yy > ny // 2)                     # items outside the tables: the rare-item totals matter too
-    f = data['QR_v']
-    f[:, wedge] = np.where(f[:, wedge] > 0, np.float32(1e-16), 0).astype(np.float32)
+    for k, tiny in (('QR_v', 1e-16), ('QS_v', 3e-18)):
+        f = data[k]
+        f[:, wedge] = np.where(f[:, wedge] > 0, np.float32(tiny) * (1 + (np.arange(f.shape[0]) % 5))[:, None], 0).astype(np.float32)
     luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
     az = np.arange(20.0, 70.0, 2.5)
     el = np.full(len(az), 2.0)
