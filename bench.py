@@ -119,11 +119,11 @@ def hydrometeors_of(workload):
 
 
 def load_profile_summary(workload):
-    """profiles/r4_<workload>_summary.json (tools/profile_summary.py; r3_* / r2_* if this round's file is
+    """profiles/r5_<workload>_summary.json (tools/profile_summary.py; r4_* / r3_* / r2_* if this round's file is
     missing): per kernel the mean FETCH_SIZE / WRITE_SIZE / SQ counters per dispatch, `hbm_bytes`
     (FETCH_SIZE weighted per kernel as profiles/README.md states, + WRITE_SIZE) and the
     kernel-trace duration."""
-    for tag in ('r4', 'r3', 'r2'):
+    for tag in ('r5', 'r4', 'r3', 'r2'):
         path = os.path.join(ROOT, 'profiles', '%s_%s_summary.json' % (tag, workload))
         try:
             with open(path) as f:
@@ -135,10 +135,10 @@ def load_profile_summary(workload):
 
 # stage of the launch sequence (cpol_counters_t.ms_*) -> its kernels in the rocprofv3 summaries
 STAGE_KERNELS = {'interp': ('k_interp_sweep', 'k_interp_classify', 'k_interp_gate1', 'k_trajectory'),   # (k_interp_classify: the gate kernel that also classifies)
-                 'classify': ('k_classify', 'k_ml_weights', 'k_gate1'),          # (k_gate1_ray: the whole rest of a single-beam sweep)
+                 'classify': ('k_classify', 'k_ml_weights', 'k_gate1'),          # (k_gate1_species / k_gate1_ray / k_gate1: the single-beam gate kernel)
                  'bucket': ('k_bucket_scan', 'k_bucket_scatter'),
                  'psd': ('k_psd_lookup', 'k_subbeam_sum', 'k_psd_rare'),     # (k_psd_rare: the integrating flavours, one launch, idle in a sweep)
-                 'final': ('k_final', 'k_rvel_terms', 'k_ice_first')}
+                 'final': ('k_final', 'k_rvel_terms', 'k_ice_first', 'k_scan_rays', 'k_upload_tables')}
 TABLE_BUILD_KERNELS = ('k_itab_', 'k_stage_', 'k_spaceborne_first_gate')      # cpol_prepare / cpol_stage_model / the swath's
                                                                               # gate windows (once per swath geometry): not part of a sweep
 

@@ -145,14 +145,14 @@ struct cpol_ctx {
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
     int lookup_split = 0;              // CPOL_LOOKUP_SPLIT=<n>: wavefronts per tile of k_psd_lookup (0: by launch size)
-    int gate1_ray = 1;                 // CPOL_GATE1_RAY=0: never k_gate1_ray (items off the tables integrated in place, the range scans by k_scan_rays: a single-beam sweep
+    int gate1_ray = 0;                 // CPOL_GATE1_RAY=1: k_gate1_ray (items off the tables integrated in place, the range scans by k_scan_rays: a single-beam sweep
                                        // of three lean launches, no integrating launch); 2: also with tables that lost panels; 3: the scans inside the gate kernel (a ticket per ray)
     int gate1_species = 1;             // CPOL_GATE1_SPECIES=0 / 2: never / always k_gate1_species (one wavefront per species; default: small launches)
     int fuse_gate1 = 0;                // CPOL_FUSE_GATE1=1: k_interp_gate1 instead of k_interp_sweep + k_gate1 (measured slower where it matters)
     int fuse_classify = 1;             // CPOL_FUSE_CLASSIFY=0: k_interp_sweep + k_classify instead of k_interp_classify (read when the context is created)
     int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
     int subsum_scalar = 0;             // CPOL_SUBSUM_FORM=scalar: the cooperative form of k_subbeam_sum takes its rows through the scalar cache instead of LDS
-    int upload_kernel = 1;             // CPOL_TABLE_UPLOAD=memcpy: the per-ray tables by hipMemcpyAsync instead of k_upload_tables
+    int upload_kernel = 0;             // CPOL_TABLE_UPLOAD=kernel: the per-ray tables by k_upload_tables instead of hipMemcpyAsync (a measurement knob)
     int geo_poly = 1;                  // CPOL_GEO_POLY=0: the non-central sub-beams take the short closed form of the geodesy instead of the per-ray polynomials
     int psd_rare = 1;                  // CPOL_PSD_RARE=0: one launch per integrating flavour also when the units are directly listed items (read when the context is created)
     int subsum_small = 0;              // CPOL_SUBSUM_SMALL=1: experiment: the gather form of k_subbeam_sum with three wavefronts per (tile, hydrometeor) and the whole block in flight (measured slower)
@@ -170,6 +170,8 @@ struct cpol_ctx {
     // sticky domain-error word (device): OR-ed by the kernels of every sweep, cleared only
     // when it has been read AND reported (host-output sweeps, cpol_synchronize, cpol_counters)
     int *d_errword = nullptr;
+    int *h_errword = nullptr;          // its page-locked host copy (report_domain_error reads it on the context's own stream: no copy through
+                                       // pageable memory, nothing on the null stream)
     std::vector<void *> host_allocs;   // pinned host memory handed out by cpol_host_alloc
     // timing: one event set per sweep since cpol_enable_timing(ctx, 1); elapsed
     // times are collected (averaged) by cpol_counters after the stream drained,
@@ -590,6 +592,8 @@ int cpol_create(int device, cpol_ctx **out)
         return CPOL_ERR_HIP;
     }
     ctx->own_stream = true;
+    if (getenv("CPOL_ERRWORD") && !strcmp(getenv("CPOL_ERRWORD"), "pageable")) ctx->h_errword = nullptr;      // (measurement knob: round 4's read)
+    else if (hipHostMalloc((void **)&ctx->h_errword, 64, hipHostMallocDefault) != hipSuccess) { ctx->h_errword = nullptr; (void)hipGetLastError(); }
     if (hipMalloc((void **)&ctx->d_errword, sizeof(int)) != hipSuccess ||
         hipMemset(ctx->d_errword, 0, sizeof(int)) != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
@@ -612,7 +616,7 @@ int cpol_create(int device, cpol_ctx **out)
     if (getenv("CPOL_GATE1")) ctx->gate1 = atoi(getenv("CPOL_GATE1"));
     if (getenv("CPOL_SUBSUM_FORM")) ctx->subsum_scalar = !strcmp(getenv("CPOL_SUBSUM_FORM"), "scalar") ? 1 : 0;
     if (getenv("CPOL_SUBSUM_SMALL")) ctx->subsum_small = atoi(getenv("CPOL_SUBSUM_SMALL")) != 0 ? 1 : 0;
-    if (getenv("CPOL_TABLE_UPLOAD")) ctx->upload_kernel = strcmp(getenv("CPOL_TABLE_UPLOAD"), "memcpy") != 0 ? 1 : 0;
+    if (getenv("CPOL_TABLE_UPLOAD")) ctx->upload_kernel = strcmp(getenv("CPOL_TABLE_UPLOAD"), "kernel") == 0 ? 1 : 0;
     if (getenv("CPOL_GEO_POLY")) ctx->geo_poly = atoi(getenv("CPOL_GEO_POLY")) != 0 ? 1 : 0;
     if (getenv("CPOL_PSD_RARE")) ctx->psd_rare = atoi(getenv("CPOL_PSD_RARE")) != 0 ? 1 : 0;
     if (getenv("CPOL_SUBSUM_COOP_ROUNDS")) ctx->subsum_coop_rounds = std::max(0, std::min(64, atoi(getenv("CPOL_SUBSUM_COOP_ROUNDS"))));
@@ -683,6 +687,7 @@ void cpol_destroy(cpol_ctx *ctx)
     for (hipGraphExec_t g : ctx->graph_exec) if (g) (void)hipGraphExecDestroy(g);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->d_errword) (void)hipFree(ctx->d_errword);
+    if (ctx->h_errword) (void)hipHostFree(ctx->h_errword);
     for (void *h : ctx->host_allocs) (void)hipHostFree(h);
     delete ctx;
 }
@@ -706,6 +711,8 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
         return CPOL_ERR_HIP;
     }
     c->own_stream = true;
+    c->h_errword = nullptr;
+    if (parent->h_errword && hipHostMalloc((void **)&c->h_errword, 64, hipHostMallocDefault) != hipSuccess) { c->h_errword = nullptr; (void)hipGetLastError(); }
     if (hipMalloc((void **)&c->d_errword, sizeof(int)) != hipSuccess ||
         hipMemset(c->d_errword, 0, sizeof(int)) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
@@ -777,10 +784,21 @@ int cpol_get_stream(cpol_ctx *ctx, void **hip_stream)
 // behind later sweeps of the same context (the reference raises IndexError at that radial)
 static int report_domain_error(cpol_ctx *ctx)
 {
+    // (called behind a hipStreamSynchronize of ctx->stream.  The word travels into page-locked memory on that stream: a
+    // blocking hipMemcpy into a stack variable goes through the null stream and the runtime's staging of pageable
+    // memory -- after the first of those, the first asynchronous copy of every following sweep took ~340 us with ~200
+    // page faults for the next two synchronisation periods: round 4's "slow mode", profiles/r5_host_mode_probe.txt)
     int flag = 0;
-    HIPCHK(hipMemcpy(&flag, ctx->d_errword, sizeof flag, hipMemcpyDeviceToHost));
+    if (ctx->h_errword) {
+        HIPCHK(hipMemcpyAsync(ctx->h_errword, ctx->d_errword, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        flag = *(volatile int *)ctx->h_errword;
+    } else {
+        HIPCHK(hipMemcpy(&flag, ctx->d_errword, sizeof flag, hipMemcpyDeviceToHost));
+    }
     if (!flag) return CPOL_OK;
-    HIPCHK(hipMemset(ctx->d_errword, 0, sizeof(int)));
+    HIPCHK(hipMemsetAsync(ctx->d_errword, 0, sizeof(int), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->err = "RADAR DOMAIN IS NOT ENTIRELY CONTAINED IN COSMO SIMULATION DOMAIN";
     return CPOL_ERR_DOMAIN;
 }
@@ -1231,11 +1249,10 @@ int cpol_ray_tables(const cpol_sweep_params *p, const double *az_deg, const doub
     return CPOL_OK;
 }
 
-// The per-ray tables of a sweep, from the page-locked staging slot (host memory the device can address) into the table
-// set's device buffer, by a kernel instead of hipMemcpyAsync: measured (tools/host_mode_probe.py, profiles/
-// r5_host_mode_probe.txt) the runtime's small host-to-device copy call takes ~2 us most of the time and ~340 us, with ~200
-// page faults per call, in the two timed regions that follow the first synchronisation of a process -- the "slow mode"
-// of round 4's host_outputs figure.  A launch costs the host the same 3-5 us every time.
+// Measurement knob (CPOL_TABLE_UPLOAD=kernel): the per-ray tables of a sweep from the page-locked staging slot (host memory
+// the device can address) into the table set's device buffer by a kernel instead of hipMemcpyAsync.  It showed that the
+// ~340 us the first asynchronous copy of a sweep cost in round 4's "slow mode" belong to whichever copy call comes first
+// (host-to-device with the memcpy, the device-to-host copy of the results with this kernel): see report_domain_error.
 __global__ __launch_bounds__(256) void k_upload_tables(uint4 *__restrict__ dst, const uint4 *__restrict__ src, long n16)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x)

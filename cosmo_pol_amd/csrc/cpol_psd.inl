@@ -2018,9 +2018,11 @@ __device__ __forceinline__ double itab2_quarter_sum(const double (&rows)[CPOL_IT
 // rows of the powers w^b with b = h (mod 2) -- 36 row values per lane in registers (h = 1: 30, padded with zeros) -- and
 // sums  w^h sum_k (w^2)^k sum_a rows u^a  for ITS slot's item; one cross-lane add joins the halves.  The per-item work
 // that is not arithmetic (operands brought to the lanes, the address, the store) is paid once per pair: ~40 wave
-// instructions per item instead of ~70 with four quarters on one item.
+// instructions per item instead of ~70 with four quarters on one item.  NOT the default: the 36 row registers cost the
+// kernel a wavefront per SIMD (128 VGPRs: 4 instead of 5) and that costs more than the instructions save -- C3 sweep
+// 56.2 -> 54.1 us of PSD stage, the 225-ray C4 share 845 -> 866, the C4 volume 2 952 -> 3 107 (profiles/r5_variants.txt).
 #ifndef CPOL_ITAB2_PAIR
-#define CPOL_ITAB2_PAIR 1
+#define CPOL_ITAB2_PAIR 0
 #endif
 #define CPOL_ITAB2_HROWS 36
 __device__ __forceinline__ void itab2_half_rows(const double *c, int h, double (&rows)[CPOL_ITAB2_HROWS])

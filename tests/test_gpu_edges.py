@@ -114,7 +114,9 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
     listed directly as one-item work units (CPOL_GATE1=0) and the single-beam fused kernel, which defers the
     gates that hold such an item to k_final -- with one and with nine sub-beams, hundreds of items each.  Also the
     two-kernel form of the direct listing (CPOL_FUSE_CLASSIFY=0), the opt-in k_interp_gate1 (CPOL_FUSE_GATE1=1) and both forms of the
-    single-beam kernel: one wavefront per species (k_gate1_species, the default of small sweeps) / one thread per gate (k_gate1)."""
+    single-beam kernel: one wavefront per species (k_gate1_species, the default of small sweeps) / one thread per gate (k_gate1),
+    and the opt-in k_gate1_ray, which integrates such items in place (lanes 0..7 of the wavefront stand in for the eight
+    wavefronts of the integrating kernel) -- with the range scans by k_scan_rays or inside the gate kernel."""
     import bench
     from cosmo_pol_amd import RadarOperator, synthetic
     hyds = ('R', 'S', 'G')
@@ -138,8 +140,9 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
                           ('direct_two_kernels', {'CPOL_GATE1': '0', 'CPOL_FUSE_CLASSIFY': '0'}),     # k_interp_sweep + k_classify
                           ('interp_gate1', {'CPOL_FUSE_GATE1': '1'}),                                  # k_interp_gate1 (opt-in)
                           ('gate1_one_thread', {'CPOL_GATE1_SPECIES': '0'}),       # k_gate1 instead of k_gate1_species (what large swaths get)
-                          ('gate1_species_then_final', {'CPOL_GATE1_RAY': '0'})):  # k_gate1_species + integrating launch + k_final (round 4's default;
-                                                                                   # the default now: k_gate1_ray, off-table items integrated in place)
+                          ('gate1_ray', {'CPOL_GATE1_RAY': '1'}),          # k_gate1_ray (off-table items integrated in place) + k_scan_rays: no
+                                                                           # integrating launch, no k_final (opt-in: no faster, profiles/r5_variants.txt)
+                          ('gate1_ray_ticket', {'CPOL_GATE1_RAY': '3'})):  # ... with the ray's scans inside the gate kernel (a ticket per ray)
             for k in ('CPOL_RARE_DIRECT', 'CPOL_GATE1', 'CPOL_FUSE_CLASSIFY', 'CPOL_FUSE_GATE1', 'CPOL_GATE1_SPECIES', 'CPOL_GATE1_RAY', 'CPOL_PSD_RARE'):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
@@ -154,7 +157,7 @@ def test_items_outside_the_integral_tables_three_ways(monkeypatch):
             results[(n_gh, mode)] = (res, n_off)
             op.close()
         ref, n_ref = results[(n_gh, 'sorted')]
-        for mode in ('direct', 'default', 'direct_launch_per_flavour', 'direct_two_kernels', 'interp_gate1', 'gate1_one_thread', 'gate1_species_then_final'):
+        for mode in ('direct', 'default', 'direct_launch_per_flavour', 'direct_two_kernels', 'interp_gate1', 'gate1_one_thread', 'gate1_ray', 'gate1_ray_ticket'):
             got, n_got = results[(n_gh, mode)]
             assert n_got == n_ref
             for k in ('ZH', 'ZV', 'ZDR', 'KDP', 'RHOHV', 'PHIDP', 'DELTA_HV', 'ATT_H', 'ATT_V', 'RVEL', 'mask'):

@@ -28,6 +28,7 @@ SCALAR_LOAD_KERNELS = ('k_subbeam_sum<true', 'k_subbeam_sum_scalar')       # coe
 
 def main():
     stats, dF, dW, dS = sys.argv[1:5]
+    extra = sys.argv[5:]                                   # optional passes: memory-side request split, L2 hit rate
     out = {'_note': 'means per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE '
                     'counts 64 B per 128-B request of the vector caches; kernels that read through the scalar cache: '
                     'FETCH_SIZE + WRITE_SIZE, hbm_bytes_upper = the vector rule); avg_us from rocprofv3 --kernel-trace --stats'}
@@ -44,6 +45,19 @@ def main():
             for c in keep:
                 if c in cs:
                     e[c] = cs[c]
+    for d in extra:
+        for k, cs in pmc(d).items():
+            e = out.setdefault(k, {})
+            for c in ('TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_DRAM_sum', 'TCC_EA0_RDREQ_32B_sum', 'TCC_HIT_sum', 'TCC_MISS_sum', 'TCC_REQ_sum'):
+                if c in cs:
+                    e[c] = cs[c]
+    for k, e in out.items():
+        if isinstance(e, dict) and e.get('TCC_EA0_RDREQ_sum'):
+            # of the L2's memory-side read requests, those routed to the DRAM side (the rest: other agents' memory);
+            # Infinity-Cache hits are not told apart here -- the MALL sits behind this interface
+            e['rdreq_dram_share'] = e.get('TCC_EA0_RDREQ_DRAM_sum', 0.0) / e['TCC_EA0_RDREQ_sum']
+        if isinstance(e, dict) and e.get('TCC_REQ_sum'):
+            e['l2_hit_rate'] = e.get('TCC_HIT_sum', 0.0) / e['TCC_REQ_sum']
     for k, e in out.items():
         if isinstance(e, dict) and 'FETCH_SIZE' in e and 'WRITE_SIZE' in e:
             e['hbm_bytes'] = (2 * e['FETCH_SIZE'] + e['WRITE_SIZE']) * 1024
