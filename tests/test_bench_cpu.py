@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 
 def test_cpu_pool_child_reports_every_leg():
     """`bench.py --cpu-pool-child` (what cpu_baseline_pool starts with a hard time limit): a fresh
-    interpreter without torch, fork pools of P = os.cpu_count() (and fewer) workers over the
+    interpreter without torch, fork pools of P = min(os.cpu_count(), 64) (and fewer) workers over the
     oracle's per-radial path, every leg time-boxed; one JSON line with the documented keys."""
     env = dict(os.environ, OMP_NUM_THREADS='1')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--cpu-pool-child', '--small',
@@ -20,9 +20,9 @@ def test_cpu_pool_child_reports_every_leg():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{') and '"partial"' not in ln]
     assert lines, r.stdout[-500:]
     d = json.loads(lines[-1])
-    assert d['cores'] == os.cpu_count() and d['unit'] == 'gates/s'
+    assert d['cores'] == min(os.cpu_count(), 64) and d['host_cpus'] == os.cpu_count() and d['unit'] == 'gates/s'
     assert d['value'] and d['value'] > 0
-    assert str(os.cpu_count()) in d['by_workers']
+    assert str(min(os.cpu_count(), 64)) in d['by_workers']
     assert d['reference_style'] and d['reference_style']['value'] > 0
     assert 'torch' not in r.stderr.lower() or 'error' not in r.stderr.lower()
 

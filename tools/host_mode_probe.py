@@ -77,6 +77,7 @@ def main():
     ap.add_argument('--small', action='store_true')
     ap.add_argument('--out', default=None)
     ap.add_argument('--sweeps', type=int, default=20)
+    ap.add_argument('--quick', action='store_true', help='the first four regions only (e.g. under AMD_LOG_LEVEL=4)')
     args = ap.parse_args()
     import torch
     import bench
@@ -172,6 +173,11 @@ def main():
             out.append(r)
         rec['phases'][tag] = out
 
+    if args.quick:
+        print('[probe] region 0', file=sys.stderr, flush=True)
+        phase('cold', 4)
+        op.close()
+        return
     phase('cold', 12)
     phase('steady', 8)
     time.sleep(2.0)
