@@ -285,7 +285,9 @@ class ShardedVolumeRunner(object):
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         if gather_to is not None and not 0 <= int(gather_to) < self.world:
             raise ValueError('gather_to = %r: not a rank of this group (world size %d)' % (gather_to, self.world))
-        self.root = None if gather_to is None else int(gather_to)
+        self.root = None if gather_to is None else int(gather_to)          # rank INSIDE `group`
+        # (torch's rooted collectives name their root by its rank in the default group)
+        self._dst = (self.root if (group is None or self.root is None) else dist.get_global_rank(group, self.root))
         self.cuda = self.device.type == 'cuda'
         self.comm = torch.cuda.Stream(self.device) if self.cuda else None
         self.n_slots = max(1, int(slots))
@@ -374,7 +376,7 @@ class ShardedVolumeRunner(object):
             if self.rooted:
                 parts = ([slot['gathered'][r * nb:(r + 1) * nb] for r in range(self.world)]
                          if self.receives else None)
-                dist.gather(block, gather_list=parts, dst=self.root, group=self.group)
+                dist.gather(block, gather_list=parts, dst=self._dst, group=self.group)
                 gathered = slot['gathered']
             else:
                 dist.all_gather_into_tensor(slot['gathered'], block, group=self.group)

@@ -235,3 +235,58 @@ def test_runner_pending_scans_all_gather_and_rooted_gather(world, rays, gather_t
                 for k in FIELDS:
                     assert res[s][k].shape == (n, N_GATES) and res[s][k].dtype == ref[k].dtype
                     assert np.array_equal(res[s][k].view(np.uint8), ref[k].view(np.uint8)), (rank, s, k)
+
+
+def _worker_subgroup(rank, world, port, rays_per_sweep, q):
+    """A runner on a SUBGROUP (ranks 1 and 2 of three; root = rank 0 of the subgroup = global rank 1) beside one on the
+    default group: what bench.py's single-GPU reference of the c4 speedups does with `dist.new_group([0])`."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from cosmo_pol_amd import distributed as D
+    fields = list(zip(FIELDS, DTYPES))
+    sub = dist.new_group([1, 2])                     # (every rank makes the call)
+    sweeps = [(np.linspace(0, 359, n), np.full(n, 0.5 + 1.5 * s)) for s, n in enumerate(rays_per_sweep)]
+
+    def run_block(a, e, ptrs):
+        res = fake_simulate(a, e)
+        for k, dt in fields:
+            n = len(a) * N_GATES
+            buf = (ctypes.c_char * (n * np.dtype(dt).itemsize)).from_address(ptrs[k])
+            np.frombuffer(buf, dtype=dt)[:] = res[k].ravel()
+    out_sub = 'not a member'
+    if rank in (1, 2):
+        r = D.ShardedVolumeRunner('cpu', group=sub, gather_to=0, slots=2)
+        assert (r.world, r.rank) == (2, rank - 1) and r._dst == 1 and r.collective.startswith('gather(dst=0)')
+        res = r.submit(run_block, 0, sweeps, fields, N_GATES).wait()
+        out_sub = None if res is None else [{k: v.copy() for k, v in x.items()} for x in res]
+    full = D.ShardedVolumeRunner('cpu', gather_to=None, slots=2).submit(run_block, 0, sweeps, fields, N_GATES).wait()
+    q.put((rank, out_sub, [{k: v.copy() for k, v in x.items()} for x in full]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_runner_on_a_subgroup_names_its_root_by_global_rank():
+    """`dist.gather(dst=...)` takes the root's rank in the DEFAULT group: a runner on a subgroup whose root is not global
+    rank 0 must translate (ShardedVolumeRunner._dst).  Ranks 1 and 2 of three shard a scan between them, global rank 1
+    receives it; the default-group runner of all three ranks works beside it."""
+    world, rays = 3, (9, 4)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_subgroup, args=(r, world, port, rays, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: (a, b) for r, a, b in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == 'not a member' and got[2][0] is None and isinstance(got[1][0], list)
+    for s, n in enumerate(rays):
+        ref = fake_simulate(np.linspace(0, 359, n), np.full(n, 0.5 + 1.5 * s))
+        for k in FIELDS:
+            assert np.array_equal(got[1][0][s][k].view(np.uint8), ref[k].view(np.uint8)), (s, k)
+            for r in range(world):
+                assert np.array_equal(got[r][1][s][k].view(np.uint8), ref[k].view(np.uint8)), (r, s, k)
