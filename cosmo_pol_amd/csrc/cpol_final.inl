@@ -315,6 +315,13 @@ __device__ __forceinline__ double fma_sgpr(double a, double b, double c_uniform)
 // with an item in them, [2] scalar-cache rounds, [3] wavefront iterations skipped (species absent in the whole tile)
 __device__ unsigned long long g_subsum_stats[4];
 #endif
+#ifdef CPOL_SUBSUM_TRACE
+// (its own build flag: the counters above are atomics and stretch the launch sevenfold)
+// per wavefront (index blockIdx.y * gridDim.x + blockIdx.x, the first CPOL_SUBSUM_TRACE_N of them): start and end on the
+// 100-MHz clock, iterations with work, HW_ID | XCC_ID << 32 (tools/subsum_trace.py draws the launch's time line from it)
+#define CPOL_SUBSUM_TRACE_N 65536
+__device__ unsigned long long g_subsum_trace[4 * CPOL_SUBSUM_TRACE_N];
+#endif
 enum { SUBSUM_GATHER = 0, SUBSUM_SCALAR = 1, SUBSUM_LDS = 2 };
 // (Measured and dropped, round 5: the gather form with every lane walking ITS OWN present sub-beams -- the set bits of its
 // validity word -- instead of the wavefront walking the union of its lanes' sub-beams: the 225-ray share 849 -> 885 us of
@@ -352,6 +359,10 @@ __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabS
     float acc[2 * NP];
 #pragma unroll
     for (int c = 0; c < 2 * NP; ++c) acc[c] = __builtin_nanf("");
+#ifdef CPOL_SUBSUM_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+    unsigned trace_work = 0;
+#endif
     int pre_b = -1;                                     // SUBSUM_LDS: block whose pieces are already on their way into s_blk[cur]
     int cur = 0;
     // sub-beams in chunks of 64: the validity bits of a whole chunk are read FIRST (independent byte
@@ -407,6 +418,9 @@ __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabS
             unsigned long long todo = __builtin_amdgcn_ballot_w64(on_tab);
 #ifdef CPOL_SUBSUM_STATS
             if (lane == 0 && part == 0) { atomicAdd(&g_subsum_stats[0], 1ull); atomicAdd(&g_subsum_stats[1], (unsigned long long)__popcll(todo)); }
+#endif
+#ifdef CPOL_SUBSUM_TRACE
+            ++trace_work;
 #endif
             // ---- SUBSUM_LDS: the block's 88 16-byte pieces go straight from global memory into LDS (two
             // global_load_lds_dwordx4 of the wavefront: no vector registers in between), every coefficient pair is
@@ -586,6 +600,18 @@ __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabS
             }
         }
     }
+#ifdef CPOL_SUBSUM_TRACE
+    {
+        const unsigned long w = (unsigned long)blockIdx.y * gridDim.x + blockIdx.x;
+        if (lane == 0 && w < CPOL_SUBSUM_TRACE_N) {
+            g_subsum_trace[4 * w] = trace_t0;
+            g_subsum_trace[4 * w + 1] = wall_clock64();
+            g_subsum_trace[4 * w + 2] = trace_work;
+            g_subsum_trace[4 * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                        (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;
+        }
+    }
+#endif
     if (!in) return;
     float2 *o = reinterpret_cast<float2 *>(a.sz_integ + (rg * a.n_hydro + j) * CPOL_N_SZ) + f0;
 #pragma unroll
@@ -601,6 +627,277 @@ void k_subbeam_sum_scalar(HydroSet hs, ItabSet its, SubsumArgs a) { subbeam_sum_
 template <int SPLIT, int GUNROLL>
 __global__ __launch_bounds__(CPOL_SUBSUM_THREADS) CPOL_SUBSUM_ATTR
 void k_subbeam_sum_gather(HydroSet hs, ItabSet its, SubsumArgs a) { subbeam_sum_body<SUBSUM_GATHER, SPLIT, GUNROLL>(hs, its, a); }
+
+// ---- the TEAM form (round 5): W wavefronts of one workgroup share a (tile, species) ----
+// What bounds the forms above on a small launch is the LENGTH OF ONE WAVEFRONT'S CHAIN, not throughput
+// (tools/subsum_trace.py on the 225-ray share of one of 8 GPUs: all 11 250 wavefronts have started after 68 us, the launch
+// ends after 617 us with ONE wavefront that walked its 49 sub-beams at 12.6 us each; median with work 166 us).  The order of
+// the float32 accumulation is what makes a chain of it -- but only the accumulation: the terms themselves (block fetch,
+// Horner chains, scale, weight) do not depend on the running sum.  So the r-th present sub-beam goes to wavefront r mod W,
+// the W terms of a round pass through LDS as float64 (12 columns x 64 lanes x 8 B per wavefront), and after a barrier
+// wavefront k adds column pairs [k PPW, (k + 1) PPW) of the round's sub-beams IN ORDER to its float32 registers: same
+// terms, same order, same bits, and a chain of ceil(49 / W) rounds.
+template <int W>
+__global__ __launch_bounds__(CPOL_WAVE * W)
+void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
+{
+    constexpr int NC = CPOL_ITAB1_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
+    constexpr int NP = CPOL_N_SZ / 2;                                    // double2 column pairs of an item
+    constexpr int PPW = (NP + W - 1) / W;                                // pairs a wavefront accumulates
+    constexpr int PIECES = NC * NFP / 2;
+    constexpr int REST = PIECES - CPOL_WAVE;
+    __shared__ double2 s_y[W][NP][CPOL_WAVE];
+    __shared__ unsigned long long s_pm[W][CPOL_WAVE];
+    __shared__ double2 s_blk[W][2][PIECES > CPOL_WAVE ? PIECES : CPOL_WAVE];
+    const long n_rg = (long)a.n_rays * a.n_gates;
+    const int j = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tg = a.tile_log2, lane = threadIdx.x & (CPOL_WAVE - 1);
+    const int gate_tiles = (a.n_gates + (1 << tg) - 1) >> tg;
+    const int ray = (int)(blockIdx.x / gate_tiles) * (CPOL_WAVE >> tg) + (lane >> tg);
+    const int gate = (int)(blockIdx.x % gate_tiles) * (1 << tg) + (lane & ((1 << tg) - 1));
+    const bool in = ray < a.n_rays && gate < a.n_gates;
+    const long rg = in ? (long)ray * a.n_gates + gate : 0;
+    const long n_sbg = n_rg * a.n_sub;
+    const long sbg0 = in ? (long)ray * a.n_sub * a.n_gates + gate : 0;
+    const ItabDev &t = its.t[j];
+    const bool tab1 = t.tab && !t.two_d;                                 // uniform
+    const int key_base = hs.h[j].key_base;
+    const double2 *R = a.rec + (long)j * n_sbg;
+    const int *K = a.key + (long)j * n_sbg;
+    const bool want_vn = tab1 && a.vn && t.writes_vn;                    // uniform
+    double wtot = 0.0;
+    if (a.wgate && in)
+        for (int s = 0; s < a.n_sub; ++s) wtot += a.wgate[sbg0 + (long)s * a.n_gates];
+    float acc[2 * PPW];
+#pragma unroll
+    for (int c = 0; c < 2 * PPW; ++c) acc[c] = __builtin_nanf("");
+    double2 (*my_blk)[PIECES > CPOL_WAVE ? PIECES : CPOL_WAVE] = s_blk[wave];
+    auto request = [&](int blk, int bufi) {
+        const double2 *src = reinterpret_cast<const double2 *>(t.tab + (long)blk * NB);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + (PIECES >= CPOL_WAVE ? lane : min(lane, PIECES - 1))),
+                                         (void __attribute__((address_space(3))) *)my_blk[bufi], 16, 0, 0);
+        if (lane < REST)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + CPOL_WAVE + lane),
+                                             (void __attribute__((address_space(3))) *)(my_blk[bufi] + CPOL_WAVE), 16, 0, 0);
+    };
+    // the w-th lowest set bit of m (-1: fewer than w + 1 bits), and m without its W lowest bits
+    auto pick = [&](unsigned long long m, int w) {
+        for (int i = 0; i < w && m; ++i) m &= m - 1;
+        return m ? __ffsll((long long)m) - 1 : -1;
+    };
+    auto drop = [&](unsigned long long m) {
+        for (int i = 0; i < W && m; ++i) m &= m - 1;
+        return m;
+    };
+    int cur = 0;
+#ifdef CPOL_SUBSUM_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+    unsigned trace_work = 0;
+    unsigned long long trace_wait = 0;
+#endif
+    for (int s_lo = 0; s_lo < a.n_sub; s_lo += 64) {
+        const int n_here = min(64, a.n_sub - s_lo);
+        // bit q: species j present at sub-beam s_lo + q (this lane) -- wavefront k reads the validity bytes of sub-beams
+        // k, k + W, ... and the W parts meet in LDS (a tile without the species costs the workgroup what it costs one wavefront)
+        unsigned long long pm = 0;
+#pragma unroll 4
+        for (int q = wave; q < n_here; q += W) {
+            const unsigned vb = in ? a.vmask[sbg0 + (long)(s_lo + q) * a.n_gates] : 0u;
+            pm |= (unsigned long long)((vb >> j) & 1u) << q;
+        }
+        if (s_lo) __syncthreads();                                       // (the parts of the chunk before are no longer read)
+        s_pm[wave][lane] = pm;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < W; ++k) pm |= s_pm[k][lane];
+        unsigned long long wp = 0;                                       // ... at any lane of the tile (the same in all W wavefronts)
+        for (int q = 0; q < n_here; ++q)
+            if (__builtin_amdgcn_ballot_w64((pm >> q) & 1ull)) wp |= 1ull << q;
+        if (!wp) continue;
+        // key + record of this wavefront's sub-beams TWO rounds ahead, the first block ONE round ahead: what a round waits
+        // for (s_waitcnt vmcnt(0) below: every load in flight) was requested a round ago or more
+        auto load_kr = [&](int q, int &key_o, double2 &rc_o) {
+            key_o = 0;
+            rc_o = make_double2(-1.0, 0.0);
+            if (q >= 0) {
+                const long sbg = sbg0 + (long)(s_lo + q) * a.n_gates;
+                const bool pr = (pm >> q) & 1ull;
+                key_o = pr ? K[sbg] : 0;
+                rc_o = (pr && tab1) ? R[sbg] : make_double2(-1.0, 0.0);
+            }
+        };
+        int q1 = pick(wp, wave), q2 = pick(drop(wp), wave);
+        int key1, key2;
+        double2 rc1, rc2;
+        load_kr(q1, key1, rc1);
+        load_kr(q2, key2, rc2);
+        int pre_b = -1;
+        while (wp) {
+            const unsigned long long wp_after = drop(wp);
+            const unsigned long long round_bits = wp ^ wp_after;
+            const int q_cur = q1;
+            const int key = key1;
+            const double2 rc = rc1;
+            q1 = q2; key1 = key2; rc1 = rc2;                              // the round after this one
+            q2 = pick(drop(wp_after), wave);                             // ... and the one after that (loads: below)
+            if (q_cur >= 0) {                                            // uniform in the wavefront
+#ifdef CPOL_SUBSUM_TRACE
+                ++trace_work;
+#endif
+                const int s = s_lo + q_cur;
+                const long sbg = sbg0 + (long)s * a.n_gates;
+                const bool present = (pm >> q_cur) & 1ull;
+                const bool on_tab = rc.x >= 0.0;
+                const int pn = on_tab ? min((int)rc.x, t.n_pan - 1) : 0;
+                const double u = 2.0 * (rc.x - (double)pn) - 1.0;
+                const int blk_id = on_tab ? (key - key_base) * t.n_pan + pn : -1;
+                double2 v[NP];
+                double2 wv = make_double2(0.0, 0.0);
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(on_tab);
+                if (todo) {
+                    int b = __builtin_amdgcn_readlane(blk_id, __ffsll((long long)todo) - 1);
+                    if (b != pre_b) request(b, cur);
+                    pre_b = -1;
+                    for (int round = 0; todo && round < a.coop_rounds; ++round) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        const bool mine = blk_id == b;
+                        todo &= ~__builtin_amdgcn_ballot_w64(mine);
+                        const bool more = todo && round + 1 < a.coop_rounds;
+                        if (more) {
+                            b = __builtin_amdgcn_readlane(blk_id, __ffsll((long long)todo) - 1);
+                            request(b, cur ^ 1);
+                        }
+                        const double2 *sb = my_blk[cur];
+                        if (mine) {
+#pragma unroll
+                            for (int f = 0; f < NP; ++f) v[f] = sb[(NC - 1) * (NFP / 2) + f];
+#pragma unroll CPOL_SUBSUM_LDS_UNROLL
+                            for (int q = NC - 2; q >= 0; --q) {
+#pragma unroll
+                                for (int f = 0; f < NP; ++f) {
+                                    const double2 cq = sb[q * (NFP / 2) + f];
+                                    v[f].x = fma(v[f].x, u, cq.x);
+                                    v[f].y = fma(v[f].y, u, cq.y);
+                                }
+                            }
+                            if (want_vn) {
+                                wv = sb[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
+                                for (int q = NC - 2; q >= 0; --q) {
+                                    const double2 cq = sb[q * (NFP / 2) + CPOL_N_SZ / 2];
+                                    wv.x = fma(wv.x, u, cq.x);
+                                    wv.y = fma(wv.y, u, cq.y);
+                                }
+                            }
+                        }
+                        if (more) cur ^= 1;
+                    }
+                }
+                if (q1 >= 0) {
+                    // the first block of this wavefront's sub-beam of the next round: on its way during the barrier and the sums
+                    const bool on_n = rc1.x >= 0.0;
+                    const unsigned long long mn = __builtin_amdgcn_ballot_w64(on_n);
+                    if (mn) {
+                        const int pn_n = on_n ? min((int)rc1.x, t.n_pan - 1) : 0;
+                        const int blk_n = on_n ? (key1 - key_base) * t.n_pan + pn_n : -1;
+                        pre_b = __builtin_amdgcn_readlane(blk_n, __ffsll((long long)mn) - 1);
+                        cur ^= 1;
+                        request(pre_b, cur);
+                    }
+                }
+                load_kr(q2, key2, rc2);
+                // the lanes still without a value after `coop_rounds` blocks: one row at a time (see subbeam_sum_body)
+                if (on_tab && ((todo >> lane) & 1ull)) {
+                    const double2 *blk = reinterpret_cast<const double2 *>(t.tab + (long)blk_id * NB);
+#pragma unroll
+                    for (int f = 0; f < NP; ++f) v[f] = blk[(NC - 1) * (NFP / 2) + f];
+#pragma unroll 1
+                    for (int q = NC - 2; q >= 0; --q) {
+#pragma unroll
+                        for (int f = 0; f < NP; ++f) {
+                            const double2 cq = blk[q * (NFP / 2) + f];
+                            v[f].x = fma(v[f].x, u, cq.x);
+                            v[f].y = fma(v[f].y, u, cq.y);
+                        }
+                    }
+                    if (want_vn) {
+                        wv = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
+#pragma unroll 1
+                        for (int q = NC - 2; q >= 0; --q) {
+                            const double2 cq = blk[q * (NFP / 2) + CPOL_N_SZ / 2];
+                            wv.x = fma(wv.x, u, cq.x);
+                            wv.y = fma(wv.y, u, cq.y);
+                        }
+                    }
+                }
+                if (present) {
+                    if (on_tab) {
+#pragma unroll
+                        for (int f = 0; f < NP; ++f) { v[f].x *= rc.y; v[f].y *= rc.y; }
+                        if (want_vn)
+                            *reinterpret_cast<double2 *>(a.vn + ((long)j * n_sbg + sbg) * 2) = make_double2(wv.x * rc.y, wv.y * rc.y);
+                    } else {
+                        const double2 *r = reinterpret_cast<const double2 *>(a.res + ((long)j * n_sbg + sbg) * CPOL_N_SZ);
+#pragma unroll
+                        for (int c = 0; c < NP; ++c) v[c] = r[c];
+                    }
+                    const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
+#pragma unroll
+                    for (int f = 0; f < NP; ++f) {
+                        double yx = v[f].x * w, yy = v[f].y * w;
+                        if (!(yx == yx)) yx = 0.0;
+                        if (!(yy == yy)) yy = 0.0;
+                        s_y[wave][f][lane] = make_double2(yx, yy);
+                    }
+                }
+            }
+#ifdef CPOL_SUBSUM_TRACE
+            const unsigned long long tw0 = wall_clock64();
+#endif
+            __syncthreads();
+#ifdef CPOL_SUBSUM_TRACE
+            trace_wait += wall_clock64() - tw0;
+#endif
+            // nansum([float32 acc, float64 term]) stored back as float32, sub-beam after sub-beam
+            if (wave * PPW < NP) {
+                unsigned long long rb = round_bits;
+                for (int i = 0; rb; ++i, rb &= rb - 1) {
+                    const int q = __ffsll((long long)rb) - 1;
+                    if (!((pm >> q) & 1ull)) continue;
+#pragma unroll
+                    for (int f = 0; f < PPW; ++f) {
+                        if (wave * PPW + f >= NP) break;
+                        const double2 y = s_y[i][wave * PPW + f][lane];
+                        const float xa = (acc[2 * f] == acc[2 * f]) ? acc[2 * f] : 0.f;
+                        const float xb = (acc[2 * f + 1] == acc[2 * f + 1]) ? acc[2 * f + 1] : 0.f;
+                        acc[2 * f] = (float)((double)xa + y.x);
+                        acc[2 * f + 1] = (float)((double)xb + y.y);
+                    }
+                }
+            }
+            __syncthreads();
+            wp = wp_after;
+        }
+    }
+#ifdef CPOL_SUBSUM_TRACE
+    {
+        const unsigned long w = ((unsigned long)blockIdx.y * gridDim.x + blockIdx.x) * W + wave;
+        if (lane == 0 && w < CPOL_SUBSUM_TRACE_N) {
+            g_subsum_trace[4 * w] = trace_t0;
+            g_subsum_trace[4 * w + 1] = wall_clock64();
+            g_subsum_trace[4 * w + 2] = trace_work | trace_wait << 32;
+            g_subsum_trace[4 * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                        (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;
+        }
+    }
+#endif
+    if (!in || wave * PPW >= NP) return;
+    float2 *o = reinterpret_cast<float2 *>(a.sz_integ + (rg * a.n_hydro + j) * CPOL_N_SZ) + wave * PPW;
+#pragma unroll
+    for (int f = 0; f < PPW; ++f)
+        if (wave * PPW + f < NP) o[f] = make_float2(acc[2 * f], acc[2 * f + 1]);
+}
 
 
 #ifndef CPOL_SKIP_RVEL
