@@ -143,7 +143,11 @@ struct cpol_ctx {
                                        // its first launch): both counter sets are cleared before the next sequence uses one
     int last_par = 0;                  // the set the last sweep used
     int subsum_coop_rounds = 6;        // CPOL_SUBSUM_COOP_ROUNDS: scalar-cache rounds per wavefront and sub-beam before the gather tail
+    int rare_overlap = 0;              // CPOL_RARE_OVERLAP=1: k_psd_rare beside k_psd_lookup on a sibling stream instead of behind it (measured: the share of
+                                       // one of 8 GPUs 1.42 -> 1.37 ms alone, 0.97 -> 0.99 with three lanes; the C3 sweep 151 -> 167 us: the fork and join cost
+                                       // more than the idle launch -- off)
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
+    int lookup_list = 1;               // CPOL_LOOKUP_LIST=0: k_psd_lookup starts one wavefront per tile instead of workgroups that list the tiles with work among their own; 2: the list for every launch size
     int lookup_split = 0;              // CPOL_LOOKUP_SPLIT=<n>: wavefronts per tile of k_psd_lookup (0: by launch size)
     int gate1_ray = 0;                 // CPOL_GATE1_RAY=1: k_gate1_ray (items off the tables integrated in place, the range scans by k_scan_rays: a single-beam sweep
                                        // of three lean launches, no integrating launch); 2: also with tables that lost panels; 3: the scans inside the gate kernel (a ticket per ray)
@@ -609,11 +613,13 @@ int cpol_create(int device, cpol_ctx **out)
     // CPOL_SUBSUM_COOP=0 / 1: k_subbeam_sum never / always takes the coefficient rows through the scalar cache
     // (default: by launch size; the results are identical)
     if (getenv("CPOL_SUBSUM_COOP")) ctx->subsum_coop = atoi(getenv("CPOL_SUBSUM_COOP")) != 0 ? 1 : 0;
+    if (getenv("CPOL_LOOKUP_LIST")) ctx->lookup_list = std::max(0, std::min(2, atoi(getenv("CPOL_LOOKUP_LIST"))));
     if (getenv("CPOL_LOOKUP_SPLIT")) ctx->lookup_split = std::max(0, std::min(16, atoi(getenv("CPOL_LOOKUP_SPLIT"))));
     if (getenv("CPOL_GATE1_SPECIES")) ctx->gate1_species = std::max(0, std::min(2, atoi(getenv("CPOL_GATE1_SPECIES"))));
     if (getenv("CPOL_GATE1_RAY")) ctx->gate1_ray = std::max(0, std::min(3, atoi(getenv("CPOL_GATE1_RAY"))));   // (2: also with tables that lost panels; 3: the scans inside the gate kernel)
     if (getenv("CPOL_FUSE_GATE1")) ctx->fuse_gate1 = atoi(getenv("CPOL_FUSE_GATE1")) != 0 ? 1 : 0;
     if (getenv("CPOL_FUSE_CLASSIFY")) ctx->fuse_classify = atoi(getenv("CPOL_FUSE_CLASSIFY")) != 0 ? 1 : 0;
+    if (getenv("CPOL_RARE_OVERLAP")) ctx->rare_overlap = atoi(getenv("CPOL_RARE_OVERLAP")) != 0 ? 1 : 0;
     if (getenv("CPOL_RARE_DIRECT")) ctx->rare_direct = atoi(getenv("CPOL_RARE_DIRECT")) != 0 ? 1 : 0;
     if (getenv("CPOL_GATE1")) ctx->gate1 = atoi(getenv("CPOL_GATE1"));
     if (getenv("CPOL_SUBSUM_FORM")) ctx->subsum_scalar = !strcmp(getenv("CPOL_SUBSUM_FORM"), "scalar") ? 1 : 0;
@@ -732,11 +738,13 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->upload_kernel = parent->upload_kernel;
     c->subsum_scalar = parent->subsum_scalar;
     c->rare_direct = parent->rare_direct;
+    c->rare_overlap = parent->rare_overlap;
     c->fuse_classify = parent->fuse_classify;
     c->fuse_gate1 = parent->fuse_gate1;
     c->gate1_species = parent->gate1_species;
     c->gate1_ray = parent->gate1_ray;
     c->lookup_split = parent->lookup_split;
+    c->lookup_list = parent->lookup_list;
     c->gate1 = parent->gate1;
     c->subsum_coop_rounds = parent->subsum_coop_rounds;
     c->parent = parent;
@@ -1830,6 +1838,26 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         ca.rare_perm = (int *)ctx->b_perm.p;
         ca.rare_totals = (unsigned long long *)tot_p;
     }
+    // k_psd_lookup's workgroups first list the tiles among their own that hold a species with a 2-D table (LookupArgs::tile_scan):
+    // when the lookup walks tiles and has nothing but the 2-D tables to evaluate, from 262 144 tiles on (C4 volume, 735 000 tiles:
+    // 1.30 -> 1.20 ms; its share of 1/8, 92 000 tiles: 247 -> 239-257 us, nothing gained.  Measured and dropped on the way: the
+    // list in global memory, made by k_interp_classify with one bit per tile and an atomicOr per item -- lookup 1.30 -> 1.09 ms
+    // and 239 -> 205 us, but the classification 3.24 -> 4.31 ms: device-scope atomics; made by a kernel of its own with one
+    // atomicAdd per wavefront and pass -- the same lookup times, and 244 / 51 us for that kernel: one address, ~11 ns per atomic)
+    static const int tile_env = getenv("CPOL_LOOKUP_TILE") ? atoi(getenv("CPOL_LOOKUP_TILE")) : 1;
+    constexpr int TILE_GATES = 1 << CPOL_TILE_GATES_LOG2, TILE_RAYS = 64 >> CPOL_TILE_GATES_LOG2;
+    bool use_tile_list = false;
+    const long n_tiles = (long)cdiv(n_rays, TILE_RAYS) * n_sub * cdiv(ng, TILE_GATES);
+    if (ctx->lookup_list && rare_direct && !gate1 && tile_env && n_rays >= TILE_RAYS && (subsum || final_inplace) && (n_tiles >= 262144 || ctx->lookup_list == 2) && n_tiles < (1L << 31)) {
+        bool any_2d = false, other = false;
+        for (int j = 0; j < n_hyd; ++j) {
+            const ItabDev &tj = ctx->its.t[j];
+            if (!tj.tab) continue;
+            if (tj.two_d) any_2d = true;
+            else if ((dop3 && ctx->hs.h[j].d.psd_family == CPOL_PSD_ICE_FIELD) || (final_inplace && doppler && tj.writes_vn)) other = true;
+        }
+        use_tile_list = any_2d && !other;
+    }
     for (int j = 0; j < n_hyd; ++j) {
         const cpol_hydro_desc &d = ctx->hs.h[j].d;
         if (d.q_source != CPOL_Q_MODEL) continue;
@@ -1962,6 +1990,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (tm_psd) HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st));
 
     // ---- 5a. items on an integral table: 15 x 11 coefficients gathered, no diameter-bin loop ----
+    bool rare_forked = false;           // k_psd_rare goes to a sibling stream that forked in front of k_psd_lookup
     {
         bool any = false;
         for (int j = 0; j < n_hyd; ++j) any = any || ctx->its.t[j].tab != nullptr;
@@ -1986,8 +2015,6 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             }
             bool two_d = false;
             for (int j = 0; j < n_hyd; ++j) two_d = two_d || (ctx->its.t[j].tab && ctx->its.t[j].two_d);
-            static const int tile_env = getenv("CPOL_LOOKUP_TILE") ? atoi(getenv("CPOL_LOOKUP_TILE")) : 1;
-            constexpr int TILE_GATES = 1 << CPOL_TILE_GATES_LOG2, TILE_RAYS = 64 >> CPOL_TILE_GATES_LOG2;
             la.tile = (two_d && tile_env && n_rays >= TILE_RAYS) ? 1 : 0;
             la.n_rays = n_rays; la.n_sub = n_sub; la.n_gates = ng;
             const long n_thr = la.tile ? (long)cdiv(n_rays, TILE_RAYS) * n_sub * cdiv(ng, TILE_GATES) * 64 : n_sbg;
@@ -1995,8 +2022,29 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             // its distinct blocks and species are dealt to `split` wavefronts (CPOL_LOOKUP_SPLIT=<n>; default by launch size)
             const long lookup_waves_per_simd = n_thr / 64 / 1024;
             la.split = ctx->lookup_split > 0 ? ctx->lookup_split : (la.tile && lookup_waves_per_simd < 16) ? 4 : 1;
-            if (launch && !gate1)
-            hipLaunchKernelGGL(k_psd_lookup, dim3(cdiv(n_thr, CPOL_LOOKUP_THREADS), la.split), dim3(CPOL_LOOKUP_THREADS), 0, st, ctx->hs, ctx->its, la);
+            long grid_x = cdiv(n_thr, CPOL_LOOKUP_THREADS);
+            if (use_tile_list && la.tile) {
+                // a fixed grid walks the list: enough wavefronts to fill the chip three times over (5 per SIMD resident), never more than tiles
+                // workgroups that own many tiles each: the chip filled `fill` times over (5 wavefronts per SIMD resident), a workgroup's
+                // list never longer than its LDS array
+                la.tile_scan = 1;
+                la.n_tiles = n_tiles;
+                for (int j = 0; j < n_hyd; ++j) if (ctx->its.t[j].tab && ctx->its.t[j].two_d) la.species2d |= 1u << j;
+                static const long fill = getenv("CPOL_LOOKUP_FILL") ? atol(getenv("CPOL_LOOKUP_FILL")) : 12;      // (C4 volume, 1 / 3 / 6 / 12 / 24 / 48: 1.28 / 1.25 / 1.24 / 1.20 / 1.23 / 1.26 ms)
+                const long cap_wg = std::max<long>(fill * 1024 * 5 * CPOL_WAVE / CPOL_LOOKUP_THREADS, cdiv(n_tiles, CPOL_LOOKUP_LIST_CAP));
+                if (grid_x > cap_wg) grid_x = cap_wg;
+            }
+            if (launch && !gate1) {
+                // the items outside the tables (k_psd_rare, below) and the 2-D table items (here) are disjoint and both wait for
+                // the classification alone: k_psd_rare goes to a sibling stream that forks HERE and joins before the sub-beam
+                // sums -- its one busy workgroup (69-80 us for a single item of the C4 volume) runs beside the lookup
+                if (ctx->rare_overlap && rare_direct && ctx->psd_rare && !ctx->use_graph && !ctx->keep_debug) {
+                    if (!ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+                    rare_forked = true;
+                }
+                hipLaunchKernelGGL(k_psd_lookup, dim3((unsigned)grid_x, la.split), dim3(CPOL_LOOKUP_THREADS), 0, st, ctx->hs, ctx->its, la);
+            }
         }
     }
 
@@ -2058,8 +2106,20 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                 if (dd.psd_family == CPOL_PSD_MELTING && dd.tab_degree != CPOL_MELT_DEGREE) modes |= 16;
             }
             pa.ice_same_launch = 1;
-            if (dop2) hipLaunchKernelGGL((k_psd_rare<true>), grd, blk, 0, st, ctx->hs, pa, modes);
-            else hipLaunchKernelGGL((k_psd_rare<false>), grd, blk, 0, st, ctx->hs, pa, modes);
+            hipStream_t sr = st;
+            if (rare_forked) {
+                if (!ctx->aux[0]) HIPCHK(hipStreamCreateWithFlags(&ctx->aux[0], hipStreamNonBlocking));
+                if (!ctx->ev_join[0]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_join[0], hipEventDisableTiming));
+                sr = ctx->aux[0];
+                HIPCHK(hipStreamWaitEvent(sr, ctx->ev_fork, 0));
+            }
+            if (dop2) hipLaunchKernelGGL((k_psd_rare<true>), grd, blk, 0, sr, ctx->hs, pa, modes);
+            else hipLaunchKernelGGL((k_psd_rare<false>), grd, blk, 0, sr, ctx->hs, pa, modes);
+            if (rare_forked) {
+                HIPCHK(hipEventRecord(ctx->ev_join[0], sr));
+                HIPCHK(hipStreamWaitEvent(st, ctx->ev_join[0], 0));
+                rare_forked = false;
+            }
             for (int m = 0; m < 4; ++m) need[m] = false;
         }
         int n_need = 0;
@@ -2172,9 +2232,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // the team form (round 5: W wavefronts per (tile, species) share the sub-beams, the float32 sums stay ordered): what bounds a small
         // launch is the length of its longest wavefront's chain (cpol_final.inl).  Share of one of 8 / 4 / 2 GPUs alone (11 / 21 / 43
         // wavefronts per SIMD), ms per volume share: 1.47 / 2.18 / 3.57 with the rule above, 1.23 / 2.00 / 3.53 with W = 2 (W = 4: 1.23 /
-        // 2.05 / 3.66); with three lanes in flight 0.97 / 1.71 either way; the whole volume 1.71 (LDS form) against 1.94 ms.
+        // 2.05 / 3.66); with three lanes in flight 0.97 / 1.71 either way (a context WITH lanes that runs one share at
+        // a time: 1.42 with the LDS form its rule picked, 1.23 with the team); the whole volume 1.71 (LDS form) against 1.94 ms.
         const int team = ctx->subsum_team >= 0 ? ctx->subsum_team       // (a form forced through CPOL_SUBSUM_COOP stays what was asked for)
-                       : (ctx->subsum_coop < 0 && waves_per_simd < (lanes_alive >= 2 ? 8 : 40) ? 2 : 0);
+                       : (ctx->subsum_coop < 0 && waves_per_simd < 40 ? 2 : 0);      // (whatever the lanes: a context with lanes may still run one sweep at a time)
 #define CPOL_TEAM_CASE(W) case W: hipLaunchKernelGGL((k_subbeam_sum_team<W>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_WAVE * W), 0, st, ctx->hs, ctx->its, sa2); break;
         if (team >= 2 && team <= 7)
             switch (team) { CPOL_TEAM_CASE(2) CPOL_TEAM_CASE(3) CPOL_TEAM_CASE(4) CPOL_TEAM_CASE(5) CPOL_TEAM_CASE(6) CPOL_TEAM_CASE(7) }
@@ -2494,9 +2555,17 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
         return 32;
     }
 #endif
-#ifdef CPOL_SUBSUM_TRACE
+#ifdef CPOL_RARE_TRACE
+    if (!strcmp(name, "rare_trace")) {
+        if (!dst || max_bytes < 64 * 8 * 8) return CPOL_ERR_ARG;
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rare_trace), 64 * 8 * 8));
+        return 64 * 8 * 8;
+    }
+#endif
+#if defined(CPOL_SUBSUM_TRACE) || defined(CPOL_LOOKUP_TRACE)
     if (!strcmp(name, "subsum_trace")) {
-        const int64_t nb = (int64_t)sizeof(unsigned long long) * 4 * CPOL_SUBSUM_TRACE_N;
+        const int64_t nb = (int64_t)sizeof(unsigned long long) * CPOL_SUBSUM_TRACE_W * CPOL_SUBSUM_TRACE_N;
         if (!dst || max_bytes < nb) return CPOL_ERR_ARG;
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_subsum_trace), (size_t)nb));

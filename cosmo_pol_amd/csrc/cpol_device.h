@@ -147,3 +147,13 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
     hi = __shfl(hi, src);
     return __hiloint2double(hi, lo);
 }
+
+#if defined(CPOL_SUBSUM_TRACE) || defined(CPOL_LOOKUP_TRACE)
+// measurement builds (tools/subsum_trace.py): per wavefront of k_subbeam_sum* (index blockIdx.y * gridDim.x + blockIdx.x, times W
+// + wave for the team form) or of k_psd_lookup (CPOL_LOOKUP_TRACE: global wavefront index), the first CPOL_SUBSUM_TRACE_N of them:
+// start and end on the 100-MHz clock, iterations with work, HW_ID | XCC_ID << 32, then (team form) seven phase times in 10-ns
+// units, two per word
+#define CPOL_SUBSUM_TRACE_N 131072
+#define CPOL_SUBSUM_TRACE_W 8
+__device__ unsigned long long g_subsum_trace[CPOL_SUBSUM_TRACE_W * CPOL_SUBSUM_TRACE_N];
+#endif

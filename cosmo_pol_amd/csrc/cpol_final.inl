@@ -316,11 +316,7 @@ __device__ __forceinline__ double fma_sgpr(double a, double b, double c_uniform)
 __device__ unsigned long long g_subsum_stats[4];
 #endif
 #ifdef CPOL_SUBSUM_TRACE
-// (its own build flag: the counters above are atomics and stretch the launch sevenfold)
-// per wavefront (index blockIdx.y * gridDim.x + blockIdx.x, the first CPOL_SUBSUM_TRACE_N of them): start and end on the
-// 100-MHz clock, iterations with work, HW_ID | XCC_ID << 32 (tools/subsum_trace.py draws the launch's time line from it)
-#define CPOL_SUBSUM_TRACE_N 65536
-__device__ unsigned long long g_subsum_trace[4 * CPOL_SUBSUM_TRACE_N];
+// (its own build flag: the counters above are atomics and stretch the launch sevenfold; the buffer: cpol_device.h)
 #endif
 enum { SUBSUM_GATHER = 0, SUBSUM_SCALAR = 1, SUBSUM_LDS = 2 };
 // (Measured and dropped, round 5: the gather form with every lane walking ITS OWN present sub-beams -- the set bits of its
@@ -383,6 +379,8 @@ __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabS
         if (lane == 0 && part == 0) atomicAdd(&g_subsum_stats[3], (unsigned long long)(n_here - __popcll(wp)));
 #endif
         if (!wp) continue;
+        // the chunk's quadrature weights: lane q keeps sub_w[s_lo + q], an iteration reads its own by readlane (no load there)
+        const double wq = (!a.wgate && lane < n_here) ? a.sub_w[s_lo + lane] : 0.0;
         // key + record of the NEXT present sub-beam are requested before the rows of the current one
         int q_next = __ffsll((long long)wp) - 1;
         int key_n = 0;
@@ -399,6 +397,7 @@ __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabS
             const int s = s_lo + q_cur;
             const long sbg = sbg0 + (long)s * a.n_gates;
             const bool present = (pm >> q_cur) & 1ull;
+            const double w_sub = readlane_f64(wq, q_cur);                // (read here, where every lane is active)
             const int key = key_n;
             const double2 rc = rc_n;
             if (wp) {
@@ -588,7 +587,7 @@ __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabS
 #pragma unroll
                 for (int c = 0; c < NP; ++c) v[c] = r[c];
             }
-            const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
+            const double w = a.wgate ? a.wgate[sbg] / wtot : w_sub;
 #pragma unroll
             for (int c = 0; c < 2 * NP; ++c) {
                 // nansum([float32 acc, float64 term]) stored back as float32
@@ -604,10 +603,10 @@ __device__ __forceinline__ void subbeam_sum_body(const HydroSet &hs, const ItabS
     {
         const unsigned long w = (unsigned long)blockIdx.y * gridDim.x + blockIdx.x;
         if (lane == 0 && w < CPOL_SUBSUM_TRACE_N) {
-            g_subsum_trace[4 * w] = trace_t0;
-            g_subsum_trace[4 * w + 1] = wall_clock64();
-            g_subsum_trace[4 * w + 2] = trace_work;
-            g_subsum_trace[4 * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w] = trace_t0;
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 1] = wall_clock64();
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 2] = trace_work;
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                         (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;
         }
     }
@@ -637,6 +636,10 @@ void k_subbeam_sum_gather(HydroSet hs, ItabSet its, SubsumArgs a) { subbeam_sum_
 // the W terms of a round pass through LDS as float64 (12 columns x 64 lanes x 8 B per wavefront), and after a barrier
 // wavefront k adds column pairs [k PPW, (k + 1) PPW) of the round's sub-beams IN ORDER to its float32 registers: same
 // terms, same order, same bits, and a chain of ceil(49 / W) rounds.
+#ifndef CPOL_TEAM_NBUF
+#define CPOL_TEAM_NBUF 2          // block buffers per wavefront (1.4 KB each): the blocks of the next round requested ahead (3: 380 -> 402 us, fewer workgroups per CU)
+#endif
+static_assert(CPOL_TEAM_NBUF >= 2 && CPOL_TEAM_NBUF <= 3, "k_subbeam_sum_team keeps the ids of at most three blocks requested ahead");
 template <int W>
 __global__ __launch_bounds__(CPOL_WAVE * W)
 void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
@@ -648,7 +651,8 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
     constexpr int REST = PIECES - CPOL_WAVE;
     __shared__ double2 s_y[W][NP][CPOL_WAVE];
     __shared__ unsigned long long s_pm[W][CPOL_WAVE];
-    __shared__ double2 s_blk[W][2][PIECES > CPOL_WAVE ? PIECES : CPOL_WAVE];
+    constexpr int NBUF = CPOL_TEAM_NBUF;
+    __shared__ double2 s_blk[W][NBUF][PIECES > CPOL_WAVE ? PIECES : CPOL_WAVE];
     const long n_rg = (long)a.n_rays * a.n_gates;
     const int j = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -690,11 +694,16 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
         for (int i = 0; i < W && m; ++i) m &= m - 1;
         return m;
     };
-    int cur = 0;
+    int pb0 = -1, pb1 = -1, pb2 = -1, npre = 0;          // blocks of the coming round already on their way into buffers 0 .. npre - 1 (uniform)
 #ifdef CPOL_SUBSUM_TRACE
     const unsigned long long trace_t0 = wall_clock64();
     unsigned trace_work = 0;
     unsigned long long trace_wait = 0;
+    unsigned trace_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long trace_last = trace_t0;
+#define TP(i) { const unsigned long long now_ = wall_clock64(); trace_ph[i] += (unsigned)(now_ - trace_last); trace_last = now_; }
+#else
+#define TP(i)
 #endif
     for (int s_lo = 0; s_lo < a.n_sub; s_lo += 64) {
         const int n_here = min(64, a.n_sub - s_lo);
@@ -732,7 +741,9 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
         double2 rc1, rc2;
         load_kr(q1, key1, rc1);
         load_kr(q2, key2, rc2);
-        int pre_b = -1;
+        // the chunk's quadrature weights: lane q keeps sub_w[s_lo + q], a round reads its own by readlane (no load in the round)
+        const double wq = (!a.wgate && lane < n_here) ? a.sub_w[s_lo + lane] : 0.0;
+        npre = 0;
         while (wp) {
             const unsigned long long wp_after = drop(wp);
             const unsigned long long round_bits = wp ^ wp_after;
@@ -741,6 +752,7 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
             const double2 rc = rc1;
             q1 = q2; key1 = key2; rc1 = rc2;                              // the round after this one
             q2 = pick(drop(wp_after), wave);                             // ... and the one after that (loads: below)
+            TP(0)
             if (q_cur >= 0) {                                            // uniform in the wavefront
 #ifdef CPOL_SUBSUM_TRACE
                 ++trace_work;
@@ -748,6 +760,7 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
                 const int s = s_lo + q_cur;
                 const long sbg = sbg0 + (long)s * a.n_gates;
                 const bool present = (pm >> q_cur) & 1ull;
+                const double w_sub = readlane_f64(wq, q_cur);            // (read here, where every lane is active)
                 const bool on_tab = rc.x >= 0.0;
                 const int pn = on_tab ? min((int)rc.x, t.n_pan - 1) : 0;
                 const double u = 2.0 * (rc.x - (double)pn) - 1.0;
@@ -755,21 +768,30 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
                 double2 v[NP];
                 double2 wv = make_double2(0.0, 0.0);
                 unsigned long long todo = __builtin_amdgcn_ballot_w64(on_tab);
+                const bool todo0 = todo != 0;
                 if (todo) {
+                    // the tile's distinct blocks in the order of their first lanes: block k sits in buffer k mod NBUF -- the first
+                    // `npre` were requested during the round before (below), the others are requested one step ahead
                     int b = __builtin_amdgcn_readlane(blk_id, __ffsll((long long)todo) - 1);
-                    if (b != pre_b) request(b, cur);
-                    pre_b = -1;
-                    for (int round = 0; todo && round < a.coop_rounds; ++round) {
+                    if (!(npre > 0 && pb0 == b)) { npre = 0; request(b, 0); }
+                    for (int k = 0; ; ++k) {
+                        TP(2)
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __builtin_amdgcn_wave_barrier();
+                        TP(1)
+                        // key + record two rounds ahead: requested after the round's first wait, so that they travel during the
+                        // chains and nothing waits for them (the next wait of this kind is a round away)
+                        if (k == 0) load_kr(q2, key2, rc2);
                         const bool mine = blk_id == b;
                         todo &= ~__builtin_amdgcn_ballot_w64(mine);
-                        const bool more = todo && round + 1 < a.coop_rounds;
+                        const bool more = todo && k + 1 < a.coop_rounds;
+                        int b_next = 0;
                         if (more) {
-                            b = __builtin_amdgcn_readlane(blk_id, __ffsll((long long)todo) - 1);
-                            request(b, cur ^ 1);
+                            b_next = __builtin_amdgcn_readlane(blk_id, __ffsll((long long)todo) - 1);
+                            const int pbn = k == 0 ? pb1 : pb2;
+                            if (!(k + 1 < npre && k + 1 < NBUF && pbn == b_next)) request(b_next, (k + 1) % NBUF);
                         }
-                        const double2 *sb = my_blk[cur];
+                        const double2 *sb = my_blk[k % NBUF];
                         if (mine) {
 #pragma unroll
                             for (int f = 0; f < NP; ++f) v[f] = sb[(NC - 1) * (NFP / 2) + f];
@@ -791,22 +813,30 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
                                 }
                             }
                         }
-                        if (more) cur ^= 1;
+                        if (!more) break;
+                        b = b_next;
                     }
                 }
+                TP(2)
+                npre = 0;
                 if (q1 >= 0) {
-                    // the first block of this wavefront's sub-beam of the next round: on its way during the barrier and the sums
+                    // the first NBUF distinct blocks of this wavefront's sub-beam of the next round: on their way during the
+                    // barrier and the sums (every buffer is free: this round's chains are done)
                     const bool on_n = rc1.x >= 0.0;
-                    const unsigned long long mn = __builtin_amdgcn_ballot_w64(on_n);
-                    if (mn) {
-                        const int pn_n = on_n ? min((int)rc1.x, t.n_pan - 1) : 0;
-                        const int blk_n = on_n ? (key1 - key_base) * t.n_pan + pn_n : -1;
-                        pre_b = __builtin_amdgcn_readlane(blk_n, __ffsll((long long)mn) - 1);
-                        cur ^= 1;
-                        request(pre_b, cur);
+                    unsigned long long mn = __builtin_amdgcn_ballot_w64(on_n);
+                    const int pn_n = on_n ? min((int)rc1.x, t.n_pan - 1) : 0;
+                    const int blk_n = on_n ? (key1 - key_base) * t.n_pan + pn_n : -1;
+#pragma unroll
+                    for (int k = 0; k < NBUF; ++k) {
+                        if (!mn) break;
+                        const int bn = __builtin_amdgcn_readlane(blk_n, __ffsll((long long)mn) - 1);
+                        mn &= ~__builtin_amdgcn_ballot_w64(blk_n == bn);
+                        if (k == 0) pb0 = bn; else if (k == 1) pb1 = bn; else pb2 = bn;
+                        request(bn, k);
+                        npre = k + 1;
                     }
                 }
-                load_kr(q2, key2, rc2);
+                if (!todo0) load_kr(q2, key2, rc2);                        // (a round without an item on the table)
                 // the lanes still without a value after `coop_rounds` blocks: one row at a time (see subbeam_sum_body)
                 if (on_tab && ((todo >> lane) & 1ull)) {
                     const double2 *blk = reinterpret_cast<const double2 *>(t.tab + (long)blk_id * NB);
@@ -842,7 +872,7 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
 #pragma unroll
                         for (int c = 0; c < NP; ++c) v[c] = r[c];
                     }
-                    const double w = a.wgate ? a.wgate[sbg] / wtot : a.sub_w[s];
+                    const double w = a.wgate ? a.wgate[sbg] / wtot : w_sub;
 #pragma unroll
                     for (int f = 0; f < NP; ++f) {
                         double yx = v[f].x * w, yy = v[f].y * w;
@@ -852,6 +882,7 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
                     }
                 }
             }
+            TP(3)
 #ifdef CPOL_SUBSUM_TRACE
             const unsigned long long tw0 = wall_clock64();
 #endif
@@ -859,6 +890,7 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
 #ifdef CPOL_SUBSUM_TRACE
             trace_wait += wall_clock64() - tw0;
 #endif
+            TP(4)
             // nansum([float32 acc, float64 term]) stored back as float32, sub-beam after sub-beam
             if (wave * PPW < NP) {
                 unsigned long long rb = round_bits;
@@ -876,7 +908,9 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
                     }
                 }
             }
+            TP(5)
             __syncthreads();
+            TP(6)
             wp = wp_after;
         }
     }
@@ -884,14 +918,16 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
     {
         const unsigned long w = ((unsigned long)blockIdx.y * gridDim.x + blockIdx.x) * W + wave;
         if (lane == 0 && w < CPOL_SUBSUM_TRACE_N) {
-            g_subsum_trace[4 * w] = trace_t0;
-            g_subsum_trace[4 * w + 1] = wall_clock64();
-            g_subsum_trace[4 * w + 2] = trace_work | trace_wait << 32;
-            g_subsum_trace[4 * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+            for (int i = 0; i < 4; ++i) g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 4 + i] = trace_ph[2 * i] | (unsigned long long)trace_ph[2 * i + 1] << 32;
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w] = trace_t0;
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 1] = wall_clock64();
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 2] = trace_work | trace_wait << 32;
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                         (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;
         }
     }
 #endif
+#undef TP
     if (!in || wave * PPW >= NP) return;
     float2 *o = reinterpret_cast<float2 *>(a.sz_integ + (rg * a.n_hydro + j) * CPOL_N_SZ) + wave * PPW;
 #pragma unroll

@@ -890,6 +890,13 @@ __device__ __forceinline__ bool ice_unit_in_table(const HydroDev &h, const PsdAr
 // LDS of the integrating kernels: one raw buffer per kernel, sized for the largest flavour, handed to the bodies (so
 // that k_psd_rare can run every flavour from ONE launch)
 #define CPOL_PSD_LDS_DOUBLES (8 * (CPOL_N_SZ + 3) * CPOL_WAVE)            /* 61 440 B: the generic flavours, 8 wave slots */
+__device__ __forceinline__ double readlane_f64(double v, int src_uniform)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_uniform);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_uniform);
+    return __hiloint2double(hi, lo);
+}
+
 template <int MODE, bool DOP2>
 __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a, double *lds_raw)
 {
@@ -969,6 +976,26 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a, d
         const double N0 = active ? P[n] : 0.0;
         const cdouble_p pre = as_const(h.pre);
         const cdouble_p dnu = as_const(h.dnu);
+        if (count == 1) {
+            // ONE item in the unit (the rule for items listed directly, k_psd_rare): with the item on lane 0 the loop below
+            // is a chain of 128 exponentials, one after the other.  The N(D_k) of the chunk do not depend on each other: 64 bins at a time, one per LANE,
+            // then the sums in the order of the loop below -- the same values, the same order, the same bits.
+            const double lam_u = readlane_f64(lam, 0), N0_u = readlane_f64(N0, 0);
+            for (int kb = k0; kb < k1; kb += CPOL_WAVE) {
+                const int kk = min(kb + lane, k1 - 1);
+                const double nk_l = (N0_u * h.pre[kk]) * exp(-(lam_u * h.dnu[kk]));
+                const int nq = min(CPOL_WAVE, k1 - kb);
+#pragma unroll 4
+                for (int q = 0; q < nq; ++q) {
+                    const double nk = readlane_f64(nk_l, q);
+                    const int k = kb + q;
+                    const cdouble_p row = slice + (long)k * CPOL_N_SZ;
+#pragma unroll
+                    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
+                    if (DOP2) { vsum = fma(rv[2 * k], nk, vsum); nsum = fma(rv[2 * k + 1], nk, nsum); }
+                }
+            }
+        } else {
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
             const double nk = (N0 * pre[k]) * exp(-(lam * dnu[k]));
@@ -976,6 +1003,7 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a, d
 #pragma unroll
             for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
             if (DOP2) { vsum = fma(rv[2 * k], nk, vsum); nsum = fma(rv[2 * k + 1], nk, nsum); }
+        }
         }
         if (!DOP2 && d.numeric_intv && a.vn) {
             // 2-moment ice: IceParticle.integrate_V on its own linspace grid
@@ -1147,6 +1175,36 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a, d
         // measured and rejected: prefetching the next unit's slice into L2 with dummy vector
         // loads (160 us); staggering half of the waves by a few hundred cycles (no change).
         const cdouble_p pq = as_const(h.aux + 1 + n_d);          // [k][4] = (pre, q1, q2, .)
+        if (count == 1) {
+            // ONE item in the unit (the rule for items listed directly, k_psd_rare): the loop below then waits for one
+            // scalar-cache round trip per bin (tools/rare_trace.py: ~60 of the 68 us k_psd_rare took for the single snow item
+            // outside its table in a C4 volume share; 38 this way).
+            // 64 bins at a time: lane q fetches the table row and the polynomial factor of bin kb + q (one round trip for
+            // all of them), then the sums in the order of the loop below, operands by readlane -- the same values, the same
+            // order, the same bits.
+            const double lam_u = readlane_f64(lam0, 0), r_u = readlane_f64(r0, 0);
+            double A_u = readlane_f64(A0, 0);
+            for (int kb = k0; kb < k1; kb += CPOL_WAVE) {
+                const int kk = min(kb + lane, k1 - 1);
+                const double *pqv = h.aux + 1 + n_d + 4 * (long)kk;
+                const double poly_l = fma(lam_u, fma(lam_u, pqv[2], -pqv[1]), pqv[0]);
+                const double *rowv = h.table + ((long)(key - h.key_base) * n_d + kk) * CPOL_N_SZ;
+                double row_l[CPOL_N_SZ];
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) row_l[c] = rowv[c];
+                double wv_l = 0.0, wr_l = 0.0;
+                if (DOP2) { wv_l = h.rcsw[((long)(key - h.key_base) * n_d + kk) * 2]; wr_l = h.rcsw[((long)(key - h.key_base) * n_d + kk) * 2 + 1]; }
+                const int nq = min(CPOL_WAVE, k1 - kb);
+#pragma unroll 2
+                for (int q = 0; q < nq; ++q) {
+                    const double n0 = A_u * readlane_f64(poly_l, q);
+                    A_u *= r_u;
+#pragma unroll
+                    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(readlane_f64(row_l[c], q), n0, acc[c]);
+                    if (DOP2) { dv0 = fma(readlane_f64(wv_l, q), n0, dv0); dn0 = fma(readlane_f64(wr_l, q), n0, dn0); }
+                }
+            }
+        } else
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
             const double pk = pq[4 * k], q1 = pq[4 * k + 1], q2 = pq[4 * k + 2];
@@ -1666,25 +1724,40 @@ __global__ __launch_bounds__(CPOL_PSD_THREADS, 4) void k_psd_ice2(HydroSet hs, P
 // five launches that found nothing to do (5-6 us apiece on the stream: 20 of the 157 us of a C3 sweep); the bodies are the
 // kernels' own, run one after the other by every workgroup (each skips the units of the other flavours), so the results
 // are the same bits.  `modes`: bit m = flavour m (PSD_MODE_*) is staged; bit 4: a melting slot without polynomial tables.
+#ifdef CPOL_RARE_TRACE
+__device__ unsigned long long g_rare_trace[64 * 8];      // measurement build: the 100-MHz clock between the flavours, per workgroup
+#endif
 template <bool DOP2>
 __global__ __launch_bounds__(CPOL_PSD_THREADS) void k_psd_rare(HydroSet hs, PsdArgs a, int modes)
 {
     static_assert(CPOL_PSD_THREADS_U == CPOL_PSD_THREADS, "k_psd_rare runs the recurrence flavour with the workgroup of the others");
     if (a.totals[1] == 0) return;                         // nothing outside the tables (the rule)
     __shared__ double lds_raw[CPOL_PSD_LDS_DOUBLES];
+#ifdef CPOL_RARE_TRACE
+#define RT(i) if (threadIdx.x == 0 && blockIdx.x < 64) g_rare_trace[blockIdx.x * 8 + (i)] = wall_clock64();
+#else
+#define RT(i)
+#endif
+    RT(0)
     if (modes & (1 << PSD_MODE_MELTING)) {
         psd_melting_tab_body<DOP2>(hs, a, lds_raw);
         __syncthreads();
         if (modes & 16) { psd_body<PSD_MODE_MELTING, DOP2>(hs, a, lds_raw); __syncthreads(); }
     }
+    RT(1)
     if (modes & (1 << PSD_MODE_ICE)) {
         psd_ice2_body<DOP2>(hs, a, lds_raw);
         __syncthreads();
+        RT(2)
         psd_body<PSD_MODE_ICE, DOP2>(hs, a, lds_raw);      // (a.ice_same_launch: tests every unit itself)
         __syncthreads();
     }
+    RT(3)
     if (modes & (1 << PSD_MODE_GAMMA_UNIFORM)) { psd_body<PSD_MODE_GAMMA_UNIFORM, DOP2>(hs, a, lds_raw); __syncthreads(); }
+    RT(4)
     if (modes & (1 << PSD_MODE_GAMMA_EXP)) psd_body<PSD_MODE_GAMMA_EXP, DOP2>(hs, a, lds_raw);
+    RT(5)
+#undef RT
 }
 
 // ---------------------------------------------------------------- integral tables (itab)
@@ -1964,14 +2037,15 @@ struct LookupArgs {
                                 // evaluates the columns in place but reads vn[]; k_subbeam_sum writes them itself)
     int skip_res_1d;            // the 12 columns of the 1-D species are evaluated by k_subbeam_sum / k_final instead
                                 // (nothing of them is stored); only vn / the ice intercept are written here
+    // round 5 (tile_scan): 85 % of the tiles of a C4 volume hold nothing for this kernel, and a wavefront needs 2.3-2.5 us to
+    // find that out.  A workgroup then owns the tiles blockIdx.x, blockIdx.x + gridDim.x, ...: its wavefronts first look at
+    // the validity bytes of all of them (16 lanes per tile, one ray each, the 4 gates as one word; four tiles per wavefront
+    // and pass, loads of different passes independent), list those with a species of `species2d` in LDS, and then take the
+    // listed tiles in turn.  0: one wavefront per tile, as before.
+    int tile_scan;
+    unsigned species2d;         // bit j: species j has a 2-D table
+    long n_tiles;
 };
-
-__device__ __forceinline__ double readlane_f64(double v, int src_uniform)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_uniform);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_uniform);
-    return __hiloint2double(hi, lo);
-}
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int m)
 {
@@ -2141,6 +2215,9 @@ __device__ __forceinline__ void itab1_columns(const double2 *c, double u, double
 // item's operands brought to its 16 lanes by ds_bpermute, no cross-lane sums: PSD stage of the C4 volume 3.05 -> 3.21 ms,
 // of the 225-ray share 850 -> 877 us, of the C3 sweep 62.5 -> 59.8 us: ~10 items share a block, staging it costs what the
 // 66 LDS reads per pass save.)
+#ifndef CPOL_LOOKUP_LIST_CAP
+#define CPOL_LOOKUP_LIST_CAP 2048     // tiles a workgroup of k_psd_lookup owns at most when it scans for those with work (8 KB of LDS)
+#endif
 #ifndef CPOL_LOOKUP_WPE
 #define CPOL_LOOKUP_WPE 5             // wavefronts per SIMD asked of the register allocator (102 VGPRs: 5 fit since round 4; C4 volume 4 / 5 / 6 / 8: 1.36 / 1.22 / 1.51 / 2.24 ms, share 245 / 227 / 278 us, C3 sweep 66.6 / 67.1 us)
 #endif
@@ -2149,9 +2226,75 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, CPOL_LOOKUP_WPE) void k_psd_lo
     constexpr int NC = CPOL_ITAB1_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;      // (1-D blocks; the 2-D walk has its own constants)
     long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = lane_id();
+#ifdef CPOL_LOOKUP_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+    const unsigned long trace_w = ((unsigned long)blockIdx.y * gridDim.x * blockDim.x + (unsigned long)i0) >> 6;
+    unsigned trace_work = 0;
+    struct TraceEnd {
+        unsigned long long t0; unsigned long w; unsigned *work; int lane;
+        __device__ ~TraceEnd() {
+            if (lane == 0 && w < CPOL_SUBSUM_TRACE_N) {
+                g_subsum_trace[CPOL_SUBSUM_TRACE_W * w] = t0;
+                g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 1] = wall_clock64();
+                g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 2] = *work;
+                g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                                              (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;
+            }
+        }
+    } trace_end{trace_t0, trace_w, &trace_work, lane};
+#endif
+    // a.tile_scan: the workgroup lists the tiles among its own that hold a species with a 2-D table, then walks the list
+    __shared__ int s_list[CPOL_LOOKUP_LIST_CAP];
+    __shared__ int s_n;
+    constexpr int WAVES = CPOL_LOOKUP_THREADS / CPOL_WAVE;
+    int n_list = 1;
+    if (a.tile_scan) {
+        constexpr int TG = CPOL_TILE_GATES_LOG2, GATES = 1 << TG, RAYS = 64 >> TG;
+        static_assert(GATES == 4 && RAYS == 16, "the tile scan reads the 4 gates of a ray as one word and joins the 16 rays of a tile");
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const int r = lane & (RAYS - 1), q = lane >> 4, wv = (int)(threadIdx.x >> 6);
+        const int n_gt = (a.n_gates + GATES - 1) >> TG;
+        const long K = a.n_tiles > (long)blockIdx.x ? (a.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;   // tiles of this workgroup
+        const bool aligned = (a.n_gates & 3) == 0 && ((unsigned long long)a.vmask & 3) == 0;
+#pragma unroll 4
+        for (long k0 = 0; k0 < K; k0 += 4 * WAVES) {
+            const long k = k0 + wv * 4 + q;
+            const long W = (long)blockIdx.x + k * gridDim.x;
+            bool has = false;
+            if (k < K) {
+                const int gt = (int)(W % n_gt), sub = (int)((W / n_gt) % a.n_sub);
+                const int ray = (int)(W / ((long)n_gt * a.n_sub)) * RAYS + r;
+                if (ray < a.n_rays) {
+                    const long ib = ((long)ray * a.n_sub + sub) * a.n_gates + (long)gt * GATES;
+                    unsigned bits = 0;
+                    if (aligned) {                                      // (n_gates a multiple of 4: the word lies inside the ray)
+                        const unsigned w4 = *reinterpret_cast<const unsigned *>(a.vmask + ib);
+                        bits = w4 | w4 >> 8 | w4 >> 16 | w4 >> 24;
+                    } else {
+                        for (int g = 0; g < GATES; ++g)
+                            if (gt * GATES + g < a.n_gates) bits |= a.vmask[ib + g];
+                    }
+                    has = (bits & a.species2d & 0xFFu) != 0;
+                }
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+            unsigned tiles = 0;                                         // bit t: tile t of this wavefront's four holds something (uniform)
+            for (int t = 0; t < 4; ++t) tiles |= ((m >> (16 * t)) & 0xFFFFull) ? 1u << t : 0u;
+            if (!tiles) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, __popc(tiles));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (r == 0 && ((tiles >> q) & 1u)) s_list[base + __popc(tiles & ((1u << q) - 1u))] = (int)W;
+        }
+        __syncthreads();
+        n_list = s_n;
+    }
+    for (int entry = a.tile_scan ? (int)(threadIdx.x >> 6) : 0; entry < n_list; entry += a.tile_scan ? WAVES : 1) {
     bool in = i0 < a.n_sbg;
     if (a.tile) {
-        const long W = i0 >> 6;                                         // tile = wavefront
+        long W = i0 >> 6;                                               // tile = wavefront
+        if (a.tile_scan) W = s_list[entry];
         constexpr int TG = CPOL_TILE_GATES_LOG2, GATES = 1 << TG, RAYS = 64 >> TG;    // tile = RAYS rays x GATES gates
         const int n_gt = (a.n_gates + GATES - 1) >> TG;
         const int gt = (int)(W % n_gt), sub = (int)((W / n_gt) % a.n_sub);
@@ -2208,6 +2351,9 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, CPOL_LOOKUP_WPE) void k_psd_lo
                 const bool mine = turn == (int)blockIdx.y;
                 turn = turn + 1 == a.split ? 0 : turn + 1;
                 if (!mine) continue;
+#ifdef CPOL_LOOKUP_TRACE
+                ++trace_work;
+#endif
 #if CPOL_ITAB2_PAIR
                 itab2_walk_pairs(t.tab + (long)cur * (CPOL_ITAB2_NB * NFP) + f, grp, u, w, q, [&](int l, double acc, bool live) {
                     // (l: lane-varying between the two slots -- the item's sub-beam gate by bpermute, not readlane)
@@ -2268,5 +2414,6 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, CPOL_LOOKUP_WPE) void k_psd_lo
                 *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = make_double2(w.x * scale, w.y * scale);
             if (want_n0) a.par_w[((long)j * CPOL_MAX_PAR + 3) * n + i] = w2 * scale;
         }
+    }
     }
 }

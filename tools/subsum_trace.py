@@ -34,8 +34,8 @@ ptrs = {k: slab[i].data_ptr() for i, k in enumerate(bench.RADAR_FIELDS)}
 for _ in range(3):
     op.simulate_rays(az, el, device_outputs=ptrs)
     op.wait()
-N = 65536
-tr = op._ctx.debug_read('subsum_trace', (N, 4), np.uint64)
+N = 131072
+tr = op._ctx.debug_read('subsum_trace', (N, 8), np.uint64)
 op.close()
 used = tr[:, 1] > 0
 t0 = tr[used, 0].astype(np.int64)
@@ -54,6 +54,9 @@ np.add.at(busy, inv, dur)
 wsum = np.zeros(len(ids))
 np.add.at(wsum, inv, work)
 heavy = work > 0
+PHASES = ('round_setup', 'wait_for_blocks', 'chains', 'prefetch_tail_scale_store', 'barrier_1', 'ordered_sums', 'barrier_2')
+phw = tr[used, 4:8]
+ph = np.stack([(phw[:, i // 2] >> np.uint64(32 * (i % 2))) & np.uint64(0xFFFFFFFF) for i in range(7)], axis=1).astype(np.float64) / 100.0
 order = np.argsort(-dur)[:8]
 span = float(t1.max())
 # wavefronts alive over time (20 samples)
@@ -69,10 +72,11 @@ out = {'tag': tag, 'rays_per_sweep': rays, 'wavefronts': int(used.sum()), 'with_
        'simds_seen': int(len(ids)), 'simd_busy_us': {'max': float(busy.max()), 'mean': float(busy.mean()), 'min': float(busy.min())},
        'simd_iterations': {'max': int(wsum.max()), 'mean': float(wsum.mean())},
        'barrier_wait_us': {'median_with_work': float(np.median(wait[heavy])) if heavy.any() else 0.0, 'max': float(wait.max())},
+       'team_phase_us_mean_with_work': {n: float(np.mean(ph[heavy, i])) for i, n in enumerate(PHASES)} if heavy.any() else {},
        'last_start_us': float(t0.max()), 'last_start_with_work_us': float(t0[heavy].max()),
        'longest': [{'start': float(t0[i]), 'end': float(t1[i]), 'work': int(work[i])} for i in order],
        'alive_at_5pct_steps': alive, 'alive_with_work': alive_work}
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 with open(os.path.join(ROOT, 'gpurun_out', 'subsum_trace_%s.json' % (tag or 'x')), 'w') as fh:
     json.dump(out, fh)
-print(json.dumps({k: out[k] for k in ('tag', 'wavefronts', 'with_work', 'span_us', 'duration_us', 'us_per_iteration', 'barrier_wait_us', 'last_start_us')}))
+print(json.dumps({k: out[k] for k in ('tag', 'wavefronts', 'with_work', 'span_us', 'duration_us', 'us_per_iteration', 'barrier_wait_us', 'team_phase_us_mean_with_work', 'last_start_us')}))
