@@ -43,8 +43,9 @@ for pass in F:FETCH_SIZE W:WRITE_SIZE "S:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_A
     need /tmp/pmc$tag "*counter_collection.csv" "pmc pass $tag" > /dev/null || exit 3
 done
 # optional passes (a counter this ROCm does not list only costs the pass): where the L2's memory-side reads go (DRAM-side
-# against all: Infinity-Cache hits are not told apart at this interface) and the L2 hit rate
-for pass in "D:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum" "L:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+# against all: Infinity-Cache hits are not told apart at this interface), the L2 hit rate, and the LDS (cycles its index
+# stage is active per CU: the bound of the kernels that broadcast table rows from it)
+for pass in "D:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum" "L:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "X:SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SALU"; do
     tag=${pass%%:*}; counters=${pass#*:}
     rm -rf /tmp/pmc$tag
     echo "[profile_cmd] $name: optional pmc pass $tag ($counters)"
@@ -52,7 +53,7 @@ for pass in "D:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum" "
     rocprofv3 --pmc $counters --kernel-trace --output-format csv -d /tmp/pmc$tag -- python3 "$script" "$@" >> "$out/stdout_pmc$tag.log" 2>> "$out/pmc$tag.log" \
         || echo "[profile_cmd] optional pass $tag failed (status $?): $out/pmc$tag.log"
 done
-python3 "$root/tools/profile_summary.py" "$out/${name}_kernel_stats.csv" /tmp/pmcF /tmp/pmcW /tmp/pmcS /tmp/pmcD /tmp/pmcL > "$out/${name}_summary.json" \
+python3 "$root/tools/profile_summary.py" "$out/${name}_kernel_stats.csv" /tmp/pmcF /tmp/pmcW /tmp/pmcS /tmp/pmcD /tmp/pmcL /tmp/pmcX > "$out/${name}_summary.json" \
     || { echo "profile_cmd: profile_summary.py failed" >&2; exit 3; }
 [ -s "$out/${name}_summary.json" ] || { echo "profile_cmd: empty summary" >&2; exit 3; }
 grep -h "^{" "$out/stdout_kt.log" | cut -c1-300 || true

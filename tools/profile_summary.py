@@ -48,7 +48,8 @@ def main():
     for d in extra:
         for k, cs in pmc(d).items():
             e = out.setdefault(k, {})
-            for c in ('TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_DRAM_sum', 'TCC_EA0_RDREQ_32B_sum', 'TCC_HIT_sum', 'TCC_MISS_sum', 'TCC_REQ_sum'):
+            for c in ('TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_DRAM_sum', 'TCC_EA0_RDREQ_32B_sum', 'TCC_HIT_sum', 'TCC_MISS_sum', 'TCC_REQ_sum',
+                      'SQ_LDS_IDX_ACTIVE', 'SQ_INSTS_LDS', 'SQ_LDS_BANK_CONFLICT', 'SQ_ACTIVE_INST_LDS', 'SQ_INSTS_SALU'):
                 if c in cs:
                     e[c] = cs[c]
     for k, e in out.items():
@@ -58,6 +59,9 @@ def main():
             e['rdreq_dram_share'] = e.get('TCC_EA0_RDREQ_DRAM_sum', 0.0) / e['TCC_EA0_RDREQ_sum']
         if isinstance(e, dict) and e.get('TCC_REQ_sum'):
             e['l2_hit_rate'] = e.get('TCC_HIT_sum', 0.0) / e['TCC_REQ_sum']
+        if isinstance(e, dict) and e.get('SQ_LDS_IDX_ACTIVE') and e.get('GRBM_GUI_ACTIVE'):
+            # cycles the LDS index stage of a CU is active (summed over 256 CUs) over the kernel's cycles (GRBM_GUI_ACTIVE: summed over 8 XCDs)
+            e['lds_busy_frac'] = (e['SQ_LDS_IDX_ACTIVE'] / 256.0) / (e['GRBM_GUI_ACTIVE'] / 8.0)
     for k, e in out.items():
         if isinstance(e, dict) and 'FETCH_SIZE' in e and 'WRITE_SIZE' in e:
             e['hbm_bytes'] = (2 * e['FETCH_SIZE'] + e['WRITE_SIZE']) * 1024
