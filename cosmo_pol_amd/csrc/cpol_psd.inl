@@ -2215,6 +2215,9 @@ __device__ __forceinline__ void itab1_columns(const double2 *c, double u, double
 // item's operands brought to its 16 lanes by ds_bpermute, no cross-lane sums: PSD stage of the C4 volume 3.05 -> 3.21 ms,
 // of the 225-ray share 850 -> 877 us, of the C3 sweep 62.5 -> 59.8 us: ~10 items share a block, staging it costs what the
 // 66 LDS reads per pass save.)
+#ifndef CPOL_LOOKUP_GROUP_LOG2
+#define CPOL_LOOKUP_GROUP_LOG2 2      // consecutive tiles per group of a workgroup's own tiles (tile scan)
+#endif
 #ifndef CPOL_LOOKUP_LIST_CAP
 #define CPOL_LOOKUP_LIST_CAP 2048     // tiles a workgroup of k_psd_lookup owns at most when it scans for those with work (8 KB of LDS)
 #endif
@@ -2255,14 +2258,18 @@ __global__ __launch_bounds__(CPOL_LOOKUP_THREADS, CPOL_LOOKUP_WPE) void k_psd_lo
         __syncthreads();
         const int r = lane & (RAYS - 1), q = lane >> 4, wv = (int)(threadIdx.x >> 6);
         const int n_gt = (a.n_gates + GATES - 1) >> TG;
-        const long K = a.n_tiles > (long)blockIdx.x ? (a.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;   // tiles of this workgroup
+        // the workgroup owns groups of 2^GL consecutive tiles (gate tiles of one sub-beam index: neighbours share table blocks in L2),
+        // group g of blockIdx.x = blockIdx.x + g gridDim.x
+        constexpr int GL = CPOL_LOOKUP_GROUP_LOG2, GS = 1 << GL;
+        const long G4 = (a.n_tiles + GS - 1) >> GL;
+        const long K = G4 > (long)blockIdx.x ? GS * ((G4 - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;   // tiles of this workgroup
         const bool aligned = (a.n_gates & 3) == 0 && ((unsigned long long)a.vmask & 3) == 0;
 #pragma unroll 4
         for (long k0 = 0; k0 < K; k0 += 4 * WAVES) {
             const long k = k0 + wv * 4 + q;
-            const long W = (long)blockIdx.x + k * gridDim.x;
+            const long W = (((long)blockIdx.x + (k >> GL) * gridDim.x) << GL) + (k & (GS - 1));
             bool has = false;
-            if (k < K) {
+            if (k < K && W < a.n_tiles) {
                 const int gt = (int)(W % n_gt), sub = (int)((W / n_gt) % a.n_sub);
                 const int ray = (int)(W / ((long)n_gt * a.n_sub)) * RAYS + r;
                 if (ray < a.n_rays) {
