@@ -160,8 +160,10 @@ struct cpol_ctx {
     int geo_poly = 1;                  // CPOL_GEO_POLY=0: the non-central sub-beams take the short closed form of the geodesy instead of the per-ray polynomials
     int psd_rare = 1;                  // CPOL_PSD_RARE=0: one launch per integrating flavour also when the units are directly listed items (read when the context is created)
     int subsum_small = 0;              // CPOL_SUBSUM_SMALL=1: experiment: the gather form of k_subbeam_sum with three wavefronts per (tile, hydrometeor) and the whole block in flight (measured slower)
-    int subsum_team = -1;              // CPOL_SUBSUM_TEAM=W: k_subbeam_sum_team<W> (W = 2..7 wavefronts per (tile, species)) for every launch; 0: never (the one-wavefront
-                                       // forms alone); -1 (default): W = 2 for the launches too small for the LDS form
+    int subsum_chain = 1;              // CPOL_SUBSUM_CHAIN=0: the team's terms pass through LDS and a barrier per round instead of its float32 sums waiting in LDS, handed
+                                       // from sub-beam to sub-beam (share of one of 8 GPUs: 385 against 334 us)
+    int subsum_team = -1;              // CPOL_SUBSUM_TEAM=W: k_subbeam_sum_team<W> (W = 2..8 wavefronts per (tile, species)) for every launch; 0: never (the one-wavefront
+                                       // forms alone); -1 (default): W = 4 for the launches too small for the LDS form
     int subsum_coop = -1;              // CPOL_SUBSUM_COOP: k_subbeam_sum takes its coefficients through the scalar cache: 0 never, 1 always, -1 by launch size
     bool last_subsum = false;          // the 1-D table items of the last sweep never went through res[] (k_subbeam_sum)
     bool keep_debug = false;
@@ -623,6 +625,7 @@ int cpol_create(int device, cpol_ctx **out)
     if (getenv("CPOL_RARE_DIRECT")) ctx->rare_direct = atoi(getenv("CPOL_RARE_DIRECT")) != 0 ? 1 : 0;
     if (getenv("CPOL_GATE1")) ctx->gate1 = atoi(getenv("CPOL_GATE1"));
     if (getenv("CPOL_SUBSUM_FORM")) ctx->subsum_scalar = !strcmp(getenv("CPOL_SUBSUM_FORM"), "scalar") ? 1 : 0;
+    if (getenv("CPOL_SUBSUM_CHAIN")) ctx->subsum_chain = atoi(getenv("CPOL_SUBSUM_CHAIN")) != 0 ? 1 : 0;
     if (getenv("CPOL_SUBSUM_TEAM")) ctx->subsum_team = atoi(getenv("CPOL_SUBSUM_TEAM"));
     if (getenv("CPOL_SUBSUM_SMALL")) ctx->subsum_small = atoi(getenv("CPOL_SUBSUM_SMALL")) != 0 ? 1 : 0;
     if (getenv("CPOL_TABLE_UPLOAD")) ctx->upload_kernel = strcmp(getenv("CPOL_TABLE_UPLOAD"), "kernel") == 0 ? 1 : 0;
@@ -733,6 +736,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->subsum_coop = parent->subsum_coop;
     c->subsum_small = parent->subsum_small;
     c->subsum_team = parent->subsum_team;
+    c->subsum_chain = parent->subsum_chain;
     c->psd_rare = parent->psd_rare;
     c->geo_poly = parent->geo_poly;
     c->upload_kernel = parent->upload_kernel;
@@ -2232,13 +2236,15 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // the team form (round 5: W wavefronts per (tile, species) share the sub-beams, the float32 sums stay ordered): what bounds a small
         // launch is the length of its longest wavefront's chain (cpol_final.inl).  Share of one of 8 / 4 / 2 GPUs alone (11 / 21 / 43
         // wavefronts per SIMD), ms per volume share: 1.47 / 2.18 / 3.57 with the rule above, 1.23 / 2.00 / 3.53 with W = 2 (W = 4: 1.23 /
-        // 2.05 / 3.66); with three lanes in flight 0.97 / 1.71 either way (a context WITH lanes that runs one share at
+        // 2.05 / 3.66; W = 4 with the sums handed on in LDS instead of a barrier per round -- the default -- 1.16 / 1.98 / 3.44); with three lanes in flight 0.97 / 1.71 either way (a context WITH lanes that runs one share at
         // a time: 1.42 with the LDS form its rule picked, 1.23 with the team); the whole volume 1.71 (LDS form) against 1.94 ms.
         const int team = ctx->subsum_team >= 0 ? ctx->subsum_team       // (a form forced through CPOL_SUBSUM_COOP stays what was asked for)
-                       : (ctx->subsum_coop < 0 && waves_per_simd < 40 ? 2 : 0);      // (whatever the lanes: a context with lanes may still run one sweep at a time)
-#define CPOL_TEAM_CASE(W) case W: hipLaunchKernelGGL((k_subbeam_sum_team<W>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_WAVE * W), 0, st, ctx->hs, ctx->its, sa2); break;
-        if (team >= 2 && team <= 7)
-            switch (team) { CPOL_TEAM_CASE(2) CPOL_TEAM_CASE(3) CPOL_TEAM_CASE(4) CPOL_TEAM_CASE(5) CPOL_TEAM_CASE(6) CPOL_TEAM_CASE(7) }
+                       : (ctx->subsum_coop < 0 && waves_per_simd < 40 ? 4 : 0);      // (whatever the lanes: a context with lanes may still run one sweep at a time)
+#define CPOL_TEAM_CASE(W) case W: if (ctx->subsum_chain) hipLaunchKernelGGL((k_subbeam_sum_team<W, true>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_WAVE * W), 0, st, ctx->hs, ctx->its, sa2); \
+                          else hipLaunchKernelGGL((k_subbeam_sum_team<W, false>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_WAVE * W), 0, st, ctx->hs, ctx->its, sa2); break;
+        if (team >= 2 && team <= 8)
+            switch (team) { CPOL_TEAM_CASE(2) CPOL_TEAM_CASE(3) CPOL_TEAM_CASE(4) CPOL_TEAM_CASE(5) CPOL_TEAM_CASE(6) CPOL_TEAM_CASE(7)
+                            case 8: hipLaunchKernelGGL((k_subbeam_sum_team<8, true>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_WAVE * 8), 0, st, ctx->hs, ctx->its, sa2); break; }
 #undef CPOL_TEAM_CASE
         else if (coop && ctx->subsum_scalar) hipLaunchKernelGGL(k_subbeam_sum_scalar, dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);
         else if (coop) hipLaunchKernelGGL(k_subbeam_sum_lds, dim3((unsigned)tiles, n_hyd), dim3(CPOL_SUBSUM_THREADS), 0, st, ctx->hs, ctx->its, sa2);

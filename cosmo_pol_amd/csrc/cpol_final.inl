@@ -640,8 +640,16 @@ void k_subbeam_sum_gather(HydroSet hs, ItabSet its, SubsumArgs a) { subbeam_sum_
 #define CPOL_TEAM_NBUF 2          // block buffers per wavefront (1.4 KB each): the blocks of the next round requested ahead (3: 380 -> 402 us, fewer workgroups per CU)
 #endif
 static_assert(CPOL_TEAM_NBUF >= 2 && CPOL_TEAM_NBUF <= 3, "k_subbeam_sum_team keeps the ids of at most three blocks requested ahead");
-template <int W>
-__global__ __launch_bounds__(CPOL_WAVE * W)
+#ifndef CPOL_TEAM_WPE
+#define CPOL_TEAM_WPE 5              // wavefronts per SIMD asked of the register allocator (100 VGPRs by its own choice: 4; chain form, W = 4, share: 352 -> 334 us; 6: 391, spills)
+#endif
+#if CPOL_TEAM_WPE
+#define CPOL_TEAM_ATTR __attribute__((amdgpu_waves_per_eu(CPOL_TEAM_WPE, CPOL_TEAM_WPE)))
+#else
+#define CPOL_TEAM_ATTR
+#endif
+template <int W, bool CHAIN>
+__global__ __launch_bounds__(CPOL_WAVE * W) CPOL_TEAM_ATTR
 void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
 {
     constexpr int NC = CPOL_ITAB1_NC, NFP = CPOL_ITAB_NFP, NB = NC * NFP;
@@ -649,7 +657,9 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
     constexpr int PPW = (NP + W - 1) / W;                                // pairs a wavefront accumulates
     constexpr int PIECES = NC * NFP / 2;
     constexpr int REST = PIECES - CPOL_WAVE;
-    __shared__ double2 s_y[W][NP][CPOL_WAVE];
+    __shared__ double2 s_y[CHAIN ? 1 : W][CHAIN ? 1 : NP][CPOL_WAVE];
+    __shared__ float2 s_acc[CHAIN ? NP : 1][CPOL_WAVE];     // CHAIN: the running float32 sums of the tile, handed from sub-beam to sub-beam
+    __shared__ int s_turn;                                   // CHAIN: sub-beams (in the order of the sums) added so far
     __shared__ unsigned long long s_pm[W][CPOL_WAVE];
     constexpr int NBUF = CPOL_TEAM_NBUF;
     __shared__ double2 s_blk[W][NBUF][PIECES > CPOL_WAVE ? PIECES : CPOL_WAVE];
@@ -676,6 +686,11 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
     float acc[2 * PPW];
 #pragma unroll
     for (int c = 0; c < 2 * PPW; ++c) acc[c] = __builtin_nanf("");
+    if constexpr (CHAIN) {
+        for (int f = wave; f < NP; f += W) s_acc[f][lane] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+        if (threadIdx.x == 0) s_turn = 0;                                // (the first barrier below comes before the first sum)
+    }
+    int turn_base = 0;                                                   // CHAIN: sub-beams with work in the chunks before this one
     double2 (*my_blk)[PIECES > CPOL_WAVE ? PIECES : CPOL_WAVE] = s_blk[wave];
     auto request = [&](int blk, int bufi) {
         const double2 *src = reinterpret_cast<const double2 *>(t.tab + (long)blk * NB);
@@ -698,7 +713,6 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
 #ifdef CPOL_SUBSUM_TRACE
     const unsigned long long trace_t0 = wall_clock64();
     unsigned trace_work = 0;
-    unsigned long long trace_wait = 0;
     unsigned trace_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long trace_last = trace_t0;
 #define TP(i) { const unsigned long long now_ = wall_clock64(); trace_ph[i] += (unsigned)(now_ - trace_last); trace_last = now_; }
@@ -724,6 +738,7 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
         for (int q = 0; q < n_here; ++q)
             if (__builtin_amdgcn_ballot_w64((pm >> q) & 1ull)) wp |= 1ull << q;
         if (!wp) continue;
+        const unsigned long long wp_all = wp;
         // key + record of this wavefront's sub-beams TWO rounds ahead, the first block ONE round ahead: what a round waits
         // for (s_waitcnt vmcnt(0) below: every load in flight) was requested a round ago or more
         auto load_kr = [&](int q, int &key_o, double2 &rc_o) {
@@ -878,18 +893,35 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
                         double yx = v[f].x * w, yy = v[f].y * w;
                         if (!(yx == yx)) yx = 0.0;
                         if (!(yy == yy)) yy = 0.0;
-                        s_y[wave][f][lane] = make_double2(yx, yy);
+                        if constexpr (CHAIN) v[f] = make_double2(yx, yy);
+                        else s_y[wave][f][lane] = make_double2(yx, yy);
                     }
                 }
+                if constexpr (CHAIN) {
+                    // this sub-beam's turn in the order of the sums: the tile's float32 sums wait in LDS; the wavefront whose
+                    // sub-beam comes next adds its terms and passes them on (nansum([float32 sum, float64 term]) as float32)
+                    const int turn = turn_base + __popcll(wp_all & ((1ull << q_cur) - 1ull));
+                    TP(3)
+                    while (__hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != turn) __builtin_amdgcn_s_sleep(1);
+                    TP(4)
+                    if (present) {
+#pragma unroll
+                        for (int f = 0; f < NP; ++f) {
+                            float2 sa = s_acc[f][lane];
+                            const float xa = (sa.x == sa.x) ? sa.x : 0.f, xb = (sa.y == sa.y) ? sa.y : 0.f;
+                            sa.x = (float)((double)xa + v[f].x);
+                            sa.y = (float)((double)xb + v[f].y);
+                            s_acc[f][lane] = sa;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_store(&s_turn, turn + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    TP(5)
+                }
             }
+            if constexpr (!CHAIN) {
             TP(3)
-#ifdef CPOL_SUBSUM_TRACE
-            const unsigned long long tw0 = wall_clock64();
-#endif
             __syncthreads();
-#ifdef CPOL_SUBSUM_TRACE
-            trace_wait += wall_clock64() - tw0;
-#endif
             TP(4)
             // nansum([float32 acc, float64 term]) stored back as float32, sub-beam after sub-beam
             if (wave * PPW < NP) {
@@ -911,8 +943,10 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
             TP(5)
             __syncthreads();
             TP(6)
+            }
             wp = wp_after;
         }
+        turn_base += __popcll(wp_all);
     }
 #ifdef CPOL_SUBSUM_TRACE
     {
@@ -921,18 +955,25 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
             for (int i = 0; i < 4; ++i) g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 4 + i] = trace_ph[2 * i] | (unsigned long long)trace_ph[2 * i + 1] << 32;
             g_subsum_trace[CPOL_SUBSUM_TRACE_W * w] = trace_t0;
             g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 1] = wall_clock64();
-            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 2] = trace_work | trace_wait << 32;
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 2] = trace_work | (unsigned long long)trace_ph[4] << 32;
             g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                         (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;
         }
     }
 #endif
 #undef TP
+    if constexpr (CHAIN) {
+        __syncthreads();                                                 // (every sub-beam has had its turn)
+        if (!in) return;
+        float2 *o = reinterpret_cast<float2 *>(a.sz_integ + (rg * a.n_hydro + j) * CPOL_N_SZ);
+        for (int f = wave; f < NP; f += W) o[f] = s_acc[f][lane];
+    } else {
     if (!in || wave * PPW >= NP) return;
     float2 *o = reinterpret_cast<float2 *>(a.sz_integ + (rg * a.n_hydro + j) * CPOL_N_SZ) + wave * PPW;
 #pragma unroll
     for (int f = 0; f < PPW; ++f)
         if (wave * PPW + f < NP) o[f] = make_float2(acc[2 * f], acc[2 * f + 1]);
+    }
 }
 
 

@@ -168,7 +168,7 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
     assert n_valid > 300 and n_melt > 100, (n_valid, n_melt)
     op.close()
     forms = {}
-    for form in ('gather', 'gather1', 'coop', 'scalar', 'tail', 'two_kernels', 'team4', 'team6', 'team7', 'listed_tiles'):
+    for form in ('gather', 'gather1', 'coop', 'scalar', 'tail', 'two_kernels', 'team4', 'team6', 'team7', 'chain2', 'chain4', 'chain8', 'listed_tiles'):
         # 'gather': the per-lane gather in its small-launch form (three wavefronts per (tile, hydrometeor), the
         # whole block requested at once: CPOL_SUBSUM_SMALL=1, an experiment); 'gather1': one wavefront per
         # (tile, hydrometeor), rows two at a time (what a small launch gets by default);
@@ -177,6 +177,8 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
         # (round 3's form, CPOL_SUBSUM_FORM=scalar); 'tail': ONE block that way, every other lane through the tail
         # 'team<W>': W wavefronts per (tile, species), the r-th present sub-beam evaluated by wavefront r mod W, the terms
         # of a round handed through LDS and added in order (k_subbeam_sum_team, round 5);
+        # 'chain<W>': the team with the tile's float32 sums waiting in LDS, handed from sub-beam to sub-beam (CPOL_SUBSUM_CHAIN=1: no
+        # barrier per round);
         # 'listed_tiles': the workgroups of k_psd_lookup list the tiles with a melting species among their own and walk that list (by
         # default only from 262 144 tiles on: CPOL_LOOKUP_LIST=2 asks for it here) instead of one wavefront per tile;
         # 'two_kernels': the default forms, but k_interp_sweep + k_classify instead of the one kernel that interpolates
@@ -186,7 +188,8 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
         monkeypatch.setenv('CPOL_SUBSUM_COOP_ROUNDS', '1' if form == 'tail' else '6')
         monkeypatch.setenv('CPOL_SUBSUM_FORM', 'scalar' if form == 'scalar' else 'lds')
         monkeypatch.setenv('CPOL_FUSE_CLASSIFY', '0' if form == 'two_kernels' else '1')
-        monkeypatch.setenv('CPOL_SUBSUM_TEAM', form[4:] if form.startswith('team') else '0')
+        monkeypatch.setenv('CPOL_SUBSUM_TEAM', form[4:] if form.startswith('team') else form[5:] if form.startswith('chain') else '0')
+        monkeypatch.setenv('CPOL_SUBSUM_CHAIN', '1' if form.startswith('chain') else '0')
         monkeypatch.setenv('CPOL_LOOKUP_LIST', '2' if form == 'listed_tiles' else '1')
         if form == 'two_kernels':
             monkeypatch.delenv('CPOL_SUBSUM_COOP'); monkeypatch.delenv('CPOL_SUBSUM_SMALL')
@@ -203,6 +206,8 @@ def test_c4_sector_with_49_subbeams_vs_oracle(monkeypatch):
         assert np.array_equal(forms['gather'][k], forms['two_kernels'][k], equal_nan=True), k
         for w in (4, 6, 7):
             assert np.array_equal(forms['gather'][k], forms['team%d' % w][k], equal_nan=True), (k, w)
+        for w in (2, 4, 8):
+            assert np.array_equal(forms['gather'][k], forms['chain%d' % w][k], equal_nan=True), (k, w)
         assert np.array_equal(forms['gather'][k], forms['listed_tiles'][k], equal_nan=True), k
         assert np.array_equal(forms['gather'][k], res[k], equal_nan=True), k     # (res: the default choice, last elevation)
 
