@@ -636,6 +636,12 @@ void k_subbeam_sum_gather(HydroSet hs, ItabSet its, SubsumArgs a) { subbeam_sum_
 // the W terms of a round pass through LDS as float64 (12 columns x 64 lanes x 8 B per wavefront), and after a barrier
 // wavefront k adds column pairs [k PPW, (k + 1) PPW) of the round's sub-beams IN ORDER to its float32 registers: same
 // terms, same order, same bits, and a chain of ceil(49 / W) rounds.
+// CHAIN (the default, W = 4): no barrier per round and no exchange of terms -- the tile's float32 sums wait in LDS (3 KB per
+// workgroup), a counter says whose turn it is; the wavefront whose sub-beam comes next waits for the counter, adds its 12
+// terms per lane to the sums in LDS and moves the counter on.  The wavefronts of a team then run apart (each is held up only
+// by the sub-beam right before its own), and a wavefront's LDS shrinks from 9.4 to 4 KB: share 385 -> 352 us, 334 at 5
+// wavefronts per SIMD (96 VGPRs).  Every turn belongs to a wavefront that takes it before it reaches the next barrier
+// (the exchange of validity bits of the next chunk of 64 sub-beams, the end): nobody waits for a wavefront that waits.
 #ifndef CPOL_TEAM_NBUF
 #define CPOL_TEAM_NBUF 2          // block buffers per wavefront (1.4 KB each): the blocks of the next round requested ahead (3: 380 -> 402 us, fewer workgroups per CU)
 #endif
