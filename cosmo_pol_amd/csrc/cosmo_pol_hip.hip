@@ -1425,7 +1425,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     if (mode == CPOL_GEOM_HOST_PATHS || ctx->keep_debug || prep_paths)
         ENSURE(ctx->b_traj, (size_t)n_rays * n_v * 3 * ng * sizeof(float));
     if (ray_prep) ENSURE(ctx->b_rayc, ((size_t)n_rays * n_h + n_rays) * 2 * sizeof(double));
-    // the rotated coordinates of the non-central sub-beams as polynomials of the arc distance (cpol_interp.inl: geo_poly_fit):
+    // the rotated coordinates of the non-central sub-beams as polynomials of the arc distance (cpol_interp.inl: k_trajectory):
     // ground radars on the 4/3-earth ray paths, one site (CPOL_GEO_POLY=0: the short closed form of round 4)
     const bool geo_poly = ray_prep && ctx->geo_poly && mode == CPOL_GEOM_GROUND_43 && !t->site;
     if (geo_poly) {
@@ -2239,7 +2239,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         // 2.05 / 3.66; W = 4 with the sums handed on in LDS instead of a barrier per round -- the default -- 1.16 / 1.98 / 3.44); with three lanes in flight 0.97 / 1.71 either way (a context WITH lanes that runs one share at
         // a time: 1.42 with the LDS form its rule picked, 1.23 with the team); the whole volume 1.71 (LDS form) against 1.94 ms.
         const int team = ctx->subsum_team >= 0 ? ctx->subsum_team       // (a form forced through CPOL_SUBSUM_COOP stays what was asked for)
-                       : (ctx->subsum_coop < 0 && waves_per_simd < 40 ? 4 : 0);      // (whatever the lanes: a context with lanes may still run one sweep at a time)
+                       : (ctx->subsum_coop < 0 && waves_per_simd < 50 ? 4 : 0);      // (whatever the lanes: a context with lanes may still run one sweep at a time)
 #define CPOL_TEAM_CASE(W) case W: if (ctx->subsum_chain) hipLaunchKernelGGL((k_subbeam_sum_team<W, true>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_WAVE * W), 0, st, ctx->hs, ctx->its, sa2); \
                           else hipLaunchKernelGGL((k_subbeam_sum_team<W, false>), dim3((unsigned)tiles, n_hyd), dim3(CPOL_WAVE * W), 0, st, ctx->hs, ctx->its, sa2); break;
         if (team >= 2 && team <= 8)

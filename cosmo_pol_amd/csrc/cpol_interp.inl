@@ -47,7 +47,7 @@ struct TrajArgs {
     double *ray_const;          // [n_rays * n_h][2] sin / cos (2 sigma1), then [n_rays][2] sin / cos (site longitude)
     int n_h;
     double lon1;
-    // rotated coordinates along a ray as polynomials of the arc distance (see geo_poly_fit): NULL: not wanted
+    // rotated coordinates along a ray as polynomials of the arc distance (k_trajectory): NULL: not wanted
     double *poly;               // [n_rays * n_h][2][CPOL_GEO_NP] monomial coefficients of rlat(x), rlon(x) [deg], x = s * poly_scale - 1
     const double *poly_M;       // [CPOL_GEO_NP][CPOL_GEO_NP] Chebyshev-node values -> monomial coefficients
     double poly_scale;          // 2 / s_max
@@ -174,31 +174,6 @@ __device__ __forceinline__ void exact_rotated_coords(const ModelDev &m, const do
     rlat_deg = asin(z_new) / CPOL_DEG;
 }
 
-// one thread per (ray, horizontal node): node values -> monomial coefficients of rlat(x), rlon(x)
-__device__ __forceinline__ void geo_poly_fit(const ModelDev &m, const TrajArgs &a, long e)
-{
-    constexpr int NP = CPOL_GEO_NP;
-    const double *gc = a.geo + e * 8;
-    double s2s1, c2s1;
-    sincos(2.0 * gc[2], &s2s1, &c2s1);
-    double vlat[NP], vlon[NP];
-#pragma unroll 1
-    for (int q = 0; q < NP; ++q) {
-        const double xq = cos(3.14159265358979323846 * ((double)q + 0.5) / (double)NP);
-        exact_rotated_coords(m, gc, a.sin_u1, a.cos_u1, a.lon1, s2s1, c2s1, (xq + 1.0) / a.poly_scale, vlat[q], vlon[q]);
-    }
-    double *o = a.poly + e * (2 * NP);
-    for (int pw = 0; pw < NP; ++pw) {
-        double c0 = 0.0, c1 = 0.0;
-        for (int q = 0; q < NP; ++q) {
-            c0 = fma(a.poly_M[pw * NP + q], vlat[q], c0);
-            c1 = fma(a.poly_M[pw * NP + q], vlon[q], c1);
-        }
-        o[pw] = c0;
-        o[NP + pw] = c1;
-    }
-}
-
 // Ray paths ahead of the sweep kernel: with several horizontal quadrature nodes the sub-beams of one
 // vertical node share their path (7 x 7 nodes: 6 of 7 evaluations of the refraction formulas saved, ~300
 // float64 instructions per sub-beam gate); also the parity access to the paths (cpol_debug_read "traj").
@@ -211,9 +186,39 @@ __global__ __launch_bounds__(256) void k_trajectory(ModelDev m, TrajArgs a)
     int g = blockIdx.y * blockDim.x + threadIdx.x;
     int rv = blockIdx.x;                       // ray * n_v + vnode
     if (a.poly && blockIdx.y == 0) {
+        // the coordinate polynomials of (ray, horizontal node) e: NP threads per e, one node each (the long form of the
+        // geodesic once per thread instead of NP times in a row: the share of one of 8 GPUs has 1 575 e and waited 36 us for
+        // this kernel), the node values meet in LDS and thread (e, pw) forms monomial coefficient pw of rlat(x), rlon(x) from them
+        constexpr int NP = CPOL_GEO_NP, EPB = 256 / NP;
+        __shared__ double s_node[2][EPB][NP];
         const long n_geo = (long)a.n_rays * a.n_h;
-        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_geo; e += (long)gridDim.x * blockDim.x)
-            geo_poly_fit(m, a, e);
+        const int el = threadIdx.x / NP, q = threadIdx.x % NP;
+        for (long e0 = (long)blockIdx.x * EPB; e0 < n_geo; e0 += (long)gridDim.x * EPB) {
+            const long e = e0 + el;
+            const bool ok = el < EPB && e < n_geo;
+            if (ok) {
+                const double *gc = a.geo + e * 8;
+                double s2s1, c2s1;
+                sincos(2.0 * gc[2], &s2s1, &c2s1);
+                const double xq = cos(3.14159265358979323846 * ((double)q + 0.5) / (double)NP);
+                double vlat, vlon;
+                exact_rotated_coords(m, gc, a.sin_u1, a.cos_u1, a.lon1, s2s1, c2s1, (xq + 1.0) / a.poly_scale, vlat, vlon);
+                s_node[0][el][q] = vlat;
+                s_node[1][el][q] = vlon;
+            }
+            __syncthreads();
+            if (ok) {
+                double c0 = 0.0, c1 = 0.0;
+                for (int k = 0; k < NP; ++k) {
+                    c0 = fma(a.poly_M[q * NP + k], s_node[0][el][k], c0);
+                    c1 = fma(a.poly_M[q * NP + k], s_node[1][el][k], c1);
+                }
+                double *o = a.poly + e * (2 * NP);
+                o[q] = c0;
+                o[NP + q] = c1;
+            }
+            __syncthreads();
+        }
     }
     if (a.ray_const && blockIdx.y == 0) {
         const long n_geo = (long)a.n_rays * a.n_h;
@@ -469,7 +474,7 @@ struct InterpArgs {
     double sin_u1, cos_u1, lon1;
     const double *site;         // per-ray site or NULL
     int exact_sub;              // debug (cpol_sweep_params.debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS): every sub-beam takes the central one's long form
-    const double *poly;         // k_trajectory's coordinate polynomials [n_rays * n_h][2][CPOL_GEO_NP] or NULL (geo_poly_fit)
+    const double *poly;         // k_trajectory's coordinate polynomials [n_rays * n_h][2][CPOL_GEO_NP] or NULL
     double poly_scale;          // x = s * poly_scale - 1
 };
 
@@ -594,7 +599,7 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     // (wave-uniform: a wavefront walks ONE sub-beam; exact_sub is a kernel argument)
     const bool short_form = sub != a.central_sub && !a.exact_sub;
     if (short_form && a.poly) {
-        // ---- non-central sub-beam: the rotated coordinates from the (ray, horizontal node)'s polynomials (geo_poly_fit) ----
+        // ---- non-central sub-beam: the rotated coordinates from the (ray, horizontal node)'s polynomials (k_trajectory) ----
         constexpr int NP = CPOL_GEO_NP;
         const double *pc = a.poly + (long)(ray * a.n_h + ih) * (2 * NP);          // (wave-uniform: scalar loads)
         const double x = fma((double)s32, a.poly_scale, -1.0);
