@@ -981,20 +981,35 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a, d
             // is a chain of 128 exponentials, one after the other.  The N(D_k) of the chunk do not depend on each other: 64 bins at a time, one per LANE,
             // then the sums in the order of the loop below -- the same values, the same order, the same bits.
             const double lam_u = readlane_f64(lam, 0), N0_u = readlane_f64(N0, 0);
+            // lane q fetches the table row of bin kb + q (one round trip for 64 bins) and lays it down in LDS; then lane c < 12
+            // sums column c, lanes 12 / 13 the two Doppler sums (scheme 2)
+            constexpr int SW = CPOL_N_SZ + (DOP2 ? 2 : 0);               // doubles per staged bin
+            static_assert(CPOL_PSD_WAVES * CPOL_WAVE * SW <= NSLOT * NV * CPOL_WAVE, "staging area of the single-item path: the LDS of k_psd<>");
+            double *stage = lds_raw + (long)wave * (CPOL_WAVE * SW);
+            const long sl0 = (long)(key - h.key_base) * n_d;
+            const bool col = lane < CPOL_N_SZ + (DOP2 ? 2 : 0);
+            double acc_l = 0.0;
             for (int kb = k0; kb < k1; kb += CPOL_WAVE) {
                 const int kk = min(kb + lane, k1 - 1);
-                const double nk_l = (N0_u * h.pre[kk]) * exp(-(lam_u * h.dnu[kk]));
+                const double nk_l = (N0_u * h.pre[kk]) * exp(-(lam_u * h.dnu[kk]));          // (lane q: bin kb + q)
+                const double *rowv = h.table + (sl0 + kk) * CPOL_N_SZ;
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) stage[lane * SW + c] = rowv[c];
+                if (DOP2) { stage[lane * SW + CPOL_N_SZ] = h.rcsw[(sl0 + kk) * 2]; stage[lane * SW + CPOL_N_SZ + 1] = h.rcsw[(sl0 + kk) * 2 + 1]; }
+                __builtin_amdgcn_wave_barrier();
                 const int nq = min(CPOL_WAVE, k1 - kb);
-#pragma unroll 4
+#pragma unroll 8
                 for (int q = 0; q < nq; ++q) {
                     const double nk = readlane_f64(nk_l, q);
-                    const int k = kb + q;
-                    const cdouble_p row = slice + (long)k * CPOL_N_SZ;
-#pragma unroll
-                    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
-                    if (DOP2) { vsum = fma(rv[2 * k], nk, vsum); nsum = fma(rv[2 * k + 1], nk, nsum); }
+                    const double x = col ? stage[q * SW + lane] : 0.0;
+                    acc_l = fma(x, nk, acc_l);
                 }
+                __builtin_amdgcn_wave_barrier();
             }
+            __syncthreads();                                             // (the partial sums below take the same LDS)
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = readlane_f64(acc_l, c);
+            if (DOP2) { vsum = readlane_f64(acc_l, CPOL_N_SZ); nsum = readlane_f64(acc_l, CPOL_N_SZ + 1); }
         } else {
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
@@ -1179,31 +1194,42 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a, d
             // ONE item in the unit (the rule for items listed directly, k_psd_rare): the loop below then waits for one
             // scalar-cache round trip per bin (tools/rare_trace.py: ~60 of the 68 us k_psd_rare took for the single snow item
             // outside its table in a C4 volume share; 38 this way).
-            // 64 bins at a time: lane q fetches the table row and the polynomial factor of bin kb + q (one round trip for
-            // all of them), then the sums in the order of the loop below, operands by readlane -- the same values, the same
-            // order, the same bits.
+            // 64 bins at a time: lane q forms the polynomial factor of bin kb + q; then lane c sums COLUMN c over the bins in the
+            // order of the loop below (the bin's factor by readlane, its own table value by a load that waits for nothing) --
+            // the same values, the same order, the same bits; the sums go back to the item's lane at the end.
             const double lam_u = readlane_f64(lam0, 0), r_u = readlane_f64(r0, 0);
             double A_u = readlane_f64(A0, 0);
+            // lane q fetches the table row of bin kb + q (one round trip for 64 bins) and lays it down in LDS; then lane c < 12
+            // sums column c, lanes 12 / 13 the two Doppler sums (scheme 2)
+            constexpr int SW = CPOL_N_SZ + (DOP2 ? 2 : 0);               // doubles per staged bin
+            static_assert(CPOL_PSD_WAVES_U * CPOL_WAVE * SW <= NSLOT * NV * CPOL_WAVE, "staging area of the single-item path: the LDS of k_psd_uniform");
+            double *stage = lds_raw + (long)wave * (CPOL_WAVE * SW);
+            const long sl0 = (long)(key - h.key_base) * n_d;
+            const bool col = lane < CPOL_N_SZ + (DOP2 ? 2 : 0);
+            double acc_l = 0.0;
             for (int kb = k0; kb < k1; kb += CPOL_WAVE) {
                 const int kk = min(kb + lane, k1 - 1);
                 const double *pqv = h.aux + 1 + n_d + 4 * (long)kk;
-                const double poly_l = fma(lam_u, fma(lam_u, pqv[2], -pqv[1]), pqv[0]);
-                const double *rowv = h.table + ((long)(key - h.key_base) * n_d + kk) * CPOL_N_SZ;
-                double row_l[CPOL_N_SZ];
+                const double poly_l = fma(lam_u, fma(lam_u, pqv[2], -pqv[1]), pqv[0]);      // (lane q: bin kb + q)
+                const double *rowv = h.table + (sl0 + kk) * CPOL_N_SZ;
 #pragma unroll
-                for (int c = 0; c < CPOL_N_SZ; ++c) row_l[c] = rowv[c];
-                double wv_l = 0.0, wr_l = 0.0;
-                if (DOP2) { wv_l = h.rcsw[((long)(key - h.key_base) * n_d + kk) * 2]; wr_l = h.rcsw[((long)(key - h.key_base) * n_d + kk) * 2 + 1]; }
+                for (int c = 0; c < CPOL_N_SZ; ++c) stage[lane * SW + c] = rowv[c];
+                if (DOP2) { stage[lane * SW + CPOL_N_SZ] = h.rcsw[(sl0 + kk) * 2]; stage[lane * SW + CPOL_N_SZ + 1] = h.rcsw[(sl0 + kk) * 2 + 1]; }
+                __builtin_amdgcn_wave_barrier();
                 const int nq = min(CPOL_WAVE, k1 - kb);
-#pragma unroll 2
+#pragma unroll 8
                 for (int q = 0; q < nq; ++q) {
                     const double n0 = A_u * readlane_f64(poly_l, q);
                     A_u *= r_u;
-#pragma unroll
-                    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(readlane_f64(row_l[c], q), n0, acc[c]);
-                    if (DOP2) { dv0 = fma(readlane_f64(wv_l, q), n0, dv0); dn0 = fma(readlane_f64(wr_l, q), n0, dn0); }
+                    const double x = col ? stage[q * SW + lane] : 0.0;
+                    acc_l = fma(x, n0, acc_l);
                 }
+                __builtin_amdgcn_wave_barrier();
             }
+            __syncthreads();                                             // (the partial sums below take the same LDS)
+#pragma unroll
+            for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = readlane_f64(acc_l, c);
+            if (DOP2) { dv0 = readlane_f64(acc_l, CPOL_N_SZ); dn0 = readlane_f64(acc_l, CPOL_N_SZ + 1); }
         } else
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
