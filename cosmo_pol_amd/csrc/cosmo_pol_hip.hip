@@ -112,6 +112,10 @@ struct cpol_ctx {
         long shape[6] = {0, 0, 0, 0, 0, 0};
         DevBuf buf;
         void *views[11] = {nullptr};
+        // single-beam sweeps: the coordinate polynomials of this set's rays (k_trajectory), made once per (version, range grid)
+        DevBuf poly;
+        uint64_t poly_version = 0;
+        double poly_scale = 0.0;
     };
     static constexpr int N_TABLE_SETS = 8;
     TableSet tsets[N_TABLE_SETS];
@@ -157,6 +161,9 @@ struct cpol_ctx {
     int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
     int subsum_scalar = 0;             // CPOL_SUBSUM_FORM=scalar: the cooperative form of k_subbeam_sum takes its rows through the scalar cache instead of LDS
     int upload_kernel = 0;             // CPOL_TABLE_UPLOAD=kernel: the per-ray tables by k_upload_tables instead of hipMemcpyAsync (a measurement knob)
+    int last_poly_central = 0;         // the last sweep's one sub-beam took the coordinate polynomials (cpol_debug_read "poly_central")
+    int geo_poly_central = 1;          // CPOL_GEO_POLY_CENTRAL=0: a single-beam sweep keeps the long form of the geodesy for its (central) sub-beam even when
+                                       // nobody asks for the float64 latitude / longitude; 2: the polynomials also with the debug reads enabled (tools/fast_sub_check.py)
     int geo_poly = 1;                  // CPOL_GEO_POLY=0: the non-central sub-beams take the short closed form of the geodesy instead of the per-ray polynomials
     int psd_rare = 1;                  // CPOL_PSD_RARE=0: one launch per integrating flavour also when the units are directly listed items (read when the context is created)
     int subsum_small = 0;              // CPOL_SUBSUM_SMALL=1: experiment: the gather form of k_subbeam_sum with three wavefronts per (tile, hydrometeor) and the whole block in flight (measured slower)
@@ -629,6 +636,7 @@ int cpol_create(int device, cpol_ctx **out)
     if (getenv("CPOL_SUBSUM_TEAM")) ctx->subsum_team = atoi(getenv("CPOL_SUBSUM_TEAM"));
     if (getenv("CPOL_SUBSUM_SMALL")) ctx->subsum_small = atoi(getenv("CPOL_SUBSUM_SMALL")) != 0 ? 1 : 0;
     if (getenv("CPOL_TABLE_UPLOAD")) ctx->upload_kernel = strcmp(getenv("CPOL_TABLE_UPLOAD"), "kernel") == 0 ? 1 : 0;
+    if (getenv("CPOL_GEO_POLY_CENTRAL")) ctx->geo_poly_central = std::max(0, std::min(2, atoi(getenv("CPOL_GEO_POLY_CENTRAL"))));
     if (getenv("CPOL_GEO_POLY")) ctx->geo_poly = atoi(getenv("CPOL_GEO_POLY")) != 0 ? 1 : 0;
     if (getenv("CPOL_PSD_RARE")) ctx->psd_rare = atoi(getenv("CPOL_PSD_RARE")) != 0 ? 1 : 0;
     if (getenv("CPOL_SUBSUM_COOP_ROUNDS")) ctx->subsum_coop_rounds = std::max(0, std::min(64, atoi(getenv("CPOL_SUBSUM_COOP_ROUNDS"))));
@@ -673,7 +681,7 @@ void cpol_destroy(cpol_ctx *ctx)
         if (sg.ev) (void)hipEventDestroy(sg.ev);
         if (sg.p) (void)hipHostFree(sg.p);
     }
-    for (auto &ts : ctx->tsets) free_buf(ts.buf);
+    for (auto &ts : ctx->tsets) { free_buf(ts.buf); free_buf(ts.poly); }
     DevBuf *all[] = {&ctx->d_H, &ctx->d_V, &ctx->b_traj, &ctx->b_wgate, &ctx->b_clk, &ctx->b_rayc,
                      &ctx->b_beam, &ctx->b_spectrum, &ctx->b_outwin, &ctx->b_vals, &ctx->b_mask,
                      &ctx->b_elev, &ctx->b_coords, &ctx->b_qmelt, &ctx->b_fwmelt, &ctx->b_key,
@@ -739,6 +747,7 @@ int cpol_fork(cpol_ctx *parent, cpol_ctx **out)
     c->subsum_chain = parent->subsum_chain;
     c->psd_rare = parent->psd_rare;
     c->geo_poly = parent->geo_poly;
+    c->geo_poly_central = parent->geo_poly_central;
     c->upload_kernel = parent->upload_kernel;
     c->subsum_scalar = parent->subsum_scalar;
     c->rare_direct = parent->rare_direct;
@@ -1379,6 +1388,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         size_t total = 0;
         for (const Item &it : items) total += (it.bytes + 63) & ~(size_t)63;
         set->version = 0;                                        // (not valid until the copy is queued)
+        set->poly_version = 0;                                   // (other rays: their polynomials are made again)
         ENSURE(set->buf, total);
         cpol_ctx::Staging &sg = ctx->stg[ctx->stg_next];
         ctx->stg_next = (ctx->stg_next + 1) % 4;
@@ -1428,8 +1438,14 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // the rotated coordinates of the non-central sub-beams as polynomials of the arc distance (cpol_interp.inl: k_trajectory):
     // ground radars on the 4/3-earth ray paths, one site (CPOL_GEO_POLY=0: the short closed form of round 4)
     const bool geo_poly = ray_prep && ctx->geo_poly && mode == CPOL_GEOM_GROUND_43 && !t->site;
-    if (geo_poly) {
-        ENSURE(ctx->b_poly, (size_t)n_rays * n_h * 2 * CPOL_GEO_NP * sizeof(double));
+    // single-beam sweeps (round 5): the one sub-beam takes the polynomials too when its float64 latitude / longitude are not
+    // outputs; they belong to the resident table set of the rays and are made once per (version, range grid)
+    const bool poly_single = !ray_prep && ctx->geo_poly && ctx->geo_poly_central && mode == CPOL_GEOM_GROUND_43 && !t->site &&
+                             (!ctx->keep_debug || ctx->geo_poly_central == 2) && t->version != 0 && !(p->debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS);
+    // arc distance <= slant range; a margin of 1e-3 for the asin of the 4/3-earth formula
+    const double geo_poly_scale = 2.0 / ((p->range0 + (double)(ng - 1) * p->range_step) * 1.001);
+    if (geo_poly || poly_single) {
+        if (geo_poly) ENSURE(ctx->b_poly, (size_t)n_rays * n_h * 2 * CPOL_GEO_NP * sizeof(double));
         if (!ctx->d_geoM.p) {
             // Chebyshev-node values -> monomial coefficients (as build_itabs' M), extended precision on the host
             constexpr int NP = CPOL_GEO_NP;
@@ -1449,6 +1465,19 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             rc = upload(ctx, ctx->d_geoM, M, sizeof M);
             if (rc != CPOL_OK) return rc;
             HIPCHK(hipStreamSynchronize(ctx->stream));           // (M is a stack array)
+        }
+        if (poly_single && (!set->poly.p || set->poly_version != set->version || set->poly_scale != geo_poly_scale)) {
+            ENSURE(set->poly, (size_t)n_rays * n_h * 2 * CPOL_GEO_NP * sizeof(double));
+            TrajArgs tp{};
+            tp.geo = (const double *)ctx->v_geo;
+            tp.n_rays = n_rays; tp.n_h = n_h; tp.n_v = n_v; tp.n_gates = ng; tp.mode = mode;
+            tp.lon1 = p->radar_lon; tp.sin_u1 = p->sin_u1; tp.cos_u1 = p->cos_u1;
+            tp.poly = (double *)set->poly.p;
+            tp.poly_M = (const double *)ctx->d_geoM.p;
+            tp.poly_scale = geo_poly_scale;
+            hipLaunchKernelGGL(k_trajectory, dim3((unsigned)cdiv((long)n_rays * n_h, 256 / CPOL_GEO_NP)), dim3(256), 0, ctx->stream, ctx->model, tp);
+            set->poly_version = set->version;
+            set->poly_scale = geo_poly_scale;
         }
     }
     ENSURE(ctx->b_vals, (size_t)n_vars * n_sbg * sizeof(float));
@@ -1701,8 +1730,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         if (geo_poly) {
             ta.poly = (double *)ctx->b_poly.p;
             ta.poly_M = (const double *)ctx->d_geoM.p;
-            // arc distance <= slant range; a margin of 1e-3 for the asin of the 4/3-earth formula
-            ta.poly_scale = 2.0 / ((p->range0 + (double)(ng - 1) * p->range_step) * 1.001);
+            ta.poly_scale = geo_poly_scale;
             ta.sin_u1 = p->sin_u1; ta.cos_u1 = p->cos_u1;
         }
         hipLaunchKernelGGL(k_trajectory, dim3((unsigned)(n_rays * n_v), paths ? cdiv(ng, 256) : 1), dim3(256), 0, st, ctx->model, ta);
@@ -1739,8 +1767,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.sin_u1 = p->sin_u1; ia.cos_u1 = p->cos_u1; ia.lon1 = p->radar_lon;
     ia.site = t->site ? (const double *)ctx->v_site : nullptr;
     ia.exact_sub = (p->debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS) ? 1 : 0;
-    ia.poly = geo_poly ? (const double *)ctx->b_poly.p : nullptr;
-    ia.poly_scale = geo_poly ? 2.0 / ((p->range0 + (double)(ng - 1) * p->range_step) * 1.001) : 0.0;
+    // (the one sub-beam of a single-beam sweep: the polynomials of its table set, unless its float64 coordinates are outputs)
+    const bool poly_central = poly_single && !user_out[O_LAT] && !user_out[O_LON];       // (nobody reads the library's own copies)
+    if (poly_central && !ctx->keep_debug) ia.lats = ia.lons = nullptr;
+    ia.poly = geo_poly ? (const double *)ctx->b_poly.p : poly_central ? (const double *)set->poly.p : nullptr;
+    ia.poly_scale = (geo_poly || poly_central) ? geo_poly_scale : 0.0;
+    ia.poly_central = poly_central ? 1 : 0;
+    ctx->last_poly_central = ia.poly_central;
     if (!fused && !fused_gate1)
     hipLaunchKernelGGL(k_interp_sweep, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256), 0, st,
                        ctx->model, ia);
@@ -2352,7 +2385,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                          ctx->b_res.p, ctx->b_vn.p, ctx->b_icefirst.p, ctx->b_wgate.p, ctx->b_blkranked.p, ctx->b_rec.p,
                          ctx->b_vmask.p, ctx->b_rayc.p, ctx->v_traj_in, ctx->v_geo, ctx->v_subh,
                          ctx->v_subv, ctx->v_subw, ctx->v_sens, ctx->v_site, ctx->v_nyq,
-                         ctx->v_subsmooth, ctx->v_mlfilter, (void *)st};
+                         ctx->v_subsmooth, ctx->v_mlfilter, (void *)st, poly_single ? set->poly.p : nullptr};
         mix(arena, sizeof arena);
         hipGraphExec_t &gexec = ctx->graph_exec[par];
         if (!gexec || ctx->graph_key[par] != key) {
@@ -2525,6 +2558,11 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     if (!strcmp(name, "enable")) { ctx->keep_debug = true; return 0; }
     if (!strcmp(name, "disable")) { ctx->keep_debug = false; return 0; }
     if (!strcmp(name, "fail_next_sweep")) { ctx->fail_next = true; return 0; }
+    if (!strcmp(name, "poly_central")) {
+        if (!dst || max_bytes < (int64_t)sizeof(int)) return CPOL_ERR_ARG;
+        memcpy(dst, &ctx->last_poly_central, sizeof(int));
+        return (int64_t)sizeof(int);
+    }
     if (!strcmp(name, "host_times")) {
         // host time of cpol_run_sweep by section since the last read (see cpol_ctx::host_ns); reading resets
         if (!dst || max_bytes < (int64_t)sizeof ctx->host_ns) return CPOL_ERR_ARG;

@@ -476,6 +476,7 @@ struct InterpArgs {
     int exact_sub;              // debug (cpol_sweep_params.debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS): every sub-beam takes the central one's long form
     const double *poly;         // k_trajectory's coordinate polynomials [n_rays * n_h][2][CPOL_GEO_NP] or NULL
     double poly_scale;          // x = s * poly_scale - 1
+    int poly_central;           // the central sub-beam takes the polynomials too (its float64 latitude / longitude are not asked for)
 };
 
 #ifndef CPOL_RAY_PREP_MIN_SUB
@@ -597,9 +598,11 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     float rlon, rlat;
     double lat_deg = 0.0, lon_deg = 0.0;
     // (wave-uniform: a wavefront walks ONE sub-beam; exact_sub is a kernel argument)
-    const bool short_form = sub != a.central_sub && !a.exact_sub;
-    if (short_form && a.poly) {
-        // ---- non-central sub-beam: the rotated coordinates from the (ray, horizontal node)'s polynomials (k_trajectory) ----
+    const bool use_poly = a.poly && (sub != a.central_sub || a.poly_central) && !a.exact_sub;
+    const bool short_form = sub != a.central_sub && !a.exact_sub && !a.poly;      // (the closed short form of round 4: CPOL_GEO_POLY=0)
+    bool long_form = !use_poly;
+    if (use_poly) {
+        // ---- the rotated coordinates from the (ray, horizontal node)'s polynomials (k_trajectory / k_geo_poly) ----
         constexpr int NP = CPOL_GEO_NP;
         const double *pc = a.poly + (long)(ray * a.n_h + ih) * (2 * NP);          // (wave-uniform: scalar loads)
         const double x = fma((double)s32, a.poly_scale, -1.0);
@@ -611,7 +614,21 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
         }
         rlat = (float)la;
         rlon = (float)lo;
-    } else {
+        // GUARD: the polynomials follow the long form to ~2e-13 deg (degree 8 through 9 Chebyshev nodes over 0.024 rad of arc;
+        // float32 ulp at 3 deg: 2.4e-7), so the two float32 coordinates are the same number or neighbours.  If the coordinate's
+        // neighbours on both sides (c -/+ 1..2 ulp) fall into the SAME cell of the model grid and inside the domain -- the
+        // reference's own float32 expressions, monotonic in c -- the cell index, the domain check and the corner columns are
+        // the long form's whatever it rounds to; only the weights inside the cell can move (by <= 1 ulp of the cell
+        // coordinate, in ~6e-7 of the gates: profiles/r5_fast_sub_check.json).  Otherwise (one gate in ~5 000) the gate takes
+        // the long form after all: index work is the long form's by construction.
+        auto spans = [](float c, float llc, float urc, float res) {
+            const float d = fmaxf(fabsf(c), 1.0e-30f) * 1.1920929e-7f;              // 2^-23 |c|: between 1 and 2 ulps of c
+            const float lo = c - d, hi = c + d;
+            return floorf((lo - llc) / res) != floorf((hi - llc) / res) || !(lo >= llc) || !(hi <= urc);   // (NaN: true)
+        };
+        long_form = spans(rlat, m.llc1, m.urc1, m.res1) || spans(rlon, m.llc0, m.urc0, m.res0);
+    }
+    if (long_form) {
     const double sin_u1 = a.site ? a.site[(long)ray * 8 + 0] : a.sin_u1;
     const double cos_u1 = a.site ? a.site[(long)ray * 8 + 1] : a.cos_u1;
     const double lon1 = a.site ? a.site[(long)ray * 8 + 2] : a.lon1;

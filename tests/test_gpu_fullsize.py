@@ -435,3 +435,51 @@ def test_short_form_of_the_subbeam_geodesy_keeps_every_cell_index():
         n += r['n_coordinates']
     assert n > 4.0e6
     op.close()
+
+
+def test_single_beam_sweep_on_the_coordinate_polynomials_keeps_every_cell_index(monkeypatch):
+    """A single-beam sweep whose float64 latitude / longitude nobody asks for (device outputs of the radar fields: bench.py's
+    c2 / c3 steps) takes the rotated coordinates of its ONE sub-beam from the polynomials of its table set too (round 5), behind
+    a guard: a gate whose float32 coordinate has a neighbour (1-2 ulp) in another model cell or outside the domain takes the
+    long form after all -- the cell indices, the domain check and the masks are the long form's BY CONSTRUCTION, only the
+    weights inside a cell may move by an ulp of the cell coordinate in a few gates per ten million.  Here: 8 sweeps of
+    360 x 500 gates both ways (CPOL_GEO_POLY_CENTRAL=2 keeps the polynomials under the debug reads; debug_flags =
+    CPOL_DEBUG_EXACT_SUBBEAMS is the long form); the record of 40 sweeps (14.4 M coordinates: 6 differ, 0 cells, 0 masks,
+    0 model values, 0 outputs) is profiles/r5_central_poly_check.json (tools/fast_sub_check.py --config c3)."""
+    import importlib.util
+    import os
+    from cosmo_pol_amd import RadarOperator
+    monkeypatch.setenv('CPOL_GEO_POLY_CENTRAL', '2')
+    spec = importlib.util.spec_from_file_location(
+        'fast_sub_check', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fast_sub_check.py'))
+    fsc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fsc)
+    fsc.DEVICE_OUTPUTS = True
+    over = bench.bench_config(False, 'c3')
+    hyds = list(bench.hydrometeors_of('c3'))
+    cube = synthetic.make_cube(hydrometeors=('R', 'S', 'G', 'I'), **synthetic.BENCH_GRID)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar', lanes=1)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    az = np.arange(0.0, 360.0, 1.0)
+    n = 0
+    for e in (0.5, 1.0, 2.0, 3.0, 5.0, 8.0, 12.0, 20.0):
+        r = fsc.compare_sweep(op, az, np.full(len(az), e))
+        assert r['n_subbeam_gates'] == 360 * 500
+        assert r['b_cells_that_differ'] == 0 and r['b_masks_that_differ'] == 0 and r['c_nan_pattern_differs'] == 0, r
+        assert r['a_max_ulp'] <= 8 and r['a_coordinates_that_differ'] <= 1e-5 * r['n_coordinates'], r
+        assert max(r['c_worst_relative_change_of_an_output'].values()) < 1e-5, r
+        n += r['n_coordinates']
+    assert n == 8 * 360 * 500 * 2
+    # ... and the polynomials WERE what the default form took (the last sweep of compare_sweep is the long form: run one more)
+    import torch
+    ng = len(op.constants.RANGE_RADAR)
+    slab = torch.empty((len(bench.RADAR_FIELDS), len(az), ng), dtype=torch.float32, device='cuda')
+    ptrs = {k: slab[i].data_ptr() for i, k in enumerate(bench.RADAR_FIELDS)}
+    op.simulate_rays(az, np.full(len(az), 3.0), device_outputs=ptrs)
+    op.wait()
+    assert int(op._ctx.debug_read('poly_central', (1,), np.int32)[0]) == 1
+    res = op.simulate_rays(az[:8], np.full(8, 3.0))              # host outputs ask for latitude / longitude: the long form
+    assert int(op._ctx.debug_read('poly_central', (1,), np.int32)[0]) == 0
+    assert np.isfinite(res['lats']).all() if 'lats' in res else True
+    op.close()

@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V', 'RVEL']
+DEVICE_OUTPUTS = False          # --config c2 / c3: see compare_sweep
 
 
 def cell_index(coords, llc, res):
@@ -55,7 +56,27 @@ def compare_sweep(op, az, el):
              'mask': op._ctx.debug_read('sub_mask', (n_sbg,), np.int8),
              'vals': op._ctx.debug_read('sub_values', (n_vars, n_sbg), np.float32)}
         op._ctx.enable_debug(False)
-        d['out'] = {k: v.copy() for k, v in op.simulate_rays(az, el).items() if k in FIELDS or k == 'mask'}
+        if DEVICE_OUTPUTS:
+            # a single-beam sweep takes the polynomials only when nobody asks for its float64 latitude / longitude: results into
+            # a device slab, as bench.py's c2 step does (the nine float32 fields)
+            import torch
+            import bench
+            ng = len(op.constants.RANGE_RADAR)
+            slab = torch.full((len(bench.RADAR_FIELDS), len(az), ng), float('nan'), dtype=torch.float32, device='cuda')
+            op._ctx.enable_debug(True)
+            op.simulate_rays(az, el, device_outputs={k: slab[i].data_ptr() for i, k in enumerate(bench.RADAR_FIELDS)})
+            op.wait()
+            d['coords'] = op._ctx.debug_read('sub_coords', (n_sbg, 2), np.float32)
+            d['mask'] = op._ctx.debug_read('sub_mask', (n_sbg,), np.int8)
+            d['vals'] = op._ctx.debug_read('sub_values', (n_vars, n_sbg), np.float32)
+            op._ctx.enable_debug(False)
+            op.simulate_rays(az, el, device_outputs={k: slab[i].data_ptr() for i, k in enumerate(bench.RADAR_FIELDS)})
+            op.wait()
+            host = slab.cpu().numpy()
+            d['out'] = {k: host[i].copy() for i, k in enumerate(bench.RADAR_FIELDS)}
+            d['out']['mask'] = d['mask'].copy()
+        else:
+            d['out'] = {k: v.copy() for k, v in op.simulate_rays(az, el).items() if k in FIELDS or k == 'mask'}
         got[form] = d
     op.debug_flags = 0
     s, l = got['short'], got['long']
@@ -77,6 +98,9 @@ def compare_sweep(op, az, el):
     worst_val = float(rel.max()) if rel.size else 0.0
     out_worst, out_diff = {}, {}
     for k in FIELDS:
+        if k not in s['out']:
+            out_diff[k], out_worst[k] = 0, 0.0
+            continue
         a, b = s['out'][k].astype(np.float64), l['out'][k].astype(np.float64)
         fin = np.isfinite(a) & np.isfinite(b)
         out_diff[k] = int(np.sum(a[fin] != b[fin])) + int(np.sum(np.isnan(a) != np.isnan(b)))
@@ -96,17 +120,23 @@ def main():
     ap.add_argument('--rays', type=int, default=360)
     ap.add_argument('--elevations', type=float, nargs='*', default=[0.5, 1.5, 3.0, 5.0, 8.0])
     ap.add_argument('--small', action='store_true')
+    ap.add_argument('--config', default='c4', help="c4: 49 sub-beams (the non-central ones); c2 / c3: ONE sub-beam -- the polynomials of a "
+                    "single-beam sweep's table set against the long form (CPOL_GEO_POLY_CENTRAL=2 keeps them under the debug reads)")
     ap.add_argument('--out', default=None)
     args = ap.parse_args()
+    if args.config != 'c4':
+        os.environ['CPOL_GEO_POLY_CENTRAL'] = '2'
+        global DEVICE_OUTPUTS
+        DEVICE_OUTPUTS = True
     import bench
     from cosmo_pol_amd import RadarOperator, synthetic
-    conf = bench.bench_config(args.small, 'c4')
-    hyds = list(bench.hydrometeors_of('c4'))
+    conf = bench.bench_config(args.small, args.config)
+    hyds = list(bench.hydrometeors_of(args.config))
     if args.small:
         cube = synthetic.small_test_cube(hydrometeors=('R', 'S', 'G', 'I'))
         luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
     else:
-        cube = synthetic.make_cube(hydrometeors=('R', 'S', 'G', 'I'), **synthetic.BENCH_GRID)
+        cube = synthetic.make_cube(hydrometeors=tuple(h for h in hyds if h in 'RSGI'), **synthetic.BENCH_GRID)
         luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
     op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
     op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
@@ -130,7 +160,8 @@ def main():
     tot['c_worst_relative_change_of_an_output'] = {k: max(r['c_worst_relative_change_of_an_output'][k] for r in per_el) for k in FIELDS}
     tot['c_output_gates_that_differ'] = {k: sum(r['c_output_gates_that_differ'][k] for r in per_el) for k in FIELDS}
     rec = {'what': 'short form of the sub-beam geodesy (default) against the long form (debug_flags = CPOL_DEBUG_EXACT_SUBBEAMS) '
-                   'on the device: c4 configuration, %d rays x %d elevations x 49 sub-beams x 500 gates' % (len(az), len(args.elevations)),
+                   'on the device: %s configuration, %d rays x %d elevations x %s x 500 gates' % (args.config, len(az), len(args.elevations),
+                   '49 sub-beams' if args.config == 'c4' else 'ONE sub-beam (the polynomials of the sweep\'s table set)'),
            'total': tot, 'per_elevation': per_el}
     text = json.dumps(rec, indent=1)
     if args.out:
