@@ -153,7 +153,8 @@ struct cpol_ctx {
     int rare_direct = 1;               // CPOL_RARE_DIRECT=0: keep the counting sort of the items outside the tables (read when the context is created)
     int lookup_list = 1;               // CPOL_LOOKUP_LIST=0: k_psd_lookup starts one wavefront per tile instead of workgroups that list the tiles with work among their own; 2: the list for every launch size
     int lookup_split = 0;              // CPOL_LOOKUP_SPLIT=<n>: wavefronts per tile of k_psd_lookup (0: by launch size)
-    int gate1_ray = 0;                 // CPOL_GATE1_RAY=1: k_gate1_ray (items off the tables integrated in place, the range scans by k_scan_rays: a single-beam sweep
+    int gate1_ray = -1;                // -1 (default): 1 in a context with lanes (sweeps in flight side by side: three launches instead of four per sweep are 6-8 % of
+                                       // c2's throughput), 0 without (the isolated sweep: 88 against 91 us); CPOL_GATE1_RAY=0: never; 1: k_gate1_ray (items off the tables integrated in place, the range scans by k_scan_rays: a single-beam sweep
                                        // of three lean launches, no integrating launch); 2: also with tables that lost panels; 3: the scans inside the gate kernel (a ticket per ray)
     int gate1_species = 1;             // CPOL_GATE1_SPECIES=0 / 2: never / always k_gate1_species (one wavefront per species; default: small launches)
     int fuse_gate1 = 0;                // CPOL_FUSE_GATE1=1: k_interp_gate1 instead of k_interp_sweep + k_gate1 (measured slower where it matters)
@@ -625,7 +626,7 @@ int cpol_create(int device, cpol_ctx **out)
     if (getenv("CPOL_LOOKUP_LIST")) ctx->lookup_list = std::max(0, std::min(2, atoi(getenv("CPOL_LOOKUP_LIST"))));
     if (getenv("CPOL_LOOKUP_SPLIT")) ctx->lookup_split = std::max(0, std::min(16, atoi(getenv("CPOL_LOOKUP_SPLIT"))));
     if (getenv("CPOL_GATE1_SPECIES")) ctx->gate1_species = std::max(0, std::min(2, atoi(getenv("CPOL_GATE1_SPECIES"))));
-    if (getenv("CPOL_GATE1_RAY")) ctx->gate1_ray = std::max(0, std::min(3, atoi(getenv("CPOL_GATE1_RAY"))));   // (2: also with tables that lost panels; 3: the scans inside the gate kernel)
+    if (getenv("CPOL_GATE1_RAY")) ctx->gate1_ray = std::max(-1, std::min(3, atoi(getenv("CPOL_GATE1_RAY"))));   // (2: also with tables that lost panels; 3: the scans inside the gate kernel)
     if (getenv("CPOL_FUSE_GATE1")) ctx->fuse_gate1 = atoi(getenv("CPOL_FUSE_GATE1")) != 0 ? 1 : 0;
     if (getenv("CPOL_FUSE_CLASSIFY")) ctx->fuse_classify = atoi(getenv("CPOL_FUSE_CLASSIFY")) != 0 ? 1 : 0;
     if (getenv("CPOL_RARE_OVERLAP")) ctx->rare_overlap = atoi(getenv("CPOL_RARE_OVERLAP")) != 0 ? 1 : 0;
@@ -1605,18 +1606,20 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // integrating kernels: gamma-family species without Doppler-scheme-2 sums and without per-ray fall-speed totals
     // (numeric_intv), whose tables kept all panels but the tail (an item off the table costs a wavefront ~10 000 cycles:
     // fine for the handful a volume has, not for a table that lost half of its panels to the accuracy gate).
-    bool gate1_ray = gate1 && ctx->gate1_ray && !ctx->fuse_gate1 && !p->with_melting && !dop2 && n_rays <= 65535;
+    const int g1r = ctx->gate1_ray >= 0 ? ctx->gate1_ray
+                  : ((ctx->parent ? ctx->parent->n_children : ctx->n_children) >= 2 ? 1 : 0);
+    bool gate1_ray = gate1 && g1r && !ctx->fuse_gate1 && !p->with_melting && !dop2 && n_rays <= 65535;
     for (int j = 0; j < n_hyd && gate1_ray; ++j) {
         const cpol_hydro_desc &d = ctx->hs.h[j].d;
         const ItabDev &tj = ctx->its.t[j];
         gate1_ray = d.psd_family == CPOL_PSD_GAMMA && !d.numeric_intv && d.q_source == CPOL_Q_MODEL && tj.tab && !tj.two_d &&
-                    ((tj.pan_lo == 0 && tj.pan_hi >= tj.n_pan - 2) || ctx->gate1_ray >= 2) && ctx->hs.h[j].pre && ctx->hs.h[j].dnu;
+                    ((tj.pan_lo == 0 && tj.pan_hi >= tj.n_pan - 2) || g1r >= 2) && ctx->hs.h[j].pre && ctx->hs.h[j].dnu;
     }
     {
         const long g1_waves = n_rg * n_hyd / 64 / 1024;
         gate1_ray = gate1_ray && (ctx->gate1_species == 2 || (ctx->gate1_species == 1 && g1_waves < 48));
     }
-    if (gate1_ray && ctx->gate1_ray == 3) {
+    if (gate1_ray && g1r == 3) {
         void *const was = ctx->b_ticket.p;
         ENSURE(ctx->b_ticket, (size_t)n_rays * sizeof(int));
         if (ctx->b_ticket.p != was || was_dirty)                 // (the kernel leaves every ticket at 0 behind it)
@@ -1961,7 +1964,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             rr.radial_res = (float)p->radial_res;
             const size_t lds_terms = (size_t)n_hyd * 64 * GATE1S_BYTES, lds_scan = (size_t)3 * ng * sizeof(float);
             const dim3 rgrid((unsigned)cdiv(ng, 64), (unsigned)n_rays);
-            if (ctx->gate1_ray == 3) {
+            if (g1r == 3) {
                 hipLaunchKernelGGL(k_gate1_ray_scan, rgrid, dim3(64 * n_hyd), lds_terms > lds_scan ? lds_terms : lds_scan, st,
                                    ctx->hs, ctx->its, ca, fa, ga, rr);
             } else {
