@@ -877,10 +877,11 @@ def run_c2(env):
         'roofline': roof,
         'stages_ms': {'interp': iso.ms_interp, 'classify': iso.ms_classify,
                       'bucket': iso.ms_bucket, 'psd': iso.ms_psd, 'final': iso.ms_final,
-                      'device_total': iso.ms_total, 'launches_per_sweep': 4,
+                      'device_total': iso.ms_total, 'launches_per_sweep': 3,
                       'note': 'one sweep at a time on one lane, HIP events around every stage (the pass after the timed '
-                              'region); single-beam fast path: k_interp_sweep, k_gate1 (`classify`), one idle '
-                              'integrating kernel (`psd`), k_final (range scans); `bucket` holds no kernel'},
+                              'region); single-beam fast path of a context with lanes: k_interp_sweep, k_gate1_ray '
+                              '(`classify`: items outside the tables integrated in place, no integrating launch), '
+                              'k_scan_rays (`final`: range scans); `bucket` and `psd` hold no kernel'},
         'counters': {'n_subbeam_gates': n_sbg, 'n_valid_items': n_valid,
                      'n_work_units': int(iso.n_work_units), 'n_table_items': int(iso.n_table_items)},
         'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
