@@ -1059,6 +1059,72 @@ __device__ __forceinline__ void psd_body(const HydroSet &hs, const PsdArgs &a, d
             double F1 = exp(-(a1 * dn0)), F2 = exp(-(a2 * dn0));
             const double r1 = exp(-(a1 * hd[0])), r2 = exp(-(a2 * hd[0]));
             const double s1 = exp(-(a1 * hd[1])), s2 = exp(-(a2 * hd[1]));
+            if (count == 1) {
+                // ONE item in the unit (an item listed directly, k_psd_rare: 68 of the 75 us of that kernel on a C4 volume were
+                // one ice-crystal item walking its bins on one lane).  32 bins at a time: every lane walks the four geometric
+                // recurrences (their roundings are part of the result) and lane q keeps the values of bin kb + q, forms the
+                // bin's two PHI_23 factors with the statements of the loop below and lays the bin's table row, Doppler weights
+                // and normalisation terms down in LDS; then lane c sums COLUMN c over the bins in the loop's order (0..11 the
+                // table columns, 12 / 13 the sums of Doppler scheme 2, 14 the mass integral, 15 / 16 the fall-speed sums) --
+                // the same values, the same order, the same bits; the sums go back to the item's lane at the end.
+                constexpr int CH = 32, SW = CPOL_N_SZ + 5;
+                static_assert(CPOL_PSD_WAVES * CH * SW <= NSLOT * NV * CPOL_WAVE, "staging area of the single-item path: the LDS of k_psd<ICE>");
+                double *stage = lds_raw + (long)wave * (CH * SW);
+                const long sl0 = (long)(key - h.key_base) * n_d;
+                const double a1u = readlane_f64(a1, 0), a2u = readlane_f64(a2, 0), Bu = readlane_f64(B, 0);
+                const double a1su = readlane_f64(a1s, 0), a1cu = readlane_f64(a1c, 0), a2su = readlane_f64(a2s, 0), a2cu = readlane_f64(a2c, 0);
+                double E1u = readlane_f64(E1, 0), E2u = readlane_f64(E2, 0), F1u = readlane_f64(F1, 0), F2u = readlane_f64(F2, 0);
+                const double r1u = readlane_f64(r1, 0), r2u = readlane_f64(r2, 0), s1u = readlane_f64(s1, 0), s2u = readlane_f64(s2, 0);
+                const bool col = lane < SW;
+                double acc_l = 0.0;
+                for (int kb = k0; kb < k1; kb += CH) {
+                    const int nq = min(CH, k1 - kb);
+                    double E1_l = 0.0, E2_l = 0.0, F1_l = 0.0, F2_l = 0.0;
+                    for (int q = 0; q < nq; ++q) {
+                        if (lane == q) { E1_l = E1u; E2_l = E2u; F1_l = F1u; F2_l = F2u; }
+                        F1u *= s1u;
+                        F2u *= s2u;
+                        E1u *= r1u;
+                        E2u *= r2u;
+                    }
+                    double ph_l = 0.0, phn_l = 0.0;
+                    if (lane < nq) {
+                        const int k = kb + lane;
+                        const double pwn = qn[4 * k], adb = qn[4 * k + 1], vk = qn[4 * k + 2];
+                        const double x1 = a1u * qn[4 * k + 3], x2 = a2u * qn[4 * k + 3];
+                        const double g1 = fma(x1, fma(x1, fma(x1, -1.0 / 6.0, 0.5), -1.0), 1.0);
+                        const double g2 = fma(x2, fma(x2, fma(x2, -1.0 / 6.0, 0.5), -1.0), 1.0);
+                        phn_l = fma(Bu * pwn, F2_l * g2, 490.6 * (F1_l * g1));
+                        const double d1 = ql[4 * k], d2 = ql[4 * k + 1], d3 = ql[4 * k + 2], pw = ql[4 * k + 3];
+                        const double c1 = fma(-a1u, d1, fma(a1su, d2, fma(-a1cu, d3, 1.0)));
+                        const double c2 = fma(-a2u, d1, fma(a2su, d2, fma(-a2cu, d3, 1.0)));
+                        ph_l = fma(Bu * pw, E2_l * c2, 490.6 * (E1_l * c1));
+                        const double *rowv = h.table + (sl0 + k) * CPOL_N_SZ;
+#pragma unroll
+                        for (int c = 0; c < CPOL_N_SZ; ++c) stage[lane * SW + c] = rowv[c];
+                        stage[lane * SW + CPOL_N_SZ] = DOP2 ? h.rcsw[(sl0 + k) * 2] : 0.0;
+                        stage[lane * SW + CPOL_N_SZ + 1] = DOP2 ? h.rcsw[(sl0 + k) * 2 + 1] : 0.0;
+                        stage[lane * SW + CPOL_N_SZ + 2] = adb;
+                        stage[lane * SW + CPOL_N_SZ + 3] = vk;
+                        stage[lane * SW + CPOL_N_SZ + 4] = 1.0;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+                    for (int q = 0; q < nq; ++q) {
+                        const double ph = readlane_f64(ph_l, q), phn = readlane_f64(phn_l, q);
+                        const double fct = lane < CPOL_N_SZ + 2 ? ph : phn;
+                        const double x = col ? stage[q * SW + lane] : 0.0;
+                        acc_l = fma(x, fct, acc_l);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                __syncthreads();                                         // (the partial sums below take the same LDS)
+#pragma unroll
+                for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = readlane_f64(acc_l, c);
+                msum = readlane_f64(acc_l, CPOL_N_SZ + 2);
+                if (DOP2) { vsum = readlane_f64(acc_l, CPOL_N_SZ); nsum = readlane_f64(acc_l, CPOL_N_SZ + 1); }
+                else { vsum = readlane_f64(acc_l, CPOL_N_SZ + 3); nsum = readlane_f64(acc_l, CPOL_N_SZ + 4); }
+            } else
 #pragma unroll 2
             for (int k = k0; k < k1; ++k) {
                 const double pwn = qn[4 * k], adb = qn[4 * k + 1], vk = qn[4 * k + 2];
