@@ -1442,7 +1442,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // single-beam sweeps (round 5): the one sub-beam takes the polynomials too when its float64 latitude / longitude are not
     // outputs; they belong to the resident table set of the rays and are made once per (version, range grid)
     const bool poly_single = !ray_prep && ctx->geo_poly && ctx->geo_poly_central && mode == CPOL_GEOM_GROUND_43 && !t->site &&
-                             (!ctx->keep_debug || ctx->geo_poly_central == 2) && t->version != 0 && !(p->debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS);
+                             (!ctx->keep_debug || ctx->geo_poly_central == 2) && t->version != 0 && !(p->debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS) &&
+                             !out->lats && !out->lons;        // (their float64 values come from the long form: nothing to prepare then)
     // arc distance <= slant range; a margin of 1e-3 for the asin of the 4/3-earth formula
     const double geo_poly_scale = 2.0 / ((p->range0 + (double)(ng - 1) * p->range_step) * 1.001);
     if (geo_poly || poly_single) {
