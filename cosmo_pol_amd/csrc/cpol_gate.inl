@@ -366,81 +366,80 @@ __global__ __launch_bounds__(CPOL_GATE1_THREADS) CPOL_GATE1_ATTR void k_interp_g
 #define CPOL_GATE1S_ATTR
 #endif
 // ---- an item outside its integral table, integrated by the wavefront that meets it (k_gate1_ray) ----
-// Lanes 0..7 of the wavefront play the eight wavefronts of the integrating kernels' workgroup (psd_body): lane w sums the
-// diameter bins [w * chunk, (w + 1) * chunk) of the item with the same statements in the same order -- GAMMA_UNIFORM:
-// exp(-lambda D_k) by the geometric recurrence from one exp at the chunk start, the partial sums joined by the tree
-// ((w0+w4)+(w2+w6)) + ((w1+w5)+(w3+w7)); GAMMA_EXP: one exp per bin, the partial sums added in wave order -- so that the
-// 12 columns are the bits k_psd_uniform / k_psd<GAMMA_EXP> leave in res[] (tests/test_gpu_edges.py compares the launch
-// sequences bit for bit).  Items outside the tables are a handful per volume (lambda beyond the last panel: a mass
-// density of 1e-17 kg m-3), ~10 000 cycles of one wavefront each; the host takes this path only when every slot is a
-// gamma-family species without Doppler-scheme-2 sums whose table kept (all but the tail of) its panels.
-// `lam`, `n0`, `slice_index`: wave-uniform.  Lane 0 leaves the 12 columns (x dD) in out[] (LDS).
-// (not inlined: the rare path must not cost the common one its registers -- inlined, the kernel needs 131 VGPRs and
-// 3 wavefronts per SIMD instead of 105 / 4)
-#ifndef CPOL_RARE_INLINE
-#define CPOL_RARE_INLINE 0
-#endif
-#if CPOL_RARE_INLINE
-#define CPOL_RARE_ATTR __forceinline__
-#else
-#define CPOL_RARE_ATTR __attribute__((noinline))
-#endif
-__device__ CPOL_RARE_ATTR void integrate_gamma_item_wave(const double *table, const double *pre, const double *dnu, const double *aux,
-                                                                    int n_d, int uniform_grid, double dD, int slice_index,
-                                                                    double lam, double n0, double *out /* LDS, [CPOL_N_SZ] */)
+// The wavefront plays the integrating kernels' workgroup (psd_body): its eight wavefronts each sum a chunk of the diameter
+// bins, column by column.  Here lane (w, c) = (chunk, column) sums column c over the bins of chunk w -- 4 chunks x 12
+// columns at a time, two passes -- with the same statements in the same order (GAMMA_UNIFORM: exp(-lambda D_k) by the
+// geometric recurrence from one exp at the chunk start; GAMMA_EXP: one exp per bin), and the eight partial sums of a column
+// are joined as there: ((w0+w4)+(w2+w6)) + ((w1+w5)+(w3+w7)), resp. in wave order -- the 12 columns are the bits
+// k_psd_uniform / k_psd<GAMMA_EXP> leave in res[] (tests/test_gpu_edges.py compares the launch sequences bit for bit).
+// One accumulator per lane: the function is inlined and costs the kernel no register it does not have anyway, and no
+// call.  (Round 5, first form: lanes 0..7 = the chunks with 12 accumulators each, behind a real call -- 126 VGPRs instead of
+// 97, and a kernel that calls sets up a stack: c2 with three sweeps side by side ran 11 % slower for a path that is never
+// taken there, 4.69-4.84 against 5.30e9 gates/s.)  Items outside the tables are a handful per volume (lambda beyond the
+// last panel: a mass density of 1e-17 kg m-3), ~40 us of one wavefront each; the host takes this path only when every slot
+// is a gamma-family species without Doppler-scheme-2 sums whose table kept (all but the tail of) its panels.
+// `lam`, `n0`, `slice_index`: wave-uniform.  The 12 columns (x dD) are left in out[] (LDS).
+__device__ __forceinline__ void integrate_gamma_item_wave(const double *table, const double *pre, const double *dnu, const double *aux,
+                                                          int n_d, int uniform_grid, double dD, int slice_index,
+                                                          double lam, double n0, double *out /* LDS, [CPOL_N_SZ] */)
 {
     const int lane = lane_id();
     constexpr int NW = 8;                                  // CPOL_PSD_WAVES = CPOL_PSD_WAVES_U = 8 chunks
     static_assert(CPOL_PSD_WAVES == 8 && CPOL_PSD_WAVES_U == 8, "integrate_gamma_item_wave mirrors the 8-wave split of psd_body");
+    static_assert(4 * CPOL_N_SZ <= CPOL_WAVE, "four chunks x 12 columns per pass");
     const int chunk = (n_d + NW - 1) / NW;
-    const int w = lane < NW ? lane : NW - 1;
-    const int k0 = w * chunk, k1 = lane < NW ? min(k0 + chunk, n_d) : k0;      // (lanes 8..63: empty range)
+    const int wl = lane / CPOL_N_SZ, c = lane - wl * CPOL_N_SZ;         // chunk of the pass (0..3; 4, 5: idle lanes), column
+    const bool on = wl < 4;
     const double *slice = table + (long)slice_index * n_d * CPOL_N_SZ;
-    double acc[CPOL_N_SZ];
-#pragma unroll
-    for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = 0.0;
+    double part[2];                                        // column c over chunk wl (pass 0) and wl + 4 (pass 1)
     if (uniform_grid) {
-        // (psd_body, PSD_MODE_GAMMA_UNIFORM, item 0 of the lane)
+        // (psd_body, PSD_MODE_GAMMA_UNIFORM)
         const double hstep = aux[0];
-        const double d0 = dnu[k0 < n_d ? k0 : 0];
-        double A0 = n0 * exp(-(lam * d0));
         const double r0 = exp(-(lam * hstep));
-        const double *pq = aux + 1 + n_d;                   // [k][4] = (pre, q1, q2, .)
+        const double *pq = aux + 1 + n_d;                       // [k][4] = (pre, q1, q2, .)
 #pragma unroll 1
-        for (int k = k0; k < k1; ++k) {
-            const double pk = pq[4 * k], q1 = pq[4 * k + 1], q2 = pq[4 * k + 2];
-            const double nk = A0 * fma(lam, fma(lam, q2, -q1), pk);
-            A0 *= r0;
-            const double *row = slice + (long)k * CPOL_N_SZ;
-#pragma unroll
-            for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
-        }
-        // the tree of the kernel: (w += w + 4), (w += w + 2), (w0 += w1)
-#pragma unroll
-        for (int c = 0; c < CPOL_N_SZ; ++c) {
-            double x = acc[c];
-            x += shfl_f64(x, (lane + 4) & 63);
-            x += shfl_f64(x, (lane + 2) & 63);
-            x += shfl_f64(x, (lane + 1) & 63);
-            if (lane == 0) out[c] = x * dD;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int w = (on ? wl : 0) + 4 * pass;
+            const int k0 = w * chunk, k1 = on ? min(k0 + chunk, n_d) : k0;
+            double A0 = n0 * exp(-(lam * dnu[k0 < n_d ? k0 : 0]));
+            double acc = 0.0;
+#pragma unroll 1
+            for (int k = k0; k < k1; ++k) {
+                const double pk = pq[4 * k], q1 = pq[4 * k + 1], q2 = pq[4 * k + 2];
+                const double nk = A0 * fma(lam, fma(lam, q2, -q1), pk);
+                A0 *= r0;
+                acc = fma(slice[(long)k * CPOL_N_SZ + c], nk, acc);
+            }
+            if (pass == 0) part[0] = acc; else part[1] = acc;
         }
     } else {
         // (psd_body, PSD_MODE_GAMMA_EXP)
 #pragma unroll 1
-        for (int k = k0; k < k1; ++k) {
-            const double nk = (n0 * pre[k]) * exp(-(lam * dnu[k]));
-            const double *row = slice + (long)k * CPOL_N_SZ;
-#pragma unroll
-            for (int c = 0; c < CPOL_N_SZ; ++c) acc[c] = fma(row[c], nk, acc[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < CPOL_N_SZ; ++c) {
-            double sum = 0.0;
-#pragma unroll
-            for (int q = 0; q < NW; ++q) sum += readlane_f64(acc[c], q);
-            if (lane == 0) out[c] = sum * dD;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int w = (on ? wl : 0) + 4 * pass;
+            const int k0 = w * chunk, k1 = on ? min(k0 + chunk, n_d) : k0;
+            double acc = 0.0;
+#pragma unroll 1
+            for (int k = k0; k < k1; ++k) {
+                const double nk = (n0 * pre[k]) * exp(-(lam * dnu[k]));
+                acc = fma(slice[(long)k * CPOL_N_SZ + c], nk, acc);
+            }
+            if (pass == 0) part[0] = acc; else part[1] = acc;
         }
     }
+    double x;
+    if (uniform_grid) {
+        // the tree of the kernel: (w += w + 4), (w += w + 2), (w0 += w1)
+        x = part[0] + part[1];
+        x += shfl_f64(x, (lane + 2 * CPOL_N_SZ) & 63);
+        x += shfl_f64(x, (lane + CPOL_N_SZ) & 63);
+    } else {
+        // wave order: ((((((w0 + w1) + w2) + w3) + w4) + w5) + w6) + w7, from 0.0
+        x = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) x += shfl_f64(part[q >> 2], ((q & 3) * CPOL_N_SZ + c) & 63);
+    }
+    if (lane < CPOL_N_SZ) out[lane] = x * dD;
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -519,26 +518,7 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
     int my_lookup = it.lookup ? 1 : 0;
     bool off_table = it.valid && !it.lookup;
     if (RAY) {
-        // ---- items outside the integral table: integrated here, one after the other (rare) ----
-        unsigned long long todo = __ballot(off_table);
-        if (todo && lane == 0) {                                  // (cpol_counters: items integrated bin by bin, one "unit" each)
-            atomicAdd(g.totals, (unsigned long long)__popcll(todo));
-            atomicAdd(g.totals + 1, (unsigned long long)__popcll(todo));
-        }
-        while (todo) {
-            const int l = (int)__ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            double *col = s_mv + j * 64;                          // (this wavefront's own piece of LDS, written for good further down)
-            integrate_gamma_item_wave(h.table, h.pre, h.dnu, h.aux, d.n_d, d.uniform_grid, d.dD,
-                                      __builtin_amdgcn_readlane(it.key, l) - h.key_base, readlane_f64(it.p0, l), readlane_f64(it.p1, l), col);
-            if (lane == l) {
-#pragma unroll
-                for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = make_double2(col[2 * c], col[2 * c + 1]);
-                have = true;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        off_table = false;                                        // (nothing is deferred)
+        // (items outside the integral table: integrated further down, when the columns of the others have left the registers)
     } else if (off_table) {
         // ---- an item outside the integral table: a work unit of its own for the integrating kernels (as k_gate1) ----
         const unsigned long long idx = atomicAdd(g.totals + 1, 1ull);
@@ -556,6 +536,28 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
         double y = ((c & 1) ? v[c / 2].y : v[c / 2].x) * w0;
         if (!(y == y)) y = 0.0;
         s_acc[(j * CPOL_N_SZ + c) * 64 + lane] = have ? (float)(0.0 + y) : 0.f;
+    }
+    if (RAY) {
+        // ---- items outside the integral table: integrated here, one after the other (rare), their terms straight into LDS ----
+        unsigned long long todo = __ballot(off_table);
+        if (todo && lane == 0) {                                  // (cpol_counters: items integrated bin by bin, one "unit" each)
+            atomicAdd(g.totals, (unsigned long long)__popcll(todo));
+            atomicAdd(g.totals + 1, (unsigned long long)__popcll(todo));
+        }
+        while (todo) {
+            const int l = (int)__ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            double *col = s_mv + j * 64;                          // (this wavefront's own piece of LDS, written for good further down)
+            integrate_gamma_item_wave(h.table, h.pre, h.dnu, h.aux, d.n_d, d.uniform_grid, d.dD,
+                                      __builtin_amdgcn_readlane(it.key, l) - h.key_base, readlane_f64(it.p0, l), readlane_f64(it.p1, l), col);
+            if (lane < CPOL_N_SZ) {                               // (lane c: column c of the item of lane l, as the loop above forms it)
+                double y = col[lane] * w0;
+                if (!(y == y)) y = 0.0;
+                s_acc[(j * CPOL_N_SZ + lane) * 64 + l] = (float)(0.0 + y);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        off_table = false;                                        // (nothing is deferred)
     }
     const bool moments = want_rvel && it.valid && f.vsrc[j] == 1;
     double vj = 0.0, nj = 0.0;
@@ -579,7 +581,7 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
         vbits |= (fl & 1u) << q;
         deferred = deferred || (fl & 2u);
     }
-    if (deferred) {
+    if (!RAY && deferred) {                              // (RAY: nothing is ever deferred -- the item's parameters are dead by now)
         gate1_store_item(a, t, j, n, i, it, g.analytic_vn != 0);
         if (want_vn && t.tab && !t.two_d && it.lookup && a.vn)
             *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = wv;
