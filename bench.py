@@ -375,9 +375,9 @@ def main():
         args.gpus = world
     workload = args.workload if args.workload != 'auto' else 'c2'
     if args.steps is None:
-        args.steps = {'c2': 200, 'c3': 20, 'c4': 10, 'c5': 5}[workload]
+        args.steps = {'c2': 20, 'c3': 20, 'c4': 10, 'c5': 5}[workload]      # (c2: the driver's own `--steps 20 --warmup 5`; five repeats of the region)
     if args.warmup is None:
-        args.warmup = {'c2': 10, 'c3': 3, 'c4': 2, 'c5': 1}[workload]
+        args.warmup = {'c2': 5, 'c3': 3, 'c4': 2, 'c5': 1}[workload]
     if workload in ('c3', 'c5') and world > 1:
         raise SystemExit('--workload %s is a single-GPU extra; the multi-GPU workloads are c4 (strong) and c2 (weak)' % workload)
     # debugging aids for a one-GPU box: CPOL_BENCH_BACKEND=gloo CPOL_BENCH_ONE_DEVICE=1 runs the
