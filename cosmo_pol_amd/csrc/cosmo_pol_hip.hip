@@ -1605,7 +1605,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // workgroup that finishes the ray last and the items outside the tables integrated in place -- the sweep is
     // k_interp_sweep + that kernel, no integrating launch, no k_final.  Only where the in-place integration mirrors the
     // integrating kernels: gamma-family species without Doppler-scheme-2 sums and without per-ray fall-speed totals
-    // (numeric_intv), whose tables kept all panels but the tail (an item off the table costs a wavefront ~10 000 cycles:
+    // (numeric_intv), whose tables kept all panels but the tail (an item off the table costs a wavefront ~40 us:
     // fine for the handful a volume has, not for a table that lost half of its panels to the accuracy gate).
     const int g1r = ctx->gate1_ray >= 0 ? ctx->gate1_ray
                   : ((ctx->parent ? ctx->parent->n_children : ctx->n_children) >= 2 ? 1 : 0);
