@@ -118,6 +118,33 @@ def hydrometeors_of(workload):
     return ('R', 'S', 'G') if workload == 'c2' else ('R', 'S', 'G', 'mS', 'mG', 'I')
 
 
+def make_inputs(workload, small=False):
+    """(configuration, hydrometeors, synthetic COSMO cube, scattering tables) of a BASELINE workload: what main() stages and
+    what tests/test_gpu_headline.py builds its operators from -- one definition, so that the test pins the path the line times."""
+    from cosmo_pol_amd import synthetic
+    conf = bench_config(small, workload)
+    hyds = hydrometeors_of(workload)
+    cube_h = tuple(h for h in hyds if h in ('R', 'S', 'G', 'H', 'I'))
+    n_e = 8 if small else None
+    if workload == 'c5':
+        cube = (synthetic.small_test_cube(hydrometeors=cube_h, two_moment=True) if small
+                else synthetic.make_cube(hydrometeors=cube_h, two_moment=True, **synthetic.BENCH_GRID))
+        _sets = {}
+
+        def luts(hl, freq, scheme):                   # (Ku / Ka / C sets, each built once)
+            key = (tuple(hl), freq, scheme)
+            if key not in _sets:
+                _sets[key] = synthetic.make_all_luts(hl, freq, scheme, n_e=n_e)
+            return _sets[key]
+    elif small:
+        cube = synthetic.small_test_cube(hydrometeors=cube_h)
+        luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
+    else:
+        cube = synthetic.make_cube(hydrometeors=cube_h, **synthetic.BENCH_GRID)
+        luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    return conf, hyds, cube, luts
+
+
 def load_profile_summary(workload):
     """profiles/r5_<workload>_summary.json (tools/profile_summary.py; r4_* / r3_* / r2_* if this round's file is
     missing): per kernel the mean FETCH_SIZE / WRITE_SIZE / SQ counters per dispatch, `hbm_bytes`
@@ -299,7 +326,7 @@ def compact_line(d):
         if ho.get('value') and cpu and cpu.get('value'):
             out['host_outputs_over_cpu_core'] = ho['value'] / cpu['value']
     for k in ('ms_per_sweep', 'value_definition', 'c4_speedup_vs_single_gpu', 'c4_speedup_single_volume', 'c4_gather_check',
-              'speedup_vs_single_gpu', 'speedup_single_volume', 'gather_check', 'n_ranks_seen_by_rccl', 'collective'):
+              'speedup_vs_single_gpu', 'speedup_single_volume', 'gather_check', 'result_check', 'n_ranks_seen_by_rccl', 'collective'):
         if d.get(k) is not None:
             out[k] = d[k][:200] if isinstance(d[k], str) else d[k]
     others = {}
@@ -385,28 +412,9 @@ def main():
     backend = os.environ.get('CPOL_BENCH_BACKEND', 'nccl')
     if os.environ.get('CPOL_BENCH_ONE_DEVICE'):
         local_rank = 0
-    from cosmo_pol_amd import RadarOperator, synthetic
-    conf = bench_config(args.small, workload)
-    hyds = hydrometeors_of(workload)
-    cube_h = tuple(h for h in hyds if h in ('R', 'S', 'G', 'H', 'I'))
+    from cosmo_pol_amd import RadarOperator
     t0 = time.time()
-    n_e = 8 if args.small else None
-    if workload == 'c5':
-        cube = (synthetic.small_test_cube(hydrometeors=cube_h, two_moment=True) if args.small
-                else synthetic.make_cube(hydrometeors=cube_h, two_moment=True, **synthetic.BENCH_GRID))
-        _sets = {}
-
-        def luts(hl, freq, scheme):                   # (Ku / Ka / C sets, each built once)
-            key = (tuple(hl), freq, scheme)
-            if key not in _sets:
-                _sets[key] = synthetic.make_all_luts(hl, freq, scheme, n_e=n_e)
-            return _sets[key]
-    elif args.small:
-        cube = synthetic.small_test_cube(hydrometeors=cube_h)
-        luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
-    else:
-        cube = synthetic.make_cube(hydrometeors=cube_h, **synthetic.BENCH_GRID)
-        luts = synthetic.make_all_luts(hyds, 5.6, '1mom')
+    conf, hyds, cube, luts = make_inputs(workload, args.small)
     t_gen = time.time() - t0
 
     # The one-core CPU baseline first (a bounded sample: --cpu-seconds of oracle work on one pinned core).  The
@@ -584,6 +592,56 @@ def stage_ms_of(c):
             'final': c.ms_final}
 
 
+def check_last_sweep(env, slabs, els, az, k_last, n_buf, n_lanes, n_cycle):
+    """`result_check` of the line (round-5 review, item 1b): what the LAST sweep of the timed region left in HBM -- which launch
+    forms it took, read from the library -- against (i) the host-output hand-over of the same elevation (`step_full`'s call:
+    NaN pattern equal, <= 1e-5; it is the same arithmetic, so the expected answer is "bitwise") and (ii), when the CPU legs
+    are on, four of its rays against the oracle (the checker, never the thing measured): the six ratio / power variables at
+    the pure relative 1e-5, the three phase-like ones on the scale of the variable over the ray, as smoke() does."""
+    op, rank, args, torch = env['op'], env['rank'], env['args'], env['torch']
+    lane = k_last % n_lanes
+    forms = op._lane(lane).launch_forms()
+    el = els[(k_last + rank) % n_cycle]
+    got = slabs[k_last % n_buf].cpu().numpy()
+    with contextlib.redirect_stdout(sys.stderr):
+        host = op.simulate_rays(az, el, lane=0)
+    out = {'sweep': 'the last of the timed region (lane %d, elevation %.2f deg)' % (lane, float(el[0])), 'launch_forms': forms,
+           'vs_host_outputs': {}, 'ok': True}
+    bitwise, worst = True, 0.0
+    for i, f in enumerate(RADAR_FIELDS):
+        a, b = got[i].astype(np.float64), host[f].astype(np.float64)
+        same_nan = bool(np.array_equal(np.isnan(a), np.isnan(b)))
+        ok = np.isfinite(b) & np.isfinite(a) & (b != 0)
+        rel = float(np.max(np.abs(a[ok] - b[ok]) / np.abs(b[ok]))) if ok.any() else 0.0
+        bitwise = bitwise and bool(np.array_equal(got[i], host[f], equal_nan=True))
+        worst = max(worst, rel)
+        out['ok'] = out['ok'] and same_nan and rel <= 1e-5
+    out['vs_host_outputs'] = {'bitwise': bitwise, 'worst_rel': worst, 'n_finite_ZH': int(np.isfinite(got[0]).sum())}
+    out['ok'] = out['ok'] and out['vs_host_outputs']['n_finite_ZH'] > 0
+    if args.cpu_seconds > 0:
+        from cosmo_pol_oracle import beam, scatter
+        oconf, oc, ol = _oracle_inputs(env['conf'], env['cube'], env['luts'])
+        rays, worst_o, ok_o = (11, 97, 203, 318) if len(az) >= 360 else (1, len(az) // 2), {}, True
+        for r in rays:
+            subs = beam.interpolate_radial(oc, oconf, float(az[r]), float(el[r]))
+            o = scatter.radar_observables(subs, ol, oconf)
+            scatter.cut_at_sensitivity([o], oconf)
+            for i, f in enumerate(RADAR_FIELDS):
+                a, b = got[i][r].astype(np.float64), np.asarray(o.values[f], dtype=np.float64)
+                fin = np.isfinite(b)
+                ok_o = ok_o and bool(np.array_equal(np.isnan(a), np.isnan(b)))
+                if not fin.any() or not np.array_equal(np.isnan(a), np.isnan(b)):
+                    continue
+                scale = np.abs(b[fin]) if f not in ('KDP', 'PHIDP', 'DELTA_HV') else np.maximum(np.abs(b[fin]), np.max(np.abs(b[fin])))
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    rel = np.nan_to_num(np.abs(a[fin] - b[fin]) / scale)
+                worst_o[f] = max(worst_o.get(f, 0.0), float(rel.max()))
+        ok_o = ok_o and all(v <= 1e-5 for v in worst_o.values())
+        out['vs_oracle'] = {'rays': list(rays), 'worst_rel': worst_o, 'ok': ok_o}
+        out['ok'] = out['ok'] and ok_o
+    return out
+
+
 def run_c2(env):
     from cosmo_pol_amd import RadarOperator
     op, lanes, n_lanes, world, rank = env['op'], env['lanes'], env['n_lanes'], env['world'], env['rank']
@@ -692,6 +750,7 @@ def run_c2(env):
     gates_per_sweep = world * n_rays * n_gates
     gates_per_step = n_cycle * gates_per_sweep
     value = gates_per_step * args.steps / elapsed
+    result_check = check_last_sweep(env, slabs, els, az, counter[0] - 1, n_buf, n_lanes, n_cycle) if rank == 0 else None
 
     # rank 0 recomputes the last sweep of every rank and compares it with the gathered block, bit for bit
     gather_ok = None
@@ -887,6 +946,8 @@ def run_c2(env):
         'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
         'host_submit_ms_per_sweep': 1e3 * t_submit / args.steps / n_cycle,
         'gather_check': gather_ok,
+        'result_check': None if result_check is None else bool(result_check['ok']),
+        'result_check_detail': result_check,
     }
     out.update(extra)
     return out

@@ -614,6 +614,14 @@ class Context(object):
                     'cpol_debug_math')
         return y
 
+    FORM_NAMES = ('g1r', 'gate1_ray', 'gate1', 'interp_classify', 'rare_direct', 'subbeam_sum', 'final_inplace',
+                  'poly_central', 'n_sub', 'lanes_alive', 'wave_scan', 'graph_replayed')
+
+    def launch_forms(self):
+        """Which launch sequence the last cpol_run_sweep of this context took (tests / bench result checks): {name: int}."""
+        v = self.debug_read('launch_forms', (len(self.FORM_NAMES),), np.int32)
+        return dict(zip(self.FORM_NAMES, (int(x) for x in v)))
+
     def debug_read(self, name, shape, dtype):
         out = np.empty(shape, dtype=dtype)
         n = self.lib.cpol_debug_read(self.h, name.encode(), _ptr(out), out.nbytes)

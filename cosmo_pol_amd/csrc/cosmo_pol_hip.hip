@@ -116,6 +116,9 @@ struct cpol_ctx {
         DevBuf poly;
         uint64_t poly_version = 0;
         double poly_scale = 0.0;
+        // ... and per (model grid rotation, radar site): k_trajectory bakes the rotated-pole matrix of the staged model and
+        // the site's constants into them (cpol_stage_model clears poly_version; the site is compared sweep by sweep)
+        double poly_site[3] = {0.0, 0.0, 0.0};
     };
     static constexpr int N_TABLE_SETS = 8;
     TableSet tsets[N_TABLE_SETS];
@@ -162,6 +165,9 @@ struct cpol_ctx {
     int gate1 = 1;                     // CPOL_GATE1=0 / 2: never / also with melting species: the single-beam fused kernel (read when the context is created)
     int subsum_scalar = 0;             // CPOL_SUBSUM_FORM=scalar: the cooperative form of k_subbeam_sum takes its rows through the scalar cache instead of LDS
     int upload_kernel = 0;             // CPOL_TABLE_UPLOAD=kernel: the per-ray tables by k_upload_tables instead of hipMemcpyAsync (a measurement knob)
+    int last_forms[12] = {0};          // the launch forms of the last sweep (cpol_debug_read "launch_forms"): [0] g1r, [1] k_gate1_ray, [2] single-beam gate kernel,
+                                       // [3] k_interp_classify, [4] items off the tables listed directly, [5] k_subbeam_sum, [6] table items evaluated in place,
+                                       // [7] coordinate polynomials for the one sub-beam, [8] n_sub, [9] lanes alive, [10] wavefront range scans, [11] HIP graph replayed
     int last_poly_central = 0;         // the last sweep's one sub-beam took the coordinate polynomials (cpol_debug_read "poly_central")
     int geo_poly_central = 1;          // CPOL_GEO_POLY_CENTRAL=0: a single-beam sweep keeps the long form of the geodesy for its (central) sub-beam even when
                                        // nobody asks for the float64 latitude / longitude; 2: the polynomials also with the debug reads enabled (tools/fast_sub_check.py)
@@ -991,6 +997,9 @@ int cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data, const 
     m.nstcp = -st * cp; m.stsp = st * sp; m.ct = ct;
     ctx->model_staged = true;
     ctx->stage_serial++;
+    // the coordinate polynomials of the resident table sets hold the PREVIOUS model's rotated-pole matrix (round-5 advisor
+    // finding: a second cube with another south pole, the same rays again -> wrong grid cells without an error)
+    for (auto &ts : ctx->tsets) ts.poly_version = 0;
     return CPOL_OK;
 }
 
@@ -1442,8 +1451,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // single-beam sweeps (round 5): the one sub-beam takes the polynomials too when its float64 latitude / longitude are not
     // outputs; they belong to the resident table set of the rays and are made once per (version, range grid)
     const bool poly_single = !ray_prep && ctx->geo_poly && ctx->geo_poly_central && mode == CPOL_GEOM_GROUND_43 && !t->site &&
-                             (!ctx->keep_debug || ctx->geo_poly_central == 2) && t->version != 0 && !(p->debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS) &&
-                             !out->lats && !out->lons;        // (their float64 values come from the long form: nothing to prepare then)
+                             (!ctx->keep_debug || ctx->geo_poly_central == 2) && t->version != 0 && !(p->debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS);
+    // (round 6: also when the float64 latitude / longitude are outputs -- the long form then runs for those two arrays alone and
+    // the float32 grid coordinates still come from the guarded polynomials: identical calls give identical bits whether or not the
+    // caller fetches the gate coordinates, round-5 advisor finding)
     // arc distance <= slant range; a margin of 1e-3 for the asin of the 4/3-earth formula
     const double geo_poly_scale = 2.0 / ((p->range0 + (double)(ng - 1) * p->range_step) * 1.001);
     if (geo_poly || poly_single) {
@@ -1468,7 +1479,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             if (rc != CPOL_OK) return rc;
             HIPCHK(hipStreamSynchronize(ctx->stream));           // (M is a stack array)
         }
-        if (poly_single && (!set->poly.p || set->poly_version != set->version || set->poly_scale != geo_poly_scale)) {
+        if (poly_single && (!set->poly.p || set->poly_version != set->version || set->poly_scale != geo_poly_scale ||
+                            set->poly_site[0] != p->radar_lon || set->poly_site[1] != p->sin_u1 || set->poly_site[2] != p->cos_u1)) {
             ENSURE(set->poly, (size_t)n_rays * n_h * 2 * CPOL_GEO_NP * sizeof(double));
             TrajArgs tp{};
             tp.geo = (const double *)ctx->v_geo;
@@ -1480,6 +1492,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             hipLaunchKernelGGL(k_trajectory, dim3((unsigned)cdiv((long)n_rays * n_h, 256 / CPOL_GEO_NP)), dim3(256), 0, ctx->stream, ctx->model, tp);
             set->poly_version = set->version;
             set->poly_scale = geo_poly_scale;
+            set->poly_site[0] = p->radar_lon; set->poly_site[1] = p->sin_u1; set->poly_site[2] = p->cos_u1;
         }
     }
     ENSURE(ctx->b_vals, (size_t)n_vars * n_sbg * sizeof(float));
@@ -1772,8 +1785,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.site = t->site ? (const double *)ctx->v_site : nullptr;
     ia.exact_sub = (p->debug_flags & CPOL_DEBUG_EXACT_SUBBEAMS) ? 1 : 0;
     // (the one sub-beam of a single-beam sweep: the polynomials of its table set, unless its float64 coordinates are outputs)
-    const bool poly_central = poly_single && !user_out[O_LAT] && !user_out[O_LON];       // (nobody reads the library's own copies)
-    if (poly_central && !ctx->keep_debug) ia.lats = ia.lons = nullptr;
+    const bool poly_central = poly_single;
+    if (poly_central && !ctx->keep_debug && !user_out[O_LAT] && !user_out[O_LON]) ia.lats = ia.lons = nullptr;   // (nobody reads the library's own copies)
     ia.poly = geo_poly ? (const double *)ctx->b_poly.p : poly_central ? (const double *)set->poly.p : nullptr;
     ia.poly_scale = (geo_poly || poly_central) ? geo_poly_scale : 0.0;
     ia.poly_central = poly_central ? 1 : 0;
@@ -2368,6 +2381,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     return CPOL_OK;
     };
 
+    const int forms[12] = {g1r, (int)gate1_ray, (int)gate1, (int)fused, (int)rare_direct, (int)subsum, (int)final_inplace, (int)poly_single,
+                           n_sub, ctx->parent ? ctx->parent->n_children : ctx->n_children, 0, 0};
+    memcpy(ctx->last_forms, forms, sizeof forms);
     const double t_buffers = now_ns();
     ctx->counters_dirty = true;         // until the sequence is queued completely (cleared where sweep_serial advances)
     // graph key: every value that ends up in a kernel argument
@@ -2391,6 +2407,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                          ctx->v_subv, ctx->v_subw, ctx->v_sens, ctx->v_site, ctx->v_nyq,
                          ctx->v_subsmooth, ctx->v_mlfilter, (void *)st, poly_single ? set->poly.p : nullptr};
         mix(arena, sizeof arena);
+        // (the launch forms chosen above from state outside *p: a graph captured before the lanes were forked must not keep
+        // replaying the four-launch sequence once k_gate1_ray is the default, nor the reverse)
+        mix(forms, sizeof forms);
         hipGraphExec_t &gexec = ctx->graph_exec[par];
         if (!gexec || ctx->graph_key[par] != key) {
             if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
@@ -2410,6 +2429,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             ctx->graph_key[par] = key;
         }
         HIPCHK(hipGraphLaunch(gexec, st));
+        ctx->last_forms[11] = 1;
     } else {
         if ((rc = launch_all()) != CPOL_OK) return rc;
     }
@@ -2566,6 +2586,11 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
         if (!dst || max_bytes < (int64_t)sizeof(int)) return CPOL_ERR_ARG;
         memcpy(dst, &ctx->last_poly_central, sizeof(int));
         return (int64_t)sizeof(int);
+    }
+    if (!strcmp(name, "launch_forms")) {
+        if (!dst || max_bytes < (int64_t)sizeof ctx->last_forms) return CPOL_ERR_ARG;
+        memcpy(dst, ctx->last_forms, sizeof ctx->last_forms);
+        return (int64_t)sizeof ctx->last_forms;
     }
     if (!strcmp(name, "host_times")) {
         // host time of cpol_run_sweep by section since the last read (see cpol_ctx::host_ns); reading resets

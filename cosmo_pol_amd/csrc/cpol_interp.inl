@@ -209,10 +209,17 @@ __global__ __launch_bounds__(256) void k_trajectory(ModelDev m, TrajArgs a)
             __syncthreads();
             if (ok) {
                 double c0 = 0.0, c1 = 0.0;
+                // (round 6, advisor: a fit nobody compares with the long form must not be badly conditioned -- a rotated longitude that
+                // wraps at +-180 deg between two nodes, a point next to the rotated pole.  Node values more than a degree apart over a
+                // fraction of a 150-km ray, or not finite: the coefficients become NaN, the gate kernel's guard reads NaN as "neighbour
+                // in another cell" and every gate of this (ray, node) takes the long form)
+                bool sane = true;
                 for (int k = 0; k < NP; ++k) {
                     c0 = fma(a.poly_M[q * NP + k], s_node[0][el][k], c0);
                     c1 = fma(a.poly_M[q * NP + k], s_node[1][el][k], c1);
+                    if (k > 0) sane = sane && fabs(s_node[0][el][k] - s_node[0][el][k - 1]) <= 1.0 && fabs(s_node[1][el][k] - s_node[1][el][k - 1]) <= 1.0;
                 }
+                if (!sane) c0 = c1 = __builtin_nan("");
                 double *o = a.poly + e * (2 * NP);
                 o[q] = c0;
                 o[NP + q] = c1;
@@ -600,7 +607,12 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     // (wave-uniform: a wavefront walks ONE sub-beam; exact_sub is a kernel argument)
     const bool use_poly = a.poly && (sub != a.central_sub || a.poly_central) && !a.exact_sub;
     const bool short_form = sub != a.central_sub && !a.exact_sub && !a.poly;      // (the closed short form of round 4: CPOL_GEO_POLY=0)
+    // (round 6: the form no longer depends on what the caller asks for.  A single-beam sweep whose float64 latitude / longitude ARE
+    // outputs runs the long form for those two arrays and still takes its float32 grid coordinates from the guarded polynomials,
+    // so that the first sweep of a table set -- which fetches the gate coordinates -- and every later one give the same bits)
+    const bool want_latlon = use_poly && sub == a.central_sub && (a.lats || a.lons);
     bool long_form = !use_poly;
+    float rlat_p = 0.0f, rlon_p = 0.0f;
     if (use_poly) {
         // ---- the rotated coordinates from the (ray, horizontal node)'s polynomials (k_trajectory / k_geo_poly) ----
         constexpr int NP = CPOL_GEO_NP;
@@ -612,8 +624,8 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
             la = fma(la, x, pc[q]);
             lo = fma(lo, x, pc[NP + q]);
         }
-        rlat = (float)la;
-        rlon = (float)lo;
+        rlat = rlat_p = (float)la;
+        rlon = rlon_p = (float)lo;
         // GUARD: the polynomials follow the long form to ~2e-13 deg (degree 8 through 9 Chebyshev nodes over 0.024 rad of arc;
         // float32 ulp at 3 deg: 2.4e-7), so the two float32 coordinates are the same number or neighbours.  If the coordinate's
         // neighbours on both sides (c -/+ 1..2 ulp) fall into the SAME cell of the model grid and inside the domain -- the
@@ -622,13 +634,16 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
         // coordinate, in ~6e-7 of the gates: profiles/r5_fast_sub_check.json).  Otherwise (one gate in ~5 000) the gate takes
         // the long form after all: index work is the long form's by construction.
         auto spans = [](float c, float llc, float urc, float res) {
-            const float d = fmaxf(fabsf(c), 1.0e-30f) * 1.1920929e-7f;              // 2^-23 |c|: between 1 and 2 ulps of c
+            // 2^-23 max(|c|, |llc|): between 1 and 2 ulps of c, and never below the rounding of `c - llc` (round 6, advisor: the rotated
+            // coordinates of a limited-area model sit near 0, where an ulp of c falls below the polynomial's own ~2e-13 deg)
+            const float d = fmaxf(fmaxf(fabsf(c), fabsf(llc)), 1.0e-30f) * 1.1920929e-7f;
             const float lo = c - d, hi = c + d;
             return floorf((lo - llc) / res) != floorf((hi - llc) / res) || !(lo >= llc) || !(hi <= urc);   // (NaN: true)
         };
         long_form = spans(rlat, m.llc1, m.urc1, m.res1) || spans(rlon, m.llc0, m.urc0, m.res0);
     }
-    if (long_form) {
+    const bool poly_ok = use_poly && !long_form;
+    if (long_form || want_latlon) {
     const double sin_u1 = a.site ? a.site[(long)ray * 8 + 0] : a.sin_u1;
     const double cos_u1 = a.site ? a.site[(long)ray * 8 + 1] : a.cos_u1;
     const double lon1 = a.site ? a.site[(long)ray * 8 + 2] : a.lon1;
@@ -753,6 +768,7 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     }
 
     }
+    if (poly_ok) { rlat = rlat_p; rlon = rlon_p; }     // (want_latlon: the long form ran for lat_deg / lon_deg alone)
 
     // interpolation.py:572-575 (IndexError in the reference)
     if (rlon < m.llc0 || rlat < m.llc1 || rlon > m.urc0 || rlat > m.urc1 ||

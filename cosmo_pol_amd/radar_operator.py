@@ -849,9 +849,17 @@ class RadarOperator(object):
         runners = self.__dict__.setdefault('_group_runners', {})
         if id(group) not in runners:
             import torch.distributed as dist
+            members = dist.get_process_group_ranks(group)
+            if dist.get_rank() not in members:
+                raise ValueError('submit_volume(group=...): rank %d is not a member of the group (ranks %s)'
+                                 % (dist.get_rank(), members))
             root = self.gather_to
             if root is not None:                  # (gather_to names a rank of the default group)
-                root = dist.get_group_rank(group, root) if root in dist.get_process_group_ranks(group) else 0
+                if root not in members:
+                    # (round-5 advisor: never re-root silently -- the scan would land on a rank nobody named)
+                    raise ValueError('gather_to=%d is not a member of the group (ranks %s): results of a rooted '
+                                     'gather must land on a rank of the group that computes them' % (root, members))
+                root = dist.get_group_rank(group, root)
             runners[id(group)] = (group, D.ShardedVolumeRunner(torch.device('cuda', self.device), group=group,
                                                                gather_to=root, slots=max(2, self.lanes + 1)))
         return runners[id(group)][1]

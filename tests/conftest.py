@@ -22,3 +22,21 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
     return load
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The ledger of operand-scaled tolerances (tests/_cases.py::assert_close_nan): per (test, variable) how many gates passed
+    only thanks to their `atol` -- appended to gpurun_out/atol_ledger.jsonl (copied to profiles/ per round)."""
+    try:
+        import json
+        import _cases
+        if not _cases.ATOL_LEDGER:
+            return
+        out = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'atol_ledger.jsonl'), 'a') as f:
+            for (test, var), (n_atol, n, worst) in sorted(_cases.ATOL_LEDGER.items()):
+                f.write(json.dumps({'test': test, 'var': var, 'gates_that_needed_atol': n_atol, 'gates_compared': n,
+                                    'worst_pure_rel_among_them': worst}) + '\n')
+    except Exception:                    # (never turn a finished run red)
+        pass

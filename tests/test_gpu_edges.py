@@ -329,3 +329,54 @@ def test_rare_items_of_every_flavour_in_one_launch(monkeypatch):
         assert np.array_equal(out['one_launch'][0][k], out['sorted'][0][k], equal_nan=True), k
         assert np.array_equal(out['per_flavour'][0][k], out['sorted'][0][k], equal_nan=True), k
     assert np.isfinite(out['one_launch'][0]['ZH']).sum() > 300
+
+
+def test_second_model_with_another_south_pole_rebuilds_the_coordinate_polynomials():
+    """Round-5 advisor finding (medium): the coordinate polynomials of a single-beam sweep's resident table set hold the
+    rotated-pole matrix of the model they were made for.  Staging a second cube with ANOTHER south pole and running the same
+    rays again (the host's 'rays' cache and the library's table set survive the staging) must rebuild them: the default
+    form then agrees with the long form of the geodesy (debug_flags = CPOL_DEBUG_EXACT_SUBBEAMS) on the new cube -- before
+    the fix it read the grid cells of the old rotation (or left the domain) without any error."""
+    import bench
+    import torch
+    from cosmo_pol_amd import RadarOperator, synthetic
+    from cosmo_pol_amd import _native as N
+    from cosmo_pol_oracle import geodesy
+    conf = bench.bench_config(True)
+    hyds = ('R', 'S', 'G')
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
+    site = conf['radar']['coords']
+    poles = [(-43.0, 10.0), (-38.5, 13.0)]
+    cubes = []
+    for sp in poles:
+        rot = geodesy.wgs_to_rotated(np.array([site[0]]), np.array([site[1]]), sp[0], sp[1])[0]      # (rotated lat, lon of the site)
+        cubes.append(synthetic.small_test_cube(center_rot=(float(rot[0]), float(rot[1])), hydrometeors=hyds, south_pole=sp))
+    assert cubes[0]['proj_info']['Lo1'] != cubes[1]['proj_info']['Lo1']
+    op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
+    az = np.arange(0.0, 360.0, 3.0)
+    el = np.full(len(az), 1.5)
+    ng = len(op.constants.RANGE_RADAR)
+    slab = torch.empty((len(bench.RADAR_FIELDS), len(az), ng), dtype=torch.float32, device='cuda')
+    ptrs = {k: slab[i].data_ptr() for i, k in enumerate(bench.RADAR_FIELDS)}
+    results = []
+    for cube in cubes:
+        op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+        for _ in range(2):
+            op.simulate_rays(az, el, device_outputs=ptrs)
+        op.wait()
+        assert op._ctx.launch_forms()['poly_central'] == 1
+        poly = slab.cpu().numpy().copy()
+        op.debug_flags = N.DEBUG_EXACT_SUBBEAMS
+        op.simulate_rays(az, el, device_outputs=ptrs)
+        op.wait()
+        assert op._ctx.launch_forms()['poly_central'] == 0
+        op.debug_flags = 0
+        exact = slab.cpu().numpy().copy()
+        assert np.isfinite(exact[0]).sum() > 2000
+        assert np.array_equal(np.isnan(poly), np.isnan(exact))
+        ok = np.isfinite(exact) & (exact != 0)
+        assert np.max(np.abs(poly[ok] - exact[ok]) / np.abs(exact[ok])) < 1e-5
+        results.append(exact)
+    # (the two rotations put different model columns under the same rays: the test would not see a stale matrix otherwise)
+    assert not np.array_equal(np.nan_to_num(results[0]), np.nan_to_num(results[1]))
+    op.close()
