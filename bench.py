@@ -565,7 +565,7 @@ def child_run(workload, flags, env=None, quiet=False, timeout=600):
         keep = {k: d.get(k) for k in ('value', 'unit', 'n_gpus', 'ms_per_step', 'steps', 'warmup', 'scaling',
                                       'gather_check', 'speedup_vs_single_gpu', 'single_gpu_same_workload',
                                       'per_rank', 'roofline', 'setup_s', 'stages_ms', 'counters', 'api_ms', 'per_band',
-                                      'single_sweep_ms', 'host_submit_ms_per_step', 'submit_loop_ms_per_step', 'speedup_device_only', 'collective',
+                                      'single_sweep_ms', 'host_submit_ms_per_step', 'submit_loop_ms_per_step', 'speedup_device_only', 'collective', 'host_block_pinned',
                                       'collectives_in_timed_region', 'n_ranks_seen_by_backend', 'n_ranks_seen_by_rccl',
                                       'process_group_backend', 'cpu_baseline', 'speedup_single_volume',
                                       'single_volume_blocking') if k in d}
@@ -1189,7 +1189,9 @@ def run_c4(env):
     az, el = lay.local_rays(rank, sweeps)
     n_loc = len(az) // n_el
     op.lanes = n_lanes                                  # (the runner keeps lanes + 1 sets of device buffers)
-    op.gather_to = None if os.environ.get('CPOL_BENCH_C4_GATHER', 'root') == 'all' else 0
+    # (round 6: the all-gather is the default -- the rooted `dist.gather` has run on one rank only so far; CPOL_BENCH_C4_GATHER=root
+    # opts into it, tests/test_gpu_distributed.py::test_two_gpus_nccl_* run both forms wherever two GPUs are visible)
+    op.gather_to = 0 if os.environ.get('CPOL_BENCH_C4_GATHER', 'all') == 'root' else None
     runner = op._dist_runner()
     pending = collections.deque()
     last = [None]
@@ -1395,6 +1397,7 @@ def run_c4(env):
         'submit_loop_ms_per_step': 1e3 * t_submit / args.steps,
         'gather_check': gather_ok,
         'collective': runner.collective,
+        'host_block_pinned': runner.host_pinned,     # the device-to-host copy behind the collective lands in memory the HIP runtime page-locked
         'collectives_in_timed_region': n_coll,
         'n_ranks_seen_by_backend': int(dist.get_world_size()),
         'api_ms': {'get_PPI_distributed_median': statistics.median(api), 'get_PPI_distributed_min': min(api),

@@ -302,6 +302,7 @@ class ShardedVolumeRunner(object):
         self._turn = 0
         self._lib = {}
         self.n_collectives = 0
+        self.host_pinned = None           # device runs: whether torch / the HIP runtime see the result blocks as page-locked
 
     def _layout(self, sweeps, fields, n_gates):
         key = (tuple(len(a) for a, _ in sweeps), tuple((k, str(dt)) for k, dt in fields), int(n_gates))
@@ -386,7 +387,16 @@ class ShardedVolumeRunner(object):
                 # rows -> their place in the scan ON THE DEVICE, then ONE copy into the page-locked block the
                 # returned arrays are views of (no host-side concatenation)
                 lay.assemble_on_device(gathered, slot['final'], self._index)
-                torch.from_numpy(arr).copy_(slot['final'], non_blocking=True)
+                host = torch.from_numpy(arr)
+                if self.cuda and self.host_pinned is None:
+                    # The result block comes from the operator's PinnedPool (hipHostMalloc through the library), not from
+                    # torch's caching host allocator.  torch asks the HIP runtime about the pointer (is_pinned ->
+                    # hipPointerGetAttributes), and the runtime itself decides at hipMemcpyAsync time: for a block it
+                    # page-locked the copy is a true asynchronous DMA on the runner's stream.  Checked once per runner and
+                    # kept for the tests / bench (`host_pinned`); a pageable block (no pool given) still copies correctly,
+                    # staged by the runtime.
+                    self.host_pinned = bool(host.is_pinned())
+                host.copy_(slot['final'], non_blocking=True)
             event = None
             if self.cuda:
                 event = torch.cuda.Event()

@@ -1,5 +1,6 @@
 """Worker of tests/test_gpu_distributed.py: two or three ranks on ONE GPU (gloo rendezvous; RCCL
-rejects two ranks on the same device) run RadarOperator(distributed=True).get_PPI (rays of every
+rejects two ranks on the same device) -- or, with CPOL_DIST_BACKEND=nccl on a box with >= 2 GPUs, one rank per GPU over
+RCCL (the rooted `dist.gather` on device tensors, three scans pending: what a one-GPU box cannot execute) -- run RadarOperator(distributed=True).get_PPI (rays of every
 sweep sharded) and .get_GPM_swath (scan lines sharded) and compare with the same scan / swath
 computed locally by each rank, bit for bit."""
 import os
@@ -14,7 +15,14 @@ import torch.distributed as dist  # noqa: E402
 
 
 def main():
-    dist.init_process_group('gloo')
+    backend = os.environ.get('CPOL_DIST_BACKEND', 'gloo')
+    local = int(os.environ.get('LOCAL_RANK', '0')) if backend == 'nccl' else 0      # (gloo: every rank on GPU 0)
+    if backend == 'nccl':
+        import torch
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     import _cases
     from cosmo_pol_amd import RadarOperator
@@ -26,7 +34,7 @@ def main():
     azs = np.arange(n_az) * (360. / n_az)       # 15 rays: uneven split over 2 ranks; 16 over 3: 6 + 6 + 4
     scans = []
     for distributed in (True, False):
-        op = RadarOperator(config=over, luts=luts, output_variables='only_radar', device=0,
+        op = RadarOperator(config=over, luts=luts, output_variables='only_radar', device=local,
                            distributed=distributed)
         op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
         scans.append(op.get_PPI(elevations=[4.0, 6.0], azimuths=azs))
@@ -34,16 +42,22 @@ def main():
     a, b = scans
     # the rooted form: rank 1 alone receives, assembles and copies the scan; pipelined submissions on
     # alternating lanes (collective + copy of scan k beside the kernels of scan k + 1) equal the blocking call
-    op = RadarOperator(config=over, luts=luts, output_variables='only_radar', device=0, distributed=True,
-                       gather_to=world - 1, lanes=2)
+    op = RadarOperator(config=over, luts=luts, output_variables='only_radar', device=local, distributed=True,
+                       gather_to=world - 1, lanes=3)
     op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
     rooted = op.get_PPI(elevations=[4.0, 6.0], azimuths=azs)
     sweeps = [[(azs, np.full(len(azs), e)) for e in els] for els in ([4.0, 6.0], [5.0, 7.0], [4.0, 6.0])]
-    pend = [op.submit_volume(sw, fields=['ZH', 'KDP', 'mask'], lane=i % 2) for i, sw in enumerate(sweeps)]
+    pend = [op.submit_volume(sw, fields=['ZH', 'KDP', 'mask'], lane=i % 3) for i, sw in enumerate(sweeps)]   # three scans pending
     got = [q.wait() for q in pend]
-    op.wait(0)
-    op.wait(1)
-    assert op._dist_runner().collective.startswith('all_gather_into_tensor / gloo')   # (gloo: no rooted device gather)
+    for i in range(3):
+        op.wait(i)
+    # (gloo has no rooted gather of device tensors: all-gather there, and still only the root assembles and copies)
+    assert op._dist_runner().collective.startswith('gather(dst=%d) / nccl' % (world - 1) if backend == 'nccl'
+                                                   else 'all_gather_into_tensor / gloo')
+    if rank == world - 1:
+        # torch (through the HIP runtime) sees the operator's page-locked result block as pinned: copy_(non_blocking=True) into it
+        # is an asynchronous DMA on the runner's stream, not a staged pageable copy
+        assert op._dist_runner().host_pinned is True
     if rank == world - 1:
         for k in b.fields:
             if k in rooted.fields:
@@ -82,7 +96,7 @@ def main():
     sw = gpm.synthetic_swath(n_scans=7, n_rays=5, cross_track_deg=4.0, scan_spacing_m=6000.0)   # 7 lines: uneven split
     swaths = []
     for distributed in (True, False):
-        op = RadarOperator(config=base, luts=provider, output_variables='only_radar', device=0,
+        op = RadarOperator(config=base, luts=provider, output_variables='only_radar', device=local,
                            distributed=distributed)
         op.load_model_arrays(cube2['data'], cube2['zlevels'], cube2['proj_info'], cube2['resolution'])
         swaths.append(op.get_GPM_swath(sw, 'Ku'))
@@ -97,7 +111,7 @@ def main():
     assert n_fin > 100
     dist.barrier()
     if rank == 0:
-        print('DIST_GPU_OK world=%d fields=%d swath_fields=%d' % (world, len(a.fields), len(sb.data)))
+        print('DIST_GPU_OK world=%d backend=%s fields=%d swath_fields=%d' % (world, backend, len(a.fields), len(sb.data)))
     dist.destroy_process_group()
 
 
