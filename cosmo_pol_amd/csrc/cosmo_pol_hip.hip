@@ -1214,10 +1214,7 @@ int cpol_stage_spectrum_tables(cpol_ctx *ctx, int slot, const float *rcs32, cons
     }
     HIPCHK(hipSetDevice(ctx->device));
     HydroDev &h = ctx->hs.h[slot];
-    if (h.d.psd_family == CPOL_PSD_MELTING) {
-        ctx->err = "cpol_stage_spectrum_tables: the Doppler spectrum covers power-law species only";
-        return CPOL_ERR_ARG;
-    }
+    // (melting species: rcs32 alone is read -- their diameter grid belongs to the gate's wet fraction, cpol_spectrum.inl)
     const size_t nr = (size_t)h.d.n_e * h.d.n_t * h.d.n_d;
     int rc;
     if ((rc = upload(ctx, ctx->d_rcs32[slot], rcs32, nr * sizeof(float))) != CPOL_OK) return rc;
@@ -1538,8 +1535,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     const bool dop3 = p->simulate_doppler == 3;
     const int n_vb = p->n_vbins;
     if (dop3) {
-        if (n_vb < 2 || n_vb > 4097 || !t->varray || p->var_rho < 0 || p->var_rho >= n_vars || p->with_melting) {
-            ctx->err = "cpol_run_sweep: Doppler scheme 3 needs n_vbins in [2, 4097], tables->varray, var_rho and no melting species";
+        if (n_vb < 2 || n_vb > 4097 || !t->varray || p->var_rho < 0 || p->var_rho >= n_vars) {
+            ctx->err = "cpol_run_sweep: Doppler scheme 3 needs n_vbins in [2, 4097], tables->varray and var_rho";
             return CPOL_ERR_ARG;
         }
         for (int j = 0; j < n_hyd; ++j) {
@@ -1549,7 +1546,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                 return CPOL_ERR_ARG;
             }
         }
-        if ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) * sizeof(float) > 64 * 1024) {
+        if (((size_t)2 * ctx->hs.h[0].d.n_d + 256) * sizeof(double) + ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) + n_vb) * sizeof(float) > 64 * 1024) {
             ctx->err = "cpol_run_sweep: Doppler scheme 3: n_hydro x (n_d + n_vbins) exceeds the LDS of a workgroup";
             return CPOL_ERR_ARG;
         }
@@ -2333,7 +2330,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sp.n_sbg = n_sbg; sp.n_gates = ng; sp.n_sub = n_sub; sp.n_h = n_h; sp.n_v = n_vb;
         sp.var_u = p->var_u; sp.var_v = p->var_v; sp.var_w = p->var_w; sp.var_rho = p->var_rho;
         sp.c_spec = (float)p->c_spectrum;
-        const size_t lds = (size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) * sizeof(float);
+        // [2][n_d] + [threads] float64 (melting species), [n_hyd][n_d] + [n_hyd + 1][n_v] float32 (cpol_spectrum.inl)
+        const size_t lds = ((size_t)2 * ctx->hs.h[0].d.n_d + CPOL_SPEC_THREADS) * sizeof(double)
+                           + ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) + n_vb) * sizeof(float);
         hipLaunchKernelGGL(k_spec_gate, dim3((unsigned)n_sbg), dim3(CPOL_SPEC_THREADS), lds, st, ctx->hs, ctx->ss, sp);
         if (p->with_attenuation) {
             SpecAttenArgs sa2{};

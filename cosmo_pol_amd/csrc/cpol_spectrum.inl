@@ -6,8 +6,13 @@
 //   get_refl                        scatter/doppler_c.c:11-32
 //   per-sub-beam attenuation, weights, accumulation   scatter/doppler_scatter.py:297-305, 353-391
 //   RVEL from the spectrum, aliasing                  scatter/doppler_scatter.py:422-437
-// Hydrometeors with power-law fall speeds only (R, S, G, H, I); the host refuses scheme 3
-// with the melting species.  float32 / float64 follow NumPy-2 promotion of the reference
+// Hydrometeors with power-law fall speeds (R, S, G, H, I) and, since round 6, the melting species (mS, mG): their fall
+// speed V(D) = phi V_rain(D_r(D)) + (1 - phi) V_dry(D) has no closed inverse, the reference inverts it at EVERY gate by
+// linear interpolation over the n_d nodes (V(D_k), D_k), D_k = linspace(d_min(fw), d_max(fw), n_d) -- `set_psd` clears the
+// interpolator, hydrometeors.py:1426,1474; get_D_from_V :480-500 -- and evaluates N(D) on the FLOAT32 copy of that grid with
+// NumPy's promotion rules (float32 powers of the float32 diameters, float64 wherever the float64 wet fraction enters:
+// melt_psd32 below follows the statements of hydrometeors.py:372-439 operand by operand).
+// float32 / float64 follow NumPy-2 promotion of the reference
 // statements (see oracle/cosmo_pol_oracle/spectrum.py); float32 libm values are float64
 // results rounded once.  Quirks kept: the diameter clamp of hydrometeor j also re-clamps
 // the columns before it (:583-586); the radar constant carries K^2 squared (:709); the
@@ -42,10 +47,71 @@ __device__ __forceinline__ float clamp_pair(float D, float d_min, float d_max)
     return D;
 }
 
+// a float32 matrix compared with the float64 limits of a melting species (shape (1,) arrays: the comparison promotes to float64,
+// the assignment rounds the limit to float32; doppler_scatter.py:585-586)
+__device__ __forceinline__ float clamp_pair64(float D, double d_min, double d_max)
+{
+    if ((double)D >= d_max) D = (float)d_max;
+    if ((double)D <= d_min) D = (float)d_min;
+    return D;
+}
+
+// NumPy's float32 power of a float32 array by a Python float (weak scalar -> float32): powf, taken as the float64 result
+// rounded once; x**2 is NumPy's square fast path
+__device__ __forceinline__ float powf32(float x, double y)
+{
+    if (y == 2.0) return x * x;
+    return (float)pow((double)x, (double)(float)y);
+}
+
+// The melting species at ONE gate (hydrometeors.py:303-478).  fw, lam_r, q: float64 as the classification left them.
+struct MeltGate {
+    double fw, fw2, phi, lam_r, q;
+    double d_min, d_max, step;       // the gate's diameter range and (d_max - d_min) / (n_d - 1)
+};
+
+// float64 diameter D: mass, D_r, fall speed; `Nraw` = rain N(D_r) V_rain(D_r) / V(D) dD_r/dD (get_N without prop_factor)
+__device__ __forceinline__ void melt_terms64(const cpol_hydro_desc &d, const MeltGate &g, double D, double &M, double &V, double &Nraw)
+{
+    const double pi6 = 3.14159265358979323846 / 6;
+    auto mass = [&](double x) { return g.fw2 * (d.r_a * pow(x, d.r_b)) + (1.0 - g.fw2) * (d.a * (d.b == 2.0 ? x * x : pow(x, d.b))); };
+    auto d_r = [&](double x) { return pow((mass(x) / (pi6 * pow(x, 3.0))) / 1.0e-6, 1 / 3.) * x; };     // RHO_W = 1e-6 kg mm-3
+    M = mass(D);
+    const double Dr = d_r(D);
+    const double dDr = (d_r(D + 0.01) - Dr) / 0.01;
+    const double sq = sqrt(Dr);                                             // rain: mu = beta = 0.5, nu = 1
+    const double Nr = (d.r_n0 * sq) * exp(-(g.lam_r * Dr));
+    const double Vr = d.r_alpha * sq;
+    const double Vd = d.alpha * pow(D, d.beta);
+    V = g.phi * Vr + (1 - g.phi) * Vd;
+    Nraw = Nr * Vr / V * dDr;
+}
+
+// float32 diameter D32 (a node of the float32 copy of the gate's grid): get_N as NumPy evaluates it on a float32 array --
+// a D^b, pi/6 D^3, alpha_dry D^beta_dry and D + 0.01 in float32; everything the float64 wet fraction touches in float64
+__device__ __forceinline__ double melt_psd32(const cpol_hydro_desc &d, const MeltGate &g, float D32, double prop)
+{
+    const float pi6_32 = (float)(3.14159265358979323846 / 6);
+    auto d_r = [&](float x) {
+        const float m_rain = (float)d.r_a * powf32(x, d.r_b), m_dry = (float)d.a * powf32(x, d.b);
+        const double M = g.fw2 * (double)m_rain + (1.0 - g.fw2) * (double)m_dry;
+        const float vol = pi6_32 * powf32(x, 3.0);
+        return pow((M / (double)vol) / 1.0e-6, 1 / 3.) * (double)x;
+    };
+    const double Dr = d_r(D32);
+    const double dDr = (d_r(D32 + 0.01f) - Dr) / 0.01;
+    const double sq = sqrt(Dr);
+    const double Nr = (d.r_n0 * sq) * exp(-(g.lam_r * Dr));
+    const double Vr = d.r_alpha * sq;
+    const float Vd = (float)d.alpha * powf32(D32, d.beta);
+    const double V = g.phi * Vr + (1 - g.phi) * (double)Vd;
+    return (prop * Nr) * Vr / V * dDr;
+}
+
 // one workgroup per sub-beam gate
 __global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, SpecSet ss, SpecArgs a)
 {
-    extern __shared__ float lds_spec[];
+    extern __shared__ __attribute__((aligned(16))) float lds_spec[];
     const long sbg = blockIdx.x;
     const int tid = threadIdx.x;
     const long n = a.n_sbg;
@@ -60,8 +126,16 @@ __global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, Sp
         if (a.key[(long)j * n + sbg] >= 0) present[n_p++] = j;
     if (n_p == 0) return;
     const int n_d = hs.h[present[0]].d.n_d;
-    float *prodL = lds_spec;                            // [n_p][n_d]
-    float *DL = lds_spec + (long)hs.n_hydro * n_d;        // [n_p][n_v]
+    // LDS: [2][n_d] float64 fall speeds of the (at most two) melting species + [CPOL_SPEC_THREADS] float64 scratch, then
+    // [n_hydro][n_d] float32 N x rcs, [n_hydro][n_v] float32 edge diameters
+    double *VL = reinterpret_cast<double *>(lds_spec);                        // [2][n_d]
+    double *redL = VL + 2 * (long)n_d;                                        // [CPOL_SPEC_THREADS]
+    float *prodL = reinterpret_cast<float *>(redL + CPOL_SPEC_THREADS);       // [n_p][n_d]
+    float *DL = prodL + (long)hs.n_hydro * n_d;                               // [n_p][n_v]
+    MeltGate mg[2];
+    int melt_of[CPOL_SPEC_MAX_H];                       // present species -> 0 / 1 (its row of VL), or -1
+    float dmin32[CPOL_SPEC_MAX_H], step32[CPOL_SPEC_MAX_H];
+    int n_melt = 0;
 
     // ---- N(D) x rcs per diameter bin (float32 product of float32 operands) ----
     for (int p = 0; p < n_p; ++p) {
@@ -72,6 +146,48 @@ __global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, Sp
         const SpecDev &sd = ss.s[j];
         const float *rcs = sd.rcs32 + (long)(key - h.key_base) * d.n_d;
         const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + sbg;
+        melt_of[p] = -1;
+        if (d.psd_family == CPOL_PSD_MELTING && n_melt < 2) {
+            // ---- a melting species: its grid, fall speeds and PSD belong to THIS gate's wet fraction ----
+            MeltGate &g = mg[n_melt];
+            g.q = P[0]; g.fw = P[n]; g.lam_r = P[2 * n];
+            g.fw2 = g.fw * g.fw;                                            // fw ** 2: NumPy's square
+            g.phi = 0.246 * g.fw + (1 - 0.246) * pow(g.fw, 7.0);
+            g.d_max = g.fw * d.r_dmax + (1 - g.fw) * d.s_dmax;              // hydrometeors.py:336-339
+            g.d_min = g.fw * d.r_dmin + (1 - g.fw) * d.s_dmin;
+            g.step = (g.d_max - g.d_min) / (double)(d.n_d - 1);
+            double *Vrow = VL + (long)n_melt * n_d;
+            // integrate_M on the float64 grid (vlinspace, utilities.py:158-173; :462-478) and, on the same nodes, the fall
+            // speeds of get_D_from_V (np.linspace: the same nodes but for the last, which is d_max itself)
+            double msum = 0.0;
+            for (int k = tid; k < d.n_d; k += CPOL_SPEC_THREADS) {
+                const double D = g.d_min + g.step * (double)k;
+                double M, V, Nraw;
+                melt_terms64(d, g, D, M, V, Nraw);
+                msum += Nraw * M;
+                if (k == d.n_d - 1 && D != g.d_max) { double M1, N1; melt_terms64(d, g, g.d_max, M1, V, N1); }
+                Vrow[k] = V;
+            }
+            redL[tid] = msum;
+            __syncthreads();
+            for (int off = CPOL_SPEC_THREADS / 2; off >= 1; off >>= 1) {
+                if (tid < off) redL[tid] += redL[tid + off];
+                __syncthreads();
+            }
+            const double dD = (g.d_min + g.step * 1.0) - (g.d_min + g.step * 0.0);
+            const double prop = g.q / (redL[0] * dD);                       // q / integrate_M (:1428, :1475)
+            __syncthreads();                                                // (redL is reused by the second melting species)
+            // the float32 grid of the spectrum: D[:, j] = np.linspace(d_min, d_max, n_d) stored as float32
+            const float D0 = (float)g.d_min, D1 = (float)(1.0 * g.step + g.d_min);
+            dmin32[p] = D0; step32[p] = D1 - D0;
+            for (int k = tid; k < d.n_d; k += CPOL_SPEC_THREADS) {
+                const float D32 = (k == d.n_d - 1) ? (float)g.d_max : (float)((double)k * g.step + g.d_min);
+                prodL[(long)p * n_d + k] = (float)melt_psd32(d, g, D32, prop) * rcs[k];
+            }
+            melt_of[p] = n_melt++;
+            continue;
+        }
+        dmin32[p] = sd.dgrid[0]; step32[p] = sd.step32;
         const double lam = P[0];
         const bool fixed_n0 = d.rule == CPOL_RULE_RAIN_1MOM || d.rule == CPOL_RULE_GRAUPEL_1MOM;
         const double N0 = (d.psd_family == CPOL_PSD_ICE_FIELD) ? P[3 * n] : (fixed_n0 ? d.n0_fixed : P[n]);
@@ -99,16 +215,48 @@ __global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, Sp
     const double U = (double)a.vals[(long)a.var_u * n + sbg], V = (double)a.vals[(long)a.var_v * n + sbg],
                  W = (double)a.vals[(long)a.var_w * n + sbg];
     const double horiz = (U * gc[0] + V * gc[1]) / (double)tan32;
+    float *okL = DL + (long)hs.n_hydro * a.n_v;         // [n_v] 1: wh >= 0 at this velocity (a row of the reference's D matrix)
+    __syncthreads();                                    // (VL complete)
     for (int v = tid; v < a.n_v; v += CPOL_SPEC_THREADS) {
         const double wh = (double)inv_rho * (W + horiz - a.varray[v] / (double)sin32);
         const bool ok = wh >= 0.0;
+        okL[v] = ok ? 1.0f : 0.0f;
         for (int p = 0; p < n_p; ++p) {
             const cpol_hydro_desc &d = hs.h[present[p]].d;
-            float D = ok ? (float)pow(wh / d.alpha, 1.0 / d.beta) : __builtin_nanf("");
+            float D = __builtin_nanf("");
+            if (ok && melt_of[p] < 0) {
+                D = (float)pow(wh / d.alpha, 1.0 / d.beta);
+            } else if (ok) {
+                // scipy.interpolate.interp1d(V_all, D_all, bounds_error=False, fill_value=nan) at wh (hydrometeors.py:494-500): for 1-D
+                // float64 data SciPy hands the evaluation to np.interp -- j with V_j <= wh < V_{j+1} by binary search, D_j when wh == V_j
+                // or j is the last node, else slope * (wh - V_j) + D_j -- and fills NaN outside [V_0, V_{n-1}]
+                const MeltGate &g = mg[melt_of[p]];
+                const double *Vrow = VL + (long)melt_of[p] * n_d;
+                if (!(wh < Vrow[0]) && !(wh > Vrow[d.n_d - 1])) {
+                    int lo_i = 0, hi_i = d.n_d;                            // first index with V > wh
+                    while (lo_i < hi_i) {
+                        const int mid = (lo_i + hi_i) >> 1;
+                        if (Vrow[mid] <= wh) lo_i = mid + 1; else hi_i = mid;
+                    }
+                    const int j = max(0, lo_i - 1);
+                    const double y_j = (j == d.n_d - 1) ? g.d_max : (double)j * g.step + g.d_min;
+                    if (j == d.n_d - 1 || Vrow[j] == wh) {
+                        D = (float)y_j;
+                    } else {
+                        const double y_n = (j + 1 == d.n_d - 1) ? g.d_max : (double)(j + 1) * g.step + g.d_min;
+                        const double slope = (y_n - y_j) / (Vrow[j + 1] - Vrow[j]);
+                        D = (float)(slope * (wh - Vrow[j]) + y_j);
+                    }
+                }
+            }
             if (ok)
-                for (int q = p; q < n_p; ++q) {           // clamps of this and the later species
-                    const SpecDev &sq = ss.s[present[q]];
-                    D = clamp_pair(D, sq.dgrid[0], sq.dgrid[hs.h[present[q]].d.n_d - 1]);
+                for (int q = p; q < n_p; ++q) {           // clamps of this and the later species (a NaN stays a NaN)
+                    if (melt_of[q] >= 0) {
+                        D = clamp_pair64(D, mg[melt_of[q]].d_min, mg[melt_of[q]].d_max);
+                    } else {
+                        const SpecDev &sq = ss.s[present[q]];
+                        D = clamp_pair(D, sq.dgrid[0], sq.dgrid[hs.h[present[q]].d.n_d - 1]);
+                    }
                 }
             DL[(long)p * a.n_v + v] = D;
         }
@@ -117,22 +265,24 @@ __global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, Sp
 
     // ---- rows = consecutive valid edges; sum N x rcs over [Da, Db) per species ----
     for (int v = tid; v + 1 < a.n_v; v += CPOL_SPEC_THREADS) {
-        const float e0 = DL[v], e1 = DL[v + 1];
-        if (!(e0 == e0) || !(e1 == e1)) continue;         // wh < 0 or NaN at one of the edges
+        if (okL[v] == 0.0f || okL[v + 1] == 0.0f) continue;   // wh < 0 at one of the edges: not a row of the D matrix
         bool keep = false;
         float refl = 0.0f;
         for (int p = 0; p < n_p; ++p) {
-            const SpecDev &h = ss.s[present[p]];
             const float x0 = DL[(long)p * a.n_v + v], x1 = DL[(long)p * a.n_v + v + 1];
+            // np.minimum / np.maximum propagate a NaN (a melting species outside its interpolator) to BOTH edges; (Db - Da) == 0
+            // is then false -- the row is kept -- and the two (int) conversions of doppler_c.c give the same index: an empty bin
+            const bool nan_edge = !(x0 == x0) || !(x1 == x1);
             const float Da = fminf(x0, x1), Db = fmaxf(x0, x1);
-            if (Db - Da != 0.0f) keep = true;
-            int ia = (int)((Da - h.dgrid[0]) / h.step32);
-            int ib = (int)((Db - h.dgrid[0]) / h.step32);
+            if (nan_edge || Db - Da != 0.0f) keep = true;
+            if (nan_edge) continue;
+            int ia = (int)((Da - dmin32[p]) / step32[p]);
+            int ib = (int)((Db - dmin32[p]) / step32[p]);
             ia = max(0, min(ia, n_d));
             ib = max(0, min(ib, n_d));
             float sum = 0.0f;
             for (int k = ia; k < ib; ++k) sum += prodL[(long)p * n_d + k];
-            refl += sum * h.step32;
+            refl += sum * step32[p];
         }
         if (keep) out[v] = refl * a.c_spec;
     }

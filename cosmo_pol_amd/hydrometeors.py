@@ -210,11 +210,13 @@ def spectrum_tables(h, scheme, lut):
     cross sections rcs = 2 pi (Z11 - Z12 - Z21 + Z22) of every table slice and bin, and
     the float32 grid D = np.linspace(d_min, d_max, n_d) with D**mu, D**nu evaluated as
     NumPy does on float32 arrays.  Returns (rcs32 [n_e, n_t, n_d], dgrid [3, n_d])."""
-    if h in ('mS', 'mG'):
-        raise NotImplementedError('Doppler scheme 3 covers the power-law species only')
-    c = _consts(h, scheme)
     t = np.asarray(lut.value_table, dtype=np.float64)
     rcs = (2 * np.pi * (t[..., 0] - t[..., 1] - t[..., 2] + t[..., 3])).astype(np.float32)
+    if h in ('mS', 'mG'):
+        # melting species: the cross sections of every (elevation, wet fraction) slice alone -- the diameter grid and N(D)
+        # belong to the wet fraction of the gate and are evaluated by the kernel (cpol_spectrum.inl)
+        return np.ascontiguousarray(rcs), np.zeros((3, t.shape[2]), dtype=np.float32)
+    c = _consts(h, scheme)
     d_ax = np.asarray(lut.axes[lut.axes_names['d']])
     D = np.zeros(t.shape[2], dtype='float32')
     D[:] = np.linspace(d_ax[0], d_ax[-1], t.shape[2])

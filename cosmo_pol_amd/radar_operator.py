@@ -353,12 +353,9 @@ class RadarOperator(object):
         scheme = conf['microphysics']['scheme']
         self.current_microphys_scheme = scheme
         hl = hyd.hydrometeor_list(conf)
+        # (Doppler scheme 3 with the melting scheme, round 6: the fall speed of a melting species is inverted gate by gate
+        # through the reference's linear interpolator over (V(D_k), D_k), hydrometeors.py:480-500 -- cpol_spectrum.inl)
         spectrum = conf['doppler']['scheme'] == 3
-        if spectrum and conf['microphysics']['with_melting']:
-            raise NotImplementedError(
-                'Doppler scheme 3 (Doppler spectrum) with the melting scheme: the reference inverts '
-                'the fall speed of the melting species through an interpolator that is built '
-                'once from the first gate it meets (hydrometeors.py:480-500); not reproduced')
         key = (scheme, conf['radar']['frequency'], conf['microphysics']['scattering'], tuple(hl),
                conf['doppler']['scheme'] == 2, spectrum)
         cache = self.__dict__.setdefault('_lut_cache', {})
@@ -593,8 +590,8 @@ class RadarOperator(object):
             p.with_attenuation = int(conf['microphysics']['with_attenuation'])
             p.integrate_model = int(want_model)
             p.outputs_on_device = 1 if device_outputs is not None else 2     # host outputs: page-locked, one copy
-            # Doppler schemes 1 (analytic mean fall speed) and 2 (rcs-weighted); none for GPM
-            # (doppler_scatter.py:83-87); scheme 3 (full spectrum) is out of scope
+            # Doppler schemes 1 (analytic mean fall speed), 2 (rcs-weighted) and 3 (the full spectrum); none for GPM
+            # (doppler_scatter.py:83-87)
             doppler = (conf['doppler']['scheme'] in (1, 2, 3) and conf['radar'].get('type') != 'GPM'
                        and mode != N.GEOM_SPACEBORNE)
             spectrum = doppler and conf['doppler']['scheme'] == 3

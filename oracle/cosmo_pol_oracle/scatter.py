@@ -81,8 +81,6 @@ def radar_observables(subbeams, luts, config, return_sz=False, doppler=True, nyq
     n_gates = max([len(sb.dist_profile) for sb in subbeams])
     if simulate_doppler and dop_scheme == 3:
         from . import spectrum as SP
-        if melting:
-            raise NotImplementedError('oracle: Doppler scheme 3 with melting species')
         varray = SP.velocity_array(config)
         doppler_spectrum = np.zeros((n_gates, len(varray)))
 

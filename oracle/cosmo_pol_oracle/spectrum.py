@@ -1,8 +1,15 @@
 """Oracle Doppler spectrum, Doppler scheme 3 (TEST INFRASTRUCTURE ONLY).
 
-Restates, for hydrometeors with power-law fall speeds (R, S, G, H, I; the melting
-species go through a lazily built, gate-dependent interpolator upstream and are not
-restated):
+Restates, for hydrometeors with power-law fall speeds (R, S, G, H, I) and -- round 6 -- for the
+melting species (mS, mG), whose fall speed is inverted through a linear interpolator over
+(V(D_k), D_k) that the reference rebuilds at EVERY gate: `set_psd` clears `vd_interpolator`
+(cosmo_pol/hydrometeors/hydrometeors.py:1426, 1474), `get_D_from_V` (:480-500) builds it from
+the gate's wet fraction.  The reference's melting branch needs NumPy < 1.16 (`np.linspace` with
+one-element array endpoints, doppler_scatter.py:687) and drops mS / mG from a sub-beam without
+melting through `dict.keys().remove`, which raises under Python 3 (:343-349): the goldens
+`radial_d3_melt*` come from the reference under oracle/ref_shim.py::numpy1_linspace on radials
+whose sub-beams all cross the melting layer; a sub-beam without melting is restated as intended
+(mS / mG skipped):
   get_diameter_from_rad_vel   cosmo_pol/scatter/doppler_scatter.py:545-600
   get_doppler_spectrum        :603-716
   get_refl                    cosmo_pol/scatter/doppler_c.c:11-32 (float32, sequential sums)
@@ -32,6 +39,42 @@ def velocity_array(config):
     return np.arange(-nvel, nvel + vres, vres)
 
 
+def interp1d_linear(x, y, x_new):
+    """scipy.interpolate.interp1d(x, y, kind='linear', bounds_error=False, fill_value=nan,
+    assume_sorted=False) restated (what hydrometeors.py:494-500 builds and calls).  For 1-D float64 data
+    SciPy (0.17 to 1.15 alike) sorts by x (stable) and hands the evaluation to `np.interp`
+    (interp1d._call_linear_np), then overwrites the queries outside [x[0], x[-1]] with the fill value.
+    np.interp (numpy/_core/src/multiarray/compiled_base.c::arr_interp): j with x[j] <= q < x[j+1] by binary
+    search, y[j] when q == x[j] or j is the last node, else slope * (q - x[j]) + y[j] with
+    slope = (y[j+1] - y[j]) / (x[j+1] - x[j]); a NaN query stays NaN."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    order = np.argsort(x, kind='mergesort')
+    x, y = x[order], y[order]
+    q = np.asarray(x_new, dtype=np.float64)
+    n = len(x)
+    j = np.clip(np.searchsorted(x, q, side='right') - 1, 0, n - 1)
+    jn = np.minimum(j + 1, n - 1)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        slope = (y[jn] - y[j]) / (x[jn] - x[j])
+        out = slope * (q - x[j]) + y[j]
+        # "if we get nan in one direction, try the other" (compiled_base.c)
+        other = slope * (q - x[jn]) + y[jn]
+        out = np.where(np.isnan(out), np.where(np.isnan(other) & (y[j] == y[jn]), y[j], other), out)
+    exact = (j == n - 1) | (x[j] == q)
+    out = np.where(exact, y[j], out)
+    out = np.where(np.isnan(q), q, out)
+    out[(q < x[0]) | (q > x[-1])] = np.nan
+    return out
+
+
+def melting_diameter_from_velocity(h, wh):
+    """get_D_from_V of a melting species (hydrometeors.py:480-500) for the wet fraction `h` holds now."""
+    D_all = np.linspace(np.min(h.d_min), np.max(h.d_max), h.nbins_D)
+    V_all = np.squeeze(h.get_V(D_all))
+    return interp1d_linear(V_all, D_all, wh)
+
+
 def diameters_from_radial_velocity(hyds, limits, varray, phi_deg, theta_deg, U, V, W, rho_corr):
     theta = np.deg2rad(theta_deg)
     phi = np.deg2rad(phi_deg)
@@ -42,7 +85,10 @@ def diameters_from_radial_velocity(hyds, limits, varray, phi_deg, theta_deg, U, 
         wh = wh[idx]
         D = np.zeros((len(idx), len(hyds)), dtype='float32')
         for i, h in enumerate(hyds):
-            D[:, i] = (wh / h.alpha) ** (1. / h.beta)
+            if hasattr(h, 'alpha'):
+                D[:, i] = (wh / h.alpha) ** (1. / h.beta)
+            else:                          # melting species: NaN outside the tabulated fall speeds stays NaN below
+                D[:, i] = melting_diameter_from_velocity(h, wh)
             d_min, d_max = limits[i]
             D[D >= d_max] = d_max          # whole matrix (quirk)
             D[D <= d_min] = d_min
@@ -60,8 +106,11 @@ def bin_reflectivities(Da, Db, rcs, N, step_D, D_min):
     with np.errstate(invalid='ignore', over='ignore'):
         ia = ((Da - D_min[None, :]) / step_D[None, :]).astype(F32)
         ib = ((Db - D_min[None, :]) / step_D[None, :]).astype(F32)
-    ia = ia.astype(np.int64)                 # (int) truncation
-    ib = ib.astype(np.int64)
+        # (int) truncation; a NaN edge (melting species, fall speed outside the interpolator) converts to INT_MIN on
+        # x86-64 for BOTH edges (np.minimum / np.maximum propagate it to Da and Db alike): an empty bin
+        nan_edge = np.isnan(ia) | np.isnan(ib)
+        ia = np.where(nan_edge, 0, ia).astype(np.int64)
+        ib = np.where(nan_edge, 0, ib).astype(np.int64)
     for r in range(n_rows):
         for j in range(n_h):
             s = F32(0)
@@ -86,11 +135,15 @@ def subbeam_spectrum(sb, hydro_names, luts, config, varray):
     with np.errstate(invalid='ignore', divide='ignore'):
         rho_corr = (sb.values['RHO'] / sb.values['RHO'][0]) ** 0.5
     objs = {}
+    if not getattr(sb, 'has_melting', True):
+        # (intended behaviour of doppler_scatter.py:343-349; as written it raises under Python 3)
+        hydro_names = [h for h in hydro_names if h not in ('mS', 'mG')]
     for h in hydro_names:
         objs[h] = create_hydrometeor(h, scheme)
         d_ax = luts[h].axes[2]
         objs[h].nbins_D = luts[h].value_table.shape[-2]
-        objs[h].d_min, objs[h].d_max = d_ax[0], d_ax[-1]
+        if h not in ('mS', 'mG'):          # (melting: set by the wet fraction of the gate, hydrometeors.py:332-339)
+            objs[h].d_min, objs[h].d_max = d_ax[0], d_ax[-1]
     for i in range(n_gates):
         if sb.mask[i] != 0:
             continue
@@ -103,7 +156,11 @@ def subbeam_spectrum(sb, hydro_names, luts, config, varray):
             if Q > 0:
                 present.append(h)
                 if scheme == '1mom':
-                    if h in ['S', 'I']:
+                    if h == 'mG':
+                        objs[h].set_psd(np.array([Q]), np.array([sb.values['fwet_' + h][i]]))
+                    elif h == 'mS':
+                        objs[h].set_psd(np.array([T]), np.array([Q]), np.array([sb.values['fwet_' + h][i]]))
+                    elif h in ['S', 'I']:
                         objs[h].set_psd(np.array([T]), np.array([Q]))
                     else:
                         objs[h].set_psd(np.array([Q]))
@@ -118,11 +175,15 @@ def subbeam_spectrum(sb, hydro_names, luts, config, varray):
         step_D = np.zeros((n_h), dtype='float32') + np.nan
         with np.errstate(invalid='ignore', over='ignore', divide='ignore'):
             for j, h in enumerate(present):
-                D[:, j] = np.linspace(objs[h].d_min, objs[h].d_max, objs[h].nbins_D)
+                # (melting: d_min / d_max have shape (1,); NumPy < 1.16's linspace gave shape (n_d,) for them)
+                D[:, j] = np.linspace(np.ravel(objs[h].d_min)[0], np.ravel(objs[h].d_max)[0], objs[h].nbins_D)
                 D_min[j] = D[0, j]
                 step_D[j] = D[1, j] - D[0, j]
                 N[:, j] = objs[h].get_N(D[:, j])
-                sz = luts[h].lookup_line(e=elev_lut[i], t=T)
+                if h in ('mS', 'mG'):
+                    sz = luts[h].lookup_line(e=elev_lut[i], wc=sb.values['fwet_' + h][i])
+                else:
+                    sz = luts[h].lookup_line(e=elev_lut[i], t=T)
                 rcs[:, j] = (2 * np.pi * (sz[:, 0] - sz[:, 1] - sz[:, 2] + sz[:, 3])).T
         Da, Db, idx = diameters_from_radial_velocity(
             [objs[h] for h in present], [(objs[h].d_min, objs[h].d_max) for h in present], varray,

@@ -326,6 +326,22 @@ RADIAL_CASES.update({
                     'integration': {'nh_GH': 1, 'nv_GH': 3}}, 75.0, 8.0, ('R', 'S', 'G', 'I'), True),
 })
 
+# Doppler scheme 3 WITH the melting scheme (round 6): the fall speed of a melting species is inverted
+# through an interpolator rebuilt at every gate (set_psd clears it, hydrometeors.py:1426,1474; get_D_from_V :480-500).
+# Every sub-beam of these radials crosses the melting layer: the reference drops mS / mG from a sub-beam without melting
+# with `dict.keys().remove`, which raises under Python 3 (doppler_scatter.py:343-349).
+RADIAL_CASES.update({
+    # (30 / 40 deg elevation: the fall-speed spread of the melting particles projects onto several velocity bins per gate)
+    'd3_melt': ({'radar': {'range': 9000, 'radial_resolution': 100, 'FFT_length': 64},
+                 'microphysics': {'with_ice_crystals': 0, 'with_melting': 1},
+                 'doppler': {'scheme': 3},
+                 'integration': {'nh_GH': 1, 'nv_GH': 1}}, 120.0, 30.0, ('R', 'S', 'G'), False),
+    'd3_melt_ice_sub': ({'radar': {'range': 7500, 'radial_resolution': 150, 'FFT_length': 32},
+                         'microphysics': {'with_ice_crystals': 1, 'with_melting': 1},
+                         'doppler': {'scheme': 3},
+                         'integration': {'nh_GH': 3, 'nv_GH': 1}}, 300.0, 40.0, ('R', 'S', 'G', 'I'), False),
+})
+
 LUT_KW = dict(seed=20260301, n_e=8, n_t=None)
 
 
@@ -403,7 +419,13 @@ def gen_radials(out, only_cases=None):
         for h in hl:
             n_valid[h] = int(sum(np.sum(np.asarray(s.values['Q' + h + '_v']) > 0) for s in subs
                                  if not (h in ('mS', 'mG') and not s.has_melting)))
-        obs = get_radar_observables(subs, luts)
+        if name.startswith('d3_melt'):
+            # (the reference's melting branch of the spectrum needs NumPy < 1.16's np.linspace: oracle/ref_shim.py)
+            with ref_shim.numpy1_linspace():
+                obs = get_radar_observables(subs, luts)
+            d['numpy1_linspace'] = 1
+        else:
+            obs = get_radar_observables(subs, luts)
         for n in obs.values:
             d['obs_' + n] = np.asarray(obs.values[n])
         d['obs_mask'] = obs.mask

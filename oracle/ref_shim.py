@@ -218,6 +218,33 @@ def load_reference():
     return cosmo_pol
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def numpy1_linspace():
+    """NumPy < 1.16 semantics of `np.linspace` for ONE-ELEMENT array endpoints, for the duration of a reference call.
+
+    The 2017 code writes `D[:, j] = np.linspace(h.d_min, h.d_max, h.nbins_D)` with `d_min`, `d_max` of shape (1,) for the
+    melting species (doppler_scatter.py:687-689; the `f_wet` setter, hydrometeors.py:335-342).  The NumPy it was written
+    for computed `arange(num) * step + start` and returned shape (num,); NumPy >= 1.16 returns (num, 1) and the assignment
+    raises ValueError -- Doppler scheme 3 with the melting scheme is dead under this container's NumPy 2.2.  Same
+    arithmetic (arange * step + start, last element = stop), only the shape of the result differs.  Used by
+    oracle/gen_golden.py for the `d3_melt*` cases ONLY, and said so in their fixtures (`numpy1_linspace` = 1)."""
+    real = np.linspace
+
+    def linspace(start, stop, num=50, *args, **kw):
+        s, e = np.asarray(start), np.asarray(stop)
+        if s.shape == (1,) and e.shape == (1,):
+            return real(s[0], e[0], num, *args, **kw)
+        return real(start, stop, num, *args, **kw)
+    np.linspace = linspace
+    try:
+        yield
+    finally:
+        np.linspace = real
+
+
 class KeyListDict(dict):
     """dict whose keys()/values() return lists (py2 idiom the reference uses,
     interpolation.py:118-119,411)."""

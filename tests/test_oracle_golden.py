@@ -219,3 +219,21 @@ def test_aliasing(golden):
         got = scatter.aliasing(g['v'].copy(), float(g['nyq_%d' % i]))
         np.testing.assert_allclose(got, g['folded_%d' % i], rtol=0, atol=1e-12)
         assert np.all(np.abs(got) <= float(g['nyq_%d' % i]) + 1e-9)
+
+
+def test_interp1d_restatement_equals_scipy():
+    """oracle/cosmo_pol_oracle/spectrum.py::interp1d_linear restates what hydrometeors.py:494-500 asks of SciPy
+    (interp1d, linear, bounds_error=False, fill_value=nan, assume_sorted=False): same bits on sorted, unsorted and
+    out-of-range queries, repeated abscissae aside (the fall-speed table of a melting species is strictly increasing)."""
+    from scipy.interpolate import interp1d
+    from cosmo_pol_oracle import spectrum as SP
+    rng = np.random.default_rng(20261005)
+    for n in (2, 3, 17, 1024):
+        x = np.cumsum(rng.uniform(1e-3, 1.0, n))
+        y = rng.normal(size=n)
+        perm = rng.permutation(n)
+        q = np.concatenate([rng.uniform(x[0] - 1, x[-1] + 1, 500), x, [x[0], x[-1], np.nan]])
+        for xs, ys in ((x, y), (x[perm], y[perm])):
+            ref = interp1d(xs, ys, bounds_error=False, fill_value=np.nan, assume_sorted=False, copy=False)(q)
+            got = SP.interp1d_linear(xs, ys, q)
+            assert np.array_equal(ref, got, equal_nan=True), n
