@@ -323,6 +323,12 @@ def compact_line(d):
         out['value_host_outputs'] = ho.get('value')
         out['host_outputs_ms_per_sweep'] = ho.get('ms_per_sweep')
         out['host_outputs_ms_per_sweep_repeats'] = ho.get('ms_per_sweep_repeats')
+        out['host_outputs_d2h_bytes_per_step'] = ho.get('d2h_bytes_per_step')
+        out['host_outputs_d2h_GBs'] = ho.get('d2h_GBs')
+        if (ho.get('with_float64_mask_from_the_device') or {}).get('value'):
+            out['value_host_outputs_f64_mask'] = ho['with_float64_mask_from_the_device']['value']
+        if (d.get('host_outputs_new_geometry') or {}).get('value'):
+            out['value_host_outputs_new_geometry'] = d['host_outputs_new_geometry']['value']
         if ho.get('value') and cpu and cpu.get('value'):
             out['host_outputs_over_cpu_core'] = ho['value'] / cpu['value']
     for k in ('ms_per_sweep', 'value_definition', 'c4_speedup_vs_single_gpu', 'c4_speedup_single_volume', 'c4_gather_check',
@@ -592,7 +598,7 @@ def stage_ms_of(c):
             'final': c.ms_final}
 
 
-def check_last_sweep(env, slabs, els, az, k_last, n_buf, n_lanes, n_cycle):
+def check_last_sweep(env, slabs, rvel_slabs, els, az, k_last, n_buf, n_lanes, n_cycle):
     """`result_check` of the line (round-5 review, item 1b): what the LAST sweep of the timed region left in HBM -- which launch
     forms it took, read from the library -- against (i) the host-output hand-over of the same elevation (`step_full`'s call:
     NaN pattern equal, <= 1e-5; it is the same arithmetic, so the expected answer is "bitwise") and (ii), when the CPU legs
@@ -603,6 +609,7 @@ def check_last_sweep(env, slabs, els, az, k_last, n_buf, n_lanes, n_cycle):
     forms = op._lane(lane).launch_forms()
     el = els[(k_last + rank) % n_cycle]
     got = slabs[k_last % n_buf].cpu().numpy()
+    got_rvel = rvel_slabs[k_last % n_buf].cpu().numpy()
     with contextlib.redirect_stdout(sys.stderr):
         host = op.simulate_rays(az, el, lane=0)
     out = {'sweep': 'the last of the timed region (lane %d, elevation %.2f deg)' % (lane, float(el[0])), 'launch_forms': forms,
@@ -616,7 +623,11 @@ def check_last_sweep(env, slabs, els, az, k_last, n_buf, n_lanes, n_cycle):
         bitwise = bitwise and bool(np.array_equal(got[i], host[f], equal_nan=True))
         worst = max(worst, rel)
         out['ok'] = out['ok'] and same_nan and rel <= 1e-5
-    out['vs_host_outputs'] = {'bitwise': bitwise, 'worst_rel': worst, 'n_finite_ZH': int(np.isfinite(got[0]).sum())}
+    rv_same = bool(np.array_equal(got_rvel, host['RVEL'], equal_nan=True))
+    bitwise = bitwise and rv_same
+    out['ok'] = out['ok'] and rv_same
+    out['vs_host_outputs'] = {'bitwise': bitwise, 'worst_rel': worst, 'n_finite_ZH': int(np.isfinite(got[0]).sum()),
+                              'RVEL_bitwise': rv_same}
     out['ok'] = out['ok'] and out['vs_host_outputs']['n_finite_ZH'] > 0
     if args.cpu_seconds > 0:
         from cosmo_pol_oracle import beam, scatter
@@ -642,6 +653,12 @@ def check_last_sweep(env, slabs, els, az, k_last, n_buf, n_lanes, n_cycle):
     return out
 
 
+def LazyMaskProbe(res):
+    """Builds the float64 mask of a pinned result from its one-byte form once more (timing probe of run_c2)."""
+    from cosmo_pol_amd.radar_operator import _mask_from_sum
+    return _mask_from_sum(res['mask_sum8'], res['n_sub'])()
+
+
 def run_c2(env):
     from cosmo_pol_amd import RadarOperator
     op, lanes, n_lanes, world, rank = env['op'], env['lanes'], env['n_lanes'], env['world'], env['rank']
@@ -663,18 +680,28 @@ def run_c2(env):
     slabs = [torch.empty((len(RADAR_FIELDS), n_rays, n_gates), dtype=torch.float32, device=dev)
              for _ in range(n_buf)]
     dev_outs = [{k: sl[i].data_ptr() for i, k in enumerate(RADAR_FIELDS)} for sl in slabs]
+    # (round 6: the tenth field, the float64 radial velocity, is left in HBM too -- it was computed all along, into a buffer of
+    # the library's own; the nine float32 observables alone travel in the all-gather that ends an N > 1 region)
+    rvel_slabs = [torch.empty((n_rays, n_gates), dtype=torch.float64, device=dev) for _ in range(n_buf)]
+    for d_o, rv in zip(dev_outs, rvel_slabs):
+        d_o['RVEL'] = rv.data_ptr()
     gathered = torch.empty(world * slabs[0].numel(), dtype=torch.float32, device=dev) if weak else None
     lane_streams = [torch.cuda.ExternalStream(l.stream_ptr(), device=dev) for l in lanes] if weak else None
     comm_stream = torch.cuda.Stream() if weak else None
     last_gathered_step = [None]
     n_cycle = 8                               # elevations of the headline step (= the host cache of per-ray constants)
+    # cycles of the 8 elevations per step (round 6: 10 -> a step = 80 sweeps, the driver's 20 steps = 1 600 sweeps = ~55 ms of GPU
+    # time per repeat instead of 5.5 ms; `ms_per_sweep` stays the figure to compare across rounds)
+    cycles_per_step = max(1, int(os.environ.get('CPOL_BENCH_CYCLES_PER_STEP', '2' if args.small else '10')))
+    sweeps_per_step = n_cycle * cycles_per_step
 
     def step_hbm():
-        """The headline step: ONE CYCLE of the 8 elevations -- 8 sweeps of the configs[1] PPI, each at another elevation
-        (per-ray constants held by the host, table sets resident on the device), all kernels, the ten radar fields of
-        every sweep left in HBM.  (A step of one sweep lasts 43 us: 20 of them are too short a timed region, and the
-        one all-gather that ends the region at N > 1 would outweigh them.)"""
-        for _ in range(n_cycle):
+        """The headline step: `cycles_per_step` CYCLES of the 8 elevations -- sweeps of the configs[1] PPI, each at another
+        elevation than the one before (per-ray constants held by the host, table sets resident on the device), all kernels,
+        the ten radar fields of every sweep left in HBM.  (A sweep lasts ~34 us: the driver's 20 steps of one cycle were a
+        5.5-ms timed region, which its utilisation sampler never saw; and the one all-gather that ends the region at N > 1
+        would outweigh a shorter region.)"""
+        for _ in range(sweeps_per_step):
             k = counter[0]
             counter[0] += 1
             op.simulate_rays(az, els[(k + rank) % n_cycle], device_outputs=dev_outs[k % n_buf], lane=k % n_lanes)
@@ -748,9 +775,9 @@ def run_c2(env):
     elapsed = statistics.median(e for e, _ in runs)
     t_submit = statistics.median(s for _, s in runs)
     gates_per_sweep = world * n_rays * n_gates
-    gates_per_step = n_cycle * gates_per_sweep
+    gates_per_step = sweeps_per_step * gates_per_sweep
     value = gates_per_step * args.steps / elapsed
-    result_check = check_last_sweep(env, slabs, els, az, counter[0] - 1, n_buf, n_lanes, n_cycle) if rank == 0 else None
+    result_check = check_last_sweep(env, slabs, rvel_slabs, els, az, counter[0] - 1, n_buf, n_lanes, n_cycle) if rank == 0 else None
 
     # rank 0 recomputes the last sweep of every rank and compares it with the gathered block, bit for bit
     gather_ok = None
@@ -768,8 +795,57 @@ def run_c2(env):
 
     extra = {}
     iso = cnt = None
-    d2h_full = n_rays * n_gates * (len(RADAR_FIELDS) * 4 + 8 + 8 + 8 + 8 + 4 + 4)
+    mask_b = 1 if getattr(op, 'compact_mask', False) else 8          # the radial mask crosses PCIe as one byte per gate (round 6)
+    d2h_full = n_rays * n_gates * (len(RADAR_FIELDS) * 4 + 8 + mask_b + 8 + 8 + 4 + 4)     # 9 observables, RVEL, mask, lats, lons, dist, heights
+    d2h_cycle = n_rays * n_gates * (len(RADAR_FIELDS) * 4 + 8 + mask_b)                    # ... of a repeated geometry: the gate coordinates are the host's
     if not weak:
+        # THE SURVEY 8(d) STEP ON A REPEATED SCAN GEOMETRY (round 6; `value_host_outputs`): a volume scan cycles through its
+        # elevations -- a radar repeats its scan strategy every few minutes -- so the host holds the per-ray constants of the
+        # 8 elevations, the device their tables, and the gate coordinates (lats, lons, dist, heights: functions of site,
+        # azimuth and elevation alone) were copied ONCE per table set: every later result carries the same read-only arrays.
+        # All 15 arrays are delivered; 11 cross PCIe (9 observables, RVEL, the mask as one byte per gate).
+        def step_host_cycle():
+            k = counter[0]
+            counter[0] += 1
+            return op.simulate_rays(az, els[(k + rank) % n_cycle], pinned=True, lane=k % n_lanes)
+        for _ in range(max(4 * n_cycle, 4 * args.steps)):
+            last_host = step_host_cycle()
+        fence()
+        assert all(k in last_host for k in RADAR_FIELDS + ['RVEL', 'mask', 'lats', 'lons', 'dist', 'heights'])
+        settle_c = [timed(step_host_cycle, n_cycle * args.steps) for _ in range(2)]
+        runs_c = [timed(step_host_cycle, n_cycle * args.steps) for _ in range(max(1, args.repeats))]
+        e_cy = statistics.median(e for e, _ in runs_c)
+        n_sw = n_cycle * args.steps
+        extra['host_outputs'] = {
+            'value': gates_per_sweep * n_sw / e_cy, 'unit': 'gates/s', 'ms_per_sweep': 1e3 * e_cy / n_sw,
+            'sweeps_timed': n_sw, 'ms_per_sweep_repeats': [1e3 * e / n_sw for e, _ in runs_c],
+            'ms_per_sweep_settling_regions_not_counted': [1e3 * e / n_sw for e, _ in settle_c],
+            'host_submit_ms_per_sweep': 1e3 * statistics.median(t for _, t in runs_c) / n_sw,
+            'd2h_bytes_per_step': d2h_cycle, 'd2h_GBs': d2h_cycle * n_sw / e_cy / 1e9,
+            'arrays_delivered': 15, 'arrays_copied_per_sweep': 11,
+            'note': 'SURVEY 8(d) step on a repeated scan geometry: the 8 elevations of the headline step in turn, every result '
+                    'handed over as the reference hands it over (all 15 arrays in host memory); the gate coordinates of a '
+                    'table set are copied once and shared read-only between results, the mask crosses PCIe as one byte per '
+                    'gate and becomes float64 on first read; PCIe-bound.  `host_outputs_new_geometry`: a NEW geometry every '
+                    'step (rounds 1-5\'s definition)'}
+        # the same step with the mask as the device's float64 array (8 bytes per gate over PCIe, nothing left to do on the host),
+        # and what making the float64 mask from its bytes costs the thread that reads it
+        op.compact_mask = False
+        for _ in range(2 * n_cycle):
+            step_host_cycle()
+        fence()
+        runs_f = [timed(step_host_cycle, n_cycle * args.steps) for _ in range(3)]
+        op.compact_mask = True
+        e_f = statistics.median(e for e, _ in runs_f)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            last_host._data['mask'] = LazyMaskProbe(last_host)
+        extra['host_outputs']['with_float64_mask_from_the_device'] = {
+            'value': gates_per_sweep * n_sw / e_f, 'ms_per_sweep': 1e3 * e_f / n_sw,
+            'd2h_bytes_per_step': d2h_cycle + 7 * n_rays * n_gates}
+        extra['host_outputs']['mask_widening_ms_per_sweep_when_read'] = 1e3 * (time.perf_counter() - t0) / 5
+        del last_host
+
         # the step with the reference's hand-over (host arrays), PCIe included: rounds 1-3's headline
         op.reuse_device_tables = False          # nothing of the scan geometry stays on the device
         for _ in range(max(2 * n_lanes, 8 * args.steps)):      # (its page-locked blocks and staging slots exist after ~150 sweeps)
@@ -784,7 +860,7 @@ def run_c2(env):
         runs_h = [timed(step_full, args.steps) for _ in range(max(1, args.repeats))]
         e_h = statistics.median(e for e, _ in runs_h)
         op.reuse_device_tables = True
-        extra['host_outputs'] = {
+        extra['host_outputs_new_geometry'] = {
             'value': gates_per_sweep * args.steps / e_h, 'unit': 'gates/s', 'ms_per_sweep': 1e3 * e_h / args.steps,
             'sweeps_timed': args.steps, 'ms_per_sweep_repeats': [1e3 * e / args.steps for e, _ in runs_h],
             'ms_per_sweep_settling_regions_not_counted': [1e3 * e / args.steps for e, _ in settle],
@@ -793,7 +869,7 @@ def run_c2(env):
             'note': 'the same sweep handed over as the reference hands it over: a new elevation out of 16 every step '
                     '(more than the host cache of per-ray tables holds: computed inside the step and uploaded), all '
                     'kernels, all 15 output arrays (9 observables, RVEL, mask, lats, lons, dist, heights) copied to '
-                    'page-locked host memory; PCIe-bound; this was `value` in rounds 1-3'}
+                    'page-locked host memory; PCIe-bound; this was `value` in rounds 1-3 and `value_host_outputs` in rounds 4-5'}
         # round 2's headline: fixed elevation, per-ray tables resident, gate coordinates copied once
         for _ in range(2 * n_lanes):
             step_cached()
@@ -872,7 +948,7 @@ def run_c2(env):
     roof['psd_stage_ms_with_three_lanes_in_flight'] = cnt.ms_psd
     ws = roof.get('whole_sweep') or {}
     if ws.get('traffic'):
-        ms_sweep = 1e3 * elapsed / args.steps / n_cycle
+        ms_sweep = 1e3 * elapsed / args.steps / sweeps_per_step
         roof['timed_region'] = {
             'ms_per_sweep': ms_sweep, 'traffic_per_sweep': ws['traffic'],
             'achieved': ws['traffic'] / (ms_sweep * 1e-3) / 1e9, 'unit': 'GB/s',
@@ -910,20 +986,24 @@ def run_c2(env):
     out = {
         'metric': 'range-gates/sec', 'value': value, 'unit': 'gates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * elapsed / args.steps, 'ms_per_sweep': 1e3 * elapsed / args.steps / n_cycle,
-        'sweeps_per_step': n_cycle, 'higher_is_better': True,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'ms_per_sweep': 1e3 * elapsed / args.steps / sweeps_per_step,
+        'sweeps_per_step': sweeps_per_step, 'ms_per_cycle_of_8_sweeps': 1e3 * elapsed / args.steps / cycles_per_step,
+        'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'value_definition': 'v2 (round 4 on): 8 sweeps per step, inputs and outputs resident in HBM; '
-                            'value_host_outputs = the SURVEY 8(d) step (v1, rounds 1-3: one sweep, H2D of its tables, D2H of 15 arrays)',
-        'config': {'workload': 'c2: step = 8 sweeps per GPU of the 360-az x 500-gate C-band PPI (R+S+G 1-mom, 1 sub-beam), '
+        'value_definition': 'v2 (round 4 on): sweeps at 8 elevations in turn (round 6: 80 per step), inputs and outputs resident in HBM; '
+                            'value_host_outputs = the SURVEY 8(d) step on a repeated scan geometry (round 6: all 15 arrays '
+                            'delivered, 11 copied per sweep); value_host_outputs_new_geometry = a new geometry every step '
+                            '(v1: `value` in rounds 1-3, `value_host_outputs` in rounds 4-5)',
+        'config': {'workload': 'c2: step = %d sweeps per GPU (%d cycles of 8 elevations) of the 360-az x 500-gate C-band PPI (R+S+G 1-mom, 1 sub-beam), '
                                'inputs and outputs resident in HBM; synthetic %s cube; each sweep = one cpol_run_sweep at one of '
                                '8 elevations (1.0 + 0.05 k deg, k = (sweep + rank) mod 8; per-ray constants on the host and '
                                'table sets on the device before the timed region), every kernel of the launch sequence, the '
-                               '10 radar fields left in HBM; the SURVEY 8(d) step with host outputs: value_host_outputs%s'
-                               % ('x'.join(map(str, cube['zlevels'].shape)),
+                               '10 radar fields (9 float32 observables + the float64 radial velocity) left in HBM; the SURVEY 8(d) '
+                               'step with host outputs: value_host_outputs%s'
+                               % (sweeps_per_step, cycles_per_step, 'x'.join(map(str, cube['zlevels'].shape)),
                                   '' if not weak else '; the timed region ends with one all-gather of every rank\'s '
-                                                      'last sweep (10 float32 fields, device to device)'),
-                   'rays_per_gpu': n_rays, 'gates_per_ray': n_gates, 'lanes': n_lanes, 'sweeps_per_step': n_cycle,
+                                                      'last sweep (its 9 float32 observables, device to device)'),
+                   'rays_per_gpu': n_rays, 'gates_per_ray': n_gates, 'lanes': n_lanes, 'sweeps_per_step': sweeps_per_step,
                    'parallelism': ('weak scaling: the sweeps of a scan are independent, rank r simulates elevation '
                                    '(sweep + r) mod 8 with the N = 1 step unchanged, no collective inside a step, ONE '
                                    'all-gather (RCCL) at the end of the timed region') if weak else 'single GPU',
@@ -944,7 +1024,7 @@ def run_c2(env):
         'counters': {'n_subbeam_gates': n_sbg, 'n_valid_items': n_valid,
                      'n_work_units': int(iso.n_work_units), 'n_table_items': int(iso.n_table_items)},
         'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
-        'host_submit_ms_per_sweep': 1e3 * t_submit / args.steps / n_cycle,
+        'host_submit_ms_per_sweep': 1e3 * t_submit / args.steps / sweeps_per_step,
         'gather_check': gather_ok,
         'result_check': None if result_check is None else bool(result_check['ok']),
         'result_check_detail': result_check,
@@ -1071,7 +1151,8 @@ def run_c3(env):
     n_vars, nz = len(op._staged_vars), cube['zlevels'].shape[0]
     roof = roofline_of_dominant_stage('c3_el3_iso', stage_ms_of(iso3), int(iso3.n_subbeam_gates), int(iso3.n_valid_items),
                                       n_rays * n_gates, n_vars, nz, note='c3 sweep at 3 deg elevation.')
-    d2h = gates * (len(RADAR_FIELDS) * 4 + 8 + 8 + 8 + 8 + 4 + 4)
+    # (9 observables, RVEL, the mask as one byte per gate since round 6 -- pinned calls --, lats, lons, dist, heights)
+    d2h = gates * (len(RADAR_FIELDS) * 4 + 8 + (1 if getattr(op, 'compact_mask', False) else 8) + 8 + 8 + 4 + 4)
     return {
         'metric': 'range-gates/sec', 'value': gates * args.steps / elapsed, 'unit': 'gates/s', 'n_gpus': 1,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,

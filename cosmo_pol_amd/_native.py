@@ -81,7 +81,7 @@ class RayTables(C.Structure):
 
 OUTPUT_FIELDS = ['ZH', 'ZV', 'ZDR', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'ATT_H', 'ATT_V',
                  'RVEL', 'mask', 'lats', 'lons', 'dist', 'heights', 'model_vars', 'sz_total',
-                 'DSPECTRUM']
+                 'DSPECTRUM', 'mask_sum8']
 
 
 class Outputs(C.Structure):

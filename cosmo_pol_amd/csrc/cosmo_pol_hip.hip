@@ -137,7 +137,7 @@ struct cpol_ctx {
     DevBuf b_beam, b_spectrum, b_outwin;
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
         b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel, b_proj, b_blkranked, b_rec, b_vmask, b_gscan, b_defer;
-    DevBuf b_out[16], b_szinteg, b_sztotal, b_model, b_ticket;
+    DevBuf b_out[16], b_szinteg, b_sztotal, b_model, b_ticket, b_mask8;
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
     int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0, last_n_keys = 0;
@@ -1562,12 +1562,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     // (every argument check and every allocation of the sequence happens before its first launch: an error return
     // further down would leave the sweep's counter set half used; see counters_dirty)
     if ((size_t)3 * ng * sizeof(float) > 64 * 1024) { ctx->err = "cpol_run_sweep: n_gates too large for the range scans (3 * n_gates floats of LDS)"; return CPOL_ERR_ARG; }
+    if (out->mask_sum8 && 2 * n_sub > 127) { ctx->err = "cpol_run_sweep: outputs->mask_sum8 needs 2 * n_sub <= 127 (one byte per gate)"; return CPOL_ERR_ARG; }
     if (dop3) {
         ENSURE(ctx->b_beam, (size_t)n_sbg * n_vb * sizeof(float));
     }
     // ---- outputs: where the kernels write each array, and how it reaches the caller ----
     enum { O_ZH, O_ZV, O_ZDR, O_KDP, O_DHV, O_PHIDP, O_RHOHV, O_ATTH, O_ATTV, O_MASK, O_LAT, O_LON,
-           O_DIST, O_HGT, O_RVEL, O_MODEL, O_SZT, O_SPEC, O_N };
+           O_DIST, O_HGT, O_RVEL, O_MODEL, O_SZT, O_SPEC, O_MASK8, O_N };
     const bool dev = p->outputs_on_device == 1;
     const bool async_host = p->outputs_on_device == 2;    // pinned host buffers, no wait
     // the sub-beam sums by one thread per (gate, hydrometeor) with the 1-D table items evaluated in
@@ -1660,7 +1661,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     void *const user_out[O_N] = {out->ZH, out->ZV, out->ZDR, out->KDP, out->DELTA_HV, out->PHIDP,
                                  out->RHOHV, out->ATT_H, out->ATT_V, out->mask, out->lats, out->lons,
                                  out->dist, out->heights, out->RVEL, out->model_vars, out->sz_total,
-                                 out->DSPECTRUM};
+                                 out->DSPECTRUM, out->mask_sum8};
     size_t obytes[O_N];
     bool produced[O_N];
     DevBuf *own[O_N];
@@ -1673,6 +1674,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     obytes[O_MODEL] = (size_t)n_vars * n_rg * sizeof(double);  produced[O_MODEL] = want_model; own[O_MODEL] = &ctx->b_model;
     obytes[O_SZT] = (size_t)n_rg * CPOL_N_SZ * sizeof(float);  produced[O_SZT] = want_szt;    own[O_SZT] = &ctx->b_sztotal;
     obytes[O_SPEC] = (size_t)n_rg * n_vb * sizeof(double);     produced[O_SPEC] = dop3;       own[O_SPEC] = &ctx->b_spectrum;
+    // the radial mask as one byte per gate (the sum of the sub-beams' codes): only when asked for; the float64 form is then
+    // written only if it is asked for too
+    obytes[O_MASK8] = (size_t)n_rg;                            produced[O_MASK8] = out->mask_sum8 != nullptr; own[O_MASK8] = &ctx->b_mask8;
+    if (out->mask_sum8 && !out->mask && !ctx->keep_debug) produced[O_MASK] = false;
     void *T[O_N];
     // pinned-host mode: when the requested arrays lie in one window of the caller's slab (only
     // alignment padding between them) the kernels write into a device image of that window and
@@ -1808,6 +1813,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     fa.DELTA_HV = (float *)T[O_DHV]; fa.RHOHV = (float *)T[O_RHOHV];
     fa.ATT_H = (float *)T[O_ATTH]; fa.ATT_V = (float *)T[O_ATTV];
     fa.mask = (double *)T[O_MASK];
+    fa.mask8 = (signed char *)T[O_MASK8];
     fa.model_vars = want_model ? (double *)T[O_MODEL] : nullptr;
     fa.n_rays = n_rays; fa.n_gates = ng; fa.n_sub = n_sub; fa.n_hydro = n_hyd; fa.n_vars = n_vars;
     fa.c_zh = (float)p->c_zh;

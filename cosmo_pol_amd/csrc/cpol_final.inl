@@ -140,7 +140,8 @@ struct FinalArgs {
     const float *sk, *sh, *sv;  // [n_rg]
     float *sz_total;            // [n_rg][12] or NULL
     float *ZH, *ZV, *ZDR, *KDP, *DELTA_HV, *RHOHV, *ATT_H, *ATT_V;   // work / outputs
-    double *mask;               // [n_rg]
+    double *mask;               // [n_rg] or NULL
+    signed char *mask8;         // [n_rg] or NULL: the sum of the sub-beams' mask codes (cpol_outputs.mask_sum8)
     double *model_vars;         // [n_vars][n_rg] or NULL
     int with_attenuation;
     float res_km;               // (float)(radial_res / 1000.)
@@ -1105,6 +1106,7 @@ __device__ __forceinline__ void gate_finish(const FinalArgs &a, int ray, int gat
         }
         for (; s < a.n_sub; ++s) msum += (double)a.sub_mask[sbg0 + (long)s * a.n_gates];
     }
+    if (a.mask8) a.mask8[rg] = (signed char)(int)msum;        // (a sum of at most 63 codes in [-1, 2]: exact)
     msum /= (double)a.n_sub;
     if (msum > -1.0 && msum <= 0.0) msum = 0.0;
     if (a.mask) a.mask[rg] = msum;

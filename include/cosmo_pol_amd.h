@@ -243,6 +243,11 @@ typedef struct {
     double *model_vars;         /* [n_vars][n_rays*n_gates] (integrate_model)   */
     float  *sz_total;           /* [n_rays*n_gates][12]  (debug / parity)       */
     double *DSPECTRUM;          /* [n_rays*n_gates][n_vbins]  (Doppler scheme 3) */
+    int8_t *mask_sum8;          /* [n_rays*n_gates] the radial mask as what it is made of: the SUM over the sub-beams of
+                                   their mask codes (-1 below the topography, 0, +1 above the model top, 2 outside the
+                                   domain; doppler_scatter.py:472-477), one byte per gate instead of the eight of `mask`.
+                                   mask = mask_sum8 / n_sub, then values in (-1, 0] -> 0: the caller's two NumPy statements.
+                                   Needs 2 * n_sub <= 127.  When it is asked for and `mask` is not, `mask` is not written. */
 } cpol_outputs;
 
 typedef struct {

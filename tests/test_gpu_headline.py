@@ -95,6 +95,9 @@ def test_c2_headline_step_vs_oracle_and_host_output_path():
     # (bench keeps max(2, lanes) slabs and overwrites them; here one per elevation, so that all eight can be read back)
     slabs = [torch.full((len(bench.RADAR_FIELDS), n_rays, n_gates), -7.0, dtype=torch.float32, device='cuda') for _ in range(n_cycle)]
     dev_outs = [{k: sl[i].data_ptr() for i, k in enumerate(bench.RADAR_FIELDS)} for sl in slabs]
+    rvel = [torch.full((n_rays, n_gates), -7.0, dtype=torch.float64, device='cuda') for _ in range(n_cycle)]
+    for d_o, rv in zip(dev_outs, rvel):
+        d_o['RVEL'] = rv.data_ptr()                  # (the tenth field of the headline step)
     forms = []
     for cycle in range(3):                           # (bench: two set-up steps, warm-up, then the timed cycles)
         for k in range(n_cycle):
@@ -109,6 +112,7 @@ def test_c2_headline_step_vs_oracle_and_host_output_path():
         assert f['poly_central'] == 1, f                          # the coordinate polynomials of the resident table set
         assert f['n_sub'] == 1 and f['lanes_alive'] >= 2, f
     got = [sl.cpu().numpy() for sl in slabs]
+    got_rvel = [rv.cpu().numpy() for rv in rvel]
     # ---- against the oracle: nine rays of every elevation, pure 1e-5 ----
     stats, n_valid = {}, 0
     for k in range(n_cycle):
@@ -116,6 +120,7 @@ def test_c2_headline_step_vs_oracle_and_host_output_path():
             o, szt = _oracle_ray(oc, oconf, ol, az[r], bench.C2_ELEVATIONS[k])
             _compare_ray('c2 el %.2f ray %d' % (bench.C2_ELEVATIONS[k], r),
                          {f: got[k][i, r] for i, f in enumerate(bench.RADAR_FIELDS)}, o, szt, oconf, stats)
+            _cases.assert_close_nan(got_rvel[k][r], o.values['RVEL'], rtol=RTOL, atol=2e-4, name='RVEL el %d ray %d' % (k, r))
             n_valid += int(np.isfinite(o.values['ZH']).sum())
     assert n_valid > 10000
     _record('c2_headline_step', stats)
@@ -125,7 +130,8 @@ def test_c2_headline_step_vs_oracle_and_host_output_path():
         for i, f in enumerate(bench.RADAR_FIELDS):
             assert host[f].dtype == np.float32
             assert np.array_equal(host[f], got[k][i], equal_nan=True), (f, k)
-        assert np.isfinite(host['lats']).all() and host['mask'].shape == (n_rays, n_gates)
+        assert np.array_equal(host['RVEL'], got_rvel[k], equal_nan=True), ('RVEL', k)
+        assert np.isfinite(host['lats']).all() and host['mask'].shape == (n_rays, n_gates) and host['mask'].dtype == np.float64
     op.close()
 
 
