@@ -1253,6 +1253,66 @@ __device__ __forceinline__ void final_gate(const FinalArgs &a, const ItabSet &it
     gate_finish(a, ray, gate, tot, false, 0.0, 0.0, wtot, k2_out, fh_out, fv_out);
 }
 
+// one strictly sequential float32 scan over sv[0 .. ng) in LDS by ONE lane (MUL: running product, else running sum), the
+// operands of the next 8 steps requested before the 8 dependent operations of the current ones
+template <bool MUL>
+__device__ __forceinline__ void scan_lds_sequential(float *sv, int ng)
+{
+    float c = 0.0f;
+    int gg = 0;
+    float nx[8];
+    if (ng >= 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nx[q] = sv[q];
+    }
+    for (; gg + 8 <= ng; gg += 8) {
+        float q8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) q8[q] = nx[q];
+        if (gg + 16 <= ng) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nx[q] = sv[gg + 8 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { c = (gg + q == 0) ? q8[0] : (MUL ? c * q8[q] : c + q8[q]); q8[q] = c; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sv[gg + q] = q8[q];
+    }
+    for (; gg < ng; ++gg) { c = (gg == 0) ? sv[gg] : (MUL ? c * sv[gg] : c + sv[gg]); sv[gg] = c; }
+}
+
+// The same scan by a whole wavefront, SAME BITS: gate 64 r + l sits in lane l of row r; inside a row the running value moves
+// one lane to the right per step (v_mov_b32_dpp wave_shr:1) and every lane applies its own operand -- after step t the lanes
+// 0..t hold their final values, because lane l's value was formed from the FINAL value of lane l - 1: the additions happen in
+// gate order with the same operands as the one-lane loop, 63 steps of two instructions per row instead of 64 dependent
+// LDS round trips.  Lane 0 is not written by the shifted operation and keeps its value; the first gate of the ray is taken
+// as it is (np.cumsum's first element), the first gate of a later row continues from the last lane of the row before; lanes
+// behind the last gate carry the identity (-0.0 for the sum: x + -0.0 == x for every x, signed zeros included; 1.0 for the product).
+template <bool MUL>
+__device__ __forceinline__ void scan_lds_wave_exact(float *sv, int ng, int lane)
+{
+    const float ident = MUL ? 1.0f : -0.0f;
+    float carry = ident;
+    for (int row0 = 0; row0 < ng; row0 += 64) {
+        const int gg = row0 + lane;
+        const float x = gg < ng ? sv[gg] : ident;
+        float s = x;
+        if (lane == 0 && row0 > 0) s = MUL ? carry * x : carry + x;
+        // (always 63 steps, unrolled: the lanes behind the ray's last gate carry the identity.  The operation itself takes its
+        // first operand through DPP: s[l] = s[l - 1] op x[l]; lane 0 has no source lane and, with bound_ctrl off, is not
+        // written -- it keeps its value.  Two wait states between a VALU write and a DPP read of the same register; five after
+        // the EXEC write that ends the `lane == 0` branch above -- the compiler cannot see into the block.)
+        if (MUL) asm volatile("s_nop 4\n\t.rept 63\n\ts_nop 1\n\tv_mul_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr" : "+&v"(s) : "v"(x));
+        else     asm volatile("s_nop 4\n\t.rept 63\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr" : "+&v"(s) : "v"(x));
+        if (gg < ng) sv[gg] = s;
+        carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 63));
+    }
+}
+
+#ifndef CPOL_SCAN_FORM
+#define CPOL_SCAN_FORM 1          // 0: one lane walks the ray through LDS (rounds 1-5); 1: the wavefront form above (same bits); 2: no scan at all (measurement of the kernel's floor: wrong results)
+#endif
+
 // One workgroup per ray: every thread finishes gates (final_gate), the operands of the three
 // strictly sequential float32 range scans (np.cumsum / np.cumprod order is part of the
 // numerical contract) go through LDS, lane 0 of waves 0..2 runs one scan each, then all
@@ -1307,39 +1367,23 @@ __global__ __launch_bounds__(THREADS) CPOL_FINAL_ATTR void k_final(FinalArgs a, 
         s_v[g] = fv;
     }
     __syncthreads();
-    // (Measured and dropped, round 4: the scanning wavefront loading 64 operands at once, one per lane, and every
-    // step taking its operand with v_readlane while all lanes carry the running value -- no LDS access inside the
-    // dependent chain: k_final 18.4 -> 35.7 us on the C2 sweep, 110 -> 127 us on the 225-ray C4 share.)
-    // strictly sequential float32 scans, one wavefront (lane 0) per scan so that the
-    // operation is wave-uniform; LDS is read in chunks of 8 so that the read latency is
-    // paid once per chunk, not once per dependent step
-    if (lane == 0 && (wave == 0 || (a.with_attenuation && wave < 3))) {
+    // strictly sequential float32 scans (np.cumsum / np.cumprod order is part of the numerical contract), one wavefront per scan.
+    // Round 6: the whole wavefront scans, same bits (scan_lds_wave_exact below: the running value moves one lane to the right per
+    // step through DPP, 63 steps of one shifted add / multiply per row of 64 gates) -- k_scan_rays 17.5 -> 10.2 us on the C2
+    // sweep, of which 6.8 are the kernel without any scan (profiles/r6_scan_variants.txt).  CPOL_SCAN_FORM=0: one lane walks
+    // the ray through LDS in chunks of 8 (rounds 1-5).  (Measured and dropped, round 4: every step taking its operand with
+    // v_readlane while all lanes carry the running value: k_final 18.4 -> 35.7 us.)
+    if (wave == 0 || (a.with_attenuation && wave < 3)) {          // (wave-uniform)
         float *sv = (wave == 0) ? s_k : (wave == 1 ? s_h : s_v);
-        float c = 0.0f;
-        int g = 0;
-        if (wave == 0) {
-            for (; g + 8 <= ng; g += 8) {
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = sv[g + q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { c = (g + q == 0) ? v[0] : c + v[q]; v[q] = c; }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) sv[g + q] = v[q];
-            }
-            for (; g < ng; ++g) { c = (g == 0) ? sv[g] : c + sv[g]; sv[g] = c; }
-        } else {
-            for (; g + 8 <= ng; g += 8) {
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = sv[g + q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { c = (g + q == 0) ? v[0] : c * v[q]; v[q] = c; }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) sv[g + q] = v[q];
-            }
-            for (; g < ng; ++g) { c = (g == 0) ? sv[g] : c * sv[g]; sv[g] = c; }
+#if CPOL_SCAN_FORM == 1
+        if (wave == 0) scan_lds_wave_exact<false>(sv, ng, lane);
+        else scan_lds_wave_exact<true>(sv, ng, lane);
+#elif CPOL_SCAN_FORM == 0
+        if (lane == 0) {
+            if (wave == 0) scan_lds_sequential<false>(sv, ng);
+            else scan_lds_sequential<true>(sv, ng);
         }
+#endif
     }
     __syncthreads();
     double *rvel = a.RVEL ? a.RVEL : r.RVEL;

@@ -655,37 +655,21 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
         s_v[gg] = g.sv[base + gg];
     }
     __syncthreads();
-    // strictly sequential float32 scans (np.cumsum / np.cumprod order is part of the numerical contract), lane 0 of
-    // a wavefront per scan (with fewer than three species a wavefront takes several), LDS read in chunks of 8 (k_final)
-    if (lane == 0) {
+    // strictly sequential float32 scans (np.cumsum / np.cumprod order is part of the numerical contract), a wavefront per scan
+    // (with fewer than three species a wavefront takes several): scan_lds_wave_exact / scan_lds_sequential (cpol_final.inl)
+    {
         const int n_scan = f.with_attenuation ? 3 : 1;
-        for (int sc = wave; sc < n_scan; sc += n_waves) {
+        for (int sc = wave; sc < n_scan; sc += n_waves) {          // (wave-uniform)
             float *sv = (sc == 0) ? s_k : (sc == 1 ? s_h : s_v);
-            float c = 0.0f;
-            int gg = 0;
-            if (sc == 0) {
-                for (; gg + 8 <= ng; gg += 8) {
-                    float q8[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) q8[q] = sv[gg + q];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { c = (gg + q == 0) ? q8[0] : c + q8[q]; q8[q] = c; }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) sv[gg + q] = q8[q];
-                }
-                for (; gg < ng; ++gg) { c = (gg == 0) ? sv[gg] : c + sv[gg]; sv[gg] = c; }
-            } else {
-                for (; gg + 8 <= ng; gg += 8) {
-                    float q8[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) q8[q] = sv[gg + q];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { c = (gg + q == 0) ? q8[0] : c * q8[q]; q8[q] = c; }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) sv[gg + q] = q8[q];
-                }
-                for (; gg < ng; ++gg) { c = (gg == 0) ? sv[gg] : c * sv[gg]; sv[gg] = c; }
+#if CPOL_SCAN_FORM == 1
+            if (sc == 0) scan_lds_wave_exact<false>(sv, ng, lane);
+            else scan_lds_wave_exact<true>(sv, ng, lane);
+#elif CPOL_SCAN_FORM == 0
+            if (lane == 0) {
+                if (sc == 0) scan_lds_sequential<false>(sv, ng);
+                else scan_lds_sequential<true>(sv, ng);
             }
+#endif
         }
     }
     __syncthreads();
@@ -738,34 +722,6 @@ __global__ __launch_bounds__(64 * CPOL_MAX_HYDRO) CPOL_GATE1S_ATTR void k_gate1_
 // one workgroup per ray, the operands of the three strictly sequential float32 scans through LDS, lane 0 of three
 // wavefronts runs one scan each, then PHIDP, the attenuated ZDR and the sensitivity cut -- the second half of k_final
 // without the per-gate function's 243 registers (k_final<256> on the C2 sweep: 15-19 us for this work).
-// one strictly sequential float32 scan over sv[0 .. ng) in LDS by ONE lane (MUL: running product, else running sum), the
-// operands of the next 8 steps requested before the 8 dependent operations of the current ones
-template <bool MUL>
-__device__ __forceinline__ void scan_lds_sequential(float *sv, int ng)
-{
-    float c = 0.0f;
-    int gg = 0;
-    float nx[8];
-    if (ng >= 8) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) nx[q] = sv[q];
-    }
-    for (; gg + 8 <= ng; gg += 8) {
-        float q8[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) q8[q] = nx[q];
-        if (gg + 16 <= ng) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) nx[q] = sv[gg + 8 + q];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { c = (gg + q == 0) ? q8[0] : (MUL ? c * q8[q] : c + q8[q]); q8[q] = c; }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) sv[gg + q] = q8[q];
-    }
-    for (; gg < ng; ++gg) { c = (gg == 0) ? sv[gg] : (MUL ? c * sv[gg] : c + sv[gg]); sv[gg] = c; }
-}
-
 __global__ __launch_bounds__(256) void k_scan_rays(FinalArgs f, GateArgs g, ScanRayArgs r)
 {
     extern __shared__ float lds_scan[];                // [3][n_gates]
@@ -793,10 +749,17 @@ __global__ __launch_bounds__(256) void k_scan_rays(FinalArgs f, GateArgs g, Scan
         p_thr[q] = r.sens_thr ? r.sens_thr[ok ? gg : 0] : 0.0;
     }
     __syncthreads();
+#if CPOL_SCAN_FORM == 1
+    if (wave == 0 || (f.with_attenuation && wave < 3)) {          // (wave-uniform)
+        if (wave == 0) scan_lds_wave_exact<false>(s_k, ng, lane);
+        else scan_lds_wave_exact<true>(wave == 1 ? s_h : s_v, ng, lane);
+    }
+#elif CPOL_SCAN_FORM == 0
     if (lane == 0 && (wave == 0 || (f.with_attenuation && wave < 3))) {
         if (wave == 0) scan_lds_sequential<false>(s_k, ng);
         else scan_lds_sequential<true>(wave == 1 ? s_h : s_v, ng);
     }
+#endif
     __syncthreads();
     double *rvel = f.RVEL ? f.RVEL : r.RVEL;
     for (int gg = tid, q = 0; gg < ng; gg += 256, ++q) {
