@@ -987,6 +987,9 @@ void k_subbeam_sum_team(HydroSet hs, ItabSet its, SubsumArgs a)
 #ifndef CPOL_SKIP_RVEL
 #define CPOL_SKIP_RVEL 0      // experiment knob (tools/variants.sh): time of the RVEL loop
 #endif
+#ifndef CPOL_EXP_FINISH_CHEAP
+#define CPOL_EXP_FINISH_CHEAP 0   // experiment knob (timing only, wrong values): the two exp10 and the atan2 of gate_finish replaced by one operation each
+#endif
 #ifndef CPOL_FINAL_BATCH
 #define CPOL_FINAL_BATCH 2
 #endif
@@ -1035,15 +1038,24 @@ __device__ __forceinline__ void gate_finish(const FinalArgs &a, int ray, int gat
     fh_out = fv_out = 1.0f;
     if (a.with_attenuation) {
         // 10**(-0.1*A*(radial_res/1000.)) in float32 (doppler_scatter.py:413-414); NaN -> 1
+#if CPOL_EXP_FINISH_CHEAP          // (timing experiment only: wrong values)
+        float fh = 1.0f - 0.1f * att_h * a.res_km;
+        float fv = 1.0f - 0.1f * att_v * a.res_km;
+#else
         float fh = (float)exp10((double)(-0.1f * att_h * a.res_km));
         float fv = (float)exp10((double)(-0.1f * att_v * a.res_km));
+#endif
         fh_out = (fh == fh) ? fh : 1.0f;
         fv_out = (fv == fv) ? fv : 1.0f;
     }
     const float t47 = tot[4] + tot[7], t65 = tot[6] - tot[5];
     const float aa = t47 * t47 + t65 * t65;
     a.RHOHV[rg] = sqrtf(aa / (b * cc));
+#if CPOL_EXP_FINISH_CHEAP
+    a.DELTA_HV[rg] = (tot[5] - tot[6]) / (-tot[4] - tot[7]);
+#else
     a.DELTA_HV[rg] = (float)atan2((double)(tot[5] - tot[6]), (double)(-tot[4] - tot[7]));
+#endif
 
     // ---- radial velocity, Doppler scheme 1 (doppler_scatter.py:276-281, 313-333, 418-420) ----
     if (a.RVEL && !CPOL_SKIP_RVEL) {

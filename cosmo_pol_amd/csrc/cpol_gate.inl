@@ -449,6 +449,9 @@ __device__ __forceinline__ void integrate_gamma_item_wave(const double *table, c
 // integrating launch behind this kernel), and the workgroup that finishes LAST of its ray -- a ticket per ray, taken behind
 // a device-scope fence -- runs the ray's three sequential float32 range scans, PHIDP, the attenuated ZDR and the
 // sensitivity cut (the second half of k_final): the whole sweep is k_interp_sweep + this kernel.
+#ifndef CPOL_EXP_ONE_BLOCK
+#define CPOL_EXP_ONE_BLOCK 0
+#endif
 template <bool RAY, bool TICKET>
 __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const ItabSet &its, const ClassifyArgs &a, const FinalArgs &f,
                                                    const GateArgs &g, const ScanRayArgs &r)
@@ -492,7 +495,11 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
         // ---- 1-D block: the lane gathers the rows of its (slice, panel) block (as k_gate1) ----
         const int pn = min((int)it.pf, t.n_pan - 1);
         const double u = 2.0 * (it.pf - (double)pn) - 1.0;
+#if CPOL_EXP_ONE_BLOCK            // (timing experiment only: every lane reads the same block -- no gather)
+        const double2 *blk = reinterpret_cast<const double2 *>(t.tab);
+#else
         const double2 *blk = reinterpret_cast<const double2 *>(t.tab + ((long)(it.key - h.key_base) * t.n_pan + pn) * NB);
+#endif
 #pragma unroll
         for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = blk[(NC - 1) * (NFP / 2) + c];
         if (want_vn) wv = blk[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];

@@ -16,9 +16,7 @@ runs on the GPU; `Lookup_table.lookup_line` here is the host twin kept for API
 compatibility and tests.
 """
 import os
-import shutil
 import tarfile
-import tempfile
 from io import BytesIO
 
 import numpy as np
@@ -29,42 +27,39 @@ class Error(Exception):
 
 
 class Lookup_table(object):
+    """A scattering table as the `.lut` format stores it.  The five attribute names below ARE the format (each is one
+    member of the tar file, read back by the reference's `load_lut`, cosmo_pol/lookup/lut.py:127-154) and are what the
+    reference's query code reads (`lookup_line`, :309-344); everything else about this class is this repo's own: a table
+    is built in one go from its axes and values (`from_axes`) and is not mutated afterwards."""
+
+    __slots__ = ('axes', 'axes_names', 'axes_limits', 'axes_step', 'axes_len', 'value_table')
+
     def __init__(self):
-        self.axes = []
-        self.axes_names = {}
-        self.axes_limits = []
-        self.axes_step = []
-        self.axes_len = []
+        self.axes, self.axes_names, self.axes_limits, self.axes_step, self.axes_len = [], {}, [], [], []
         self.value_table = []
 
-    def add_axis(self, name, axis_values=None):
-        if name in self.axes_names:
-            raise Error("Axis already exists with name: '%s'" % name)
-        axis_values = np.asarray(axis_values).astype('float32')
-        self.axes_names[name] = len(self.axes)
-        self.axes_limits.append([np.min(axis_values), np.max(axis_values)])
-        self.axes_step.append(axis_values[1] - axis_values[0])
-        self.axes_len.append(axis_values.shape[-1])
-        self.axes.append(axis_values)
-
-    def set_axis_values(self, axis_name, axis_values):
-        i = self.axes_names[axis_name]
-        axis_values = np.asarray(axis_values).astype('float32')
-        self.axes_limits[i] = [np.min(axis_values), np.max(axis_values)]
-        self.axes[i] = axis_values
-
-    def set_value_table(self, value_table):
+    @classmethod
+    def from_axes(cls, axes, value_table):
+        """axes: [(name, values), ...] in table order (values float32 on file; the last dimension of a 2-D axis -- the
+        diameters of a melting species, one row per wet fraction -- is the table's); value_table: array of that shape."""
+        t = cls()
+        for position, (name, values) in enumerate(axes):
+            if name in t.axes_names:
+                raise Error("Axis already exists with name: '%s'" % name)
+            values = np.asarray(values).astype('float32')
+            t.axes_names[name] = position
+            t.axes.append(values)
+            t.axes_limits.append([np.min(values), np.max(values)])
+            t.axes_step.append(values[1] - values[0])
+            t.axes_len.append(values.shape[-1])
         value_table = np.asarray(value_table)
-        if value_table.shape != tuple(self.axes_len):
-            raise ValueError('value_table shape %s does not match the axes %s'
-                             % (value_table.shape, tuple(self.axes_len)))
-        self.value_table = value_table
+        if value_table.shape != tuple(t.axes_len):
+            raise ValueError('value_table shape %s does not match the axes %s' % (value_table.shape, tuple(t.axes_len)))
+        t.value_table = value_table
+        return t
 
-    def get_axis_name(self, axis_i):
-        for name, i in self.axes_names.items():
-            if i == axis_i:
-                return name
-        return None
+    def axis(self, name):
+        return self.axes[self.axes_names[name]]
 
     def bin_index(self, name, values):
         """Lower-bin index of `values` along axis `name`, clipped to the table
@@ -84,41 +79,44 @@ class Lookup_table(object):
         return self.value_table[tuple(I)]
 
 
-def _as_array(obj):
+# the members of a .lut tar file, in the order they are written; `ragged`: a list of arrays of different shapes (the axes: one
+# of them is 2-D for a melting species) goes into ONE object array, as np.save needs it
+_MEMBERS = (('axes', True), ('axes_limits', True), ('axes_names', False), ('axes_step', True), ('value_table', False))
+
+
+def _object_array(items):
     try:
-        return np.array(obj)
+        return np.array(items)
     except ValueError:
-        arr = np.empty(len(obj), dtype=object)
-        for i, o in enumerate(obj):
-            arr[i] = o
-        return arr
+        out = np.empty(len(items), dtype=object)
+        out[:] = list(items)
+        return out
 
 
 def save_lut(lut, filename):
-    tmp_dir = tempfile.mkdtemp(prefix='cpol_lut_')
-    try:
-        np.save(os.path.join(tmp_dir, 'value_table'), lut.value_table)
-        np.save(os.path.join(tmp_dir, 'axes'), _as_array(lut.axes), allow_pickle=True)
-        np.save(os.path.join(tmp_dir, 'axes_names'), lut.axes_names, allow_pickle=True)
-        np.save(os.path.join(tmp_dir, 'axes_step'), _as_array(lut.axes_step), allow_pickle=True)
-        np.save(os.path.join(tmp_dir, 'axes_limits'), _as_array(lut.axes_limits), allow_pickle=True)
-        with tarfile.open(filename, 'w') as tar:
-            for n in sorted(os.listdir(tmp_dir)):
-                tar.add(os.path.join(tmp_dir, n), arcname=n)
-    finally:
-        shutil.rmtree(tmp_dir)
+    """Writes `lut` as the reference's `save_lut` does (lut.py:78-125: a tar of five .npy members), straight from memory."""
+    with tarfile.open(filename, 'w') as tar:
+        for name, ragged in _MEMBERS:
+            payload = getattr(lut, name)
+            buf = BytesIO()
+            np.save(buf, _object_array(payload) if ragged else payload, allow_pickle=name != 'value_table')
+            info = tarfile.TarInfo(name + '.npy')
+            info.size = buf.tell()
+            buf.seek(0)
+            tar.addfile(info, buf)
 
 
 def load_lut(filename):
+    """Reads a .lut file written by either side."""
     lut = Lookup_table()
+    wanted = {name for name, _ in _MEMBERS}
     with tarfile.open(filename, 'r') as tar:
         for member in tar.getmembers():
-            buf = BytesIO(tar.extractfile(member).read())
-            name = member.name.replace('.npy', '')
-            data = np.load(buf, allow_pickle=True, encoding='latin1')
-            if name == 'axes_names':
-                data = data.item()      # 0-d object array holding the dict
-            setattr(lut, name, data)
+            name = os.path.splitext(os.path.basename(member.name))[0]
+            if name not in wanted:
+                continue
+            data = np.load(BytesIO(tar.extractfile(member).read()), allow_pickle=True, encoding='latin1')
+            setattr(lut, name, data.item() if name == 'axes_names' else data)     # (the dict sits in a 0-d object array)
     lut.axes_len = list(np.shape(lut.value_table))
     return lut
 

@@ -88,13 +88,8 @@ def mie_table_like(lut, h, frequency, scheme='1mom'):
     r_h = (sa / sphere)[None] + 0 * e
     r_v = (sa[None] * np.sin(e) ** 2 + sz[None] * np.cos(e) ** 2) / sphere[None]
     tab = syn.table_columns(h, f_b[None] * r_h, f_b[None] * r_v, f_f[None] * r_h, f_f[None] * r_v)
-    out = Lookup_table()
-    out.add_axis('e', np.asarray(lut.axes[names['e']]))
-    out.add_axis('t', np.asarray(lut.axes[names['t']]))
-    out.add_axis('d', list_D)
-    out.add_axis('sz', np.arange(12))
-    out.set_value_table(np.ascontiguousarray(tab))
-    return out
+    return Lookup_table.from_axes([('e', np.asarray(lut.axes[names['e']])), ('t', np.asarray(lut.axes[names['t']])),
+                                   ('d', list_D), ('sz', np.arange(12))], np.ascontiguousarray(tab))
 
 
 def make_lut(h, frequency=5.6, scheme='1mom', n_e=None, n_t=None):

@@ -147,7 +147,6 @@ def make_lut(h, frequency=5.6, scheme='1mom', seed=20260301, n_e=None, n_t=None)
     k0 = 2 * np.pi / wavelength
     rng = np.random.default_rng(seed + 1000 * _HYD_SEED[h] + int(round(frequency * 10)))
     elev = ELEVATIONS if n_e is None else ELEVATIONS[:n_e]
-    lut = Lookup_table()
     if h in ('mS', 'mG'):
         solid = 'S' if h == 'mS' else 'G'
         wcs = W_CONTENTS if n_t is None else W_CONTENTS[:n_t]
@@ -167,9 +166,7 @@ def make_lut(h, frequency=5.6, scheme='1mom', seed=20260301, n_e=None, n_t=None)
         ar = (1 - fw[None]) * _axis_ratio(solid, D) + fw[None] * _axis_ratio('R', np.minimum(D, 8.0))
         tab = _fill_table(h, D, eps, ar, k0, rng)
         tab = tab[:len(elev)] if tab.shape[0] != len(elev) else tab
-        lut.add_axis('e', elev)
-        lut.add_axis('wc', wcs)
-        lut.add_axis('d', array_D)
+        axes = [('e', elev), ('wc', wcs), ('d', array_D)]
     else:
         temps = TEMPERATURES_LIQ if h == 'R' else TEMPERATURES_SOL
         if n_t is not None:
@@ -186,12 +183,8 @@ def make_lut(h, frequency=5.6, scheme='1mom', seed=20260301, n_e=None, n_t=None)
         ar = _axis_ratio(h, D) + 0 * T
         tab = _fill_table(h, D, eps, ar, k0, rng)
         tab = tab[:len(elev)]
-        lut.add_axis('e', elev)
-        lut.add_axis('t', temps)
-        lut.add_axis('d', list_D)
-    lut.add_axis('sz', np.arange(12))
-    lut.set_value_table(np.ascontiguousarray(tab))
-    return lut
+        axes = [('e', elev), ('t', temps), ('d', list_D)]
+    return Lookup_table.from_axes(axes + [('sz', np.arange(12))], np.ascontiguousarray(tab))
 
 
 def make_all_luts(hydrometeors, frequency=5.6, scheme='1mom', seed=20260301, n_e=None, n_t=None):
