@@ -1793,7 +1793,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.poly_scale = (geo_poly || poly_central) ? geo_poly_scale : 0.0;
     ia.poly_central = poly_central ? 1 : 0;
     ctx->last_poly_central = ia.poly_central;
-    if (!fused && !fused_gate1)
+    static const int exp_skip_interp = getenv("CPOL_EXP_SKIP") ? (atoi(getenv("CPOL_EXP_SKIP")) & 1) : 0;
+    if (!fused && !fused_gate1 && !exp_skip_interp)
     hipLaunchKernelGGL(k_interp_sweep, dim3((unsigned)(n_rays * n_sub), cdiv(ng, 256)), dim3(256), 0, st,
                        ctx->model, ia);
     if (tm && !fused && !fused_gate1) HIPCHK(hipEventRecord(ctx->ev[EV_INTERP], st));
@@ -1985,9 +1986,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                 hipLaunchKernelGGL(k_gate1_ray_scan, rgrid, dim3(64 * n_hyd), lds_terms > lds_scan ? lds_terms : lds_scan, st,
                                    ctx->hs, ctx->its, ca, fa, ga, rr);
             } else {
+                // (CPOL_EXP_SKIP, timing experiments only -- wrong results: bit 0 the gate interpolation, bit 1 this kernel, bit 2 the scans)
+                static const int exp_skip = getenv("CPOL_EXP_SKIP") ? atoi(getenv("CPOL_EXP_SKIP")) : 0;
+                if (!(exp_skip & 2))
                 hipLaunchKernelGGL(k_gate1_ray, rgrid, dim3(64 * n_hyd), lds_terms, st, ctx->hs, ctx->its, ca, fa, ga, rr);
                 if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_CLASSIFY], st));
                 if (tm_psd) { HIPCHK(hipEventRecord(ctx->ev[EV_BUCKET], st)); HIPCHK(hipEventRecord(ctx->ev[EV_PSD], st)); }
+                if (!(exp_skip & 4))
                 hipLaunchKernelGGL(k_scan_rays, dim3((unsigned)n_rays), dim3(256), lds_scan, st, fa, ga, rr);
                 if (tm) HIPCHK(hipEventRecord(ctx->ev[EV_FINAL], st));
                 HIPCHK(hipGetLastError());
