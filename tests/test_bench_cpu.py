@@ -184,7 +184,7 @@ def test_stage_kernels_cover_every_kernel_of_a_sweep():
     integrating = ('k_psd_uniform', 'k_psd<', 'k_psd_ice2', 'k_psd_melting', 'k_psd_rare', 'k_spec_', 'k_ml_weights')
     for name in ('c2_iso', 'c3_el3_iso', 'c4_volume_iso', 'c4_share8_iso', 'c5_ku_iso'):
         prof, path = bench.load_profile_summary(name)
-        assert prof is not None and path.endswith(('r5_%s_summary.json' % name, 'r4_%s_summary.json' % name))
+        assert prof is not None and path.endswith(('r6_%s_summary.json' % name, 'r5_%s_summary.json' % name, 'r4_%s_summary.json' % name))
         if name in ('c2_iso', 'c5_ku_iso'):                  # single-beam sweeps run the fused kernel
             assert any('k_gate1' in k for k in prof) and not any('k_classify' in k for k in prof)
         for kernel, c in prof.items():

@@ -13,7 +13,7 @@ back, and what it left in HBM is compared
   operand scale only gate by gate, every such gate counted and recorded (profiles/r6_parity_records.jsonl);
 * bit for bit with the host-output path of the same elevations (the reference's hand-over).
 
-The same for the c3 step (`bench.run_c3::volume`: five lanes, page-locked host outputs, per-ray tables uploaded per sweep).
+The same for the c3 step (`bench.run_c3::volume`: five lanes, page-locked host outputs of a repeating volume scan).
 """
 import numpy as np
 import pytest
@@ -143,14 +143,12 @@ def test_c3_step_vs_oracle_and_blocking_path():
     els = [np.full(len(az), e) for e in bench.C4_ELEVATIONS]
     for i in range(n_el):
         op._lane(i)
-    op.reuse_device_tables = False                 # (as bench.run_c3: the per-ray tables are uploaded with every sweep)
     vol = None
     for _ in range(3):
         vol = [op.simulate_rays(az, els[e], pinned=True, lane=e) for e in range(n_el)]
         for i in range(n_el):
             op.wait(i)
     torch.cuda.synchronize()
-    op.reuse_device_tables = True
     stats, n_valid, n_melt = {}, 0, 0
     for e in range(n_el):
         for r in SAMPLE_RAYS:
