@@ -196,9 +196,12 @@ def _mask_from_sum(sum8, n_sub):
     """Builder of the radial mask from cpol_outputs.mask_sum8: the two statements of doppler_scatter.py:472-477 on the
     sum of the sub-beams' mask codes (the sum itself comes from the device)."""
     def make():
-        mask = sum8 / float(n_sub)
-        mask[np.logical_and(mask > -1, mask <= 0)] = 0
-        return mask
+        if n_sub == 1:
+            return sum8.astype(np.float64)          # (one sub-beam: the codes themselves; the (-1, 0] -> 0 rule changes no integer)
+        # the two statements on the 256 possible sums, then one gather (5 x faster than the statements on the whole array)
+        lut = np.arange(-128, 128) / float(n_sub)
+        lut[np.logical_and(lut > -1, lut <= 0)] = 0
+        return np.take(lut, sum8.astype(np.intp) + 128)
     return make
 
 
