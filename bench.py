@@ -602,8 +602,9 @@ def check_last_sweep(env, slabs, rvel_slabs, els, az, k_last, n_buf, n_lanes, n_
     """`result_check` of the line (round-5 review, item 1b): what the LAST sweep of the timed region left in HBM -- which launch
     forms it took, read from the library -- against (i) the host-output hand-over of the same elevation (`step_full`'s call:
     NaN pattern equal, <= 1e-5; it is the same arithmetic, so the expected answer is "bitwise") and (ii), when the CPU legs
-    are on, four of its rays against the oracle (the checker, never the thing measured): the six ratio / power variables at
-    the pure relative 1e-5, the three phase-like ones on the scale of the variable over the ray, as smoke() does."""
+    are on, the first radials of the one-core `cpu_baseline` leg -- whose oracle results that leg keeps -- against the same
+    rays through the product: the six ratio / power variables at the pure relative 1e-5, the three phase-like ones on the
+    scale of the variable over the ray, as smoke() does.  The oracle is called by the cpu_baseline leg alone."""
     op, rank, args, torch = env['op'], env['rank'], env['args'], env['torch']
     lane = k_last % n_lanes
     forms = op._lane(lane).launch_forms()
@@ -629,26 +630,30 @@ def check_last_sweep(env, slabs, rvel_slabs, els, az, k_last, n_buf, n_lanes, n_
     out['vs_host_outputs'] = {'bitwise': bitwise, 'worst_rel': worst, 'n_finite_ZH': int(np.isfinite(got[0]).sum()),
                               'RVEL_bitwise': rv_same}
     out['ok'] = out['ok'] and out['vs_host_outputs']['n_finite_ZH'] > 0
-    if args.cpu_seconds > 0:
-        from cosmo_pol_oracle import beam, scatter
-        oconf, oc, ol = _oracle_inputs(env['conf'], env['cube'], env['luts'])
-        rays, worst_o, ok_o = (11, 97, 203, 318) if len(az) >= 360 else (1, len(az) // 2), {}, True
-        for r in rays:
-            subs = beam.interpolate_radial(oc, oconf, float(az[r]), float(el[r]))
-            o = scatter.radar_observables(subs, ol, oconf)
-            scatter.cut_at_sensitivity([o], oconf)
-            for i, f in enumerate(RADAR_FIELDS):
-                a, b = got[i][r].astype(np.float64), np.asarray(o.values[f], dtype=np.float64)
+    if _CPU_LEG_RAYS:
+        # (ii) against the oracle, through what the cpu_baseline leg kept of its first radials (this function never calls the
+        # oracle): the same rays at the leg's elevation through the product's blocking call, without the sensitivity cut
+        keys = sorted(_CPU_LEG_RAYS)
+        with contextlib.redirect_stdout(sys.stderr):
+            mine = op.simulate_rays([k[0] for k in keys], [k[1] for k in keys], apply_sensitivity=False, lane=0)
+        worst_o, ok_o = {}, True
+        for r, key in enumerate(keys):
+            ref = _CPU_LEG_RAYS[key]
+            for f in RADAR_FIELDS:
+                a, b = np.asarray(mine[f][r], dtype=np.float64), np.asarray(ref[f], dtype=np.float64)
+                same = bool(np.array_equal(np.isnan(a), np.isnan(b)))
+                ok_o = ok_o and same
                 fin = np.isfinite(b)
-                ok_o = ok_o and bool(np.array_equal(np.isnan(a), np.isnan(b)))
-                if not fin.any() or not np.array_equal(np.isnan(a), np.isnan(b)):
+                if not same or not fin.any():
                     continue
                 scale = np.abs(b[fin]) if f not in ('KDP', 'PHIDP', 'DELTA_HV') else np.maximum(np.abs(b[fin]), np.max(np.abs(b[fin])))
                 with np.errstate(divide='ignore', invalid='ignore'):
                     rel = np.nan_to_num(np.abs(a[fin] - b[fin]) / scale)
                 worst_o[f] = max(worst_o.get(f, 0.0), float(rel.max()))
         ok_o = ok_o and all(v <= 1e-5 for v in worst_o.values())
-        out['vs_oracle'] = {'rays': list(rays), 'worst_rel': worst_o, 'ok': ok_o}
+        out['vs_oracle'] = {'rays': ['az %.0f el %.2f' % k for k in keys], 'worst_rel': worst_o, 'ok': ok_o,
+                            'note': 'the radials the one-core CPU leg computed first, kept by that leg; the three phase-like '
+                                    'variables on the scale of the variable over the ray, the others purely relative'}
         out['ok'] = out['ok'] and ok_o
     return out
 
@@ -1512,11 +1517,20 @@ def _oracle_inputs(conf, cube, luts):
     return oconf, oc, ol
 
 
-def _one_radial(inputs, a, el):
+# what the one-core CPU leg keeps of its first radials: the oracle's observables of rays 0..3 (azimuth order, the leg's
+# elevation, no sensitivity cut) -- `result_check` compares the GPU's sweep of that elevation with them, so that the
+# oracle is touched by the cpu_baseline leg alone
+_CPU_LEG_RAYS = {}
+
+
+def _one_radial(inputs, a, el, keep=None):
     from cosmo_pol_oracle import beam, scatter
     oconf, oc, ol = inputs
     subs = beam.interpolate_radial(oc, oconf, float(a), float(el))
-    return len(scatter.radar_observables(subs, ol, oconf).values['ZH'])
+    obs = scatter.radar_observables(subs, ol, oconf)
+    if keep is not None and len(keep) < 4 and (float(a), float(el)) not in keep:
+        keep[(float(a), float(el))] = {k: np.array(v, copy=True) for k, v in obs.values.items()}
+    return len(obs.values['ZH'])
 
 
 def _pool_radial(a):
@@ -1560,7 +1574,7 @@ def cpu_baseline(conf, cube, luts, az, el, budget_s, n_samples=5):
     per-variable C gate kernel, float64 LUT gather + einsum) on ONE core, radials in azimuth order."""
     inputs = _oracle_inputs(conf, cube, luts)
     n_sub = conf['integration']['nh_GH'] * conf['integration']['nv_GH']
-    return _sample_one_core(lambda k: _one_radial(inputs, az[k], el), len(az), budget_s, n_samples,
+    return _sample_one_core(lambda k: _one_radial(inputs, az[k], el, keep=_CPU_LEG_RAYS), len(az), budget_s, n_samples,
                             'radials in azimuth order (el %.1f deg, %d sub-beam%s each; output gates counted)'
                             % (el, n_sub, '' if n_sub == 1 else 's'))
 
