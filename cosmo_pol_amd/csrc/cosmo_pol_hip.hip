@@ -1980,7 +1980,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             rr.RVEL = nullptr;
             rr.sens_thr = cut ? (const double *)ctx->v_sens : nullptr;
             rr.radial_res = (float)p->radial_res;
-            const size_t lds_terms = (size_t)n_hyd * 64 * GATE1S_BYTES, lds_scan = (size_t)3 * ng * sizeof(float);
+            const size_t lds_terms = (size_t)n_hyd * (64 * GATE1S_BYTES + GATE1S_BLK_BYTES), lds_scan = (size_t)3 * ng * sizeof(float);
             const dim3 rgrid((unsigned)cdiv(ng, 64), (unsigned)n_rays);
             if (g1r == 3) {
                 hipLaunchKernelGGL(k_gate1_ray_scan, rgrid, dim3(64 * n_hyd), lds_terms > lds_scan ? lds_terms : lds_scan, st,
@@ -2005,7 +2005,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             return CPOL_OK;
         }
         if (by_species) hipLaunchKernelGGL(k_gate1_species, dim3((unsigned)cdiv(n_rg, 64)), dim3(64 * n_hyd),
-                                           (size_t)n_hyd * 64 * GATE1S_BYTES, st, ctx->hs, ctx->its, ca, fa, ga);
+                                           (size_t)n_hyd * (64 * GATE1S_BYTES + GATE1S_BLK_BYTES), st, ctx->hs, ctx->its, ca, fa, ga);
         else if (fused_gate1 && melt_tab) hipLaunchKernelGGL((k_interp_gate1<true>), ggrid, dim3(CPOL_GATE1_THREADS), glds, st,
                                                         ctx->model, ia, ctx->hs, ctx->its, ca, fa, ga);
         else if (fused_gate1) hipLaunchKernelGGL((k_interp_gate1<false>), ggrid, dim3(CPOL_GATE1_THREADS), glds, st,

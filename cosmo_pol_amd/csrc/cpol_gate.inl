@@ -452,6 +452,15 @@ __device__ __forceinline__ void integrate_gamma_item_wave(const double *table, c
 #ifndef CPOL_EXP_ONE_BLOCK
 #define CPOL_EXP_ONE_BLOCK 0
 #endif
+#ifndef CPOL_GATE1_LDS
+#define CPOL_GATE1_LDS 0          // 1 (build knob, measured and rejected in round 6): the single-beam species kernels take the coefficient blocks of a
+                                  // wavefront's gates through LDS, each distinct block once, instead of every lane gathering its own.  Same bits
+                                  // (tests/test_gpu_edges.py, test_gpu_parity.py, test_gpu_headline.py pass with it), but the wavefront's 4-6
+                                  // distinct blocks become 4-6 SERIAL global -> LDS round trips with a few lanes busy in each Horner round:
+                                  // k_gate1_ray 36 -> 81 us, the pipelined C2 sweep 35 -> 70 us (profiles/r6_variants.txt, item 7)
+#endif
+// dynamic LDS of k_gate1_species / k_gate1_ray behind the species' terms: two block buffers per wavefront
+#define GATE1S_BLK_BYTES (CPOL_GATE1_LDS ? 2 * ((CPOL_ITAB1_NC * CPOL_ITAB_NFP / 2) > CPOL_WAVE ? (CPOL_ITAB1_NC * CPOL_ITAB_NFP / 2) : CPOL_WAVE) * 16 : 0)
 template <bool RAY, bool TICKET>
 __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const ItabSet &its, const ClassifyArgs &a, const FinalArgs &f,
                                                    const GateArgs &g, const ScanRayArgs &r)
@@ -491,6 +500,73 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
     for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = make_double2(0.0, 0.0);
     double2 wv = make_double2(0.0, 0.0);
     bool have = false;
+#if CPOL_GATE1_LDS
+    {
+        // ---- 1-D blocks through LDS (round 6): the 64 gates of a wavefront -- neighbours along one ray, one species -- sit on 4 to 6
+        // distinct (slice, panel) blocks on average (12 at most on the C2 sweep), yet every lane gathered its own 77 double2.  Here
+        // the wavefront walks its DISTINCT blocks (k_subbeam_sum_lds's scheme): the 88 16-byte pieces of a block go straight from
+        // global memory into LDS (two global_load_lds_dwordx4), the lanes on that block run their Horner chains on coefficients all
+        // read from ONE address (ds_read_b128 broadcast), while the pieces of the next block are on their way into the second
+        // buffer.  Same coefficients, same order of the chains: the same bits as the gather.
+        constexpr int PIECES = NC * NFP / 2;                 // 16-byte pieces of a block (88 at degree 10)
+        constexpr int PBUF = PIECES > CPOL_WAVE ? PIECES : CPOL_WAVE;
+        constexpr int REST = PIECES - CPOL_WAVE;
+        double2 *my_blk = reinterpret_cast<double2 *>(s_raw + (size_t)n_h * 64 * GATE1S_BYTES) + (size_t)j * 2 * PBUF;
+        const bool on_tab = t.tab && it.lookup;
+        const int pn = on_tab ? min((int)it.pf, t.n_pan - 1) : 0;
+        const double u = 2.0 * (it.pf - (double)pn) - 1.0;
+        const int blk_id = on_tab ? (it.key - h.key_base) * t.n_pan + pn : -1;
+        auto request = [&](int blk, int bufi) {
+            const double2 *src = reinterpret_cast<const double2 *>(t.tab + (long)blk * NB);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + (PIECES >= CPOL_WAVE ? lane : min(lane, PIECES - 1))),
+                                             (void __attribute__((address_space(3))) *)(my_blk + bufi * PBUF), 16, 0, 0);
+            if (lane < REST)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + CPOL_WAVE + lane),
+                                                 (void __attribute__((address_space(3))) *)(my_blk + bufi * PBUF + CPOL_WAVE), 16, 0, 0);
+        };
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(on_tab);
+        if (todo) {
+            int cur = 0;
+            int b = __builtin_amdgcn_readlane(blk_id, __ffsll((long long)todo) - 1);
+            request(b, 0);
+            while (todo) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const bool mine = blk_id == b;
+                todo &= ~__builtin_amdgcn_ballot_w64(mine);
+                if (todo) {
+                    b = __builtin_amdgcn_readlane(blk_id, __ffsll((long long)todo) - 1);
+                    request(b, cur ^ 1);                    // in flight during the chains below
+                }
+                const double2 *sb = my_blk + cur * PBUF;
+                if (mine) {
+#pragma unroll
+                    for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = sb[(NC - 1) * (NFP / 2) + c];
+                    if (want_vn) wv = sb[(NC - 1) * (NFP / 2) + CPOL_N_SZ / 2];
+#pragma unroll CPOL_GATE1S_ROW_UNROLL
+                    for (int q = NC - 2; q >= 0; --q) {
+#pragma unroll
+                        for (int c = 0; c < CPOL_N_SZ / 2; ++c) {
+                            const double2 cq = sb[q * (NFP / 2) + c];
+                            v[c].x = fma(v[c].x, u, cq.x);
+                            v[c].y = fma(v[c].y, u, cq.y);
+                        }
+                        if (want_vn) {
+                            const double2 cq = sb[q * (NFP / 2) + CPOL_N_SZ / 2];
+                            wv.x = fma(wv.x, u, cq.x);
+                            wv.y = fma(wv.y, u, cq.y);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < CPOL_N_SZ / 2; ++c) { v[c].x *= it.scale; v[c].y *= it.scale; }
+                    wv.x *= it.scale; wv.y *= it.scale;
+                    have = true;
+                }
+                cur ^= 1;
+            }
+        }
+    }
+#else
     if (t.tab && it.lookup) {
         // ---- 1-D block: the lane gathers the rows of its (slice, panel) block (as k_gate1) ----
         const int pn = min((int)it.pf, t.n_pan - 1);
@@ -522,6 +598,7 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
         wv.x *= it.scale; wv.y *= it.scale;
         have = true;
     }
+#endif
     int my_lookup = it.lookup ? 1 : 0;
     bool off_table = it.valid && !it.lookup;
     if (RAY) {
