@@ -1534,6 +1534,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     const bool dop2 = p->simulate_doppler == 2;
     const bool dop3 = p->simulate_doppler == 3;
     const int n_vb = p->n_vbins;
+    bool spec_melt = false;                // Doppler scheme 3: a melting species is staged (its fall-speed tables take LDS of k_spec_gate)
     if (dop3) {
         if (n_vb < 2 || n_vb > 4097 || !t->varray || p->var_rho < 0 || p->var_rho >= n_vars) {
             ctx->err = "cpol_run_sweep: Doppler scheme 3 needs n_vbins in [2, 4097], tables->varray and var_rho";
@@ -1546,7 +1547,8 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                 return CPOL_ERR_ARG;
             }
         }
-        if (((size_t)2 * ctx->hs.h[0].d.n_d + 256) * sizeof(double) + ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) + n_vb) * sizeof(float) > 64 * 1024) {
+        for (int j = 0; j < n_hyd; ++j) spec_melt = spec_melt || ctx->hs.h[j].d.psd_family == CPOL_PSD_MELTING;
+        if ((spec_melt ? ((size_t)2 * ctx->hs.h[0].d.n_d + 256) * sizeof(double) : 0) + ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) + n_vb) * sizeof(float) > 64 * 1024) {
             ctx->err = "cpol_run_sweep: Doppler scheme 3: n_hydro x (n_d + n_vbins) exceeds the LDS of a workgroup";
             return CPOL_ERR_ARG;
         }
@@ -2341,8 +2343,9 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sp.n_sbg = n_sbg; sp.n_gates = ng; sp.n_sub = n_sub; sp.n_h = n_h; sp.n_v = n_vb;
         sp.var_u = p->var_u; sp.var_v = p->var_v; sp.var_w = p->var_w; sp.var_rho = p->var_rho;
         sp.c_spec = (float)p->c_spectrum;
-        // [2][n_d] + [threads] float64 (melting species), [n_hyd][n_d] + [n_hyd + 1][n_v] float32 (cpol_spectrum.inl)
-        const size_t lds = ((size_t)2 * ctx->hs.h[0].d.n_d + CPOL_SPEC_THREADS) * sizeof(double)
+        // [2][n_d] + [threads] float64 (only with melting species), [n_hyd][n_d] + [n_hyd + 1][n_v] float32 (cpol_spectrum.inl)
+        sp.n_melt_rows = spec_melt ? 2 : 0;
+        const size_t lds = (spec_melt ? ((size_t)2 * ctx->hs.h[0].d.n_d + CPOL_SPEC_THREADS) * sizeof(double) : 0)
                            + ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) + n_vb) * sizeof(float);
         hipLaunchKernelGGL(k_spec_gate, dim3((unsigned)n_sbg), dim3(CPOL_SPEC_THREADS), lds, st, ctx->hs, ctx->ss, sp);
         if (p->with_attenuation) {
@@ -2695,6 +2698,7 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
     else if (!strcmp(name, "sub_mask")) { src = ctx->b_mask.p; bytes = n_sbg; }
     else if (!strcmp(name, "sub_elev")) { src = ctx->b_elev.p; bytes = n_sbg * 4; }
     else if (!strcmp(name, "sub_coords")) { src = ctx->b_coords.p; bytes = n_sbg * 8; }
+    else if (!strcmp(name, "sub_wgate")) { src = ctx->b_wgate.p; bytes = n_sbg * 8; }      // integration scheme 'ml': per-gate weights of every sub-beam
     else if (!strcmp(name, "item_key")) { src = ctx->b_key.p; bytes = (int64_t)n_hyd * n_sbg * 4; }
     else if (!strcmp(name, "item_res")) {
         if (ctx->last_subsum) {

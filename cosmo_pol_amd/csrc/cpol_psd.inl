@@ -324,11 +324,18 @@ __device__ __forceinline__ void count_table_items(int *n_lookup, int items)
     if (items) atomicAdd(n_lookup + 2 + slot, items);
 }
 
+#ifndef CPOL_EXP_NO_TFUN
+#define CPOL_EXP_NO_TFUN 0
+#endif
 __device__ __forceinline__ bool tfun_lookup(const float *tab, float T, float &out)
 {
     const unsigned idx = __float_as_uint(T) - CPOL_TFUN_FIRST_BITS;
     if (!tab || idx >= CPOL_TFUN_COUNT) return false;
+#if CPOL_EXP_NO_TFUN               // (timing experiment only, wrong values: no gather into the 64-MB table)
+    out = T * 1.0e-3f;
+#else
     out = tab[idx];
+#endif
     return true;
 }
 

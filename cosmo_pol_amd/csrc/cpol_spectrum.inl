@@ -38,6 +38,7 @@ struct SpecArgs {
     int n_gates, n_sub, n_h, n_v;
     int var_u, var_v, var_w, var_rho, var_t;
     float c_spec;               // (float)(wavelength^4 / (pi^5 K^2 K^2))
+    int n_melt_rows;            // 0, or 2 when a melting species is staged: rows of n_d float64 fall speeds in front of the float32 part of the LDS image
 };
 
 __device__ __forceinline__ float clamp_pair(float D, float d_min, float d_max)
@@ -128,9 +129,9 @@ __global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, Sp
     const int n_d = hs.h[present[0]].d.n_d;
     // LDS: [2][n_d] float64 fall speeds of the (at most two) melting species + [CPOL_SPEC_THREADS] float64 scratch, then
     // [n_hydro][n_d] float32 N x rcs, [n_hydro][n_v] float32 edge diameters
-    double *VL = reinterpret_cast<double *>(lds_spec);                        // [2][n_d]
-    double *redL = VL + 2 * (long)n_d;                                        // [CPOL_SPEC_THREADS]
-    float *prodL = reinterpret_cast<float *>(redL + CPOL_SPEC_THREADS);       // [n_p][n_d]
+    double *VL = reinterpret_cast<double *>(lds_spec);                        // [n_melt_rows][n_d]
+    double *redL = VL + (long)a.n_melt_rows * n_d;                            // [CPOL_SPEC_THREADS] (with melting species only)
+    float *prodL = reinterpret_cast<float *>(redL + (a.n_melt_rows ? CPOL_SPEC_THREADS : 0));       // [n_p][n_d]
     float *DL = prodL + (long)hs.n_hydro * n_d;                               // [n_p][n_v]
     MeltGate mg[2];
     int melt_of[CPOL_SPEC_MAX_H];                       // present species -> 0 / 1 (its row of VL), or -1
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(CPOL_SPEC_THREADS) void k_spec_gate(HydroSet hs, Sp
         const float *rcs = sd.rcs32 + (long)(key - h.key_base) * d.n_d;
         const double *P = a.par + ((long)j * CPOL_MAX_PAR) * n + sbg;
         melt_of[p] = -1;
-        if (d.psd_family == CPOL_PSD_MELTING && n_melt < 2) {
+        if (d.psd_family == CPOL_PSD_MELTING && n_melt < a.n_melt_rows) {
             // ---- a melting species: its grid, fall speeds and PSD belong to THIS gate's wet fraction ----
             MeltGate &g = mg[n_melt];
             g.q = P[0]; g.fw = P[n]; g.lam_r = P[2 * n];

@@ -23,8 +23,13 @@ def draw(rng):
     two = bool(rng.random() < 0.3)
     melting = (not two) and bool(rng.random() < 0.4)
     dop = int(rng.choice([1, 1, 2, 3]))
-    if melting and dop == 3:
-        dop = 2
+    force = os.environ.get('CPOL_FUZZ_FORCE', '')
+    if force == 'melt_dop3' and not two:
+        # (round 6: the Doppler spectrum with the melting species on every 1-moment case -- sub-beams with and without melting,
+        # 'ml' weights, ice, attenuation, the sensitivity cut)
+        melting, dop = True, 3
+    if melting and dop == 3 and not force and not os.environ.get('CPOL_FUZZ_MELT_SPECTRUM'):
+        dop = 2                           # (the draws of rounds 1-5, whose seeds the records quote: replayed unchanged)
     quad = rng.choice(['gh', 'gh', 'ml', 'leg'])
     if quad == 'ml' and not melting:
         quad = 'gh'
@@ -106,8 +111,25 @@ def main():
                     with np.errstate(invalid='ignore'):
                         mag = np.nanmax([np.abs(np.nan_to_num(np.asarray(sb.values[nm], dtype=np.float64)))
                                          for sb in subs], axis=0)
-                    _cases.assert_close_nan(res['model_vars'][i][r], integ.values[nm], rtol=1e-12,
-                                            atol=1e-13 * mag, name='model:' + nm)
+                    try:
+                        _cases.assert_close_nan(res['model_vars'][i][r], integ.values[nm], rtol=1e-12,
+                                                atol=1e-13 * mag, name='model:' + nm)
+                    except AssertionError:
+                        # A float32 coordinate of a NON-CENTRAL sub-beam one ulp off the long form's (the coordinate polynomials of
+                        # round 5: ~6e-7 of the coordinates, never another cell or mask -- DESIGN.md section 4) moves the weights
+                        # inside the cell and with them a gate's interpolated values by a few float32 ulp: seed 9802, case 404, the
+                        # first such hit in ~4 000 cases.  Then the long form of every sub-beam (debug_flags =
+                        # CPOL_DEBUG_EXACT_SUBBEAMS) must meet the strict bound, and the default form a float32 one.
+                        from cosmo_pol_amd import _native as N
+                        op.debug_flags = N.DEBUG_EXACT_SUBBEAMS
+                        exact = op.simulate_rays(azs, els, apply_sensitivity=cut)
+                        op.debug_flags = 0
+                        _cases.assert_close_nan(exact['model_vars'][i][r], integ.values[nm], rtol=1e-12,
+                                                atol=1e-13 * mag, name='model (long form of every sub-beam):' + nm)
+                        _cases.assert_close_nan(res['model_vars'][i][r], integ.values[nm], rtol=1e-6,
+                                                atol=1e-7 * mag, name='model (coordinate polynomials):' + nm)
+                        print('note: case %d ray %d %s: a sub-beam coordinate one ulp off the long form (strict bound met by the long form)'
+                              % (case, r, nm), flush=True)
                 o = scatter.radar_observables(subs, olut, conf, return_sz=True, nyquist=nyq)
                 if cut:
                     scatter.cut_at_sensitivity([[o]], conf)   # the scan form (list of sweeps): spectrum censored bin by bin, as the device does
