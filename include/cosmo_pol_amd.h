@@ -430,7 +430,14 @@ CPOL_API int  cpol_enable_timing(cpol_ctx *ctx, int on);
  * float32 [n_sbg], "sub_coords" float32 [n_sbg][2], "item_key" int32
  * [n_hydro][n_sbg], "sz_integ" float32 [n_rays*n_gates][n_hydro][12],
  * "traj" float32 [n_rays][n_vnodes][3][n_gates], "item_res" float64
- * [n_hydro][n_sbg][12].  Returns bytes copied or < 0. */
+ * [n_hydro][n_sbg][12], "sub_wgate" float64 [n_sbg] (integration scheme 'ml': the per-gate
+ * sub-beam weights).  Without the debug reads enabled: "launch_forms" int32 [12] -- which launch
+ * sequence the last cpol_run_sweep of this context took: [0] the CPOL_GATE1_RAY rule in force,
+ * [1] k_gate1_ray ran, [2] the single-beam gate kernel, [3] k_interp_classify, [4] items off the
+ * tables listed directly, [5] k_subbeam_sum, [6] table items evaluated in place, [7] the one
+ * sub-beam on the coordinate polynomials, [8] n_sub, [9] lanes alive, [10] reserved, [11] a HIP
+ * graph was replayed; "poly_central", "host_times", "cache", "itab_check", "itab_times",
+ * "itab_detail<slot>" (see cosmo_pol_amd/_native.py).  Returns bytes copied or < 0. */
 CPOL_API int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_bytes);
 
 /* test hook: evaluates one of the device math helpers of the melting-species kernel on
