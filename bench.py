@@ -325,8 +325,8 @@ def compact_line(d):
         out['host_outputs_ms_per_sweep_repeats'] = ho.get('ms_per_sweep_repeats')
         out['host_outputs_d2h_bytes_per_step'] = ho.get('d2h_bytes_per_step')
         out['host_outputs_d2h_GBs'] = ho.get('d2h_GBs')
-        if (ho.get('with_float64_mask_from_the_device') or {}).get('value'):
-            out['value_host_outputs_f64_mask'] = ho['with_float64_mask_from_the_device']['value']
+        if (ho.get('with_the_mask_as_one_byte_per_gate') or {}).get('value'):
+            out['value_host_outputs_mask_bytes'] = ho['with_the_mask_as_one_byte_per_gate']['value']
         if (d.get('host_outputs_new_geometry') or {}).get('value'):
             out['value_host_outputs_new_geometry'] = d['host_outputs_new_geometry']['value']
         if ho.get('value') and cpu and cpu.get('value'):
@@ -800,23 +800,24 @@ def run_c2(env):
 
     extra = {}
     iso = cnt = None
-    mask_b = 1 if getattr(op, 'compact_mask', False) else 8          # the radial mask crosses PCIe as one byte per gate (round 6)
-    d2h_full = n_rays * n_gates * (len(RADAR_FIELDS) * 4 + 8 + mask_b + 8 + 8 + 4 + 4)     # 9 observables, RVEL, mask, lats, lons, dist, heights
-    d2h_cycle = n_rays * n_gates * (len(RADAR_FIELDS) * 4 + 8 + mask_b)                    # ... of a repeated geometry: the gate coordinates are the host's
+    d2h_full = n_rays * n_gates * (len(RADAR_FIELDS) * 4 + 8 + 8 + 8 + 8 + 4 + 4)     # 9 observables, RVEL, mask, lats, lons, dist, heights
+    d2h_cycle = n_rays * n_gates * (len(RADAR_FIELDS) * 4 + 8 + 8)                    # ... of a repeated geometry: the gate coordinates are the host's
     if not weak:
         # THE SURVEY 8(d) STEP ON A REPEATED SCAN GEOMETRY (round 6; `value_host_outputs`): a volume scan cycles through its
         # elevations -- a radar repeats its scan strategy every few minutes -- so the host holds the per-ray constants of the
         # 8 elevations, the device their tables, and the gate coordinates (lats, lons, dist, heights: functions of site,
         # azimuth and elevation alone) were copied ONCE per table set: every later result carries the same read-only arrays.
-        # All 15 arrays are delivered; 11 cross PCIe (9 observables, RVEL, the mask as one byte per gate).
+        # All 15 arrays are delivered complete; 11 cross PCIe (9 observables, RVEL, the float64 mask: 52 B per gate).
         def step_host_cycle():
             k = counter[0]
             counter[0] += 1
             return op.simulate_rays(az, els[(k + rank) % n_cycle], pinned=True, lane=k % n_lanes)
+        op.compact_mask = False                  # (the default: the mask as the device's float64 array -- nothing left to do on the host)
         for _ in range(max(4 * n_cycle, 4 * args.steps)):
             last_host = step_host_cycle()
         fence()
         assert all(k in last_host for k in RADAR_FIELDS + ['RVEL', 'mask', 'lats', 'lons', 'dist', 'heights'])
+        assert last_host['mask'].dtype == np.float64 and 'mask_sum8' not in last_host
         settle_c = [timed(step_host_cycle, n_cycle * args.steps) for _ in range(2)]
         runs_c = [timed(step_host_cycle, n_cycle * args.steps) for _ in range(max(1, args.repeats))]
         e_cy = statistics.median(e for e, _ in runs_c)
@@ -829,26 +830,27 @@ def run_c2(env):
             'd2h_bytes_per_step': d2h_cycle, 'd2h_GBs': d2h_cycle * n_sw / e_cy / 1e9,
             'arrays_delivered': 15, 'arrays_copied_per_sweep': 11,
             'note': 'SURVEY 8(d) step on a repeated scan geometry: the 8 elevations of the headline step in turn, every result '
-                    'handed over as the reference hands it over (all 15 arrays in host memory); the gate coordinates of a '
-                    'table set are copied once and shared read-only between results, the mask crosses PCIe as one byte per '
-                    'gate and becomes float64 on first read; PCIe-bound.  `host_outputs_new_geometry`: a NEW geometry every '
-                    'step (rounds 1-5\'s definition)'}
-        # the same step with the mask as the device's float64 array (8 bytes per gate over PCIe, nothing left to do on the host),
-        # and what making the float64 mask from its bytes costs the thread that reads it
-        op.compact_mask = False
+                    'handed over as the reference hands it over (all 15 arrays complete in host memory); the gate coordinates '
+                    'of a table set are copied once and shared read-only between results; PCIe-bound.  '
+                    '`with_the_mask_as_one_byte_per_gate`: RadarOperator.compact_mask = True (the mask crosses PCIe as the sum '
+                    'of the sub-beams\' codes and becomes float64 when first read, on the reader\'s thread).  '
+                    '`host_outputs_new_geometry`: a NEW geometry every step (rounds 1-5\'s definition)'}
+        # the same step with the mask as one byte per gate over PCIe (RadarOperator.compact_mask = True), and what making the
+        # float64 mask from its bytes then costs the thread that reads it
+        op.compact_mask = True
         for _ in range(2 * n_cycle):
-            step_host_cycle()
+            last_host = step_host_cycle()
         fence()
         runs_f = [timed(step_host_cycle, n_cycle * args.steps) for _ in range(3)]
-        op.compact_mask = True
+        op.compact_mask = False
         e_f = statistics.median(e for e, _ in runs_f)
         t0 = time.perf_counter()
         for _ in range(5):
-            last_host._data['mask'] = LazyMaskProbe(last_host)
-        extra['host_outputs']['with_float64_mask_from_the_device'] = {
+            LazyMaskProbe(last_host)
+        extra['host_outputs']['with_the_mask_as_one_byte_per_gate'] = {
             'value': gates_per_sweep * n_sw / e_f, 'ms_per_sweep': 1e3 * e_f / n_sw,
-            'd2h_bytes_per_step': d2h_cycle + 7 * n_rays * n_gates}
-        extra['host_outputs']['mask_widening_ms_per_sweep_when_read'] = 1e3 * (time.perf_counter() - t0) / 5
+            'd2h_bytes_per_step': d2h_cycle - 7 * n_rays * n_gates,
+            'mask_widening_ms_per_sweep_when_read': 1e3 * (time.perf_counter() - t0) / 5}
         del last_host
 
         # the step with the reference's hand-over (host arrays), PCIe included: rounds 1-3's headline
@@ -997,7 +999,7 @@ def run_c2(env):
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'value_definition': 'v2 (round 4 on): sweeps at 8 elevations in turn (round 6: 80 per step), inputs and outputs resident in HBM; '
                             'value_host_outputs = the SURVEY 8(d) step on a repeated scan geometry (round 6: all 15 arrays '
-                            'delivered, 11 copied per sweep); value_host_outputs_new_geometry = a new geometry every step '
+                            'delivered complete, 11 copied per sweep: 52 B per gate); value_host_outputs_new_geometry = a new geometry every step '
                             '(v1: `value` in rounds 1-3, `value_host_outputs` in rounds 4-5)',
         'config': {'workload': 'c2: step = %d sweeps per GPU (%d cycles of 8 elevations) of the 360-az x 500-gate C-band PPI (R+S+G 1-mom, 1 sub-beam), '
                                'inputs and outputs resident in HBM; synthetic %s cube; each sweep = one cpol_run_sweep at one of '
@@ -1091,7 +1093,7 @@ def run_c3(env):
     """BASELINE configs[2] on one GPU: 5 elevations x (360 x 500), R,S,G,mS,mG,I, one sub-beam.  A step
     = one volume through the C ABI, a volume scan that REPEATS (round 6; rounds 1-5 re-uploaded the per-ray tables and
     copied the gate coordinates with every sweep): the per-ray tables of the five elevations stay on the device,
-    per sweep the kernels run and 11 arrays (9 observables, RVEL, the mask as one byte per gate) go down into
+    per sweep the kernels run and 11 arrays (9 observables, RVEL, the mask) go down into
     page-locked host memory, the gate coordinates of the unchanged geometry come from the host's cache -- all 15
     arrays are delivered; every sweep on a lane of its own (5 lanes), so that the arrays of a volume stay valid
     until the next volume starts.  `api_ms`: the same volume through
@@ -1156,9 +1158,8 @@ def run_c3(env):
     n_vars, nz = len(op._staged_vars), cube['zlevels'].shape[0]
     roof = roofline_of_dominant_stage('c3_el3_iso', stage_ms_of(iso3), int(iso3.n_subbeam_gates), int(iso3.n_valid_items),
                                       n_rays * n_gates, n_vars, nz, note='c3 sweep at 3 deg elevation.')
-    # (9 observables, RVEL, the mask as one byte per gate since round 6 -- pinned calls; the gate coordinates of the repeated
-    # geometry are the host's: not copied)
-    d2h = gates * (len(RADAR_FIELDS) * 4 + 8 + (1 if getattr(op, 'compact_mask', False) else 8))
+    # (9 observables, RVEL, the float64 mask; the gate coordinates of the repeated geometry are the host's: not copied)
+    d2h = gates * (len(RADAR_FIELDS) * 4 + 8 + (1 if getattr(op, 'compact_mask', False) else 8))       # (compact_mask: off by default)
     return {
         'metric': 'range-gates/sec', 'value': gates * args.steps / elapsed, 'unit': 'gates/s', 'n_gpus': 1,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,

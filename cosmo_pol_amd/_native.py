@@ -615,7 +615,7 @@ class Context(object):
         return y
 
     FORM_NAMES = ('g1r', 'gate1_ray', 'gate1', 'interp_classify', 'rare_direct', 'subbeam_sum', 'final_inplace',
-                  'poly_central', 'n_sub', 'lanes_alive', 'wave_scan', 'graph_replayed')
+                  'poly_central', 'n_sub', 'lanes_alive', 'scan_form', 'graph_replayed')
 
     def launch_forms(self):
         """Which launch sequence the last cpol_run_sweep of this context took (tests / bench result checks): {name: int}."""

@@ -167,7 +167,7 @@ struct cpol_ctx {
     int upload_kernel = 0;             // CPOL_TABLE_UPLOAD=kernel: the per-ray tables by k_upload_tables instead of hipMemcpyAsync (a measurement knob)
     int last_forms[12] = {0};          // the launch forms of the last sweep (cpol_debug_read "launch_forms"): [0] g1r, [1] k_gate1_ray, [2] single-beam gate kernel,
                                        // [3] k_interp_classify, [4] items off the tables listed directly, [5] k_subbeam_sum, [6] table items evaluated in place,
-                                       // [7] coordinate polynomials for the one sub-beam, [8] n_sub, [9] lanes alive, [10] wavefront range scans, [11] HIP graph replayed
+                                       // [7] coordinate polynomials for the one sub-beam, [8] n_sub, [9] lanes alive, [10] CPOL_SCAN_FORM (1: the range scans by a whole wavefront), [11] HIP graph replayed
     int last_poly_central = 0;         // the last sweep's one sub-beam took the coordinate polynomials (cpol_debug_read "poly_central")
     int geo_poly_central = 1;          // CPOL_GEO_POLY_CENTRAL=0: a single-beam sweep keeps the long form of the geodesy for its (central) sub-beam even when
                                        // nobody asks for the float64 latitude / longitude; 2: the polynomials also with the debug reads enabled (tools/fast_sub_check.py)
@@ -2395,7 +2395,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     };
 
     const int forms[12] = {g1r, (int)gate1_ray, (int)gate1, (int)fused, (int)rare_direct, (int)subsum, (int)final_inplace, (int)poly_single,
-                           n_sub, ctx->parent ? ctx->parent->n_children : ctx->n_children, 0, 0};
+                           n_sub, ctx->parent ? ctx->parent->n_children : ctx->n_children, CPOL_SCAN_FORM, 0};
     memcpy(ctx->last_forms, forms, sizeof forms);
     const double t_buffers = now_ns();
     ctx->counters_dirty = true;         // until the sequence is queued completely (cleared where sweep_serial advances)

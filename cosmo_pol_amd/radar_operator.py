@@ -257,11 +257,12 @@ class RadarOperator(object):
                                                # sub-beam gate with six species): a scan beyond it is run as several
                                                # sequences of whole sweeps.  None: a third of the memory free at the time
         self.debug_flags = 0                   # cpol_sweep_params.debug_flags (tests / tools only: N.DEBUG_EXACT_SUBBEAMS)
-        self.compact_mask = True               # pinned (non-blocking) host outputs: the radial mask crosses PCIe as one byte per
-                                               # gate (the sum of the sub-beams' codes, cpol_outputs.mask_sum8) and becomes the
+        self.compact_mask = False              # True: in pinned (non-blocking) host outputs the radial mask crosses PCIe as one byte
+                                               # per gate (the sum of the sub-beams' codes, cpol_outputs.mask_sum8) and becomes the
                                                # reference's float64 array -- sum / n_sub, (-1, 0] -> 0: doppler_scatter.py:472-477 --
-                                               # on the host when `mask` is first read; False (and every blocking call): the
-                                               # float64 array comes from the device, 8 bytes per gate
+                                               # on the host when `mask` is first read (0.13 ms per 180 k gates, on the reader's
+                                               # thread: worth it for a consumer that seldom reads the mask; measured by bench.py).
+                                               # False (the default, and every blocking call): the float64 array from the device
         self.lut_dir = lut_dir
         if lut_dir:
             from . import tablecache

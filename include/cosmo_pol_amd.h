@@ -435,7 +435,7 @@ CPOL_API int  cpol_enable_timing(cpol_ctx *ctx, int on);
  * sequence the last cpol_run_sweep of this context took: [0] the CPOL_GATE1_RAY rule in force,
  * [1] k_gate1_ray ran, [2] the single-beam gate kernel, [3] k_interp_classify, [4] items off the
  * tables listed directly, [5] k_subbeam_sum, [6] table items evaluated in place, [7] the one
- * sub-beam on the coordinate polynomials, [8] n_sub, [9] lanes alive, [10] reserved, [11] a HIP
+ * sub-beam on the coordinate polynomials, [8] n_sub, [9] lanes alive, [10] the build's CPOL_SCAN_FORM (1: wavefront range scans), [11] a HIP
  * graph was replayed; "poly_central", "host_times", "cache", "itab_check", "itab_times",
  * "itab_detail<slot>" (see cosmo_pol_amd/_native.py).  Returns bytes copied or < 0. */
 CPOL_API int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_bytes);

@@ -81,10 +81,10 @@ def test_pinned_outputs_equal_blocking_outputs():
 
 
 def test_pinned_mask_from_its_one_byte_form_with_sub_beams():
-    """A pinned result carries the radial mask as cpol_outputs.mask_sum8 (the SUM of the sub-beams' codes, one byte per gate) and
-    makes the reference's float64 mask from it on first read (doppler_scatter.py:472-477): with 15 and 49 sub-beams -- fractional
-    masks where the sub-beams disagree (rays that leave the model top / start below the topography) -- it equals the float64 array
-    the device writes for a blocking call; `compact_mask = False` asks for that array in pinned calls too."""
+    """With `RadarOperator.compact_mask = True` a pinned result carries the radial mask as cpol_outputs.mask_sum8 (the SUM of the
+    sub-beams' codes, one byte per gate) and makes the reference's float64 mask from it on first read (doppler_scatter.py:472-477):
+    with 15 and 49 sub-beams -- fractional masks where the sub-beams disagree (rays that leave the model top / start below the
+    topography) -- it equals the float64 array the device writes for a blocking call and for a pinned call by default."""
     for name, els in (('c4_subbeams', (2.0, 25.0, 60.0)), ('c4_7x7', (3.0, 40.0))):
         op, _, _, _ = _op(name, lanes=1)
         az = np.arange(0., 360., 45.)
@@ -93,18 +93,18 @@ def test_pinned_mask_from_its_one_byte_form_with_sub_beams():
             el = np.full(len(az), e)
             ref = op.simulate_rays(az, el)
             assert 'mask_sum8' not in ref and ref['mask'].dtype == np.float64
+            op.compact_mask = True
             out = op.simulate_rays(az, el, pinned=True)
             op.wait(0)
+            op.compact_mask = False
             assert out['mask_sum8'].dtype == np.int8 and out.pending('mask')
             m = out['mask']
             assert m.dtype == np.float64 and np.array_equal(m, ref['mask']) and not out.pending('mask')
             n_frac += int(np.sum((ref['mask'] != np.round(ref['mask']))))
             for k in FIELDS:
                 assert np.array_equal(out[k], ref[k], equal_nan=True), (name, e, k)
-            op.compact_mask = False
-            plain = op.simulate_rays(az, el, pinned=True)
+            plain = op.simulate_rays(az, el, pinned=True)               # (the default: the float64 array from the device)
             op.wait(0)
-            op.compact_mask = True
             assert 'mask_sum8' not in plain and np.array_equal(plain['mask'], ref['mask'])
         assert n_frac > 0, 'no gate where the sub-beams disagree: the fractional masks were not exercised'
         op.close()
