@@ -1279,7 +1279,7 @@ def run_c4(env):
     n_loc = len(az) // n_el
     op.lanes = n_lanes                                  # (the runner keeps lanes + 1 sets of device buffers)
     # (round 6: the all-gather is the default -- the rooted `dist.gather` has run on one rank only so far; CPOL_BENCH_C4_GATHER=root
-    # opts into it, tests/test_gpu_distributed.py::test_two_gpus_nccl_* run both forms wherever two GPUs are visible)
+    # opts into it, tests/test_gpu_zz_two_gpus.py run both forms wherever two GPUs are visible)
     op.gather_to = 0 if os.environ.get('CPOL_BENCH_C4_GATHER', 'all') == 'root' else None
     runner = op._dist_runner()
     pending = collections.deque()
