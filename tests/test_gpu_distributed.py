@@ -34,6 +34,18 @@ def test_three_ranks_one_gpu_uneven_volume_split():
     assert 'DIST_GPU_OK world=3' in out.stdout
 
 
+def test_one_rank_nccl_worker_rooted_gather_three_scans_pending():
+    """The worker of the two-GPU tests (tests/test_gpu_zz_two_gpus.py) in its RCCL mode with ONE rank: process group with a
+    device id, the rooted `dist.gather` over `nccl` with three scans pending on three lanes, the page-locked result block,
+    the sharded swath -- what a one-GPU box can execute of that code."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1', CPOL_DIST_BACKEND='nccl', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', '29539', os.path.join(HERE, '_dist_gpu_worker.py')]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert 'DIST_GPU_OK world=1 backend=nccl' in out.stdout
+
+
 def _bench_two_ranks(port, *flags):
     import json
     root = os.path.dirname(HERE)
