@@ -1548,8 +1548,10 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
             }
         }
         for (int j = 0; j < n_hyd; ++j) spec_melt = spec_melt || ctx->hs.h[j].d.psd_family == CPOL_PSD_MELTING;
-        if ((spec_melt ? ((size_t)2 * ctx->hs.h[0].d.n_d + 256) * sizeof(double) : 0) + ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) + n_vb) * sizeof(float) > 64 * 1024) {
-            ctx->err = "cpol_run_sweep: Doppler scheme 3: n_hydro x (n_d + n_vbins) exceeds the LDS of a workgroup";
+        if ((spec_melt ? ((size_t)2 * ctx->hs.h[0].d.n_d + 256) * sizeof(double) : 0) + ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) + n_vb) * sizeof(float) > 160 * 1024 - 256) {
+            // (gfx950: 160 KB of LDS per CU, all of it available to ONE workgroup of k_spec_gate when the launch asks for it --
+            // six species with FFT_length = 2048, the upper end of the reference's valid range (cfg.py:91), need 100 KB)
+            ctx->err = "cpol_run_sweep: Doppler scheme 3: n_hydro x (n_d + n_vbins) exceeds the 160 KB of LDS of a gfx950 CU";
             return CPOL_ERR_ARG;
         }
     }
@@ -2347,6 +2349,14 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         sp.n_melt_rows = spec_melt ? 2 : 0;
         const size_t lds = (spec_melt ? ((size_t)2 * ctx->hs.h[0].d.n_d + CPOL_SPEC_THREADS) * sizeof(double) : 0)
                            + ((size_t)n_hyd * (ctx->hs.h[0].d.n_d + n_vb) + n_vb) * sizeof(float);
+        if (lds > 64 * 1024) {
+            // beyond the default 64 KB per workgroup: ask for it (an attribute of the kernel; the largest request so far is kept)
+            static size_t lds_allowed = 64 * 1024;
+            if (lds > lds_allowed) {
+                HIPCHK(hipFuncSetAttribute((const void *)k_spec_gate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_allowed = lds;
+            }
+        }
         hipLaunchKernelGGL(k_spec_gate, dim3((unsigned)n_sbg), dim3(CPOL_SPEC_THREADS), lds, st, ctx->hs, ctx->ss, sp);
         if (p->with_attenuation) {
             SpecAttenArgs sa2{};
