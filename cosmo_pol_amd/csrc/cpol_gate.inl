@@ -452,6 +452,9 @@ __device__ __forceinline__ void integrate_gamma_item_wave(const double *table, c
 #ifndef CPOL_EXP_ONE_BLOCK
 #define CPOL_EXP_ONE_BLOCK 0
 #endif
+#ifndef CPOL_GATE1_LAST_WAVE
+#define CPOL_GATE1_LAST_WAVE 1    // k_gate1_ray: the wavefront that finishes last finishes the gates, the others leave early (0: two workgroup barriers, wavefront 0 finishes)
+#endif
 #ifndef CPOL_GATE1_LDS
 #define CPOL_GATE1_LDS 0          // 1 (build knob, measured and rejected in round 6): the single-beam species kernels take the coefficient blocks of a
                                   // wavefront's gates through LDS, each distinct block once, instead of every lane gathering its own.  Same bits
@@ -474,7 +477,16 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
     unsigned *s_flag = reinterpret_cast<unsigned *>(s_mn + n_h * 64);                  // [n_h][64]: 1 valid, 2 off the tables, 4 moments
     __shared__ int s_lookup;
     __shared__ int s_last;
-    if (threadIdx.x == 0) s_lookup = 0;
+    __shared__ int s_done;                       // LAST_WAVE: wavefronts whose terms are in LDS
+    // LAST_WAVE (k_gate1_ray, round 6): no workgroup barrier behind the species' work.  60 % of the wavefronts of a C2 sweep hold no
+    // item at all (a species absent from the tile's 64 gates) and used to sit at the barrier -- each holding one of the 4 wave
+    // slots per SIMD the kernel's registers allow -- until the slowest wavefront of their workgroup had gathered and evaluated
+    // its blocks.  Now a wavefront that has put its terms into LDS adds to a counter and LEAVES; the one whose add comes last
+    // finishes the 64 gates (the sum over the species in order, get_pol_from_sz, RVEL, mask: the same statements on the same
+    // LDS values, whoever runs them).  The only barrier left stands at the start, where every wavefront arrives at once.
+    constexpr bool LAST_WAVE = RAY && !TICKET && CPOL_GATE1_LAST_WAVE;
+    if (threadIdx.x == 0) { s_lookup = 0; s_done = 0; }
+    if (LAST_WAVE) __syncthreads();
     const int lane = lane_id();
     const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                    // the wavefront's hydrometeor
     const int ray_b = RAY ? (int)blockIdx.y : 0;
@@ -654,8 +666,22 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
     s_flag[j * 64 + lane] = (it.valid ? 1u : 0u) | (off_table ? 2u : 0u) | (moments ? 4u : 0u);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) my_lookup += __shfl_xor(my_lookup, off);
+    if (LAST_WAVE) {
+        // this wavefront's share of the sweep's table-item count, then its ticket: release (its LDS stores are complete),
+        // acquire for the wavefront that finds every other ticket taken
+        if (lane == 0 && my_lookup) {
+            const unsigned slot = ((blockIdx.x + blockIdx.y * gridDim.x) * 4u + (unsigned)j) & (CPOL_COUNT_SLOTS - 1);
+            atomicAdd(a.n_lookup + 2 + slot, my_lookup);
+        }
+        int old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(&s_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != n_h - 1) return;                   // (not the last: the slot is free for the next workgroup's wavefronts)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
     __syncthreads();                                  // (s_lookup = 0 is visible; the species' terms are in LDS)
     if (lane == 0 && my_lookup) atomicAdd(&s_lookup, my_lookup);
+    }
 
     // ---- the gate: deferred if any species is off its table; the items of a deferred gate are stored for final_gate ----
     unsigned vbits = 0;
@@ -670,12 +696,14 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
         if (want_vn && t.tab && !t.two_d && it.lookup && a.vn)
             *reinterpret_cast<double2 *>(a.vn + ((long)j * n + i) * 2) = wv;
     }
+    if (!LAST_WAVE) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned slot = ((blockIdx.x + blockIdx.y * gridDim.x) * 4u) & (CPOL_COUNT_SLOTS - 1);
         if (s_lookup) atomicAdd(a.n_lookup + 2 + slot, s_lookup);
     }
-    if (j == 0) {
+    }
+    if (j == 0 || LAST_WAVE) {
         // ---- wavefront 0: sum over the species in order, get_pol_from_sz, RVEL, mask; the operands of the range scans ----
         if (in && deferred) a.vmask[i] = (unsigned char)vbits;
         if (in && !RAY) g.defer[i] = deferred ? 1 : 0;
