@@ -452,6 +452,9 @@ __device__ __forceinline__ void integrate_gamma_item_wave(const double *table, c
 #ifndef CPOL_EXP_ONE_BLOCK
 #define CPOL_EXP_ONE_BLOCK 0
 #endif
+#ifndef CPOL_GATE1_TILE_SWIZZLE
+#define CPOL_GATE1_TILE_SWIZZLE 0
+#endif
 #ifndef CPOL_GATE1_LAST_WAVE
 #define CPOL_GATE1_LAST_WAVE 1    // k_gate1_ray: the wavefront that finishes last finishes the gates, the others leave early (0: two workgroup barriers, wavefront 0 finishes)
 #endif
@@ -490,7 +493,13 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
     const int lane = lane_id();
     const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                    // the wavefront's hydrometeor
     const int ray_b = RAY ? (int)blockIdx.y : 0;
+#if CPOL_GATE1_TILE_SWIZZLE
+    // (experiment: workgroup (x, y) takes gate tile (x + y) mod n_tiles of ray y, so that every XCD -- workgroups go to the XCDs
+    // round robin by their linear index, x fastest -- sees every range of the ray instead of ONE gate tile of all rays)
+    const int gate_b = (RAY ? (int)((blockIdx.x + blockIdx.y) % gridDim.x) : (int)blockIdx.x) * 64 + lane;
+#else
     const int gate_b = (int)blockIdx.x * 64 + lane;
+#endif
     const long i0 = RAY ? (long)ray_b * f.n_gates + gate_b : (long)blockIdx.x * 64 + lane;
     const bool in = RAY ? gate_b < f.n_gates : i0 < a.n_sbg;
     const long n = a.n_sbg;
