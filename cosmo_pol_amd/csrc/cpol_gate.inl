@@ -453,7 +453,10 @@ __device__ __forceinline__ void integrate_gamma_item_wave(const double *table, c
 #define CPOL_EXP_ONE_BLOCK 0
 #endif
 #ifndef CPOL_GATE1_TILE_SWIZZLE
-#define CPOL_GATE1_TILE_SWIZZLE 0
+#define CPOL_GATE1_TILE_SWIZZLE 1  // k_gate1_ray: workgroup (x, y) takes gate tile (x + y) mod n_tiles of ray y (0: tile x).  Workgroups go to the 8 XCDs
+                                   // round robin by their linear index, x fastest: with 8 tiles per 500-gate ray tile x of EVERY ray landed on XCD x -- and
+                                   // the tiles differ threefold in work (the first two hold no hydrometeor at 1 deg, tile 4 the melting region): the XCDs of the
+                                   // empty tiles were idle after 14.6 us of a 31.7-us launch (tools/gate1_trace.py).  Rotated, every XCD ends within 2 us of 27.4
 #endif
 #ifndef CPOL_GATE1_LAST_WAVE
 #define CPOL_GATE1_LAST_WAVE 1    // k_gate1_ray: the wavefront that finishes last finishes the gates, the others leave early (0: two workgroup barriers, wavefront 0 finishes)
@@ -494,8 +497,8 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
     const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                    // the wavefront's hydrometeor
     const int ray_b = RAY ? (int)blockIdx.y : 0;
 #if CPOL_GATE1_TILE_SWIZZLE
-    // (experiment: workgroup (x, y) takes gate tile (x + y) mod n_tiles of ray y, so that every XCD -- workgroups go to the XCDs
-    // round robin by their linear index, x fastest -- sees every range of the ray instead of ONE gate tile of all rays)
+    // (workgroup (x, y) takes gate tile (x + y) mod n_tiles of ray y, so that every XCD -- workgroups go to the XCDs round robin
+    // by their linear index, x fastest -- sees every range of the ray instead of ONE gate tile of all rays: see the knob)
     const int gate_b = (RAY ? (int)((blockIdx.x + blockIdx.y) % gridDim.x) : (int)blockIdx.x) * 64 + lane;
 #else
     const int gate_b = (int)blockIdx.x * 64 + lane;
@@ -514,8 +517,19 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
     const float e = in ? a.elev[i] : 0.f;
     const float T = in ? a.vals[d.var_t * n + i] : 0.f;
     const float qm = in ? a.vals[d.var_q * n + i] : 0.f;                               // (q_source == CPOL_Q_MODEL: no melting species here)
+#ifdef CPOL_SUBSUM_TRACE
+    // (-DCPOL_SUBSUM_TRACE build, tools/gate1_trace.py: the phases of every wavefront of k_gate1_ray on the 100-MHz clock)
+    unsigned long long g1t[6], g1_valid = 0, g1_hw = 0;
+    g1t[0] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g1t[1] = wall_clock64();                           // the gate's model values have arrived
+#endif
     ClassItem it;
     classify_item(h, t, a, a.vals, n, i, i, in, qm, 0.0, T, d.var_t, e, it);
+#ifdef CPOL_SUBSUM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g1t[2] = wall_clock64();                           // PSD parameters, table position
+#endif
     double2 v[CPOL_N_SZ / 2];
 #pragma unroll
     for (int c = 0; c < CPOL_N_SZ / 2; ++c) v[c] = make_double2(0.0, 0.0);
@@ -620,6 +634,15 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
         have = true;
     }
 #endif
+#ifdef CPOL_SUBSUM_TRACE
+    {
+        double keep = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPOL_N_SZ / 2; ++c) keep += v[c].x + v[c].y;
+        asm volatile("" :: "v"(keep));
+        g1t[3] = wall_clock64();                       // coefficient gather + Horner chains
+    }
+#endif
     int my_lookup = it.lookup ? 1 : 0;
     bool off_table = it.valid && !it.lookup;
     if (RAY) {
@@ -685,6 +708,21 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(&s_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);
+#ifdef CPOL_SUBSUM_TRACE
+        g1t[4] = wall_clock64();                       // terms in LDS, ticket taken
+        g1_valid = (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(it.valid)) | ((unsigned long long)j << 32);
+        g1_hw = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;
+        if (old != n_h - 1) {
+            const unsigned long w = ((unsigned long)blockIdx.y * gridDim.x + blockIdx.x) * n_h + j;
+            if (lane == 0 && w < CPOL_SUBSUM_TRACE_N) {
+                for (int q = 0; q < 5; ++q) g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + q] = g1t[q];
+                g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 5] = 0;
+                g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 6] = g1_valid;
+                g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 7] = g1_hw;
+            }
+        }
+#endif
         if (old != n_h - 1) return;                   // (not the last: the slot is free for the next workgroup's wavefronts)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     } else {
@@ -739,6 +777,18 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
             g.sv[i] = fv;
         }
     }
+#ifdef CPOL_SUBSUM_TRACE
+    if (LAST_WAVE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long w = ((unsigned long)blockIdx.y * gridDim.x + blockIdx.x) * n_h + j;
+        if (lane == 0 && w < CPOL_SUBSUM_TRACE_N) {
+            for (int q = 0; q < 5; ++q) g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + q] = g1t[q];
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 5] = wall_clock64();      // the 64 gates finished (this wavefront took the last ticket)
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 6] = g1_valid;
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 7] = g1_hw;
+        }
+    }
+#endif
     if (!TICKET) return;
 
     // ---- the ray's ticket: the workgroup that finishes LAST of the ray scans it ----
