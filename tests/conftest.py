@@ -26,7 +26,9 @@ def golden():
 
 def pytest_sessionfinish(session, exitstatus):
     """The ledger of operand-scaled tolerances (tests/_cases.py::assert_close_nan): per (test, variable) how many gates passed
-    only thanks to their `atol` -- appended to gpurun_out/atol_ledger.jsonl (copied to profiles/ per round)."""
+    only thanks to their `atol` -- appended to gpurun_out/atol_ledger.jsonl (copied to profiles/ per round).  Child pytest
+    sessions (tests/test_gpu_boundary.py runs the parity module again in other staging modes) append their own rows: `session`
+    tells them apart."""
     try:
         import json
         import _cases
@@ -36,7 +38,7 @@ def pytest_sessionfinish(session, exitstatus):
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, 'atol_ledger.jsonl'), 'a') as f:
             for (test, var), (n_atol, n, worst) in sorted(_cases.ATOL_LEDGER.items()):
-                f.write(json.dumps({'test': test, 'var': var, 'gates_that_needed_atol': n_atol, 'gates_compared': n,
+                f.write(json.dumps({'session': os.getpid(), 'test': test, 'var': var, 'gates_that_needed_atol': n_atol, 'gates_compared': n,
                                     'worst_pure_rel_among_them': worst}) + '\n')
     except Exception:                    # (never turn a finished run red)
         pass
