@@ -2659,7 +2659,7 @@ int64_t cpol_debug_read(cpol_ctx *ctx, const char *name, void *dst, int64_t max_
         return 64 * 8 * 8;
     }
 #endif
-#if defined(CPOL_SUBSUM_TRACE) || defined(CPOL_LOOKUP_TRACE)
+#if defined(CPOL_SUBSUM_TRACE) || defined(CPOL_LOOKUP_TRACE) || defined(CPOL_INTERP_TRACE)
     if (!strcmp(name, "subsum_trace")) {
         const int64_t nb = (int64_t)sizeof(unsigned long long) * CPOL_SUBSUM_TRACE_W * CPOL_SUBSUM_TRACE_N;
         if (!dst || max_bytes < nb) return CPOL_ERR_ARG;

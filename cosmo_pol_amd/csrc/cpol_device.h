@@ -148,7 +148,8 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-#if defined(CPOL_SUBSUM_TRACE) || defined(CPOL_LOOKUP_TRACE)
+#if defined(CPOL_SUBSUM_TRACE) || defined(CPOL_LOOKUP_TRACE) || defined(CPOL_INTERP_TRACE)
+// (CPOL_INTERP_TRACE, tools/interp_trace.py: the phases of every wavefront of k_interp_sweep / k_interp_classify)
 // measurement builds (tools/subsum_trace.py): per wavefront of k_subbeam_sum* (index blockIdx.y * gridDim.x + blockIdx.x, times W
 // + wave for the team form) or of k_psd_lookup (CPOL_LOOKUP_TRACE: global wavefront index), the first CPOL_SUBSUM_TRACE_N of them:
 // start and end on the 100-MHz clock, iterations with work, HW_ID | XCC_ID << 32, then (team form) seven phase times in 10-ns

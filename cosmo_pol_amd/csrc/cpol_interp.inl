@@ -277,6 +277,16 @@ __global__ void k_spaceborne_first_gate(const double *__restrict__ ray_traj,
 }
 
 // ---------------------------------------------------------------- gate kernel
+#ifdef CPOL_INTERP_TRACE
+// (measurement build: phase k of this wavefront on the 100-MHz clock, after everything issued before it has arrived)
+#define ITRACE(tr, k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); (tr)[k] = wall_clock64(); } while (0)
+#define ITRACE_ARG , unsigned long long *itr
+#define ITRACE_PASS , itr
+#else
+#define ITRACE(tr, k) do { } while (0)
+#define ITRACE_ARG
+#define ITRACE_PASS
+#endif
 // largest i in [0, n-2] with col[i] >= key (col strictly descending, col[0] >= key)
 __device__ __forceinline__ int level_search(const float *__restrict__ col, int n, float key)
 {
@@ -292,6 +302,13 @@ __device__ __forceinline__ int level_search(const float *__restrict__ col, int n
 }
 
 struct __attribute__((packed, aligned(4))) F2 { float v[2]; };
+struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
+#ifndef CPOL_LEVEL_SEARCH_WIDE
+#define CPOL_LEVEL_SEARCH_WIDE 1
+#endif
+#ifndef CPOL_INTERP_XCD_RAYS
+#define CPOL_INTERP_XCD_RAYS 1
+#endif
 
 struct GateGeom {
     int status;            // 0 ok, +1 above model top, -1 below topography
@@ -302,7 +319,7 @@ struct GateGeom {
 };
 
 __device__ __forceinline__ void gate_geometry(const ModelDev &m, float rlat, float rlon, float h,
-                                              GateGeom &g)
+                                              GateGeom &g ITRACE_ARG)
 {
     // interpolation_c.c:43-57
     float p0 = (rlat - m.llc1) / m.res1;
@@ -329,6 +346,7 @@ __device__ __forceinline__ void gate_geometry(const ModelDev &m, float rlat, flo
     for (int k = 0; k < 4; ++k) { const float2 tl = m.HT[g.cell[k]]; top[k] = tl.x; t[k] = tl.y; }
     // interpolation_c.c:61
     float topo = g.dx * g.dy * t[0] + g.x * t[2] * g.dy + g.dx * t[1] * g.y + g.x * g.y * t[3];
+    ITRACE(itr, 2);                                        // topography of the four columns
     if (!(topo < h)) { g.status = -1; return; }
     g.status = 0;
     // Level search (interpolation_c.c:108-135: the largest i in [0, nz - 2] with col[i] >= h, 0 if
@@ -344,18 +362,60 @@ __device__ __forceinline__ void gate_geometry(const ModelDev &m, float rlat, flo
     int idx[4];
     float za[4], zb[4];                 // col[idx], col[idx + 1]
     {
-        int i = 0, step = 1;
-        while ((step << 1) <= nz - 2) step <<= 1;            // wave-uniform
+        int i = 0;
+#if CPOL_LEVEL_SEARCH_WIDE
+        // (round 6: the bisection is 7 DEPENDENT gathers -- 2.2 us of a wavefront's 13 on the C2 sweep, 4.2 of 21 on the C4 volume,
+        // tools/interp_trace.py -- for 7 loads.  Strictly descending columns make the index a COUNT: the number of levels 1 .. nz - 2
+        // at or above the gate.  Two rounds of independent loads: every 16th level, then the 15 levels behind the last of those at
+        // or above -- 4 + 4 gathers, the same index.)
+        if (nz >= 4 && nz <= 16 * 9) {
+            float cv[8];
+#pragma unroll
+            for (int q = 1; q <= 4; ++q) cv[q - 1] = col[0][min(16 * q, nz - 1)];   // (independent loads, no branch between them)
+#pragma unroll
+            for (int q = 5; q <= 8; ++q) cv[q - 1] = 0.0f;
+            if (nz - 2 >= 16 * 5) {                                                  // (wave-uniform)
+#pragma unroll
+                for (int q = 5; q <= 8; ++q) cv[q - 1] = col[0][min(16 * q, nz - 1)];
+            }
+            int c = 0;
+#pragma unroll
+            for (int q = 1; q <= 8; ++q) c += (16 * q <= nz - 2 && cv[q - 1] >= h) ? 1 : 0;
+            const int base = 16 * c;
+            // levels base + 1 .. base + 16 (the last is the next of the sixteenths -- below the gate, or past nz - 2 -- and counts nothing)
+            F4 w[4];
+            int s0[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] = min(base + 1 + 4 * r, nz - 4);                               // (window kept inside the column)
+                w[r] = *(const F4 *)(col[0] + s0[r]);
+            }
+            int cnt = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int lev = s0[r] + t;
+                    cnt += (lev >= base + 1 + 4 * r && lev <= nz - 2 && w[r].v[t] >= h) ? 1 : 0;
+                }
+            i = base + cnt;
+        } else
+#endif
+        {
+            int step = 1;
+            while ((step << 1) <= nz - 2) step <<= 1;        // wave-uniform
 #pragma unroll 1
-        for (; step >= 1; step >>= 1) {
-            const int j = min(i + step, nz - 2);
-            const float v = col[0][j];
-            if (i + step <= nz - 2 && v >= h) i = j;
+            for (; step >= 1; step >>= 1) {
+                const int j = min(i + step, nz - 2);
+                const float v = col[0][j];
+                if (i + step <= nz - 2 && v >= h) i = j;
+            }
         }
         idx[0] = i;
         const F2 p = *(const F2 *)(col[0] + i);
         za[0] = p.v[0]; zb[0] = p.v[1];
     }
+    ITRACE(itr, 3);                                        // column 0 bisected
 #pragma unroll
     for (int k = 1; k < 4; ++k) {
         int i = idx[0];
@@ -373,6 +433,7 @@ __device__ __forceinline__ void gate_geometry(const ModelDev &m, float rlat, flo
         }
         idx[k] = i; za[k] = a; zb[k] = b;
     }
+    ITRACE(itr, 4);                                        // the three neighbour columns bracketed
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (h > top[k]) { g.status = 1; return; }            // interpolation_c.c:70-73
@@ -411,7 +472,6 @@ __device__ __forceinline__ float gate_value(const ModelDev &m, const GateGeom &g
 // (Measured and dropped: the 36 float32 divisions of a gate as ONE float64 reciprocal per column and a
 // float64 product rounded to float32 -- provably the same quotient -- 2.17 -> 2.11 ms on the C4 volume at the
 // same 5 wavefronts per SIMD, 2.52 ms at the 3 the allocator then chooses.)
-struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
 
 __device__ __forceinline__ void gate_value4(const ModelDev &m, const GateGeom &g, float h, int v0,
                                             float out[4])
@@ -439,7 +499,10 @@ __global__ void k_interp_points(ModelDev m, const float *__restrict__ coords,
     if (i >= n) return;
     GateGeom g;
     float h = heights[i];
-    gate_geometry(m, coords[2 * i], coords[2 * i + 1], h, g);
+#ifdef CPOL_INTERP_TRACE
+    unsigned long long itr[8];
+#endif
+    gate_geometry(m, coords[2 * i], coords[2 * i + 1], h, g ITRACE_PASS);
     for (int v = 0; v < m.n_vars; ++v) {
         float r;
         if (g.status == 1) r = -9999.0f;
@@ -568,8 +631,36 @@ __device__ __forceinline__ double asin_small(double x)
 template <bool KEEP>
 __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &a, float *sv, long &sbg_out, float &elev_out)
 {
-    const int gate = blockIdx.y * blockDim.x + threadIdx.x;
-    const int sub = blockIdx.x % a.n_sub, ray = blockIdx.x / a.n_sub;
+    // ---- which (ray, sub-beam, block of gates) this workgroup takes ----
+    // The hardware deals workgroups to the 8 XCDs round robin by their linear index, and every XCD has its own L2.  With
+    // blockIdx.x = ray * n_sub + sub the 49 sub-beams of a ray -- which read the same model columns, a few kilometres apart --
+    // went to all eight L2s, each fetching the columns for itself.  Here XCD k takes the rays k, k + 8, ... whole, in order
+    // (round 6; the rays beyond a multiple of 8 in the plain order): the sub-beams of a ray, and both halves of its gates, share one L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+#if CPOL_INTERP_XCD_RAYS
+    if (a.n_sub > 1 && gridDim.x == (unsigned)(a.n_rays * a.n_sub)) {                            // (wave-uniform)
+        const unsigned L = blockIdx.y * gridDim.x + blockIdx.x;                                   // (decoded from scratch: any bijection will do)
+        const unsigned per_ray = (unsigned)a.n_sub * gridDim.y;
+        const unsigned n8 = (unsigned)a.n_rays & ~7u, T8 = n8 * per_ray;                         // (the rays beyond a multiple of 8: plain order)
+        unsigned ray_, w;
+        if (L < T8) {
+            const unsigned xcd = L & 7u, q = L >> 3;
+            ray_ = (q / per_ray) * 8u + xcd;
+            w = q % per_ray;
+        } else {
+            ray_ = n8 + (L - T8) / per_ray;
+            w = (L - T8) % per_ray;
+        }
+        bx = (int)(ray_ * (unsigned)a.n_sub + w % (unsigned)a.n_sub);
+        by = (int)(w / (unsigned)a.n_sub);
+    }
+#endif
+    const int gate = by * blockDim.x + threadIdx.x;
+    const int sub = bx % a.n_sub, ray = bx / a.n_sub;
+#ifdef CPOL_INTERP_TRACE
+    unsigned long long itr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    itr[0] = wall_clock64();
+#endif
     if (gate >= a.n_gates) return 3;
     const int ih = a.sub_h[sub], jv = a.sub_v[sub];
     const long sbg = ((long)ray * a.n_sub + sub) * a.n_gates + gate;
@@ -791,7 +882,8 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     }
 
     GateGeom g;
-    gate_geometry(m, rlat, rlon, h32, g);
+    ITRACE(itr, 1);                                        // trajectory + grid coordinates
+    gate_geometry(m, rlat, rlon, h32, g ITRACE_PASS);
     if (g.status == 0) {
         int v = 0;
         for (; v + 4 <= m.n_vars; v += 4) {
@@ -812,6 +904,7 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
         for (int v = 0; v < m.n_vars; ++v)
             if (!KEEP || ((a.store_mask >> v) & 1u)) a.vals[(long)v * n_sbg + sbg] = qnan;
     }
+    ITRACE(itr, 5);                                        // the variables gathered and interpolated (KEEP: in LDS)
     a.mask[sbg] = (signed char)g.status;
 
     // elevation folded into [0, 90] for the LUT (doppler_scatter.py:173-176, in place)
@@ -828,6 +921,18 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
         if (a.dist) a.dist[rg] = s32;
         if (a.heights) a.heights[rg] = h32;
     }
+#ifdef CPOL_INTERP_TRACE
+    {
+        ITRACE(itr, 6);                                    // everything stored
+        const unsigned long w = ((unsigned long)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + threadIdx.x / 64;
+        const unsigned long long n_ok = (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(g.status == 0));
+        if ((threadIdx.x & 63) == 0 && w < CPOL_SUBSUM_TRACE_N) {
+            for (int q = 0; q < 7; ++q) g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + q] = itr[q];
+            g_subsum_trace[CPOL_SUBSUM_TRACE_W * w + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15ull) << 32 | n_ok << 40;
+        }
+    }
+#endif
     return g.status;
 }
 
