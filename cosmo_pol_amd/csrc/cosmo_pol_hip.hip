@@ -138,6 +138,7 @@ struct cpol_ctx {
     DevBuf b_vals, b_mask, b_elev, b_coords, b_qmelt, b_fwmelt, b_key, b_par, b_count, b_offset,
         b_units, b_totals, b_perm, b_res, b_pos, b_vn, b_icefirst, b_rvel, b_proj, b_blkranked, b_rec, b_vmask, b_gscan, b_defer;
     DevBuf b_out[16], b_szinteg, b_sztotal, b_model, b_ticket, b_mask8;
+    DevBuf b_present;                  // k_gate1_ray's sweeps: one word per (ray, 64-gate tile), which hydrometeor slots may have an item there (k_interp_sweep writes, k_gate1_ray reads)
     // last sweep shapes (debug reads)
     long last_n_sbg = 0, last_n_rg = 0;
     int last_n_rays = 0, last_n_gates = 0, last_n_sub = 0, last_n_v = 0, last_n_keys = 0;
@@ -695,7 +696,7 @@ void cpol_destroy(cpol_ctx *ctx)
                      &ctx->b_par, &ctx->b_count, &ctx->b_offset, &ctx->b_units,
                      &ctx->b_totals, &ctx->b_perm, &ctx->b_res, &ctx->b_pos,
                      &ctx->b_vn, &ctx->b_icefirst, &ctx->b_rvel, &ctx->b_proj, &ctx->b_blkranked, &ctx->b_rec, &ctx->b_vmask, &ctx->b_gscan, &ctx->b_defer,
-                     &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model, &ctx->b_ticket, &ctx->b_poly, &ctx->d_geoM};
+                     &ctx->b_szinteg, &ctx->b_sztotal, &ctx->b_model, &ctx->b_ticket, &ctx->b_poly, &ctx->d_geoM, &ctx->b_present, &ctx->b_mask8};
     for (DevBuf *b : all) free_buf(*b);
     for (auto &b : ctx->b_out) free_buf(b);
     for (int j = 0; j < CPOL_MAX_HYDRO; ++j) {
@@ -1635,6 +1636,13 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
         const long g1_waves = n_rg * n_hyd / 64 / 1024;
         gate1_ray = gate1_ray && (ctx->gate1_species == 2 || (ctx->gate1_species == 1 && g1_waves < 48));
     }
+    if (gate1_ray && CPOL_GATE1_PRESENT) {
+        // (the presence words: every one "anything may be here" until k_interp_sweep has written it -- a wavefront none of whose gates
+        // exists leaves its word alone)
+        void *const was = ctx->b_present.p;
+        ENSURE(ctx->b_present, (size_t)n_rays * cdiv(ng, 64) * sizeof(unsigned));
+        if (ctx->b_present.p != was) HIPCHK(hipMemsetAsync(ctx->b_present.p, 0xFF, ctx->b_present.cap, ctx->stream));
+    }
     if (gate1_ray && g1r == 3) {
         void *const was = ctx->b_ticket.p;
         ENSURE(ctx->b_ticket, (size_t)n_rays * sizeof(int));
@@ -1796,6 +1804,12 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ia.poly = geo_poly ? (const double *)ctx->b_poly.p : poly_central ? (const double *)set->poly.p : nullptr;
     ia.poly_scale = (geo_poly || poly_central) ? geo_poly_scale : 0.0;
     ia.poly_central = poly_central ? 1 : 0;
+    static const int use_present = getenv("CPOL_GATE1_PRESENT") ? atoi(getenv("CPOL_GATE1_PRESENT")) : 1;
+    if (gate1_ray && use_present && CPOL_GATE1_PRESENT) {
+        ia.present = (unsigned *)ctx->b_present.p;
+        ia.n_pres = n_hyd;
+        for (int j = 0; j < n_hyd; ++j) ia.pres_var[j] = ctx->hs.h[j].d.var_q;
+    }
     ctx->last_poly_central = ia.poly_central;
     static const int exp_skip_interp = getenv("CPOL_EXP_SKIP") ? (atoi(getenv("CPOL_EXP_SKIP")) & 1) : 0;
     if (!fused && !fused_gate1 && !exp_skip_interp)
@@ -1882,6 +1896,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
     ca.par = (double *)ctx->b_par.p;
     ca.count = cnt_p;
     ca.n_sbg = n_sbg;
+    ca.present = ia.present;              // (k_gate1_ray: the presence words k_interp_sweep has just written)
     ca.with_melting = p->with_melting;
     ca.var_qr = ca.var_qs = ca.var_qg = -1;
     ca.doppler = doppler ? 1 : 0;
@@ -2428,7 +2443,7 @@ int cpol_run_sweep(cpol_ctx *ctx, const cpol_sweep_params *p, const cpol_ray_tab
                          ctx->b_res.p, ctx->b_vn.p, ctx->b_icefirst.p, ctx->b_wgate.p, ctx->b_blkranked.p, ctx->b_rec.p,
                          ctx->b_vmask.p, ctx->b_rayc.p, ctx->v_traj_in, ctx->v_geo, ctx->v_subh,
                          ctx->v_subv, ctx->v_subw, ctx->v_sens, ctx->v_site, ctx->v_nyq,
-                         ctx->v_subsmooth, ctx->v_mlfilter, (void *)st, poly_single ? set->poly.p : nullptr};
+                         ctx->v_subsmooth, ctx->v_mlfilter, (void *)st, poly_single ? set->poly.p : nullptr, gate1_ray ? ctx->b_present.p : nullptr};
         mix(arena, sizeof arena);
         // (the launch forms chosen above from state outside *p: a graph captured before the lanes were forked must not keep
         // replaying the four-launch sequence once k_gate1_ray is the default, nor the reverse)

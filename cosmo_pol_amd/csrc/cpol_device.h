@@ -148,6 +148,14 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+#ifndef CPOL_GATE1_PRESENT
+#define CPOL_GATE1_PRESENT 0      // 1 (build knob, measured and rejected in round 6): k_interp_sweep leaves one word per (ray, 64-gate tile) saying which
+                                  // hydrometeor slots have a positive mass density anywhere in the tile, and the wavefront of k_gate1_ray whose species is
+                                  // absent from its tile (60 % of them on the C2 sweep, 2.4 us of life each) loads nothing, writes nothing, takes its
+                                  // ticket and leaves.  Same bits (edges, headline, parity tests), and no gain: pipelined sweep 33.2 against 32.7 us,
+                                  // isolated 79.6 against 77.8 (k_interp_sweep pays for the words) -- the wave slots those wavefronts held were not
+                                  // what the kernel waits for (profiles/r6_variants.txt, item 13)
+#endif
 #if defined(CPOL_SUBSUM_TRACE) || defined(CPOL_LOOKUP_TRACE) || defined(CPOL_INTERP_TRACE)
 // (CPOL_INTERP_TRACE, tools/interp_trace.py: the phases of every wavefront of k_interp_sweep / k_interp_classify)
 // measurement builds (tools/subsum_trace.py): per wavefront of k_subbeam_sum* (index blockIdx.y * gridDim.x + blockIdx.x, times W

@@ -514,9 +514,20 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
     const bool want_vn = want_rvel && t.writes_vn;                                     // uniform: the table carries the Doppler sums
     const double w0 = f.sub_w[0];
 
-    const float e = in ? a.elev[i] : 0.f;
-    const float T = in ? a.vals[d.var_t * n + i] : 0.f;
-    const float qm = in ? a.vals[d.var_q * n + i] : 0.f;                               // (q_source == CPOL_Q_MODEL: no melting species here)
+    // (round 6) k_interp_sweep's word of this tile: bit q clear = no gate of the tile has a positive mass density of slot q, so the slot
+    // has no item here (classify_item: valid needs qm > 0).  The wavefront of such a slot -- 60 % of them on the C2 sweep, 2.4 us of
+    // life each for two loads and 15 LDS columns of zeros -- loads nothing, writes nothing, takes its ticket and leaves; the
+    // finishing wavefront reads the same word and leaves the slot's LDS columns alone (x + 0.0f = x: the same bits).
+    unsigned pmask = ~0u;
+#if CPOL_GATE1_PRESENT
+    if (LAST_WAVE && a.present)
+        pmask = a.present[(long)ray_b * gridDim.x + (gate_b >> 6)];                    // (wave-uniform: one scalar load)
+#endif
+    const bool here = (pmask >> j) & 1u;                                               // (wave-uniform)
+    const bool inl = in && here;
+    const float e = inl ? a.elev[i] : 0.f;
+    const float T = inl ? a.vals[d.var_t * n + i] : 0.f;
+    const float qm = inl ? a.vals[d.var_q * n + i] : 0.f;                              // (q_source == CPOL_Q_MODEL: no melting species here)
 #ifdef CPOL_SUBSUM_TRACE
     // (-DCPOL_SUBSUM_TRACE build, tools/gate1_trace.py: the phases of every wavefront of k_gate1_ray on the 100-MHz clock)
     unsigned long long g1t[6], g1_valid = 0, g1_hw = 0;
@@ -525,7 +536,7 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
     g1t[1] = wall_clock64();                           // the gate's model values have arrived
 #endif
     ClassItem it;
-    classify_item(h, t, a, a.vals, n, i, i, in, qm, 0.0, T, d.var_t, e, it);
+    classify_item(h, t, a, a.vals, n, i, i, inl, qm, 0.0, T, d.var_t, e, it);
 #ifdef CPOL_SUBSUM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     g1t[2] = wall_clock64();                           // PSD parameters, table position
@@ -659,11 +670,13 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
         if (h.n_par >= 3) P[2 * n] = it.p2;
     }
     // ---- this species' term of the ONE sub-beam (nansum([NaN, y]) stored as float32) and its fall-speed moments ----
+    if (here) {
 #pragma unroll
     for (int c = 0; c < CPOL_N_SZ; ++c) {
         double y = ((c & 1) ? v[c / 2].y : v[c / 2].x) * w0;
         if (!(y == y)) y = 0.0;
         s_acc[(j * CPOL_N_SZ + c) * 64 + lane] = have ? (float)(0.0 + y) : 0.f;
+    }
     }
     if (RAY) {
         // ---- items outside the integral table: integrated here, one after the other (rare), their terms straight into LDS ----
@@ -693,9 +706,11 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
         if (want_vn) { vj = wv.x; nj = wv.y; }
         else { vj = it.dv; nj = it.dn; }
     }
+    if (here) {
     s_mv[j * 64 + lane] = vj;
     s_mn[j * 64 + lane] = nj;
     s_flag[j * 64 + lane] = (it.valid ? 1u : 0u) | (off_table ? 2u : 0u) | (moments ? 4u : 0u);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) my_lookup += __shfl_xor(my_lookup, off);
     if (LAST_WAVE) {
@@ -734,7 +749,7 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
     unsigned vbits = 0;
     bool deferred = false;
     for (int q = 0; q < n_h; ++q) {
-        const unsigned fl = s_flag[q * 64 + lane];
+        const unsigned fl = ((pmask >> q) & 1u) ? s_flag[q * 64 + lane] : 0u;          // (a slot absent from the tile wrote nothing)
         vbits |= (fl & 1u) << q;
         deferred = deferred || (fl & 2u);
     }
@@ -758,6 +773,11 @@ __device__ __forceinline__ void gate1_species_body(const HydroSet &hs, const Ita
             float tot[CPOL_N_SZ];
             double mom_v = 0.0, mom_n = 0.0;
             for (int q = 0; q < n_h; ++q) {
+                if (!((pmask >> q) & 1u)) {                 // (wave-uniform) absent from the tile: the column of +0.0f it would have written
+#pragma unroll                                              // (added all the same: -0.0f + 0.0f = +0.0f, the bits of the other forms)
+                    for (int c = 0; c < CPOL_N_SZ; ++c) tot[c] = (q == 0) ? 0.f : tot[c] + 0.f;
+                    continue;
+                }
 #pragma unroll
                 for (int c = 0; c < CPOL_N_SZ; ++c) {
                     const float acc = s_acc[(q * CPOL_N_SZ + c) * 64 + lane];

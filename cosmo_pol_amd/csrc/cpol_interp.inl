@@ -547,6 +547,13 @@ struct InterpArgs {
     const double *poly;         // k_trajectory's coordinate polynomials [n_rays * n_h][2][CPOL_GEO_NP] or NULL
     double poly_scale;          // x = s * poly_scale - 1
     int poly_central;           // the central sub-beam takes the polynomials too (its float64 latitude / longitude are not asked for)
+    // k_gate1_ray's sweeps (round 6, CPOL_GATE1_PRESENT builds only): one word per (ray, 64-gate tile) -- bit s set if ANY gate of the tile has pres_var[s] > 0, the
+    // necessary condition of an item of hydrometeor slot s (classify_item: valid = inside && qm > 0 ...).  The tile is this kernel's
+    // wavefront AND k_gate1_ray's workgroup: the wavefront of a species absent from the tile (60 % of them on the C2 sweep) then
+    // neither loads nor classifies nor writes terms, it takes its ticket and leaves.  NULL: not produced.
+    unsigned *present;          // [n_rays][ceil(n_gates / 64)]
+    int n_pres;
+    int pres_var[CPOL_MAX_HYDRO];
 };
 
 #ifndef CPOL_RAY_PREP_MIN_SUB
@@ -884,6 +891,9 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
     GateGeom g;
     ITRACE(itr, 1);                                        // trajectory + grid coordinates
     gate_geometry(m, rlat, rlon, h32, g ITRACE_PASS);
+#if CPOL_GATE1_PRESENT
+    unsigned pres = 0;                                     // (KEEP = false: bit s = this gate has pres_var[s] > 0)
+#endif
     if (g.status == 0) {
         int v = 0;
         for (; v + 4 <= m.n_vars; v += 4) {
@@ -893,12 +903,20 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
             for (int j = 0; j < 4; ++j) {
                 if (KEEP) sv[(v + j) * blockDim.x] = o[j];
                 else a.vals[(long)(v + j) * n_sbg + sbg] = o[j];
+#if CPOL_GATE1_PRESENT
+                if (!KEEP && a.present)
+                    for (int s = 0; s < a.n_pres; ++s) pres |= (a.pres_var[s] == v + j && o[j] > 0.f) ? 1u << s : 0u;
+#endif
             }
         }
         for (; v < m.n_vars; ++v) {
             const float o = gate_value(m, g, h32, v);
             if (KEEP) sv[v * blockDim.x] = o;
             else a.vals[(long)v * n_sbg + sbg] = o;
+#if CPOL_GATE1_PRESENT
+            if (!KEEP && a.present)
+                for (int s = 0; s < a.n_pres; ++s) pres |= (a.pres_var[s] == v && o > 0.f) ? 1u << s : 0u;
+#endif
         }
     } else {
         for (int v = 0; v < m.n_vars; ++v)
@@ -921,6 +939,18 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
         if (a.dist) a.dist[rg] = s32;
         if (a.heights) a.heights[rg] = h32;
     }
+#if CPOL_GATE1_PRESENT
+    if (!KEEP && a.present) {
+        // the tile's word: OR over the lanes that came this far (the others -- no gate, outside the domain -- hold no item); written by
+        // the first of them.  A wavefront none of whose lanes comes here leaves its word as it was: whatever it says, the tile has no item.
+        unsigned word = 0;
+        for (int s = 0; s < a.n_pres; ++s)
+            word |= __builtin_amdgcn_ballot_w64((pres >> s) & 1u) ? 1u << s : 0u;
+        const int lane = (int)(threadIdx.x & 63);
+        if (lane == __builtin_amdgcn_readfirstlane(lane))
+            a.present[(long)ray * ((a.n_gates + 63) / 64) + gate / 64] = word;
+    }
+#endif
 #ifdef CPOL_INTERP_TRACE
     {
         ITRACE(itr, 6);                                    // everything stored

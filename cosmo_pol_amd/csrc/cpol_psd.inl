@@ -311,6 +311,8 @@ struct ClassifyArgs {
     int *blk_ranked;             // [gridDim.x] items of this workgroup's gates ranked for the integrating kernels
                                  // (k_bucket_scatter skips the gates of a workgroup without any; pos[] is only
                                  // written where there are some)
+    const unsigned *present;     // k_gate1_ray: [n_rays][ceil(n_gates / 64)] bit s = slot s may have an item in the tile (k_interp_sweep's
+                                 // InterpArgs.present) or NULL
 };
 
 // The count of the items on integral tables (reported by cpol_counters, nothing on the device reads it): ONE word

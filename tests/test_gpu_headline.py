@@ -133,6 +133,20 @@ def test_c2_headline_step_vs_oracle_and_host_output_path():
         assert np.array_equal(host['RVEL'], got_rvel[k], equal_nan=True), ('RVEL', k)
         assert np.isfinite(host['lats']).all() and host['mask'].shape == (n_rays, n_gates) and host['mask'].dtype == np.float64
     op.close()
+    # ---- and against a context WITHOUT lanes: the four-launch sequence (k_gate1_species + k_final: one workgroup barrier, no
+    # presence words, no tile rotation, no tickets) on the whole sweep, bit for bit ----
+    from cosmo_pol_amd import RadarOperator
+    conf, hyds, cube, luts = bench.make_inputs('c2', False)
+    op1 = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=1)
+    op1.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    for k in (0, 5):
+        one = op1.simulate_rays(az, els[k])
+        f1 = op1._ctx.launch_forms()
+        assert f1['gate1_ray'] == 0 and f1['gate1'] == 1, f1
+        for i, f in enumerate(bench.RADAR_FIELDS):
+            assert np.array_equal(one[f], got[k][i], equal_nan=True), (f, k)
+        assert np.array_equal(one['RVEL'], got_rvel[k], equal_nan=True), ('RVEL', k)
+    op1.close()
 
 
 def test_c3_step_vs_oracle_and_blocking_path():
