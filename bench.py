@@ -1122,12 +1122,20 @@ def run_c3(env):
     for _ in range(args.warmup):
         volume()
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        volume()
-    t_submit = time.perf_counter() - t0
-    fence()
-    elapsed = time.perf_counter() - t0
+    # (five timed regions of `steps` volumes, the median: the single 30-ms region of rounds 5-6 gave 1.51 and 2.10 ms per volume on two
+    # boxes with identical device times)
+    # The first regions are not the step either: the results of a region are all in flight until its fence, so the operator's pool of
+    # page-locked blocks grows to `steps` volumes' worth (hipHostMalloc, and the first copy into a new block blocks the submitting
+    # thread for its whole duration: 298 us per sweep, tools/c3_settle.py) -- three settling regions, as c2's host-output step has.
+    regions, settling = [], []
+    for r in range(8):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            volume()
+        t_sub = time.perf_counter() - t0
+        fence()
+        (settling if r < 3 else regions).append((time.perf_counter() - t0, t_sub))
+    elapsed, t_submit = sorted(regions)[len(regions) // 2]
     gates = n_el * n_rays * n_gates
     # one sweep at a time, events around every stage (3 deg: what profiles/r3_c3_el3_iso_* profiles)
     slab = torch.empty((len(RADAR_FIELDS), n_rays, n_gates), dtype=torch.float32, device='cuda')
@@ -1178,6 +1186,8 @@ def run_c3(env):
                            'sequence, gate coordinates of the unchanged geometry from the cache, RadarScan with fields '
                            'built on first access)'},
         'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
+        'ms_per_step_repeats': [round(1e3 * r[0] / args.steps, 4) for r in regions],
+        'ms_per_step_settling_regions_not_counted': [round(1e3 * r[0] / args.steps, 4) for r in settling],
     }
 
 
