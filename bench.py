@@ -1097,8 +1097,8 @@ def run_c3(env):
     page-locked host memory, the gate coordinates of the unchanged geometry come from the host's cache -- all 15
     arrays are delivered; every sweep on a lane of its own (5 lanes), so that the arrays of a volume stay valid
     until the next volume starts.  `api_ms`: the same volume through
-    RadarOperator.get_PPI (the drop-in call: the five sweeps as ONE launch sequence, + dB fields, masked
-    arrays, scan container -- built on first access)."""
+    RadarOperator.get_PPI (the drop-in call: the five sweeps queued on three lanes the same way, one wait, + dB fields,
+    masked arrays, scan container -- built on first access)."""
     op, args, torch, cube = env['op'], env['args'], env['torch'], env['cube']
     az = np.arange(0, 360, 1.0 if not args.small else 4.0)
     n_el, n_rays, n_gates = len(C4_ELEVATIONS), len(az), len(op.constants.RANGE_RADAR)
@@ -1106,9 +1106,9 @@ def run_c3(env):
     for i in range(n_el):
         op._lane(i)
     def volume():
-        # (one call per sweep, each on a lane of its own: the 14 MB copy of one sweep overlaps the kernels
-        # of the next.  The five sweeps as ONE launch sequence -- what get_PPI does, `api_ms` below -- give
-        # one 68 MB copy per volume that overlaps nothing: 2.05 against 1.82 ms per volume in this loop)
+        # (one call per sweep, each on a lane of its own: the 9.4 MB copy of one sweep overlaps the kernels
+        # of the next.  The five sweeps as ONE launch sequence -- get_PPI's form for scans with sub-beams, and for this scan
+        # until round 6 -- give one 47 MB copy per volume that overlaps nothing: 1.37 against 0.93 ms per volume in this loop)
         return [op.simulate_rays(az, els[e], pinned=True, lane=e) for e in range(n_el)]
 
     def fence():
@@ -1158,8 +1158,9 @@ def run_c3(env):
     api = []
     with contextlib.redirect_stdout(sys.stderr):
         op.lanes = 3
-        op.get_PPI(C4_ELEVATIONS, azimuths=az)
-        for _ in range(max(3, args.steps // 4)):
+        for _ in range(1 if args.small else 12):      # (the pool of page-locked blocks of these calls settles, as above)
+            op.get_PPI(C4_ELEVATIONS, azimuths=az)
+        for _ in range(max(3, args.steps // 2)):
             t0 = time.perf_counter()
             op.get_PPI(C4_ELEVATIONS, azimuths=az)
             api.append(1e3 * (time.perf_counter() - t0))
@@ -1182,9 +1183,10 @@ def run_c3(env):
         'stages_ms': dict(stage_ms_of(iso3), device_total=iso3.ms_total, sweep='3 deg'),
         'single_sweep_ms': per_sweep,
         'api_ms': {'get_PPI_volume_median': statistics.median(api), 'get_PPI_volume_min': min(api),
-                   'note': 'RadarOperator.get_PPI(5 elevations): the same volume through the drop-in call (one launch '
-                           'sequence, gate coordinates of the unchanged geometry from the cache, RadarScan with fields '
-                           'built on first access)'},
+                   'note': 'RadarOperator.get_PPI(5 elevations): the same volume through the drop-in call (a single-beam scan: '
+                           'its sweeps queued on the operator\'s lanes with page-locked outputs, one wait at the end -- round 6; '
+                           'rounds 4-5: ONE launch sequence and one copy, 1.37 ms; gate coordinates of the unchanged geometry '
+                           'from the cache, RadarScan with fields built on first access)'},
         'host_submit_ms_per_step': 1e3 * t_submit / args.steps,
         'ms_per_step_repeats': [round(1e3 * r[0] / args.steps, 4) for r in regions],
         'ms_per_step_settling_regions_not_counted': [round(1e3 * r[0] / args.steps, 4) for r in settling],

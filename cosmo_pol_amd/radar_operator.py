@@ -252,6 +252,7 @@ class RadarOperator(object):
         self.pyart_output = bool(pyart_output) # get_PPI / get_RHI return a pyart.core.Radar (needs Py-ART)
         self.reuse_device_tables = True        # keep per-ray tables in HBM between equal sweeps
         self.volume_in_one_sequence = True     # get_PPI / get_RHI: all sweeps of a scan in one launch sequence
+        self.pipeline_single_beam_scans = True # ... unless the scan has ONE sub-beam per ray and the operator lanes: a sweep per lane, page-locked outputs, one wait
                                                # (False: sweep by sweep, spread over the lanes)
         self.sequence_memory_budget = None     # bytes of device work buffers ONE launch sequence may need (about 1.2 KB per
                                                # sub-beam gate with six species): a scan beyond it is run as several
@@ -789,6 +790,27 @@ class RadarOperator(object):
             res = self._simulate_volume_sharded(sweeps)
             if res is None:
                 return None                   # gather_to: this rank computed its share, another holds the scan
+            return [self._package(r, az, el) for r, (az, el) in zip(res, sweeps)]
+        if self.pipeline_single_beam_scans and len(sweeps) > 1 and self.lanes > 1 \
+                and self._cached('sub', lambda: quadrature.subbeams(self.__config)).n_sub == 1:
+            # Single-beam scans are bound by PCIe, not by their kernels (a 360 x 500 sweep: 0.15 ms on the device, 0.17 ms for its
+            # 9.4 MB of results): every sweep is queued on a lane with page-locked outputs and the call waits once, at the end --
+            # the copy of one sweep runs beside the kernels of the next (a 5-elevation volume with melting layer: 0.93 ms against
+            # 1.37 ms as ONE launch sequence, whose one copy overlaps nothing; bench.py's c3 step / `api_ms`).  Same bits
+            # (tests/test_gpu_headline.py::test_c3_step_vs_oracle_and_blocking_path).
+            n_par = min(self.lanes, len(sweeps))
+            res, failure = [], None
+            try:
+                for k, (az, el) in enumerate(sweeps):
+                    res.append(self.simulate_rays(az, el, pinned=True, lane=k % n_par))
+            finally:
+                for i in range(n_par):
+                    try:
+                        self.wait(i)                  # (every lane is drained, whatever happened: no copy may outlive the call)
+                    except Exception as exc:          # noqa: BLE001  (re-raised below: the first failure of the scan)
+                        failure = failure or exc
+            if failure is not None:
+                raise failure
             return [self._package(r, az, el) for r, (az, el) in zip(res, sweeps)]
         if self.volume_in_one_sequence and len(sweeps) > 1:
             # all sweeps of the scan as ONE launch sequence (rays of different elevations / azimuths in one

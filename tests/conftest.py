@@ -13,6 +13,24 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    # A GPU session on a cold box: the first `import torch` pages in gigabytes of libraries and has taken more than seven minutes
+    # (round 6: a run killed for silence in the middle of it, with every test before it green).  One line a minute on the real
+    # stderr says the session is alive and where it is.
+    expr = config.getoption('-m', default='') or ''
+    if 'gpu' in expr and 'not gpu' not in expr:
+        import threading
+        import time
+
+        def beat():
+            t0 = time.time()
+            while True:
+                time.sleep(60)
+                try:
+                    sys.__stderr__.write('[tests] alive after %d s: %s\n' % (time.time() - t0, os.environ.get('PYTEST_CURRENT_TEST', '(between tests)')))
+                    sys.__stderr__.flush()
+                except Exception:
+                    return
+        threading.Thread(target=beat, name='cpol-test-heartbeat', daemon=True).start()
 
 
 @pytest.fixture(scope='session')

@@ -233,9 +233,10 @@ def test_rhi_and_vprof_api(full):
 
 
 def test_lanes_volume_scan_equals_sequential():
-    """A volume scan three ways -- its sweeps one after the other, spread over forked contexts
-    (cpol_fork, one host thread per lane), and as ONE launch sequence (the default of get_PPI: rays
-    of all elevations in one cpol_run_sweep call) -- gives bit-identical fields."""
+    """A volume scan four ways -- its sweeps one after the other, spread over forked contexts
+    (cpol_fork, one host thread per lane), as ONE launch sequence (get_PPI's form for scans with sub-beams: rays
+    of all elevations in one cpol_run_sweep call), and queued sweep by sweep on the lanes with page-locked outputs and
+    one wait at the end (get_PPI's form for single-beam scans, round 6) -- gives bit-identical fields."""
     from cosmo_pol_amd import RadarOperator, synthetic
     import bench
     conf = bench.bench_config(True)
@@ -245,9 +246,11 @@ def test_lanes_volume_scan_equals_sequential():
     luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
     elevs = [0.5, 1.5, 3.0, 5.0, 8.0]
     scans = []
-    for lanes, one_sequence in ((1, False), (3, False), (3, True), (2, 'budget')):
+    for lanes, one_sequence, pipelined in ((1, False, False), (3, False, False), (3, True, False), (2, 'budget', False), (3, True, True)):
         op = RadarOperator(config=conf, luts=luts, output_variables='all', lanes=lanes)
+        assert op.pipeline_single_beam_scans is True          # (the default)
         op.volume_in_one_sequence = bool(one_sequence)
+        op.pipeline_single_beam_scans = pipelined
         op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
         if one_sequence == 'budget':
             # a memory budget of two sweeps' work buffers: the scan runs as sequences of 2 + 2 + 1 sweeps
@@ -265,8 +268,10 @@ def test_lanes_volume_scan_equals_sequential():
                 op._ctx.set_num_hydro(len(hyds))
             op.set_lut()
             assert op._lane_ctx == []
-        if one_sequence:
+        if one_sequence and not pipelined:
             assert op._lane_ctx == []                    # calls on the root context only
+        if pipelined:
+            assert len(op._lane_ctx) == 2                # lanes 0 (the root), 1, 2 took the five sweeps in turn
         op.close()
     a = scans[0]
     for b in scans[1:]:
