@@ -124,12 +124,38 @@ def main():
                         op.debug_flags = N.DEBUG_EXACT_SUBBEAMS
                         exact = op.simulate_rays(azs, els, apply_sensitivity=cut)
                         op.debug_flags = 0
-                        _cases.assert_close_nan(exact['model_vars'][i][r], integ.values[nm], rtol=1e-12,
-                                                atol=1e-13 * mag, name='model (long form of every sub-beam):' + nm)
+                        try:
+                            _cases.assert_close_nan(exact['model_vars'][i][r], integ.values[nm], rtol=1e-12,
+                                                    atol=1e-13 * mag, name='model (long form of every sub-beam):' + nm)
+                            why = 'a sub-beam coordinate one ulp off the long form (strict bound met by the long form)'
+                        except AssertionError:
+                            # The long form itself: float64 geodesy through the device's OCML sin / cos / atan2 / asin here, through
+                            # NumPy's libm in the oracle -- last-bit differences that the cast to the float32 grid coordinate shows in
+                            # ~1e-8 of the coordinates (seed 9905, case 638: the first such hit in ~12 000 cases).
+                            # Accepted only when PROVEN: some sub-beam's float32 coordinate at an offending gate differs from the
+                            # oracle's by exactly one ulp, every other coordinate of the ray is the oracle's, and the float32 bound holds.
+                            op.debug_flags = N.DEBUG_EXACT_SUBBEAMS
+                            op._ctx.enable_debug(True)
+                            op.simulate_rays(azs, els, apply_sensitivity=cut)
+                            n_sub_, ng_ = exact['n_sub'], exact['ZH'].shape[1]
+                            dc = op._ctx.debug_read('sub_coords', (2, n_sub_, ng_, 2), np.float32)[r]
+                            op._ctx.enable_debug(False)
+                            op.debug_flags = 0
+                            orc = np.array([beam.gate_coordinates(ocube, conf['radar']['coords'], sb.quad_pt[0], sb.dist_profile)[2]
+                                            for sb in subs], dtype=np.float32)
+                            ulps = np.abs(dc.astype(np.float64) - orc.astype(np.float64)) / np.spacing(np.abs(orc)).astype(np.float64)
+                            a_, b_ = exact['model_vars'][i][r], np.asarray(integ.values[nm], dtype=np.float64)
+                            with np.errstate(invalid='ignore'):
+                                bad_g = np.nonzero(np.abs(a_ - b_) > 1e-12 * np.abs(b_) + 1e-13 * mag)[0]
+                            assert np.nanmax(ulps) <= 1.0 and all(np.nanmax(ulps[:, g_]) == 1.0 for g_ in bad_g), \
+                                'model (long form):%s: beyond the strict bound with no one-ulp coordinate to explain it' % nm
+                            _cases.assert_close_nan(exact['model_vars'][i][r], integ.values[nm], rtol=1e-6,
+                                                    atol=1e-7 * mag, name='model (long form, libm / OCML):' + nm)
+                            why = ('a sub-beam coordinate of the LONG form one float32 ulp off the oracle\'s at gate(s) %s (OCML / libm last bits)'
+                                   % bad_g.tolist())
                         _cases.assert_close_nan(res['model_vars'][i][r], integ.values[nm], rtol=1e-6,
                                                 atol=1e-7 * mag, name='model (coordinate polynomials):' + nm)
-                        print('note: case %d ray %d %s: a sub-beam coordinate one ulp off the long form (strict bound met by the long form)'
-                              % (case, r, nm), flush=True)
+                        print('note: case %d ray %d %s: %s' % (case, r, nm, why), flush=True)
                 o = scatter.radar_observables(subs, olut, conf, return_sz=True, nyquist=nyq)
                 if cut:
                     scatter.cut_at_sensitivity([[o]], conf)   # the scan form (list of sweeps): spectrum censored bin by bin, as the device does
@@ -139,9 +165,13 @@ def main():
                 flipped = np.zeros(len(o.values['RVEL']), dtype=bool)
                 if 'DSPECTRUM' in o.values:
                     osp0 = o.values['DSPECTRUM']
-                    with np.errstate(invalid='ignore'):
+                    # (per GATE: a table bin that moves between two velocity bins of a weak gate is far below 1e-6 of the ray's
+                    # strongest bin and still moves that gate's first moment -- seed 9905, case 708: 5.6e-4 of the gate's power,
+                    # 6.7e-4 m/s, 3e-6 of the ray's maximum)
+                    with np.errstate(invalid='ignore', all='ignore'):
+                        gmax = np.nan_to_num(np.nanmax(np.where(np.isfinite(osp0), osp0, -np.inf), axis=1, keepdims=True), neginf=0.0)
                         flipped = (np.abs(res['DSPECTRUM'][r] - osp0)
-                                   > 1e-6 * max(np.nanmax(osp0), 1e-300) + 2e-5 * np.abs(osp0)).any(axis=1)
+                                   > 1e-6 * np.maximum(gmax, 1e-300) + 2e-5 * np.abs(osp0)).any(axis=1)
                     # (a bin whose power sits on the sensitivity threshold may be censored on one side only: the first
                     # moment of that gate moves with it)
                     flipped |= (np.isnan(res['DSPECTRUM'][r]) != np.isnan(osp0)).any(axis=1)

@@ -56,6 +56,21 @@ def main():
                     print('   masks  ', M.tolist(), ' total weight', W[:, g].sum())
                     if wg is not None:
                         print('   device weights - oracle weights', (wg[r][:, g] - W[:, g]).tolist())
+                    # per sub-beam at that gate: the device's interpolated value and float32 grid coordinates against the oracle's,
+                    # in the default form and with every sub-beam on the long form (CPOL_DEBUG_EXACT_SUBBEAMS)
+                    from cosmo_pol_amd import _native as N
+                    for flags, tag in ((0, 'default'), (N.DEBUG_EXACT_SUBBEAMS, 'long form')):
+                        op.debug_flags = flags
+                        op.simulate_rays(azs, els, apply_sensitivity=cut)
+                        dv = op._ctx.debug_read('sub_values', (len(op._staged_vars), 2, n_sub, ngt), np.float32)[i, r, :, g]
+                        dc = op._ctx.debug_read('sub_coords', (2, n_sub, ngt, 2), np.float32)[r, :, g]
+                        oc_rc = np.array([beam.gate_coordinates(oc, conf['radar']['coords'], sb.quad_pt[0], sb.dist_profile)[2][g] for sb in subs], dtype=np.float32)
+                        print('   [%s] device value - oracle value (float32 ulps of the value):' % tag,
+                              [None if not np.isfinite(x) else float(np.round((np.float64(d) - x) / np.spacing(np.float32(x)), 2)) for d, x in zip(dv, V)])
+                        print('   [%s] device coords - oracle coords (ulps): lat' % tag,
+                              [float((np.float64(a_) - np.float64(b_)) / np.spacing(np.float32(b_))) for a_, b_ in zip(dc[:, 0], oc_rc[:, 0])],
+                              'lon', [float((np.float64(a_) - np.float64(b_)) / np.spacing(np.float32(b_))) for a_, b_ in zip(dc[:, 1], oc_rc[:, 1])])
+                    op.debug_flags = 0
         op.close()
 
 
