@@ -16,7 +16,7 @@ def pytest_configure(config):
     # A GPU session on a cold box: the first `import torch` pages in gigabytes of libraries and has taken more than seven minutes
     # (round 6: a run killed for silence in the middle of it, with every test before it green).  One line a minute on the real
     # stderr says the session is alive and where it is.
-    expr = config.getoption('-m', default='') or ''
+    expr = getattr(config.option, 'markexpr', '') or ''
     if 'gpu' in expr and 'not gpu' not in expr:
         import threading
         import time
