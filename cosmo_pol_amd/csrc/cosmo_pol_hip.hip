@@ -991,6 +991,7 @@ int cpol_stage_model(cpol_ctx *ctx, int n_vars, const float *const *data, const 
     m.llc0 = llc[0]; m.llc1 = llc[1];
     m.urc0 = urc[0]; m.urc1 = urc[1];
     m.res0 = res[0]; m.res1 = res[1];
+    m.rres0 = 1.0 / (double)m.res0; m.rres1 = 1.0 / (double)m.res1;      // (IEEE division on the host: correctly rounded)
     // rotation constants (oracle/cosmo_pol_oracle/geodesy.py: rotation_constants)
     const double theta = (90.0 + south_pole[0]) * CPOL_DEG, phi = south_pole[1] * CPOL_DEG;
     const double ct = cos(theta), st = sin(theta), cp = cos(phi), sp = sin(phi);

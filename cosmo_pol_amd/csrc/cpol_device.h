@@ -24,6 +24,7 @@ struct ModelDev {
     float llc0, llc1;      // Lo1 (lon), La1 (lat)
     float urc0, urc1;
     float res0, res1;      // dlon, dlat
+    double rres0, rres1;   // RN64(1 / res): the float32 quotients by the grid resolution as float64 products (div32_by, cpol_interp.inl)
     // rotated-pole rotation: products of sin/cos evaluated on the host
     double ctcp, ctsp, st, nsp, cp, nstcp, stsp, ct;
 };

@@ -301,6 +301,31 @@ __device__ __forceinline__ int level_search(const float *__restrict__ col, int n
     return i;
 }
 
+// ---- IEEE float32 quotients n / d as float64 products (round 6) ----
+// The compiler's correctly rounded float32 division is 11 instructions (v_div_scale x2, v_rcp, 2 + 4 FMA steps, v_div_fmas,
+// v_div_fixup), and a gate divides 36 + 6 times -- by FOUR distinct column thicknesses and the two grid resolutions: a fifth of
+// the gate kernel's instructions.  RN32(RN64(n * r)) with r within one float64 ulp of 1 / d IS RN32(n / d) for every pair of
+// float32 operands: the exact quotient of two 24-bit significands is never a float32 rounding boundary (a 25-bit number m with
+// m d = n would need 25 significant bits in n) and keeps a relative distance >= 2^-49 from the nearest one, while the product
+// is within 2^-53 (its own rounding) + 2^-52 (r) of it -- subnormal quotients have coarser boundaries, overflow is the boundary
+// 2^128 (1 - 2^-25), zeros / infinities / NaN follow from r = 1 / d as IEEE gives it (the last branch below).  One reciprocal
+// per column (v_rcp_f64, 2^-23, and two Newton steps: 2^-46, then the final FMA's rounding) and 3 instructions per quotient.
+// Pinned by tests/test_gpu_math.py (10^8 random operand pairs of every class against `/`, bit for bit) and by every bit-exact
+// test of the gate kernel (test_gate_kernel_bit_exact: uint32 views against the gcc-compiled reference C).
+#ifndef CPOL_DIV_AS_PRODUCT
+#define CPOL_DIV_AS_PRODUCT 1
+#endif
+__device__ __forceinline__ double rcp_for_div32(float d)
+{
+    const double x = (double)d;
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    if (!(fabsf(d) > 0.0f) || !(fabsf(d) < __builtin_inff())) r = 1.0 / x;         // (0, inf, NaN: what IEEE gives)
+    return r;
+}
+__device__ __forceinline__ float div32_by(float n, double r) { return (float)((double)n * r); }
+
 struct __attribute__((packed, aligned(4))) F2 { float v[2]; };
 struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
 #ifndef CPOL_LEVEL_SEARCH_WIDE
@@ -316,14 +341,20 @@ struct GateGeom {
     long cell[4];          // the 4 neighbour columns (i0,i1) (i0,i1+1) (i0+1,i1) (i0+1,i1+1)
     int c1[4];             // upper level of the bracketing pair (c2 = c1+1)
     float z1[4], z2[4];
+    double rz[4];          // 1 / (z1 - z2) for div32_by (CPOL_DIV_AS_PRODUCT)
 };
 
 __device__ __forceinline__ void gate_geometry(const ModelDev &m, float rlat, float rlon, float h,
                                               GateGeom &g ITRACE_ARG)
 {
     // interpolation_c.c:43-57
+#if CPOL_DIV_AS_PRODUCT
+    float p0 = div32_by(rlat - m.llc1, m.rres1);
+    float p1 = div32_by(rlon - m.llc0, m.rres0);
+#else
     float p0 = (rlat - m.llc1) / m.res1;
     float p1 = (rlon - m.llc0) / m.res0;
+#endif
     int i0 = (int)floor((double)p0);
     int i1 = (int)floor((double)p1);
     // fmodf(p, 1.0f) = p - trunc(p) with the sign of p: exact (the difference of a float and its integer part
@@ -449,6 +480,10 @@ __device__ __forceinline__ void gate_geometry(const ModelDev &m, float rlat, flo
             g.z2[k] = col[k][g.c1[k] + 1];
         }
     }
+#if CPOL_DIV_AS_PRODUCT
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.rz[k] = rcp_for_div32(g.z1[k] - g.z2[k]);
+#endif
 }
 
 __device__ __forceinline__ float gate_value(const ModelDev &m, const GateGeom &g, float h, int v)
@@ -459,7 +494,11 @@ __device__ __forceinline__ float gate_value(const ModelDev &m, const GateGeom &g
         const float *p = m.V + ((g.cell[k] * m.nz + g.c1[k]) * m.n_vars + v);
         float v1 = p[0], v2 = p[m.n_vars];
         // interpolation_c.c:151
+#if CPOL_DIV_AS_PRODUCT
+        val[k] = v2 - div32_by(v2 - v1, g.rz[k]) * (h - g.z2[k]);
+#else
         val[k] = v2 - (v2 - v1) / (g.z1[k] - g.z2[k]) * (h - g.z2[k]);
+#endif
     }
     // interpolation_c.c:162
     return g.dx * g.dy * val[0] + g.x * val[2] * g.dy + g.dx * val[1] * g.y + g.x * g.y * val[3];
@@ -481,9 +520,15 @@ __device__ __forceinline__ void gate_value4(const ModelDev &m, const GateGeom &g
     for (int k = 0; k < 4; ++k) {
         const float *p = m.V + ((g.cell[k] * m.nz + g.c1[k]) * m.n_vars + v0);
         const F4 a = *(const F4 *)p, b = *(const F4 *)(p + m.n_vars);
-        const float dz = g.z1[k] - g.z2[k], dh = h - g.z2[k];
+        const float dh = h - g.z2[k];
+#if CPOL_DIV_AS_PRODUCT
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[k][j] = b.v[j] - div32_by(b.v[j] - a.v[j], g.rz[k]) * dh;
+#else
+        const float dz = g.z1[k] - g.z2[k];
 #pragma unroll
         for (int j = 0; j < 4; ++j) val[k][j] = b.v[j] - (b.v[j] - a.v[j]) / dz * dh;
+#endif
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -731,14 +776,18 @@ __device__ __forceinline__ int interp_gate(const ModelDev &m, const InterpArgs &
         // the long form's whatever it rounds to; only the weights inside the cell can move (by <= 1 ulp of the cell
         // coordinate, in ~6e-7 of the gates: profiles/r5_fast_sub_check.json).  Otherwise (one gate in ~5 000) the gate takes
         // the long form after all: index work is the long form's by construction.
-        auto spans = [](float c, float llc, float urc, float res) {
+        auto spans = [](float c, float llc, float urc, float res, double rres) {
             // 2^-23 max(|c|, |llc|): between 1 and 2 ulps of c, and never below the rounding of `c - llc` (round 6, advisor: the rotated
             // coordinates of a limited-area model sit near 0, where an ulp of c falls below the polynomial's own ~2e-13 deg)
             const float d = fmaxf(fmaxf(fabsf(c), fabsf(llc)), 1.0e-30f) * 1.1920929e-7f;
             const float lo = c - d, hi = c + d;
+#if CPOL_DIV_AS_PRODUCT
+            return floorf(div32_by(lo - llc, rres)) != floorf(div32_by(hi - llc, rres)) || !(lo >= llc) || !(hi <= urc);   // (NaN: true)
+#else
             return floorf((lo - llc) / res) != floorf((hi - llc) / res) || !(lo >= llc) || !(hi <= urc);   // (NaN: true)
+#endif
         };
-        long_form = spans(rlat, m.llc1, m.urc1, m.res1) || spans(rlon, m.llc0, m.urc0, m.res0);
+        long_form = spans(rlat, m.llc1, m.urc1, m.res1, m.rres1) || spans(rlon, m.llc0, m.urc0, m.res0, m.rres0);
     }
     const bool poly_ok = use_poly && !long_form;
     if (long_form || want_latlon) {

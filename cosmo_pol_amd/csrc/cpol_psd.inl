@@ -256,6 +256,11 @@ __global__ void k_debug_math(int op, const double *__restrict__ x, double *__res
     case 4: cp_cbrt_and_sixth(x[i], a, b); y[i] = b; break;
     case 5: y[i] = cp_fourth_root(x[i]); break;
     case 6: y[i] = cp_rcp(x[i]); break;
+    case 7: {       // x[i] holds two float32 (n, d): 0 if div32_by(n, rcp_for_div32(d)) has the bits of n / d (two NaNs count as equal), else 1
+        const float n = __int_as_float(__double2loint(x[i])), d = __int_as_float(__double2hiint(x[i]));
+        const float q = n / d, p = div32_by(n, rcp_for_div32(d));
+        y[i] = (__float_as_int(q) == __float_as_int(p) || (q != q && p != p)) ? 0.0 : 1.0;
+        break; }
     default: y[i] = x[i];
     }
 }
