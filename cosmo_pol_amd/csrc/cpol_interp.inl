@@ -508,9 +508,10 @@ __device__ __forceinline__ float gate_value(const ModelDev &m, const GateGeom &g
 // contiguous in V, so each of the 8 neighbours is ONE 16-byte load per lane instead of four
 // 4-byte ones (every lane gathers from its own cache lines: the load COUNT is what the
 // texture path pays for).  Same arithmetic, statement by statement, as gate_value.
-// (Measured and dropped: the 36 float32 divisions of a gate as ONE float64 reciprocal per column and a
-// float64 product rounded to float32 -- provably the same quotient -- 2.17 -> 2.11 ms on the C4 volume at the
-// same 5 wavefronts per SIMD, 2.52 ms at the 3 the allocator then chooses.)
+// (Round 3 measured and dropped the 36 float32 divisions of a gate as ONE float64 reciprocal per column and a
+// float64 product rounded to float32: 2.17 -> 2.11 ms on the C4 volume at the same 5 wavefronts per SIMD, 2.52 ms
+// at the 3 the allocator then chose.  Round 6 has it -- div32_by above, with the proof and the device comparison --
+// inside the fused kernel's fixed register budget.)
 
 __device__ __forceinline__ void gate_value4(const ModelDev &m, const GateGeom &g, float h, int v0,
                                             float out[4])
