@@ -380,3 +380,38 @@ def test_second_model_with_another_south_pole_rebuilds_the_coordinate_polynomial
     # (the two rotations put different model columns under the same rays: the test would not see a stale matrix otherwise)
     assert not np.array_equal(np.nan_to_num(results[0]), np.nan_to_num(results[1]))
     op.close()
+
+
+def test_pipelined_single_beam_scan_drains_its_lanes_when_a_sweep_fails():
+    """get_PPI of a single-beam scan queues a sweep per lane with page-locked outputs and waits once (round 6,
+    RadarOperator.pipeline_single_beam_scans).  A sweep that fails on the way (the test hook `fail_next_sweep` on the lane
+    that takes the second sweep) must surface as the call's exception with every lane drained -- no copy may still be
+    writing into a block the caller never received -- and the same scan must then give the bits of the one launch sequence."""
+    import bench
+    from cosmo_pol_amd import RadarOperator, synthetic
+    from cosmo_pol_amd._native import NativeError
+    hyds = ('R', 'S', 'G')
+    cube = synthetic.small_test_cube(hydrometeors=hyds)
+    luts = synthetic.make_all_luts(hyds, 5.6, '1mom', n_e=8)
+    conf = bench.bench_config(True)
+    elevs = [1.0, 2.0, 4.0, 7.0]
+    op = RadarOperator(config=conf, luts=luts, output_variables='only_radar', lanes=3)
+    op.load_model_arrays(cube['data'], cube['zlevels'], cube['proj_info'], cube['resolution'])
+    good = op.get_PPI(elevs, az_step=6.0)
+    lane1 = op._lane(1)                                           # (the lane of the second sweep)
+    assert lane1.lib.cpol_debug_read(lane1.h, b'fail_next_sweep', None, 0) == 0
+    with pytest.raises(NativeError, match='fail_next_sweep'):
+        op.get_PPI(elevs, az_step=6.0)
+    for i in range(3):                                            # nothing left in flight on any lane
+        assert op._lane(i).submitted == op._lane(i).completed, i
+    again = op.get_PPI(elevs, az_step=6.0)
+    op.pipeline_single_beam_scans = False
+    one_seq = op.get_PPI(elevs, az_step=6.0)
+    for i in range(len(elevs)):
+        for name in good.fields:
+            a = np.ma.asarray(good.get_field(i, name))
+            for other in (again, one_seq):
+                b = np.ma.asarray(other.get_field(i, name))
+                assert np.array_equal(np.ma.getmaskarray(a), np.ma.getmaskarray(b)), name
+                assert np.array_equal(a.filled(0), b.filled(0)), name
+    op.close()
